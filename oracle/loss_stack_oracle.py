@@ -1,0 +1,524 @@
+"""ORACLE -- test infrastructure only, never the product path.
+
+CPU (PyTorch fp32, ATen) restatement of the reference's photometric-warping loss
+stack.  The arithmetic of this path lives in ATen (``grid_sample``, ``avg_pool2d``,
+``interpolate``, ``softmax``, ``bmm``, ``inverse``), so the oracle calls the same
+ATen operators in the same association order as the reference and is therefore a
+torch program rather than C/numpy.  It is pinned against golden vectors captured
+from the real reference in the build container (``tests/golden/make_golden.py``);
+the reference itself has no tests for this path.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module.  The product (``unsupervised_depth_opticalflow_egomotion_amd``)
+never does and fails loudly when its HIP library is missing.
+
+Every function cites the reference lines it follows (paths relative to
+/root/reference).  ``align_corners`` is explicit everywhere: the reference leaves
+it to the installed torch (SURVEY.md "three things", item 2); ``False`` is what
+torch 2.10 does.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------- helpers
+
+
+def _pixel_grid(b, h, w, like):
+    """[B,2,H,W] float grid, channel 0 = x, 1 = y (net_utils.py:28-32)."""
+    xs = torch.arange(0, w).view(1, 1, 1, w).expand(b, 1, h, w)
+    ys = torch.arange(0, h).view(1, 1, h, 1).expand(b, 1, h, w)
+    return torch.cat((xs, ys), 1).float().to(like.device)
+
+
+def _gs(img, grid, align_corners):
+    return F.grid_sample(img, grid, mode="bilinear", padding_mode="zeros", align_corners=align_corners)
+
+
+# --------------------------------------------------------------------------- a2 warp_flow
+
+
+def warp_flow(x, flow, use_mask=False, align_corners=False):
+    """Backward bilinear warp of ``x`` by ``flow`` (net_utils.py:16-54).
+
+    gx = 2*(x+u)/max(W-1,1) - 1 (:42-43); zeros padding; with ``use_mask`` the output is
+    zeroed wherever the in-bounds bilinear weight sum is < 0.9999 (:47-52)."""
+    b, c, h, w = x.shape
+    if (b, 2, h, w) != tuple(flow.shape):
+        raise ValueError("the shape of grid {0} is not equal to the shape of flow {1}.".format(
+            torch.Size((b, 2, h, w)), flow.shape))
+    pos = _pixel_grid(b, h, w, x) + flow
+    gx = 2.0 * pos[:, 0] / max(w - 1, 1) - 1.0
+    gy = 2.0 * pos[:, 1] / max(h - 1, 1) - 1.0
+    grid = torch.stack((gx, gy), dim=3)
+    out = _gs(x, grid, align_corners)
+    if not use_mask:
+        return out
+    cover = _gs(torch.ones_like(x), grid, align_corners).detach()
+    keep = torch.where(cover < 0.9999, torch.zeros_like(cover), cover)
+    keep = torch.where(keep > 0, torch.ones_like(keep), keep)
+    return out * keep
+
+
+# --------------------------------------------------------------------------- a3 pose
+
+
+def euler2mat(angle):
+    """R = Rx(rx) @ Ry(ry) @ Rz(rz) (inverse_warp.py:110-145)."""
+    n = angle.shape[0]
+    rx, ry, rz = angle[:, 0], angle[:, 1], angle[:, 2]
+    zero = rz.detach() * 0
+    one = zero.detach() + 1
+    cz, sz = torch.cos(rz), torch.sin(rz)
+    cy, sy = torch.cos(ry), torch.sin(ry)
+    cx, sx = torch.cos(rx), torch.sin(rx)
+    zm = torch.stack([cz, -sz, zero, sz, cz, zero, zero, zero, one], dim=1).reshape(n, 3, 3)
+    ym = torch.stack([cy, zero, sy, zero, one, zero, -sy, zero, cy], dim=1).reshape(n, 3, 3)
+    xm = torch.stack([one, zero, zero, zero, cx, -sx, zero, sx, cx], dim=1).reshape(n, 3, 3)
+    return xm @ ym @ zm
+
+
+def pose_vec2mat(vec, rotation_mode="euler"):
+    """(tx,ty,tz,rx,ry,rz) -> [R|t] [B,3,4] (inverse_warp.py:172-187)."""
+    if rotation_mode != "euler":
+        raise ValueError("only the euler parameterisation is on the hot path")
+    return torch.cat([euler2mat(vec[:, 3:]), vec[:, :3].unsqueeze(-1)], dim=2)
+
+
+def compute_essential_matrix(vec):
+    """E = [t]x @ R (inverse_warp.py:344-364)."""
+    t = vec[:, :3]
+    n = t.shape[0]
+    x, y, z = t[:, 0:1], t[:, 1:2], t[:, 2:3]
+    zero = torch.zeros_like(x)
+    skew = torch.cat([zero, -z, y, z, zero, -x, -y, x, zero], dim=1).view(n, 3, 3)
+    return skew.bmm(euler2mat(vec[:, 3:]))
+
+
+# --------------------------------------------------------------------------- a4-a7 rigid projection
+
+
+def _project(depth, pose, intrinsics):
+    """cam = depth * K^-1 (x,y,1); p = (K R) cam + K t (inverse_warp.py:30-45,284-292,329-338).
+    Returns X, Y, Z(clamped at 1e-3) as [B, H*W]."""
+    b, _, h, w = depth.shape
+    xs = torch.arange(0, w).view(1, 1, w).expand(1, h, w).type_as(depth)
+    ys = torch.arange(0, h).view(1, h, 1).expand(1, h, w).type_as(depth)
+    pix = torch.stack((xs, ys, torch.ones(1, h, w).type_as(depth)), dim=1)
+    pix = pix.expand(b, 3, h, w).reshape(b, 3, -1)
+    cam = (intrinsics.inverse() @ pix).reshape(b, 3, h, w) * depth.squeeze(1).unsqueeze(1)
+    proj = intrinsics @ pose_vec2mat(pose)
+    p = proj[:, :, :3] @ cam.reshape(b, 3, -1) + proj[:, :, -1:]
+    return p[:, 0], p[:, 1], p[:, 2].clamp(min=1e-3)
+
+
+def inverse_warp2(img, depth, ref_depth, pose, intrinsics, padding_mode="zeros", align_corners=False):
+    """Rigid view synthesis (inverse_warp.py:263-303 with cam2pixel2 :227-260)."""
+    assert img.dim() == 4 and img.shape[1] == 3, "wrong size for img"
+    assert depth.dim() == 4 and depth.shape[1] == 1, "wrong size for depth"
+    assert ref_depth.dim() == 4 and ref_depth.shape[1] == 1, "wrong size for ref_depth"
+    assert pose.dim() == 2 and pose.shape[1] == 6, "wrong size for pose"
+    assert intrinsics.dim() == 3 and tuple(intrinsics.shape[1:]) == (3, 3), "wrong size for intrinsics"
+    b, _, h, w = img.shape
+    X, Y, Z = _project(depth, pose, intrinsics)
+    xn = 2 * (X / Z) / (w - 1) - 1
+    yn = 2 * (Y / Z) / (h - 1) - 1
+    if padding_mode == "zeros":
+        xn = torch.where(((xn > 1) + (xn < -1)).detach(), torch.full_like(xn, 2.0), xn)
+        yn = torch.where(((yn > 1) + (yn < -1)).detach(), torch.full_like(yn, 2.0), yn)
+    grid = torch.stack([xn, yn], dim=2).reshape(b, h, w, 2)
+    projected_img = F.grid_sample(img, grid, mode="bilinear", padding_mode=padding_mode,
+                                  align_corners=align_corners)
+    valid = (grid.abs().max(dim=-1)[0] <= 1).unsqueeze(1).float()
+    projected_depth = F.grid_sample(ref_depth, grid, mode="bilinear", padding_mode=padding_mode,
+                                    align_corners=align_corners).clamp(min=1e-3)
+    return projected_img, valid, projected_depth, Z.reshape(b, 1, h, w)
+
+
+def calculate_rigid_flow(depth, pose, intrinsics):
+    """(X/Z, Y/Z) - (x, y) (inverse_warp.py:311-342, cam2pixel_change_shape :47-78)."""
+    b, _, h, w = depth.shape
+    X, Y, Z = _project(depth, pose, intrinsics)
+    px = torch.cat([(X / Z).reshape(b, h, w).unsqueeze(1), (Y / Z).reshape(b, h, w).unsqueeze(1)], dim=1)
+    return px - _pixel_grid(b, h, w, depth)
+
+
+# --------------------------------------------------------------------------- a8 SSIM, a20 correlation
+
+
+def SSIM(x, y):
+    """3x3 zero-padded box SSIM, divisor always 9 (pytorch_ssim/ssim.py:4-19)."""
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+
+    def box(t):
+        return F.avg_pool2d(t, 3, 1, padding=1)
+    mu_x, mu_y = box(x), box(y)
+    var_x = box(x ** 2) - mu_x ** 2
+    var_y = box(y ** 2) - mu_y ** 2
+    cov = box(x * y) - mu_x * mu_y
+    num = (2 * mu_x * mu_y + c1) * (2 * cov + c2)
+    den = (mu_x ** 2 + mu_y ** 2 + c1) * (var_x + var_y + c2)
+    return num / den
+
+
+def corr_naive(input1, input2, d=4):
+    """81-tap channel-mean cost volume, dy outer / dx inner (pwc_tf.py:97-106)."""
+    assert input1.shape == input2.shape
+    h, w = input1.shape[2:4]
+    padded = F.pad(input2, (d, d, d, d), value=0)
+    planes = []
+    for dy in range(2 * d + 1):
+        for dx in range(2 * d + 1):
+            planes.append((input1 * padded[:, :, dy:dy + h, dx:dx + w]).mean(1).unsqueeze(1))
+    return torch.cat(planes, 1)
+
+
+# --------------------------------------------------------------------------- loss-stack composition
+
+
+def _l2norm(flow):
+    """||flow||_2 over the channel + 1e-12 (model_geometry.py:46-52)."""
+    return torch.norm(flow, p=2, dim=1).unsqueeze(1) + 1e-12
+
+
+def _unit(flow):
+    return flow / _l2norm(flow).repeat(1, 2, 1, 1)
+
+
+class GeomLossOracle:
+    """The ``compute_*`` / ``fusion_*`` methods of the reference models, stateless.
+
+    Method names follow ``Model_geometry`` (model_geometry.py) so the parity tests read
+    like calls into the reference."""
+
+    def __init__(self, num_scales=3, flow_consist_alpha=0.01, flow_consist_beta=0.5,
+                 rigid_thres=0.5, inlier_thres=0.1, align_corners=False):
+        self.num_scales = num_scales
+        self.flow_consist_alpha = flow_consist_alpha
+        self.flow_consist_beta = flow_consist_beta
+        self.rigid_thres = rigid_thres
+        self.inlier_thres = inlier_thres
+        self.align_corners = align_corners
+
+    # a1 ---------------------------------------------------------------
+    def generate_img_pyramid(self, img, num_pyramid):
+        """Bilinear (align_corners=False) resize to int(H/2^s) x int(W/2^s) (model_geometry.py:65-72)."""
+        h, w = img.shape[2], img.shape[3]
+        return [F.interpolate(img, (int(h / (2 ** s)), int(w / (2 ** s))), mode="bilinear", align_corners=False)
+                for s in range(num_pyramid)]
+
+    def generate_img_pyramid_avgpool(self, img, num_pyramid):
+        """Model_flow's box-mean pyramid (model_flow.py:58-64)."""
+        h, w = img.shape[2], img.shape[3]
+        return [F.adaptive_avg_pool2d(img, [int(h / (2 ** s)), int(w / (2 ** s))]).data
+                for s in range(num_pyramid)]
+
+    def warp_flow_pyramid(self, img_pyramid, flow_pyramid):
+        """zip() truncates to the shorter list (model_geometry.py:74-78)."""
+        return [warp_flow(i, f, use_mask=True, align_corners=self.align_corners)
+                for i, f in zip(img_pyramid, flow_pyramid)]
+
+    # a6 caller ----------------------------------------------------------
+    def reconstruction(self, ref_img, intrinsics, depth, depth_ref, pose):
+        """Area-downsample the source, scale K rows 0-1, inverse_warp2 (model_geometry.py:80-103)."""
+        outs = ([], [], [], [])
+        for s in range(self.num_scales):
+            b, _, h, w = depth[s].shape
+            src = F.interpolate(ref_img, (h, w), mode="area")
+            down = ref_img.size(2) / h
+            k_s = torch.cat((intrinsics[:, 0:2] / down, intrinsics[:, 2:]), dim=1)
+            res = inverse_warp2(src, depth[s], depth_ref[s], pose, k_s, align_corners=self.align_corners)
+            for lst, r in zip(outs, res):
+                lst.append(r)
+        return outs
+
+    # a11 -----------------------------------------------------------------
+    def compute_occ_weight(self, from_l, tgt, from_r):
+        """Hard occlusion weights from a 2-way softmax of the L1 errors (model_geometry.py:105-132)."""
+        w_bwd, w_fwd, v_bwd, v_fwd = [], [], [], []
+        for s in range(self.num_scales):
+            il, it, ir = from_l[s], tgt[s], from_r[s]
+            v_fwd.append(1 - (ir == 0).prod(1, keepdim=True).type_as(ir))
+            v_bwd.append(1 - (il == 0).prod(1, keepdim=True).type_as(il))
+            dl = torch.abs(it - il).mean(1, True)
+            dr = torch.abs(it - ir).mean(1, True)
+            wgt = 1 - F.softmax(torch.cat((dl, dr), 1), 1)
+            with torch.no_grad():
+                hard = (wgt > 0.48).float()
+                w_bwd.append(hard[:, 0:1])
+                w_fwd.append(hard[:, 1:2])
+        return w_bwd, w_fwd, v_bwd, v_fwd
+
+    def compute_diff_weight(self, from_l, tgt, from_r):
+        """Model_flow's soft gaussian weights (model_flow.py:105-138)."""
+        d_bwd, d_fwd, w_bwd, w_fwd = [], [], [], []
+        for s in range(self.num_scales):
+            il, it, ir = from_l[s], tgt[s], from_r[s]
+            vf = 1 - (ir == 0).prod(1, keepdim=True).type_as(ir)
+            vb = 1 - (il == 0).prod(1, keepdim=True).type_as(il)
+            dl = torch.abs(it - il).mean(1, True)
+            dr = torch.abs(it - ir).mean(1, True)
+            wgt = (1 - F.softmax(torch.cat((dl, dr), 1), 1)).detach()
+            wgt = 2 * torch.exp(-(wgt - 0.5) ** 2 / 0.03)
+            w_bwd.append(wgt[:, 0:1] * vb)
+            w_fwd.append(wgt[:, 1:2] * vf)
+            d_fwd.append(dr)
+            d_bwd.append(dl)
+        return d_bwd, d_fwd, w_bwd, w_fwd
+
+    # a12 -----------------------------------------------------------------
+    def compute_texture_mask(self, img_list, warped_list, source_list):
+        """(mean_c|I-recon| < mean_c|I-I_src|) (model_geometry.py:134-140)."""
+        return [(torch.abs(img_list[s] - warped_list[s]).mean(1, keepdim=True)
+                 < torch.abs(img_list[s] - source_list[s]).mean(1, keepdim=True)).float()
+                for s in range(self.num_scales)]
+
+    # a10 / a9 ------------------------------------------------------------
+    def compute_photometric_loss(self, img_list, warped_list, mask_list):
+        """Masked L1, normalised by the mask mean (model_geometry.py:143-153)."""
+        terms = []
+        for s in range(self.num_scales):
+            img, warped, mask = img_list[s], warped_list[s], mask_list[s]
+            div = mask.mean((1, 2, 3))
+            diff = torch.abs(img - warped) * mask.repeat(1, 3, 1, 1)
+            terms.append((diff.mean((1, 2, 3)) / (div + 1e-12))[:, None])
+        return torch.cat(terms, 1).sum(1)
+
+    def compute_loss_with_mask(self, diff_list, mask_list):
+        """Model_flow pixel loss on the 1-channel diff (model_flow.py:94-103)."""
+        terms = []
+        for s in range(self.num_scales):
+            diff, mask = diff_list[s], mask_list[s]
+            div = mask.mean((1, 2, 3))
+            terms.append(((diff * mask.repeat(1, 3, 1, 1)).mean((1, 2, 3)) / (div + 1e-12))[:, None])
+        return torch.cat(terms, 1).sum(1)
+
+    def compute_ssim_loss(self, img_list, warped_list, mask_list):
+        """clamp((1-SSIM(I*m, W*m))/2) mean over mask mean (model_geometry.py:212-223)."""
+        terms = []
+        for s in range(self.num_scales):
+            img, warped, mask = img_list[s], warped_list[s], mask_list[s]
+            div = mask.mean((1, 2, 3))
+            m3 = mask.repeat(1, 3, 1, 1)
+            val = torch.clamp((1.0 - SSIM(img * m3, warped * m3)) / 2.0, 0, 1).mean((1, 2, 3))
+            terms.append((val / (div + 1e-12))[:, None])
+        return torch.cat(terms, 1).sum(1)
+
+    # a16 / a17 / a18 -------------------------------------------------------
+    def compute_smooth_loss(self, img, disps):
+        """First-order edge-aware disparity smoothness at full resolution (model_geometry.py:225-252)."""
+        h, w = img.shape[2], img.shape[3]
+        terms = []
+        for s in range(self.num_scales):
+            d = F.interpolate(disps[s], size=(h, w), mode="bilinear", align_corners=False)
+            gdx = torch.abs(d[:, :, :, :-1] - d[:, :, :, 1:])
+            gdy = torch.abs(d[:, :, :-1, :] - d[:, :, 1:, :])
+            gix = torch.mean(torch.abs(img[:, :, :, :-1] - img[:, :, :, 1:]), 1, keepdim=True)
+            giy = torch.mean(torch.abs(img[:, :, :-1, :] - img[:, :, 1:, :]), 1, keepdim=True)
+            gdx = gdx * torch.exp(-gix)
+            gdy = gdy * torch.exp(-giy)
+            terms.append((gdx.mean((1, 2, 3)) + gdy.mean((1, 2, 3)))[:, None])
+        return torch.cat(terms, 1).sum(1)
+
+    def cal_grad2_error(self, flow, img):
+        """Second-order flow smoothness with exp(-10|dI|) weights (model_geometry.py:254-270)."""
+        idx = img[:, :, :, 1:] - img[:, :, :, :-1]
+        idy = img[:, :, 1:, :] - img[:, :, :-1, :]
+        wx = torch.exp(-10.0 * torch.abs(idx).mean(1).unsqueeze(1))
+        wy = torch.exp(-10.0 * torch.abs(idy).mean(1).unsqueeze(1))
+        fx = flow[:, :, :, 1:] - flow[:, :, :, :-1]
+        fy = flow[:, :, 1:, :] - flow[:, :, :-1, :]
+        fxx = fx[:, :, :, 1:] - fx[:, :, :, :-1]
+        fyy = fy[:, :, 1:, :] - fy[:, :, :-1, :]
+        err = (wx[:, :, :, 1:] * torch.abs(fxx)).mean((1, 2, 3)) + (wy[:, :, 1:, :] * torch.abs(fyy)).mean((1, 2, 3))
+        return err / 2.0
+
+    def compute_loss_flow_smooth(self, flows, img_pyramid):
+        """flow/20 per scale (model_geometry.py:272-279)."""
+        terms = [self.cal_grad2_error(flows[s] / 20.0, img_pyramid[s])[:, None] for s in range(self.num_scales)]
+        return torch.cat(terms, 1).sum(1)
+
+    def compute_loss_flow_consis(self, fwd_flows, bwd_flows, occ_list):
+        """|unit(fwd)+unit(bwd).detach| on (1-occ) (model_geometry.py:195-210)."""
+        terms = []
+        for s in range(self.num_scales):
+            uf = _unit(fwd_flows[s])
+            ub = _unit(bwd_flows[s]).float().detach()
+            inv = 1 - occ_list[s]
+            div = inv.mean((1, 2, 3))
+            val = (torch.abs(uf + ub) * inv).mean((1, 2, 3))
+            terms.append((val / (div + 1e-12))[:, None])
+        return torch.cat(terms, 1).sum(1)
+
+    # a13 / a14 -------------------------------------------------------------
+    def compute_dynamic_mask(self, intrinsics, depth, pose, flow):
+        """|rigid-flow|, dynamic mask and score per scale (model_geometry.py:685-713)."""
+        diffs, masks, scores = [], [], []
+        h0 = depth[0].size(2)
+        for s in range(self.num_scales):
+            h = depth[s].size(2)
+            down = h0 / h
+            k_s = torch.cat((intrinsics[:, 0:2] / down, intrinsics[:, 2:]), dim=1)
+            rigid = calculate_rigid_flow(depth[s], pose, k_s)
+            bound = self.flow_consist_alpha * (torch.pow(_l2norm(flow[s]), 2) + torch.pow(_l2norm(rigid), 2)) \
+                + self.flow_consist_beta
+            diff = torch.abs(rigid - flow[s])
+            diffs.append(diff)
+            with torch.no_grad():
+                masks.append((torch.pow(_l2norm(diff), 2) < bound).float())
+                scores.append(1.0 / (1e-4 + _l2norm(diff)))
+        return diffs, masks, scores
+
+    def compute_depth_flow_consis_loss(self, flow_diffs, masks=None, scales=3):
+        """Masked mean of |rigid-flow| (model_geometry.py:716-732)."""
+        terms = []
+        for s in range(scales):
+            diff = flow_diffs[s]
+            b, _, hh, ww = diff.shape
+            mask = torch.ones(b, 1, hh, ww).to(diff.device) if masks is None else masks[s]
+            div = mask.mean((1, 2, 3))
+            terms.append(((diff * mask.repeat(1, 2, 1, 1)).mean((1, 2, 3)) / (div + 1e-12))[:, None])
+        return torch.cat(terms, 1).sum(1)
+
+    # a15 -------------------------------------------------------------------
+    def compute_epipolar_map(self, pose, flow, intrinsics, intrinsics_inverse):
+        """Point-to-epipolar-line distance at one scale (model_geometry.py:355-403)."""
+        b, _, h, w = flow.shape
+        grid = _pixel_grid(b, h, w, flow)
+        p1 = torch.cat([grid.view(b, 2, -1), torch.ones(b, 1, h * w).to(flow.device)], 1)
+        p2 = torch.cat([(grid + flow).view(b, 2, -1), torch.ones(b, 1, h * w).to(flow.device)], 1)
+        e_mat = compute_essential_matrix(pose)
+        f_mat = intrinsics_inverse.transpose(1, 2).bmm(e_mat.bmm(intrinsics_inverse))
+        line = f_mat.bmm(p1)
+        la, lb = line[:, 0:1], line[:, 1:2]
+        div = torch.sqrt(la * la + lb * lb) + 1e-6
+        dist = torch.abs(torch.sum(p2 * line, dim=1, keepdim=True)) / div
+        return dist.view(b, 1, h, w)
+
+    def compute_epipolar_loss(self, dist_map, rigid_mask):
+        """The masked mean is overwritten by the plain mean (model_geometry.py:413-418)."""
+        return dist_map.mean((1, 2, 3))
+
+    def get_rigid_mask(self, dist_map):
+        """(model_geometry.py:420-425)."""
+        with torch.no_grad():
+            rigid = (dist_map < self.rigid_thres).float()
+            inlier = (dist_map < self.inlier_thres).float()
+            score = rigid * 1.0 / (1.0 + dist_map)
+        return rigid, inlier, score
+
+    # a19 -------------------------------------------------------------------
+    def fusion_mask(self, valid, occ, dyna):
+        return [valid[s] * occ[s] * dyna[s] for s in range(self.num_scales)]
+
+    def fusion_mask_2item(self, a, b):
+        return [a[s] * b[s] for s in range(self.num_scales)]
+
+    # a21 geom ----------------------------------------------------------------
+    def geom_losses(self, img_l, img, img_r, disp_l_list, disp_list, disp_r_list, pose_vectors,
+                    flows_bwd, flows_fwd, K, K_inv):
+        """Everything from model_geometry.py:797 to :951 given the nets' outputs.
+
+        Returns ``(loss_pack, masks)`` where ``masks`` holds the full-batch float masks the
+        reference keeps as locals (the reference's ``mask_pack`` takes sample 0 of some of them)."""
+        S = self.num_scales
+        pose_bwd, pose_fwd = pose_vectors[:, 0, :], pose_vectors[:, 1, :]
+        img_list = self.generate_img_pyramid(img, S)
+        img_l_list = self.generate_img_pyramid(img_l, S)
+        img_r_list = self.generate_img_pyramid(img_r, S)
+        rec_l, valid_to_l, _, _ = self.reconstruction(img_l, K, disp_list, disp_l_list, pose_bwd)
+        rec_r, valid_to_r, _, _ = self.reconstruction(img_r, K, disp_list, disp_r_list, pose_fwd)
+        tex_bwd = self.compute_texture_mask(img_list, rec_l, img_l_list)
+        tex_fwd = self.compute_texture_mask(img_list, rec_r, img_r_list)
+        warp_l = self.warp_flow_pyramid(img_l_list, flows_bwd)
+        warp_r = self.warp_flow_pyramid(img_r_list, flows_fwd)
+        occ_bwd, occ_fwd, val_bwd, val_fwd = self.compute_occ_weight(warp_l, img_list, warp_r)
+        diff_bwd, dyn_bwd, _ = self.compute_dynamic_mask(K, disp_list, pose_bwd, flows_bwd)
+        diff_fwd, dyn_fwd, _ = self.compute_dynamic_mask(K, disp_list, pose_fwd, flows_fwd)
+        dist_bwd = self.compute_epipolar_map(pose_bwd, flows_bwd[0], K, K_inv)
+        dist_fwd = self.compute_epipolar_map(pose_fwd, flows_fwd[0], K, K_inv)
+        rigid_bwd, inlier_bwd, _ = self.get_rigid_mask(dist_bwd)
+        rigid_fwd, inlier_fwd, _ = self.get_rigid_mask(dist_fwd)
+        fwd_mask = self.fusion_mask(val_fwd, occ_fwd, dyn_fwd)
+        bwd_mask = self.fusion_mask(val_bwd, occ_bwd, dyn_bwd)
+        fwd_tex = self.fusion_mask_2item(fwd_mask, tex_fwd)
+        bwd_tex = self.fusion_mask_2item(bwd_mask, tex_bwd)
+        fwd_vo = self.fusion_mask_2item(val_fwd, occ_fwd)
+        bwd_vo = self.fusion_mask_2item(val_bwd, occ_bwd)
+        fwd_vo_rigid = self.fusion_mask_2item(fwd_vo, dyn_fwd)
+        bwd_vo_rigid = self.fusion_mask_2item(bwd_vo, dyn_bwd)
+        fwd_vo_dyna = self.fusion_mask_2item(fwd_vo, [1 - m for m in dyn_fwd])
+        bwd_vo_dyna = self.fusion_mask_2item(bwd_vo, [1 - m for m in dyn_bwd])
+
+        dev = img_l.device
+        lp = {}
+        lp["loss_depth_pixel"] = self.compute_photometric_loss(img_list, rec_l, bwd_tex) + \
+            self.compute_photometric_loss(img_list, rec_r, fwd_tex)
+        lp["loss_depth_ssim"] = torch.zeros([2]).to(dev).requires_grad_()
+        lp["loss_depth_smooth"] = self.compute_smooth_loss(img, disp_list) + \
+            self.compute_smooth_loss(img_l, disp_l_list) + self.compute_smooth_loss(img_r, disp_r_list)
+        lp["loss_depth_consis"] = torch.zeros([2]).to(dev).requires_grad_()
+        lp["loss_flow_pixel"] = self.compute_photometric_loss(img_list, warp_l, bwd_vo_rigid) + \
+            self.compute_photometric_loss(img_list, warp_r, fwd_vo_rigid) + \
+            2 * self.compute_photometric_loss(img_list, warp_l, bwd_vo_dyna) + \
+            2 * self.compute_photometric_loss(img_list, warp_r, fwd_vo_dyna)
+        lp["loss_flow_ssim"] = self.compute_ssim_loss(img_list, warp_l, bwd_vo) + \
+            self.compute_ssim_loss(img_list, warp_r, fwd_vo)
+        lp["loss_flow_smooth"] = self.compute_loss_flow_smooth(flows_fwd, img_list) + \
+            self.compute_loss_flow_smooth(flows_bwd, img_list)
+        lp["loss_flow_consis"] = self.compute_loss_flow_consis(flows_fwd, flows_bwd, occ_fwd)
+        lp["loss_depth_flow_consis"] = self.compute_depth_flow_consis_loss(diff_bwd, bwd_mask, 1) + \
+            self.compute_depth_flow_consis_loss(diff_fwd, fwd_mask, 1)
+        lp["loss_epipolar"] = self.compute_epipolar_loss(dist_bwd, dyn_bwd[0]) + \
+            self.compute_epipolar_loss(dist_fwd, dyn_fwd[0])
+        lp["loss_triangle"] = torch.zeros([2]).to(dev).requires_grad_()
+        lp["loss_pnp"] = torch.zeros([2]).to(dev).requires_grad_()
+        lp["loss_eight_point"] = torch.zeros([2]).to(dev).requires_grad_()
+        masks = dict(occ_bwd=occ_bwd, occ_fwd=occ_fwd, valid_bwd=val_bwd, valid_fwd=val_fwd,
+                     dyna_bwd=dyn_bwd, dyna_fwd=dyn_fwd, texture_bwd=tex_bwd, texture_fwd=tex_fwd,
+                     valid_to_l=valid_to_l, valid_to_r=valid_to_r, rigid_bwd=rigid_bwd, rigid_fwd=rigid_fwd,
+                     inlier_bwd=inlier_bwd, inlier_fwd=inlier_fwd, fwd_mask=fwd_mask, bwd_mask=bwd_mask,
+                     dist_bwd=dist_bwd, dist_fwd=dist_fwd)
+        return lp, masks
+
+    # Model_depth.forward loss stack (model_depth.py:272-337) ----------------------
+    def depth_losses(self, img_l, img, img_r, depth_l_list, depth_list, depth_r_list, pose_vectors, K):
+        S = self.num_scales
+        pose_bwd, pose_fwd = pose_vectors[:, 0, :], pose_vectors[:, 1, :]
+        img_list = self.generate_img_pyramid(img, S)
+        img_l_list = self.generate_img_pyramid(img_l, S)
+        img_r_list = self.generate_img_pyramid(img_r, S)
+        rec_l, valid_l, _, _ = self.reconstruction(img_l, K, depth_list, depth_l_list, pose_bwd)
+        rec_r, valid_r, _, _ = self.reconstruction(img_r, K, depth_list, depth_r_list, pose_fwd)
+        tex_bwd = self.compute_texture_mask(img_list, rec_l, img_l_list)
+        tex_fwd = self.compute_texture_mask(img_list, rec_r, img_r_list)
+        m_bwd = self.fusion_mask_2item(valid_l, tex_bwd)
+        m_fwd = self.fusion_mask_2item(valid_r, tex_fwd)
+        dev = img_l.device
+        lp = {}
+        lp["loss_depth_pixel"] = self.compute_photometric_loss(img_list, rec_l, m_bwd) + \
+            self.compute_photometric_loss(img_list, rec_r, m_fwd)
+        lp["loss_depth_ssim"] = torch.zeros([2]).to(dev).requires_grad_()
+        lp["loss_depth_smooth"] = self.compute_smooth_loss(img, depth_list) + \
+            self.compute_smooth_loss(img_l, depth_l_list) + self.compute_smooth_loss(img_r, depth_r_list)
+        lp["loss_depth_consis"] = torch.zeros([2]).to(dev).requires_grad_()
+        return lp, dict(mask_bwd=m_bwd, mask_fwd=m_fwd, texture_bwd=tex_bwd, texture_fwd=tex_fwd,
+                        valid_to_l=valid_l, valid_to_r=valid_r)
+
+    # Model_flow.forward loss stack (model_flow.py:209-261, with the fixes of SURVEY.md) -----
+    def flow_losses(self, img_l, img, img_r, flows_bwd, flows_fwd):
+        n = len(flows_fwd)
+        il = self.generate_img_pyramid_avgpool(img_l, n)
+        it = self.generate_img_pyramid_avgpool(img, n)
+        ir = self.generate_img_pyramid_avgpool(img_r, n)
+        warp_l = self.warp_flow_pyramid(il, flows_bwd)
+        warp_r = self.warp_flow_pyramid(ir, flows_fwd)
+        d_bwd, d_fwd, w_bwd, w_fwd = self.compute_diff_weight(warp_l, it, warp_r)
+        lp = {}
+        lp["loss_flow_pixel"] = self.compute_loss_with_mask(d_fwd, w_fwd) + self.compute_loss_with_mask(d_bwd, w_bwd)
+        lp["loss_flow_ssim"] = self.compute_ssim_loss(it, warp_r, w_fwd) + self.compute_ssim_loss(it, warp_l, w_bwd)
+        lp["loss_flow_smooth"] = self.compute_loss_flow_smooth(flows_fwd, it) + \
+            self.compute_loss_flow_smooth(flows_bwd, it)
+        lp["loss_flow_consis"] = self.compute_loss_flow_consis(flows_fwd, flows_bwd, w_fwd)
+        return lp, dict(weight_bwd=w_bwd, weight_fwd=w_fwd)
