@@ -1,0 +1,214 @@
+"""GPU parity of the per-operator HIP kernels (through the C ABI) against the oracle and the
+golden vectors.  Tolerances (fp32): maps 1e-5 abs for bilinear outputs on [0,1] images, 2e-5
+for SSIM maps, pixel coordinates 2e-3 px (one fp32 ulp at x~800 is 6e-5 and the projection
+chains ~10 roundings), grads 1e-4 relative to the gradient scale, masks bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_stack_oracle as O
+from tests.golden import make_golden as MG
+
+pytestmark = pytest.mark.gpu
+T, N = MG.T, MG.N
+
+
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def G(a, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).float().to(dev())
+    return t.requires_grad_(True) if grad else t
+
+
+def close(a, b, atol=1e-5, rtol=1e-5):
+    np.testing.assert_allclose(N(a) if isinstance(a, torch.Tensor) else a,
+                               N(b) if isinstance(b, torch.Tensor) else b, atol=atol, rtol=rtol)
+
+
+def gclose(a, b, rel=1e-4, max_outliers=0, atol=0.0):
+    """max |a-b| <= rel * max|b| + atol; ``max_outliers`` elements may exceed it (pixels whose
+    {0,1} validity decision sits within fp32 noise of its threshold differ legitimately).
+    ``atol`` is the cancellation-noise floor for gradients that are analytically ~0."""
+    a, b = N(a), (N(b) if isinstance(b, torch.Tensor) else b)
+    scale = max(np.abs(b).max(), 1e-12)
+    bad = int((np.abs(a - b) > rel * scale + atol).sum())
+    assert bad <= max_outliers, "grad mismatch: %d elements (allowed %d), max %g vs scale %g" % (
+        bad, max_outliers, np.abs(a - b).max(), scale)
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+@pytest.mark.parametrize("ac", [False, True])
+def test_warp_flow_golden(golden_dir, ac):
+    from unsupervised_depth_opticalflow_egomotion_amd.structures import warp_flow
+    g = load(golden_dir, "G1_ac%d" % ac)
+    x, flows, wgt = MG.g1_inputs()
+    for name, fl in flows.items():
+        for um in (False, True):
+            xt, ft = G(x, True), G(fl, True)
+            y = warp_flow(xt, ft, use_mask=um, align_corners=ac)
+            (y * G(wgt)).sum().backward()
+            key = "%s_mask%d" % (name, int(um))
+            close(y, g[key + "_out"], atol=2e-6)
+            # exact agreement of the zeroed (masked) pixels
+            assert np.array_equal(N(y) == 0, g[key + "_out"] == 0), key
+            gclose(ft.grad, g[key + "_gflow"])
+            gclose(xt.grad, g[key + "_gx"])
+
+
+def test_warp_flow_errors():
+    from unsupervised_depth_opticalflow_egomotion_amd.structures import warp_flow
+    from unsupervised_depth_opticalflow_egomotion_amd._lib import DfeError
+    with pytest.raises(ValueError):
+        warp_flow(torch.zeros(1, 3, 8, 8, device=dev()), torch.zeros(1, 2, 8, 9, device=dev()))
+    with pytest.raises(DfeError):  # no CPU fallback
+        warp_flow(torch.zeros(1, 3, 8, 8), torch.zeros(1, 2, 8, 8))
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 64, 208), (1, 32, 64, 208), (2, 128, 8, 26), (1, 3, 375, 1242)])
+@pytest.mark.parametrize("ac", [False, True])
+def test_warp_flow_oracle(shape, ac):
+    from unsupervised_depth_opticalflow_egomotion_amd.structures import warp_flow
+    r = MG.rng(7 + shape[1])
+    b, c, h, w = shape
+    x = r.random(shape).astype(np.float32)
+    fl = (3.0 * r.standard_normal((b, 2, h, w))).astype(np.float32)
+    wgt = r.standard_normal(shape).astype(np.float32)
+    for um in (False, True):
+        xo, fo = T(x, True), T(fl, True)
+        yo = O.warp_flow(xo, fo, use_mask=um, align_corners=ac)
+        (yo * T(wgt)).sum().backward()
+        xt, ft = G(x, True), G(fl, True)
+        y = warp_flow(xt, ft, use_mask=um, align_corners=ac)
+        (y * G(wgt)).sum().backward()
+        close(y, yo, atol=2e-6)
+        assert np.array_equal(N(y) == 0, N(yo) == 0)
+        gclose(ft.grad, fo.grad)
+        gclose(xt.grad, xo.grad)
+
+
+@pytest.mark.parametrize("ac", [False, True])
+def test_rigid_golden(golden_dir, ac):
+    from unsupervised_depth_opticalflow_egomotion_amd.structures import (
+        inverse_warp2, calculate_rigid_flow, pose_vec2mat, compute_essential_matrix)
+    g = load(golden_dir, "G2_ac%d" % ac)
+    close(pose_vec2mat(G(g["vec"])), g["pose_mat"], atol=1e-6)
+    close(compute_essential_matrix(G(g["vec"])), g["essential"], atol=1e-6)
+    for i, (h, w, case) in enumerate(MG.G2_CASES):
+        img, depth, ref_depth, pose, k, wi, wd, wf = MG.g2_inputs(h, w, 210 + i, case)
+        key = "%dx%d_%s" % (h, w, case)
+        dt, rdt, pt = G(depth, True), G(ref_depth, True), G(pose, True)
+        pi, valid, pd, cd = inverse_warp2(G(img), dt, rdt, pt, G(k), align_corners=ac)
+        ((pi * G(wi)).sum() + (pd * G(wd)).sum() + (cd * G(wd)).sum() * 0.5).backward()
+        mism = N(valid) != g[key + "_valid"]
+        assert mism.mean() <= 2e-3, (key, mism.sum())   # validity flips only within fp32 noise of |grid|==1
+        ok = ~np.broadcast_to(mism, N(pi).shape)
+        close(N(pi)[ok], g[key + "_img"][ok], atol=2e-4)
+        close(N(pd)[~mism], g[key + "_pdepth"][~mism], atol=2e-4)
+        close(cd, g[key + "_cdepth"], atol=1e-5, rtol=1e-5)
+        nflip = int(mism.sum())
+        gclose(dt.grad, g[key + "_gdepth"], rel=2e-3, max_outliers=nflip, atol=1e-3)
+        gclose(rdt.grad, g[key + "_grefdepth"], rel=2e-3, max_outliers=4 * nflip)
+        if nflip == 0:
+            gclose(pt.grad, g[key + "_gpose"], rel=2e-3, atol=1e-2)
+        dt3, pt3 = G(depth, True), G(pose, True)
+        rf = calculate_rigid_flow(dt3, pt3, G(k))
+        (rf * G(wf)).sum().backward()
+        close(rf, g[key + "_rflow"], atol=2e-3, rtol=1e-5)
+        gclose(dt3.grad, g[key + "_rflow_gdepth"], rel=1e-3, atol=1e-3)
+        gclose(pt3.grad, g[key + "_rflow_gpose"], rel=1e-3, atol=1e-2)
+
+
+def test_pose_mats_backward():
+    from unsupervised_depth_opticalflow_egomotion_amd.structures import pose_vec2mat, compute_essential_matrix
+    r = MG.rng(11)
+    vec = (0.3 * r.standard_normal((7, 6))).astype(np.float32)
+    wt, we = r.standard_normal((7, 3, 4)).astype(np.float32), r.standard_normal((7, 3, 3)).astype(np.float32)
+    vo = T(vec, True)
+    ((O.pose_vec2mat(vo) * T(wt)).sum() + (O.compute_essential_matrix(vo) * T(we)).sum()).backward()
+    vg = G(vec, True)
+    ((pose_vec2mat(vg) * G(wt)).sum() + (compute_essential_matrix(vg) * G(we)).sum()).backward()
+    gclose(vg.grad, vo.grad, rel=1e-5)
+
+
+def test_ssim_golden(golden_dir):
+    from unsupervised_depth_opticalflow_egomotion_amd.pytorch_ssim import SSIM
+    g = load(golden_dir, "G3")
+    x, y, m, c, wgt = MG.g3_inputs()
+    xt, yt = G(x, True), G(y, True)
+    s = SSIM(xt, yt)
+    (s * G(wgt)).sum().backward()
+    close(s, g["rand"], atol=2e-5)
+    gclose(xt.grad, g["rand_gx"], rel=2e-4)
+    gclose(yt.grad, g["rand_gy"], rel=2e-4)
+    close(SSIM(G(x) * G(m), G(y) * G(m)), g["masked"], atol=2e-5)
+    close(SSIM(G(c), G(c)), g["const"], atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 64, 208), (1, 3, 33, 70), (1, 3, 256, 832)])
+def test_ssim_oracle(shape):
+    from unsupervised_depth_opticalflow_egomotion_amd.pytorch_ssim import SSIM
+    r = MG.rng(21)
+    x = r.random(shape).astype(np.float32)
+    y = np.clip(x + 0.1 * r.standard_normal(shape), 0, 1).astype(np.float32)
+    wgt = r.standard_normal(shape).astype(np.float32)
+    xo, yo = T(x, True), T(y, True)
+    so = O.SSIM(xo, yo)
+    (so * T(wgt)).sum().backward()
+    xt, yt = G(x, True), G(y, True)
+    s = SSIM(xt, yt)
+    (s * G(wgt)).sum().backward()
+    close(s, so, atol=2e-5)
+    gclose(xt.grad, xo.grad, rel=2e-4)
+    gclose(yt.grad, yo.grad, rel=2e-4)
+
+
+def test_corr_golden(golden_dir):
+    from unsupervised_depth_opticalflow_egomotion_amd.ops import corr81
+    g = load(golden_dir, "G4")
+    for i in range(len(MG.G4_CASES)):
+        f1, f2, wgt = MG.g4_inputs(i)
+        a, b = G(f1, True), G(f2, True)
+        cv = corr81(a, b)
+        (cv * G(wgt)).sum().backward()
+        close(cv, g["c%d_out" % i], atol=1e-5)
+        gclose(a.grad, g["c%d_g1" % i])
+        gclose(b.grad, g["c%d_g2" % i])
+
+
+@pytest.mark.parametrize("shape", [(4, 196, 4, 13), (2, 128, 8, 26), (2, 96, 16, 52), (2, 64, 32, 104), (1, 32, 64, 208)])
+def test_corr_oracle(shape):
+    from unsupervised_depth_opticalflow_egomotion_amd.ops import corr81
+    r = MG.rng(31)
+    f1 = r.standard_normal(shape).astype(np.float32)
+    f2 = r.standard_normal(shape).astype(np.float32)
+    wgt = r.standard_normal((shape[0], 81, shape[2], shape[3])).astype(np.float32)
+    ao, bo = T(f1, True), T(f2, True)
+    co = O.corr_naive(ao, bo)
+    (co * T(wgt)).sum().backward()
+    a, b = G(f1, True), G(f2, True)
+    cv = corr81(a, b)
+    (cv * G(wgt)).sum().backward()
+    close(cv, co, atol=1e-5)
+    gclose(a.grad, ao.grad)
+    gclose(b.grad, bo.grad)
+
+
+@pytest.mark.parametrize("hw", [(256, 832), (375, 1242), (64, 208)])
+def test_resize_oracle(hw):
+    from unsupervised_depth_opticalflow_egomotion_amd.ops import resize
+    import torch.nn.functional as F
+    r = MG.rng(41)
+    h, w = hw
+    img = r.random((2, 3, h, w)).astype(np.float32)
+    for s in range(1, 4):
+        oh, ow = int(h / 2 ** s), int(w / 2 ** s)
+        close(resize(G(img), (oh, ow), "bilinear"), F.interpolate(T(img), (oh, ow), mode="bilinear", align_corners=False), atol=1e-6)
+        close(resize(G(img), (oh, ow), "area"), F.interpolate(T(img), (oh, ow), mode="area"), atol=1e-6)

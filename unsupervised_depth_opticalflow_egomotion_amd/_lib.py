@@ -1,0 +1,116 @@
+"""ctypes binding of libdfe_hip.so (the C ABI declared in include/dfe_hip.h).
+
+The product path has no CPU fallback: if the library is missing or a tensor is not a
+contiguous fp32 HIP tensor, the call raises.  PyTorch is used only for device memory and
+the current HIP stream."""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdfe_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dfe_hip.h")
+
+_lib = None
+_lock = threading.Lock()
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+
+# symbol -> argtypes (restype is int unless listed in _RESTYPES)
+_SIGNATURES = {
+    "dfe_abi_version": [],
+    "dfe_error_string": [_I],
+    "dfe_camera_floats": [],
+    "dfe_prepare_cameras": [_P, _P, _P, _I, _I, _I, _P, _P],
+    "dfe_pose_vec2mat_fwd": [_P, _P, _P, _I, _P],
+    "dfe_pose_vec2mat_bwd": [_P, _P, _P, _P, _I, _P],
+    "dfe_warp_flow_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "dfe_warp_flow_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "dfe_pose_partials_floats": [_I, _I, _I],
+    "dfe_inverse_warp2_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "dfe_inverse_warp2_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "dfe_rigid_flow_fwd": [_P, _P, _P, _I, _I, _I, _P],
+    "dfe_rigid_flow_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "dfe_ssim_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "dfe_ssim_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "dfe_corr_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dfe_corr_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dfe_resize": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "dfe_geom_workspace_floats": [_P],
+    "dfe_geom_loss_fwd": [_P, _P],
+    "dfe_geom_loss_bwd": [_P, _P],
+}
+_RESTYPES = {"dfe_error_string": ctypes.c_char_p}
+
+
+class DfeError(RuntimeError):
+    pass
+
+
+def header_symbols(path: str = HEADER_PATH):
+    """Function names declared in include/dfe_hip.h."""
+    with open(path) as fh:
+        text = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(dfe_[a-z0-9_]+)\s*\(", text)))
+
+
+def get_lib():
+    """Load libdfe_hip.so once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise DfeError(
+                    "libdfe_hip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; "
+                    "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+            lib = ctypes.CDLL(LIB_PATH)
+            for name in header_symbols():
+                fn = getattr(lib, name)  # AttributeError if the header and the library disagree
+                if name in _SIGNATURES:
+                    fn.argtypes = _SIGNATURES[name]
+                fn.restype = _RESTYPES.get(name, ctypes.c_int)
+            if lib.dfe_abi_version() != 1:
+                raise DfeError("libdfe_hip.so ABI version mismatch")
+            _lib = lib
+    return _lib
+
+
+def check(code: int, what: str = ""):
+    if code != 0:
+        msg = get_lib().dfe_error_string(code)
+        raise DfeError("%s failed: %s (code %d)" % (what or "dfe call", msg.decode() if msg else "?", code))
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32 HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise DfeError("expected a torch.Tensor, got %r" % type(t))
+    if not t.is_cuda:
+        raise DfeError("the HIP loss stack only accepts tensors on a HIP device (got %s); there is no CPU "
+                       "fallback in the product path" % t.device)
+    if t.dtype != torch.float32 and t.dtype != torch.uint8 and t.dtype != torch.int32:
+        raise DfeError("unsupported dtype %s" % t.dtype)
+    if not t.is_contiguous():
+        raise DfeError("tensor must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def f32c(t):
+    """Contiguous fp32 view/copy on the same device."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()

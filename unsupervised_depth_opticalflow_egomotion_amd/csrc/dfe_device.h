@@ -1,0 +1,283 @@
+// Shared device-side arithmetic for the loss-stack kernels (gfx950, wave64).
+//
+// Every expression that feeds a {0,1} mask decision is written in the association order
+// the reference's ATen CPU path evaluates it in (probed bit-for-bit in the build
+// container): the bilinear coordinate is fma(g+1, size/2, -0.5) (align_corners=False) or
+// (g+1)*((size-1)/2) (True), the four weights are rounded products and the interpolation
+// is the chain t=v_nw*nw; t=fma(v_ne,ne,t); t=fma(v_sw,sw,t); t=fma(v_se,se,t).
+// All translation units are compiled with -ffp-contract=off; FMAs appear only where
+// written explicitly.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define DFE_WAVE 64
+
+namespace dfe {
+
+// ---------------------------------------------------------------- bilinear sampling
+// grid_sample(bilinear, zeros padding) geometry for one sample point.
+struct Tap {
+  int x0, y0;          // north-west corner (may be out of bounds)
+  float nw, ne, sw, se; // weights (not yet masked by bounds)
+  bool in_nw, in_ne, in_sw, in_se;
+  float wx, wy;        // fractional offsets (w = ix - x0, n = iy - y0)
+};
+
+__device__ __forceinline__ float unnormalize(float g, int size, int align_corners) {
+  // reference semantics: torch grid_sample; SURVEY.md A.1
+  if (align_corners) return (g + 1.0f) * (static_cast<float>(size - 1) / 2.0f);
+  return __fmaf_rn(g + 1.0f, static_cast<float>(size) / 2.0f, -0.5f);
+}
+
+__device__ __forceinline__ Tap make_tap(float ix, float iy, int H, int W) {
+  Tap t;
+  float xw = floorf(ix), yn = floorf(iy);
+  float w = ix - xw, e = 1.0f - w, n = iy - yn, s = 1.0f - n;
+  t.wx = w; t.wy = n;
+  t.nw = s * e; t.ne = s * w; t.sw = n * e; t.se = n * w;
+  // NaN / huge coordinates: comparisons below are false for NaN -> fully out of bounds.
+  bool xin0 = (xw > -1.0f) && (xw < static_cast<float>(W));
+  bool xin1 = (xw + 1.0f > -1.0f) && (xw + 1.0f < static_cast<float>(W));
+  bool yin0 = (yn > -1.0f) && (yn < static_cast<float>(H));
+  bool yin1 = (yn + 1.0f > -1.0f) && (yn + 1.0f < static_cast<float>(H));
+  t.in_nw = xin0 && yin0; t.in_ne = xin1 && yin0; t.in_sw = xin0 && yin1; t.in_se = xin1 && yin1;
+  // keep the int conversion defined for out-of-range coordinates
+  float xc = fminf(fmaxf(xw, -2.0f), static_cast<float>(W) + 1.0f);
+  float yc = fminf(fmaxf(yn, -2.0f), static_cast<float>(H) + 1.0f);
+  t.x0 = (xw == xw) ? static_cast<int>(xc) : -2;
+  t.y0 = (yn == yn) ? static_cast<int>(yc) : -2;
+  return t;
+}
+
+// Sum of the in-bounds weights, in ATen's accumulation order (== grid_sample(ones)).
+__device__ __forceinline__ float tap_cover(const Tap& t) {
+  float c = t.in_nw ? t.nw : 0.0f;
+  c = c + (t.in_ne ? t.ne : 0.0f);
+  c = c + (t.in_sw ? t.sw : 0.0f);
+  c = c + (t.in_se ? t.se : 0.0f);
+  return c;
+}
+
+struct Corners { float nw, ne, sw, se; };
+
+__device__ __forceinline__ Corners load_corners(const float* __restrict__ plane, const Tap& t, int W) {
+  Corners c;
+  const float* p = plane + static_cast<long>(t.y0) * W + t.x0;
+  c.nw = t.in_nw ? p[0] : 0.0f;
+  c.ne = t.in_ne ? p[1] : 0.0f;
+  c.sw = t.in_sw ? p[W] : 0.0f;
+  c.se = t.in_se ? p[W + 1] : 0.0f;
+  return c;
+}
+
+__device__ __forceinline__ float interp(const Corners& c, const Tap& t) {
+  float r = c.nw * t.nw;
+  r = __fmaf_rn(c.ne, t.ne, r);
+  r = __fmaf_rn(c.sw, t.sw, r);
+  r = __fmaf_rn(c.se, t.se, r);
+  return r;
+}
+
+// d(out)/d(ix), d(out)/d(iy) of the bilinear interpolation
+__device__ __forceinline__ void interp_grad(const Corners& c, const Tap& t, float& dix, float& diy) {
+  float s = 1.0f - t.wy, e = 1.0f - t.wx;
+  dix = (c.ne - c.nw) * s + (c.se - c.sw) * t.wy;
+  diy = (c.sw - c.nw) * e + (c.se - c.ne) * t.wx;
+}
+
+// ---------------------------------------------------------------- flow warp coordinates
+// net_utils.py:42-43: g = 2*(x+u)/max(W-1,1) - 1, then grid_sample's unnormalisation.
+__device__ __forceinline__ void flow_coords(int x, int y, float u, float v, int H, int W, int ac,
+                                            float& ix, float& iy) {
+  float gx = 2.0f * (static_cast<float>(x) + u) / static_cast<float>(W > 1 ? W - 1 : 1) - 1.0f;
+  float gy = 2.0f * (static_cast<float>(y) + v) / static_cast<float>(H > 1 ? H - 1 : 1) - 1.0f;
+  ix = unnormalize(gx, W, ac);
+  iy = unnormalize(gy, H, ac);
+}
+// d(ix)/d(u): chain of the two affine maps above
+__device__ __forceinline__ float flow_coord_scale(int size, int ac) {
+  float den = static_cast<float>(size > 1 ? size - 1 : 1);
+  return ac ? (static_cast<float>(size - 1) / den) : (static_cast<float>(size) / den);
+}
+
+// ---------------------------------------------------------------- rigid projection
+// Per (sample, direction, scale) camera block prepared by k_prepare_cameras:
+//   kinv = inverse(K_s), A = K_s R, b = K_s t, plus what the backward needs.
+struct Camera {
+  float kinv[9];
+  float A[9];
+  float b[3];
+  float K[9];      // scaled intrinsics K_s
+  float R[9];
+  float dR[27];    // dR/d(rx), dR/d(ry), dR/d(rz)
+};
+
+struct Proj {
+  float q0, q1, q2;  // A * Kinv * (x,y,1)
+  float r0, r1, r2;  // Kinv * (x,y,1)
+  float Z, U, V;     // clamped depth and pixel coordinates
+  bool clamped;
+};
+
+__device__ __forceinline__ Proj project(const Camera& c, int x, int y, float depth) {
+  Proj p;
+  float fx = static_cast<float>(x), fy = static_cast<float>(y);
+  p.r0 = c.kinv[0] * fx + c.kinv[1] * fy + c.kinv[2];
+  p.r1 = c.kinv[3] * fx + c.kinv[4] * fy + c.kinv[5];
+  p.r2 = c.kinv[6] * fx + c.kinv[7] * fy + c.kinv[8];
+  float c0 = p.r0 * depth, c1 = p.r1 * depth, c2 = p.r2 * depth;
+  float X = (c.A[0] * c0 + c.A[1] * c1 + c.A[2] * c2) + c.b[0];
+  float Y = (c.A[3] * c0 + c.A[4] * c1 + c.A[5] * c2) + c.b[1];
+  float Zr = (c.A[6] * c0 + c.A[7] * c1 + c.A[8] * c2) + c.b[2];
+  p.q0 = c.A[0] * p.r0 + c.A[1] * p.r1 + c.A[2] * p.r2;
+  p.q1 = c.A[3] * p.r0 + c.A[4] * p.r1 + c.A[5] * p.r2;
+  p.q2 = c.A[6] * p.r0 + c.A[7] * p.r1 + c.A[8] * p.r2;
+  p.clamped = !(Zr >= 1e-3f);
+  p.Z = (Zr >= 1e-3f) ? Zr : 1e-3f;   // clamp(min=1e-3); NaN propagates like torch.clamp
+  if (Zr != Zr) p.Z = Zr;
+  p.U = X / p.Z;
+  p.V = Y / p.Z;
+  return p;
+}
+
+// Normalised sampling grid of inverse_warp2 with the zeros-padding overwrite
+// (inverse_warp.py:250-257).  live_x/live_y say whether gradient flows through Xn/Yn.
+__device__ __forceinline__ void rigid_grid(const Proj& p, int H, int W, float& xn, float& yn,
+                                           bool& live_x, bool& live_y) {
+  xn = 2.0f * p.U / static_cast<float>(W - 1) - 1.0f;
+  yn = 2.0f * p.V / static_cast<float>(H - 1) - 1.0f;
+  live_x = !((xn > 1.0f) || (xn < -1.0f));
+  live_y = !((yn > 1.0f) || (yn < -1.0f));
+  if (!live_x) xn = 2.0f;
+  if (!live_y) yn = 2.0f;
+}
+
+// Back-propagate (gU, gV) = dL/dU, dL/dV (and optionally gZ = dL/dZ) of one pixel to
+// depth and to the 12 camera sums (dL/db[3], dL/dA[9]) -- SURVEY.md A.3.
+__device__ __forceinline__ void project_backward(const Proj& p, float depth, float gU, float gV, float gZ,
+                                                 float& gdepth, float acc[12]) {
+  float invZ = 1.0f / p.Z;
+  float gX = gU * invZ, gY = gV * invZ;
+  float gZr = p.clamped ? 0.0f : (gZ - (gU * p.U + gV * p.V) * invZ);
+  gdepth = gX * p.q0 + gY * p.q1 + gZr * p.q2;
+  acc[0] += gX; acc[1] += gY; acc[2] += gZr;
+  float c0 = p.r0 * depth, c1 = p.r1 * depth, c2 = p.r2 * depth;
+  acc[3] += gX * c0;  acc[4] += gX * c1;  acc[5] += gX * c2;
+  acc[6] += gY * c0;  acc[7] += gY * c1;  acc[8] += gY * c2;
+  acc[9] += gZr * c0; acc[10] += gZr * c1; acc[11] += gZr * c2;
+}
+
+// ---------------------------------------------------------------- mask decisions
+__device__ __forceinline__ float mean3_abs_diff(float a0, float a1, float a2, float b0, float b1, float b2) {
+  return ((fabsf(a0 - b0) + fabsf(a1 - b1)) + fabsf(a2 - b2)) / 3.0f;
+}
+
+// 1 - softmax([dl, dr]) > 0.48, evaluated through the softmax as the reference does
+// (model_geometry.py:119-130).  Returns soft weights too (Model_flow uses them).
+__device__ __forceinline__ void occ_weights(float dl, float dr, float& w_bwd, float& w_fwd) {
+  float m = fmaxf(dl, dr);
+  float el = expf(dl - m), er = expf(dr - m);
+  float sum = el + er;
+  w_bwd = 1.0f - el / sum;
+  w_fwd = 1.0f - er / sum;
+}
+
+__device__ __forceinline__ float l2norm2(float a, float b) {  // torch.norm(p=2,dim=1) + 1e-12
+  return sqrtf(a * a + b * b) + 1e-12f;
+}
+
+// dynamic mask: ||diff||^2 < alpha (||flow||^2 + ||rigid||^2) + beta (model_geometry.py:701-707)
+__device__ __forceinline__ bool dyna_decision(float fu, float fv, float ru, float rv, float du, float dv,
+                                              float alpha, float beta) {
+  float nf = l2norm2(fu, fv), nr = l2norm2(ru, rv), nd = l2norm2(du, dv);
+  float bound = alpha * (nf * nf + nr * nr) + beta;
+  return (nd * nd) < bound;
+}
+
+// ---------------------------------------------------------------- SSIM from 3x3 box sums
+// sums are already divided by 9 (AvgPool2d(3,1,1), count_include_pad) -- ssim.py:4-19
+__device__ __forceinline__ float ssim_from_means(float mx, float my, float exx, float eyy, float exy) {
+  const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+  float sx = exx - mx * mx, sy = eyy - my * my, sxy = exy - mx * my;
+  float num = (2.0f * mx * my + C1) * (2.0f * sxy + C2);
+  float den = (mx * mx + my * my + C1) * (sx + sy + C2);
+  return num / den;
+}
+
+// partial derivatives of SSIM wrt (mx, my, exx, eyy, exy)
+__device__ __forceinline__ void ssim_partials(float mx, float my, float exx, float eyy, float exy,
+                                              float& d_mx, float& d_my, float& d_exx, float& d_eyy, float& d_exy) {
+  const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+  float sxy = exy - mx * my;
+  float n1 = 2.0f * mx * my + C1, n2 = 2.0f * sxy + C2;
+  float d1 = mx * mx + my * my + C1, d2 = (exx - mx * mx) + (eyy - my * my) + C2;
+  float inv = 1.0f / (d1 * d2);
+  float s = n1 * n2 * inv;
+  // num = n1*n2 ; den = d1*d2
+  // dn1/dmx = 2my, dn2/dmx = -2my, dd1/dmx = 2mx, dd2/dmx = -2mx
+  d_mx = (2.0f * my * n2 - 2.0f * my * n1) * inv - s * (2.0f * mx * d2 - 2.0f * mx * d1) * inv;
+  d_my = (2.0f * mx * n2 - 2.0f * mx * n1) * inv - s * (2.0f * my * d2 - 2.0f * my * d1) * inv;
+  d_exy = 2.0f * n1 * inv;
+  d_exx = -s * d1 * inv;
+  d_eyy = d_exx;
+}
+
+// ---------------------------------------------------------------- resize helpers
+// ATen upsample_bilinear2d source index, align_corners=False: max(0, fma(scale, dst+0.5, -0.5))
+// (the CPU build contracts the expression into one FMA -- probed bit-for-bit)
+__device__ __forceinline__ void bilinear_src(int dst, float scale, int in_size, int& i0, int& i1, float& l0, float& l1) {
+  float src = __fmaf_rn(scale, static_cast<float>(dst) + 0.5f, -0.5f);
+  if (src < 0.0f) src = 0.0f;
+  i0 = static_cast<int>(src);
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = src - static_cast<float>(i0);
+  l0 = 1.0f - l1;
+}
+
+__device__ __forceinline__ float resize_bilinear_at(const float* __restrict__ plane, int inH, int inW,
+                                                    int y, int x, float sh, float sw) {
+  int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+  bilinear_src(y, sh, inH, y0, y1, ly0, ly1);
+  bilinear_src(x, sw, inW, x0, x1, lx0, lx1);
+  const float* r0 = plane + static_cast<long>(y0) * inW;
+  const float* r1 = plane + static_cast<long>(y1) * inW;
+  return ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
+}
+
+// ---------------------------------------------------------------- reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, DFE_WAVE);
+  return v;
+}
+
+// Block-wide sum of N per-thread values; result valid in thread 0 (written to out[0..N)).
+// smem must hold N * (blockDim.x / 64) floats.
+template <int N>
+__device__ __forceinline__ void block_sum(float (&vals)[N], float* smem, float* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    float s = wave_sum(vals[i]);
+    if (lane == 0) smem[wave * N + i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < N) {
+    float s = 0.0f;
+    for (int w = 0; w < nwaves; ++w) s += smem[w * N + threadIdx.x];
+    out[threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
+// XCD-aware block index: consecutive logical blocks land on the same XCD (blocks are dealt
+// round-robin over the 8 XCDs; MI355X_MICROARCH.md "Workgroup dispatch").  Speed only.
+__device__ __forceinline__ unsigned xcd_swizzle(unsigned bid, unsigned nblocks) {
+  const unsigned nx = 8;
+  unsigned per = nblocks / nx;
+  if (per == 0 || bid >= per * nx) return bid;   // tail blocks keep their index
+  return (bid % nx) * per + (bid / nx);
+}
+
+}  // namespace dfe

@@ -1,0 +1,715 @@
+// Per-operator HIP kernels behind the reference's free functions (drop-in level 3):
+//   warp_flow            core/networks/structures/net_utils.py:16-54
+//   pose_vec2mat/euler   core/networks/structures/inverse_warp.py:110-187
+//   inverse_warp2        core/networks/structures/inverse_warp.py:227-303
+//   calculate_rigid_flow core/networks/structures/inverse_warp.py:311-342
+//   essential matrix     core/networks/structures/inverse_warp.py:344-364
+//   SSIM                 core/networks/pytorch_ssim/ssim.py:4-19
+//   corr_naive           core/networks/structures/pwc_tf.py:97-106
+//   pyramids             core/networks/model_geometry.py:65-72,91 ; model_flow.py:58-64
+// All kernels are HBM/L2-bound stencil or gather work: no MFMA, coalesced row-major
+// accesses, LDS only where a tile is re-read (SSIM window, correlation window).
+#include "dfe_device.h"
+#include "dfe_internal.h"
+
+namespace dfe {
+
+// ====================================================================== cameras
+__device__ inline void mat3_mul(const double* a, const double* b, double* o) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) o[i * 3 + j] = a[i * 3] * b[j] + a[i * 3 + 1] * b[3 + j] + a[i * 3 + 2] * b[6 + j];
+}
+
+__device__ inline void euler_mats(double rx, double ry, double rz, double* X, double* Y, double* Z,
+                                  double* dX, double* dY, double* dZ) {
+  double cx = cos(rx), sx = sin(rx), cy = cos(ry), sy = sin(ry), cz = cos(rz), sz = sin(rz);
+  double x[9] = {1, 0, 0, 0, cx, -sx, 0, sx, cx};
+  double y[9] = {cy, 0, sy, 0, 1, 0, -sy, 0, cy};
+  double z[9] = {cz, -sz, 0, sz, cz, 0, 0, 0, 1};
+  double dx[9] = {0, 0, 0, 0, -sx, -cx, 0, cx, -sx};
+  double dy[9] = {-sy, 0, cy, 0, 0, 0, -cy, 0, -sy};
+  double dz[9] = {-sz, -cz, 0, cz, -sz, 0, 0, 0, 0};
+  for (int i = 0; i < 9; ++i) { X[i] = x[i]; Y[i] = y[i]; Z[i] = z[i]; dX[i] = dx[i]; dY[i] = dy[i]; dZ[i] = dz[i]; }
+}
+
+// One thread per camera.  cams[(b*ndir + d)*nscale + s]; pose laid out [B, ndir, 6];
+// K [B,3,3]; K_s = K with rows 0-1 divided by downscale[s] (model_geometry.py:92-93).
+__global__ void k_prepare_cameras(const float* __restrict__ pose, const float* __restrict__ K,
+                                  Camera* __restrict__ cams, int B, int ndir, int nscale, ScaleList downs) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * ndir * nscale) return;
+  int s = idx % nscale, d = (idx / nscale) % ndir, b = idx / (nscale * ndir);
+  const float* pv = pose + (static_cast<long>(b) * ndir + d) * 6;
+  double Ks[9];
+  // the reference divides in fp32: intrinsics[:,0:2]/downscale
+  for (int i = 0; i < 9; ++i) {
+    float k = K[b * 9 + i];
+    Ks[i] = (i < 6) ? static_cast<double>(k / downs.v[s]) : static_cast<double>(k);
+  }
+  double X[9], Y[9], Z[9], dX[9], dY[9], dZ[9], XY[9], R[9], T1[9], T2[9];
+  euler_mats(pv[3], pv[4], pv[5], X, Y, Z, dX, dY, dZ);
+  mat3_mul(X, Y, XY); mat3_mul(XY, Z, R);
+  Camera c;
+  double A[9]; mat3_mul(Ks, R, A);
+  for (int i = 0; i < 9; ++i) { c.A[i] = static_cast<float>(A[i]); c.K[i] = static_cast<float>(Ks[i]); c.R[i] = static_cast<float>(R[i]); }
+  for (int i = 0; i < 3; ++i)
+    c.b[i] = static_cast<float>(Ks[i * 3] * pv[0] + Ks[i * 3 + 1] * pv[1] + Ks[i * 3 + 2] * pv[2]);
+  // general 3x3 inverse (adjugate / determinant) in double
+  double det = Ks[0] * (Ks[4] * Ks[8] - Ks[5] * Ks[7]) - Ks[1] * (Ks[3] * Ks[8] - Ks[5] * Ks[6]) +
+               Ks[2] * (Ks[3] * Ks[7] - Ks[4] * Ks[6]);
+  double id = 1.0 / det;
+  c.kinv[0] = static_cast<float>((Ks[4] * Ks[8] - Ks[5] * Ks[7]) * id);
+  c.kinv[1] = static_cast<float>((Ks[2] * Ks[7] - Ks[1] * Ks[8]) * id);
+  c.kinv[2] = static_cast<float>((Ks[1] * Ks[5] - Ks[2] * Ks[4]) * id);
+  c.kinv[3] = static_cast<float>((Ks[5] * Ks[6] - Ks[3] * Ks[8]) * id);
+  c.kinv[4] = static_cast<float>((Ks[0] * Ks[8] - Ks[2] * Ks[6]) * id);
+  c.kinv[5] = static_cast<float>((Ks[2] * Ks[3] - Ks[0] * Ks[5]) * id);
+  c.kinv[6] = static_cast<float>((Ks[3] * Ks[7] - Ks[4] * Ks[6]) * id);
+  c.kinv[7] = static_cast<float>((Ks[1] * Ks[6] - Ks[0] * Ks[7]) * id);
+  c.kinv[8] = static_cast<float>((Ks[0] * Ks[4] - Ks[1] * Ks[3]) * id);
+  // dR/d(rx) = dX Y Z ; dR/d(ry) = X dY Z ; dR/d(rz) = X Y dZ
+  mat3_mul(dX, Y, T1); mat3_mul(T1, Z, T2);
+  for (int i = 0; i < 9; ++i) c.dR[i] = static_cast<float>(T2[i]);
+  mat3_mul(X, dY, T1); mat3_mul(T1, Z, T2);
+  for (int i = 0; i < 9; ++i) c.dR[9 + i] = static_cast<float>(T2[i]);
+  mat3_mul(XY, dZ, T2);
+  for (int i = 0; i < 9; ++i) c.dR[18 + i] = static_cast<float>(T2[i]);
+  cams[idx] = c;
+}
+
+// grad_pose[cam] (6) from the 12 camera sums per (cam, scale): acc = [dL/db(3), dL/dA(9)].
+// partials laid out [ncam][nscale][nblk_max][12]; nblk[s] valid rows per scale.  Fixed order,
+// double accumulation -> bitwise reproducible.  One thread per camera (b,d).
+__global__ void k_pose_finalize(const float* __restrict__ partials, const Camera* __restrict__ cams,
+                                float* __restrict__ gpose, int ncam, int nscale, int nblk_max, IntList nblk,
+                                int accumulate) {
+  int cam = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cam >= ncam) return;
+  double g[6] = {0, 0, 0, 0, 0, 0};
+  for (int s = 0; s < nscale; ++s) {
+    double acc[12];
+    for (int i = 0; i < 12; ++i) acc[i] = 0.0;
+    const float* p = partials + (static_cast<long>(cam) * nscale + s) * nblk_max * 12;
+    for (int k = 0; k < nblk.v[s]; ++k)
+      for (int i = 0; i < 12; ++i) acc[i] += static_cast<double>(p[k * 12 + i]);
+    const Camera& c = cams[cam * nscale + s];
+    // dL/dt = K^T dL/db
+    for (int j = 0; j < 3; ++j) g[j] += c.K[j] * acc[0] + c.K[3 + j] * acc[1] + c.K[6 + j] * acc[2];
+    // dL/dR = K^T dL/dA ; dL/dtheta_k = <dL/dR, dR/dtheta_k>
+    double gR[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j)
+        gR[i * 3 + j] = c.K[i] * acc[3 + j] + c.K[3 + i] * acc[6 + j] + c.K[6 + i] * acc[9 + j];
+    for (int k = 0; k < 3; ++k) {
+      double t = 0.0;
+      for (int i = 0; i < 9; ++i) t += gR[i] * c.dR[k * 9 + i];
+      g[3 + k] += t;
+    }
+  }
+  for (int i = 0; i < 6; ++i) {
+    float v = static_cast<float>(g[i]);
+    gpose[cam * 6 + i] = accumulate ? gpose[cam * 6 + i] + v : v;
+  }
+}
+
+// pose_vec2mat / essential matrix, forward and backward, one thread per pose vector.
+__global__ void k_pose_mats(const float* __restrict__ vec, float* __restrict__ T34, float* __restrict__ E, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* v = vec + i * 6;
+  // fp32 like the reference (torch.cos/sin on fp32, R = (X@Y)@Z)
+  float cx = cosf(v[3]), sx = sinf(v[3]), cy = cosf(v[4]), sy = sinf(v[4]), cz = cosf(v[5]), sz = sinf(v[5]);
+  float X[9] = {1, 0, 0, 0, cx, -sx, 0, sx, cx}, Y[9] = {cy, 0, sy, 0, 1, 0, -sy, 0, cy}, Z[9] = {cz, -sz, 0, sz, cz, 0, 0, 0, 1};
+  float XY[9], R[9];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) XY[r * 3 + c] = X[r * 3] * Y[c] + X[r * 3 + 1] * Y[3 + c] + X[r * 3 + 2] * Y[6 + c];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[r * 3 + c] = XY[r * 3] * Z[c] + XY[r * 3 + 1] * Z[3 + c] + XY[r * 3 + 2] * Z[6 + c];
+  if (T34) for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T34[i * 12 + r * 4 + c] = R[r * 3 + c]; T34[i * 12 + r * 4 + 3] = v[r]; }
+  if (E) {
+    float S[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) E[i * 9 + r * 3 + c] = S[r * 3] * R[c] + S[r * 3 + 1] * R[3 + c] + S[r * 3 + 2] * R[6 + c];
+  }
+}
+
+__global__ void k_pose_mats_bwd(const float* __restrict__ vec, const float* __restrict__ gT34,
+                                const float* __restrict__ gE, float* __restrict__ gvec, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* v = vec + i * 6;
+  double X[9], Y[9], Z[9], dX[9], dY[9], dZ[9], XY[9], R[9], T1[9], dRk[3][9];
+  euler_mats(v[3], v[4], v[5], X, Y, Z, dX, dY, dZ);
+  mat3_mul(X, Y, XY); mat3_mul(XY, Z, R);
+  mat3_mul(dX, Y, T1); mat3_mul(T1, Z, dRk[0]);
+  mat3_mul(X, dY, T1); mat3_mul(T1, Z, dRk[1]);
+  mat3_mul(XY, dZ, dRk[2]);
+  double gR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gt[3] = {0, 0, 0};
+  if (gT34) {
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) gR[r * 3 + c] += gT34[i * 12 + r * 4 + c]; gt[r] += gT34[i * 12 + r * 4 + 3]; }
+  }
+  if (gE) {
+    // E = S R : dL/dR += S^T gE ; dL/dS = gE R^T
+    double S[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+    double gS[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+      double a = 0, bq = 0;
+      for (int k = 0; k < 3; ++k) { a += S[k * 3 + r] * gE[i * 9 + k * 3 + c]; bq += gE[i * 9 + r * 3 + k] * R[c * 3 + k]; }
+      gR[r * 3 + c] += a; gS[r * 3 + c] = bq;
+    }
+    gt[0] += gS[7] - gS[5]; gt[1] += gS[2] - gS[6]; gt[2] += gS[3] - gS[1];
+  }
+  for (int k = 0; k < 3; ++k) { double t = 0; for (int j = 0; j < 9; ++j) t += gR[j] * dRk[k][j]; gvec[i * 6 + 3 + k] = static_cast<float>(t); }
+  for (int k = 0; k < 3; ++k) gvec[i * 6 + k] = static_cast<float>(gt[k]);
+}
+
+// ====================================================================== warp_flow
+__global__ void k_warp_flow_fwd(const float* __restrict__ x, const float* __restrict__ flow,
+                                float* __restrict__ out, int C, int H, int W, int use_mask, int ac) {
+  const int b = blockIdx.y, HW = H * W;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  const int py = p / W, px = p - py * W;
+  const float* f = flow + static_cast<long>(b) * 2 * HW;
+  float ix, iy;
+  flow_coords(px, py, f[p], f[HW + p], H, W, ac, ix, iy);
+  Tap t = make_tap(ix, iy, H, W);
+  float keep = 1.0f;
+  if (use_mask) keep = (tap_cover(t) < 0.9999f) ? 0.0f : 1.0f;
+  for (int c = 0; c < C; ++c) {
+    const float* plane = x + (static_cast<long>(b) * C + c) * HW;
+    Corners q = load_corners(plane, t, W);
+    out[(static_cast<long>(b) * C + c) * HW + p] = interp(q, t) * keep;
+  }
+}
+
+// grad wrt flow (sum over channels) and optionally wrt x (scatter-add; gx pre-zeroed).
+__global__ void k_warp_flow_bwd(const float* __restrict__ x, const float* __restrict__ flow,
+                                const float* __restrict__ gout, float* __restrict__ gflow,
+                                float* __restrict__ gx, int C, int H, int W, int use_mask, int ac) {
+  const int b = blockIdx.y, HW = H * W;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  const int py = p / W, px = p - py * W;
+  const float* f = flow + static_cast<long>(b) * 2 * HW;
+  float ix, iy;
+  flow_coords(px, py, f[p], f[HW + p], H, W, ac, ix, iy);
+  Tap t = make_tap(ix, iy, H, W);
+  float keep = 1.0f;
+  if (use_mask) keep = (tap_cover(t) < 0.9999f) ? 0.0f : 1.0f;
+  float gix = 0.0f, giy = 0.0f;
+  for (int c = 0; c < C; ++c) {
+    const long off = (static_cast<long>(b) * C + c) * HW;
+    float g = gout[off + p] * keep;
+    if (gflow) {
+      Corners q = load_corners(x + off, t, W);
+      float dx, dy;
+      interp_grad(q, t, dx, dy);
+      gix += g * dx; giy += g * dy;
+    }
+    if (gx && g != 0.0f) {
+      float* base = gx + off + static_cast<long>(t.y0) * W + t.x0;
+      if (t.in_nw) atomicAdd(base, g * t.nw);
+      if (t.in_ne) atomicAdd(base + 1, g * t.ne);
+      if (t.in_sw) atomicAdd(base + W, g * t.sw);
+      if (t.in_se) atomicAdd(base + W + 1, g * t.se);
+    }
+  }
+  if (gflow) {
+    float* gf = gflow + static_cast<long>(b) * 2 * HW;
+    gf[p] = gix * flow_coord_scale(W, ac);
+    gf[HW + p] = giy * flow_coord_scale(H, ac);
+  }
+}
+
+// ====================================================================== inverse_warp2 / rigid flow
+__global__ void k_inverse_warp2_fwd(const float* __restrict__ img, const float* __restrict__ depth,
+                                    const float* __restrict__ ref_depth, const Camera* __restrict__ cams,
+                                    float* __restrict__ out_img, float* __restrict__ out_valid,
+                                    float* __restrict__ out_pdepth, float* __restrict__ out_cdepth,
+                                    int H, int W, int ac) {
+  const int b = blockIdx.y, HW = H * W;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  const int py = p / W, px = p - py * W;
+  const Camera& cam = cams[b];
+  Proj pr = project(cam, px, py, depth[static_cast<long>(b) * HW + p]);
+  float xn, yn; bool lx, ly;
+  rigid_grid(pr, H, W, xn, yn, lx, ly);
+  Tap t = make_tap(unnormalize(xn, W, ac), unnormalize(yn, H, ac), H, W);
+  for (int c = 0; c < 3; ++c) {
+    const float* plane = img + (static_cast<long>(b) * 3 + c) * HW;
+    out_img[(static_cast<long>(b) * 3 + c) * HW + p] = interp(load_corners(plane, t, W), t);
+  }
+  if (out_valid) out_valid[static_cast<long>(b) * HW + p] = (fmaxf(fabsf(xn), fabsf(yn)) <= 1.0f) ? 1.0f : 0.0f;
+  if (out_pdepth) {
+    float v = interp(load_corners(ref_depth + static_cast<long>(b) * HW, t, W), t);
+    out_pdepth[static_cast<long>(b) * HW + p] = (v >= 1e-3f || v != v) ? v : 1e-3f;
+  }
+  if (out_cdepth) out_cdepth[static_cast<long>(b) * HW + p] = pr.Z;
+}
+
+// Backward of inverse_warp2: grads wrt depth, ref_depth (scatter) and the 12 camera sums.
+// partials [B][1][gridDim.x][12].
+__global__ void k_inverse_warp2_bwd(const float* __restrict__ img, const float* __restrict__ depth,
+                                    const float* __restrict__ ref_depth, const Camera* __restrict__ cams,
+                                    const float* __restrict__ g_img, const float* __restrict__ g_pdepth,
+                                    const float* __restrict__ g_cdepth, float* __restrict__ g_depth,
+                                    float* __restrict__ g_refdepth, float* __restrict__ partials,
+                                    int H, int W, int ac) {
+  __shared__ float red[12 * 4];
+  const int b = blockIdx.y, HW = H * W;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  float acc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = 0.0f;
+  if (p < HW) {
+    const int py = p / W, px = p - py * W;
+    const Camera& cam = cams[b];
+    const float d = depth[static_cast<long>(b) * HW + p];
+    Proj pr = project(cam, px, py, d);
+    float xn, yn; bool lx, ly;
+    rigid_grid(pr, H, W, xn, yn, lx, ly);
+    Tap t = make_tap(unnormalize(xn, W, ac), unnormalize(yn, H, ac), H, W);
+    float gix = 0.0f, giy = 0.0f;
+    if (g_img) {
+      for (int c = 0; c < 3; ++c) {
+        const long off = (static_cast<long>(b) * 3 + c) * HW;
+        float dx, dy;
+        interp_grad(load_corners(img + off, t, W), t, dx, dy);
+        float g = g_img[off + p];
+        gix += g * dx; giy += g * dy;
+      }
+    }
+    if (g_pdepth) {
+      Corners q = load_corners(ref_depth + static_cast<long>(b) * HW, t, W);
+      float v = interp(q, t);
+      float g = (v >= 1e-3f) ? g_pdepth[static_cast<long>(b) * HW + p] : 0.0f;
+      float dx, dy;
+      interp_grad(q, t, dx, dy);
+      gix += g * dx; giy += g * dy;
+      if (g_refdepth && g != 0.0f) {
+        float* base = g_refdepth + static_cast<long>(b) * HW + static_cast<long>(t.y0) * W + t.x0;
+        if (t.in_nw) atomicAdd(base, g * t.nw);
+        if (t.in_ne) atomicAdd(base + 1, g * t.ne);
+        if (t.in_sw) atomicAdd(base + W, g * t.sw);
+        if (t.in_se) atomicAdd(base + W + 1, g * t.se);
+      }
+    }
+    const float sx = ac ? static_cast<float>(W - 1) / 2.0f : static_cast<float>(W) / 2.0f;
+    const float sy = ac ? static_cast<float>(H - 1) / 2.0f : static_cast<float>(H) / 2.0f;
+    float gU = lx ? gix * sx * (2.0f / static_cast<float>(W - 1)) : 0.0f;
+    float gV = ly ? giy * sy * (2.0f / static_cast<float>(H - 1)) : 0.0f;
+    float gZ = g_cdepth ? g_cdepth[static_cast<long>(b) * HW + p] : 0.0f;
+    float gd;
+    project_backward(pr, d, gU, gV, gZ, gd, acc);
+    g_depth[static_cast<long>(b) * HW + p] = gd;
+  }
+  block_sum<12>(acc, red, partials + (static_cast<long>(b) * gridDim.x + blockIdx.x) * 12);
+}
+
+__global__ void k_rigid_flow_fwd(const float* __restrict__ depth, const Camera* __restrict__ cams,
+                                 float* __restrict__ out, int H, int W) {
+  const int b = blockIdx.y, HW = H * W;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  const int py = p / W, px = p - py * W;
+  Proj pr = project(cams[b], px, py, depth[static_cast<long>(b) * HW + p]);
+  out[static_cast<long>(b) * 2 * HW + p] = pr.U - static_cast<float>(px);
+  out[static_cast<long>(b) * 2 * HW + HW + p] = pr.V - static_cast<float>(py);
+}
+
+__global__ void k_rigid_flow_bwd(const float* __restrict__ depth, const Camera* __restrict__ cams,
+                                 const float* __restrict__ gout, float* __restrict__ g_depth,
+                                 float* __restrict__ partials, int H, int W) {
+  __shared__ float red[12 * 4];
+  const int b = blockIdx.y, HW = H * W;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  float acc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = 0.0f;
+  if (p < HW) {
+    const int py = p / W, px = p - py * W;
+    const float d = depth[static_cast<long>(b) * HW + p];
+    Proj pr = project(cams[b], px, py, d);
+    float gd;
+    project_backward(pr, d, gout[static_cast<long>(b) * 2 * HW + p], gout[static_cast<long>(b) * 2 * HW + HW + p], 0.0f, gd, acc);
+    g_depth[static_cast<long>(b) * HW + p] = gd;
+  }
+  block_sum<12>(acc, red, partials + (static_cast<long>(b) * gridDim.x + blockIdx.x) * 12);
+}
+
+// ====================================================================== SSIM (3x3 box, zero pad)
+constexpr int SS_TX = 32, SS_TY = 8;
+
+__global__ void k_ssim_fwd(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out,
+                           int H, int W) {
+  __shared__ float sx[SS_TY + 2][SS_TX + 2], sy[SS_TY + 2][SS_TX + 2];
+  const long plane = static_cast<long>(blockIdx.z) * H * W;
+  const int x0 = blockIdx.x * SS_TX, y0 = blockIdx.y * SS_TY;
+  for (int i = threadIdx.x; i < (SS_TY + 2) * (SS_TX + 2); i += blockDim.x) {
+    int ly = i / (SS_TX + 2), lx = i - ly * (SS_TX + 2);
+    int gy = y0 + ly - 1, gx = x0 + lx - 1;
+    bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    sx[ly][lx] = in ? x[plane + static_cast<long>(gy) * W + gx] : 0.0f;
+    sy[ly][lx] = in ? y[plane + static_cast<long>(gy) * W + gx] : 0.0f;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x % SS_TX, ty = threadIdx.x / SS_TX;
+  const int gx = x0 + tx, gy = y0 + ty;
+  if (gx >= W || gy >= H) return;
+  float a = 0, bq = 0, aa = 0, bb = 0, ab = 0;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      float u = sx[ty + dy][tx + dx], v = sy[ty + dy][tx + dx];
+      a += u; bq += v; aa += u * u; bb += v * v; ab += u * v;
+    }
+  out[plane + static_cast<long>(gy) * W + gx] = ssim_from_means(a / 9.0f, bq / 9.0f, aa / 9.0f, bb / 9.0f, ab / 9.0f);
+}
+
+__global__ void k_ssim_bwd(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gout,
+                           float* __restrict__ gx_out, float* __restrict__ gy_out, int H, int W) {
+  __shared__ float sx[SS_TY + 4][SS_TX + 4], sy[SS_TY + 4][SS_TX + 4];
+  __shared__ float co[5][SS_TY + 2][SS_TX + 2];
+  const long plane = static_cast<long>(blockIdx.z) * H * W;
+  const int x0 = blockIdx.x * SS_TX, y0 = blockIdx.y * SS_TY;
+  for (int i = threadIdx.x; i < (SS_TY + 4) * (SS_TX + 4); i += blockDim.x) {
+    int ly = i / (SS_TX + 4), lx = i - ly * (SS_TX + 4);
+    int gy = y0 + ly - 2, gx = x0 + lx - 2;
+    bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    sx[ly][lx] = in ? x[plane + static_cast<long>(gy) * W + gx] : 0.0f;
+    sy[ly][lx] = in ? y[plane + static_cast<long>(gy) * W + gx] : 0.0f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (SS_TY + 2) * (SS_TX + 2); i += blockDim.x) {
+    int ly = i / (SS_TX + 2), lx = i - ly * (SS_TX + 2);
+    int gy = y0 + ly - 1, gx = x0 + lx - 1;
+    float c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      float a = 0, bq = 0, aa = 0, bb = 0, ab = 0;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          float u = sx[ly + dy][lx + dx], v = sy[ly + dy][lx + dx];
+          a += u; bq += v; aa += u * u; bb += v * v; ab += u * v;
+        }
+      float g = gout[plane + static_cast<long>(gy) * W + gx];
+      ssim_partials(a / 9.0f, bq / 9.0f, aa / 9.0f, bb / 9.0f, ab / 9.0f, c0, c1, c2, c3, c4);
+      c0 *= g; c1 *= g; c2 *= g; c3 *= g; c4 *= g;
+    }
+    co[0][ly][lx] = c0; co[1][ly][lx] = c1; co[2][ly][lx] = c2; co[3][ly][lx] = c3; co[4][ly][lx] = c4;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x % SS_TX, ty = threadIdx.x / SS_TX;
+  const int gx = x0 + tx, gy = y0 + ty;
+  if (gx >= W || gy >= H) return;
+  float s[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) s[k] += co[k][ty + dy][tx + dx];
+  float xv = sx[ty + 2][tx + 2], yv = sy[ty + 2][tx + 2];
+  if (gx_out) gx_out[plane + static_cast<long>(gy) * W + gx] = (s[0] + 2.0f * xv * s[2] + yv * s[4]) / 9.0f;
+  if (gy_out) gy_out[plane + static_cast<long>(gy) * W + gx] = (s[1] + 2.0f * yv * s[3] + xv * s[4]) / 9.0f;
+}
+
+// ====================================================================== correlation (d = 4, 81 taps)
+constexpr int CR_D = 4, CR_K = 2 * CR_D + 1, CR_TX = 32, CR_TY = 8, CR_CK = 8;
+constexpr int CR_LW = CR_TX + 2 * CR_D, CR_LH = CR_TY + 2 * CR_D;
+
+// stage `nch` channel planes of `src` (tile origin x0,y0, halo CR_D, zero outside) into LDS
+__device__ __forceinline__ void corr_stage(float (*tile)[CR_LH][CR_LW], const float* __restrict__ src, int c0, int nch,
+                                           int C, int H, int W, int x0, int y0) {
+  const int per = CR_LH * CR_LW;
+  for (int i = threadIdx.x; i < nch * per; i += blockDim.x) {
+    int c = i / per, r = i - c * per;
+    int ly = r / CR_LW, lx = r - ly * CR_LW;
+    int gy = y0 + ly - CR_D, gx = x0 + lx - CR_D;
+    bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    tile[c][ly][lx] = in ? src[(static_cast<long>(c0 + c) * H + gy) * W + gx] : 0.0f;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_corr_fwd(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                  float* __restrict__ out, int C, int H, int W) {
+  __shared__ float tile[CR_CK][CR_LH][CR_LW];
+  const int b = blockIdx.z, x0 = blockIdx.x * CR_TX, y0 = blockIdx.y * CR_TY;
+  const int tx = threadIdx.x % CR_TX, ty = threadIdx.x / CR_TX;
+  const int gx = x0 + tx, gy = y0 + ty;
+  const bool live = gx < W && gy < H;
+  const long HW = static_cast<long>(H) * W;
+  const float* f1b = f1 + static_cast<long>(b) * C * HW;
+  const float* f2b = f2 + static_cast<long>(b) * C * HW;
+  float acc[CR_K * CR_K];
+#pragma unroll
+  for (int k = 0; k < CR_K * CR_K; ++k) acc[k] = 0.0f;
+  for (int c0 = 0; c0 < C; c0 += CR_CK) {
+    const int nch = min(CR_CK, C - c0);
+    __syncthreads();
+    corr_stage(tile, f2b, c0, nch, C, H, W, x0, y0);
+    __syncthreads();
+    if (live) {
+      for (int c = 0; c < nch; ++c) {
+        const float a = f1b[(c0 + c) * HW + static_cast<long>(gy) * W + gx];
+#pragma unroll
+        for (int i = 0; i < CR_K; ++i)
+#pragma unroll
+          for (int j = 0; j < CR_K; ++j) acc[i * CR_K + j] += a * tile[c][ty + i][tx + j];
+      }
+    }
+  }
+  if (!live) return;
+  float* o = out + static_cast<long>(b) * CR_K * CR_K * HW + static_cast<long>(gy) * W + gx;
+  const float fc = static_cast<float>(C);
+#pragma unroll
+  for (int k = 0; k < CR_K * CR_K; ++k) o[k * HW] = acc[k] / fc;
+}
+
+// MODE 0: g1[c,p] = 1/C sum_k g[k,p] * f2pad[c, p + off_k]   (other = f2, taps read at +off)
+// MODE 1: g2[c,p] = 1/C sum_k g[k,p - off_k] * f1[c, p - off_k]  (other = f1, taps read at -off)
+template <int MODE>
+__global__ void __launch_bounds__(256) k_corr_bwd(const float* __restrict__ other, const float* __restrict__ gout,
+                                                  float* __restrict__ gin, int C, int H, int W) {
+  __shared__ float tile[CR_CK][CR_LH][CR_LW];
+  const int b = blockIdx.z, x0 = blockIdx.x * CR_TX, y0 = blockIdx.y * CR_TY;
+  const int tx = threadIdx.x % CR_TX, ty = threadIdx.x / CR_TX;
+  const int gx = x0 + tx, gy = y0 + ty;
+  const bool live = gx < W && gy < H;
+  const long HW = static_cast<long>(H) * W;
+  const float* ob = other + static_cast<long>(b) * C * HW;
+  const float* gb = gout + static_cast<long>(b) * CR_K * CR_K * HW;
+  float g[CR_K * CR_K];
+#pragma unroll
+  for (int i = 0; i < CR_K; ++i)
+#pragma unroll
+    for (int j = 0; j < CR_K; ++j) {
+      float v = 0.0f;
+      if (live) {
+        if (MODE == 0) {
+          v = gb[(i * CR_K + j) * HW + static_cast<long>(gy) * W + gx];
+        } else {
+          int sy = gy - (i - CR_D), sx = gx - (j - CR_D);
+          if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = gb[(i * CR_K + j) * HW + static_cast<long>(sy) * W + sx];
+        }
+      }
+      g[i * CR_K + j] = v;
+    }
+  const float fc = static_cast<float>(C);
+  for (int c0 = 0; c0 < C; c0 += CR_CK) {
+    const int nch = min(CR_CK, C - c0);
+    __syncthreads();
+    corr_stage(tile, ob, c0, nch, C, H, W, x0, y0);
+    __syncthreads();
+    if (live) {
+      for (int c = 0; c < nch; ++c) {
+        float a = 0.0f;
+#pragma unroll
+        for (int i = 0; i < CR_K; ++i)
+#pragma unroll
+          for (int j = 0; j < CR_K; ++j) {
+            float t = (MODE == 0) ? tile[c][ty + i][tx + j] : tile[c][ty + 2 * CR_D - i][tx + 2 * CR_D - j];
+            a += g[i * CR_K + j] * t;
+          }
+        gin[static_cast<long>(b) * C * HW + (c0 + c) * HW + static_cast<long>(gy) * W + gx] = a / fc;
+      }
+    }
+  }
+}
+
+// ====================================================================== resize (pyramids)
+// mode 0: bilinear align_corners=False (F.interpolate); mode 1: area (adaptive average pool)
+__global__ void k_resize(const float* __restrict__ in, float* __restrict__ out, int planes, int inH, int inW,
+                         int outH, int outW, int mode) {
+  const long n = static_cast<long>(planes) * outH * outW;
+  const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int ox = static_cast<int>(i % outW), oy = static_cast<int>((i / outW) % outH);
+  const long pl = i / (static_cast<long>(outW) * outH);
+  const float* src = in + pl * inH * inW;
+  if (mode == 0) {
+    out[i] = resize_bilinear_at(src, inH, inW, oy, ox, static_cast<float>(inH) / outH, static_cast<float>(inW) / outW);
+  } else {
+    // adaptive_avg_pool2d window: [floor(o*in/out), ceil((o+1)*in/out))
+    int ys = (oy * inH) / outH, ye = ((oy + 1) * inH + outH - 1) / outH;
+    int xs = (ox * inW) / outW, xe = ((ox + 1) * inW + outW - 1) / outW;
+    float s = 0.0f;
+    for (int yy = ys; yy < ye; ++yy)
+      for (int xx = xs; xx < xe; ++xx) s += src[static_cast<long>(yy) * inW + xx];
+    out[i] = s / static_cast<float>((ye - ys) * (xe - xs));
+  }
+}
+
+}  // namespace dfe
+
+// ====================================================================== C ABI
+using namespace dfe;
+
+#define DFE_REQUIRE(cond, code) do { if (!(cond)) return (code); } while (0)
+#define DFE_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return DFE_ERR_LAUNCH; } while (0)
+
+static inline dim3 grid1d(long n, int bs) { return dim3(static_cast<unsigned>((n + bs - 1) / bs)); }
+
+extern "C" {
+
+int dfe_camera_floats(void) { return static_cast<int>(sizeof(Camera) / sizeof(float)); }
+
+int dfe_prepare_cameras(const float* pose, const float* K, float* cams, int B, int ndir, int nscale,
+                        const float* downscale_host, void* stream) {
+  DFE_REQUIRE(pose && K && cams && downscale_host, DFE_ERR_NULL);
+  DFE_REQUIRE(B > 0 && ndir > 0 && nscale > 0 && nscale <= DFE_MAX_SCALES, DFE_ERR_DIMS);
+  ScaleList dl;
+  for (int s = 0; s < nscale; ++s) dl.v[s] = downscale_host[s];
+  int n = B * ndir * nscale;
+  k_prepare_cameras<<<grid1d(n, 64), 64, 0, static_cast<hipStream_t>(stream)>>>(pose, K, reinterpret_cast<Camera*>(cams), B, ndir, nscale, dl);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+int dfe_pose_vec2mat_fwd(const float* vec, float* T34, float* E, int n, void* stream) {
+  DFE_REQUIRE(vec && (T34 || E), DFE_ERR_NULL);
+  DFE_REQUIRE(n > 0, DFE_ERR_DIMS);
+  k_pose_mats<<<grid1d(n, 64), 64, 0, static_cast<hipStream_t>(stream)>>>(vec, T34, E, n);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+int dfe_pose_vec2mat_bwd(const float* vec, const float* gT34, const float* gE, float* gvec, int n, void* stream) {
+  DFE_REQUIRE(vec && gvec && (gT34 || gE), DFE_ERR_NULL);
+  DFE_REQUIRE(n > 0, DFE_ERR_DIMS);
+  k_pose_mats_bwd<<<grid1d(n, 64), 64, 0, static_cast<hipStream_t>(stream)>>>(vec, gT34, gE, gvec, n);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+int dfe_warp_flow_fwd(const float* x, const float* flow, float* out, int B, int C, int H, int W, int use_mask,
+                      int align_corners, void* stream) {
+  DFE_REQUIRE(x && flow && out, DFE_ERR_NULL);
+  DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
+  dim3 g(static_cast<unsigned>((static_cast<long>(H) * W + 255) / 256), B);
+  k_warp_flow_fwd<<<g, 256, 0, static_cast<hipStream_t>(stream)>>>(x, flow, out, C, H, W, use_mask, align_corners);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+int dfe_warp_flow_bwd(const float* x, const float* flow, const float* gout, float* gflow, float* gx, int B, int C,
+                      int H, int W, int use_mask, int align_corners, void* stream) {
+  DFE_REQUIRE(x && flow && gout && (gflow || gx), DFE_ERR_NULL);
+  DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
+  dim3 g(static_cast<unsigned>((static_cast<long>(H) * W + 255) / 256), B);
+  k_warp_flow_bwd<<<g, 256, 0, static_cast<hipStream_t>(stream)>>>(x, flow, gout, gflow, gx, C, H, W, use_mask, align_corners);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+int dfe_pose_partials_floats(int B, int H, int W) {
+  return B * static_cast<int>((static_cast<long>(H) * W + 255) / 256) * 12;
+}
+
+int dfe_inverse_warp2_fwd(const float* img, const float* depth, const float* ref_depth, const float* cams,
+                          float* out_img, float* out_valid, float* out_pdepth, float* out_cdepth, int B, int H, int W,
+                          int align_corners, void* stream) {
+  DFE_REQUIRE(img && depth && cams && out_img, DFE_ERR_NULL);
+  DFE_REQUIRE(!out_pdepth || ref_depth, DFE_ERR_NULL);
+  DFE_REQUIRE(B > 0 && H > 1 && W > 1, DFE_ERR_DIMS);
+  dim3 g(static_cast<unsigned>((static_cast<long>(H) * W + 255) / 256), B);
+  k_inverse_warp2_fwd<<<g, 256, 0, static_cast<hipStream_t>(stream)>>>(img, depth, ref_depth, reinterpret_cast<const Camera*>(cams), out_img, out_valid, out_pdepth, out_cdepth, H, W, align_corners);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+int dfe_inverse_warp2_bwd(const float* img, const float* depth, const float* ref_depth, const float* cams,
+                          const float* g_img, const float* g_pdepth, const float* g_cdepth, float* g_depth,
+                          float* g_refdepth, float* g_pose, float* partials, int B, int H, int W, int align_corners,
+                          void* stream) {
+  DFE_REQUIRE(img && depth && cams && g_depth && g_pose && partials, DFE_ERR_NULL);
+  DFE_REQUIRE(!g_pdepth || ref_depth, DFE_ERR_NULL);
+  DFE_REQUIRE(B > 0 && H > 1 && W > 1, DFE_ERR_DIMS);
+  const int nblk = static_cast<int>((static_cast<long>(H) * W + 255) / 256);
+  dim3 g(nblk, B);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  k_inverse_warp2_bwd<<<g, 256, 0, st>>>(img, depth, ref_depth, reinterpret_cast<const Camera*>(cams), g_img, g_pdepth, g_cdepth, g_depth, g_refdepth, partials, H, W, align_corners);
+  DFE_LAUNCH_CHECK();
+  IntList nb; nb.v[0] = nblk;
+  k_pose_finalize<<<grid1d(B, 64), 64, 0, st>>>(partials, reinterpret_cast<const Camera*>(cams), g_pose, B, 1, nblk, nb, 0);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+int dfe_rigid_flow_fwd(const float* depth, const float* cams, float* out, int B, int H, int W, void* stream) {
+  DFE_REQUIRE(depth && cams && out, DFE_ERR_NULL);
+  DFE_REQUIRE(B > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
+  dim3 g(static_cast<unsigned>((static_cast<long>(H) * W + 255) / 256), B);
+  k_rigid_flow_fwd<<<g, 256, 0, static_cast<hipStream_t>(stream)>>>(depth, reinterpret_cast<const Camera*>(cams), out, H, W);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+int dfe_rigid_flow_bwd(const float* depth, const float* cams, const float* gout, float* g_depth, float* g_pose,
+                       float* partials, int B, int H, int W, void* stream) {
+  DFE_REQUIRE(depth && cams && gout && g_depth && g_pose && partials, DFE_ERR_NULL);
+  DFE_REQUIRE(B > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
+  const int nblk = static_cast<int>((static_cast<long>(H) * W + 255) / 256);
+  dim3 g(nblk, B);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  k_rigid_flow_bwd<<<g, 256, 0, st>>>(depth, reinterpret_cast<const Camera*>(cams), gout, g_depth, partials, H, W);
+  DFE_LAUNCH_CHECK();
+  IntList nb; nb.v[0] = nblk;
+  k_pose_finalize<<<grid1d(B, 64), 64, 0, st>>>(partials, reinterpret_cast<const Camera*>(cams), g_pose, B, 1, nblk, nb, 0);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+int dfe_ssim_fwd(const float* x, const float* y, float* out, int B, int C, int H, int W, void* stream) {
+  DFE_REQUIRE(x && y && out, DFE_ERR_NULL);
+  DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && static_cast<long>(B) * C <= 65535, DFE_ERR_DIMS);
+  dim3 g((W + SS_TX - 1) / SS_TX, (H + SS_TY - 1) / SS_TY, B * C);
+  k_ssim_fwd<<<g, SS_TX * SS_TY, 0, static_cast<hipStream_t>(stream)>>>(x, y, out, H, W);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+int dfe_ssim_bwd(const float* x, const float* y, const float* gout, float* gx, float* gy, int B, int C, int H, int W,
+                 void* stream) {
+  DFE_REQUIRE(x && y && gout && (gx || gy), DFE_ERR_NULL);
+  DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && static_cast<long>(B) * C <= 65535, DFE_ERR_DIMS);
+  dim3 g((W + SS_TX - 1) / SS_TX, (H + SS_TY - 1) / SS_TY, B * C);
+  k_ssim_bwd<<<g, SS_TX * SS_TY, 0, static_cast<hipStream_t>(stream)>>>(x, y, gout, gx, gy, H, W);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+int dfe_corr_fwd(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int d, void* stream) {
+  DFE_REQUIRE(f1 && f2 && out, DFE_ERR_NULL);
+  DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && B <= 65535, DFE_ERR_DIMS);
+  DFE_REQUIRE(d == CR_D, DFE_ERR_UNSUPPORTED);
+  dim3 g((W + CR_TX - 1) / CR_TX, (H + CR_TY - 1) / CR_TY, B);
+  k_corr_fwd<<<g, 256, 0, static_cast<hipStream_t>(stream)>>>(f1, f2, out, C, H, W);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+int dfe_corr_bwd(const float* f1, const float* f2, const float* gout, float* g1, float* g2, int B, int C, int H, int W,
+                 int d, void* stream) {
+  DFE_REQUIRE(f1 && f2 && gout && (g1 || g2), DFE_ERR_NULL);
+  DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && B <= 65535, DFE_ERR_DIMS);
+  DFE_REQUIRE(d == CR_D, DFE_ERR_UNSUPPORTED);
+  dim3 g((W + CR_TX - 1) / CR_TX, (H + CR_TY - 1) / CR_TY, B);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (g1) { k_corr_bwd<0><<<g, 256, 0, st>>>(f2, gout, g1, C, H, W); DFE_LAUNCH_CHECK(); }
+  if (g2) { k_corr_bwd<1><<<g, 256, 0, st>>>(f1, gout, g2, C, H, W); DFE_LAUNCH_CHECK(); }
+  return DFE_OK;
+}
+
+int dfe_resize(const float* in, float* out, int planes, int inH, int inW, int outH, int outW, int mode, void* stream) {
+  DFE_REQUIRE(in && out, DFE_ERR_NULL);
+  DFE_REQUIRE(planes > 0 && inH > 0 && inW > 0 && outH > 0 && outW > 0, DFE_ERR_DIMS);
+  DFE_REQUIRE(mode == 0 || mode == 1, DFE_ERR_UNSUPPORTED);
+  long n = static_cast<long>(planes) * outH * outW;
+  k_resize<<<grid1d(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(in, out, planes, inH, inW, outH, outW, mode);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+}  // extern "C"

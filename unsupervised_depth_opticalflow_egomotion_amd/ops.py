@@ -1,0 +1,256 @@
+"""torch.autograd wrappers over the C ABI (include/dfe_hip.h).
+
+Each Function is the device-side implementation of one reference free function; the
+reference-signature shims live in ``structures/`` and ``pytorch_ssim``.  PyTorch supplies
+device memory, the current HIP stream and the autograd graph -- the arithmetic is in
+libdfe_hip.so.  There is no CPU fallback: CPU tensors raise ``DfeError``."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, f32c, get_lib, ptr, stream_ptr
+
+_ALIGN_CORNERS = False
+
+
+def set_align_corners(flag: bool):
+    """grid_sample convention used by every warp (the reference leaves it to the installed torch;
+    False = torch>=1.3 default = what the golden vectors of this container use)."""
+    global _ALIGN_CORNERS
+    _ALIGN_CORNERS = bool(flag)
+
+
+def get_align_corners() -> bool:
+    return _ALIGN_CORNERS
+
+
+def _ac(flag):
+    return int(_ALIGN_CORNERS if flag is None else bool(flag))
+
+
+# --------------------------------------------------------------------------- cameras
+def prepare_cameras(pose, K, downscales):
+    """pose [B,ndir,6] or [B,6], K [B,3,3] -> opaque camera buffer [B*ndir*len(downscales), 66]."""
+    lib = get_lib()
+    pose = f32c(pose.detach())
+    if pose.dim() == 2:
+        pose = pose.unsqueeze(1)
+    B, ndir = pose.shape[0], pose.shape[1]
+    K = f32c(K.detach())
+    n = len(downscales)
+    cams = torch.empty(B * ndir * n, lib.dfe_camera_floats(), device=pose.device, dtype=torch.float32)
+    ds = (ctypes.c_float * n)(*[float(d) for d in downscales])
+    check(lib.dfe_prepare_cameras(ptr(pose), ptr(K), ptr(cams), B, ndir, n, ctypes.cast(ds, ctypes.c_void_p),
+                                  stream_ptr()), "dfe_prepare_cameras")
+    return cams
+
+
+# --------------------------------------------------------------------------- warp_flow
+class WarpFlowFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, flow, use_mask, align_corners):
+        lib = get_lib()
+        x, flow = f32c(x), f32c(flow)
+        B, C, H, W = x.shape
+        out = torch.empty_like(x)
+        check(lib.dfe_warp_flow_fwd(ptr(x), ptr(flow), ptr(out), B, C, H, W, int(use_mask), align_corners,
+                                    stream_ptr()), "dfe_warp_flow_fwd")
+        ctx.save_for_backward(x, flow)
+        ctx.cfg = (int(use_mask), align_corners)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = get_lib()
+        x, flow = ctx.saved_tensors
+        use_mask, ac = ctx.cfg
+        B, C, H, W = x.shape
+        gout = f32c(gout)
+        gflow = torch.empty_like(flow) if ctx.needs_input_grad[1] else None
+        gx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
+        if gflow is None and gx is None:
+            return None, None, None, None
+        check(lib.dfe_warp_flow_bwd(ptr(x), ptr(flow), ptr(gout), ptr(gflow), ptr(gx), B, C, H, W, use_mask, ac,
+                                    stream_ptr()), "dfe_warp_flow_bwd")
+        return gx, gflow, None, None
+
+
+def warp_flow(x, flow, use_mask=False, align_corners=None):
+    B, C, H, W = x.size()
+    if tuple(flow.shape) != (B, 2, H, W):
+        raise ValueError("the shape of grid {0} is not equal to the shape of flow {1}.".format(
+            torch.Size((B, 2, H, W)), flow.shape))
+    return WarpFlowFn.apply(x, flow, bool(use_mask), _ac(align_corners))
+
+
+# --------------------------------------------------------------------------- pose matrices
+class PoseMatsFn(torch.autograd.Function):
+    """vec [n,6] -> (T34 [n,3,4], E [n,3,3])."""
+
+    @staticmethod
+    def forward(ctx, vec):
+        lib = get_lib()
+        vec = f32c(vec)
+        n = vec.shape[0]
+        T = torch.empty(n, 3, 4, device=vec.device, dtype=torch.float32)
+        E = torch.empty(n, 3, 3, device=vec.device, dtype=torch.float32)
+        check(lib.dfe_pose_vec2mat_fwd(ptr(vec), ptr(T), ptr(E), n, stream_ptr()), "dfe_pose_vec2mat_fwd")
+        ctx.save_for_backward(vec)
+        return T, E
+
+    @staticmethod
+    def backward(ctx, gT, gE):
+        lib = get_lib()
+        (vec,) = ctx.saved_tensors
+        gvec = torch.empty_like(vec)
+        gT = f32c(gT) if gT is not None else None
+        gE = f32c(gE) if gE is not None else None
+        check(lib.dfe_pose_vec2mat_bwd(ptr(vec), ptr(gT), ptr(gE), ptr(gvec), vec.shape[0], stream_ptr()),
+              "dfe_pose_vec2mat_bwd")
+        return gvec
+
+
+# --------------------------------------------------------------------------- inverse_warp2
+class InverseWarp2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, depth, ref_depth, pose, intrinsics, align_corners):
+        lib = get_lib()
+        img, depth, ref_depth = f32c(img), f32c(depth), f32c(ref_depth)
+        pose, intrinsics = f32c(pose), f32c(intrinsics)
+        B, _, H, W = img.shape
+        cams = prepare_cameras(pose, intrinsics, [1.0])
+        dev = img.device
+        o_img = torch.empty(B, 3, H, W, device=dev)
+        o_valid = torch.empty(B, 1, H, W, device=dev)
+        o_pd = torch.empty(B, 1, H, W, device=dev)
+        o_cd = torch.empty(B, 1, H, W, device=dev)
+        check(lib.dfe_inverse_warp2_fwd(ptr(img), ptr(depth), ptr(ref_depth), ptr(cams), ptr(o_img), ptr(o_valid),
+                                        ptr(o_pd), ptr(o_cd), B, H, W, align_corners, stream_ptr()),
+              "dfe_inverse_warp2_fwd")
+        ctx.save_for_backward(img, depth, ref_depth, cams)
+        ctx.ac = align_corners
+        ctx.mark_non_differentiable(o_valid)
+        return o_img, o_valid, o_pd, o_cd
+
+    @staticmethod
+    def backward(ctx, g_img, g_valid, g_pd, g_cd):
+        lib = get_lib()
+        img, depth, ref_depth, cams = ctx.saved_tensors
+        B, _, H, W = img.shape
+        dev = img.device
+        if ctx.needs_input_grad[0]:
+            raise _lib.DfeError("gradient wrt the source image of inverse_warp2 is not implemented "
+                                "(images are inputs on the reference's path)")
+        g_img = f32c(g_img) if g_img is not None else None
+        g_pd = f32c(g_pd) if g_pd is not None else None
+        g_cd = f32c(g_cd) if g_cd is not None else None
+        g_depth = torch.empty(B, 1, H, W, device=dev)
+        g_ref = torch.zeros(B, 1, H, W, device=dev) if (ctx.needs_input_grad[2] and g_pd is not None) else None
+        g_pose = torch.empty(B, 6, device=dev)
+        ws = torch.empty(lib.dfe_pose_partials_floats(B, H, W), device=dev)
+        check(lib.dfe_inverse_warp2_bwd(ptr(img), ptr(depth), ptr(ref_depth), ptr(cams), ptr(g_img), ptr(g_pd),
+                                        ptr(g_cd), ptr(g_depth), ptr(g_ref), ptr(g_pose), ptr(ws), B, H, W, ctx.ac,
+                                        stream_ptr()), "dfe_inverse_warp2_bwd")
+        return None, g_depth, g_ref, g_pose, None, None
+
+
+# --------------------------------------------------------------------------- rigid flow
+class RigidFlowFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, pose, intrinsics):
+        lib = get_lib()
+        depth, pose, intrinsics = f32c(depth), f32c(pose), f32c(intrinsics)
+        B, _, H, W = depth.shape
+        cams = prepare_cameras(pose, intrinsics, [1.0])
+        out = torch.empty(B, 2, H, W, device=depth.device)
+        check(lib.dfe_rigid_flow_fwd(ptr(depth), ptr(cams), ptr(out), B, H, W, stream_ptr()), "dfe_rigid_flow_fwd")
+        ctx.save_for_backward(depth, cams)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = get_lib()
+        depth, cams = ctx.saved_tensors
+        B, _, H, W = depth.shape
+        g_depth = torch.empty_like(depth)
+        g_pose = torch.empty(B, 6, device=depth.device)
+        ws = torch.empty(lib.dfe_pose_partials_floats(B, H, W), device=depth.device)
+        check(lib.dfe_rigid_flow_bwd(ptr(depth), ptr(cams), ptr(f32c(gout)), ptr(g_depth), ptr(g_pose), ptr(ws),
+                                     B, H, W, stream_ptr()), "dfe_rigid_flow_bwd")
+        return g_depth, g_pose, None
+
+
+# --------------------------------------------------------------------------- SSIM
+class SSIMFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        lib = get_lib()
+        x, y = f32c(x), f32c(y)
+        B, C, H, W = x.shape
+        out = torch.empty_like(x)
+        check(lib.dfe_ssim_fwd(ptr(x), ptr(y), ptr(out), B, C, H, W, stream_ptr()), "dfe_ssim_fwd")
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = get_lib()
+        x, y = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        if gx is None and gy is None:
+            return None, None
+        check(lib.dfe_ssim_bwd(ptr(x), ptr(y), ptr(f32c(gout)), ptr(gx), ptr(gy), B, C, H, W, stream_ptr()),
+              "dfe_ssim_bwd")
+        return gx, gy
+
+
+# --------------------------------------------------------------------------- correlation
+class CorrFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f1, f2, d):
+        lib = get_lib()
+        f1, f2 = f32c(f1), f32c(f2)
+        B, C, H, W = f1.shape
+        out = torch.empty(B, (2 * d + 1) ** 2, H, W, device=f1.device)
+        check(lib.dfe_corr_fwd(ptr(f1), ptr(f2), ptr(out), B, C, H, W, d, stream_ptr()), "dfe_corr_fwd")
+        ctx.save_for_backward(f1, f2)
+        ctx.d = d
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = get_lib()
+        f1, f2 = ctx.saved_tensors
+        B, C, H, W = f1.shape
+        g1 = torch.empty_like(f1) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty_like(f2) if ctx.needs_input_grad[1] else None
+        if g1 is None and g2 is None:
+            return None, None, None
+        check(lib.dfe_corr_bwd(ptr(f1), ptr(f2), ptr(f32c(gout)), ptr(g1), ptr(g2), B, C, H, W, ctx.d, stream_ptr()),
+              "dfe_corr_bwd")
+        return g1, g2, None
+
+
+def corr81(f1, f2, d=4):
+    assert f1.shape == f2.shape
+    if d != 4:
+        raise _lib.DfeError("corr_naive: only d=4 (81 taps) is implemented in HIP")
+    return CorrFn.apply(f1, f2, int(d))
+
+
+# --------------------------------------------------------------------------- resize (no grad)
+def resize(img, out_hw, mode):
+    """mode 'bilinear' (align_corners=False) or 'area'; images carry no gradient on this path."""
+    lib = get_lib()
+    img = f32c(img.detach())
+    B, C, H, W = img.shape
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    out = torch.empty(B, C, oh, ow, device=img.device)
+    check(lib.dfe_resize(ptr(img), ptr(out), B * C, H, W, oh, ow, {"bilinear": 0, "area": 1}[mode], stream_ptr()),
+          "dfe_resize")
+    return out

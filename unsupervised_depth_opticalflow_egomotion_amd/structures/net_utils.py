@@ -1,0 +1,23 @@
+"""Reference-signature shims for core/networks/structures/net_utils.py (warp_flow :16-54,
+conv :7-11, deconv :13-14).  warp_flow runs the HIP kernel k_warp_flow_fwd/bwd."""
+import torch.nn as nn
+
+from .. import ops
+
+
+def conv(in_planes, out_planes, kernel_size=3, stride=1, padding=1, dilation=1):
+    """Conv2d + LeakyReLU(0.1) block (the ``.0`` in the state-dict keys is the Conv2d)."""
+    return nn.Sequential(
+        nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride, padding=padding,
+                  dilation=dilation, bias=True),
+        nn.LeakyReLU(0.1))
+
+
+def deconv(in_planes, out_planes, kernel_size=4, stride=2, padding=1):
+    return nn.ConvTranspose2d(in_planes, out_planes, kernel_size, stride, padding, bias=True)
+
+
+def warp_flow(x, flow, use_mask=False, align_corners=None):
+    """Warp ``x`` [B,C,H,W] (im2) back to im1 along ``flow`` [B,2,H,W]; with ``use_mask`` every
+    sample whose in-bounds bilinear weight is < 0.9999 is zeroed.  Differentiable wrt flow and x."""
+    return ops.warp_flow(x, flow, use_mask=use_mask, align_corners=align_corners)
