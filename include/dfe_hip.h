@@ -93,6 +93,63 @@ int dfe_corr_bwd(const float* f1, const float* f2, const float* gout, float* g1,
  * mode 1 = F.interpolate(area) == adaptive_avg_pool2d (model_geometry.py:91, model_flow.py:58-64). */
 int dfe_resize(const float* in, float* out, int planes, int inH, int inW, int outH, int outW, int mode, void* stream);
 
+/* ---- fused loss stack: everything from model_geometry.py:797 to :951 given the nets' outputs ---
+ * One call computes the active loss_pack vectors of Model_geometry.forward (mode 0) for a batch:
+ * pyramids (:65-72,:91), rigid view synthesis (:80-103), texture / occlusion / validity / dynamic
+ * masks (:105-140,:685-713), flow warps (:74-78), masked L1 (:143-153), SSIM (:212-223),
+ * smoothness (:225-279), flow consistency (:195-210), depth-flow consistency (:716-732) and the
+ * epipolar distance (:355-418).  The backward call consumes d(total)/d(loss vectors) and writes
+ * gradients wrt disparities, flows and pose (recompute-in-backward; only the 1-byte mask pack and
+ * the masked warped images are kept in the workspace).
+ *
+ * loss rows of `losses` / `grad_losses` ([DFE_NUM_LOSSES][B], fp32): */
+#define DFE_LOSS_DEPTH_PIXEL 0
+#define DFE_LOSS_DEPTH_SMOOTH 1
+#define DFE_LOSS_FLOW_PIXEL 2
+#define DFE_LOSS_FLOW_SSIM 3
+#define DFE_LOSS_FLOW_SMOOTH 4
+#define DFE_LOSS_FLOW_CONSIS 5
+#define DFE_LOSS_DEPTH_FLOW_CONSIS 6
+#define DFE_LOSS_EPIPOLAR 7
+#define DFE_NUM_LOSSES 8
+
+/* mask pack: one byte per pixel of every scale, [scale][B][Hs*Ws] */
+#define DFE_MASK_VALID_BWD 0x01
+#define DFE_MASK_VALID_FWD 0x02
+#define DFE_MASK_OCC_BWD 0x04
+#define DFE_MASK_OCC_FWD 0x08
+#define DFE_MASK_DYNA_BWD 0x10
+#define DFE_MASK_DYNA_FWD 0x20
+#define DFE_MASK_TEX_BWD 0x40
+#define DFE_MASK_TEX_FWD 0x80
+
+typedef struct dfe_geom_args {
+  int B, H, W;               /* batch, full-resolution frame size */
+  int num_scales;            /* S <= DFE_MAX_SCALES; scale s is int(H/2^s) x int(W/2^s) */
+  int align_corners;
+  int mode;                  /* 0 = Model_geometry loss stack (the only mode implemented) */
+  float alpha, beta;         /* flow_consist_alpha / flow_consist_beta (model_geometry.py:25-26) */
+  const float* img[3];       /* left, target, right frames [B,3,H,W] */
+  const float* disp[3][DFE_MAX_SCALES]; /* depth_net outputs per frame (l,t,r) and scale [B,1,Hs,Ws] */
+  const float* flow[2][DFE_MAX_SCALES]; /* pwc flows, dir 0 = target->left (bwd), 1 = target->right (fwd), [B,2,Hs,Ws] */
+  const float* pose;         /* [B,2,6]; index 0 = bwd, 1 = fwd (model_geometry.py:789-790) */
+  const float* K;            /* [B,3,3] scale-0 intrinsics */
+  const float* K_inv;        /* [B,3,3] */
+  float* workspace;          /* dfe_geom_workspace_floats(args) floats, kept from forward to backward */
+  long workspace_floats;
+  float* losses;             /* forward out */
+  const float* grad_losses;  /* backward in */
+  float* grad_disp[3][DFE_MAX_SCALES]; /* backward out, same shapes as disp (NULL = skip) */
+  float* grad_flow[2][DFE_MAX_SCALES]; /* backward out, same shapes as flow (NULL = skip) */
+  float* grad_pose;          /* backward out [B,2,6] (NULL = skip) */
+} dfe_geom_args;
+
+long dfe_geom_workspace_floats(const dfe_geom_args* args);
+/* byte offset of the mask pack inside the workspace, and its size in bytes per scale start */
+long dfe_geom_maskpack_offset_bytes(const dfe_geom_args* args, int scale);
+int dfe_geom_loss_fwd(const dfe_geom_args* args, void* stream);
+int dfe_geom_loss_bwd(const dfe_geom_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,10 +43,12 @@ _SIGNATURES = {
     "dfe_corr_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_resize": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dfe_geom_workspace_floats": [_P],
+    "dfe_geom_maskpack_offset_bytes": [_P, _I],
     "dfe_geom_loss_fwd": [_P, _P],
     "dfe_geom_loss_bwd": [_P, _P],
 }
-_RESTYPES = {"dfe_error_string": ctypes.c_char_p}
+_RESTYPES = {"dfe_error_string": ctypes.c_char_p, "dfe_geom_workspace_floats": ctypes.c_long,
+             "dfe_geom_maskpack_offset_bytes": ctypes.c_long}
 
 
 class DfeError(RuntimeError):

@@ -1,0 +1,66 @@
+// Workspace layout and device-side tables of the fused loss stack (dfe_geom_loss_fwd/bwd).
+#pragma once
+#include "dfe_device.h"
+#include "dfe_internal.h"
+
+namespace dfe {
+
+constexpr int GS_BLOCK = 256;   // threads per block of the pointwise kernels (1 pixel / thread)
+constexpr int GS_TX = 32, GS_TY = 8;  // SSIM tile
+
+// ---- per-block partial sums of k_geom_point_fwd (per direction d: index d*PT_PER_DIR + i)
+enum { PT_M_TEX = 0, PT_L1_DEPTH, PT_M_RIG, PT_L1_RIG, PT_M_DYN, PT_L1_DYN, PT_M_VO, PT_FDIFF, PT_EPI, PT_PER_DIR };
+constexpr int PT_INV = 2 * PT_PER_DIR, PT_CONSIS = PT_INV + 1, PT_COUNT = PT_CONSIS + 1;   // 20
+
+// ---- reduced sums per (b, scale): [0,PT_COUNT) pointwise, then ssim[2], flow-smooth x/y per dir
+constexpr int SUM_SSIM = PT_COUNT, SUM_FS = SUM_SSIM + 2, SUM_COUNT = SUM_FS + 4;            // 26
+
+// ---- normalisers saved for the backward per (b, scale): per direction then shared
+enum { CF_DEPTH = 0, CF_RIG, CF_DYN, CF_VO, CF_FD, CF_PER_DIR };
+constexpr int CF_CONSIS = 2 * CF_PER_DIR, CF_COUNT = CF_CONSIS + 1;                          // 11
+
+// ---- per-block partial sums of k_geom_point_bwd: per direction 12 camera sums + 9 dF sums
+constexpr int PB_PER_DIR = 21, PB_COUNT = 2 * PB_PER_DIR;
+
+struct Epi { float F[9]; float Kinv[9]; float S[9]; };   // fundamental matrix and the factors its backward needs
+
+struct GeomLayout {
+  int B, S;
+  int H[DFE_MAX_SCALES], W[DFE_MAX_SCALES], N[DFE_MAX_SCALES];
+  long off_px[DFE_MAX_SCALES + 1];   // prefix of N (per single image plane)
+  int nblk[DFE_MAX_SCALES], blk_start[DFE_MAX_SCALES + 1];      // pointwise blocks per image
+  int ntile[DFE_MAX_SCALES], tile_start[DFE_MAX_SCALES + 1], tiles_x[DFE_MAX_SCALES];
+  int nblk0;                          // full-resolution blocks (disp smoothness)
+  // workspace offsets in floats
+  long o_cams, o_epi, o_pyr, o_area, o_mask, o_yw, o_part, o_spart, o_fpart, o_dpart, o_sums, o_coef, o_dsum,
+      o_gw, o_gup, o_bpart, total;
+  long pyr_plane;   // floats of one frame's bilinear pyramid levels >= 1 (B*3*sum_{s>=1} N_s)
+};
+
+// Kernel-argument tables (passed by value).
+struct GeomDev {
+  int B, S, ac;
+  float alpha, beta;
+  int H[DFE_MAX_SCALES], W[DFE_MAX_SCALES], N[DFE_MAX_SCALES];
+  int blk_start[DFE_MAX_SCALES + 1], tile_start[DFE_MAX_SCALES + 1], tiles_x[DFE_MAX_SCALES];
+  const float* pyr[3][DFE_MAX_SCALES];    // bilinear pyramid per frame (level 0 = the frame itself)
+  const float* area[2][DFE_MAX_SCALES];   // area pyramid of the left / right frame
+  const float* disp[3][DFE_MAX_SCALES];
+  const float* flow[2][DFE_MAX_SCALES];
+  const Camera* cams;                      // [(b*2+d)*S + s]
+  const Epi* epi;                          // [b*2+d]
+  unsigned char* mask[DFE_MAX_SCALES];     // [B][N_s]
+  float* yw[DFE_MAX_SCALES];               // [2][B][3][N_s] masked warped images
+};
+
+int geom_layout(const dfe_geom_args* a, GeomLayout* L);
+void geom_dev(const dfe_geom_args* a, const GeomLayout& L, GeomDev* D);
+
+__device__ __forceinline__ int find_scale(const int* starts, int S, int idx) {
+  int s = 0;
+#pragma unroll
+  for (int k = 1; k < DFE_MAX_SCALES; ++k) s += (k < S && idx >= starts[k]) ? 1 : 0;
+  return s;
+}
+
+}  // namespace dfe

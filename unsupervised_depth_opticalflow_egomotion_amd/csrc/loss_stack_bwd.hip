@@ -1,0 +1,442 @@
+// Fused loss stack, backward: dfe_geom_loss_bwd (include/dfe_hip.h).
+//
+// Recompute-in-backward: only the 1-byte mask pack, the masked warped images and the
+// per-(sample,scale) normalisers survive from the forward.  Launches:
+//   k_geom_ssim_bwd         dL/d(warped) of the SSIM term from an LDS tile with a 2-px halo
+//   k_geom_point_bwd        per pixel, both directions: bilinear-warp and projection chain rule,
+//                           writes grad_flow / grad_disp(target), block sums for the pose
+//   k_geom_flow_smooth_bwd  adds the 2nd-order smoothness gradient into grad_flow
+//   k_geom_disp_smooth_bwd1 dL/d(up-sampled disp) per full-res pixel (writes scale 0 directly)
+//   k_geom_disp_smooth_bwd2 adjoint of the bilinear up-sampling as a gather per low-res pixel
+//   k_geom_pose_finalize    fixed-order reduction + closed-form 3x3 chains -> grad_pose
+// No float atomics anywhere: gradients are bitwise reproducible run to run.
+#include "loss_stack.h"
+
+namespace dfe {
+
+struct GeomBwd {
+  const float* gl;      // [DFE_NUM_LOSSES][B]
+  const float* coef;    // [B][S][CF_COUNT]
+  float* gw[DFE_MAX_SCALES];     // [2][B][3][N_s]
+  float* gup;           // [3][S-1][B][N_0]
+  float* gdisp[3][DFE_MAX_SCALES];
+  float* gflow[2][DFE_MAX_SCALES];
+  float* bpart;         // [B][nblk_total][PB_COUNT]
+};
+
+__device__ __forceinline__ float sgn(float v) { return static_cast<float>(v > 0.0f) - static_cast<float>(v < 0.0f); }
+
+// ---------------------------------------------------------------------- SSIM backward
+__global__ void __launch_bounds__(GS_TX * GS_TY) k_geom_ssim_bwd(GeomDev D, GeomBwd G) {
+  __shared__ float sx[3][GS_TY + 4][GS_TX + 4], sy[3][GS_TY + 4][GS_TX + 4];
+  __shared__ float co[9][GS_TY + 2][GS_TX + 2];
+  const unsigned ntile_total = D.tile_start[D.S];
+  const unsigned tile = xcd_swizzle(blockIdx.x, ntile_total);
+  const int b = blockIdx.y >> 1, d = blockIdx.y & 1;
+  const int s = find_scale(D.tile_start, D.S, tile);
+  const int H = D.H[s], W = D.W[s], N = D.N[s];
+  const int tl = tile - D.tile_start[s];
+  const int x0 = (tl % D.tiles_x[s]) * GS_TX, y0 = (tl / D.tiles_x[s]) * GS_TY;
+  const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
+  const float* yw = D.yw[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
+  const unsigned char* mk = D.mask[s] + static_cast<long>(b) * N;
+  const unsigned need = (DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD) << d;
+  const float gscale = -0.5f * G.gl[DFE_LOSS_FLOW_SSIM * D.B + b] *
+                       G.coef[(static_cast<long>(b) * D.S + s) * CF_COUNT + d * CF_PER_DIR + CF_VO];
+  for (int i = threadIdx.x; i < (GS_TY + 4) * (GS_TX + 4); i += blockDim.x) {
+    const int ly = i / (GS_TX + 4), lx = i - ly * (GS_TX + 4);
+    const int gy = y0 + ly - 2, gx = x0 + lx - 2;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const long q = static_cast<long>(gy) * W + gx;
+    const float vo = (in && (mk[q] & need) == need) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      sx[c][ly][lx] = in ? it[q + static_cast<long>(c) * N] * vo : 0.0f;
+      sy[c][ly][lx] = in ? yw[q + static_cast<long>(c) * N] : 0.0f;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (GS_TY + 2) * (GS_TX + 2); i += blockDim.x) {
+    const int ly = i / (GS_TX + 2), lx = i - ly * (GS_TX + 2);
+    const int gy = y0 + ly - 1, gx = x0 + lx - 1;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float c_my = 0.0f, c_eyy = 0.0f, c_exy = 0.0f;
+      if (in) {
+        float a = 0, bq = 0, aa = 0, bb = 0, ab = 0;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const float u = sx[c][ly + dy][lx + dx], w = sy[c][ly + dy][lx + dx];
+            a += u; bq += w; aa += u * u; bb += w * w; ab += u * w;
+          }
+        const float mx = a / 9.0f, my = bq / 9.0f, exx = aa / 9.0f, eyy = bb / 9.0f, exy = ab / 9.0f;
+        const float v = (1.0f - ssim_from_means(mx, my, exx, eyy, exy)) / 2.0f;
+        if (v >= 0.0f && v <= 1.0f) {   // clamp(.,0,1) passes gradient on the closed interval
+          float d_mx, d_my, d_exx, d_eyy, d_exy;
+          ssim_partials(mx, my, exx, eyy, exy, d_mx, d_my, d_exx, d_eyy, d_exy);
+          c_my = d_my * gscale; c_eyy = d_eyy * gscale; c_exy = d_exy * gscale;
+        }
+      }
+      co[c * 3 + 0][ly][lx] = c_my; co[c * 3 + 1][ly][lx] = c_eyy; co[c * 3 + 2][ly][lx] = c_exy;
+    }
+  }
+  __syncthreads();
+  const int tx = threadIdx.x % GS_TX, ty = threadIdx.x / GS_TX;
+  const int gx = x0 + tx, gy = y0 + ty;
+  if (gx >= W || gy >= H) return;
+  const long q = static_cast<long>(gy) * W + gx;
+  const float vo = ((mk[q] & need) == need) ? 1.0f : 0.0f;
+  float* gw = G.gw[s] + (static_cast<long>(d) * D.B + b) * 3 * N + q;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        s0 += co[c * 3 + 0][ty + dy][tx + dx]; s1 += co[c * 3 + 1][ty + dy][tx + dx]; s2 += co[c * 3 + 2][ty + dy][tx + dx];
+      }
+    const float xv = sx[c][ty + 2][tx + 2], yv = sy[c][ty + 2][tx + 2];
+    gw[static_cast<long>(c) * N] = ((s0 + 2.0f * yv * s1 + xv * s2) / 9.0f) * vo;
+  }
+}
+
+// ---------------------------------------------------------------------- pointwise backward
+__global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomBwd G) {
+  __shared__ float red[PB_COUNT * (GS_BLOCK / 64)];
+  const unsigned nblk_total = D.blk_start[D.S];
+  const unsigned blk = xcd_swizzle(blockIdx.x, nblk_total);
+  const int b = blockIdx.y, B = D.B;
+  const int s = find_scale(D.blk_start, D.S, blk);
+  const int H = D.H[s], W = D.W[s], N = D.N[s];
+  const int p = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
+  float acc[PB_COUNT];
+#pragma unroll
+  for (int i = 0; i < PB_COUNT; ++i) acc[i] = 0.0f;
+  if (p < N) {
+    const int py = p / W, px = p - py * W;
+    const long o3 = static_cast<long>(b) * 3 * N + p, o2 = static_cast<long>(b) * 2 * N + p, o1 = static_cast<long>(b) * N + p;
+    const float* it = D.pyr[1][s];
+    const float im[3] = {it[o3], it[o3 + N], it[o3 + 2 * N]};
+    const unsigned bits = D.mask[s][o1];
+    const float dsp = D.disp[1][s][o1];
+    const float* cf = G.coef + (static_cast<long>(b) * D.S + s) * CF_COUNT;
+    const float g_dp = G.gl[DFE_LOSS_DEPTH_PIXEL * B + b], g_fp = G.gl[DFE_LOSS_FLOW_PIXEL * B + b];
+    const float g_fc = G.gl[DFE_LOSS_FLOW_CONSIS * B + b], g_dfc = G.gl[DFE_LOSS_DEPTH_FLOW_CONSIS * B + b];
+    const float g_epi = G.gl[DFE_LOSS_EPIPOLAR * B + b];
+    float fu[2], fv[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) { fu[d] = D.flow[d][s][o2]; fv[d] = D.flow[d][s][o2 + N]; }
+    float gdisp = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const bool valid = bits & (DFE_MASK_VALID_BWD << d), occ = bits & (DFE_MASK_OCC_BWD << d);
+      const bool dyna = bits & (DFE_MASK_DYNA_BWD << d), tex = bits & (DFE_MASK_TEX_BWD << d);
+      const float vo = (valid && occ) ? 1.0f : 0.0f;
+      const float m_rig = dyna ? vo : 0.0f, m_dyn = dyna ? 0.0f : vo, m_tex = tex ? m_rig : 0.0f;
+      float gfu = 0.0f, gfv = 0.0f;
+      // ---- flow warp: L1 (rigid + 2x dynamic masks) and SSIM gradients wrt the warped image
+      {
+        float ix, iy;
+        flow_coords(px, py, fu[d], fv[d], H, W, D.ac, ix, iy);
+        Tap t = make_tap(ix, iy, H, W);
+        const float keep = (tap_cover(t) < 0.9999f) ? 0.0f : 1.0f;
+        if (keep != 0.0f) {
+          const float* src = D.pyr[d == 0 ? 0 : 2][s] + static_cast<long>(b) * 3 * N;
+          const float* gw = G.gw[s] + (static_cast<long>(d) * B + b) * 3 * N + p;
+          const float l1c = g_fp * (m_rig * cf[d * CF_PER_DIR + CF_RIG] + m_dyn * cf[d * CF_PER_DIR + CF_DYN]);
+          float gix = 0.0f, giy = 0.0f;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            Corners q = load_corners(src + static_cast<long>(c) * N, t, W);
+            const float wv = interp(q, t);
+            float dx, dy;
+            interp_grad(q, t, dx, dy);
+            const float g = gw[static_cast<long>(c) * N] + sgn(wv - im[c]) * l1c;
+            gix += g * dx; giy += g * dy;
+          }
+          gfu = gix * flow_coord_scale(W, D.ac);
+          gfv = giy * flow_coord_scale(H, D.ac);
+        }
+      }
+      // ---- rigid branch
+      const Camera& cam = D.cams[(b * 2 + d) * D.S + s];
+      Proj pr = project(cam, px, py, dsp);
+      float gU = 0.0f, gV = 0.0f;
+      if (m_tex != 0.0f) {
+        float xn, yn; bool lx, ly;
+        rigid_grid(pr, H, W, xn, yn, lx, ly);
+        Tap t = make_tap(unnormalize(xn, W, D.ac), unnormalize(yn, H, D.ac), H, W);
+        const float* ar = D.area[d][s] + static_cast<long>(b) * 3 * N;
+        const float gc = g_dp * cf[d * CF_PER_DIR + CF_DEPTH];
+        float gix = 0.0f, giy = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          Corners q = load_corners(ar + static_cast<long>(c) * N, t, W);
+          float dx, dy;
+          interp_grad(q, t, dx, dy);
+          const float g = sgn(interp(q, t) - im[c]) * gc;
+          gix += g * dx; giy += g * dy;
+        }
+        const float sx = D.ac ? static_cast<float>(W - 1) / 2.0f : static_cast<float>(W) / 2.0f;
+        const float sy = D.ac ? static_cast<float>(H - 1) / 2.0f : static_cast<float>(H) / 2.0f;
+        if (lx) gU = gix * sx * (2.0f / static_cast<float>(W - 1));
+        if (ly) gV = giy * sy * (2.0f / static_cast<float>(H - 1));
+      }
+      if (s == 0) {
+        // depth-flow consistency |rigid - flow| on valid*occ*dyna (model_geometry.py:716-732, scale 0 only)
+        const float ru = pr.U - static_cast<float>(px), rv = pr.V - static_cast<float>(py);
+        const float g = g_dfc * cf[d * CF_PER_DIR + CF_FD] * m_rig;
+        const float su = sgn(ru - fu[d]) * g, sv = sgn(rv - fv[d]) * g;
+        gU += su; gV += sv; gfu -= su; gfv -= sv;
+        // epipolar distance (plain mean; model_geometry.py:413-418)
+        const Epi& e = D.epi[b * 2 + d];
+        const float x1 = static_cast<float>(px), y1 = static_cast<float>(py);
+        const float l0 = e.F[0] * x1 + e.F[1] * y1 + e.F[2];
+        const float l1 = e.F[3] * x1 + e.F[4] * y1 + e.F[5];
+        const float l2 = e.F[6] * x1 + e.F[7] * y1 + e.F[8];
+        const float r = sqrtf(l0 * l0 + l1 * l1), div = r + 1e-6f;
+        const float x2 = x1 + fu[d], y2 = y1 + fv[d];
+        const float n = (x2 * l0 + y2 * l1) + l2;
+        const float ge = g_epi / static_cast<float>(N), sg = sgn(n);
+        gfu += ge * sg * l0 / div; gfv += ge * sg * l1 / div;
+        const float tail = (r > 0.0f) ? fabsf(n) / (div * div * r) : 0.0f;
+        const float dl0 = ge * (sg * x2 / div - tail * l0), dl1 = ge * (sg * y2 / div - tail * l1), dl2 = ge * sg / div;
+        float* aF = acc + d * PB_PER_DIR + 12;
+        aF[0] = dl0 * x1; aF[1] = dl0 * y1; aF[2] = dl0;
+        aF[3] = dl1 * x1; aF[4] = dl1 * y1; aF[5] = dl1;
+        aF[6] = dl2 * x1; aF[7] = dl2 * y1; aF[8] = dl2;
+      }
+      float gd;
+      project_backward(pr, dsp, gU, gV, 0.0f, gd, acc + d * PB_PER_DIR);
+      gdisp += gd;
+      if (d == 1) {
+        // flow consistency: only the forward flow carries gradient (bwd is detached)
+        const float inv = occ ? 0.0f : 1.0f;
+        const float k = inv * cf[CF_CONSIS] * g_fc;
+        if (k != 0.0f) {
+          const float rf = sqrtf(fu[1] * fu[1] + fv[1] * fv[1]), nf = rf + 1e-12f;
+          const float nb = l2norm2(fu[0], fv[0]);
+          const float uu = fu[1] / nf, uv = fv[1] / nf;
+          const float au = sgn(uu + fu[0] / nb) * k, av = sgn(uv + fv[0] / nb) * k;
+          const float ir = (rf > 0.0f) ? 1.0f / (rf * nf * nf) : 0.0f;
+          gfu += au * (1.0f / nf - fu[1] * fu[1] * ir) + av * (-fv[1] * fu[1] * ir);
+          gfv += au * (-fu[1] * fv[1] * ir) + av * (1.0f / nf - fv[1] * fv[1] * ir);
+        }
+      }
+      if (G.gflow[d][s]) { G.gflow[d][s][o2] = gfu; G.gflow[d][s][o2 + N] = gfv; }
+    }
+    if (G.gdisp[1][s]) G.gdisp[1][s][o1] = gdisp;
+  }
+  block_sum<PB_COUNT>(acc, red, G.bpart + (static_cast<long>(b) * nblk_total + blk) * PB_COUNT);
+}
+
+// ---------------------------------------------------------------------- flow smoothness backward
+// grid.y = d*B + b ; adds into grad_flow (after k_geom_point_bwd wrote it).
+__global__ void __launch_bounds__(GS_BLOCK) k_geom_flow_smooth_bwd(GeomDev D, GeomBwd G) {
+  const unsigned blk = blockIdx.x;
+  const int d = blockIdx.y / D.B, b = blockIdx.y - d * D.B;
+  const int s = find_scale(D.blk_start, D.S, blk);
+  const int H = D.H[s], W = D.W[s], N = D.N[s];
+  const int p = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
+  if (p >= N || !G.gflow[d][s]) return;
+  const int py = p / W, px = p - py * W;
+  const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
+  const float* fl = D.flow[d][s] + static_cast<long>(b) * 2 * N;
+  const float g = G.gl[DFE_LOSS_FLOW_SMOOTH * D.B + b];
+  const float cx = g / (2.0f * H * (W - 2.0f)) / 2.0f / 20.0f, cy = g / (2.0f * (H - 2.0f) * W) / 2.0f / 20.0f;
+  float out[2] = {0.0f, 0.0f};
+  const float kc[3] = {1.0f, -2.0f, 1.0f};   // coefficient of f(q) in the stencil starting at q, q-1, q-2
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int i = px - k;            // stencil start along x
+    if (i >= 0 && i + 2 < W) {
+      const int q = p - k;
+      const float w = expf(-10.0f * mean3_abs_diff(it[q + 2], it[q + 2 + N], it[q + 2 + 2 * N], it[q + 1], it[q + 1 + N], it[q + 1 + 2 * N]));
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float a0 = fl[c * N + q] / 20.0f, a1 = fl[c * N + q + 1] / 20.0f, a2 = fl[c * N + q + 2] / 20.0f;
+        out[c] += cx * kc[k] * w * sgn((a2 - a1) - (a1 - a0));
+      }
+    }
+    const int j = py - k;            // stencil start along y
+    if (j >= 0 && j + 2 < H) {
+      const int q = p - k * W, q1 = q + W, q2 = q + 2 * W;
+      const float w = expf(-10.0f * mean3_abs_diff(it[q2], it[q2 + N], it[q2 + 2 * N], it[q1], it[q1 + N], it[q1 + 2 * N]));
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float a0 = fl[c * N + q] / 20.0f, a1 = fl[c * N + q1] / 20.0f, a2 = fl[c * N + q2] / 20.0f;
+        out[c] += cy * kc[k] * w * sgn((a2 - a1) - (a1 - a0));
+      }
+    }
+  }
+  float* gf = G.gflow[d][s] + static_cast<long>(b) * 2 * N;
+  gf[p] += out[0];
+  gf[N + p] += out[1];
+}
+
+// ---------------------------------------------------------------------- disparity smoothness backward
+__device__ __forceinline__ float up_at(const float* __restrict__ dp, int s, int Hs, int Ws, int H, int W, int y, int x) {
+  if (s == 0) return dp[static_cast<long>(y) * W + x];
+  return resize_bilinear_at(dp, Hs, Ws, y, x, static_cast<float>(Hs) / H, static_cast<float>(Ws) / W);
+}
+
+// stage 1: per full-resolution pixel, dL/d(up_s(p)) for every scale.  grid.y = f*B + b.
+__global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_bwd1(GeomDev D, GeomBwd G) {
+  const int f = blockIdx.y / D.B, b = blockIdx.y - f * D.B;
+  const int H = D.H[0], W = D.W[0], N = D.N[0];
+  const int p = blockIdx.x * GS_BLOCK + threadIdx.x;
+  if (p >= N) return;
+  const int py = p / W, px = p - py * W;
+  const float* im = D.pyr[f][0] + static_cast<long>(b) * 3 * N;
+  const float g = G.gl[DFE_LOSS_DEPTH_SMOOTH * D.B + b];
+  const float cx = g / (static_cast<float>(H) * (W - 1.0f)), cy = g / ((H - 1.0f) * static_cast<float>(W));
+  const bool hxp = px + 1 < W, hxm = px > 0, hyp = py + 1 < H, hym = py > 0;
+  const float c0 = im[p], c1 = im[p + N], c2 = im[p + 2 * N];
+  float wxp = 0, wxm = 0, wyp = 0, wym = 0;
+  if (hxp) wxp = expf(-mean3_abs_diff(c0, c1, c2, im[p + 1], im[p + 1 + N], im[p + 1 + 2 * N]));
+  if (hxm) wxm = expf(-mean3_abs_diff(im[p - 1], im[p - 1 + N], im[p - 1 + 2 * N], c0, c1, c2));
+  if (hyp) wyp = expf(-mean3_abs_diff(c0, c1, c2, im[p + W], im[p + W + N], im[p + W + 2 * N]));
+  if (hym) wym = expf(-mean3_abs_diff(im[p - W], im[p - W + N], im[p - W + 2 * N], c0, c1, c2));
+  for (int s = 0; s < D.S; ++s) {
+    const float* dp = D.disp[f][s] + static_cast<long>(b) * D.N[s];
+    const int Hs = D.H[s], Ws = D.W[s];
+    const float u0 = up_at(dp, s, Hs, Ws, H, W, py, px);
+    float gsum = 0.0f;
+    if (hxp) gsum += cx * sgn(u0 - up_at(dp, s, Hs, Ws, H, W, py, px + 1)) * wxp;
+    if (hxm) gsum -= cx * sgn(up_at(dp, s, Hs, Ws, H, W, py, px - 1) - u0) * wxm;
+    if (hyp) gsum += cy * sgn(u0 - up_at(dp, s, Hs, Ws, H, W, py + 1, px)) * wyp;
+    if (hym) gsum -= cy * sgn(up_at(dp, s, Hs, Ws, H, W, py - 1, px) - u0) * wym;
+    if (s == 0) {
+      float* o = G.gdisp[f][0];
+      if (o) { if (f == 1) o[static_cast<long>(b) * N + p] += gsum; else o[static_cast<long>(b) * N + p] = gsum; }
+    } else {
+      G.gup[((static_cast<long>(f) * (D.S - 1) + (s - 1)) * D.B + b) * N + p] = gsum;
+    }
+  }
+}
+
+// stage 2: adjoint of the bilinear up-sampling, one thread per low-res pixel of scales >= 1.
+// grid.x covers blocks [blk_start[1], blk_start[S]); grid.y = f*B + b.
+__global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_bwd2(GeomDev D, GeomBwd G) {
+  const unsigned blk = blockIdx.x + D.blk_start[1];
+  const int f = blockIdx.y / D.B, b = blockIdx.y - f * D.B;
+  const int s = find_scale(D.blk_start, D.S, blk);
+  const int Hs = D.H[s], Ws = D.W[s], Ns = D.N[s];
+  const int q = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
+  if (q >= Ns || !G.gdisp[f][s]) return;
+  const int H = D.H[0], W = D.W[0], N = D.N[0];
+  const int i = q / Ws, j = q - i * Ws;
+  const float rh = static_cast<float>(Hs) / H, rw = static_cast<float>(Ws) / W;
+  const float* gu = G.gup + ((static_cast<long>(f) * (D.S - 1) + (s - 1)) * D.B + b) * N;
+  int ylo = static_cast<int>(floorf((i - 0.5f) / rh - 0.5f)) - 1, yhi = static_cast<int>(ceilf((i + 1.5f) / rh - 0.5f)) + 1;
+  int xlo = static_cast<int>(floorf((j - 0.5f) / rw - 0.5f)) - 1, xhi = static_cast<int>(ceilf((j + 1.5f) / rw - 0.5f)) + 1;
+  ylo = max(ylo, 0); xlo = max(xlo, 0); yhi = min(yhi, H - 1); xhi = min(xhi, W - 1);
+  float total = 0.0f;
+  for (int y = ylo; y <= yhi; ++y) {
+    int y0, y1; float l0, l1;
+    bilinear_src(y, rh, Hs, y0, y1, l0, l1);
+    const float wy = (y0 == i ? l0 : 0.0f) + (y1 == i ? l1 : 0.0f);
+    if (wy == 0.0f) continue;
+    float row = 0.0f;
+    for (int x = xlo; x <= xhi; ++x) {
+      int x0, x1; float m0, m1;
+      bilinear_src(x, rw, Ws, x0, x1, m0, m1);
+      const float wx = (x0 == j ? m0 : 0.0f) + (x1 == j ? m1 : 0.0f);
+      if (wx != 0.0f) row += wx * gu[static_cast<long>(y) * W + x];
+    }
+    total += wy * row;
+  }
+  float* o = G.gdisp[f][s] + static_cast<long>(b) * Ns + q;
+  if (f == 1) *o += total; else *o = total;
+}
+
+// ---------------------------------------------------------------------- pose finalize
+// One block per (b, d).  Thread t < S*12 reduces camera sum (s, i); threads S*12..S*12+8 reduce dF.
+__global__ void k_geom_pose_finalize(GeomDev D, GeomBwd G, float* __restrict__ gpose) {
+  __shared__ double sm[DFE_MAX_SCALES * 12 + 9];
+  const int cam = blockIdx.x, b = cam >> 1, d = cam & 1, S = D.S;
+  const unsigned nblk_total = D.blk_start[S];
+  const int ncol = S * 12 + 9;
+  for (int t = threadIdx.x; t < ncol; t += blockDim.x) {
+    int s, col;
+    if (t < S * 12) { s = t / 12; col = d * PB_PER_DIR + (t - s * 12); } else { s = 0; col = d * PB_PER_DIR + 12 + (t - S * 12); }
+    double a = 0.0;
+    for (int k = D.blk_start[s]; k < D.blk_start[s + 1]; ++k) a += G.bpart[(static_cast<long>(b) * nblk_total + k) * PB_COUNT + col];
+    sm[t] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double g[6] = {0, 0, 0, 0, 0, 0}, gR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int s = 0; s < S; ++s) {
+    const double* acc = sm + s * 12;
+    const Camera& c = D.cams[cam * S + s];
+    for (int j = 0; j < 3; ++j) g[j] += c.K[j] * acc[0] + c.K[3 + j] * acc[1] + c.K[6 + j] * acc[2];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) gR[i * 3 + j] += c.K[i] * acc[3 + j] + c.K[3 + i] * acc[6 + j] + c.K[6 + i] * acc[9 + j];
+  }
+  // epipolar: F = Ki^T E Ki, E = S R
+  const Epi& e = D.epi[cam];
+  const Camera& c0 = D.cams[cam * S];
+  const double* gF = sm + S * 12;
+  double T[9], gE[9];
+  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) T[r * 3 + q] = e.Kinv[r * 3] * gF[q] + e.Kinv[r * 3 + 1] * gF[3 + q] + e.Kinv[r * 3 + 2] * gF[6 + q];
+  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) gE[r * 3 + q] = T[r * 3] * e.Kinv[q * 3] + T[r * 3 + 1] * e.Kinv[q * 3 + 1] + T[r * 3 + 2] * e.Kinv[q * 3 + 2];
+  double gS[9];
+  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) {
+    double a = 0, bq = 0;
+    for (int k = 0; k < 3; ++k) { a += e.S[k * 3 + r] * gE[k * 3 + q]; bq += gE[r * 3 + k] * c0.R[q * 3 + k]; }
+    gR[r * 3 + q] += a; gS[r * 3 + q] = bq;
+  }
+  g[0] += gS[7] - gS[5]; g[1] += gS[2] - gS[6]; g[2] += gS[3] - gS[1];
+  for (int k = 0; k < 3; ++k) { double t = 0; for (int i = 0; i < 9; ++i) t += gR[i] * c0.dR[k * 9 + i]; g[3 + k] += t; }
+  for (int i = 0; i < 6; ++i) gpose[cam * 6 + i] = static_cast<float>(g[i]);
+}
+
+}  // namespace dfe
+
+using namespace dfe;
+
+#define DFE_LAUNCH_CHECK() do { if (hipGetLastError() != hipSuccess) return DFE_ERR_LAUNCH; } while (0)
+
+extern "C" int dfe_geom_loss_bwd(const dfe_geom_args* a, void* stream) {
+  GeomLayout L;
+  int rc = geom_layout(a, &L);
+  if (rc != DFE_OK) return rc;
+  if (!a->workspace || !a->grad_losses || !a->pose) return DFE_ERR_NULL;
+  if (a->workspace_floats < L.total) return DFE_ERR_WORKSPACE;
+  for (int f = 0; f < 3; ++f) { if (!a->img[f]) return DFE_ERR_NULL; for (int s = 0; s < L.S; ++s) if (!a->disp[f][s]) return DFE_ERR_NULL; }
+  for (int d = 0; d < 2; ++d) for (int s = 0; s < L.S; ++s) if (!a->flow[d][s]) return DFE_ERR_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* ws = a->workspace;
+  GeomDev D;
+  geom_dev(a, L, &D);
+  GeomBwd G;
+  G.gl = a->grad_losses; G.coef = ws + L.o_coef; G.gup = ws + L.o_gup; G.bpart = ws + L.o_bpart;
+  for (int s = 0; s < DFE_MAX_SCALES; ++s) {
+    G.gw[s] = (s < L.S) ? ws + L.o_gw + 6L * L.B * L.off_px[s] : nullptr;
+    for (int f = 0; f < 3; ++f) G.gdisp[f][s] = (s < L.S) ? a->grad_disp[f][s] : nullptr;
+    for (int d = 0; d < 2; ++d) G.gflow[d][s] = (s < L.S) ? a->grad_flow[d][s] : nullptr;
+  }
+  const unsigned nblk_total = L.blk_start[L.S], ntile_total = L.tile_start[L.S];
+  k_geom_ssim_bwd<<<dim3(ntile_total, L.B * 2), GS_TX * GS_TY, 0, st>>>(D, G);
+  DFE_LAUNCH_CHECK();
+  k_geom_point_bwd<<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, G);
+  DFE_LAUNCH_CHECK();
+  k_geom_flow_smooth_bwd<<<dim3(nblk_total, 2 * L.B), GS_BLOCK, 0, st>>>(D, G);
+  DFE_LAUNCH_CHECK();
+  k_geom_disp_smooth_bwd1<<<dim3(L.nblk0, 3 * L.B), GS_BLOCK, 0, st>>>(D, G);
+  DFE_LAUNCH_CHECK();
+  if (L.S > 1) {
+    k_geom_disp_smooth_bwd2<<<dim3(nblk_total - L.blk_start[1], 3 * L.B), GS_BLOCK, 0, st>>>(D, G);
+    DFE_LAUNCH_CHECK();
+  }
+  if (a->grad_pose) {
+    k_geom_pose_finalize<<<L.B * 2, 64, 0, st>>>(D, G, a->grad_pose);
+    DFE_LAUNCH_CHECK();
+  }
+  return DFE_OK;
+}

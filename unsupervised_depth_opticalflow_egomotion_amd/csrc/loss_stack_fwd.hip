@@ -1,0 +1,502 @@
+// Fused loss stack, forward: dfe_geom_loss_fwd (include/dfe_hip.h).
+//
+// Five launches replace the ~3 270 ATen dispatches of model_geometry.py:797-951:
+//   k_geom_pyramids        bilinear pyramids of the 3 frames + area pyramids of the 2 sources
+//   k_geom_point_fwd       per pixel, both directions: flow warp, validity, occlusion softmax,
+//                          rigid projection, recon, texture/dynamic masks, masked-L1 sums,
+//                          |rigid-flow| and epipolar sums, flow consistency; writes the 1-byte
+//                          mask pack and the masked warped images (stage W of SURVEY.md 8(d))
+//   k_geom_ssim_fwd        3x3 SSIM of (I*m, warped*m) from an LDS tile with halo (stage P)
+//   k_geom_smooth_fwd      disparity (1st order, full-res) and flow (2nd order) smoothness
+//   k_geom_finalize_fwd    fixed-order reduction of block partials -> loss vectors + normalisers
+// All (sample, scale) images are batched into each launch: scale 2 alone (13 k px) cannot fill
+// 256 CUs.  Partials are reduced in a fixed order (no float atomics): bitwise reproducible.
+#include "loss_stack.h"
+
+namespace dfe {
+
+static inline long align4(long v) { return (v + 3) & ~3L; }
+
+int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
+  if (!a) return DFE_ERR_NULL;
+  if (a->B <= 0 || a->H < 8 || a->W < 8 || a->num_scales <= 0 || a->num_scales > DFE_MAX_SCALES) return DFE_ERR_DIMS;
+  if (a->mode != 0) return DFE_ERR_UNSUPPORTED;
+  L->B = a->B; L->S = a->num_scales;
+  L->off_px[0] = 0; L->blk_start[0] = 0; L->tile_start[0] = 0;
+  for (int s = 0; s < L->S; ++s) {
+    // int(H / 2**s) as the reference computes it (model_geometry.py:70)
+    L->H[s] = static_cast<int>(static_cast<double>(a->H) / static_cast<double>(1 << s));
+    L->W[s] = static_cast<int>(static_cast<double>(a->W) / static_cast<double>(1 << s));
+    if (L->H[s] < 3 || L->W[s] < 3) return DFE_ERR_DIMS;
+    L->N[s] = L->H[s] * L->W[s];
+    L->off_px[s + 1] = L->off_px[s] + L->N[s];
+    L->nblk[s] = (L->N[s] + GS_BLOCK - 1) / GS_BLOCK;
+    L->blk_start[s + 1] = L->blk_start[s] + L->nblk[s];
+    L->tiles_x[s] = (L->W[s] + GS_TX - 1) / GS_TX;
+    L->ntile[s] = L->tiles_x[s] * ((L->H[s] + GS_TY - 1) / GS_TY);
+    L->tile_start[s + 1] = L->tile_start[s] + L->ntile[s];
+  }
+  L->nblk0 = L->nblk[0];
+  const long B = L->B, S = L->S, sumN = L->off_px[S];
+  const long nblk_total = L->blk_start[S], ntile_total = L->tile_start[S];
+  L->pyr_plane = B * 3 * (sumN - L->N[0]);
+  long o = 0;
+  L->o_cams = o; o = align4(o + B * 2 * S * static_cast<long>(sizeof(Camera) / sizeof(float)));
+  L->o_epi = o; o = align4(o + B * 2 * static_cast<long>(sizeof(Epi) / sizeof(float)));
+  L->o_pyr = o; o = align4(o + 3 * L->pyr_plane);
+  L->o_area = o; o = align4(o + 2 * L->pyr_plane);
+  L->o_mask = o; o = align4(o + (B * sumN + 3) / 4);
+  L->o_yw = o; o = align4(o + 2 * B * 3 * sumN);
+  L->o_part = o; o = align4(o + B * nblk_total * PT_COUNT);
+  L->o_spart = o; o = align4(o + B * 2 * ntile_total);
+  L->o_fpart = o; o = align4(o + 2 * B * nblk_total * 2);
+  L->o_dpart = o; o = align4(o + 3 * B * L->nblk0 * 2);
+  L->o_sums = o; o = align4(o + B * S * SUM_COUNT);
+  L->o_coef = o; o = align4(o + B * S * CF_COUNT);
+  L->o_dsum = o; o = align4(o + 3 * B * 2);
+  L->o_gw = o; o = align4(o + 2 * B * 3 * sumN);
+  L->o_gup = o; o = align4(o + 3 * (S - 1) * B * static_cast<long>(L->N[0]));
+  L->o_bpart = o; o = align4(o + B * nblk_total * PB_COUNT);
+  L->total = o;
+  return DFE_OK;
+}
+
+void geom_dev(const dfe_geom_args* a, const GeomLayout& L, GeomDev* D) {
+  float* ws = a->workspace;
+  D->B = L.B; D->S = L.S; D->ac = a->align_corners; D->alpha = a->alpha; D->beta = a->beta;
+  for (int s = 0; s <= L.S; ++s) { D->blk_start[s] = L.blk_start[s]; D->tile_start[s] = L.tile_start[s]; }
+  for (int s = 0; s < L.S; ++s) {
+    D->H[s] = L.H[s]; D->W[s] = L.W[s]; D->N[s] = L.N[s]; D->tiles_x[s] = L.tiles_x[s];
+    const long lvl = static_cast<long>(L.B) * 3 * (L.off_px[s] - L.N[0]);   // offset of level s (>=1) in a frame's block
+    for (int f = 0; f < 3; ++f) {
+      D->pyr[f][s] = (s == 0) ? a->img[f] : ws + L.o_pyr + f * L.pyr_plane + lvl;
+      D->disp[f][s] = a->disp[f][s];
+    }
+    for (int d = 0; d < 2; ++d) {
+      D->area[d][s] = (s == 0) ? a->img[d == 0 ? 0 : 2] : ws + L.o_area + d * L.pyr_plane + lvl;
+      D->flow[d][s] = a->flow[d][s];
+    }
+    D->mask[s] = reinterpret_cast<unsigned char*>(ws + L.o_mask) + static_cast<long>(L.B) * L.off_px[s];
+    D->yw[s] = ws + L.o_yw + 6L * L.B * L.off_px[s];
+  }
+  D->cams = reinterpret_cast<const Camera*>(ws + L.o_cams);
+  D->epi = reinterpret_cast<const Epi*>(ws + L.o_epi);
+}
+
+// ---------------------------------------------------------------------- epipolar geometry
+// F = K_inv^T (E K_inv), E = [t]x R (model_geometry.py:375-378, inverse_warp.py:344-364).
+__global__ void k_prepare_epi(const float* __restrict__ pose, const float* __restrict__ Kinv, Epi* __restrict__ epi,
+                              const Camera* __restrict__ cams, int B, int S) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * 2) return;
+  const int b = i / 2;
+  const float* v = pose + i * 6;
+  const Camera& c = cams[i * S];    // R is scale independent
+  double Sk[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+  double E[9], M[9], F[9], Ki[9];
+  for (int k = 0; k < 9; ++k) Ki[k] = Kinv[b * 9 + k];
+  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) E[r * 3 + q] = Sk[r * 3] * c.R[q] + Sk[r * 3 + 1] * c.R[3 + q] + Sk[r * 3 + 2] * c.R[6 + q];
+  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) M[r * 3 + q] = E[r * 3] * Ki[q] + E[r * 3 + 1] * Ki[3 + q] + E[r * 3 + 2] * Ki[6 + q];
+  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) F[r * 3 + q] = Ki[r] * M[q] + Ki[3 + r] * M[3 + q] + Ki[6 + r] * M[6 + q];
+  Epi e;
+  for (int k = 0; k < 9; ++k) { e.F[k] = static_cast<float>(F[k]); e.Kinv[k] = static_cast<float>(Ki[k]); e.S[k] = static_cast<float>(Sk[k]); }
+  epi[i] = e;
+}
+
+// ---------------------------------------------------------------------- pyramids
+struct PyrJob { const float* in; float* out; int outH, outW, mode; };
+struct PyrJobs { PyrJob j[5 * (DFE_MAX_SCALES - 1)]; int n, planes, inH, inW; };
+
+__global__ void k_geom_pyramids(PyrJobs jobs) {
+  const PyrJob jb = jobs.j[blockIdx.y];
+  const long n = static_cast<long>(jobs.planes) * jb.outH * jb.outW;
+  const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int ox = static_cast<int>(i % jb.outW), oy = static_cast<int>((i / jb.outW) % jb.outH);
+  const long pl = i / (static_cast<long>(jb.outW) * jb.outH);
+  const int inH = jobs.inH, inW = jobs.inW;
+  const float* src = jb.in + pl * inH * inW;
+  if (jb.mode == 0) {
+    jb.out[i] = resize_bilinear_at(src, inH, inW, oy, ox, static_cast<float>(inH) / jb.outH, static_cast<float>(inW) / jb.outW);
+  } else {
+    int ys = (oy * inH) / jb.outH, ye = ((oy + 1) * inH + jb.outH - 1) / jb.outH;
+    int xs = (ox * inW) / jb.outW, xe = ((ox + 1) * inW + jb.outW - 1) / jb.outW;
+    float s = 0.0f;
+    for (int yy = ys; yy < ye; ++yy)
+      for (int xx = xs; xx < xe; ++xx) s += src[static_cast<long>(yy) * inW + xx];
+    jb.out[i] = s / static_cast<float>((ye - ys) * (xe - xs));
+  }
+}
+
+// ---------------------------------------------------------------------- pointwise forward
+__global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, float* __restrict__ part) {
+  __shared__ float red[PT_COUNT * (GS_BLOCK / 64)];
+  const unsigned nblk_total = D.blk_start[D.S];
+  const unsigned blk = xcd_swizzle(blockIdx.x, nblk_total);
+  const int b = blockIdx.y;
+  const int s = find_scale(D.blk_start, D.S, blk);
+  const int H = D.H[s], W = D.W[s], N = D.N[s];
+  const int p = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
+  float acc[PT_COUNT];
+#pragma unroll
+  for (int i = 0; i < PT_COUNT; ++i) acc[i] = 0.0f;
+  if (p < N) {
+    const int py = p / W, px = p - py * W;
+    const long o3 = static_cast<long>(b) * 3 * N + p, o2 = static_cast<long>(b) * 2 * N + p, o1 = static_cast<long>(b) * N + p;
+    const float* it = D.pyr[1][s];
+    const float i0 = it[o3], i1 = it[o3 + N], i2 = it[o3 + 2 * N];
+    float fu[2], fv[2], wv[2][3], dif[2];
+    bool valid[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const float* fl = D.flow[d][s];
+      fu[d] = fl[o2]; fv[d] = fl[o2 + N];
+      float ix, iy;
+      flow_coords(px, py, fu[d], fv[d], H, W, D.ac, ix, iy);
+      Tap t = make_tap(ix, iy, H, W);
+      const float keep = (tap_cover(t) < 0.9999f) ? 0.0f : 1.0f;
+      const float* src = D.pyr[d == 0 ? 0 : 2][s] + static_cast<long>(b) * 3 * N;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) wv[d][c] = interp(load_corners(src + static_cast<long>(c) * N, t, W), t) * keep;
+      valid[d] = !(wv[d][0] == 0.0f && wv[d][1] == 0.0f && wv[d][2] == 0.0f);
+      dif[d] = mean3_abs_diff(i0, i1, i2, wv[d][0], wv[d][1], wv[d][2]);
+    }
+    float wb, wf;
+    occ_weights(dif[0], dif[1], wb, wf);
+    const bool occ[2] = {wb > 0.48f, wf > 0.48f};
+    const float dsp = D.disp[1][s][o1];
+    unsigned bits = 0;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const Camera& cam = D.cams[(b * 2 + d) * D.S + s];
+      Proj pr = project(cam, px, py, dsp);
+      const float ru = pr.U - static_cast<float>(px), rv = pr.V - static_cast<float>(py);
+      const float du = fabsf(ru - fu[d]), dv = fabsf(rv - fv[d]);
+      const bool dyna = dyna_decision(fu[d], fv[d], ru, rv, du, dv, D.alpha, D.beta);
+      float xn, yn; bool lx, ly;
+      rigid_grid(pr, H, W, xn, yn, lx, ly);
+      Tap t = make_tap(unnormalize(xn, W, D.ac), unnormalize(yn, H, D.ac), H, W);
+      const float* ar = D.area[d][s] + static_cast<long>(b) * 3 * N;
+      float rec[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rec[c] = interp(load_corners(ar + static_cast<long>(c) * N, t, W), t);
+      const float* sp = D.pyr[d == 0 ? 0 : 2][s];
+      const float e_rec = mean3_abs_diff(i0, i1, i2, rec[0], rec[1], rec[2]);
+      const float e_src = mean3_abs_diff(i0, i1, i2, sp[o3], sp[o3 + N], sp[o3 + 2 * N]);
+      const bool tex = e_rec < e_src;
+      const float vo = (valid[d] && occ[d]) ? 1.0f : 0.0f;
+      const float m_rig = dyna ? vo : 0.0f, m_dyn = dyna ? 0.0f : vo;
+      const float m_tex = tex ? m_rig : 0.0f;
+      const float l1_rec = (fabsf(i0 - rec[0]) + fabsf(i1 - rec[1])) + fabsf(i2 - rec[2]);
+      const float l1_wrp = (fabsf(i0 - wv[d][0]) + fabsf(i1 - wv[d][1])) + fabsf(i2 - wv[d][2]);
+      float* a = acc + d * PT_PER_DIR;
+      a[PT_M_TEX] = m_tex;       a[PT_L1_DEPTH] = l1_rec * m_tex;
+      a[PT_M_RIG] = m_rig;       a[PT_L1_RIG] = l1_wrp * m_rig;
+      a[PT_M_DYN] = m_dyn;       a[PT_L1_DYN] = l1_wrp * m_dyn;
+      a[PT_M_VO] = vo;
+      if (s == 0) {
+        a[PT_FDIFF] = (du + dv) * m_rig;
+        const Epi& e = D.epi[b * 2 + d];
+        const float x1 = static_cast<float>(px), y1 = static_cast<float>(py);
+        const float l0 = e.F[0] * x1 + e.F[1] * y1 + e.F[2];
+        const float l1 = e.F[3] * x1 + e.F[4] * y1 + e.F[5];
+        const float l2 = e.F[6] * x1 + e.F[7] * y1 + e.F[8];
+        const float div = sqrtf(l0 * l0 + l1 * l1) + 1e-6f;
+        a[PT_EPI] = fabsf(((x1 + fu[d]) * l0 + (y1 + fv[d]) * l1) + l2) / div;
+      }
+      bits |= (valid[d] ? (DFE_MASK_VALID_BWD << d) : 0u) | (occ[d] ? (DFE_MASK_OCC_BWD << d) : 0u) |
+              (dyna ? (DFE_MASK_DYNA_BWD << d) : 0u) | (tex ? (DFE_MASK_TEX_BWD << d) : 0u);
+      float* yw = D.yw[s] + (static_cast<long>(d) * D.B + b) * 3 * N + p;
+      yw[0] = wv[d][0] * vo; yw[N] = wv[d][1] * vo; yw[2 * N] = wv[d][2] * vo;
+    }
+    D.mask[s][o1] = static_cast<unsigned char>(bits);
+    // flow consistency (model_geometry.py:195-210): |unit(fwd) + unit(bwd)| on (1 - occ_fwd)
+    const float nf = l2norm2(fu[1], fv[1]), nb = l2norm2(fu[0], fv[0]);
+    const float inv = occ[1] ? 0.0f : 1.0f;
+    acc[PT_INV] = inv;
+    acc[PT_CONSIS] = (fabsf(fu[1] / nf + fu[0] / nb) + fabsf(fv[1] / nf + fv[0] / nb)) * inv;
+  }
+  block_sum<PT_COUNT>(acc, red, part + (static_cast<long>(b) * nblk_total + blk) * PT_COUNT);
+}
+
+// ---------------------------------------------------------------------- SSIM forward (stage P)
+// grid: x = tile over all scales, y = b*2 + d.  x = I * vo (mask bits), y = yw (already masked).
+__global__ void __launch_bounds__(GS_TX * GS_TY) k_geom_ssim_fwd(GeomDev D, float* __restrict__ spart) {
+  __shared__ float sx[3][GS_TY + 2][GS_TX + 2], sy[3][GS_TY + 2][GS_TX + 2];
+  __shared__ float red[GS_TX * GS_TY / 64];
+  const unsigned ntile_total = D.tile_start[D.S];
+  const unsigned tile = xcd_swizzle(blockIdx.x, ntile_total);
+  const int b = blockIdx.y >> 1, d = blockIdx.y & 1;
+  const int s = find_scale(D.tile_start, D.S, tile);
+  const int H = D.H[s], W = D.W[s], N = D.N[s];
+  const int tl = tile - D.tile_start[s];
+  const int x0 = (tl % D.tiles_x[s]) * GS_TX, y0 = (tl / D.tiles_x[s]) * GS_TY;
+  const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
+  const float* yw = D.yw[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
+  const unsigned char* mk = D.mask[s] + static_cast<long>(b) * N;
+  const unsigned need = (DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD) << d;
+  for (int i = threadIdx.x; i < (GS_TY + 2) * (GS_TX + 2); i += blockDim.x) {
+    const int ly = i / (GS_TX + 2), lx = i - ly * (GS_TX + 2);
+    const int gy = y0 + ly - 1, gx = x0 + lx - 1;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const long q = static_cast<long>(gy) * W + gx;
+    const float vo = (in && (mk[q] & need) == need) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      sx[c][ly][lx] = in ? it[q + static_cast<long>(c) * N] * vo : 0.0f;
+      sy[c][ly][lx] = in ? yw[q + static_cast<long>(c) * N] : 0.0f;
+    }
+  }
+  __syncthreads();
+  const int tx = threadIdx.x % GS_TX, ty = threadIdx.x / GS_TX;
+  float v = 0.0f;
+  if (x0 + tx < W && y0 + ty < H) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float a = 0, bq = 0, aa = 0, bb = 0, ab = 0;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const float u = sx[c][ty + dy][tx + dx], w = sy[c][ty + dy][tx + dx];
+          a += u; bq += w; aa += u * u; bb += w * w; ab += u * w;
+        }
+      const float ss = ssim_from_means(a / 9.0f, bq / 9.0f, aa / 9.0f, bb / 9.0f, ab / 9.0f);
+      v += fminf(fmaxf((1.0f - ss) / 2.0f, 0.0f), 1.0f);
+    }
+  }
+  float vv[1] = {v};
+  block_sum<1>(vv, red, spart + static_cast<long>(blockIdx.y) * ntile_total + tile);
+}
+
+// ---------------------------------------------------------------------- smoothness forward
+// Second-order flow smoothness on flow/20 (model_geometry.py:254-279).  grid.y = d*B + b.
+__global__ void __launch_bounds__(GS_BLOCK) k_geom_flow_smooth_fwd(GeomDev D, float* __restrict__ fpart) {
+  __shared__ float red[2 * (GS_BLOCK / 64)];
+  const unsigned nblk_total = D.blk_start[D.S];
+  const unsigned blk = blockIdx.x;
+  const int d = blockIdx.y / D.B, b = blockIdx.y - d * D.B;
+  const int s = find_scale(D.blk_start, D.S, blk);
+  const int H = D.H[s], W = D.W[s], N = D.N[s];
+  const int p = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
+  float acc[2] = {0.0f, 0.0f};
+  if (p < N) {
+    const int py = p / W, px = p - py * W;
+    const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
+    const float* fl = D.flow[d][s] + static_cast<long>(b) * 2 * N;
+    if (px + 2 < W) {
+      const float w = expf(-10.0f * mean3_abs_diff(it[p + 2], it[p + 2 + N], it[p + 2 + 2 * N], it[p + 1], it[p + 1 + N], it[p + 1 + 2 * N]));
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float a0 = fl[c * N + p] / 20.0f, a1 = fl[c * N + p + 1] / 20.0f, a2 = fl[c * N + p + 2] / 20.0f;
+        acc[0] += w * fabsf((a2 - a1) - (a1 - a0));
+      }
+    }
+    if (py + 2 < H) {
+      const int q1 = p + W, q2 = p + 2 * W;
+      const float w = expf(-10.0f * mean3_abs_diff(it[q2], it[q2 + N], it[q2 + 2 * N], it[q1], it[q1 + N], it[q1 + 2 * N]));
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float a0 = fl[c * N + p] / 20.0f, a1 = fl[c * N + q1] / 20.0f, a2 = fl[c * N + q2] / 20.0f;
+        acc[1] += w * fabsf((a2 - a1) - (a1 - a0));
+      }
+    }
+  }
+  block_sum<2>(acc, red, fpart + (static_cast<long>(blockIdx.y) * nblk_total + blk) * 2);
+}
+
+// First-order edge-aware disparity smoothness at full resolution, all scales fused
+// (model_geometry.py:225-252).  grid.y = f*B + b over the 3 frames.
+__global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_fwd(GeomDev D, float* __restrict__ dpart) {
+  __shared__ float red[2 * (GS_BLOCK / 64)];
+  const int f = blockIdx.y / D.B, b = blockIdx.y - f * D.B;
+  const int H = D.H[0], W = D.W[0], N = D.N[0];
+  const int p = blockIdx.x * GS_BLOCK + threadIdx.x;
+  float acc[2] = {0.0f, 0.0f};
+  if (p < N) {
+    const int py = p / W, px = p - py * W;
+    const float* im = D.pyr[f][0] + static_cast<long>(b) * 3 * N;
+    const bool hx = px + 1 < W, hy = py + 1 < H;
+    float wx = 0.0f, wy = 0.0f;
+    const float c0 = im[p], c1 = im[p + N], c2 = im[p + 2 * N];
+    if (hx) wx = expf(-mean3_abs_diff(c0, c1, c2, im[p + 1], im[p + 1 + N], im[p + 1 + 2 * N]));
+    if (hy) wy = expf(-mean3_abs_diff(c0, c1, c2, im[p + W], im[p + W + N], im[p + W + 2 * N]));
+    for (int s = 0; s < D.S; ++s) {
+      const float* dp = D.disp[f][s] + static_cast<long>(b) * D.N[s];
+      float u0, ux = 0.0f, uy = 0.0f;
+      if (s == 0) {
+        u0 = dp[p];
+        if (hx) ux = dp[p + 1];
+        if (hy) uy = dp[p + W];
+      } else {
+        const float sh = static_cast<float>(D.H[s]) / H, sw = static_cast<float>(D.W[s]) / W;
+        u0 = resize_bilinear_at(dp, D.H[s], D.W[s], py, px, sh, sw);
+        if (hx) ux = resize_bilinear_at(dp, D.H[s], D.W[s], py, px + 1, sh, sw);
+        if (hy) uy = resize_bilinear_at(dp, D.H[s], D.W[s], py + 1, px, sh, sw);
+      }
+      if (hx) acc[0] += fabsf(u0 - ux) * wx;
+      if (hy) acc[1] += fabsf(u0 - uy) * wy;
+    }
+  }
+  block_sum<2>(acc, red, dpart + (static_cast<long>(blockIdx.y) * gridDim.x + blockIdx.x) * 2);
+}
+
+// ---------------------------------------------------------------------- finalize
+// One block per sample.  Phase 1: thread (s,i) sums its partials in block order (double).
+// Phase 2: thread 0 assembles the eight loss values and the backward normalisers.
+__global__ void k_geom_finalize_fwd(GeomDev D, const float* __restrict__ part, const float* __restrict__ spart,
+                                    const float* __restrict__ fpart, const float* __restrict__ dpart, int nblk0,
+                                    float* __restrict__ sums, float* __restrict__ coef, float* __restrict__ dsum,
+                                    float* __restrict__ losses) {
+  __shared__ double sm[DFE_MAX_SCALES][SUM_COUNT];
+  __shared__ double ds[3][2];
+  const int b = blockIdx.x, S = D.S, B = D.B;
+  const unsigned nblk_total = D.blk_start[S], ntile_total = D.tile_start[S];
+  for (int t = threadIdx.x; t < S * SUM_COUNT + 6; t += blockDim.x) {
+    double a = 0.0;
+    if (t < S * SUM_COUNT) {
+      const int s = t / SUM_COUNT, i = t - s * SUM_COUNT;
+      if (i < PT_COUNT) {
+        for (int k = D.blk_start[s]; k < D.blk_start[s + 1]; ++k) a += part[(static_cast<long>(b) * nblk_total + k) * PT_COUNT + i];
+      } else if (i < SUM_FS) {
+        const int d = i - SUM_SSIM;
+        for (int k = D.tile_start[s]; k < D.tile_start[s + 1]; ++k) a += spart[static_cast<long>(b * 2 + d) * ntile_total + k];
+      } else {
+        const int d = (i - SUM_FS) >> 1, xy = (i - SUM_FS) & 1;
+        for (int k = D.blk_start[s]; k < D.blk_start[s + 1]; ++k) a += fpart[(static_cast<long>(d * B + b) * nblk_total + k) * 2 + xy];
+      }
+      sm[s][i] = a;
+      sums[(static_cast<long>(b) * S + s) * SUM_COUNT + i] = static_cast<float>(a);
+    } else {
+      const int q = t - S * SUM_COUNT, f = q >> 1, xy = q & 1;
+      for (int k = 0; k < nblk0; ++k) a += dpart[(static_cast<long>(f * B + b) * nblk0 + k) * 2 + xy];
+      ds[f][xy] = a;
+      dsum[(f * B + b) * 2 + xy] = static_cast<float>(a);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const double eps = 1e-12;
+  double l_dp = 0, l_fp = 0, l_fs = 0, l_sm = 0, l_fc = 0, l_dfc = 0, l_epi = 0;
+  for (int s = 0; s < S; ++s) {
+    const double N = D.N[s], H = D.H[s], W = D.W[s];
+    float* cf = coef + (static_cast<long>(b) * S + s) * CF_COUNT;
+    for (int d = 0; d < 2; ++d) {
+      const double* a = sm[s] + d * PT_PER_DIR;
+      const double n_tex = a[PT_M_TEX] / N + eps, n_rig = a[PT_M_RIG] / N + eps, n_dyn = a[PT_M_DYN] / N + eps,
+                   n_vo = a[PT_M_VO] / N + eps;
+      l_dp += (a[PT_L1_DEPTH] / (3.0 * N)) / n_tex;
+      l_fp += (a[PT_L1_RIG] / (3.0 * N)) / n_rig + 2.0 * (a[PT_L1_DYN] / (3.0 * N)) / n_dyn;
+      l_fs += (sm[s][SUM_SSIM + d] / (3.0 * N)) / n_vo;
+      l_sm += (sm[s][SUM_FS + 2 * d] / (2.0 * H * (W - 2.0)) + sm[s][SUM_FS + 2 * d + 1] / (2.0 * (H - 2.0) * W)) / 2.0;
+      cf[d * CF_PER_DIR + CF_DEPTH] = static_cast<float>(1.0 / (3.0 * N * n_tex));
+      cf[d * CF_PER_DIR + CF_RIG] = static_cast<float>(1.0 / (3.0 * N * n_rig));
+      cf[d * CF_PER_DIR + CF_DYN] = static_cast<float>(2.0 / (3.0 * N * n_dyn));
+      cf[d * CF_PER_DIR + CF_VO] = static_cast<float>(1.0 / (3.0 * N * n_vo));
+      cf[d * CF_PER_DIR + CF_FD] = static_cast<float>(1.0 / (2.0 * N * n_rig));
+      if (s == 0) {
+        l_dfc += (a[PT_FDIFF] / (2.0 * N)) / n_rig;
+        l_epi += a[PT_EPI] / N;
+      }
+    }
+    const double n_inv = sm[s][PT_INV] / N + eps;
+    l_fc += (sm[s][PT_CONSIS] / (2.0 * N)) / n_inv;
+    cf[CF_CONSIS] = static_cast<float>(1.0 / (2.0 * N * n_inv));
+  }
+  double l_ds = 0;
+  {
+    const double H = D.H[0], W = D.W[0];
+    for (int f = 0; f < 3; ++f) l_ds += ds[f][0] / (H * (W - 1.0)) + ds[f][1] / ((H - 1.0) * W);
+  }
+  losses[DFE_LOSS_DEPTH_PIXEL * B + b] = static_cast<float>(l_dp);
+  losses[DFE_LOSS_DEPTH_SMOOTH * B + b] = static_cast<float>(l_ds);
+  losses[DFE_LOSS_FLOW_PIXEL * B + b] = static_cast<float>(l_fp);
+  losses[DFE_LOSS_FLOW_SSIM * B + b] = static_cast<float>(l_fs);
+  losses[DFE_LOSS_FLOW_SMOOTH * B + b] = static_cast<float>(l_sm);
+  losses[DFE_LOSS_FLOW_CONSIS * B + b] = static_cast<float>(l_fc);
+  losses[DFE_LOSS_DEPTH_FLOW_CONSIS * B + b] = static_cast<float>(l_dfc);
+  losses[DFE_LOSS_EPIPOLAR * B + b] = static_cast<float>(l_epi);
+}
+
+}  // namespace dfe
+
+using namespace dfe;
+
+static int check_args(const dfe_geom_args* a, const GeomLayout& L, bool bwd) {
+  if (!a->workspace || !a->pose || !a->K || !a->K_inv) return DFE_ERR_NULL;
+  if (a->workspace_floats < L.total) return DFE_ERR_WORKSPACE;
+  for (int f = 0; f < 3; ++f) {
+    if (!a->img[f]) return DFE_ERR_NULL;
+    for (int s = 0; s < L.S; ++s) if (!a->disp[f][s]) return DFE_ERR_NULL;
+  }
+  for (int d = 0; d < 2; ++d) for (int s = 0; s < L.S; ++s) if (!a->flow[d][s]) return DFE_ERR_NULL;
+  if (!bwd && !a->losses) return DFE_ERR_NULL;
+  if (bwd && !a->grad_losses) return DFE_ERR_NULL;
+  if (a->B > 32767) return DFE_ERR_DIMS;
+  return DFE_OK;
+}
+
+#define DFE_LAUNCH_CHECK() do { if (hipGetLastError() != hipSuccess) return DFE_ERR_LAUNCH; } while (0)
+
+extern "C" {
+
+long dfe_geom_workspace_floats(const dfe_geom_args* args) {
+  GeomLayout L;
+  int rc = geom_layout(args, &L);
+  return rc == DFE_OK ? L.total : static_cast<long>(rc);
+}
+
+long dfe_geom_maskpack_offset_bytes(const dfe_geom_args* args, int scale) {
+  GeomLayout L;
+  int rc = geom_layout(args, &L);
+  if (rc != DFE_OK) return rc;
+  if (scale < 0 || scale >= L.S) return DFE_ERR_DIMS;
+  return L.o_mask * 4 + static_cast<long>(L.B) * L.off_px[scale];
+}
+
+int dfe_geom_loss_fwd(const dfe_geom_args* a, void* stream) {
+  GeomLayout L;
+  int rc = geom_layout(a, &L);
+  if (rc != DFE_OK) return rc;
+  rc = check_args(a, L, false);
+  if (rc != DFE_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* ws = a->workspace;
+  GeomDev D;
+  geom_dev(a, L, &D);
+  // cameras: downscale = H / H_s as the reference computes it (float division of ints)
+  float downs[DFE_MAX_SCALES];
+  for (int s = 0; s < L.S; ++s) downs[s] = static_cast<float>(static_cast<double>(a->H) / static_cast<double>(L.H[s]));
+  rc = dfe_prepare_cameras(a->pose, a->K, ws + L.o_cams, L.B, 2, L.S, downs, stream);
+  if (rc != DFE_OK) return rc;
+  k_prepare_epi<<<(L.B * 2 + 63) / 64, 64, 0, st>>>(a->pose, a->K_inv, reinterpret_cast<Epi*>(ws + L.o_epi), D.cams, L.B, L.S);
+  DFE_LAUNCH_CHECK();
+  if (L.S > 1) {
+    PyrJobs jobs;
+    jobs.n = 0; jobs.planes = L.B * 3; jobs.inH = a->H; jobs.inW = a->W;
+    int max_out = 0;
+    for (int s = 1; s < L.S; ++s) {
+      for (int f = 0; f < 3; ++f) jobs.j[jobs.n++] = PyrJob{a->img[f], const_cast<float*>(D.pyr[f][s]), L.H[s], L.W[s], 0};
+      for (int d = 0; d < 2; ++d) jobs.j[jobs.n++] = PyrJob{a->img[d == 0 ? 0 : 2], const_cast<float*>(D.area[d][s]), L.H[s], L.W[s], 1};
+      if (L.N[s] > max_out) max_out = L.N[s];
+    }
+    dim3 g(static_cast<unsigned>((static_cast<long>(jobs.planes) * max_out + 255) / 256), jobs.n);
+    k_geom_pyramids<<<g, 256, 0, st>>>(jobs);
+    DFE_LAUNCH_CHECK();
+  }
+  const unsigned nblk_total = L.blk_start[L.S], ntile_total = L.tile_start[L.S];
+  k_geom_point_fwd<<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
+  DFE_LAUNCH_CHECK();
+  k_geom_ssim_fwd<<<dim3(ntile_total, L.B * 2), GS_TX * GS_TY, 0, st>>>(D, ws + L.o_spart);
+  DFE_LAUNCH_CHECK();
+  k_geom_flow_smooth_fwd<<<dim3(nblk_total, 2 * L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_fpart);
+  DFE_LAUNCH_CHECK();
+  k_geom_disp_smooth_fwd<<<dim3(L.nblk0, 3 * L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_dpart);
+  DFE_LAUNCH_CHECK();
+  k_geom_finalize_fwd<<<L.B, 256, 0, st>>>(D, ws + L.o_part, ws + L.o_spart, ws + L.o_fpart, ws + L.o_dpart, L.nblk0,
+                                         ws + L.o_sums, ws + L.o_coef, ws + L.o_dsum, a->losses);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+}  // extern "C"

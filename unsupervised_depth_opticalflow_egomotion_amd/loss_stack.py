@@ -1,0 +1,175 @@
+"""Host side of the fused loss stack: dfe_geom_loss_fwd / dfe_geom_loss_bwd (include/dfe_hip.h).
+
+``geom_loss_stack`` computes the eight active ``loss_pack`` vectors of the reference's
+``Model_geometry.forward`` (model_geometry.py:797-951) from the nets' outputs in a handful of
+HIP launches, and is differentiable wrt the disparities, the flows and the pose.  PyTorch is
+only the allocator, the stream and the autograd graph."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import ops
+from ._lib import DfeError, check, f32c, get_lib, stream_ptr
+
+MAX_SCALES = 8
+LOSS_ROWS = ("loss_depth_pixel", "loss_depth_smooth", "loss_flow_pixel", "loss_flow_ssim", "loss_flow_smooth",
+             "loss_flow_consis", "loss_depth_flow_consis", "loss_epipolar")
+MASK_BITS = dict(valid_bwd=0x01, valid_fwd=0x02, occ_bwd=0x04, occ_fwd=0x08, dyna_bwd=0x10, dyna_fwd=0x20,
+                 texture_bwd=0x40, texture_fwd=0x80)
+
+_FP = ctypes.c_void_p
+
+
+class GeomArgs(ctypes.Structure):
+    """Mirror of ``dfe_geom_args`` (include/dfe_hip.h)."""
+    _fields_ = [
+        ("B", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("num_scales", ctypes.c_int),
+        ("align_corners", ctypes.c_int), ("mode", ctypes.c_int),
+        ("alpha", ctypes.c_float), ("beta", ctypes.c_float),
+        ("img", _FP * 3),
+        ("disp", (_FP * MAX_SCALES) * 3),
+        ("flow", (_FP * MAX_SCALES) * 2),
+        ("pose", _FP), ("K", _FP), ("K_inv", _FP),
+        ("workspace", _FP), ("workspace_floats", ctypes.c_long),
+        ("losses", _FP), ("grad_losses", _FP),
+        ("grad_disp", (_FP * MAX_SCALES) * 3),
+        ("grad_flow", (_FP * MAX_SCALES) * 2),
+        ("grad_pose", _FP),
+    ]
+
+
+def _dp(t):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise DfeError("loss stack tensors must be contiguous fp32 HIP tensors (no CPU fallback)")
+    return t.data_ptr()
+
+
+def _scale_hw(h, w, s):
+    return int(h / (2 ** s)), int(w / (2 ** s))
+
+
+def _fill_args(imgs, disps, flows, pose, K, K_inv, S, alpha, beta, ac):
+    a = GeomArgs()
+    B, _, H, W = imgs[0].shape
+    a.B, a.H, a.W, a.num_scales, a.align_corners, a.mode = B, H, W, S, int(ac), 0
+    a.alpha, a.beta = float(alpha), float(beta)
+    for f in range(3):
+        if tuple(imgs[f].shape) != (B, 3, H, W):
+            raise ValueError("frames must be [B,3,H,W]")
+        a.img[f] = _dp(imgs[f])
+        for s in range(S):
+            hs, ws = _scale_hw(H, W, s)
+            if tuple(disps[f][s].shape) != (B, 1, hs, ws):
+                raise ValueError("disp[%d][%d] must be %s, got %s" % (f, s, (B, 1, hs, ws), tuple(disps[f][s].shape)))
+            a.disp[f][s] = _dp(disps[f][s])
+    for d in range(2):
+        for s in range(S):
+            hs, ws = _scale_hw(H, W, s)
+            if tuple(flows[d][s].shape) != (B, 2, hs, ws):
+                raise ValueError("flow[%d][%d] must be %s, got %s" % (d, s, (B, 2, hs, ws), tuple(flows[d][s].shape)))
+            a.flow[d][s] = _dp(flows[d][s])
+    if tuple(pose.shape) != (B, 2, 6) or tuple(K.shape) != (B, 3, 3) or tuple(K_inv.shape) != (B, 3, 3):
+        raise ValueError("pose must be [B,2,6] and K, K_inv [B,3,3]")
+    a.pose, a.K, a.K_inv = _dp(pose), _dp(K), _dp(K_inv)
+    return a
+
+
+class GeomLossFn(torch.autograd.Function):
+    """forward(*tensors) -> losses [8,B].  Tensor order: 3 frames, 3*S disps (frame-major),
+    2*S flows (bwd scales then fwd scales), pose, K, K_inv."""
+
+    @staticmethod
+    def forward(ctx, S, alpha, beta, ac, *t):
+        lib = get_lib()
+        t = [f32c(x) for x in t]
+        imgs = t[0:3]
+        disps = [t[3 + f * S: 3 + (f + 1) * S] for f in range(3)]
+        flows = [t[3 + 3 * S + d * S: 3 + 3 * S + (d + 1) * S] for d in range(2)]
+        pose, K, K_inv = t[3 + 5 * S:]
+        a = _fill_args(imgs, disps, flows, pose, K, K_inv, S, alpha, beta, ac)
+        n = lib.dfe_geom_workspace_floats(ctypes.byref(a))
+        if n < 0:
+            check(int(n), "dfe_geom_workspace_floats")
+        dev = imgs[0].device
+        ws = torch.empty(n, device=dev, dtype=torch.float32)
+        losses = torch.empty(len(LOSS_ROWS), a.B, device=dev, dtype=torch.float32)
+        a.workspace, a.workspace_floats, a.losses = ws.data_ptr(), n, losses.data_ptr()
+        check(lib.dfe_geom_loss_fwd(ctypes.byref(a), stream_ptr()), "dfe_geom_loss_fwd")
+        ctx.save_for_backward(*t)
+        ctx.cfg = (S, alpha, beta, ac)
+        ctx.ws = ws
+        ctx.mark_non_differentiable(ws)
+        return losses, ws
+
+    @staticmethod
+    def backward(ctx, glosses, _gws=None):
+        lib = get_lib()
+        S, alpha, beta, ac = ctx.cfg
+        t = list(ctx.saved_tensors)
+        imgs = t[0:3]
+        disps = [t[3 + f * S: 3 + (f + 1) * S] for f in range(3)]
+        flows = [t[3 + 3 * S + d * S: 3 + 3 * S + (d + 1) * S] for d in range(2)]
+        pose, K, K_inv = t[3 + 5 * S:]
+        a = _fill_args(imgs, disps, flows, pose, K, K_inv, S, alpha, beta, ac)
+        glosses = f32c(glosses)
+        a.workspace, a.workspace_floats = ctx.ws.data_ptr(), ctx.ws.numel()
+        a.grad_losses = glosses.data_ptr()
+        gd = [[torch.empty_like(x) for x in lst] for lst in disps]
+        gf = [[torch.empty_like(x) for x in lst] for lst in flows]
+        gp = torch.empty_like(pose)
+        for f in range(3):
+            for s in range(S):
+                a.grad_disp[f][s] = gd[f][s].data_ptr()
+        for d in range(2):
+            for s in range(S):
+                a.grad_flow[d][s] = gf[d][s].data_ptr()
+        a.grad_pose = gp.data_ptr()
+        check(lib.dfe_geom_loss_bwd(ctypes.byref(a), stream_ptr()), "dfe_geom_loss_bwd")
+        grads = [None, None, None, None, None, None, None]  # S, alpha, beta, ac, 3 frames
+        for f in range(3):
+            grads += gd[f]
+        for d in range(2):
+            grads += gf[d]
+        grads += [gp, None, None]
+        return tuple(grads)
+
+
+def geom_loss_stack(img_l, img, img_r, disp_l_list, disp_list, disp_r_list, pose_vectors, flows_bwd, flows_fwd,
+                    K, K_inv, num_scales=3, flow_consist_alpha=0.01, flow_consist_beta=0.5, align_corners=None,
+                    return_masks=False):
+    """Active ``loss_pack`` entries of Model_geometry.forward as a dict of (B,) tensors.
+
+    ``flows_*`` may hold more scales than ``num_scales`` (the reference's zip() drops the 1/8
+    flow, model_geometry.py:74-78); extra scales receive no gradient.  With ``return_masks`` the
+    second return value maps mask names to per-scale float {0,1} tensors [B,1,Hs,Ws] decoded from
+    the kernel's 1-byte mask pack."""
+    S = int(num_scales)
+    ac = ops.get_align_corners() if align_corners is None else bool(align_corners)
+    tensors = [img_l, img, img_r] + list(disp_l_list[:S]) + list(disp_list[:S]) + list(disp_r_list[:S]) \
+        + list(flows_bwd[:S]) + list(flows_fwd[:S]) + [pose_vectors, K, K_inv]
+    losses, ws = GeomLossFn.apply(S, float(flow_consist_alpha), float(flow_consist_beta), int(ac), *tensors)
+    pack = {name: losses[i] for i, name in enumerate(LOSS_ROWS)}
+    if not return_masks:
+        return pack
+    B, _, H, W = img.shape
+    return pack, decode_masks(ws, B, H, W, S)
+
+
+def decode_masks(ws, B, H, W, S):
+    """Decode the 1-byte mask pack kept in the forward workspace into float {0,1} masks."""
+    lib = get_lib()
+    a = GeomArgs()
+    a.B, a.H, a.W, a.num_scales, a.mode = B, H, W, S, 0
+    raw = ws.view(torch.uint8)
+    out = {k: [] for k in MASK_BITS}
+    for s in range(S):
+        off = lib.dfe_geom_maskpack_offset_bytes(ctypes.byref(a), s)
+        hs, ws_ = _scale_hw(H, W, s)
+        m = raw[off: off + B * hs * ws_].view(B, 1, hs, ws_)
+        for k, bit in MASK_BITS.items():
+            out[k].append(((m & bit) != 0).float())
+    return out
