@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X.  Contract: python bench.py --gpus N --steps K --warmup W
+prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for every definition used here.
+
+Workloads (BASELINE.json configs; synthetic KITTI-shaped inputs, seed 1234 + rank):
+  train_step  mode=geom, 832x256, B=4/GPU: DepthNet x3 + PoseCNN + PWC x2 (PyTorch-ROCm) + the HIP loss
+              stack, forward + backward + Adam  (configs[2]; the configuration the metric is quoted on)
+  loss_stack  the loss stack alone on synthetic net outputs, forward + backward (hot path in isolation)
+Unit: frame pair = one (target, source) direction of one triplet; a batch of B triplets is 2B pairs.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+POINT_FWD_BYTES_PER_PX = 105   # algorithmic bytes of k_geom_point_fwd per pixel, both directions
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4, help="triplets per GPU")
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=832)
+    ap.add_argument("--scales", type=int, default=3)
+    ap.add_argument("--workload", default="auto", choices=["auto", "train_step", "loss_stack"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    return ap.parse_args()
+
+
+def init_dist(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    return world, rank, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(x, world, dev):
+    if world == 1:
+        return x
+    import torch.distributed as dist
+    t = torch.tensor([x], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+# ------------------------------------------------------------------------------------------------ loss stack
+class LossStackWorkload:
+    name = "loss_stack"
+
+    def __init__(self, args, dev, seed):
+        from unsupervised_depth_opticalflow_egomotion_amd import synthetic
+        self.S = args.scales
+        inp = synthetic.make_loss_stack_inputs(args.batch, args.height, args.width, self.S, seed=seed)
+        self.inp = inp
+        g = lambda a, grad=False: torch.from_numpy(np.ascontiguousarray(a)).to(dev).requires_grad_(grad)
+        self.imgs = [g(a) for a in inp.imgs]
+        self.disps = [[g(a, True) for a in lst] for lst in inp.disps]
+        self.pose = g(inp.pose, True)
+        self.fb = [g(a, True) for a in inp.flows_bwd]
+        self.ff = [g(a, True) for a in inp.flows_fwd]
+        self.K, self.Ki = g(inp.K), g(inp.K_inv)
+        from tests.golden.make_golden import GEOM_WEIGHTS
+        self.weights = GEOM_WEIGHTS
+        self.leaves = [t for lst in self.disps for t in lst] + [self.pose] + self.fb + self.ff
+
+    def step(self):
+        from unsupervised_depth_opticalflow_egomotion_amd.loss_stack import geom_loss_stack
+        for t in self.leaves:
+            t.grad = None
+        lp = geom_loss_stack(self.imgs[0], self.imgs[1], self.imgs[2], self.disps[0], self.disps[1], self.disps[2],
+                             self.pose, self.fb, self.ff, self.K, self.Ki, num_scales=self.S)
+        loss = sum(self.weights[k] * v.mean() for k, v in lp.items())
+        loss.backward()
+        return loss
+
+    def cpu_step_fn(self, threads):
+        """The oracle (CPU restatement of the reference) on the same inputs: forward + backward."""
+        from oracle import loss_stack_oracle as O
+        inp = self.inp
+        m = O.GeomLossOracle(num_scales=self.S)
+        c = lambda a, grad=False: torch.from_numpy(np.ascontiguousarray(a)).requires_grad_(grad)
+        imgs = [c(a) for a in inp.imgs]
+        disps = [[c(a, True) for a in lst] for lst in inp.disps]
+        pose, fb, ff = c(inp.pose, True), [c(a, True) for a in inp.flows_bwd], [c(a, True) for a in inp.flows_fwd]
+        K, Ki = c(inp.K), c(inp.K_inv)
+
+        def run():
+            lp, _ = m.geom_losses(imgs[0], imgs[1], imgs[2], disps[0], disps[1], disps[2], pose, fb, ff, K, Ki)
+            sum(self.weights[k] * v.mean() for k, v in lp.items()).backward()
+        return run
+
+
+# ------------------------------------------------------------------------------------------------ roofline
+def point_fwd_roofline(args, wl, steps):
+    """Average duration of k_geom_point_fwd (HIP events on the launch stream, diagnostic entry point of the
+    C ABI) over `steps` forward passes on the bench inputs -> achieved algorithmic GB/s."""
+    from unsupervised_depth_opticalflow_egomotion_amd import loss_stack as LS
+    from unsupervised_depth_opticalflow_egomotion_amd._lib import get_lib, check, stream_ptr
+    lib = get_lib()
+    S = args.scales
+    det = lambda lst: [t.detach() for t in lst]
+    a = LS._fill_args(wl.imgs, [det(l[:S]) for l in wl.disps], [det(wl.fb[:S]), det(wl.ff[:S])], wl.pose.detach(),
+                      wl.K, wl.Ki, S, 0.01, 0.5, 0)
+    n = lib.dfe_geom_workspace_floats(ctypes.byref(a))
+    ws = torch.empty(n, device=wl.imgs[0].device)
+    losses = torch.empty(len(LS.LOSS_ROWS), a.B, device=ws.device)
+    a.workspace, a.workspace_floats, a.losses = ws.data_ptr(), n, losses.data_ptr()
+    glosses = torch.full_like(losses, 1.0 / a.B)
+    a.grad_losses = glosses.data_ptr()
+    keep = []
+    for f in range(3):
+        for s in range(S):
+            t = torch.empty_like(wl.disps[f][s]); keep.append(t); a.grad_disp[f][s] = t.data_ptr()
+    for d, lst in enumerate((wl.fb, wl.ff)):
+        for s in range(S):
+            t = torch.empty_like(lst[s]); keep.append(t); a.grad_flow[d][s] = t.data_ptr()
+    gp = torch.empty_like(wl.pose); a.grad_pose = gp.data_ptr()
+    fwd = (ctypes.c_float * 7)()
+    bwd = (ctypes.c_float * 6)()
+    acc_f, acc_b = np.zeros(7), np.zeros(6)
+    for i in range(steps + 2):
+        check(lib.dfe_geom_loss_fwd_profiled(ctypes.byref(a), stream_ptr(), ctypes.cast(fwd, ctypes.c_void_p)), "fwd_profiled")
+        check(lib.dfe_geom_loss_bwd_profiled(ctypes.byref(a), stream_ptr(), ctypes.cast(bwd, ctypes.c_void_p)), "bwd_profiled")
+        if i >= 2:
+            acc_f += np.array(fwd[:]); acc_b += np.array(bwd[:])
+    acc_f /= steps; acc_b /= steps
+    npx = args.batch * sum(int(args.height / 2 ** s) * int(args.width / 2 ** s) for s in range(S))
+    bytes_per_launch = POINT_FWD_BYTES_PER_PX * npx
+    t_ms = float(acc_f[2])
+    achieved = bytes_per_launch / (t_ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "kernel": "k_geom_point_fwd", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "bytes_per_launch": bytes_per_launch, "avg_kernel_ms": round(t_ms, 5)}
+    segs = {"fwd_ms": [round(float(x), 5) for x in acc_f], "bwd_ms": [round(float(x), 5) for x in acc_b]}
+    return roof, segs
+
+
+def cpu_baseline(wl, args, unit_pairs):
+    """Oracle timed on the host cores on a bounded sample.  torch CPU ops on these tensor sizes do not scale
+    past a few threads (256 threads ran 40x slower than 8), so the leg uses min(cores, 16) threads."""
+    threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    run = wl.cpu_step_fn(threads)
+    run()                       # warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        run(); n += 1
+        if time.perf_counter() - t0 > 15.0 or n >= 3:
+            break
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(unit_pairs / dt, 4), "unit": "frame-pairs/s", "cores": threads, "kind": "port",
+            "sample": "%d timed step(s) of the same workload (B=%d, %dx%d, S=%d, fwd+bwd) on the host CPU, %.2f s/step"
+                      % (n, args.batch, args.height, args.width, args.scales, dt)}
+
+
+def main():
+    args = parse()
+    world, rank, local = init_dist(args)
+    dev = torch.device("cuda", local)
+    wl_name = args.workload
+    if wl_name == "auto":
+        try:
+            from unsupervised_depth_opticalflow_egomotion_amd import train_step as _ts  # noqa: F401
+            wl_name = "train_step"
+        except Exception:
+            wl_name = "loss_stack"
+    if wl_name == "train_step":
+        from unsupervised_depth_opticalflow_egomotion_amd.train_step import TrainStepWorkload
+        wl = TrainStepWorkload(args, dev, seed=1234 + rank, world=world)
+    else:
+        wl = LossStackWorkload(args, dev, seed=1234 + rank)
+    for _ in range(args.warmup):
+        wl.step()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+    pairs_per_step = 2 * args.batch * world
+    value = pairs_per_step * args.steps / dt
+    out = {
+        "metric": "frame-pairs/sec (832x256, geom mode)", "value": round(value, 2), "unit": "frame-pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wl.name + ": mode=geom, %dx%d, batch=%d/GPU, num_scales=%d, fwd+bwd%s" % (
+            args.width, args.height, args.batch, args.scales, "+Adam" if wl.name == "train_step" else ""),
+            "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+    }
+    if rank == 0:
+        ls = wl if isinstance(wl, LossStackWorkload) else wl.loss_stack_workload()
+        roof, segs = point_fwd_roofline(args, ls, max(args.steps, 10))
+        out["roofline"] = roof
+        out["kernel_ms"] = segs
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, args, 2 * args.batch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

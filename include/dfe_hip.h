@@ -150,6 +150,17 @@ long dfe_geom_maskpack_offset_bytes(const dfe_geom_args* args, int scale);
 int dfe_geom_loss_fwd(const dfe_geom_args* args, void* stream);
 int dfe_geom_loss_bwd(const dfe_geom_args* args, void* stream);
 
+/* Diagnostic variants used by bench.py: identical launches with a hipEvent recorded on `stream`
+ * between them; they synchronise on the last event and return the per-segment durations in
+ * milliseconds in `ms_host` (host array).  Forward segments: 0 cameras+epipolar prep, 1 pyramids,
+ * 2 k_geom_point_fwd (warp stage), 3 k_geom_ssim_fwd, 4 flow smoothness, 5 disparity smoothness,
+ * 6 finalize.  Backward segments: 0 k_geom_ssim_bwd, 1 k_geom_point_bwd, 2 flow smoothness,
+ * 3 disparity smoothness stage 1, 4 stage 2, 5 pose finalize. */
+#define DFE_GEOM_FWD_SEGMENTS 7
+#define DFE_GEOM_BWD_SEGMENTS 6
+int dfe_geom_loss_fwd_profiled(const dfe_geom_args* args, void* stream, float* ms_host);
+int dfe_geom_loss_bwd_profiled(const dfe_geom_args* args, void* stream, float* ms_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,8 @@ _SIGNATURES = {
     "dfe_geom_maskpack_offset_bytes": [_P, _I],
     "dfe_geom_loss_fwd": [_P, _P],
     "dfe_geom_loss_bwd": [_P, _P],
+    "dfe_geom_loss_fwd_profiled": [_P, _P, _P],
+    "dfe_geom_loss_bwd_profiled": [_P, _P, _P],
 }
 _RESTYPES = {"dfe_error_string": ctypes.c_char_p, "dfe_geom_workspace_floats": ctypes.c_long,
              "dfe_geom_maskpack_offset_bytes": ctypes.c_long}

@@ -60,13 +60,20 @@ __device__ __forceinline__ float tap_cover(const Tap& t) {
 
 struct Corners { float nw, ne, sw, se; };
 
-__device__ __forceinline__ Corners load_corners(const float* __restrict__ plane, const Tap& t, int W) {
+// Branch-free: the four addresses are clamped into the plane and loaded unconditionally (so the
+// loads of all corners and channels issue back to back under one wait), then zeroed by the
+// in-bounds flags -- same values as ATen's masked gather.
+__device__ __forceinline__ Corners load_corners(const float* __restrict__ plane, const Tap& t, int W, int H) {
   Corners c;
-  const float* p = plane + static_cast<long>(t.y0) * W + t.x0;
-  c.nw = t.in_nw ? p[0] : 0.0f;
-  c.ne = t.in_ne ? p[1] : 0.0f;
-  c.sw = t.in_sw ? p[W] : 0.0f;
-  c.se = t.in_se ? p[W + 1] : 0.0f;
+  const int xa = min(max(t.x0, 0), W - 1), xb = min(max(t.x0 + 1, 0), W - 1);
+  const int ya = min(max(t.y0, 0), H - 1), yb = min(max(t.y0 + 1, 0), H - 1);
+  const float* r0 = plane + static_cast<long>(ya) * W;
+  const float* r1 = plane + static_cast<long>(yb) * W;
+  const float v00 = r0[xa], v01 = r0[xb], v10 = r1[xa], v11 = r1[xb];
+  c.nw = t.in_nw ? v00 : 0.0f;
+  c.ne = t.in_ne ? v01 : 0.0f;
+  c.sw = t.in_sw ? v10 : 0.0f;
+  c.se = t.in_se ? v11 : 0.0f;
   return c;
 }
 
@@ -246,9 +253,21 @@ __device__ __forceinline__ float resize_bilinear_at(const float* __restrict__ pl
 }
 
 // ---------------------------------------------------------------- reductions
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, DFE_WAVE);
+// Wave64 sum with DPP adds (no LDS traffic): quad butterflies, row mirrors, then the gfx9
+// row_bcast15 / row_bcast31 steps.  The total is valid in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+  return v + __int_as_float(moved);
+}
+
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xF>(v);   // row_half_mirror
+  v = dpp_add<0x140, 0xF>(v);   // row_mirror  -> every lane holds its row (16 lanes) sum
+  v = dpp_add<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3 -> lane 63 holds the wave sum
   return v;
 }
 
@@ -259,8 +278,8 @@ __device__ __forceinline__ void block_sum(float (&vals)[N], float* smem, float* 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    float s = wave_sum(vals[i]);
-    if (lane == 0) smem[wave * N + i] = s;
+    float s = wave_sum_to_lane63(vals[i]);
+    if (lane == 63) smem[wave * N + i] = s;
   }
   __syncthreads();
   if (threadIdx.x < N) {

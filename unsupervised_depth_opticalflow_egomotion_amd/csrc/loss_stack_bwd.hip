@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(GS_TX * GS_TY) k_geom_ssim_bwd(GeomDev D, Geom
             const float u = sx[c][ly + dy][lx + dx], w = sy[c][ly + dy][lx + dx];
             a += u; bq += w; aa += u * u; bb += w * w; ab += u * w;
           }
-        const float mx = a / 9.0f, my = bq / 9.0f, exx = aa / 9.0f, eyy = bb / 9.0f, exy = ab / 9.0f;
+        const float r9 = 1.0f / 9.0f, mx = a * r9, my = bq * r9, exx = aa * r9, eyy = bb * r9, exy = ab * r9;
         const float v = (1.0f - ssim_from_means(mx, my, exx, eyy, exy)) / 2.0f;
         if (v >= 0.0f && v <= 1.0f) {   // clamp(.,0,1) passes gradient on the closed interval
           float d_mx, d_my, d_exx, d_eyy, d_exy;
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomBwd 
           float gix = 0.0f, giy = 0.0f;
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            Corners q = load_corners(src + static_cast<long>(c) * N, t, W);
+            Corners q = load_corners(src + static_cast<long>(c) * N, t, W, H);
             const float wv = interp(q, t);
             float dx, dy;
             interp_grad(q, t, dx, dy);
@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomBwd 
         float gix = 0.0f, giy = 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          Corners q = load_corners(ar + static_cast<long>(c) * N, t, W);
+          Corners q = load_corners(ar + static_cast<long>(c) * N, t, W, H);
           float dx, dy;
           interp_grad(q, t, dx, dy);
           const float g = sgn(interp(q, t) - im[c]) * gc;
@@ -355,18 +355,33 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_bwd2(GeomDev D, G
 }
 
 // ---------------------------------------------------------------------- pose finalize
-// One block per (b, d).  Thread t < S*12 reduces camera sum (s, i); threads S*12..S*12+8 reduce dF.
-__global__ void k_geom_pose_finalize(GeomDev D, GeomBwd G, float* __restrict__ gpose) {
+// One 256-thread block per (b, d).  Per scale, thread t accumulates rows k = t (mod 256) of the 21
+// columns (12 camera sums + 9 dF sums, the latter only at scale 0) in double; one thread per column
+// then adds the 256 per-thread sums in thread order (fixed order -> reproducible).
+__global__ void __launch_bounds__(256) k_geom_pose_finalize(GeomDev D, GeomBwd G, float* __restrict__ gpose) {
+  __shared__ double lds[256][PB_PER_DIR + 1];
   __shared__ double sm[DFE_MAX_SCALES * 12 + 9];
-  const int cam = blockIdx.x, b = cam >> 1, d = cam & 1, S = D.S;
+  const int cam = blockIdx.x, b = cam >> 1, d = cam & 1, S = D.S, t = threadIdx.x;
   const unsigned nblk_total = D.blk_start[S];
-  const int ncol = S * 12 + 9;
-  for (int t = threadIdx.x; t < ncol; t += blockDim.x) {
-    int s, col;
-    if (t < S * 12) { s = t / 12; col = d * PB_PER_DIR + (t - s * 12); } else { s = 0; col = d * PB_PER_DIR + 12 + (t - S * 12); }
-    double a = 0.0;
-    for (int k = D.blk_start[s]; k < D.blk_start[s + 1]; ++k) a += G.bpart[(static_cast<long>(b) * nblk_total + k) * PB_COUNT + col];
-    sm[t] = a;
+  for (int s = 0; s < S; ++s) {
+    double a[PB_PER_DIR];
+#pragma unroll
+    for (int i = 0; i < PB_PER_DIR; ++i) a[i] = 0.0;
+    for (int k = D.blk_start[s] + t; k < D.blk_start[s + 1]; k += 256) {
+      const float* r = G.bpart + (static_cast<long>(b) * nblk_total + k) * PB_COUNT + d * PB_PER_DIR;
+#pragma unroll
+      for (int i = 0; i < PB_PER_DIR; ++i) a[i] += r[i];
+    }
+#pragma unroll
+    for (int i = 0; i < PB_PER_DIR; ++i) lds[t][i] = a[i];
+    __syncthreads();
+    if (t < PB_PER_DIR) {
+      double v = 0.0;
+      for (int k = 0; k < 256; ++k) v += lds[k][t];
+      if (t < 12) sm[s * 12 + t] = v;
+      else if (s == 0) sm[S * 12 + (t - 12)] = v;
+    }
+    __syncthreads();
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
@@ -402,7 +417,7 @@ using namespace dfe;
 
 #define DFE_LAUNCH_CHECK() do { if (hipGetLastError() != hipSuccess) return DFE_ERR_LAUNCH; } while (0)
 
-extern "C" int dfe_geom_loss_bwd(const dfe_geom_args* a, void* stream) {
+static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   GeomLayout L;
   int rc = geom_layout(a, &L);
   if (rc != DFE_OK) return rc;
@@ -422,21 +437,46 @@ extern "C" int dfe_geom_loss_bwd(const dfe_geom_args* a, void* stream) {
     for (int d = 0; d < 2; ++d) G.gflow[d][s] = (s < L.S) ? a->grad_flow[d][s] : nullptr;
   }
   const unsigned nblk_total = L.blk_start[L.S], ntile_total = L.tile_start[L.S];
+  int seg = 0;
+#define DFE_MARK() do { if (ev) (void)hipEventRecord(ev[++seg], st); } while (0)
+  if (ev) (void)hipEventRecord(ev[0], st);
   k_geom_ssim_bwd<<<dim3(ntile_total, L.B * 2), GS_TX * GS_TY, 0, st>>>(D, G);
   DFE_LAUNCH_CHECK();
+  DFE_MARK();
   k_geom_point_bwd<<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, G);
   DFE_LAUNCH_CHECK();
+  DFE_MARK();
   k_geom_flow_smooth_bwd<<<dim3(nblk_total, 2 * L.B), GS_BLOCK, 0, st>>>(D, G);
   DFE_LAUNCH_CHECK();
+  DFE_MARK();
   k_geom_disp_smooth_bwd1<<<dim3(L.nblk0, 3 * L.B), GS_BLOCK, 0, st>>>(D, G);
   DFE_LAUNCH_CHECK();
+  DFE_MARK();
   if (L.S > 1) {
     k_geom_disp_smooth_bwd2<<<dim3(nblk_total - L.blk_start[1], 3 * L.B), GS_BLOCK, 0, st>>>(D, G);
     DFE_LAUNCH_CHECK();
   }
+  DFE_MARK();
   if (a->grad_pose) {
-    k_geom_pose_finalize<<<L.B * 2, 64, 0, st>>>(D, G, a->grad_pose);
+    k_geom_pose_finalize<<<L.B * 2, 256, 0, st>>>(D, G, a->grad_pose);
     DFE_LAUNCH_CHECK();
   }
+  DFE_MARK();
+#undef DFE_MARK
   return DFE_OK;
+}
+
+extern "C" int dfe_geom_loss_bwd(const dfe_geom_args* a, void* stream) { return geom_bwd_impl(a, stream, nullptr); }
+
+extern "C" int dfe_geom_loss_bwd_profiled(const dfe_geom_args* a, void* stream, float* ms_host) {
+  if (!ms_host) return DFE_ERR_NULL;
+  hipEvent_t ev[DFE_GEOM_BWD_SEGMENTS + 1];
+  for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return DFE_ERR_LAUNCH;
+  int rc = geom_bwd_impl(a, stream, ev);
+  if (rc == DFE_OK) {
+    (void)hipEventSynchronize(ev[DFE_GEOM_BWD_SEGMENTS]);
+    for (int i = 0; i < DFE_GEOM_BWD_SEGMENTS; ++i) (void)hipEventElapsedTime(&ms_host[i], ev[i], ev[i + 1]);
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
 }

@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, float* _
       const float keep = (tap_cover(t) < 0.9999f) ? 0.0f : 1.0f;
       const float* src = D.pyr[d == 0 ? 0 : 2][s] + static_cast<long>(b) * 3 * N;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) wv[d][c] = interp(load_corners(src + static_cast<long>(c) * N, t, W), t) * keep;
+      for (int c = 0; c < 3; ++c) wv[d][c] = interp(load_corners(src + static_cast<long>(c) * N, t, W, H), t) * keep;
       valid[d] = !(wv[d][0] == 0.0f && wv[d][1] == 0.0f && wv[d][2] == 0.0f);
       dif[d] = mean3_abs_diff(i0, i1, i2, wv[d][0], wv[d][1], wv[d][2]);
     }
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, float* _
       const float* ar = D.area[d][s] + static_cast<long>(b) * 3 * N;
       float rec[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) rec[c] = interp(load_corners(ar + static_cast<long>(c) * N, t, W), t);
+      for (int c = 0; c < 3; ++c) rec[c] = interp(load_corners(ar + static_cast<long>(c) * N, t, W, H), t);
       const float* sp = D.pyr[d == 0 ? 0 : 2][s];
       const float e_rec = mean3_abs_diff(i0, i1, i2, rec[0], rec[1], rec[2]);
       const float e_src = mean3_abs_diff(i0, i1, i2, sp[o3], sp[o3 + N], sp[o3 + 2 * N]);
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(GS_TX * GS_TY) k_geom_ssim_fwd(GeomDev D, floa
           const float u = sx[c][ty + dy][tx + dx], w = sy[c][ty + dy][tx + dx];
           a += u; bq += w; aa += u * u; bb += w * w; ab += u * w;
         }
-      const float ss = ssim_from_means(a / 9.0f, bq / 9.0f, aa / 9.0f, bb / 9.0f, ab / 9.0f);
+      const float ss = ssim_from_means(a * (1.0f / 9.0f), bq * (1.0f / 9.0f), aa * (1.0f / 9.0f), bb * (1.0f / 9.0f), ab * (1.0f / 9.0f));
       v += fminf(fmaxf((1.0f - ss) / 2.0f, 0.0f), 1.0f);
     }
   }
@@ -342,36 +342,64 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_fwd(GeomDev D, fl
 }
 
 // ---------------------------------------------------------------------- finalize
-// One block per sample.  Phase 1: thread (s,i) sums its partials in block order (double).
-// Phase 2: thread 0 assembles the eight loss values and the backward normalisers.
-__global__ void k_geom_finalize_fwd(GeomDev D, const float* __restrict__ part, const float* __restrict__ spart,
-                                    const float* __restrict__ fpart, const float* __restrict__ dpart, int nblk0,
-                                    float* __restrict__ sums, float* __restrict__ coef, float* __restrict__ dsum,
-                                    float* __restrict__ losses) {
+// One 256-thread block per sample.  Phase 1: thread t accumulates the partial rows k = t (mod 256)
+// of every column in double; phase 2: one thread per column adds the 256 per-thread sums in thread
+// order.  Both orders are fixed -> bitwise reproducible.  Thread 0 then assembles the eight loss
+// values and the normalisers the backward needs.
+__global__ void __launch_bounds__(256) k_geom_finalize_fwd(GeomDev D, const float* __restrict__ part,
+                                    const float* __restrict__ spart, const float* __restrict__ fpart,
+                                    const float* __restrict__ dpart, int nblk0, float* __restrict__ sums,
+                                    float* __restrict__ coef, float* __restrict__ dsum, float* __restrict__ losses) {
+  __shared__ double lds[256][SUM_COUNT + 1];
   __shared__ double sm[DFE_MAX_SCALES][SUM_COUNT];
   __shared__ double ds[3][2];
-  const int b = blockIdx.x, S = D.S, B = D.B;
+  const int b = blockIdx.x, S = D.S, B = D.B, t = threadIdx.x;
   const unsigned nblk_total = D.blk_start[S], ntile_total = D.tile_start[S];
-  for (int t = threadIdx.x; t < S * SUM_COUNT + 6; t += blockDim.x) {
-    double a = 0.0;
-    if (t < S * SUM_COUNT) {
-      const int s = t / SUM_COUNT, i = t - s * SUM_COUNT;
-      if (i < PT_COUNT) {
-        for (int k = D.blk_start[s]; k < D.blk_start[s + 1]; ++k) a += part[(static_cast<long>(b) * nblk_total + k) * PT_COUNT + i];
-      } else if (i < SUM_FS) {
-        const int d = i - SUM_SSIM;
-        for (int k = D.tile_start[s]; k < D.tile_start[s + 1]; ++k) a += spart[static_cast<long>(b * 2 + d) * ntile_total + k];
-      } else {
-        const int d = (i - SUM_FS) >> 1, xy = (i - SUM_FS) & 1;
-        for (int k = D.blk_start[s]; k < D.blk_start[s + 1]; ++k) a += fpart[(static_cast<long>(d * B + b) * nblk_total + k) * 2 + xy];
+  for (int s = 0; s < S; ++s) {
+    double a[SUM_COUNT];
+#pragma unroll
+    for (int i = 0; i < SUM_COUNT; ++i) a[i] = 0.0;
+    for (int k = D.blk_start[s] + t; k < D.blk_start[s + 1]; k += 256) {
+      const float* r = part + (static_cast<long>(b) * nblk_total + k) * PT_COUNT;
+#pragma unroll
+      for (int i = 0; i < PT_COUNT; ++i) a[i] += r[i];
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const float* q = fpart + (static_cast<long>(d * B + b) * nblk_total + k) * 2;
+        a[SUM_FS + 2 * d] += q[0]; a[SUM_FS + 2 * d + 1] += q[1];
       }
-      sm[s][i] = a;
-      sums[(static_cast<long>(b) * S + s) * SUM_COUNT + i] = static_cast<float>(a);
-    } else {
-      const int q = t - S * SUM_COUNT, f = q >> 1, xy = q & 1;
-      for (int k = 0; k < nblk0; ++k) a += dpart[(static_cast<long>(f * B + b) * nblk0 + k) * 2 + xy];
-      ds[f][xy] = a;
-      dsum[(f * B + b) * 2 + xy] = static_cast<float>(a);
+    }
+    for (int k = D.tile_start[s] + t; k < D.tile_start[s + 1]; k += 256) {
+      a[SUM_SSIM] += spart[static_cast<long>(b * 2) * ntile_total + k];
+      a[SUM_SSIM + 1] += spart[static_cast<long>(b * 2 + 1) * ntile_total + k];
+    }
+#pragma unroll
+    for (int i = 0; i < SUM_COUNT; ++i) lds[t][i] = a[i];
+    __syncthreads();
+    if (t < SUM_COUNT) {
+      double v = 0.0;
+      for (int k = 0; k < 256; ++k) v += lds[k][t];
+      sm[s][t] = v;
+      sums[(static_cast<long>(b) * S + s) * SUM_COUNT + t] = static_cast<float>(v);
+    }
+    __syncthreads();
+  }
+  {
+    double a[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = t; k < nblk0; k += 256)
+#pragma unroll
+      for (int f = 0; f < 3; ++f) {
+        const float* q = dpart + (static_cast<long>(f * B + b) * nblk0 + k) * 2;
+        a[f * 2] += q[0]; a[f * 2 + 1] += q[1];
+      }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) lds[t][i] = a[i];
+    __syncthreads();
+    if (t < 6) {
+      double v = 0.0;
+      for (int k = 0; k < 256; ++k) v += lds[k][t];
+      ds[t >> 1][t & 1] = v;
+      dsum[((t >> 1) * B + b) * 2 + (t & 1)] = static_cast<float>(v);
     }
   }
   __syncthreads();
@@ -454,7 +482,7 @@ long dfe_geom_maskpack_offset_bytes(const dfe_geom_args* args, int scale) {
   return L.o_mask * 4 + static_cast<long>(L.B) * L.off_px[scale];
 }
 
-int dfe_geom_loss_fwd(const dfe_geom_args* a, void* stream) {
+static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   GeomLayout L;
   int rc = geom_layout(a, &L);
   if (rc != DFE_OK) return rc;
@@ -464,6 +492,9 @@ int dfe_geom_loss_fwd(const dfe_geom_args* a, void* stream) {
   float* ws = a->workspace;
   GeomDev D;
   geom_dev(a, L, &D);
+  int seg = 0;
+#define DFE_MARK() do { if (ev) (void)hipEventRecord(ev[++seg], st); } while (0)
+  if (ev) (void)hipEventRecord(ev[0], st);
   // cameras: downscale = H / H_s as the reference computes it (float division of ints)
   float downs[DFE_MAX_SCALES];
   for (int s = 0; s < L.S; ++s) downs[s] = static_cast<float>(static_cast<double>(a->H) / static_cast<double>(L.H[s]));
@@ -471,6 +502,7 @@ int dfe_geom_loss_fwd(const dfe_geom_args* a, void* stream) {
   if (rc != DFE_OK) return rc;
   k_prepare_epi<<<(L.B * 2 + 63) / 64, 64, 0, st>>>(a->pose, a->K_inv, reinterpret_cast<Epi*>(ws + L.o_epi), D.cams, L.B, L.S);
   DFE_LAUNCH_CHECK();
+  DFE_MARK();
   if (L.S > 1) {
     PyrJobs jobs;
     jobs.n = 0; jobs.planes = L.B * 3; jobs.inH = a->H; jobs.inW = a->W;
@@ -484,19 +516,41 @@ int dfe_geom_loss_fwd(const dfe_geom_args* a, void* stream) {
     k_geom_pyramids<<<g, 256, 0, st>>>(jobs);
     DFE_LAUNCH_CHECK();
   }
+  DFE_MARK();
   const unsigned nblk_total = L.blk_start[L.S], ntile_total = L.tile_start[L.S];
   k_geom_point_fwd<<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
   DFE_LAUNCH_CHECK();
+  DFE_MARK();
   k_geom_ssim_fwd<<<dim3(ntile_total, L.B * 2), GS_TX * GS_TY, 0, st>>>(D, ws + L.o_spart);
   DFE_LAUNCH_CHECK();
+  DFE_MARK();
   k_geom_flow_smooth_fwd<<<dim3(nblk_total, 2 * L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_fpart);
   DFE_LAUNCH_CHECK();
+  DFE_MARK();
   k_geom_disp_smooth_fwd<<<dim3(L.nblk0, 3 * L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_dpart);
   DFE_LAUNCH_CHECK();
+  DFE_MARK();
   k_geom_finalize_fwd<<<L.B, 256, 0, st>>>(D, ws + L.o_part, ws + L.o_spart, ws + L.o_fpart, ws + L.o_dpart, L.nblk0,
                                          ws + L.o_sums, ws + L.o_coef, ws + L.o_dsum, a->losses);
   DFE_LAUNCH_CHECK();
+  DFE_MARK();
+#undef DFE_MARK
   return DFE_OK;
+}
+
+int dfe_geom_loss_fwd(const dfe_geom_args* a, void* stream) { return geom_fwd_impl(a, stream, nullptr); }
+
+int dfe_geom_loss_fwd_profiled(const dfe_geom_args* a, void* stream, float* ms_host) {
+  if (!ms_host) return DFE_ERR_NULL;
+  hipEvent_t ev[DFE_GEOM_FWD_SEGMENTS + 1];
+  for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return DFE_ERR_LAUNCH;
+  int rc = geom_fwd_impl(a, stream, ev);
+  if (rc == DFE_OK) {
+    (void)hipEventSynchronize(ev[DFE_GEOM_FWD_SEGMENTS]);
+    for (int i = 0; i < DFE_GEOM_FWD_SEGMENTS; ++i) (void)hipEventElapsedTime(&ms_host[i], ev[i], ev[i + 1]);
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
 }
 
 }  // extern "C"

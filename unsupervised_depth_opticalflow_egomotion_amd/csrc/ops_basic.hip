@@ -175,7 +175,7 @@ __global__ void k_warp_flow_fwd(const float* __restrict__ x, const float* __rest
   if (use_mask) keep = (tap_cover(t) < 0.9999f) ? 0.0f : 1.0f;
   for (int c = 0; c < C; ++c) {
     const float* plane = x + (static_cast<long>(b) * C + c) * HW;
-    Corners q = load_corners(plane, t, W);
+    Corners q = load_corners(plane, t, W, H);
     out[(static_cast<long>(b) * C + c) * HW + p] = interp(q, t) * keep;
   }
 }
@@ -199,7 +199,7 @@ __global__ void k_warp_flow_bwd(const float* __restrict__ x, const float* __rest
     const long off = (static_cast<long>(b) * C + c) * HW;
     float g = gout[off + p] * keep;
     if (gflow) {
-      Corners q = load_corners(x + off, t, W);
+      Corners q = load_corners(x + off, t, W, H);
       float dx, dy;
       interp_grad(q, t, dx, dy);
       gix += g * dx; giy += g * dy;
@@ -236,11 +236,11 @@ __global__ void k_inverse_warp2_fwd(const float* __restrict__ img, const float* 
   Tap t = make_tap(unnormalize(xn, W, ac), unnormalize(yn, H, ac), H, W);
   for (int c = 0; c < 3; ++c) {
     const float* plane = img + (static_cast<long>(b) * 3 + c) * HW;
-    out_img[(static_cast<long>(b) * 3 + c) * HW + p] = interp(load_corners(plane, t, W), t);
+    out_img[(static_cast<long>(b) * 3 + c) * HW + p] = interp(load_corners(plane, t, W, H), t);
   }
   if (out_valid) out_valid[static_cast<long>(b) * HW + p] = (fmaxf(fabsf(xn), fabsf(yn)) <= 1.0f) ? 1.0f : 0.0f;
   if (out_pdepth) {
-    float v = interp(load_corners(ref_depth + static_cast<long>(b) * HW, t, W), t);
+    float v = interp(load_corners(ref_depth + static_cast<long>(b) * HW, t, W, H), t);
     out_pdepth[static_cast<long>(b) * HW + p] = (v >= 1e-3f || v != v) ? v : 1e-3f;
   }
   if (out_cdepth) out_cdepth[static_cast<long>(b) * HW + p] = pr.Z;
@@ -273,13 +273,13 @@ __global__ void k_inverse_warp2_bwd(const float* __restrict__ img, const float* 
       for (int c = 0; c < 3; ++c) {
         const long off = (static_cast<long>(b) * 3 + c) * HW;
         float dx, dy;
-        interp_grad(load_corners(img + off, t, W), t, dx, dy);
+        interp_grad(load_corners(img + off, t, W, H), t, dx, dy);
         float g = g_img[off + p];
         gix += g * dx; giy += g * dy;
       }
     }
     if (g_pdepth) {
-      Corners q = load_corners(ref_depth + static_cast<long>(b) * HW, t, W);
+      Corners q = load_corners(ref_depth + static_cast<long>(b) * HW, t, W, H);
       float v = interp(q, t);
       float g = (v >= 1e-3f) ? g_pdepth[static_cast<long>(b) * HW + p] : 0.0f;
       float dx, dy;
