@@ -401,7 +401,69 @@ def gen_g8(ref, out):
         grad_summary(out, "flow_gflow_f_%d" % s, ff[s], stride=31)
 
 
-GENERATORS = dict(G1=gen_g1, G2=gen_g2, G3=gen_g3, G4=gen_g4, G5=gen_g5, G6=gen_g6, G8=gen_g8)
+# ------------------------------------------------------------------------------------ G7 (real nets)
+def closed_form_state(model, scale=0.02):
+    """Fill every parameter/buffer with a closed-form function of (key, flat index) so that the reference
+    model here and the build's model on the GPU box hold identical weights without shipping 86 MB."""
+    import zlib
+    sd = model.state_dict()
+    out = {}
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked"):
+            out[k] = torch.zeros_like(v)
+        elif k.endswith("running_mean"):
+            out[k] = torch.zeros_like(v)
+        elif k.endswith("running_var"):
+            out[k] = torch.ones_like(v)
+        elif ".bn" in k or "downsample.1" in k:
+            out[k] = torch.ones_like(v) if k.endswith("weight") else torch.zeros_like(v)
+        else:
+            n = v.numel()
+            phase = float(zlib.crc32(k.encode()) % 97)
+            idx = torch.arange(n, dtype=torch.float64)
+            fan = max(n // max(v.shape[0], 1), 1)
+            amp = scale if k.endswith("bias") else min(1.0, 1.7 / np.sqrt(fan))
+            out[k] = (amp * torch.sin(0.37 * idx + phase)).float().view_as(v)
+    model.load_state_dict(out)
+    return out
+
+
+def g7_cfg():
+    return types.SimpleNamespace(dataset="kitti_depth", num_scales=3, flow_consist_alpha=0.01, flow_consist_beta=0.5,
+                                 num_input_frames=3, geometric_ratio=0.3, geometric_num=6000, pose_beta=1, mode="geom")
+
+
+def g7_inputs():
+    images, k_ms, ki_ms = synthetic.make_triplet_batch(1, 256, 832, 3, seed=707)
+    return T(images), T(k_ms), T(ki_ms)
+
+
+def gen_g7(ref, out):
+    m = ref["Model_geometry"](g7_cfg())
+    closed_form_state(m)
+    out["state_keys"] = np.array(list(m.state_dict().keys()))
+    out["state_shapes"] = np.array([str(tuple(v.shape)) for v in m.state_dict().values()])
+    images, k_ms, ki_ms = g7_inputs()
+    m.train()
+    torch.manual_seed(0)
+    lp, mp = m([images, k_ms, ki_ms])
+    for k, v in lp.items():
+        out["train_" + k] = N(v)
+    m.eval()
+    h = 256
+    img_l, img, img_r = images[:, :, :h], images[:, :, h:2 * h], images[:, :, 2 * h:]
+    with torch.no_grad():
+        d = m.infer_depth(img)
+        p = m.infer_pose(torch.cat([img_l, img, img_r], 1))
+        f = m.inference_flow(img, img_r)
+    out["eval_depth_stats"] = np.array([float(d.mean()), float(d.std()), float(d.min()), float(d.max())])
+    out["eval_depth_crop"] = N(d[0, 0, 100:108, 400:408])
+    out["eval_pose"] = N(p)
+    out["eval_flow_stats"] = np.array([float(f.mean()), float(f.std()), float(f.abs().max())])
+    out["eval_flow_crop"] = N(f[0, :, 100:108, 400:408])
+
+
+GENERATORS = dict(G1=gen_g1, G2=gen_g2, G3=gen_g3, G4=gen_g4, G5=gen_g5, G6=gen_g6, G7=gen_g7, G8=gen_g8)
 AC_INDEPENDENT = {"G3", "G4"}   # no grid_sample inside
 
 

@@ -1,0 +1,249 @@
+"""``Model_geometry`` / ``Model_depth`` / ``Model_flow`` and ``get_model`` with the reference's API surface
+(core/networks/__init__.py:22-30, model_geometry.py, model_depth.py, model_flow.py).
+
+forward(inputs) with inputs = [images [B,3,3H,W] (left/target/right stacked along H), K_ms [B,S,3,3],
+K_inv_ms [B,S,3,3]] returns (loss_pack, mask_pack) (Model_flow returns them too -- the shipped
+Model_flow.forward raises NameError and returns one value where train.py:172 unpacks two; fixed here).
+Sub-module names and state-dict keys are the reference's.  The joint model's loss stack runs as the fused
+HIP launches of loss_stack.py; the networks run on PyTorch-ROCm."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .loss_stack import geom_loss_stack
+from .loss_terms import LossTerms
+from .networks import Depth_Model, PoseCNN, FeaturePyramid, PWC_tf
+
+PLACEHOLDER_KEYS_GEOM = ("loss_depth_ssim", "loss_depth_consis", "loss_triangle", "loss_pnp", "loss_eight_point")
+LOSS_ORDER_GEOM = ("loss_depth_pixel", "loss_depth_ssim", "loss_depth_smooth", "loss_depth_consis", "loss_flow_pixel",
+                   "loss_flow_ssim", "loss_flow_smooth", "loss_flow_consis", "loss_depth_flow_consis", "loss_epipolar",
+                   "loss_triangle", "loss_pnp", "loss_eight_point")
+
+
+class LazyPack(dict):
+    """dict whose values are produced on first access.  The reference builds ``mask_pack`` with nine
+    ``.cpu().numpy()`` calls every iteration (model_geometry.py:871-880), a forced device sync per step;
+    the keys and value types are kept, the device->host copies happen only when a value is read."""
+
+    def __init__(self, thunks):
+        super().__init__()
+        self._thunks = dict(thunks)
+        for k in self._thunks:
+            dict.__setitem__(self, k, None)
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        if v is None and k in self._thunks:
+            v = self._thunks.pop(k)()
+            dict.__setitem__(self, k, v)
+        return v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+
+def _split_frames(images):
+    assert images.shape[1] == 3
+    h = int(images.shape[2] / 3)
+    return images[:, :, :h, :], images[:, :, h:2 * h, :], images[:, :, 2 * h:3 * h, :], h, images.shape[3]
+
+
+def _zeros2(dev):
+    return torch.zeros([2]).to(dev).requires_grad_()
+
+
+class Model_geometry(LossTerms, nn.Module):
+    """Joint depth + pose + flow model ("monodepth2 + dynamic mask", model_geometry.py:15-953)."""
+
+    def __init__(self, cfg):
+        nn.Module.__init__(self)
+        self.dataset = cfg.dataset
+        self.num_scales = cfg.num_scales
+        self.flow_consist_alpha = cfg.flow_consist_alpha
+        self.flow_consist_beta = cfg.flow_consist_beta
+        self.depth_net = Depth_Model(cfg.num_scales)
+        self.pose_net = PoseCNN(cfg.num_input_frames)
+        self.fpyramid = FeaturePyramid()
+        self.pwc_model = PWC_tf()
+        self.inlier_thres = 0.1
+        self.rigid_thres = 0.5
+        self.ratio = getattr(cfg, "geometric_ratio", 0.3)
+        self.num = getattr(cfg, "geometric_num", 6000)
+        self.beta = getattr(cfg, "pose_beta", 1)
+
+    # ---- inference API (model_geometry.py:282-302)
+    def infer_depth(self, img):
+        return self.disp2depth(self.depth_net(img)[0])
+
+    def inference_flow(self, img1, img2):
+        hw = [img1.shape[2], img1.shape[3]]
+        return self.pwc_model(self.fpyramid(img1), self.fpyramid(img2), hw)[0]
+
+    def infer_pose(self, imgs):
+        return self.pose_net(imgs)
+
+    def run_networks(self, img_l, img, img_r):
+        """model_geometry.py:781-795.  depth_net is called once per frame (BatchNorm statistics per call)."""
+        h, w = img.shape[2], img.shape[3]
+        disp_l, disp_t, disp_r = self.depth_net(img_l), self.depth_net(img), self.depth_net(img_r)
+        pose = self.pose_net(torch.cat([img_l, img, img_r], 1))
+        f_l, f_t, f_r = self.fpyramid(img_l), self.fpyramid(img), self.fpyramid(img_r)
+        flows_bwd = self.pwc_model(f_t, f_l, [h, w])
+        flows_fwd = self.pwc_model(f_t, f_r, [h, w])
+        return disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd
+
+    def forward(self, inputs):
+        images, K_ms, K_inv_ms = inputs
+        K, K_inv = K_ms[:, 0, :, :], K_inv_ms[:, 0, :, :]
+        img_l, img, img_r, h, w = _split_frames(images)
+        img_l, img, img_r = img_l.contiguous(), img.contiguous(), img_r.contiguous()
+        disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd = self.run_networks(img_l, img, img_r)
+        return self.loss_stack(img_l, img, img_r, disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd, K, K_inv)
+
+    def loss_stack(self, img_l, img, img_r, disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd, K, K_inv):
+        """Everything from model_geometry.py:797 to :951 -> (loss_pack, mask_pack)."""
+        S = self.num_scales
+        active, masks = geom_loss_stack(img_l, img, img_r, disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd,
+                                        K.contiguous(), K_inv.contiguous(), num_scales=S,
+                                        flow_consist_alpha=self.flow_consist_alpha,
+                                        flow_consist_beta=self.flow_consist_beta, return_masks=True)
+        dev = img.device
+        loss_pack = {k: (active[k] if k in active else _zeros2(dev)) for k in LOSS_ORDER_GEOM}
+
+        def u8(t):
+            return lambda: 255 * t.detach().cpu().numpy().astype(np.uint8)
+
+        def epi_masks(which):
+            def run():
+                with torch.no_grad():
+                    dist = self.compute_epipolar_map(pose[:, 1].detach(), flows_fwd[0].detach(), K, K_inv)
+                    rigid, inlier, _ = self.get_rigid_mask(dist)
+                return 255 * (rigid if which == 0 else inlier)[0].cpu().numpy().astype(np.uint8)
+            return run
+
+        def valid_to_r():
+            with torch.no_grad():
+                from .structures import inverse_warp2
+                v = inverse_warp2(img_r, disp_t[0].detach(), disp_r[0].detach(), pose[:, 1].detach().contiguous(), K)[1]
+            return 255 * v[0].cpu().numpy().astype(np.uint8)
+
+        fwd_mask = masks["valid_fwd"][0] * masks["occ_fwd"][0] * masks["dyna_fwd"][0]
+        mask_pack = LazyPack({
+            "occ_fwd_mask": u8(masks["occ_fwd"][0][0]),
+            "rigid_fwd_mask": epi_masks(0),
+            "inlier_fwd_mask": epi_masks(1),
+            "dyna_fwd_mask": u8(masks["dyna_fwd"][0][0]),
+            "valid_fwd_mask": valid_to_r,
+            "fwd_mask": u8(fwd_mask[0]),
+            "texture_mask_fwd": u8(masks["texture_fwd"][0][0]),
+            "pred_depth_img": lambda: disp_t[0][0],
+            "pred_flow_img": lambda: flows_fwd[0][0].detach().cpu().numpy().transpose([1, 2, 0]),
+            "origin_middle_image": lambda: img[0].cpu().detach().numpy(),
+        })
+        return loss_pack, mask_pack
+
+
+class Model_depth(LossTerms, nn.Module):
+    """Depth + pose only (model_depth.py:272-337): pixel + smoothness terms; per-operator HIP kernels."""
+
+    def __init__(self, cfg):
+        nn.Module.__init__(self)
+        self.dataset = cfg.dataset
+        self.num_scales = cfg.num_scales
+        self.depth_net = Depth_Model(cfg.num_scales)
+        self.pose_net = PoseCNN(cfg.num_input_frames)
+
+    def infer_depth(self, img):
+        return self.disp2depth(self.depth_net(img)[0])
+
+    def infer_pose(self, imgs):
+        return self.pose_net(imgs)
+
+    def fusion_mask(self, valid_mask, texture_mask):
+        return [valid_mask[s] * texture_mask[s] for s in range(self.num_scales)]
+
+    def forward(self, inputs):
+        images, K_ms, K_inv_ms = inputs
+        K = K_ms[:, 0, :, :]
+        img_l, img, img_r, h, w = _split_frames(images)
+        img_l, img, img_r = img_l.contiguous(), img.contiguous(), img_r.contiguous()
+        depth_l, depth_t, depth_r = self.depth_net(img_l), self.depth_net(img), self.depth_net(img_r)
+        pose = self.pose_net(torch.cat([img_l, img, img_r], 1))
+        return self.loss_stack(img_l, img, img_r, depth_l, depth_t, depth_r, pose, K)
+
+    def loss_stack(self, img_l, img, img_r, depth_l, depth_t, depth_r, pose, K):
+        S = self.num_scales
+        pyr_t, pyr_l, pyr_r = (self.generate_img_pyramid(x, S) for x in (img, img_l, img_r))
+        rec_l, valid_l, _, _ = self.reconstruction(img_l, K, depth_t, depth_l, pose[:, 0, :].contiguous())
+        rec_r, valid_r, _, _ = self.reconstruction(img_r, K, depth_t, depth_r, pose[:, 1, :].contiguous())
+        tex_b = self.compute_texture_mask(pyr_t, rec_l, pyr_l)
+        tex_f = self.compute_texture_mask(pyr_t, rec_r, pyr_r)
+        m_b, m_f = self.fusion_mask(valid_l, tex_b), self.fusion_mask(valid_r, tex_f)
+        dev = img.device
+        loss_pack = {
+            "loss_depth_pixel": self.compute_photometric_loss(pyr_t, rec_l, m_b) + self.compute_photometric_loss(pyr_t, rec_r, m_f),
+            "loss_depth_ssim": _zeros2(dev),
+            "loss_depth_smooth": self.compute_smooth_loss(img, depth_t) + self.compute_smooth_loss(img_l, depth_l)
+            + self.compute_smooth_loss(img_r, depth_r),
+            "loss_depth_consis": _zeros2(dev),
+        }
+        return loss_pack, {}
+
+
+class Model_flow(LossTerms, nn.Module):
+    """Flow only (model_flow.py:14-261): soft occlusion weights, box-mean pyramid."""
+
+    def __init__(self, cfg):
+        nn.Module.__init__(self)
+        self.fpyramid = FeaturePyramid()
+        self.pwc_model = PWC_tf()
+        if getattr(cfg, "mode", "flow") in ("depth", "flowposenet"):
+            for p in list(self.fpyramid.parameters()) + list(self.pwc_model.parameters()):
+                p.requires_grad = False
+        self.dataset = cfg.dataset
+        self.num_scales = cfg.num_scales
+        # the shipped class reads cfg.h_flow_consist_* which the YAML does not define (model_flow.py:29-30)
+        self.flow_consist_alpha = getattr(cfg, "h_flow_consist_alpha", getattr(cfg, "flow_consist_alpha", 0.01))
+        self.flow_consist_beta = getattr(cfg, "h_flow_consist_beta", getattr(cfg, "flow_consist_beta", 0.5))
+
+    def inference_flow(self, img1, img2):
+        hw = [img1.shape[2], img1.shape[3]]
+        return self.pwc_model(self.fpyramid(img1), self.fpyramid(img2), hw)[0]
+
+    def forward(self, inputs):
+        images = inputs[0]
+        img_l, img, img_r, h, w = _split_frames(images)
+        img_l, img, img_r = img_l.contiguous(), img.contiguous(), img_r.contiguous()
+        f_l, f_t, f_r = self.fpyramid(img_l), self.fpyramid(img), self.fpyramid(img_r)
+        flows_bwd = self.pwc_model(f_t, f_l, [h, w])
+        flows_fwd = self.pwc_model(f_t, f_r, [h, w])
+        return self.loss_stack(img_l, img, img_r, flows_bwd, flows_fwd)
+
+    def loss_stack(self, img_l, img, img_r, flows_bwd, flows_fwd):
+        n = len(flows_fwd)
+        pl, pt, pr = (self.generate_img_pyramid_avgpool(x, n) for x in (img_l, img, img_r))
+        warp_l, warp_r = self.warp_flow_pyramid(pl, flows_bwd), self.warp_flow_pyramid(pr, flows_fwd)
+        d_b, d_f, w_b, w_f = self.compute_diff_weight(warp_l, pt, warp_r)
+        loss_pack = {
+            "loss_flow_pixel": self.compute_loss_with_mask(d_f, w_f) + self.compute_loss_with_mask(d_b, w_b),
+            "loss_flow_ssim": self.compute_loss_ssim(pt, warp_r, w_f) + self.compute_loss_ssim(pt, warp_l, w_b),
+            "loss_flow_smooth": self.compute_loss_flow_smooth(flows_fwd, pt) + self.compute_loss_flow_smooth(flows_bwd, pt),
+            "loss_flow_consis": self.compute_loss_flow_consis(flows_fwd, flows_bwd, w_f),
+        }
+        return loss_pack, {}
+
+
+def get_model(mode):
+    if mode == "flow":
+        return Model_flow
+    elif mode == "depth":
+        return Model_depth
+    elif mode == "geom":
+        return Model_geometry
+    raise ValueError("Mode {} not found.".format(mode))

@@ -1,0 +1,94 @@
+"""DepthNet: monodepth2-style ResNet-18 encoder + skip decoder (reference depth_model.py:60-211).
+Sigmoid disparities at ``depth_scale`` scales, finest first."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import resnet
+
+
+class ResnetEncoder(nn.Module):
+    def __init__(self, num_layers=18, pretrained=False):
+        super().__init__()
+        if num_layers not in (18, 34):
+            raise ValueError("{} is not a valid number of resnet layers".format(num_layers))
+        self.num_ch_enc = np.array([64, 64, 128, 256, 512])
+        self.encoder = {18: resnet.resnet18, 34: resnet.resnet34}[num_layers](pretrained)
+
+    def forward(self, image):
+        e = self.encoder
+        x = (image - 0.45) / 0.225
+        f0 = e.relu(e.bn1(e.conv1(x)))
+        f1 = e.layer1(e.maxpool(f0))
+        f2 = e.layer2(f1)
+        f3 = e.layer3(f2)
+        f4 = e.layer4(f3)
+        return [f0, f1, f2, f3, f4]
+
+
+class Conv3x3(nn.Module):
+    """Reflection-pad + 3x3 conv (key: ``.conv``)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.pad = nn.ReflectionPad2d(1)
+        self.conv = nn.Conv2d(int(cin), int(cout), 3)
+
+    def forward(self, x):
+        return self.conv(self.pad(x))
+
+
+class ConvBlock(nn.Module):
+    """Conv3x3 + ELU (key: ``.conv.conv``)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = Conv3x3(cin, cout)
+        self.nonlin = nn.ELU(inplace=True)
+
+    def forward(self, x):
+        return self.nonlin(self.conv(x))
+
+
+class DepthDecoder(nn.Module):
+    def __init__(self, num_ch_enc, scales=range(4)):
+        super().__init__()
+        self.scales = list(scales)
+        self.num_ch_enc = num_ch_enc
+        self.num_ch_dec = np.array([16, 32, 64, 128, 256])
+        self.upconvs = nn.ModuleList()
+        for i in range(4, -1, -1):
+            cin = num_ch_enc[-1] if i == 4 else self.num_ch_dec[i + 1]
+            pair = nn.ModuleList([ConvBlock(cin, self.num_ch_dec[i])])
+            cin2 = self.num_ch_dec[i] + (num_ch_enc[i - 1] if i > 0 else 0)
+            pair.append(ConvBlock(cin2, self.num_ch_dec[i]))
+            self.upconvs.append(pair)
+        self.dispconvs = nn.ModuleList([Conv3x3(self.num_ch_dec[s], 1) for s in self.scales])
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, feats):
+        out = {}
+        x = feats[-1]
+        for scale in range(4, -1, -1):
+            blk = self.upconvs[4 - scale]
+            x = blk[0](x)
+            x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+            if scale > 0:
+                x = torch.cat([x, feats[scale - 1]], 1)
+            x = blk[1](x)
+            if scale in self.scales:
+                out[scale] = self.sigmoid(self.dispconvs[self.scales.index(scale)](x))
+        return out
+
+
+class Depth_Model(nn.Module):
+    def __init__(self, depth_scale, num_layers=18):
+        super().__init__()
+        self.depth_scale = depth_scale
+        self.encoder = ResnetEncoder(num_layers=num_layers, pretrained=False)
+        self.decoder = DepthDecoder(self.encoder.num_ch_enc, scales=range(depth_scale))
+
+    def forward(self, img):
+        out = self.decoder(self.encoder(img))
+        return [out[i] for i in range(self.depth_scale)]

@@ -1,0 +1,45 @@
+"""PoseCNN with the attention refinement head (reference pose_cnn.py:14-93).  Output [B, F-1, 6];
+index 0 = target->left ("bwd"), 1 = target->right ("fwd").  The three Linear(14,14) layers act over
+H/128 * W/128 positions, i.e. the net only accepts 256x832-like inputs (pose_cnn.py:37-39)."""
+import torch
+import torch.nn as nn
+
+
+class PoseCNN(nn.Module):
+    def __init__(self, num_input_frames):
+        super().__init__()
+        self.num_input_frames = num_input_frames
+        n = 6 * (num_input_frames - 1)
+        chans = [(3 * num_input_frames, 16, 7), (16, 32, 5), (32, 64, 3), (64, 128, 3), (128, 256, 3),
+                 (256, 256, 3), (256, 256, 3)]
+        convs = [nn.Conv2d(ci, co, k, 2, k // 2) for ci, co, k in chans]
+        # registration order follows the reference (pose_conv before net): parameter order is what
+        # optimizer_state_dict indexes, so resumed checkpoints stay compatible
+        self.pose_conv = nn.Conv2d(256, n, 1)
+        self.relu = nn.ReLU(True)
+        self.net = nn.ModuleList(convs)
+        self.query_fc = nn.Linear(14, 14)
+        self.key_fc = nn.Linear(14, 14)
+        self.value_fc = nn.Linear(14, 14)
+        self.refine_net = nn.ModuleList([nn.Conv2d(2 * n, n, 1, 1, 0), nn.Conv2d(n, n, 3, 1, 1),
+                                         nn.Conv2d(n, n, 3, 1, 1), nn.Conv2d(n, n, 3, 1, 1)])
+        self.refine_pose_conv = nn.Conv2d(n, n, 1)
+
+    def atten_refine(self, x):
+        B, C, H, W = x.size()
+        flat = x.view(B, C, H * W)
+        q, k, v = self.query_fc(flat), self.key_fc(flat), self.value_fc(flat)
+        attn = torch.softmax(torch.bmm(q, k.permute(0, 2, 1)), 1)
+        out = torch.cat([flat, torch.bmm(attn, v)], 1).view(B, 2 * C, H, W)
+        for conv in self.refine_net:
+            out = self.relu(conv(out))
+        out = self.refine_pose_conv(out).mean(3).mean(2)
+        return 0.01 * out.view(-1, self.num_input_frames - 1, 6)
+
+    def forward(self, x):
+        for conv in self.net:
+            x = self.relu(conv(x))
+        x = self.pose_conv(x)
+        delta = self.atten_refine(x)
+        x = x.mean(3).mean(2)
+        return 0.01 * x.view(-1, self.num_input_frames - 1, 6) + delta

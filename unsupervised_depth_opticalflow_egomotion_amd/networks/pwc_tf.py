@@ -1,0 +1,72 @@
+"""PWC-style coarse-to-fine flow decoder (reference pwc_tf.py:16-179).  The per-level feature warp and
+the 81-tap cost volume run the HIP kernels (k_warp_flow_*, k_corr_*); the convolutions run on MIOpen.
+Needs H and W divisible by 64."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..structures.net_utils import conv, warp_flow
+
+
+class PWC_tf(nn.Module):
+    def __init__(self, md=4):
+        super().__init__()
+        self.md = md
+        self.corr = self.corr_naive
+        self.leakyRELU = nn.LeakyReLU(0.1)
+        nd = (2 * md + 1) ** 2
+        dd = [128, 128, 96, 64, 32]
+        feat = {6: 0, 5: 128, 4: 96, 3: 64, 2: 32}
+        for lvl in (6, 5, 4, 3, 2):
+            od = nd + (feat[lvl] + 2 if lvl < 6 else 0)
+            setattr(self, "conv%d_0" % lvl, conv(od, 128, kernel_size=3, stride=1))
+            setattr(self, "conv%d_1" % lvl, conv(dd[0], 128, kernel_size=3, stride=1))
+            setattr(self, "conv%d_2" % lvl, conv(dd[0] + dd[1], 96, kernel_size=3, stride=1))
+            setattr(self, "conv%d_3" % lvl, conv(dd[1] + dd[2], 64, kernel_size=3, stride=1))
+            setattr(self, "conv%d_4" % lvl, conv(dd[2] + dd[3], 32, kernel_size=3, stride=1))
+            setattr(self, "predict_flow%d" % lvl, self.predict_flow(dd[3] + dd[4]))
+        self.dc_conv1 = conv(dd[4] + 2, 128, kernel_size=3, stride=1, padding=1, dilation=1)
+        self.dc_conv2 = conv(128, 128, kernel_size=3, stride=1, padding=2, dilation=2)
+        self.dc_conv3 = conv(128, 128, kernel_size=3, stride=1, padding=4, dilation=4)
+        self.dc_conv4 = conv(128, 96, kernel_size=3, stride=1, padding=8, dilation=8)
+        self.dc_conv5 = conv(96, 64, kernel_size=3, stride=1, padding=16, dilation=16)
+        self.dc_conv6 = conv(64, 32, kernel_size=3, stride=1, padding=1, dilation=1)
+        self.dc_conv7 = self.predict_flow(32)
+
+    def predict_flow(self, in_planes):
+        return nn.Conv2d(in_planes, 2, kernel_size=3, stride=1, padding=1, bias=True)
+
+    def warp(self, x, flow):
+        return warp_flow(x, flow, use_mask=False)
+
+    def corr_naive(self, input1, input2, d=4):
+        """81-displacement channel-mean correlation [B,(2d+1)^2,H,W] (HIP)."""
+        return ops.corr81(input1, input2, d)
+
+    def _decode(self, lvl, x):
+        x0 = getattr(self, "conv%d_0" % lvl)(x)
+        x1 = getattr(self, "conv%d_1" % lvl)(x0)
+        x2 = getattr(self, "conv%d_2" % lvl)(torch.cat((x0, x1), 1))
+        x3 = getattr(self, "conv%d_3" % lvl)(torch.cat((x1, x2), 1))
+        x4 = getattr(self, "conv%d_4" % lvl)(torch.cat((x2, x3), 1))
+        return getattr(self, "predict_flow%d" % lvl)(torch.cat((x3, x4), 1)), x4
+
+    def forward(self, feature_list_1, feature_list_2, img_hw):
+        c1 = dict(zip((1, 2, 3, 4, 5, 6), feature_list_1))
+        c2 = dict(zip((1, 2, 3, 4, 5, 6), feature_list_2))
+        flow, _ = self._decode(6, self.corr(c1[6], c2[6]))
+        flows = {6: flow}
+        x4 = None
+        for lvl in (5, 4, 3, 2):
+            up = F.interpolate(flows[lvl + 1], scale_factor=2.0, mode="bilinear", align_corners=False) * 2.0
+            cv = self.corr(c1[lvl], self.warp(c2[lvl], up))
+            delta, x4 = self._decode(lvl, torch.cat((cv, c1[lvl], up), 1))
+            flows[lvl] = delta + up
+        x = self.dc_conv4(self.dc_conv3(self.dc_conv2(self.dc_conv1(torch.cat([flows[2], x4], 1)))))
+        flows[2] = flows[2] + self.dc_conv7(self.dc_conv6(self.dc_conv5(x)))
+        h, w = img_hw[0], img_hw[1]
+        return [F.interpolate(flows[2] * 4.0, [h, w], mode="bilinear", align_corners=False),
+                F.interpolate(flows[3] * 4.0, [h // 2, w // 2], mode="bilinear", align_corners=False),
+                F.interpolate(flows[4] * 4.0, [h // 4, w // 4], mode="bilinear", align_corners=False),
+                F.interpolate(flows[5] * 4.0, [h // 8, w // 8], mode="bilinear", align_corners=False)]
