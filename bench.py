@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--workload", default="auto", choices=["auto", "train_step", "loss_stack"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--miopen-benchmark", type=int, default=0, help="torch.backends.cudnn.benchmark (MIOpen exhaustive find)")
     return ap.parse_args()
 
 
@@ -181,6 +182,7 @@ def cpu_baseline(wl, args, unit_pairs):
 
 def main():
     args = parse()
+    torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
     world, rank, local = init_dist(args)
     dev = torch.device("cuda", local)
     wl_name = args.workload

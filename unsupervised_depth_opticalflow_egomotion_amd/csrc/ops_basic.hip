@@ -11,6 +11,7 @@
 // accesses, LDS only where a tile is re-read (SSIM window, correlation window).
 #include "dfe_device.h"
 #include "dfe_internal.h"
+#include <cstdint>
 
 namespace dfe {
 
@@ -416,105 +417,139 @@ __global__ void k_ssim_bwd(const float* __restrict__ x, const float* __restrict_
 }
 
 // ====================================================================== correlation (d = 4, 81 taps)
-constexpr int CR_D = 4, CR_K = 2 * CR_D + 1, CR_TX = 32, CR_TY = 8, CR_CK = 8;
-constexpr int CR_LW = CR_TX + 2 * CR_D, CR_LH = CR_TY + 2 * CR_D;
+// out[b, i*9+j, y, x] = 1/C sum_c f1[b,c,y,x] * f2[b,c,y+i-4,x+j-4]   (zero outside; pwc_tf.py:97-106)
+// Bandwidth-bound (AI ~ 9 FLOP/B): no MFMA.  Parallelism comes from the displacement rows: one thread
+// owns (b, dy, y, 4 consecutive x) -> 36 outputs, and per channel reads one float4 of f1 and a 12-float
+// window of the f2 row (3 aligned float4): 36 FMAs per 4 vector loads, fully coalesced, no LDS and no
+// barriers (the coarsest PWC level is 4x13 px -- a tile/LDS formulation leaves 252 of 256 CUs idle).
+// W % 4 != 0 (levels 8x26, 4x13) takes the scalar instantiation V = 1.
+constexpr int CR_D = 4, CR_K = 2 * CR_D + 1;
 
-// stage `nch` channel planes of `src` (tile origin x0,y0, halo CR_D, zero outside) into LDS
-__device__ __forceinline__ void corr_stage(float (*tile)[CR_LH][CR_LW], const float* __restrict__ src, int c0, int nch,
-                                           int C, int H, int W, int x0, int y0) {
-  const int per = CR_LH * CR_LW;
-  for (int i = threadIdx.x; i < nch * per; i += blockDim.x) {
-    int c = i / per, r = i - c * per;
-    int ly = r / CR_LW, lx = r - ly * CR_LW;
-    int gy = y0 + ly - CR_D, gx = x0 + lx - CR_D;
-    bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-    tile[c][ly][lx] = in ? src[(static_cast<long>(c0 + c) * H + gy) * W + gx] : 0.0f;
+template <int V>
+__device__ __forceinline__ void load_window(const float* __restrict__ row, int x0, int W, bool row_ok, float (&w)[V + 2 * CR_D]) {
+  // w[m] = row[x0 - 4 + m], zero outside [0, W)
+  if (V == 4) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int xs = x0 - 4 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row_ok && xs >= 0 && xs < W) v = *reinterpret_cast<const float4*>(row + xs);
+      w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < V + 2 * CR_D; ++m) {
+      const int xs = x0 - CR_D + m;
+      w[m] = (row_ok && xs >= 0 && xs < W) ? row[xs] : 0.0f;
+    }
   }
 }
 
+template <int V>
 __global__ void __launch_bounds__(256) k_corr_fwd(const float* __restrict__ f1, const float* __restrict__ f2,
-                                                  float* __restrict__ out, int C, int H, int W) {
-  __shared__ float tile[CR_CK][CR_LH][CR_LW];
-  const int b = blockIdx.z, x0 = blockIdx.x * CR_TX, y0 = blockIdx.y * CR_TY;
-  const int tx = threadIdx.x % CR_TX, ty = threadIdx.x / CR_TX;
-  const int gx = x0 + tx, gy = y0 + ty;
-  const bool live = gx < W && gy < H;
+                                                  float* __restrict__ out, int B, int C, int H, int W) {
+  const int WQ = (W + V - 1) / V;
+  const long total = static_cast<long>(B) * CR_K * H * WQ;
+  const long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int xq = static_cast<int>(t % WQ), y = static_cast<int>((t / WQ) % H);
+  const int i = static_cast<int>((t / (static_cast<long>(WQ) * H)) % CR_K), b = static_cast<int>(t / (static_cast<long>(WQ) * H * CR_K));
+  const int x0 = xq * V, r = y + i - CR_D;
+  const bool row_ok = r >= 0 && r < H;
   const long HW = static_cast<long>(H) * W;
-  const float* f1b = f1 + static_cast<long>(b) * C * HW;
-  const float* f2b = f2 + static_cast<long>(b) * C * HW;
-  float acc[CR_K * CR_K];
+  const float* p1 = f1 + static_cast<long>(b) * C * HW + static_cast<long>(y) * W + x0;
+  const float* p2 = f2 + static_cast<long>(b) * C * HW + static_cast<long>(row_ok ? r : 0) * W;
+  float acc[V][CR_K];
 #pragma unroll
-  for (int k = 0; k < CR_K * CR_K; ++k) acc[k] = 0.0f;
-  for (int c0 = 0; c0 < C; c0 += CR_CK) {
-    const int nch = min(CR_CK, C - c0);
-    __syncthreads();
-    corr_stage(tile, f2b, c0, nch, C, H, W, x0, y0);
-    __syncthreads();
-    if (live) {
+  for (int u = 0; u < V; ++u)
+#pragma unroll
+    for (int j = 0; j < CR_K; ++j) acc[u][j] = 0.0f;
+  if (row_ok) {
+    for (int c = 0; c < C; ++c) {
+      float a[V], w[V + 2 * CR_D];
+      if (V == 4) { float4 v = *reinterpret_cast<const float4*>(p1 + c * HW); a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
+      else a[0] = p1[c * HW];
+      load_window<V>(p2 + c * HW, x0, W, true, w);
+#pragma unroll
+      for (int u = 0; u < V; ++u)
+#pragma unroll
+        for (int j = 0; j < CR_K; ++j) acc[u][j] += a[u] * w[u + j];
+    }
+  }
+  const float fc = static_cast<float>(C);
+  float* o = out + (static_cast<long>(b) * CR_K * CR_K + i * CR_K) * HW + static_cast<long>(y) * W + x0;
+#pragma unroll
+  for (int j = 0; j < CR_K; ++j) {
+    if (V == 4) *reinterpret_cast<float4*>(o + j * HW) = make_float4(acc[0][j] / fc, acc[1][j] / fc, acc[2][j] / fc, acc[3][j] / fc);
+    else o[j * HW] = acc[0][j] / fc;
+  }
+}
+
+// g1[c,p] = 1/C sum_{i,j} g[i*9+j, p] * f2[c, p + (i-4, j-4)]          (MODE 0, other = f2)
+// g2[c,p] = 1/C sum_{i,j} g[i*9+j, p - (i-4,j-4)] * f1[c, p - (i-4,j-4)]  (MODE 1, other = f1)
+// One thread owns (b, chunk of CK channels, y, V consecutive x).  Per displacement row it holds the 9 (MODE 0)
+// gradient vectors or streams the 9 gradient windows (MODE 1) and re-uses them across the CK channels.
+constexpr int CR_CK = 8;
+
+template <int V, int MODE>
+__global__ void __launch_bounds__(256) k_corr_bwd(const float* __restrict__ other, const float* __restrict__ gout,
+                                                  float* __restrict__ gin, int B, int C, int H, int W) {
+  const int WQ = (W + V - 1) / V, NCH = (C + CR_CK - 1) / CR_CK;
+  const long total = static_cast<long>(B) * NCH * H * WQ;
+  const long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int xq = static_cast<int>(t % WQ), y = static_cast<int>((t / WQ) % H);
+  const int ch = static_cast<int>((t / (static_cast<long>(WQ) * H)) % NCH), b = static_cast<int>(t / (static_cast<long>(WQ) * H * NCH));
+  const int x0 = xq * V, c0 = ch * CR_CK, nch = min(CR_CK, C - c0);
+  const long HW = static_cast<long>(H) * W;
+  const float* ob = other + (static_cast<long>(b) * C + c0) * HW;
+  const float* gb = gout + static_cast<long>(b) * CR_K * CR_K * HW;
+  float acc[CR_CK][V];
+#pragma unroll
+  for (int c = 0; c < CR_CK; ++c)
+#pragma unroll
+    for (int u = 0; u < V; ++u) acc[c][u] = 0.0f;
+#pragma unroll 1
+  for (int i = 0; i < CR_K; ++i) {
+    const int r = (MODE == 0) ? y + i - CR_D : y - (i - CR_D);
+    if (r < 0 || r >= H) continue;
+    if (MODE == 0) {
+      float g[CR_K][V];
+#pragma unroll
+      for (int j = 0; j < CR_K; ++j) {
+        const float* gp = gb + (i * CR_K + j) * HW + static_cast<long>(y) * W + x0;
+        if (V == 4) { float4 v = *reinterpret_cast<const float4*>(gp); g[j][0] = v.x; g[j][1] = v.y; g[j][2] = v.z; g[j][3] = v.w; }
+        else g[j][0] = gp[0];
+      }
       for (int c = 0; c < nch; ++c) {
-        const float a = f1b[(c0 + c) * HW + static_cast<long>(gy) * W + gx];
+        float w[V + 2 * CR_D];
+        load_window<V>(ob + c * HW + static_cast<long>(r) * W, x0, W, true, w);
 #pragma unroll
-        for (int i = 0; i < CR_K; ++i)
+        for (int u = 0; u < V; ++u)
 #pragma unroll
-          for (int j = 0; j < CR_K; ++j) acc[i * CR_K + j] += a * tile[c][ty + i][tx + j];
+          for (int j = 0; j < CR_K; ++j) acc[c][u] += g[j][u] * w[u + j];
+      }
+    } else {
+      float w[CR_CK][V + 2 * CR_D];
+#pragma unroll
+      for (int c = 0; c < CR_CK; ++c) load_window<V>(ob + (c < nch ? c : 0) * HW + static_cast<long>(r) * W, x0, W, c < nch, w[c]);
+#pragma unroll
+      for (int j = 0; j < CR_K; ++j) {
+        float gw[V + 2 * CR_D];
+        load_window<V>(gb + (i * CR_K + j) * HW + static_cast<long>(r) * W, x0, W, true, gw);
+        // source column q = x - (j-4)  ->  window index m = u - j + 8
+#pragma unroll
+        for (int c = 0; c < CR_CK; ++c)
+#pragma unroll
+          for (int u = 0; u < V; ++u) acc[c][u] += gw[u - j + 2 * CR_D] * w[c][u - j + 2 * CR_D];
       }
     }
   }
-  if (!live) return;
-  float* o = out + static_cast<long>(b) * CR_K * CR_K * HW + static_cast<long>(gy) * W + gx;
   const float fc = static_cast<float>(C);
-#pragma unroll
-  for (int k = 0; k < CR_K * CR_K; ++k) o[k * HW] = acc[k] / fc;
-}
-
-// MODE 0: g1[c,p] = 1/C sum_k g[k,p] * f2pad[c, p + off_k]   (other = f2, taps read at +off)
-// MODE 1: g2[c,p] = 1/C sum_k g[k,p - off_k] * f1[c, p - off_k]  (other = f1, taps read at -off)
-template <int MODE>
-__global__ void __launch_bounds__(256) k_corr_bwd(const float* __restrict__ other, const float* __restrict__ gout,
-                                                  float* __restrict__ gin, int C, int H, int W) {
-  __shared__ float tile[CR_CK][CR_LH][CR_LW];
-  const int b = blockIdx.z, x0 = blockIdx.x * CR_TX, y0 = blockIdx.y * CR_TY;
-  const int tx = threadIdx.x % CR_TX, ty = threadIdx.x / CR_TX;
-  const int gx = x0 + tx, gy = y0 + ty;
-  const bool live = gx < W && gy < H;
-  const long HW = static_cast<long>(H) * W;
-  const float* ob = other + static_cast<long>(b) * C * HW;
-  const float* gb = gout + static_cast<long>(b) * CR_K * CR_K * HW;
-  float g[CR_K * CR_K];
-#pragma unroll
-  for (int i = 0; i < CR_K; ++i)
-#pragma unroll
-    for (int j = 0; j < CR_K; ++j) {
-      float v = 0.0f;
-      if (live) {
-        if (MODE == 0) {
-          v = gb[(i * CR_K + j) * HW + static_cast<long>(gy) * W + gx];
-        } else {
-          int sy = gy - (i - CR_D), sx = gx - (j - CR_D);
-          if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = gb[(i * CR_K + j) * HW + static_cast<long>(sy) * W + sx];
-        }
-      }
-      g[i * CR_K + j] = v;
-    }
-  const float fc = static_cast<float>(C);
-  for (int c0 = 0; c0 < C; c0 += CR_CK) {
-    const int nch = min(CR_CK, C - c0);
-    __syncthreads();
-    corr_stage(tile, ob, c0, nch, C, H, W, x0, y0);
-    __syncthreads();
-    if (live) {
-      for (int c = 0; c < nch; ++c) {
-        float a = 0.0f;
-#pragma unroll
-        for (int i = 0; i < CR_K; ++i)
-#pragma unroll
-          for (int j = 0; j < CR_K; ++j) {
-            float t = (MODE == 0) ? tile[c][ty + i][tx + j] : tile[c][ty + 2 * CR_D - i][tx + 2 * CR_D - j];
-            a += g[i * CR_K + j] * t;
-          }
-        gin[static_cast<long>(b) * C * HW + (c0 + c) * HW + static_cast<long>(gy) * W + gx] = a / fc;
-      }
-    }
+  for (int c = 0; c < nch; ++c) {
+    float* o = gin + (static_cast<long>(b) * C + c0 + c) * HW + static_cast<long>(y) * W + x0;
+    if (V == 4) *reinterpret_cast<float4*>(o) = make_float4(acc[c][0] / fc, acc[c][1] / fc, acc[c][2] / fc, acc[c][3] / fc);
+    else o[0] = acc[c][0] / fc;
   }
 }
 
@@ -680,12 +715,23 @@ int dfe_ssim_bwd(const float* x, const float* y, const float* gout, float* gx, f
   return DFE_OK;
 }
 
+static inline bool corr_vec_ok(const void* a, const void* b, const void* c, int W) {
+  auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return (W % 4 == 0) && al(a) && al(b) && al(c);
+}
+
 int dfe_corr_fwd(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int d, void* stream) {
   DFE_REQUIRE(f1 && f2 && out, DFE_ERR_NULL);
-  DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && B <= 65535, DFE_ERR_DIMS);
+  DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
   DFE_REQUIRE(d == CR_D, DFE_ERR_UNSUPPORTED);
-  dim3 g((W + CR_TX - 1) / CR_TX, (H + CR_TY - 1) / CR_TY, B);
-  k_corr_fwd<<<g, 256, 0, static_cast<hipStream_t>(stream)>>>(f1, f2, out, C, H, W);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (corr_vec_ok(f1, f2, out, W)) {
+    long n = static_cast<long>(B) * CR_K * H * (W / 4);
+    k_corr_fwd<4><<<grid1d(n, 256), 256, 0, st>>>(f1, f2, out, B, C, H, W);
+  } else {
+    long n = static_cast<long>(B) * CR_K * H * W;
+    k_corr_fwd<1><<<grid1d(n, 256), 256, 0, st>>>(f1, f2, out, B, C, H, W);
+  }
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
@@ -693,12 +739,22 @@ int dfe_corr_fwd(const float* f1, const float* f2, float* out, int B, int C, int
 int dfe_corr_bwd(const float* f1, const float* f2, const float* gout, float* g1, float* g2, int B, int C, int H, int W,
                  int d, void* stream) {
   DFE_REQUIRE(f1 && f2 && gout && (g1 || g2), DFE_ERR_NULL);
-  DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && B <= 65535, DFE_ERR_DIMS);
+  DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
   DFE_REQUIRE(d == CR_D, DFE_ERR_UNSUPPORTED);
-  dim3 g((W + CR_TX - 1) / CR_TX, (H + CR_TY - 1) / CR_TY, B);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (g1) { k_corr_bwd<0><<<g, 256, 0, st>>>(f2, gout, g1, C, H, W); DFE_LAUNCH_CHECK(); }
-  if (g2) { k_corr_bwd<1><<<g, 256, 0, st>>>(f1, gout, g2, C, H, W); DFE_LAUNCH_CHECK(); }
+  const int nchunk = (C + CR_CK - 1) / CR_CK;
+  const bool vec = corr_vec_ok(f1, f2, gout, W) && corr_vec_ok(g1, g2, nullptr, W);
+  const long n = static_cast<long>(B) * nchunk * H * (vec ? W / 4 : W);
+  if (g1) {
+    if (vec) k_corr_bwd<4, 0><<<grid1d(n, 256), 256, 0, st>>>(f2, gout, g1, B, C, H, W);
+    else k_corr_bwd<1, 0><<<grid1d(n, 256), 256, 0, st>>>(f2, gout, g1, B, C, H, W);
+    DFE_LAUNCH_CHECK();
+  }
+  if (g2) {
+    if (vec) k_corr_bwd<4, 1><<<grid1d(n, 256), 256, 0, st>>>(f1, gout, g2, B, C, H, W);
+    else k_corr_bwd<1, 1><<<grid1d(n, 256), 256, 0, st>>>(f1, gout, g2, B, C, H, W);
+    DFE_LAUNCH_CHECK();
+  }
   return DFE_OK;
 }
 
