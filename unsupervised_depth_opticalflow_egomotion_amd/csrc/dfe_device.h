@@ -60,20 +60,28 @@ __device__ __forceinline__ float tap_cover(const Tap& t) {
 
 struct Corners { float nw, ne, sw, se; };
 
-// Branch-free: the four addresses are clamped into the plane and loaded unconditionally (so the
-// loads of all corners and channels issue back to back under one wait), then zeroed by the
-// in-bounds flags -- same values as ATen's masked gather.
+// Branch-free and pair-wise: each row of the 2x2 footprint is one dword-aligned 8-byte load at
+// xs = clamp(x0, 0, W-2) (memory-instruction count is what bounds these kernels: the texture-address unit
+// takes ~16 cycles per wave-wide load whatever its width); the values are then routed to (nw, ne) / (sw, se)
+// and zeroed by the in-bounds flags -- same values as ATen's masked gather.  W == 1 falls back to scalars.
+struct __attribute__((packed, aligned(4))) PairF { float a, b; };
+
 __device__ __forceinline__ Corners load_corners(const float* __restrict__ plane, const Tap& t, int W, int H) {
   Corners c;
-  const int xa = min(max(t.x0, 0), W - 1), xb = min(max(t.x0 + 1, 0), W - 1);
   const int ya = min(max(t.y0, 0), H - 1), yb = min(max(t.y0 + 1, 0), H - 1);
-  const float* r0 = plane + static_cast<long>(ya) * W;
-  const float* r1 = plane + static_cast<long>(yb) * W;
-  const float v00 = r0[xa], v01 = r0[xb], v10 = r1[xa], v11 = r1[xb];
-  c.nw = t.in_nw ? v00 : 0.0f;
-  c.ne = t.in_ne ? v01 : 0.0f;
-  c.sw = t.in_sw ? v10 : 0.0f;
-  c.se = t.in_se ? v11 : 0.0f;
+  if (W >= 2) {
+    const int xs = min(max(t.x0, 0), W - 2);
+    const bool lo = t.x0 < xs, hi = t.x0 > xs;
+    const PairF r0 = *reinterpret_cast<const PairF*>(plane + static_cast<long>(ya) * W + xs);
+    const PairF r1 = *reinterpret_cast<const PairF*>(plane + static_cast<long>(yb) * W + xs);
+    c.nw = t.in_nw ? (hi ? r0.b : r0.a) : 0.0f;
+    c.ne = t.in_ne ? (lo ? r0.a : r0.b) : 0.0f;
+    c.sw = t.in_sw ? (hi ? r1.b : r1.a) : 0.0f;
+    c.se = t.in_se ? (lo ? r1.a : r1.b) : 0.0f;
+  } else {
+    const float v0 = plane[static_cast<long>(ya) * W], v1 = plane[static_cast<long>(yb) * W];
+    c.nw = t.in_nw ? v0 : 0.0f; c.ne = 0.0f; c.sw = t.in_sw ? v1 : 0.0f; c.se = 0.0f;
+  }
   return c;
 }
 
@@ -92,12 +100,81 @@ __device__ __forceinline__ void interp_grad(const Corners& c, const Tap& t, floa
   diy = (c.sw - c.nw) * e + (c.se - c.ne) * t.wx;
 }
 
+// ---------------------------------------------------------------- exact division by a known divisor
+// Correctly rounded x / y in 3 instructions when r = RN(1/y) is available (Markstein): q = RN(x r);
+// q' = RN(q + RN(x - q y) r).  Bit-identical to IEEE division for the divisors used here (3, 20, W-1, H-1:
+// small integers, no all-ones significand) on normal-range operands; replaces ~11-instruction v_div_* chains.
+struct Divisor { float y, r; };
+__host__ __device__ __forceinline__ Divisor make_divisor(float y) { return Divisor{y, 1.0f / y}; }
+__device__ __forceinline__ float div_exact(float x, const Divisor d) {
+  const float q = x * d.r;
+  return __fmaf_rn(__fmaf_rn(-d.y, q, x), d.r, q);
+}
+
+// ---------------------------------------------------------------- fast forward-only bilinear tap
+// Same values as make_tap/load_corners/interp for finite inputs, fewer instructions: the coordinate is
+// clamped to [-2, size+1] first (everything outside is fully out of bounds either way), bounds are integer
+// compares, and the in-bounds mask is applied to the four WEIGHTS once instead of to 4 values per channel.
+// Horizontal corner pairs are adjacent in memory, so each row of the 2x2 footprint is ONE 8-byte load
+// (dword-aligned dwordx2): the texture-address unit handles 4 lanes/clk, i.e. a wave-wide load costs ~16 TA
+// cycles whatever its width, and the kernel is bound by the number of memory instructions (TA_BUSY 80 %).
+// The pair is fetched at xs = clamp(x0, 0, W-2); at the left/right border the in-bounds corner sits in the
+// other half of the pair, which is folded into the pair WEIGHTS (one of the two is zero there).
+struct FastTap { unsigned o0, o1; float wa0, wb0, wa1, wb1; };   // row y0: (a,b) pair weights, row y1 likewise
+
+__device__ __forceinline__ FastTap make_fast_tap(float ix, float iy, int H, int W) {
+  FastTap t;
+  ix = fminf(fmaxf(ix, -2.0f), static_cast<float>(W) + 1.0f);   // NaN -> -2 (out of bounds)
+  iy = fminf(fmaxf(iy, -2.0f), static_cast<float>(H) + 1.0f);
+  const float xw = floorf(ix), yn = floorf(iy);
+  const float w = ix - xw, e = 1.0f - w, n = iy - yn, s = 1.0f - n;
+  const int x0 = static_cast<int>(xw), y0 = static_cast<int>(yn);
+  const bool xin0 = static_cast<unsigned>(x0) < static_cast<unsigned>(W), xin1 = static_cast<unsigned>(x0 + 1) < static_cast<unsigned>(W);
+  const bool yin0 = static_cast<unsigned>(y0) < static_cast<unsigned>(H), yin1 = static_cast<unsigned>(y0 + 1) < static_cast<unsigned>(H);
+  // corner weights in ATen's order (nw, ne, sw, se), zeroed when out of bounds
+  const float nw = (xin0 && yin0) ? s * e : 0.0f, ne = (xin1 && yin0) ? s * w : 0.0f;
+  const float sw = (xin0 && yin1) ? n * e : 0.0f, se = (xin1 && yin1) ? n * w : 0.0f;
+  const int xs = min(max(x0, 0), W - 2);
+  // x0 == xs: pair = (x0, x1).  x0 < xs (x0 = -1): pair.a is x1.  x0 > xs (x0 = W-1): pair.b is x0.
+  const bool lo = x0 < xs, hi = x0 > xs;
+  t.wa0 = lo ? ne : (hi ? 0.0f : nw);  t.wb0 = lo ? 0.0f : (hi ? nw : ne);
+  t.wa1 = lo ? se : (hi ? 0.0f : sw);  t.wb1 = lo ? 0.0f : (hi ? sw : se);
+  const int ya = min(max(y0, 0), H - 1) * W, yb = min(max(y0 + 1, 0), H - 1) * W;
+  t.o0 = static_cast<unsigned>(ya + xs) * 4u;    // BYTE offsets (32-bit): scalar base + VGPR offset addressing
+  t.o1 = static_cast<unsigned>(yb + xs) * 4u;
+  return t;
+}
+// load a float at a 32-bit byte offset from a (block-uniform) base
+__device__ __forceinline__ float ldb(const float* __restrict__ base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void stb(float* __restrict__ base, unsigned byte_off, float v) {
+  *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+__device__ __forceinline__ float fast_cover(const FastTap& t) { return ((t.wa0 + t.wb0) + t.wa1) + t.wb1; }
+__device__ __forceinline__ float fast_sample(const float* __restrict__ plane, const FastTap& t) {
+  const PairF r0 = *reinterpret_cast<const PairF*>(reinterpret_cast<const char*>(plane) + t.o0);
+  const PairF r1 = *reinterpret_cast<const PairF*>(reinterpret_cast<const char*>(plane) + t.o1);
+  float r = r0.a * t.wa0;
+  r = __fmaf_rn(r0.b, t.wb0, r);
+  r = __fmaf_rn(r1.a, t.wa1, r);
+  r = __fmaf_rn(r1.b, t.wb1, r);
+  return r;
+}
+
 // ---------------------------------------------------------------- flow warp coordinates
 // net_utils.py:42-43: g = 2*(x+u)/max(W-1,1) - 1, then grid_sample's unnormalisation.
 __device__ __forceinline__ void flow_coords(int x, int y, float u, float v, int H, int W, int ac,
                                             float& ix, float& iy) {
   float gx = 2.0f * (static_cast<float>(x) + u) / static_cast<float>(W > 1 ? W - 1 : 1) - 1.0f;
   float gy = 2.0f * (static_cast<float>(y) + v) / static_cast<float>(H > 1 ? H - 1 : 1) - 1.0f;
+  ix = unnormalize(gx, W, ac);
+  iy = unnormalize(gy, H, ac);
+}
+__device__ __forceinline__ void flow_coords_d(int x, int y, float u, float v, int H, int W, int ac,
+                                              const Divisor dw, const Divisor dh, float& ix, float& iy) {
+  const float gx = div_exact(2.0f * (static_cast<float>(x) + u), dw) - 1.0f;
+  const float gy = div_exact(2.0f * (static_cast<float>(y) + v), dh) - 1.0f;
   ix = unnormalize(gx, W, ac);
   iy = unnormalize(gy, H, ac);
 }
@@ -159,6 +236,16 @@ __device__ __forceinline__ void rigid_grid(const Proj& p, int H, int W, float& x
   if (!live_y) yn = 2.0f;
 }
 
+__device__ __forceinline__ void rigid_grid_d(const Proj& p, const Divisor dw, const Divisor dh, float& xn, float& yn,
+                                             bool& live_x, bool& live_y) {
+  xn = div_exact(2.0f * p.U, dw) - 1.0f;
+  yn = div_exact(2.0f * p.V, dh) - 1.0f;
+  live_x = !((xn > 1.0f) || (xn < -1.0f));
+  live_y = !((yn > 1.0f) || (yn < -1.0f));
+  if (!live_x) xn = 2.0f;
+  if (!live_y) yn = 2.0f;
+}
+
 // Back-propagate (gU, gV) = dL/dU, dL/dV (and optionally gZ = dL/dZ) of one pixel to
 // depth and to the 12 camera sums (dL/db[3], dL/dA[9]) -- SURVEY.md A.3.
 __device__ __forceinline__ void project_backward(const Proj& p, float depth, float gU, float gV, float gZ,
@@ -176,7 +263,7 @@ __device__ __forceinline__ void project_backward(const Proj& p, float depth, flo
 
 // ---------------------------------------------------------------- mask decisions
 __device__ __forceinline__ float mean3_abs_diff(float a0, float a1, float a2, float b0, float b1, float b2) {
-  return ((fabsf(a0 - b0) + fabsf(a1 - b1)) + fabsf(a2 - b2)) / 3.0f;
+  return div_exact((fabsf(a0 - b0) + fabsf(a1 - b1)) + fabsf(a2 - b2), Divisor{3.0f, 1.0f / 3.0f});
 }
 
 // 1 - softmax([dl, dr]) > 0.48, evaluated through the softmax as the reference does
@@ -253,38 +340,37 @@ __device__ __forceinline__ float resize_bilinear_at(const float* __restrict__ pl
 }
 
 // ---------------------------------------------------------------- reductions
-// Wave64 sum with DPP adds (no LDS traffic): quad butterflies, row mirrors, then the gfx9
-// row_bcast15 / row_bcast31 steps.  The total is valid in lane 63.
-template <int CTRL, int ROW_MASK>
+// Block-wide sums of N per-thread values with DPP adds.  The N reductions are interleaved step-major (all
+// values take butterfly step k before any takes step k+1) so that the DPP read-after-write hazards are
+// covered by independent instructions instead of s_nop.  Four steps leave each row of 16 lanes holding
+// its row sum; one lane per row stores it to LDS and a final thread per value adds the 4*waves row sums
+// in a fixed order.  Result: out[0..N) written by threads 0..N-1.  smem: N * 4 * (blockDim.x/64) floats.
+template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
-  int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+  int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false);
   return v + __int_as_float(moved);
 }
 
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-  v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
-  v = dpp_add<0x141, 0xF>(v);   // row_half_mirror
-  v = dpp_add<0x140, 0xF>(v);   // row_mirror  -> every lane holds its row (16 lanes) sum
-  v = dpp_add<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
-  v = dpp_add<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3 -> lane 63 holds the wave sum
-  return v;
-}
-
-// Block-wide sum of N per-thread values; result valid in thread 0 (written to out[0..N)).
-// smem must hold N * (blockDim.x / 64) floats.
 template <int N>
 __device__ __forceinline__ void block_sum(float (&vals)[N], float* smem, float* out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    float s = wave_sum_to_lane63(vals[i]);
-    if (lane == 63) smem[wave * N + i] = s;
+  for (int i = 0; i < N; ++i) vals[i] = dpp_add<0xB1>(vals[i]);    // quad_perm [1,0,3,2]
+#pragma unroll
+  for (int i = 0; i < N; ++i) vals[i] = dpp_add<0x4E>(vals[i]);    // quad_perm [2,3,0,1]
+#pragma unroll
+  for (int i = 0; i < N; ++i) vals[i] = dpp_add<0x141>(vals[i]);   // row_half_mirror
+#pragma unroll
+  for (int i = 0; i < N; ++i) vals[i] = dpp_add<0x140>(vals[i]);   // row_mirror -> every lane holds its row sum
+  if ((lane & 15) == 0) {
+    const int slot = wave * 4 + (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < N; ++i) smem[slot * N + i] = vals[i];
   }
   __syncthreads();
   if (threadIdx.x < N) {
     float s = 0.0f;
-    for (int w = 0; w < nwaves; ++w) s += smem[w * N + threadIdx.x];
+    for (int w = 0; w < nwaves * 4; ++w) s += smem[w * N + threadIdx.x];
     out[threadIdx.x] = s;
   }
   __syncthreads();

@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(GS_TX * GS_TY) k_geom_ssim_bwd(GeomDev D, Geom
 
 // ---------------------------------------------------------------------- pointwise backward
 __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomBwd G) {
-  __shared__ float red[PB_COUNT * (GS_BLOCK / 64)];
+  __shared__ float red[PB_COUNT * 4 * (GS_BLOCK / 64)];
   const unsigned nblk_total = D.blk_start[D.S];
   const unsigned blk = xcd_swizzle(blockIdx.x, nblk_total);
   const int b = blockIdx.y, B = D.B;
@@ -249,6 +249,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_flow_smooth_bwd(GeomDev D, Ge
   const float g = G.gl[DFE_LOSS_FLOW_SMOOTH * D.B + b];
   const float cx = g / (2.0f * H * (W - 2.0f)) / 2.0f / 20.0f, cy = g / (2.0f * (H - 2.0f) * W) / 2.0f / 20.0f;
   float out[2] = {0.0f, 0.0f};
+  const Divisor D20{20.0f, 1.0f / 20.0f};
   const float kc[3] = {1.0f, -2.0f, 1.0f};   // coefficient of f(q) in the stencil starting at q, q-1, q-2
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -258,7 +259,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_flow_smooth_bwd(GeomDev D, Ge
       const float w = expf(-10.0f * mean3_abs_diff(it[q + 2], it[q + 2 + N], it[q + 2 + 2 * N], it[q + 1], it[q + 1 + N], it[q + 1 + 2 * N]));
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const float a0 = fl[c * N + q] / 20.0f, a1 = fl[c * N + q + 1] / 20.0f, a2 = fl[c * N + q + 2] / 20.0f;
+        const float a0 = div_exact(fl[c * N + q], D20), a1 = div_exact(fl[c * N + q + 1], D20), a2 = div_exact(fl[c * N + q + 2], D20);
         out[c] += cx * kc[k] * w * sgn((a2 - a1) - (a1 - a0));
       }
     }
@@ -268,7 +269,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_flow_smooth_bwd(GeomDev D, Ge
       const float w = expf(-10.0f * mean3_abs_diff(it[q2], it[q2 + N], it[q2 + 2 * N], it[q1], it[q1 + N], it[q1 + 2 * N]));
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const float a0 = fl[c * N + q] / 20.0f, a1 = fl[c * N + q1] / 20.0f, a2 = fl[c * N + q2] / 20.0f;
+        const float a0 = div_exact(fl[c * N + q], D20), a1 = div_exact(fl[c * N + q1], D20), a2 = div_exact(fl[c * N + q2], D20);
         out[c] += cy * kc[k] * w * sgn((a2 - a1) - (a1 - a0));
       }
     }

@@ -129,60 +129,67 @@ __global__ void k_geom_pyramids(PyrJobs jobs) {
 }
 
 // ---------------------------------------------------------------------- pointwise forward
+// VALU-issue-bound (profiles/r01b_pmc_loss_stack.json: 1 390 VALU instr per wave, 68 % VALU busy, FETCH+WRITE
+// = algorithmic bytes).  Everything that does not change a result bit is therefore written for instruction
+// count: exact 3-instruction divisions by the launch constants, integer bounds tests, masked bilinear
+// weights, 32-bit offsets from block-uniform bases (scalar base + VGPR offset addressing).
 __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, float* __restrict__ part) {
-  __shared__ float red[PT_COUNT * (GS_BLOCK / 64)];
+  __shared__ float red[PT_COUNT * 4 * (GS_BLOCK / 64)];
   const unsigned nblk_total = D.blk_start[D.S];
   const unsigned blk = xcd_swizzle(blockIdx.x, nblk_total);
   const int b = blockIdx.y;
   const int s = find_scale(D.blk_start, D.S, blk);
   const int H = D.H[s], W = D.W[s], N = D.N[s];
-  const int p = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
+  const unsigned p = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
   float acc[PT_COUNT];
 #pragma unroll
   for (int i = 0; i < PT_COUNT; ++i) acc[i] = 0.0f;
-  if (p < N) {
-    const int py = p / W, px = p - py * W;
-    const long o3 = static_cast<long>(b) * 3 * N + p, o2 = static_cast<long>(b) * 2 * N + p, o1 = static_cast<long>(b) * N + p;
-    const float* it = D.pyr[1][s];
-    const float i0 = it[o3], i1 = it[o3 + N], i2 = it[o3 + 2 * N];
+  if (p < static_cast<unsigned>(N)) {
+    const unsigned py = p / static_cast<unsigned>(W), px = p - py * W;
+    const unsigned p4 = p * 4u, N4 = static_cast<unsigned>(N) * 4u;
+    // block-uniform bases
+    const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
+    const float* dispt = D.disp[1][s] + static_cast<long>(b) * N;
+    const Divisor dw = make_divisor(static_cast<float>(W > 1 ? W - 1 : 1)), dh = make_divisor(static_cast<float>(H > 1 ? H - 1 : 1));
+    const float i0 = ldb(it, p4), i1 = ldb(it, p4 + N4), i2 = ldb(it, p4 + 2 * N4);
     float fu[2], fv[2], wv[2][3], dif[2];
     bool valid[2];
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
-      const float* fl = D.flow[d][s];
-      fu[d] = fl[o2]; fv[d] = fl[o2 + N];
+      const float* fl = D.flow[d][s] + static_cast<long>(b) * 2 * N;
+      fu[d] = ldb(fl, p4); fv[d] = ldb(fl, p4 + N4);
       float ix, iy;
-      flow_coords(px, py, fu[d], fv[d], H, W, D.ac, ix, iy);
-      Tap t = make_tap(ix, iy, H, W);
-      const float keep = (tap_cover(t) < 0.9999f) ? 0.0f : 1.0f;
+      flow_coords_d(px, py, fu[d], fv[d], H, W, D.ac, dw, dh, ix, iy);
+      const FastTap t = make_fast_tap(ix, iy, H, W);
+      const float keep = (fast_cover(t) < 0.9999f) ? 0.0f : 1.0f;
       const float* src = D.pyr[d == 0 ? 0 : 2][s] + static_cast<long>(b) * 3 * N;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) wv[d][c] = interp(load_corners(src + static_cast<long>(c) * N, t, W, H), t) * keep;
+      for (int c = 0; c < 3; ++c) wv[d][c] = fast_sample(src + static_cast<long>(c) * N, t) * keep;
       valid[d] = !(wv[d][0] == 0.0f && wv[d][1] == 0.0f && wv[d][2] == 0.0f);
       dif[d] = mean3_abs_diff(i0, i1, i2, wv[d][0], wv[d][1], wv[d][2]);
     }
     float wb, wf;
     occ_weights(dif[0], dif[1], wb, wf);
     const bool occ[2] = {wb > 0.48f, wf > 0.48f};
-    const float dsp = D.disp[1][s][o1];
+    const float dsp = ldb(dispt, p4);
     unsigned bits = 0;
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
       const Camera& cam = D.cams[(b * 2 + d) * D.S + s];
-      Proj pr = project(cam, px, py, dsp);
+      const Proj pr = project(cam, px, py, dsp);
       const float ru = pr.U - static_cast<float>(px), rv = pr.V - static_cast<float>(py);
       const float du = fabsf(ru - fu[d]), dv = fabsf(rv - fv[d]);
       const bool dyna = dyna_decision(fu[d], fv[d], ru, rv, du, dv, D.alpha, D.beta);
       float xn, yn; bool lx, ly;
-      rigid_grid(pr, H, W, xn, yn, lx, ly);
-      Tap t = make_tap(unnormalize(xn, W, D.ac), unnormalize(yn, H, D.ac), H, W);
+      rigid_grid_d(pr, make_divisor(static_cast<float>(W - 1)), make_divisor(static_cast<float>(H - 1)), xn, yn, lx, ly);
+      const FastTap t = make_fast_tap(unnormalize(xn, W, D.ac), unnormalize(yn, H, D.ac), H, W);
       const float* ar = D.area[d][s] + static_cast<long>(b) * 3 * N;
       float rec[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) rec[c] = interp(load_corners(ar + static_cast<long>(c) * N, t, W, H), t);
-      const float* sp = D.pyr[d == 0 ? 0 : 2][s];
+      for (int c = 0; c < 3; ++c) rec[c] = fast_sample(ar + static_cast<long>(c) * N, t);
+      const float* sp = D.pyr[d == 0 ? 0 : 2][s] + static_cast<long>(b) * 3 * N;
       const float e_rec = mean3_abs_diff(i0, i1, i2, rec[0], rec[1], rec[2]);
-      const float e_src = mean3_abs_diff(i0, i1, i2, sp[o3], sp[o3 + N], sp[o3 + 2 * N]);
+      const float e_src = mean3_abs_diff(i0, i1, i2, ldb(sp, p4), ldb(sp, p4 + N4), ldb(sp, p4 + 2 * N4));
       const bool tex = e_rec < e_src;
       const float vo = (valid[d] && occ[d]) ? 1.0f : 0.0f;
       const float m_rig = dyna ? vo : 0.0f, m_dyn = dyna ? 0.0f : vo;
@@ -206,10 +213,10 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, float* _
       }
       bits |= (valid[d] ? (DFE_MASK_VALID_BWD << d) : 0u) | (occ[d] ? (DFE_MASK_OCC_BWD << d) : 0u) |
               (dyna ? (DFE_MASK_DYNA_BWD << d) : 0u) | (tex ? (DFE_MASK_TEX_BWD << d) : 0u);
-      float* yw = D.yw[s] + (static_cast<long>(d) * D.B + b) * 3 * N + p;
-      yw[0] = wv[d][0] * vo; yw[N] = wv[d][1] * vo; yw[2 * N] = wv[d][2] * vo;
+      float* yw = D.yw[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
+      stb(yw, p4, wv[d][0] * vo); stb(yw, p4 + N4, wv[d][1] * vo); stb(yw, p4 + 2 * N4, wv[d][2] * vo);
     }
-    D.mask[s][o1] = static_cast<unsigned char>(bits);
+    (D.mask[s] + static_cast<long>(b) * N)[p] = static_cast<unsigned char>(bits);
     // flow consistency (model_geometry.py:195-210): |unit(fwd) + unit(bwd)| on (1 - occ_fwd)
     const float nf = l2norm2(fu[1], fv[1]), nb = l2norm2(fu[0], fv[0]);
     const float inv = occ[1] ? 0.0f : 1.0f;
@@ -223,7 +230,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, float* _
 // grid: x = tile over all scales, y = b*2 + d.  x = I * vo (mask bits), y = yw (already masked).
 __global__ void __launch_bounds__(GS_TX * GS_TY) k_geom_ssim_fwd(GeomDev D, float* __restrict__ spart) {
   __shared__ float sx[3][GS_TY + 2][GS_TX + 2], sy[3][GS_TY + 2][GS_TX + 2];
-  __shared__ float red[GS_TX * GS_TY / 64];
+  __shared__ float red[4 * GS_TX * GS_TY / 64];
   const unsigned ntile_total = D.tile_start[D.S];
   const unsigned tile = xcd_swizzle(blockIdx.x, ntile_total);
   const int b = blockIdx.y >> 1, d = blockIdx.y & 1;
@@ -272,7 +279,7 @@ __global__ void __launch_bounds__(GS_TX * GS_TY) k_geom_ssim_fwd(GeomDev D, floa
 // ---------------------------------------------------------------------- smoothness forward
 // Second-order flow smoothness on flow/20 (model_geometry.py:254-279).  grid.y = d*B + b.
 __global__ void __launch_bounds__(GS_BLOCK) k_geom_flow_smooth_fwd(GeomDev D, float* __restrict__ fpart) {
-  __shared__ float red[2 * (GS_BLOCK / 64)];
+  __shared__ float red[2 * 4 * (GS_BLOCK / 64)];
   const unsigned nblk_total = D.blk_start[D.S];
   const unsigned blk = blockIdx.x;
   const int d = blockIdx.y / D.B, b = blockIdx.y - d * D.B;
@@ -280,6 +287,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_flow_smooth_fwd(GeomDev D, fl
   const int H = D.H[s], W = D.W[s], N = D.N[s];
   const int p = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
   float acc[2] = {0.0f, 0.0f};
+  const Divisor D20{20.0f, 1.0f / 20.0f};
   if (p < N) {
     const int py = p / W, px = p - py * W;
     const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
@@ -288,7 +296,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_flow_smooth_fwd(GeomDev D, fl
       const float w = expf(-10.0f * mean3_abs_diff(it[p + 2], it[p + 2 + N], it[p + 2 + 2 * N], it[p + 1], it[p + 1 + N], it[p + 1 + 2 * N]));
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const float a0 = fl[c * N + p] / 20.0f, a1 = fl[c * N + p + 1] / 20.0f, a2 = fl[c * N + p + 2] / 20.0f;
+        const float a0 = div_exact(fl[c * N + p], D20), a1 = div_exact(fl[c * N + p + 1], D20), a2 = div_exact(fl[c * N + p + 2], D20);
         acc[0] += w * fabsf((a2 - a1) - (a1 - a0));
       }
     }
@@ -297,7 +305,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_flow_smooth_fwd(GeomDev D, fl
       const float w = expf(-10.0f * mean3_abs_diff(it[q2], it[q2 + N], it[q2 + 2 * N], it[q1], it[q1 + N], it[q1 + 2 * N]));
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const float a0 = fl[c * N + p] / 20.0f, a1 = fl[c * N + q1] / 20.0f, a2 = fl[c * N + q2] / 20.0f;
+        const float a0 = div_exact(fl[c * N + p], D20), a1 = div_exact(fl[c * N + q1], D20), a2 = div_exact(fl[c * N + q2], D20);
         acc[1] += w * fabsf((a2 - a1) - (a1 - a0));
       }
     }
@@ -308,7 +316,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_flow_smooth_fwd(GeomDev D, fl
 // First-order edge-aware disparity smoothness at full resolution, all scales fused
 // (model_geometry.py:225-252).  grid.y = f*B + b over the 3 frames.
 __global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_fwd(GeomDev D, float* __restrict__ dpart) {
-  __shared__ float red[2 * (GS_BLOCK / 64)];
+  __shared__ float red[2 * 4 * (GS_BLOCK / 64)];
   const int f = blockIdx.y / D.B, b = blockIdx.y - f * D.B;
   const int H = D.H[0], W = D.W[0], N = D.N[0];
   const int p = blockIdx.x * GS_BLOCK + threadIdx.x;

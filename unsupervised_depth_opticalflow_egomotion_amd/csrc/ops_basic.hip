@@ -255,7 +255,7 @@ __global__ void k_inverse_warp2_bwd(const float* __restrict__ img, const float* 
                                     const float* __restrict__ g_cdepth, float* __restrict__ g_depth,
                                     float* __restrict__ g_refdepth, float* __restrict__ partials,
                                     int H, int W, int ac) {
-  __shared__ float red[12 * 4];
+  __shared__ float red[12 * 16];
   const int b = blockIdx.y, HW = H * W;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   float acc[12];
@@ -320,7 +320,7 @@ __global__ void k_rigid_flow_fwd(const float* __restrict__ depth, const Camera* 
 __global__ void k_rigid_flow_bwd(const float* __restrict__ depth, const Camera* __restrict__ cams,
                                  const float* __restrict__ gout, float* __restrict__ g_depth,
                                  float* __restrict__ partials, int H, int W) {
-  __shared__ float red[12 * 4];
+  __shared__ float red[12 * 16];
   const int b = blockIdx.y, HW = H * W;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   float acc[12];

@@ -77,6 +77,15 @@ class Model_geometry(LossTerms, nn.Module):
         self.num = getattr(cfg, "geometric_num", 6000)
         self.beta = getattr(cfg, "pose_beta", 1)
 
+    def use_channels_last(self, flag=True):
+        """Run DepthNet / PoseNet in NHWC (MIOpen's igemm kernels are NHWC; avoids their transposes).  The loss
+        stack and the PWC warp/correlation kernels stay NCHW; C=1 disparities are layout-neutral."""
+        self._channels_last = bool(flag)
+        fmt = torch.channels_last if flag else torch.contiguous_format
+        self.depth_net.to(memory_format=fmt)
+        self.pose_net.to(memory_format=fmt)
+        return self
+
     # ---- inference API (model_geometry.py:282-302)
     def infer_depth(self, img):
         return self.disp2depth(self.depth_net(img)[0])
@@ -91,8 +100,13 @@ class Model_geometry(LossTerms, nn.Module):
     def run_networks(self, img_l, img, img_r):
         """model_geometry.py:781-795.  depth_net is called once per frame (BatchNorm statistics per call)."""
         h, w = img.shape[2], img.shape[3]
-        disp_l, disp_t, disp_r = self.depth_net(img_l), self.depth_net(img), self.depth_net(img_r)
-        pose = self.pose_net(torch.cat([img_l, img, img_r], 1))
+        if getattr(self, "_channels_last", False):
+            cl = torch.channels_last
+            disp_l, disp_t, disp_r = (self.depth_net(x.contiguous(memory_format=cl)) for x in (img_l, img, img_r))
+            pose = self.pose_net(torch.cat([img_l, img, img_r], 1).contiguous(memory_format=cl))
+        else:
+            disp_l, disp_t, disp_r = self.depth_net(img_l), self.depth_net(img), self.depth_net(img_r)
+            pose = self.pose_net(torch.cat([img_l, img, img_r], 1))
         f_l, f_t, f_r = self.fpyramid(img_l), self.fpyramid(img), self.fpyramid(img_r)
         flows_bwd = self.pwc_model(f_t, f_l, [h, w])
         flows_fwd = self.pwc_model(f_t, f_r, [h, w])

@@ -52,6 +52,9 @@ class TrainStepWorkload:
         self.cfg = make_cfg(num_scales=args.scales, img_hw=(args.height, args.width))
         torch.manual_seed(1234)           # identical initial weights on every rank
         self.model = get_model("geom")(self.cfg).to(dev)
+        import os
+        if os.environ.get("DFE_CHANNELS_LAST", "0") == "1":
+            self.model.use_channels_last(True)
         self.model.train()
         self.model = ddp.wrap(self.model, dev)
         params = [p for p in self.model.parameters() if p.requires_grad]
