@@ -124,24 +124,26 @@ struct FastTap { unsigned o0, o1; float wa0, wb0, wa1, wb1; };   // row y0: (a,b
 
 __device__ __forceinline__ FastTap make_fast_tap(float ix, float iy, int H, int W) {
   FastTap t;
-  ix = fminf(fmaxf(ix, -2.0f), static_cast<float>(W) + 1.0f);   // NaN -> -2 (out of bounds)
-  iy = fminf(fmaxf(iy, -2.0f), static_cast<float>(H) + 1.0f);
+  ix = __builtin_amdgcn_fmed3f(ix, -2.0f, static_cast<float>(W) + 1.0f);   // clamp (NaN -> out of bounds)
+  iy = __builtin_amdgcn_fmed3f(iy, -2.0f, static_cast<float>(H) + 1.0f);
   const float xw = floorf(ix), yn = floorf(iy);
   const float w = ix - xw, e = 1.0f - w, n = iy - yn, s = 1.0f - n;
   const int x0 = static_cast<int>(xw), y0 = static_cast<int>(yn);
-  const bool xin0 = static_cast<unsigned>(x0) < static_cast<unsigned>(W), xin1 = static_cast<unsigned>(x0 + 1) < static_cast<unsigned>(W);
-  const bool yin0 = static_cast<unsigned>(y0) < static_cast<unsigned>(H), yin1 = static_cast<unsigned>(y0 + 1) < static_cast<unsigned>(H);
-  // corner weights in ATen's order (nw, ne, sw, se), zeroed when out of bounds
-  const float nw = (xin0 && yin0) ? s * e : 0.0f, ne = (xin1 && yin0) ? s * w : 0.0f;
-  const float sw = (xin0 && yin1) ? n * e : 0.0f, se = (xin1 && yin1) ? n * w : 0.0f;
+  // ATen masks the products s*e, s*w, n*e, n*w; masking the non-negative factors first gives the same bits
+  const float wx0 = static_cast<unsigned>(x0) < static_cast<unsigned>(W) ? e : 0.0f;
+  const float wx1 = static_cast<unsigned>(x0 + 1) < static_cast<unsigned>(W) ? w : 0.0f;
+  const float wy0 = static_cast<unsigned>(y0) < static_cast<unsigned>(H) ? s : 0.0f;
+  const float wy1 = static_cast<unsigned>(y0 + 1) < static_cast<unsigned>(H) ? n : 0.0f;
+  // the pair is fetched at xs = clamp(x0, 0, W-2): at x0 = -1 or W-1 the single in-bounds corner sits in the
+  // other half of the pair (and the out-of-bounds weight is already 0) -> swap the two x weights
+  const bool swap = static_cast<unsigned>(x0) > static_cast<unsigned>(W - 2);
+  const float wa = swap ? wx1 : wx0, wb = swap ? wx0 : wx1;
+  t.wa0 = wy0 * wa; t.wb0 = wy0 * wb; t.wa1 = wy1 * wa; t.wb1 = wy1 * wb;
   const int xs = min(max(x0, 0), W - 2);
-  // x0 == xs: pair = (x0, x1).  x0 < xs (x0 = -1): pair.a is x1.  x0 > xs (x0 = W-1): pair.b is x0.
-  const bool lo = x0 < xs, hi = x0 > xs;
-  t.wa0 = lo ? ne : (hi ? 0.0f : nw);  t.wb0 = lo ? 0.0f : (hi ? nw : ne);
-  t.wa1 = lo ? se : (hi ? 0.0f : sw);  t.wb1 = lo ? 0.0f : (hi ? sw : se);
-  const int ya = min(max(y0, 0), H - 1) * W, yb = min(max(y0 + 1, 0), H - 1) * W;
-  t.o0 = static_cast<unsigned>(ya + xs) * 4u;    // BYTE offsets (32-bit): scalar base + VGPR offset addressing
-  t.o1 = static_cast<unsigned>(yb + xs) * 4u;
+  const int ya = min(max(y0, 0), H - 1), yb = min(max(y0 + 1, 0), H - 1);
+  // 24-bit multiplies (full rate): rows and widths are < 2^24
+  t.o0 = (__umul24(ya, W) + xs) * 4u;    // BYTE offsets (32-bit): scalar base + VGPR offset addressing
+  t.o1 = (__umul24(yb, W) + xs) * 4u;
   return t;
 }
 // load a float at a 32-bit byte offset from a (block-uniform) base
@@ -206,6 +208,9 @@ struct Proj {
 __device__ __forceinline__ Proj project(const Camera& c, int x, int y, float depth) {
   Proj p;
   float fx = static_cast<float>(x), fy = static_cast<float>(y);
+  // Plain multiply-add association, no FMA: with an identity pose the border pixels must project EXACTLY
+  // onto |grid| = 1 as they do in the reference (golden G2 "identity"); an FMA chain lands 1 ulp outside and
+  // flips the validity of the whole border ring.
   p.r0 = c.kinv[0] * fx + c.kinv[1] * fy + c.kinv[2];
   p.r1 = c.kinv[3] * fx + c.kinv[4] * fy + c.kinv[5];
   p.r2 = c.kinv[6] * fx + c.kinv[7] * fy + c.kinv[8];
@@ -269,9 +274,10 @@ __device__ __forceinline__ float mean3_abs_diff(float a0, float a1, float a2, fl
 // 1 - softmax([dl, dr]) > 0.48, evaluated through the softmax as the reference does
 // (model_geometry.py:119-130).  Returns soft weights too (Model_flow uses them).
 __device__ __forceinline__ void occ_weights(float dl, float dr, float& w_bwd, float& w_fwd) {
-  float m = fmaxf(dl, dr);
-  float el = expf(dl - m), er = expf(dr - m);
-  float sum = el + er;
+  // softmax([dl, dr]): exp(x - max) is exactly 1 for the larger entry, so only one exp is evaluated
+  const float tt = expf(-fabsf(dl - dr));
+  const float el = (dl >= dr) ? 1.0f : tt, er = (dr >= dl) ? 1.0f : tt;
+  const float sum = el + er;
   w_bwd = 1.0f - el / sum;
   w_fwd = 1.0f - er / sum;
 }

@@ -31,6 +31,8 @@ struct GeomLayout {
   int nblk[DFE_MAX_SCALES], blk_start[DFE_MAX_SCALES + 1];      // pointwise blocks per image
   int ntile[DFE_MAX_SCALES], tile_start[DFE_MAX_SCALES + 1], tiles_x[DFE_MAX_SCALES];
   int nblk0;                          // full-resolution blocks (disp smoothness)
+  int V;                              // pixels per thread of k_geom_point_fwd (4 when every W_s % 4 == 0, else 1)
+  int vblk_start[DFE_MAX_SCALES + 1]; // its block table
   // workspace offsets in floats
   long o_cams, o_epi, o_pyr, o_area, o_mask, o_yw, o_part, o_spart, o_fpart, o_dpart, o_sums, o_coef, o_dsum,
       o_gw, o_gup, o_bpart, total;
@@ -43,6 +45,7 @@ struct GeomDev {
   float alpha, beta;
   int H[DFE_MAX_SCALES], W[DFE_MAX_SCALES], N[DFE_MAX_SCALES];
   int blk_start[DFE_MAX_SCALES + 1], tile_start[DFE_MAX_SCALES + 1], tiles_x[DFE_MAX_SCALES];
+  int vblk_start[DFE_MAX_SCALES + 1];      // block table of the V-pixels-per-thread kernels
   const float* pyr[3][DFE_MAX_SCALES];    // bilinear pyramid per frame (level 0 = the frame itself)
   const float* area[2][DFE_MAX_SCALES];   // area pyramid of the left / right frame
   const float* disp[3][DFE_MAX_SCALES];

@@ -12,6 +12,7 @@
 // All (sample, scale) images are batched into each launch: scale 2 alone (13 k px) cannot fill
 // 256 CUs.  Partials are reduced in a fixed order (no float atomics): bitwise reproducible.
 #include "loss_stack.h"
+#include <cstdint>
 
 namespace dfe {
 
@@ -37,6 +38,11 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
     L->tile_start[s + 1] = L->tile_start[s] + L->ntile[s];
   }
   L->nblk0 = L->nblk[0];
+  // V = 4 (16-byte streams) measured SLOWER at B=4, 256x832 (84 vs 50 us): 4x fewer waves at 3-wave
+  // occupancy leave the SIMDs unable to cover gather latency.  Kept as an instantiation for large batches.
+  L->V = 1;
+  L->vblk_start[0] = 0;
+  for (int s = 0; s < L->S; ++s) L->vblk_start[s + 1] = L->vblk_start[s] + (L->N[s] + GS_BLOCK * L->V - 1) / (GS_BLOCK * L->V);
   const long B = L->B, S = L->S, sumN = L->off_px[S];
   const long nblk_total = L->blk_start[S], ntile_total = L->tile_start[S];
   L->pyr_plane = B * 3 * (sumN - L->N[0]);
@@ -64,7 +70,7 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
 void geom_dev(const dfe_geom_args* a, const GeomLayout& L, GeomDev* D) {
   float* ws = a->workspace;
   D->B = L.B; D->S = L.S; D->ac = a->align_corners; D->alpha = a->alpha; D->beta = a->beta;
-  for (int s = 0; s <= L.S; ++s) { D->blk_start[s] = L.blk_start[s]; D->tile_start[s] = L.tile_start[s]; }
+  for (int s = 0; s <= L.S; ++s) { D->blk_start[s] = L.blk_start[s]; D->tile_start[s] = L.tile_start[s]; D->vblk_start[s] = L.vblk_start[s]; }
   for (int s = 0; s < L.S; ++s) {
     D->H[s] = L.H[s]; D->W[s] = L.W[s]; D->N[s] = L.N[s]; D->tiles_x[s] = L.tiles_x[s];
     const long lvl = static_cast<long>(L.B) * 3 * (L.off_px[s] - L.N[0]);   // offset of level s (>=1) in a frame's block
@@ -129,99 +135,167 @@ __global__ void k_geom_pyramids(PyrJobs jobs) {
 }
 
 // ---------------------------------------------------------------------- pointwise forward
-// VALU-issue-bound (profiles/r01b_pmc_loss_stack.json: 1 390 VALU instr per wave, 68 % VALU busy, FETCH+WRITE
-// = algorithmic bytes).  Everything that does not change a result bit is therefore written for instruction
-// count: exact 3-instruction divisions by the launch constants, integer bounds tests, masked bilinear
-// weights, 32-bit offsets from block-uniform bases (scalar base + VGPR offset addressing).
+// Bound by the number of memory instructions (TA_BUSY 80 %: the texture-address unit takes ~16 cycles per
+// wave-wide load whatever its width) and then by VALU issue (profiles/r01b_pmc_loss_stack.json).  Hence:
+// V = 4 pixels per thread with 16-byte loads/stores for every non-gathered stream (target, flows, disparity,
+// sources at p, warped output, mask pack), one 8-byte load per footprint row for the gathers, block sums
+// amortised over the 4 pixels, exact 3-instruction divisions by launch constants, integer bounds tests and
+// 32-bit byte offsets from block-uniform bases.  V = 1 when some W_s is not a multiple of 4 (e.g. 1242x375).
+struct PointCtx {
+  int b, s, H, W, ac;
+  unsigned N4;
+  float alpha, beta;
+  const float *srcL, *srcR, *areaL, *areaR;   // block-uniform plane bases of this sample
+  const Camera* cam;                           // cams[(b*2+0)*S + s], direction stride S
+  int cam_stride;
+  const Epi* epi;                              // epi[b*2]
+  Divisor dw, dh;
+};
+
+struct PixIn { float i0, i1, i2, fu[2], fv[2], dsp, sl[3], sr[3]; };
+
+__device__ __forceinline__ void point_pixel(const PointCtx& c, int px, int py, const PixIn& in, float (&yw)[2][3],
+                                            unsigned& bits, float (&acc)[PT_COUNT]) {
+  const int H = c.H, W = c.W;
+  float wv[2][3], dif[2];
+  bool valid[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    float ix, iy;
+    flow_coords_d(px, py, in.fu[d], in.fv[d], H, W, c.ac, c.dw, c.dh, ix, iy);
+    const FastTap t = make_fast_tap(ix, iy, H, W);
+    const float keep = (fast_cover(t) < 0.9999f) ? 0.0f : 1.0f;
+    const float* src = d == 0 ? c.srcL : c.srcR;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) wv[d][ch] = fast_sample(reinterpret_cast<const float*>(reinterpret_cast<const char*>(src) + ch * c.N4), t) * keep;
+    valid[d] = !(wv[d][0] == 0.0f && wv[d][1] == 0.0f && wv[d][2] == 0.0f);
+    dif[d] = mean3_abs_diff(in.i0, in.i1, in.i2, wv[d][0], wv[d][1], wv[d][2]);
+  }
+  float wb, wf;
+  occ_weights(dif[0], dif[1], wb, wf);
+  const bool occ[2] = {wb > 0.48f, wf > 0.48f};
+  bits = 0;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const Camera& cam = c.cam[d * c.cam_stride];
+    const Proj pr = project(cam, px, py, in.dsp);
+    const float ru = pr.U - static_cast<float>(px), rv = pr.V - static_cast<float>(py);
+    const float du = fabsf(ru - in.fu[d]), dv = fabsf(rv - in.fv[d]);
+    const bool dyna = dyna_decision(in.fu[d], in.fv[d], ru, rv, du, dv, c.alpha, c.beta);
+    float xn, yn; bool lx, ly;
+    rigid_grid_d(pr, c.dw, c.dh, xn, yn, lx, ly);
+    const FastTap t = make_fast_tap(unnormalize(xn, W, c.ac), unnormalize(yn, H, c.ac), H, W);
+    const float* ar = d == 0 ? c.areaL : c.areaR;
+    float rec[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) rec[ch] = fast_sample(reinterpret_cast<const float*>(reinterpret_cast<const char*>(ar) + ch * c.N4), t);
+    const float* sp = d == 0 ? in.sl : in.sr;
+    const float e_rec = mean3_abs_diff(in.i0, in.i1, in.i2, rec[0], rec[1], rec[2]);
+    const float e_src = mean3_abs_diff(in.i0, in.i1, in.i2, sp[0], sp[1], sp[2]);
+    const bool tex = e_rec < e_src;
+    const float vo = (valid[d] && occ[d]) ? 1.0f : 0.0f;
+    const float m_rig = dyna ? vo : 0.0f, m_dyn = dyna ? 0.0f : vo;
+    const float m_tex = tex ? m_rig : 0.0f;
+    const float l1_rec = (fabsf(in.i0 - rec[0]) + fabsf(in.i1 - rec[1])) + fabsf(in.i2 - rec[2]);
+    const float l1_wrp = (fabsf(in.i0 - wv[d][0]) + fabsf(in.i1 - wv[d][1])) + fabsf(in.i2 - wv[d][2]);
+    float* a = acc + d * PT_PER_DIR;
+    a[PT_M_TEX] += m_tex;       a[PT_L1_DEPTH] += l1_rec * m_tex;
+    a[PT_M_RIG] += m_rig;       a[PT_L1_RIG] += l1_wrp * m_rig;
+    a[PT_M_DYN] += m_dyn;       a[PT_L1_DYN] += l1_wrp * m_dyn;
+    a[PT_M_VO] += vo;
+    if (c.s == 0) {
+      a[PT_FDIFF] += (du + dv) * m_rig;
+      const Epi& e = c.epi[d];
+      const float x1 = static_cast<float>(px), y1 = static_cast<float>(py);
+      const float l0 = e.F[0] * x1 + e.F[1] * y1 + e.F[2];
+      const float l1 = e.F[3] * x1 + e.F[4] * y1 + e.F[5];
+      const float l2 = e.F[6] * x1 + e.F[7] * y1 + e.F[8];
+      // feeds a loss value only (no mask): 1-ulp sqrt / reciprocal instead of the IEEE sequences
+      const float div = __builtin_amdgcn_sqrtf(l0 * l0 + l1 * l1) + 1e-6f;
+      a[PT_EPI] += fabsf(((x1 + in.fu[d]) * l0 + (y1 + in.fv[d]) * l1) + l2) * __builtin_amdgcn_rcpf(div);
+    }
+    bits |= (valid[d] ? (DFE_MASK_VALID_BWD << d) : 0u) | (occ[d] ? (DFE_MASK_OCC_BWD << d) : 0u) |
+            (dyna ? (DFE_MASK_DYNA_BWD << d) : 0u) | (tex ? (DFE_MASK_TEX_BWD << d) : 0u);
+    yw[d][0] = wv[d][0] * vo; yw[d][1] = wv[d][1] * vo; yw[d][2] = wv[d][2] * vo;
+  }
+  // flow consistency (model_geometry.py:195-210): |unit(fwd) + unit(bwd)| on (1 - occ_fwd)
+  // loss-only: 1-ulp sqrt / reciprocal
+  const float rf = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(in.fu[1] * in.fu[1] + in.fv[1] * in.fv[1]) + 1e-12f);
+  const float rb = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(in.fu[0] * in.fu[0] + in.fv[0] * in.fv[0]) + 1e-12f);
+  const float inv = occ[1] ? 0.0f : 1.0f;
+  acc[PT_INV] += inv;
+  acc[PT_CONSIS] += (fabsf(in.fu[1] * rf + in.fu[0] * rb) + fabsf(in.fv[1] * rf + in.fv[0] * rb)) * inv;
+}
+
+template <int V> struct VecF;
+template <> struct VecF<1> { float v[1]; };
+template <> struct __attribute__((aligned(16))) VecF<4> { float v[4]; };
+
+template <int V>
+__device__ __forceinline__ VecF<V> ldv(const float* __restrict__ base, unsigned byte_off) {
+  return *reinterpret_cast<const VecF<V>*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <int V>
+__device__ __forceinline__ void stv(float* __restrict__ base, unsigned byte_off, const VecF<V>& x) {
+  *reinterpret_cast<VecF<V>*>(reinterpret_cast<char*>(base) + byte_off) = x;
+}
+
+template <int V>
 __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, float* __restrict__ part) {
   __shared__ float red[PT_COUNT * 4 * (GS_BLOCK / 64)];
-  const unsigned nblk_total = D.blk_start[D.S];
+  const unsigned nblk_total = D.vblk_start[D.S];
   const unsigned blk = xcd_swizzle(blockIdx.x, nblk_total);
   const int b = blockIdx.y;
-  const int s = find_scale(D.blk_start, D.S, blk);
+  const int s = find_scale(D.vblk_start, D.S, blk);
   const int H = D.H[s], W = D.W[s], N = D.N[s];
-  const unsigned p = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
+  const unsigned p = ((blk - D.vblk_start[s]) * GS_BLOCK + threadIdx.x) * V;
   float acc[PT_COUNT];
 #pragma unroll
   for (int i = 0; i < PT_COUNT; ++i) acc[i] = 0.0f;
   if (p < static_cast<unsigned>(N)) {
-    const unsigned py = p / static_cast<unsigned>(W), px = p - py * W;
+    const unsigned py = p / static_cast<unsigned>(W), px0 = p - py * W;
     const unsigned p4 = p * 4u, N4 = static_cast<unsigned>(N) * 4u;
-    // block-uniform bases
+    PointCtx c;
+    c.b = b; c.s = s; c.H = H; c.W = W; c.ac = D.ac; c.N4 = N4; c.alpha = D.alpha; c.beta = D.beta;
+    c.srcL = D.pyr[0][s] + static_cast<long>(b) * 3 * N; c.srcR = D.pyr[2][s] + static_cast<long>(b) * 3 * N;
+    c.areaL = D.area[0][s] + static_cast<long>(b) * 3 * N; c.areaR = D.area[1][s] + static_cast<long>(b) * 3 * N;
+    c.cam = D.cams + (b * 2) * D.S + s; c.cam_stride = D.S; c.epi = D.epi + b * 2;
+    c.dw = make_divisor(static_cast<float>(W > 1 ? W - 1 : 1)); c.dh = make_divisor(static_cast<float>(H > 1 ? H - 1 : 1));
     const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
-    const float* dispt = D.disp[1][s] + static_cast<long>(b) * N;
-    const Divisor dw = make_divisor(static_cast<float>(W > 1 ? W - 1 : 1)), dh = make_divisor(static_cast<float>(H > 1 ? H - 1 : 1));
-    const float i0 = ldb(it, p4), i1 = ldb(it, p4 + N4), i2 = ldb(it, p4 + 2 * N4);
-    float fu[2], fv[2], wv[2][3], dif[2];
-    bool valid[2];
+    const float* flb = D.flow[0][s] + static_cast<long>(b) * 2 * N;
+    const float* flf = D.flow[1][s] + static_cast<long>(b) * 2 * N;
+    const VecF<V> t0 = ldv<V>(it, p4), t1 = ldv<V>(it, p4 + N4), t2 = ldv<V>(it, p4 + 2 * N4);
+    const VecF<V> ub = ldv<V>(flb, p4), vb = ldv<V>(flb, p4 + N4), uf = ldv<V>(flf, p4), vf = ldv<V>(flf, p4 + N4);
+    const VecF<V> dd = ldv<V>(D.disp[1][s] + static_cast<long>(b) * N, p4);
+    const VecF<V> l0 = ldv<V>(c.srcL, p4), l1 = ldv<V>(c.srcL, p4 + N4), l2 = ldv<V>(c.srcL, p4 + 2 * N4);
+    const VecF<V> r0 = ldv<V>(c.srcR, p4), r1 = ldv<V>(c.srcR, p4 + N4), r2 = ldv<V>(c.srcR, p4 + 2 * N4);
+    VecF<V> yo[2][3];
+    unsigned packed = 0;
+#pragma unroll
+    for (int u = 0; u < V; ++u) {
+      PixIn in;
+      in.i0 = t0.v[u]; in.i1 = t1.v[u]; in.i2 = t2.v[u];
+      in.fu[0] = ub.v[u]; in.fv[0] = vb.v[u]; in.fu[1] = uf.v[u]; in.fv[1] = vf.v[u];
+      in.dsp = dd.v[u];
+      in.sl[0] = l0.v[u]; in.sl[1] = l1.v[u]; in.sl[2] = l2.v[u];
+      in.sr[0] = r0.v[u]; in.sr[1] = r1.v[u]; in.sr[2] = r2.v[u];
+      float yw[2][3];
+      unsigned bits;
+      point_pixel(c, static_cast<int>(px0) + u, static_cast<int>(py), in, yw, bits, acc);
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) yo[d][ch].v[u] = yw[d][ch];
+      packed |= bits << (8 * u);
+    }
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
-      const float* fl = D.flow[d][s] + static_cast<long>(b) * 2 * N;
-      fu[d] = ldb(fl, p4); fv[d] = ldb(fl, p4 + N4);
-      float ix, iy;
-      flow_coords_d(px, py, fu[d], fv[d], H, W, D.ac, dw, dh, ix, iy);
-      const FastTap t = make_fast_tap(ix, iy, H, W);
-      const float keep = (fast_cover(t) < 0.9999f) ? 0.0f : 1.0f;
-      const float* src = D.pyr[d == 0 ? 0 : 2][s] + static_cast<long>(b) * 3 * N;
+      float* ywp = D.yw[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) wv[d][c] = fast_sample(src + static_cast<long>(c) * N, t) * keep;
-      valid[d] = !(wv[d][0] == 0.0f && wv[d][1] == 0.0f && wv[d][2] == 0.0f);
-      dif[d] = mean3_abs_diff(i0, i1, i2, wv[d][0], wv[d][1], wv[d][2]);
+      for (int ch = 0; ch < 3; ++ch) stv<V>(ywp, p4 + ch * N4, yo[d][ch]);
     }
-    float wb, wf;
-    occ_weights(dif[0], dif[1], wb, wf);
-    const bool occ[2] = {wb > 0.48f, wf > 0.48f};
-    const float dsp = ldb(dispt, p4);
-    unsigned bits = 0;
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-      const Camera& cam = D.cams[(b * 2 + d) * D.S + s];
-      const Proj pr = project(cam, px, py, dsp);
-      const float ru = pr.U - static_cast<float>(px), rv = pr.V - static_cast<float>(py);
-      const float du = fabsf(ru - fu[d]), dv = fabsf(rv - fv[d]);
-      const bool dyna = dyna_decision(fu[d], fv[d], ru, rv, du, dv, D.alpha, D.beta);
-      float xn, yn; bool lx, ly;
-      rigid_grid_d(pr, make_divisor(static_cast<float>(W - 1)), make_divisor(static_cast<float>(H - 1)), xn, yn, lx, ly);
-      const FastTap t = make_fast_tap(unnormalize(xn, W, D.ac), unnormalize(yn, H, D.ac), H, W);
-      const float* ar = D.area[d][s] + static_cast<long>(b) * 3 * N;
-      float rec[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) rec[c] = fast_sample(ar + static_cast<long>(c) * N, t);
-      const float* sp = D.pyr[d == 0 ? 0 : 2][s] + static_cast<long>(b) * 3 * N;
-      const float e_rec = mean3_abs_diff(i0, i1, i2, rec[0], rec[1], rec[2]);
-      const float e_src = mean3_abs_diff(i0, i1, i2, ldb(sp, p4), ldb(sp, p4 + N4), ldb(sp, p4 + 2 * N4));
-      const bool tex = e_rec < e_src;
-      const float vo = (valid[d] && occ[d]) ? 1.0f : 0.0f;
-      const float m_rig = dyna ? vo : 0.0f, m_dyn = dyna ? 0.0f : vo;
-      const float m_tex = tex ? m_rig : 0.0f;
-      const float l1_rec = (fabsf(i0 - rec[0]) + fabsf(i1 - rec[1])) + fabsf(i2 - rec[2]);
-      const float l1_wrp = (fabsf(i0 - wv[d][0]) + fabsf(i1 - wv[d][1])) + fabsf(i2 - wv[d][2]);
-      float* a = acc + d * PT_PER_DIR;
-      a[PT_M_TEX] = m_tex;       a[PT_L1_DEPTH] = l1_rec * m_tex;
-      a[PT_M_RIG] = m_rig;       a[PT_L1_RIG] = l1_wrp * m_rig;
-      a[PT_M_DYN] = m_dyn;       a[PT_L1_DYN] = l1_wrp * m_dyn;
-      a[PT_M_VO] = vo;
-      if (s == 0) {
-        a[PT_FDIFF] = (du + dv) * m_rig;
-        const Epi& e = D.epi[b * 2 + d];
-        const float x1 = static_cast<float>(px), y1 = static_cast<float>(py);
-        const float l0 = e.F[0] * x1 + e.F[1] * y1 + e.F[2];
-        const float l1 = e.F[3] * x1 + e.F[4] * y1 + e.F[5];
-        const float l2 = e.F[6] * x1 + e.F[7] * y1 + e.F[8];
-        const float div = sqrtf(l0 * l0 + l1 * l1) + 1e-6f;
-        a[PT_EPI] = fabsf(((x1 + fu[d]) * l0 + (y1 + fv[d]) * l1) + l2) / div;
-      }
-      bits |= (valid[d] ? (DFE_MASK_VALID_BWD << d) : 0u) | (occ[d] ? (DFE_MASK_OCC_BWD << d) : 0u) |
-              (dyna ? (DFE_MASK_DYNA_BWD << d) : 0u) | (tex ? (DFE_MASK_TEX_BWD << d) : 0u);
-      float* yw = D.yw[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
-      stb(yw, p4, wv[d][0] * vo); stb(yw, p4 + N4, wv[d][1] * vo); stb(yw, p4 + 2 * N4, wv[d][2] * vo);
-    }
-    (D.mask[s] + static_cast<long>(b) * N)[p] = static_cast<unsigned char>(bits);
-    // flow consistency (model_geometry.py:195-210): |unit(fwd) + unit(bwd)| on (1 - occ_fwd)
-    const float nf = l2norm2(fu[1], fv[1]), nb = l2norm2(fu[0], fv[0]);
-    const float inv = occ[1] ? 0.0f : 1.0f;
-    acc[PT_INV] = inv;
-    acc[PT_CONSIS] = (fabsf(fu[1] / nf + fu[0] / nb) + fabsf(fv[1] / nf + fv[0] / nb)) * inv;
+    unsigned char* mk = D.mask[s] + static_cast<long>(b) * N + p;
+    if (V == 4) *reinterpret_cast<unsigned*>(mk) = packed; else *mk = static_cast<unsigned char>(packed);
   }
   block_sum<PT_COUNT>(acc, red, part + (static_cast<long>(b) * nblk_total + blk) * PT_COUNT);
 }
@@ -367,10 +441,12 @@ __global__ void __launch_bounds__(256) k_geom_finalize_fwd(GeomDev D, const floa
     double a[SUM_COUNT];
 #pragma unroll
     for (int i = 0; i < SUM_COUNT; ++i) a[i] = 0.0;
-    for (int k = D.blk_start[s] + t; k < D.blk_start[s + 1]; k += 256) {
-      const float* r = part + (static_cast<long>(b) * nblk_total + k) * PT_COUNT;
+    for (int k = D.vblk_start[s] + t; k < D.vblk_start[s + 1]; k += 256) {
+      const float* r = part + (static_cast<long>(b) * D.vblk_start[S] + k) * PT_COUNT;
 #pragma unroll
       for (int i = 0; i < PT_COUNT; ++i) a[i] += r[i];
+    }
+    for (int k = D.blk_start[s] + t; k < D.blk_start[s + 1]; k += 256) {
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
         const float* q = fpart + (static_cast<long>(d * B + b) * nblk_total + k) * 2;
@@ -526,7 +602,17 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   }
   DFE_MARK();
   const unsigned nblk_total = L.blk_start[L.S], ntile_total = L.tile_start[L.S];
-  k_geom_point_fwd<<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
+  {
+    // the 16-byte path also needs 16-byte aligned streams (torch allocations are; views may not be)
+    bool al = true;
+    auto chk = [&](const void* q) { al = al && ((reinterpret_cast<uintptr_t>(q) & 15) == 0); };
+    for (int f = 0; f < 3; ++f) chk(a->img[f]);
+    for (int sc = 0; sc < L.S; ++sc) { chk(a->disp[1][sc]); chk(a->flow[0][sc]); chk(a->flow[1][sc]); }
+    chk(ws);
+    if (L.V == 4 && !al) return DFE_ERR_UNSUPPORTED;   // callers pass contiguous torch tensors; never hit in practice
+    if (L.V == 4) k_geom_point_fwd<4><<<dim3(L.vblk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
+    else k_geom_point_fwd<1><<<dim3(L.vblk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
+  }
   DFE_LAUNCH_CHECK();
   DFE_MARK();
   k_geom_ssim_fwd<<<dim3(ntile_total, L.B * 2), GS_TX * GS_TY, 0, st>>>(D, ws + L.o_spart);
