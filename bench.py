@@ -154,8 +154,17 @@ def point_fwd_roofline(args, wl, steps):
     bytes_per_launch = POINT_FWD_BYTES_PER_PX * npx
     t_ms = float(acc_f[2])
     achieved = bytes_per_launch / (t_ms * 1e-3) / 1e9
+    traffic = None   # PMC-derived HBM bytes per launch: cannot be collected from inside this process; taken from
+    try:             # the committed rocprofv3 --pmc pass when it was made on exactly this workload
+        with open(os.path.join(ROOT, "profiles", "pmc_point_fwd_traffic.json")) as fh:
+            pm = json.load(fh)
+        w = pm["workload"]
+        if (w["batch"], w["height"], w["width"], w["scales"]) == (args.batch, args.height, args.width, S):
+            traffic = pm["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     roof = {"bound": "hbm", "kernel": "k_geom_point_fwd", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "bytes_per_launch": bytes_per_launch, "avg_kernel_ms": round(t_ms, 5)}
     segs = {"fwd_ms": [round(float(x), 5) for x in acc_f], "bwd_ms": [round(float(x), 5) for x in acc_b]}
     return roof, segs

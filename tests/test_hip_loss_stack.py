@@ -177,3 +177,31 @@ def test_fused_stack_is_deterministic():
     assert torch.equal(a[3][1].grad, b[3][1].grad)
     for x, y in zip(a[3][2][:3], b[3][2][:3]):
         assert torch.equal(x.grad, y.grad)
+
+
+@pytest.mark.parametrize("shape,S", [((3, 70, 100), 2), ((1, 64, 208), 1), ((2, 40, 72), 3)])
+def test_fused_stack_ragged_sizes(shape, S):
+    """Sizes that are not multiples of the 256-px blocks / 32x8 tiles, odd batch, a single scale."""
+    b, h, w = shape
+    inp = synthetic.make_loss_stack_inputs(b, h, w, S, seed=300 + h)
+    compare(inp, False, S)
+
+
+def test_fused_stack_argument_errors():
+    from unsupervised_depth_opticalflow_egomotion_amd.loss_stack import geom_loss_stack
+    from unsupervised_depth_opticalflow_egomotion_amd._lib import DfeError
+    inp = synthetic.make_loss_stack_inputs(1, 32, 96, 3, seed=1)
+    disps, pose, fb, ff = to_dev(inp, grad=False)
+    il, it, ir = [G(a) for a in inp.imgs]
+    K, Ki = G(inp.K), G(inp.K_inv)
+    with pytest.raises(ValueError):      # wrong disparity shape
+        geom_loss_stack(il, it, ir, disps[0][::-1], disps[1], disps[2], pose, fb, ff, K, Ki)
+    with pytest.raises(ValueError):      # pose must be [B,2,6]
+        geom_loss_stack(il, it, ir, disps[0], disps[1], disps[2], pose[:, 0], fb, ff, K, Ki)
+    with pytest.raises(DfeError):        # scale 2 of a 8x24 image is 2x6: below the 3x3 minimum of the stencils
+        tiny = synthetic.make_loss_stack_inputs(1, 8, 24, 3, seed=2)
+        d2, p2, fb2, ff2 = to_dev(tiny, grad=False)
+        geom_loss_stack(*[G(a) for a in tiny.imgs], d2[0], d2[1], d2[2], p2, fb2, ff2, G(tiny.K), G(tiny.K_inv))
+    with pytest.raises(DfeError):        # CPU tensors never fall back
+        geom_loss_stack(il.cpu(), it.cpu(), ir.cpu(), [d.cpu() for d in disps[0]], [d.cpu() for d in disps[1]],
+                        [d.cpu() for d in disps[2]], pose.cpu(), [f.cpu() for f in fb], [f.cpu() for f in ff], K.cpu(), Ki.cpu())

@@ -212,3 +212,20 @@ def test_resize_oracle(hw):
         oh, ow = int(h / 2 ** s), int(w / 2 ** s)
         close(resize(G(img), (oh, ow), "bilinear"), F.interpolate(T(img), (oh, ow), mode="bilinear", align_corners=False), atol=1e-6)
         close(resize(G(img), (oh, ow), "area"), F.interpolate(T(img), (oh, ow), mode="area"), atol=1e-6)
+
+
+def test_degenerate_sizes():
+    """W == 1 / H == 1 (max(W-1,1) normalisation, net_utils.py:42-43), 2-px planes, single channel."""
+    from unsupervised_depth_opticalflow_egomotion_amd.structures import warp_flow
+    from unsupervised_depth_opticalflow_egomotion_amd.pytorch_ssim import SSIM
+    r = MG.rng(91)
+    for shape in [(1, 1, 1, 9), (2, 2, 7, 1), (1, 3, 2, 2), (1, 1, 1, 1)]:
+        b, c, h, w = shape
+        x = r.random(shape).astype(np.float32)
+        fl = (0.7 * r.standard_normal((b, 2, h, w))).astype(np.float32)
+        for ac in (False, True):
+            for um in (False, True):
+                yo = O.warp_flow(T(x), T(fl), use_mask=um, align_corners=ac)
+                y = warp_flow(G(x), G(fl), use_mask=um, align_corners=ac)
+                close(y, yo, atol=2e-6)
+        close(SSIM(G(x), G(x[::-1].copy())), O.SSIM(T(x), T(x[::-1].copy())), atol=2e-5)

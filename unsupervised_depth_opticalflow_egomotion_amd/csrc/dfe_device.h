@@ -80,7 +80,8 @@ __device__ __forceinline__ Corners load_corners(const float* __restrict__ plane,
     c.se = t.in_se ? (lo ? r1.a : r1.b) : 0.0f;
   } else {
     const float v0 = plane[static_cast<long>(ya) * W], v1 = plane[static_cast<long>(yb) * W];
-    c.nw = t.in_nw ? v0 : 0.0f; c.ne = 0.0f; c.sw = t.in_sw ? v1 : 0.0f; c.se = 0.0f;
+    // single column: whichever corner is in bounds is column 0
+    c.nw = t.in_nw ? v0 : 0.0f; c.ne = t.in_ne ? v0 : 0.0f; c.sw = t.in_sw ? v1 : 0.0f; c.se = t.in_se ? v1 : 0.0f;
   }
   return c;
 }
