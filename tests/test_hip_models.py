@@ -102,7 +102,12 @@ def test_model_depth_and_flow_loss_stacks(golden_dir):
     disps = [[G(a, True) for a in lst] for lst in inp.disps]
     pose = G(inp.pose, True)
     il, it, ir = [G(a) for a in inp.imgs]
+    # fused mode-1 launches and the per-operator path must agree with each other and with the reference
+    lp2, _ = md.loss_stack_per_op(il, it, ir, [d.detach() for d in disps[0]], [d.detach() for d in disps[1]],
+                                  [d.detach() for d in disps[2]], pose.detach(), G(inp.K))
     lp, _ = md.loss_stack(il, it, ir, disps[0], disps[1], disps[2], pose, G(inp.K))
+    for k in lp:
+        np.testing.assert_allclose(N(lp[k]), N(lp2[k]), rtol=2e-4, atol=1e-6, err_msg=k)
     (lp["loss_depth_pixel"].mean() + 0.5 * lp["loss_depth_smooth"].mean()).backward()
     for k, v in lp.items():
         np.testing.assert_allclose(N(v), g["depth_" + k], rtol=2e-4, atol=1e-6, err_msg=k)

@@ -41,7 +41,7 @@ struct GeomLayout {
 
 // Kernel-argument tables (passed by value).
 struct GeomDev {
-  int B, S, ac;
+  int B, S, ac, mode;
   float alpha, beta;
   int H[DFE_MAX_SCALES], W[DFE_MAX_SCALES], N[DFE_MAX_SCALES];
   int blk_start[DFE_MAX_SCALES + 1], tile_start[DFE_MAX_SCALES + 1], tiles_x[DFE_MAX_SCALES];

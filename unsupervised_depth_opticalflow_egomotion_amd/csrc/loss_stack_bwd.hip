@@ -234,6 +234,64 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomBwd 
   block_sum<PB_COUNT>(acc, red, G.bpart + (static_cast<long>(b) * nblk_total + blk) * PB_COUNT);
 }
 
+// ---------------------------------------------------------------------- depth-only pointwise backward
+// Model_depth: gradient of the masked L1 on the rigid recon wrt the target disparity and the camera sums.
+__global__ void __launch_bounds__(GS_BLOCK) k_depth_point_bwd(GeomDev D, GeomBwd G) {
+  __shared__ float red[PB_COUNT * 4 * (GS_BLOCK / 64)];
+  const unsigned nblk_total = D.blk_start[D.S];
+  const unsigned blk = xcd_swizzle(blockIdx.x, nblk_total);
+  const int b = blockIdx.y, B = D.B;
+  const int s = find_scale(D.blk_start, D.S, blk);
+  const int H = D.H[s], W = D.W[s], N = D.N[s];
+  const int p = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
+  float acc[PB_COUNT];
+#pragma unroll
+  for (int i = 0; i < PB_COUNT; ++i) acc[i] = 0.0f;
+  if (p < N) {
+    const int py = p / W, px = p - py * W;
+    const long o3 = static_cast<long>(b) * 3 * N + p, o1 = static_cast<long>(b) * N + p;
+    const float* it = D.pyr[1][s];
+    const float im[3] = {it[o3], it[o3 + N], it[o3 + 2 * N]};
+    const unsigned bits = D.mask[s][o1];
+    const float dsp = D.disp[1][s][o1];
+    const float* cf = G.coef + (static_cast<long>(b) * D.S + s) * CF_COUNT;
+    const float g_dp = G.gl[DFE_LOSS_DEPTH_PIXEL * B + b];
+    float gdisp = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const bool m = (bits & (DFE_MASK_VALID_BWD << d)) && (bits & (DFE_MASK_TEX_BWD << d));
+      const Camera& cam = D.cams[(b * 2 + d) * D.S + s];
+      Proj pr = project(cam, px, py, dsp);
+      float gU = 0.0f, gV = 0.0f;
+      if (m) {
+        float xn, yn; bool lx, ly;
+        rigid_grid(pr, H, W, xn, yn, lx, ly);
+        Tap t = make_tap(unnormalize(xn, W, D.ac), unnormalize(yn, H, D.ac), H, W);
+        const float* ar = D.area[d][s] + static_cast<long>(b) * 3 * N;
+        const float gc = g_dp * cf[d * CF_PER_DIR + CF_DEPTH];
+        float gix = 0.0f, giy = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          Corners q = load_corners(ar + static_cast<long>(c) * N, t, W, H);
+          float dx, dy;
+          interp_grad(q, t, dx, dy);
+          const float g = sgn(interp(q, t) - im[c]) * gc;
+          gix += g * dx; giy += g * dy;
+        }
+        const float sx = D.ac ? static_cast<float>(W - 1) / 2.0f : static_cast<float>(W) / 2.0f;
+        const float sy = D.ac ? static_cast<float>(H - 1) / 2.0f : static_cast<float>(H) / 2.0f;
+        if (lx) gU = gix * sx * (2.0f / static_cast<float>(W - 1));
+        if (ly) gV = giy * sy * (2.0f / static_cast<float>(H - 1));
+      }
+      float gd;
+      project_backward(pr, dsp, gU, gV, 0.0f, gd, acc + d * PB_PER_DIR);
+      gdisp += gd;
+    }
+    if (G.gdisp[1][s]) G.gdisp[1][s][o1] = gdisp;
+  }
+  block_sum<PB_COUNT>(acc, red, G.bpart + (static_cast<long>(b) * nblk_total + blk) * PB_COUNT);
+}
+
 // ---------------------------------------------------------------------- flow smoothness backward
 // grid.y = d*B + b ; adds into grad_flow (after k_geom_point_bwd wrote it).
 __global__ void __launch_bounds__(GS_BLOCK) k_geom_flow_smooth_bwd(GeomDev D, GeomBwd G) {
@@ -394,9 +452,10 @@ __global__ void __launch_bounds__(256) k_geom_pose_finalize(GeomDev D, GeomBwd G
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) gR[i * 3 + j] += c.K[i] * acc[3 + j] + c.K[3 + i] * acc[6 + j] + c.K[6 + i] * acc[9 + j];
   }
+  const Camera& c0 = D.cams[cam * S];
+  if (D.mode == 0) {
   // epipolar: F = Ki^T E Ki, E = S R
   const Epi& e = D.epi[cam];
-  const Camera& c0 = D.cams[cam * S];
   const double* gF = sm + S * 12;
   double T[9], gE[9];
   for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) T[r * 3 + q] = e.Kinv[r * 3] * gF[q] + e.Kinv[r * 3 + 1] * gF[3 + q] + e.Kinv[r * 3 + 2] * gF[6 + q];
@@ -408,6 +467,7 @@ __global__ void __launch_bounds__(256) k_geom_pose_finalize(GeomDev D, GeomBwd G
     gR[r * 3 + q] += a; gS[r * 3 + q] = bq;
   }
   g[0] += gS[7] - gS[5]; g[1] += gS[2] - gS[6]; g[2] += gS[3] - gS[1];
+  }
   for (int k = 0; k < 3; ++k) { double t = 0; for (int i = 0; i < 9; ++i) t += gR[i] * c0.dR[k * 9 + i]; g[3 + k] += t; }
   for (int i = 0; i < 6; ++i) gpose[cam * 6 + i] = static_cast<float>(g[i]);
 }
@@ -425,7 +485,7 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   if (!a->workspace || !a->grad_losses || !a->pose) return DFE_ERR_NULL;
   if (a->workspace_floats < L.total) return DFE_ERR_WORKSPACE;
   for (int f = 0; f < 3; ++f) { if (!a->img[f]) return DFE_ERR_NULL; for (int s = 0; s < L.S; ++s) if (!a->disp[f][s]) return DFE_ERR_NULL; }
-  for (int d = 0; d < 2; ++d) for (int s = 0; s < L.S; ++s) if (!a->flow[d][s]) return DFE_ERR_NULL;
+  if (a->mode == 0) for (int d = 0; d < 2; ++d) for (int s = 0; s < L.S; ++s) if (!a->flow[d][s]) return DFE_ERR_NULL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* ws = a->workspace;
   GeomDev D;
@@ -441,15 +501,22 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   int seg = 0;
 #define DFE_MARK() do { if (ev) (void)hipEventRecord(ev[++seg], st); } while (0)
   if (ev) (void)hipEventRecord(ev[0], st);
-  k_geom_ssim_bwd<<<dim3(ntile_total, L.B * 2), GS_TX * GS_TY, 0, st>>>(D, G);
-  DFE_LAUNCH_CHECK();
-  DFE_MARK();
-  k_geom_point_bwd<<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, G);
-  DFE_LAUNCH_CHECK();
-  DFE_MARK();
-  k_geom_flow_smooth_bwd<<<dim3(nblk_total, 2 * L.B), GS_BLOCK, 0, st>>>(D, G);
-  DFE_LAUNCH_CHECK();
-  DFE_MARK();
+  if (a->mode == 1) {
+    DFE_MARK();
+    k_depth_point_bwd<<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, G);
+    DFE_LAUNCH_CHECK();
+    DFE_MARK(); DFE_MARK();
+  } else {
+    k_geom_ssim_bwd<<<dim3(ntile_total, L.B * 2), GS_TX * GS_TY, 0, st>>>(D, G);
+    DFE_LAUNCH_CHECK();
+    DFE_MARK();
+    k_geom_point_bwd<<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, G);
+    DFE_LAUNCH_CHECK();
+    DFE_MARK();
+    k_geom_flow_smooth_bwd<<<dim3(nblk_total, 2 * L.B), GS_BLOCK, 0, st>>>(D, G);
+    DFE_LAUNCH_CHECK();
+    DFE_MARK();
+  }
   k_geom_disp_smooth_bwd1<<<dim3(L.nblk0, 3 * L.B), GS_BLOCK, 0, st>>>(D, G);
   DFE_LAUNCH_CHECK();
   DFE_MARK();

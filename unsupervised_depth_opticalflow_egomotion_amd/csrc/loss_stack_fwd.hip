@@ -21,7 +21,7 @@ static inline long align4(long v) { return (v + 3) & ~3L; }
 int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
   if (!a) return DFE_ERR_NULL;
   if (a->B <= 0 || a->H < 8 || a->W < 8 || a->num_scales <= 0 || a->num_scales > DFE_MAX_SCALES) return DFE_ERR_DIMS;
-  if (a->mode != 0) return DFE_ERR_UNSUPPORTED;
+  if (a->mode != 0 && a->mode != 1) return DFE_ERR_UNSUPPORTED;
   L->B = a->B; L->S = a->num_scales;
   L->off_px[0] = 0; L->blk_start[0] = 0; L->tile_start[0] = 0;
   for (int s = 0; s < L->S; ++s) {
@@ -69,7 +69,7 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
 
 void geom_dev(const dfe_geom_args* a, const GeomLayout& L, GeomDev* D) {
   float* ws = a->workspace;
-  D->B = L.B; D->S = L.S; D->ac = a->align_corners; D->alpha = a->alpha; D->beta = a->beta;
+  D->B = L.B; D->S = L.S; D->ac = a->align_corners; D->mode = a->mode; D->alpha = a->alpha; D->beta = a->beta;
   for (int s = 0; s <= L.S; ++s) { D->blk_start[s] = L.blk_start[s]; D->tile_start[s] = L.tile_start[s]; D->vblk_start[s] = L.vblk_start[s]; }
   for (int s = 0; s < L.S; ++s) {
     D->H[s] = L.H[s]; D->W[s] = L.W[s]; D->N[s] = L.N[s]; D->tiles_x[s] = L.tiles_x[s];
@@ -300,6 +300,52 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, float* _
   block_sum<PT_COUNT>(acc, red, part + (static_cast<long>(b) * nblk_total + blk) * PT_COUNT);
 }
 
+// ---------------------------------------------------------------------- depth-only pointwise forward
+// Model_depth loss stack (model_depth.py:296-323): rigid recon of both sources, mask = inverse_warp2
+// validity * texture mask, masked-L1 sums.  One pixel per thread over the 1-px block table.
+__global__ void __launch_bounds__(GS_BLOCK) k_depth_point_fwd(GeomDev D, float* __restrict__ part) {
+  __shared__ float red[PT_COUNT * 4 * (GS_BLOCK / 64)];
+  const unsigned nblk_total = D.vblk_start[D.S];
+  const unsigned blk = xcd_swizzle(blockIdx.x, nblk_total);
+  const int b = blockIdx.y;
+  const int s = find_scale(D.vblk_start, D.S, blk);
+  const int H = D.H[s], W = D.W[s], N = D.N[s];
+  const unsigned p = (blk - D.vblk_start[s]) * GS_BLOCK + threadIdx.x;
+  float acc[PT_COUNT];
+#pragma unroll
+  for (int i = 0; i < PT_COUNT; ++i) acc[i] = 0.0f;
+  if (p < static_cast<unsigned>(N)) {
+    const unsigned py = p / static_cast<unsigned>(W), px = p - py * W;
+    const unsigned p4 = p * 4u, N4 = static_cast<unsigned>(N) * 4u;
+    const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
+    const float i0 = ldb(it, p4), i1 = ldb(it, p4 + N4), i2 = ldb(it, p4 + 2 * N4);
+    const float dsp = ldb(D.disp[1][s] + static_cast<long>(b) * N, p4);
+    const Divisor dw = make_divisor(static_cast<float>(W - 1)), dh = make_divisor(static_cast<float>(H - 1));
+    unsigned bits = 0;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const Camera& cam = D.cams[(b * 2 + d) * D.S + s];
+      const Proj pr = project(cam, px, py, dsp);
+      float xn, yn; bool lx, ly;
+      rigid_grid_d(pr, dw, dh, xn, yn, lx, ly);
+      const bool valid = fmaxf(fabsf(xn), fabsf(yn)) <= 1.0f;
+      const FastTap t = make_fast_tap(unnormalize(xn, W, D.ac), unnormalize(yn, H, D.ac), H, W);
+      const float* ar = D.area[d][s] + static_cast<long>(b) * 3 * N;
+      float rec[3];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) rec[ch] = fast_sample(reinterpret_cast<const float*>(reinterpret_cast<const char*>(ar) + ch * N4), t);
+      const float* sp = D.pyr[d == 0 ? 0 : 2][s] + static_cast<long>(b) * 3 * N;
+      const bool tex = mean3_abs_diff(i0, i1, i2, rec[0], rec[1], rec[2]) < mean3_abs_diff(i0, i1, i2, ldb(sp, p4), ldb(sp, p4 + N4), ldb(sp, p4 + 2 * N4));
+      const float m = (valid && tex) ? 1.0f : 0.0f;
+      acc[d * PT_PER_DIR + PT_M_TEX] = m;
+      acc[d * PT_PER_DIR + PT_L1_DEPTH] = ((fabsf(i0 - rec[0]) + fabsf(i1 - rec[1])) + fabsf(i2 - rec[2])) * m;
+      bits |= (valid ? (DFE_MASK_VALID_BWD << d) : 0u) | (tex ? (DFE_MASK_TEX_BWD << d) : 0u);
+    }
+    (D.mask[s] + static_cast<long>(b) * N)[p] = static_cast<unsigned char>(bits);
+  }
+  block_sum<PT_COUNT>(acc, red, part + (static_cast<long>(b) * nblk_total + blk) * PT_COUNT);
+}
+
 // ---------------------------------------------------------------------- SSIM forward (stage P)
 // grid: x = tile over all scales, y = b*2 + d.  x = I * vo (mask bits), y = yw (already masked).
 __global__ void __launch_bounds__(GS_TX * GS_TY) k_geom_ssim_fwd(GeomDev D, float* __restrict__ spart) {
@@ -446,14 +492,14 @@ __global__ void __launch_bounds__(256) k_geom_finalize_fwd(GeomDev D, const floa
 #pragma unroll
       for (int i = 0; i < PT_COUNT; ++i) a[i] += r[i];
     }
-    for (int k = D.blk_start[s] + t; k < D.blk_start[s + 1]; k += 256) {
+    if (D.mode == 0) for (int k = D.blk_start[s] + t; k < D.blk_start[s + 1]; k += 256) {
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
         const float* q = fpart + (static_cast<long>(d * B + b) * nblk_total + k) * 2;
         a[SUM_FS + 2 * d] += q[0]; a[SUM_FS + 2 * d + 1] += q[1];
       }
     }
-    for (int k = D.tile_start[s] + t; k < D.tile_start[s + 1]; k += 256) {
+    if (D.mode == 0) for (int k = D.tile_start[s] + t; k < D.tile_start[s + 1]; k += 256) {
       a[SUM_SSIM] += spart[static_cast<long>(b * 2) * ntile_total + k];
       a[SUM_SSIM + 1] += spart[static_cast<long>(b * 2 + 1) * ntile_total + k];
     }
@@ -535,13 +581,14 @@ __global__ void __launch_bounds__(256) k_geom_finalize_fwd(GeomDev D, const floa
 using namespace dfe;
 
 static int check_args(const dfe_geom_args* a, const GeomLayout& L, bool bwd) {
-  if (!a->workspace || !a->pose || !a->K || !a->K_inv) return DFE_ERR_NULL;
+  if (!a->workspace || !a->pose || !a->K) return DFE_ERR_NULL;
+  if (a->mode == 0 && !a->K_inv) return DFE_ERR_NULL;
   if (a->workspace_floats < L.total) return DFE_ERR_WORKSPACE;
   for (int f = 0; f < 3; ++f) {
     if (!a->img[f]) return DFE_ERR_NULL;
     for (int s = 0; s < L.S; ++s) if (!a->disp[f][s]) return DFE_ERR_NULL;
   }
-  for (int d = 0; d < 2; ++d) for (int s = 0; s < L.S; ++s) if (!a->flow[d][s]) return DFE_ERR_NULL;
+  if (a->mode == 0) for (int d = 0; d < 2; ++d) for (int s = 0; s < L.S; ++s) if (!a->flow[d][s]) return DFE_ERR_NULL;
   if (!bwd && !a->losses) return DFE_ERR_NULL;
   if (bwd && !a->grad_losses) return DFE_ERR_NULL;
   if (a->B > 32767) return DFE_ERR_DIMS;
@@ -584,8 +631,10 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   for (int s = 0; s < L.S; ++s) downs[s] = static_cast<float>(static_cast<double>(a->H) / static_cast<double>(L.H[s]));
   rc = dfe_prepare_cameras(a->pose, a->K, ws + L.o_cams, L.B, 2, L.S, downs, stream);
   if (rc != DFE_OK) return rc;
-  k_prepare_epi<<<(L.B * 2 + 63) / 64, 64, 0, st>>>(a->pose, a->K_inv, reinterpret_cast<Epi*>(ws + L.o_epi), D.cams, L.B, L.S);
-  DFE_LAUNCH_CHECK();
+  if (a->mode == 0) {
+    k_prepare_epi<<<(L.B * 2 + 63) / 64, 64, 0, st>>>(a->pose, a->K_inv, reinterpret_cast<Epi*>(ws + L.o_epi), D.cams, L.B, L.S);
+    DFE_LAUNCH_CHECK();
+  }
   DFE_MARK();
   if (L.S > 1) {
     PyrJobs jobs;
@@ -602,7 +651,12 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   }
   DFE_MARK();
   const unsigned nblk_total = L.blk_start[L.S], ntile_total = L.tile_start[L.S];
-  {
+  if (a->mode == 1) {
+    // Model_depth: rigid recon + validity*texture mask + masked L1 only (no flows, no SSIM, no flow terms)
+    k_depth_point_fwd<<<dim3(L.vblk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
+    DFE_LAUNCH_CHECK();
+    DFE_MARK(); DFE_MARK(); DFE_MARK();
+  } else {
     // the 16-byte path also needs 16-byte aligned streams (torch allocations are; views may not be)
     bool al = true;
     auto chk = [&](const void* q) { al = al && ((reinterpret_cast<uintptr_t>(q) & 15) == 0); };
@@ -612,15 +666,15 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     if (L.V == 4 && !al) return DFE_ERR_UNSUPPORTED;   // callers pass contiguous torch tensors; never hit in practice
     if (L.V == 4) k_geom_point_fwd<4><<<dim3(L.vblk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
     else k_geom_point_fwd<1><<<dim3(L.vblk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
+    DFE_LAUNCH_CHECK();
+    DFE_MARK();
+    k_geom_ssim_fwd<<<dim3(ntile_total, L.B * 2), GS_TX * GS_TY, 0, st>>>(D, ws + L.o_spart);
+    DFE_LAUNCH_CHECK();
+    DFE_MARK();
+    k_geom_flow_smooth_fwd<<<dim3(nblk_total, 2 * L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_fpart);
+    DFE_LAUNCH_CHECK();
+    DFE_MARK();
   }
-  DFE_LAUNCH_CHECK();
-  DFE_MARK();
-  k_geom_ssim_fwd<<<dim3(ntile_total, L.B * 2), GS_TX * GS_TY, 0, st>>>(D, ws + L.o_spart);
-  DFE_LAUNCH_CHECK();
-  DFE_MARK();
-  k_geom_flow_smooth_fwd<<<dim3(nblk_total, 2 * L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_fpart);
-  DFE_LAUNCH_CHECK();
-  DFE_MARK();
   k_geom_disp_smooth_fwd<<<dim3(L.nblk0, 3 * L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_dpart);
   DFE_LAUNCH_CHECK();
   DFE_MARK();

@@ -52,10 +52,10 @@ def _scale_hw(h, w, s):
     return int(h / (2 ** s)), int(w / (2 ** s))
 
 
-def _fill_args(imgs, disps, flows, pose, K, K_inv, S, alpha, beta, ac):
+def _fill_args(imgs, disps, flows, pose, K, K_inv, S, alpha, beta, ac, mode=0):
     a = GeomArgs()
     B, _, H, W = imgs[0].shape
-    a.B, a.H, a.W, a.num_scales, a.align_corners, a.mode = B, H, W, S, int(ac), 0
+    a.B, a.H, a.W, a.num_scales, a.align_corners, a.mode = B, H, W, S, int(ac), int(mode)
     a.alpha, a.beta = float(alpha), float(beta)
     for f in range(3):
         if tuple(imgs[f].shape) != (B, 3, H, W):
@@ -66,31 +66,41 @@ def _fill_args(imgs, disps, flows, pose, K, K_inv, S, alpha, beta, ac):
             if tuple(disps[f][s].shape) != (B, 1, hs, ws):
                 raise ValueError("disp[%d][%d] must be %s, got %s" % (f, s, (B, 1, hs, ws), tuple(disps[f][s].shape)))
             a.disp[f][s] = _dp(disps[f][s])
-    for d in range(2):
+    for d in range(2 if mode == 0 else 0):
         for s in range(S):
             hs, ws = _scale_hw(H, W, s)
             if tuple(flows[d][s].shape) != (B, 2, hs, ws):
                 raise ValueError("flow[%d][%d] must be %s, got %s" % (d, s, (B, 2, hs, ws), tuple(flows[d][s].shape)))
             a.flow[d][s] = _dp(flows[d][s])
-    if tuple(pose.shape) != (B, 2, 6) or tuple(K.shape) != (B, 3, 3) or tuple(K_inv.shape) != (B, 3, 3):
+    if tuple(pose.shape) != (B, 2, 6) or tuple(K.shape) != (B, 3, 3) or (mode == 0 and tuple(K_inv.shape) != (B, 3, 3)):
         raise ValueError("pose must be [B,2,6] and K, K_inv [B,3,3]")
-    a.pose, a.K, a.K_inv = _dp(pose), _dp(K), _dp(K_inv)
+    a.pose, a.K = _dp(pose), _dp(K)
+    a.K_inv = _dp(K_inv) if mode == 0 else None
     return a
 
 
-class GeomLossFn(torch.autograd.Function):
-    """forward(*tensors) -> losses [8,B].  Tensor order: 3 frames, 3*S disps (frame-major),
-    2*S flows (bwd scales then fwd scales), pose, K, K_inv."""
-
-    @staticmethod
-    def forward(ctx, S, alpha, beta, ac, *t):
-        lib = get_lib()
-        t = [f32c(x) for x in t]
-        imgs = t[0:3]
-        disps = [t[3 + f * S: 3 + (f + 1) * S] for f in range(3)]
+def _unpack(t, S, mode):
+    imgs = t[0:3]
+    disps = [t[3 + f * S: 3 + (f + 1) * S] for f in range(3)]
+    if mode == 0:
         flows = [t[3 + 3 * S + d * S: 3 + 3 * S + (d + 1) * S] for d in range(2)]
         pose, K, K_inv = t[3 + 5 * S:]
-        a = _fill_args(imgs, disps, flows, pose, K, K_inv, S, alpha, beta, ac)
+    else:
+        flows, (pose, K), K_inv = None, t[3 + 3 * S:], None
+    return imgs, disps, flows, pose, K, K_inv
+
+
+class GeomLossFn(torch.autograd.Function):
+    """forward(*tensors) -> losses [8,B].  Tensor order: 3 frames, 3*S disps (frame-major), then for
+    mode 0 (Model_geometry) 2*S flows (bwd scales then fwd scales), pose, K, K_inv; for mode 1 (Model_depth)
+    pose, K."""
+
+    @staticmethod
+    def forward(ctx, mode, S, alpha, beta, ac, *t):
+        lib = get_lib()
+        t = [f32c(x) for x in t]
+        imgs, disps, flows, pose, K, K_inv = _unpack(t, S, mode)
+        a = _fill_args(imgs, disps, flows, pose, K, K_inv, S, alpha, beta, ac, mode)
         n = lib.dfe_geom_workspace_floats(ctypes.byref(a))
         if n < 0:
             check(int(n), "dfe_geom_workspace_floats")
@@ -100,7 +110,7 @@ class GeomLossFn(torch.autograd.Function):
         a.workspace, a.workspace_floats, a.losses = ws.data_ptr(), n, losses.data_ptr()
         check(lib.dfe_geom_loss_fwd(ctypes.byref(a), stream_ptr()), "dfe_geom_loss_fwd")
         ctx.save_for_backward(*t)
-        ctx.cfg = (S, alpha, beta, ac)
+        ctx.cfg = (mode, S, alpha, beta, ac)
         ctx.ws = ws
         ctx.mark_non_differentiable(ws)
         return losses, ws
@@ -108,33 +118,30 @@ class GeomLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, glosses, _gws=None):
         lib = get_lib()
-        S, alpha, beta, ac = ctx.cfg
+        mode, S, alpha, beta, ac = ctx.cfg
         t = list(ctx.saved_tensors)
-        imgs = t[0:3]
-        disps = [t[3 + f * S: 3 + (f + 1) * S] for f in range(3)]
-        flows = [t[3 + 3 * S + d * S: 3 + 3 * S + (d + 1) * S] for d in range(2)]
-        pose, K, K_inv = t[3 + 5 * S:]
-        a = _fill_args(imgs, disps, flows, pose, K, K_inv, S, alpha, beta, ac)
+        imgs, disps, flows, pose, K, K_inv = _unpack(t, S, mode)
+        a = _fill_args(imgs, disps, flows, pose, K, K_inv, S, alpha, beta, ac, mode)
         glosses = f32c(glosses)
         a.workspace, a.workspace_floats = ctx.ws.data_ptr(), ctx.ws.numel()
         a.grad_losses = glosses.data_ptr()
         gd = [[torch.empty_like(x) for x in lst] for lst in disps]
-        gf = [[torch.empty_like(x) for x in lst] for lst in flows]
+        gf = [[torch.empty_like(x) for x in lst] for lst in flows] if mode == 0 else []
         gp = torch.empty_like(pose)
         for f in range(3):
             for s in range(S):
                 a.grad_disp[f][s] = gd[f][s].data_ptr()
-        for d in range(2):
+        for d in range(len(gf)):
             for s in range(S):
                 a.grad_flow[d][s] = gf[d][s].data_ptr()
         a.grad_pose = gp.data_ptr()
         check(lib.dfe_geom_loss_bwd(ctypes.byref(a), stream_ptr()), "dfe_geom_loss_bwd")
-        grads = [None, None, None, None, None, None, None]  # S, alpha, beta, ac, 3 frames
+        grads = [None] * 8          # mode, S, alpha, beta, ac, 3 frames
         for f in range(3):
             grads += gd[f]
-        for d in range(2):
+        for d in range(len(gf)):
             grads += gf[d]
-        grads += [gp, None, None]
+        grads += [gp, None, None] if mode == 0 else [gp, None]
         return tuple(grads)
 
 
@@ -151,12 +158,30 @@ def geom_loss_stack(img_l, img, img_r, disp_l_list, disp_list, disp_r_list, pose
     ac = ops.get_align_corners() if align_corners is None else bool(align_corners)
     tensors = [img_l, img, img_r] + list(disp_l_list[:S]) + list(disp_list[:S]) + list(disp_r_list[:S]) \
         + list(flows_bwd[:S]) + list(flows_fwd[:S]) + [pose_vectors, K, K_inv]
-    losses, ws = GeomLossFn.apply(S, float(flow_consist_alpha), float(flow_consist_beta), int(ac), *tensors)
+    losses, ws = GeomLossFn.apply(0, S, float(flow_consist_alpha), float(flow_consist_beta), int(ac), *tensors)
     pack = {name: losses[i] for i, name in enumerate(LOSS_ROWS)}
     if not return_masks:
         return pack
     B, _, H, W = img.shape
     return pack, decode_masks(ws, B, H, W, S)
+
+
+def depth_loss_stack(img_l, img, img_r, depth_l_list, depth_list, depth_r_list, pose_vectors, K, num_scales=3,
+                     align_corners=None, return_masks=False):
+    """Active ``loss_pack`` entries of Model_depth.forward (model_depth.py:272-337): ``loss_depth_pixel`` with
+    the inverse_warp2-validity x texture mask and ``loss_depth_smooth``, in the fused launches (mode 1)."""
+    S = int(num_scales)
+    ac = ops.get_align_corners() if align_corners is None else bool(align_corners)
+    tensors = [img_l, img, img_r] + list(depth_l_list[:S]) + list(depth_list[:S]) + list(depth_r_list[:S]) \
+        + [pose_vectors, K]
+    losses, ws = GeomLossFn.apply(1, S, 0.0, 0.0, int(ac), *tensors)
+    pack = {"loss_depth_pixel": losses[0], "loss_depth_smooth": losses[1]}
+    if not return_masks:
+        return pack
+    B, _, H, W = img.shape
+    m = decode_masks(ws, B, H, W, S)
+    return pack, {"valid_to_l": m["valid_bwd"], "valid_to_r": m["valid_fwd"], "texture_bwd": m["texture_bwd"],
+                  "texture_fwd": m["texture_fwd"]}
 
 
 def decode_masks(ws, B, H, W, S):

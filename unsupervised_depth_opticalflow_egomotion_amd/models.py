@@ -10,7 +10,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .loss_stack import geom_loss_stack
+from .loss_stack import geom_loss_stack, depth_loss_stack
 from .loss_terms import LossTerms
 from .networks import Depth_Model, PoseCNN, FeaturePyramid, PWC_tf
 
@@ -192,6 +192,16 @@ class Model_depth(LossTerms, nn.Module):
         return self.loss_stack(img_l, img, img_r, depth_l, depth_t, depth_r, pose, K)
 
     def loss_stack(self, img_l, img, img_r, depth_l, depth_t, depth_r, pose, K):
+        """model_depth.py:296-335 in the fused HIP launches (mode 1 of dfe_geom_loss_fwd/bwd)."""
+        active = depth_loss_stack(img_l, img, img_r, depth_l, depth_t, depth_r, pose, K.contiguous(),
+                                  num_scales=self.num_scales)
+        dev = img.device
+        loss_pack = {"loss_depth_pixel": active["loss_depth_pixel"], "loss_depth_ssim": _zeros2(dev),
+                     "loss_depth_smooth": active["loss_depth_smooth"], "loss_depth_consis": _zeros2(dev)}
+        return loss_pack, {}
+
+    def loss_stack_per_op(self, img_l, img, img_r, depth_l, depth_t, depth_r, pose, K):
+        """The same terms through the per-operator kernels and the per-method API (kept for cross-checking)."""
         S = self.num_scales
         pyr_t, pyr_l, pyr_r = (self.generate_img_pyramid(x, S) for x in (img, img_l, img_r))
         rec_l, valid_l, _, _ = self.reconstruction(img_l, K, depth_t, depth_l, pose[:, 0, :].contiguous())
