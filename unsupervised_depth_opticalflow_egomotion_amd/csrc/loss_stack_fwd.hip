@@ -38,8 +38,8 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
     L->tile_start[s + 1] = L->tile_start[s] + L->ntile[s];
   }
   L->nblk0 = L->nblk[0];
-  // V = 4 (16-byte streams) measured SLOWER at B=4, 256x832 (84 vs 50 us): 4x fewer waves at 3-wave
-  // occupancy leave the SIMDs unable to cover gather latency.  Kept as an instantiation for large batches.
+  // Measured at B=4, 256x832 (MI355X): V=1 48 us, V=2 62 us, V=4 83 us; 128-thread blocks 51 us.  Fatter threads
+  // lose more occupancy / wave count than their wider streams save; the V>1 instantiations stay for large batches.
   L->V = 1;
   L->vblk_start[0] = 0;
   for (int s = 0; s < L->S; ++s) L->vblk_start[s + 1] = L->vblk_start[s] + (L->N[s] + GS_BLOCK * L->V - 1) / (GS_BLOCK * L->V);
@@ -229,6 +229,7 @@ __device__ __forceinline__ void point_pixel(const PointCtx& c, int px, int py, c
 
 template <int V> struct VecF;
 template <> struct VecF<1> { float v[1]; };
+template <> struct __attribute__((aligned(8))) VecF<2> { float v[2]; };
 template <> struct __attribute__((aligned(16))) VecF<4> { float v[4]; };
 
 template <int V>
@@ -295,7 +296,9 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, float* _
       for (int ch = 0; ch < 3; ++ch) stv<V>(ywp, p4 + ch * N4, yo[d][ch]);
     }
     unsigned char* mk = D.mask[s] + static_cast<long>(b) * N + p;
-    if (V == 4) *reinterpret_cast<unsigned*>(mk) = packed; else *mk = static_cast<unsigned char>(packed);
+    if (V == 4) *reinterpret_cast<unsigned*>(mk) = packed;
+    else if (V == 2) *reinterpret_cast<unsigned short*>(mk) = static_cast<unsigned short>(packed);
+    else *mk = static_cast<unsigned char>(packed);
   }
   block_sum<PT_COUNT>(acc, red, part + (static_cast<long>(b) * nblk_total + blk) * PT_COUNT);
 }
@@ -665,6 +668,7 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     chk(ws);
     if (L.V == 4 && !al) return DFE_ERR_UNSUPPORTED;   // callers pass contiguous torch tensors; never hit in practice
     if (L.V == 4) k_geom_point_fwd<4><<<dim3(L.vblk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
+    else if (L.V == 2) k_geom_point_fwd<2><<<dim3(L.vblk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
     else k_geom_point_fwd<1><<<dim3(L.vblk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
     DFE_LAUNCH_CHECK();
     DFE_MARK();
