@@ -162,9 +162,14 @@ __global__ void k_pose_mats_bwd(const float* __restrict__ vec, const float* __re
 }
 
 // ====================================================================== warp_flow
-__global__ void k_warp_flow_fwd(const float* __restrict__ x, const float* __restrict__ flow,
-                                float* __restrict__ out, int C, int H, int W, int use_mask, int ac) {
-  const int b = blockIdx.y, HW = H * W;
+// One thread per (sample, chunk of WF_CK channels, pixel): the PWC feature warps have 32-196 channels on
+// images as small as 4x13, so parallelism has to come from the channels; the chunk's 2*WF_CK pair loads are
+// all in flight together.  grid: x = pixel blocks of 64, y = channel chunk, z = sample.
+constexpr int WF_CK = 8;
+
+__global__ void __launch_bounds__(64) k_warp_flow_fwd(const float* __restrict__ x, const float* __restrict__ flow,
+                                                      float* __restrict__ out, int C, int H, int W, int use_mask, int ac) {
+  const int b = blockIdx.z, c0 = blockIdx.y * WF_CK, HW = H * W;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= HW) return;
   const int py = p / W, px = p - py * W;
@@ -174,18 +179,21 @@ __global__ void k_warp_flow_fwd(const float* __restrict__ x, const float* __rest
   Tap t = make_tap(ix, iy, H, W);
   float keep = 1.0f;
   if (use_mask) keep = (tap_cover(t) < 0.9999f) ? 0.0f : 1.0f;
-  for (int c = 0; c < C; ++c) {
-    const float* plane = x + (static_cast<long>(b) * C + c) * HW;
-    Corners q = load_corners(plane, t, W, H);
-    out[(static_cast<long>(b) * C + c) * HW + p] = interp(q, t) * keep;
-  }
+  const int nch = min(WF_CK, C - c0);
+  Corners q[WF_CK];
+#pragma unroll
+  for (int c = 0; c < WF_CK; ++c) q[c] = load_corners(x + (static_cast<long>(b) * C + c0 + (c < nch ? c : 0)) * HW, t, W, H);
+#pragma unroll
+  for (int c = 0; c < WF_CK; ++c)
+    if (c < nch) out[(static_cast<long>(b) * C + c0 + c) * HW + p] = interp(q[c], t) * keep;
 }
 
-// grad wrt flow (sum over channels) and optionally wrt x (scatter-add; gx pre-zeroed).
-__global__ void k_warp_flow_bwd(const float* __restrict__ x, const float* __restrict__ flow,
-                                const float* __restrict__ gout, float* __restrict__ gflow,
-                                float* __restrict__ gx, int C, int H, int W, int use_mask, int ac) {
-  const int b = blockIdx.y, HW = H * W;
+// grad wrt flow (sum over channels: float atomics across the channel chunks when C > WF_CK; gflow is
+// zero-filled by the launcher in that case) and optionally wrt x (scatter-add; gx pre-zeroed by the caller).
+__global__ void __launch_bounds__(64) k_warp_flow_bwd(const float* __restrict__ x, const float* __restrict__ flow,
+                                                      const float* __restrict__ gout, float* __restrict__ gflow,
+                                                      float* __restrict__ gx, int C, int H, int W, int use_mask, int ac) {
+  const int b = blockIdx.z, c0 = blockIdx.y * WF_CK, HW = H * W;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= HW) return;
   const int py = p / W, px = p - py * W;
@@ -195,28 +203,37 @@ __global__ void k_warp_flow_bwd(const float* __restrict__ x, const float* __rest
   Tap t = make_tap(ix, iy, H, W);
   float keep = 1.0f;
   if (use_mask) keep = (tap_cover(t) < 0.9999f) ? 0.0f : 1.0f;
-  float gix = 0.0f, giy = 0.0f;
-  for (int c = 0; c < C; ++c) {
-    const long off = (static_cast<long>(b) * C + c) * HW;
-    float g = gout[off + p] * keep;
-    if (gflow) {
-      Corners q = load_corners(x + off, t, W, H);
-      float dx, dy;
-      interp_grad(q, t, dx, dy);
-      gix += g * dx; giy += g * dy;
-    }
-    if (gx && g != 0.0f) {
-      float* base = gx + off + static_cast<long>(t.y0) * W + t.x0;
-      if (t.in_nw) atomicAdd(base, g * t.nw);
-      if (t.in_ne) atomicAdd(base + 1, g * t.ne);
-      if (t.in_sw) atomicAdd(base + W, g * t.sw);
-      if (t.in_se) atomicAdd(base + W + 1, g * t.se);
-    }
-  }
+  const int nch = min(WF_CK, C - c0);
+  float g[WF_CK];
+#pragma unroll
+  for (int c = 0; c < WF_CK; ++c) g[c] = (c < nch) ? gout[(static_cast<long>(b) * C + c0 + c) * HW + p] * keep : 0.0f;
   if (gflow) {
+    Corners q[WF_CK];
+#pragma unroll
+    for (int c = 0; c < WF_CK; ++c) q[c] = load_corners(x + (static_cast<long>(b) * C + c0 + (c < nch ? c : 0)) * HW, t, W, H);
+    float gix = 0.0f, giy = 0.0f;
+#pragma unroll
+    for (int c = 0; c < WF_CK; ++c) {
+      float dx, dy;
+      interp_grad(q[c], t, dx, dy);
+      gix += g[c] * dx; giy += g[c] * dy;
+    }
     float* gf = gflow + static_cast<long>(b) * 2 * HW;
-    gf[p] = gix * flow_coord_scale(W, ac);
-    gf[HW + p] = giy * flow_coord_scale(H, ac);
+    const float vx = gix * flow_coord_scale(W, ac), vy = giy * flow_coord_scale(H, ac);
+    if (gridDim.y == 1) { gf[p] = vx; gf[HW + p] = vy; }
+    else { atomicAdd(gf + p, vx); atomicAdd(gf + HW + p, vy); }
+  }
+  if (gx) {
+#pragma unroll
+    for (int c = 0; c < WF_CK; ++c) {
+      if (c < nch && g[c] != 0.0f) {
+        float* base = gx + (static_cast<long>(b) * C + c0 + c) * HW + static_cast<long>(t.y0) * W + t.x0;
+        if (t.in_nw) atomicAdd(base, g[c] * t.nw);
+        if (t.in_ne) atomicAdd(base + 1, g[c] * t.ne);
+        if (t.in_sw) atomicAdd(base + W, g[c] * t.sw);
+        if (t.in_se) atomicAdd(base + W + 1, g[c] * t.se);
+      }
+    }
   }
 }
 
@@ -465,7 +482,8 @@ __global__ void __launch_bounds__(256) k_corr_fwd(const float* __restrict__ f1, 
 #pragma unroll
     for (int j = 0; j < CR_K; ++j) acc[u][j] = 0.0f;
   if (row_ok) {
-    for (int c = 0; c < C; ++c) {
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {   // 4 channels of loads in flight: the mid levels run ~1 wave per SIMD
       float a[V], w[V + 2 * CR_D];
       if (V == 4) { float4 v = *reinterpret_cast<const float4*>(p1 + c * HW); a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
       else a[0] = p1[c * HW];
@@ -483,6 +501,55 @@ __global__ void __launch_bounds__(256) k_corr_fwd(const float* __restrict__ f1, 
     if (V == 4) *reinterpret_cast<float4*>(o + j * HW) = make_float4(acc[0][j] / fc, acc[1][j] / fc, acc[2][j] / fc, acc[3][j] / fc);
     else o[j * HW] = acc[0][j] / fc;
   }
+}
+
+// W % 4 != 0 (the 8x26 and 4x13 PWC levels): one thread per OUTPUT element.  These levels are tiny (<= 208 px)
+// with the most channels (128/196); a thread per (b, k, y, x) gives 81x the threads of a per-pixel mapping and
+// two independent, coalesced loads per channel (4-way unrolled), instead of 52 px * 9 threads looping 196 channels.
+__global__ void __launch_bounds__(256) k_corr_fwd_naive(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                        float* __restrict__ out, int B, int C, int H, int W) {
+  const long HW = static_cast<long>(H) * W, total = static_cast<long>(B) * CR_K * CR_K * HW;
+  const long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int x = static_cast<int>(t % W), y = static_cast<int>((t / W) % H);
+  const int k = static_cast<int>((t / HW) % (CR_K * CR_K)), b = static_cast<int>(t / (HW * CR_K * CR_K));
+  const int r = y + k / CR_K - CR_D, q = x + k % CR_K - CR_D;
+  float acc = 0.0f;
+  if (r >= 0 && r < H && q >= 0 && q < W) {
+    const float* p1 = f1 + static_cast<long>(b) * C * HW + static_cast<long>(y) * W + x;
+    const float* p2 = f2 + static_cast<long>(b) * C * HW + static_cast<long>(r) * W + q;
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) acc += p1[c * HW] * p2[c * HW];
+  }
+  out[t] = acc / static_cast<float>(C);
+}
+
+// one thread per (b, c, y, x); MODE as in k_corr_bwd below
+template <int MODE>
+__global__ void __launch_bounds__(256) k_corr_bwd_naive(const float* __restrict__ other, const float* __restrict__ gout,
+                                                        float* __restrict__ gin, int B, int C, int H, int W) {
+  const long HW = static_cast<long>(H) * W, total = static_cast<long>(B) * C * HW;
+  const long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int x = static_cast<int>(t % W), y = static_cast<int>((t / W) % H);
+  const int c = static_cast<int>((t / HW) % C), b = static_cast<int>(t / (HW * C));
+  const float* ob = other + (static_cast<long>(b) * C + c) * HW;
+  const float* gb = gout + static_cast<long>(b) * CR_K * CR_K * HW;
+  float acc = 0.0f;
+#pragma unroll 3
+  for (int i = 0; i < CR_K; ++i) {
+    const int r = (MODE == 0) ? y + i - CR_D : y - (i - CR_D);
+    if (r < 0 || r >= H) continue;
+#pragma unroll
+    for (int j = 0; j < CR_K; ++j) {
+      const int q = (MODE == 0) ? x + j - CR_D : x - (j - CR_D);
+      if (q < 0 || q >= W) continue;
+      const float g = (MODE == 0) ? gb[(i * CR_K + j) * HW + static_cast<long>(y) * W + x]
+                                  : gb[(i * CR_K + j) * HW + static_cast<long>(r) * W + q];
+      acc += g * ob[static_cast<long>(r) * W + q];
+    }
+  }
+  gin[t] = acc / static_cast<float>(C);
 }
 
 // g1[c,p] = 1/C sum_{i,j} g[i*9+j, p] * f2[c, p + (i-4, j-4)]          (MODE 0, other = f2)
@@ -521,9 +588,10 @@ __global__ void __launch_bounds__(256) k_corr_bwd(const float* __restrict__ othe
         if (V == 4) { float4 v = *reinterpret_cast<const float4*>(gp); g[j][0] = v.x; g[j][1] = v.y; g[j][2] = v.z; g[j][3] = v.w; }
         else g[j][0] = gp[0];
       }
-      for (int c = 0; c < nch; ++c) {
+#pragma unroll
+      for (int c = 0; c < CR_CK; ++c) {   // fully unrolled: all CR_CK windows in flight
         float w[V + 2 * CR_D];
-        load_window<V>(ob + c * HW + static_cast<long>(r) * W, x0, W, true, w);
+        load_window<V>(ob + (c < nch ? c : 0) * HW + static_cast<long>(r) * W, x0, W, c < nch, w);
 #pragma unroll
         for (int u = 0; u < V; ++u)
 #pragma unroll
@@ -622,8 +690,9 @@ int dfe_warp_flow_fwd(const float* x, const float* flow, float* out, int B, int 
                       int align_corners, void* stream) {
   DFE_REQUIRE(x && flow && out, DFE_ERR_NULL);
   DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
-  dim3 g(static_cast<unsigned>((static_cast<long>(H) * W + 255) / 256), B);
-  k_warp_flow_fwd<<<g, 256, 0, static_cast<hipStream_t>(stream)>>>(x, flow, out, C, H, W, use_mask, align_corners);
+  DFE_REQUIRE(B <= 65535 && (C + WF_CK - 1) / WF_CK <= 65535, DFE_ERR_DIMS);
+  dim3 g(static_cast<unsigned>((static_cast<long>(H) * W + 63) / 64), (C + WF_CK - 1) / WF_CK, B);
+  k_warp_flow_fwd<<<g, 64, 0, static_cast<hipStream_t>(stream)>>>(x, flow, out, C, H, W, use_mask, align_corners);
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
@@ -632,8 +701,11 @@ int dfe_warp_flow_bwd(const float* x, const float* flow, const float* gout, floa
                       int H, int W, int use_mask, int align_corners, void* stream) {
   DFE_REQUIRE(x && flow && gout && (gflow || gx), DFE_ERR_NULL);
   DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
-  dim3 g(static_cast<unsigned>((static_cast<long>(H) * W + 255) / 256), B);
-  k_warp_flow_bwd<<<g, 256, 0, static_cast<hipStream_t>(stream)>>>(x, flow, gout, gflow, gx, C, H, W, use_mask, align_corners);
+  DFE_REQUIRE(B <= 65535 && (C + WF_CK - 1) / WF_CK <= 65535, DFE_ERR_DIMS);
+  dim3 g(static_cast<unsigned>((static_cast<long>(H) * W + 63) / 64), (C + WF_CK - 1) / WF_CK, B);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (gflow && g.y > 1 && hipMemsetAsync(gflow, 0, static_cast<size_t>(B) * 2 * H * W * sizeof(float), st) != hipSuccess) return DFE_ERR_LAUNCH;
+  k_warp_flow_bwd<<<g, 64, 0, st>>>(x, flow, gout, gflow, gx, C, H, W, use_mask, align_corners);
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
@@ -729,8 +801,8 @@ int dfe_corr_fwd(const float* f1, const float* f2, float* out, int B, int C, int
     long n = static_cast<long>(B) * CR_K * H * (W / 4);
     k_corr_fwd<4><<<grid1d(n, 256), 256, 0, st>>>(f1, f2, out, B, C, H, W);
   } else {
-    long n = static_cast<long>(B) * CR_K * H * W;
-    k_corr_fwd<1><<<grid1d(n, 256), 256, 0, st>>>(f1, f2, out, B, C, H, W);
+    long n = static_cast<long>(B) * CR_K * CR_K * H * W;
+    k_corr_fwd_naive<<<grid1d(n, 256), 256, 0, st>>>(f1, f2, out, B, C, H, W);
   }
   DFE_LAUNCH_CHECK();
   return DFE_OK;
@@ -744,15 +816,15 @@ int dfe_corr_bwd(const float* f1, const float* f2, const float* gout, float* g1,
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nchunk = (C + CR_CK - 1) / CR_CK;
   const bool vec = corr_vec_ok(f1, f2, gout, W) && corr_vec_ok(g1, g2, nullptr, W);
-  const long n = static_cast<long>(B) * nchunk * H * (vec ? W / 4 : W);
+  const long n = static_cast<long>(B) * nchunk * H * (W / 4), nn = static_cast<long>(B) * C * H * W;
   if (g1) {
     if (vec) k_corr_bwd<4, 0><<<grid1d(n, 256), 256, 0, st>>>(f2, gout, g1, B, C, H, W);
-    else k_corr_bwd<1, 0><<<grid1d(n, 256), 256, 0, st>>>(f2, gout, g1, B, C, H, W);
+    else k_corr_bwd_naive<0><<<grid1d(nn, 256), 256, 0, st>>>(f2, gout, g1, B, C, H, W);
     DFE_LAUNCH_CHECK();
   }
   if (g2) {
     if (vec) k_corr_bwd<4, 1><<<grid1d(n, 256), 256, 0, st>>>(f1, gout, g2, B, C, H, W);
-    else k_corr_bwd<1, 1><<<grid1d(n, 256), 256, 0, st>>>(f1, gout, g2, B, C, H, W);
+    else k_corr_bwd_naive<1><<<grid1d(nn, 256), 256, 0, st>>>(f1, gout, g2, B, C, H, W);
     DFE_LAUNCH_CHECK();
   }
   return DFE_OK;

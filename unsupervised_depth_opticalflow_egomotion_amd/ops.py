@@ -69,7 +69,7 @@ class WarpFlowFn(torch.autograd.Function):
         use_mask, ac = ctx.cfg
         B, C, H, W = x.shape
         gout = f32c(gout)
-        gflow = torch.empty_like(flow) if ctx.needs_input_grad[1] else None
+        gflow = torch.empty_like(flow) if ctx.needs_input_grad[1] else None   # zero-filled by the library when C > 8
         gx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
         if gflow is None and gx is None:
             return None, None, None, None
