@@ -116,6 +116,79 @@ class LossStackWorkload:
         return run
 
 
+# ------------------------------------------------------------------------------------------------ train step
+class TrainStepWorkload:
+    """bench.py workload: mode=geom on synthetic KITTI-shaped triplets (configs[2] / configs[3])."""
+    name = "train_step"
+
+    def __init__(self, args, dev, seed, world=1):
+        self.args, self.dev = args, dev
+        from unsupervised_depth_opticalflow_egomotion_amd import ddp, synthetic
+        from unsupervised_depth_opticalflow_egomotion_amd.models import get_model
+        from unsupervised_depth_opticalflow_egomotion_amd.train_step import make_cfg
+        self.cfg = make_cfg(num_scales=args.scales, img_hw=(args.height, args.width))
+        torch.manual_seed(1234)           # identical initial weights on every rank
+        self.model = get_model("geom")(self.cfg).to(dev)
+        if os.environ.get("DFE_CHANNELS_LAST", "0") == "1":
+            self.model.use_channels_last(True)
+        self.model.train()
+        self.model = ddp.wrap(self.model, dev)
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        self.opt = torch.optim.Adam(params, lr=self.cfg.lr)
+        im, k, ki = synthetic.make_triplet_batch(args.batch, args.height, args.width, args.scales, seed=seed)
+        self.np_inputs = (im, k, ki)
+        self.inputs = [torch.from_numpy(a).to(dev) for a in (im, k, ki)]   # resident in HBM before timing
+        self._ls = None
+
+    def step(self):
+        from unsupervised_depth_opticalflow_egomotion_amd.train_step import train_step
+        return train_step(self.model, self.opt, self.inputs, self.cfg)[0]
+
+    def loss_stack_workload(self):
+        """Loss-stack-only view on the same shapes, for the per-kernel roofline measurement."""
+        if self._ls is None:
+            self._ls = LossStackWorkload(self.args, self.dev, seed=1234)
+        return self._ls
+
+    def cpu_step_fn(self, threads):
+        """CPU baseline: the same networks on the host + the oracle's loss stack + Adam."""
+        from oracle import loss_stack_oracle as O
+        from unsupervised_depth_opticalflow_egomotion_amd import ddp
+        from unsupervised_depth_opticalflow_egomotion_amd.models import get_model
+        from unsupervised_depth_opticalflow_egomotion_amd.networks import pwc_tf
+        from unsupervised_depth_opticalflow_egomotion_amd.train_step import total_loss
+
+        class OraclePWC(pwc_tf.PWC_tf):
+            def warp(self, x, flow):
+                return O.warp_flow(x, flow, use_mask=False)
+
+            def corr_naive(self, a, b, d=4):
+                return O.corr_naive(a, b, d)
+
+        cfg = self.cfg
+        torch.manual_seed(1234)
+        model = get_model("geom")(cfg)
+        pw = OraclePWC()
+        pw.load_state_dict(model.pwc_model.state_dict())
+        pw.corr = pw.corr_naive
+        model.pwc_model = pw
+        model.train()
+        ddp.freeze_unused(model)
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=cfg.lr)
+        oracle = O.GeomLossOracle(num_scales=cfg.num_scales)
+        images, k_ms, ki_ms = [torch.from_numpy(a) for a in self.np_inputs]
+        h = images.shape[2] // 3
+
+        def run():
+            opt.zero_grad(set_to_none=True)
+            img_l, img, img_r = images[:, :, :h], images[:, :, h:2 * h], images[:, :, 2 * h:]
+            dl, dt, dr, pose, fb, ff = model.run_networks(img_l, img, img_r)
+            lp, _ = oracle.geom_losses(img_l, img, img_r, dl, dt, dr, pose, fb, ff, k_ms[:, 0], ki_ms[:, 0])
+            total_loss(lp, cfg).backward()
+            opt.step()
+        return run
+
+
 # ------------------------------------------------------------------------------------------------ roofline
 def point_fwd_roofline(args, wl, steps):
     """Average duration of k_geom_point_fwd (HIP events on the launch stream, diagnostic entry point of the
@@ -185,8 +258,9 @@ def cpu_baseline(wl, args, unit_pairs):
             break
     dt = (time.perf_counter() - t0) / n
     return {"value": round(unit_pairs / dt, 4), "unit": "frame-pairs/s", "cores": threads, "kind": "port",
-            "sample": "%d timed step(s) of the same workload (B=%d, %dx%d, S=%d, fwd+bwd) on the host CPU, %.2f s/step"
-                      % (n, args.batch, args.height, args.width, args.scales, dt)}
+            "sample": "%d timed step(s) of the same workload (%s, B=%d, %dx%d, S=%d, fwd+bwd%s) on the host CPU, %.2f s/step"
+                      % (n, wl.name, args.batch, args.height, args.width, args.scales,
+                         "+Adam" if wl.name == "train_step" else "", dt)}
 
 
 def main():
@@ -196,13 +270,8 @@ def main():
     dev = torch.device("cuda", local)
     wl_name = args.workload
     if wl_name == "auto":
-        try:
-            from unsupervised_depth_opticalflow_egomotion_amd import train_step as _ts  # noqa: F401
-            wl_name = "train_step"
-        except Exception:
-            wl_name = "loss_stack"
+        wl_name = "train_step"
     if wl_name == "train_step":
-        from unsupervised_depth_opticalflow_egomotion_amd.train_step import TrainStepWorkload
         wl = TrainStepWorkload(args, dev, seed=1234 + rank, world=world)
     else:
         wl = LossStackWorkload(args, dev, seed=1234 + rank)
