@@ -358,6 +358,13 @@ __device__ __forceinline__ float dpp_add(float v) {
   return v + __int_as_float(moved);
 }
 
+// lane l receives lane l-1 / l+1 of the same wave (0 at the wave edge): gfx9 DPP wave_shr:1 / wave_shl:1
+__device__ __forceinline__ float wave_nbr_sum(float v) {
+  const int a = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, true);
+  const int b = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, true);
+  return (v + __int_as_float(a)) + __int_as_float(b);
+}
+
 template <int N>
 __device__ __forceinline__ void block_sum(float (&vals)[N], float* smem, float* out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;

@@ -6,7 +6,11 @@
 namespace dfe {
 
 constexpr int GS_BLOCK = 256;   // threads per block of the pointwise kernels (1 pixel / thread)
-constexpr int GS_TX = 32, GS_TY = 8;  // SSIM tile
+constexpr int GS_TX = 32, GS_TY = 8;  // SSIM tile (backward)
+constexpr int RS_COLS = 62, RS_ROWS = 8;   // rolling SSIM forward: valid columns per wave (64 lanes - 2 halo), rows per wave
+                                            // (measured: rows 4/6/8/16/32 -> 24.2/22.8/21.9/24.0/30.3 us; LDS tile kernel 33 us)
+constexpr int RSB_COLS = 60, RSB_ROWS = 8;  // rolling SSIM backward: 2-lane halo on each side
+                                            // (measured: rows 5/8/16 -> 49.2/44.4/48.0 us; LDS tile kernel 56.9 us)
 
 // ---- per-block partial sums of k_geom_point_fwd (per direction d: index d*PT_PER_DIR + i)
 enum { PT_M_TEX = 0, PT_L1_DEPTH, PT_M_RIG, PT_L1_RIG, PT_M_DYN, PT_L1_DYN, PT_M_VO, PT_FDIFF, PT_EPI, PT_PER_DIR };
@@ -31,6 +35,8 @@ struct GeomLayout {
   int nblk[DFE_MAX_SCALES], blk_start[DFE_MAX_SCALES + 1];      // pointwise blocks per image
   int ntile[DFE_MAX_SCALES], tile_start[DFE_MAX_SCALES + 1], tiles_x[DFE_MAX_SCALES];
   int nblk0;                          // full-resolution blocks (disp smoothness)
+  int roll_start[DFE_MAX_SCALES + 1], roll_strips[DFE_MAX_SCALES];   // rolling-SSIM units (strip x row block) per scale
+  int rollb_start[DFE_MAX_SCALES + 1], rollb_strips[DFE_MAX_SCALES]; // same for the backward kernel
   int V;                              // pixels per thread of k_geom_point_fwd (4 when every W_s % 4 == 0, else 1)
   int vblk_start[DFE_MAX_SCALES + 1]; // its block table
   // workspace offsets in floats
@@ -46,6 +52,8 @@ struct GeomDev {
   int H[DFE_MAX_SCALES], W[DFE_MAX_SCALES], N[DFE_MAX_SCALES];
   int blk_start[DFE_MAX_SCALES + 1], tile_start[DFE_MAX_SCALES + 1], tiles_x[DFE_MAX_SCALES];
   int vblk_start[DFE_MAX_SCALES + 1];      // block table of the V-pixels-per-thread kernels
+  int roll_start[DFE_MAX_SCALES + 1], roll_strips[DFE_MAX_SCALES];   // rolling-SSIM unit table
+  int rollb_start[DFE_MAX_SCALES + 1], rollb_strips[DFE_MAX_SCALES];
   const float* pyr[3][DFE_MAX_SCALES];    // bilinear pyramid per frame (level 0 = the frame itself)
   const float* area[2][DFE_MAX_SCALES];   // area pyramid of the left / right frame
   const float* disp[3][DFE_MAX_SCALES];
@@ -58,6 +66,41 @@ struct GeomDev {
 
 int geom_layout(const dfe_geom_args* a, GeomLayout* L);
 void geom_dev(const dfe_geom_args* a, const GeomLayout& L, GeomDev* D);
+
+// ---- rolling-window SSIM helpers (forward and backward kernels)
+struct RowSums { float v[15]; };   // per channel: sum x, y, xx, yy, xy over the 3 horizontal neighbours
+struct RowRaw { float a[3], b[3]; };   // masked target / warped values of one row at this lane's column
+
+// issue the 7 loads of one row (returns zeros outside the image); kept separate from the DPP sums so that
+// the loads of rows y+2.. are in flight while row y is reduced (software prefetch: ~2 waves per SIMD only)
+__device__ __forceinline__ RowRaw ssim_load(const float* __restrict__ it, const float* __restrict__ yw,
+                                            const unsigned char* __restrict__ mk, unsigned need, int y, int x,
+                                            int H, int W, int N) {
+  RowRaw r;
+  const bool in = y >= 0 && y < H && x >= 0 && x < W;
+  const int q = in ? y * W + x : 0;
+  const unsigned m = mk[q];
+  float ta[3], tb[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { ta[c] = it[q + c * N]; tb[c] = yw[q + c * N]; }
+  const float vo = (in && (m & need) == need) ? 1.0f : 0.0f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { r.a[c] = in ? ta[c] * vo : 0.0f; r.b[c] = in ? tb[c] : 0.0f; }
+  return r;
+}
+
+__device__ __forceinline__ RowSums ssim_hsum(const RowRaw& w) {
+  RowSums r;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    r.v[c * 5 + 0] = wave_nbr_sum(w.a[c]);
+    r.v[c * 5 + 1] = wave_nbr_sum(w.b[c]);
+    r.v[c * 5 + 2] = wave_nbr_sum(w.a[c] * w.a[c]);
+    r.v[c * 5 + 3] = wave_nbr_sum(w.b[c] * w.b[c]);
+    r.v[c * 5 + 4] = wave_nbr_sum(w.a[c] * w.b[c]);
+  }
+  return r;
+}
 
 __device__ __forceinline__ int find_scale(const int* starts, int S, int idx) {
   int s = 0;

@@ -2,7 +2,7 @@
 //
 // Recompute-in-backward: only the 1-byte mask pack, the masked warped images and the
 // per-(sample,scale) normalisers survive from the forward.  Launches:
-//   k_geom_ssim_bwd         dL/d(warped) of the SSIM term from an LDS tile with a 2-px halo
+//   k_geom_ssim_bwd_roll    dL/d(warped) of the SSIM term: rolling 60-column strips, DPP row sums, register windows
 //   k_geom_point_bwd        per pixel, both directions: bilinear-warp and projection chain rule,
 //                           writes grad_flow / grad_disp(target), block sums for the pose
 //   k_geom_flow_smooth_bwd  adds the 2nd-order smoothness gradient into grad_flow
@@ -26,81 +26,112 @@ struct GeomBwd {
 
 __device__ __forceinline__ float sgn(float v) { return static_cast<float>(v > 0.0f) - static_cast<float>(v < 0.0f); }
 
-// ---------------------------------------------------------------------- SSIM backward
-__global__ void __launch_bounds__(GS_TX * GS_TY) k_geom_ssim_bwd(GeomDev D, GeomBwd G) {
-  __shared__ float sx[3][GS_TY + 4][GS_TX + 4], sy[3][GS_TY + 4][GS_TX + 4];
-  __shared__ float co[9][GS_TY + 2][GS_TX + 2];
-  const unsigned ntile_total = D.tile_start[D.S];
-  const unsigned tile = xcd_swizzle(blockIdx.x, ntile_total);
+// ---------------------------------------------------------------------- SSIM backward, rolling window
+// Same structure as k_geom_ssim_fwd_roll with a 2-lane / 2-row halo: raw rows -> DPP row sums -> SSIM
+// partial-derivative coefficients of the row above -> DPP row sums of the coefficients -> 3-row sum ->
+// dL/d(warped) of the row two above.  Lanes 2..61 are valid (60 columns per wave).  The centre values needed
+// at gradient time are re-loaded (prefetched) instead of kept, so every rolling window has period 3 and the
+// 3-way unrolled loop needs no register shuffling.
+struct CoefH { float v[9]; };
+
+__device__ __forceinline__ CoefH ssim_coef_hsum(const RowSums& r0, const RowSums& r1, const RowSums& r2, float gscale, bool in) {
+  CoefH o;
+  const float r9 = 1.0f / 9.0f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float c_my = 0.0f, c_eyy = 0.0f, c_exy = 0.0f;
+    const float mx = ((r0.v[c * 5] + r1.v[c * 5]) + r2.v[c * 5]) * r9, my = ((r0.v[c * 5 + 1] + r1.v[c * 5 + 1]) + r2.v[c * 5 + 1]) * r9;
+    const float exx = ((r0.v[c * 5 + 2] + r1.v[c * 5 + 2]) + r2.v[c * 5 + 2]) * r9, eyy = ((r0.v[c * 5 + 3] + r1.v[c * 5 + 3]) + r2.v[c * 5 + 3]) * r9;
+    const float exy = ((r0.v[c * 5 + 4] + r1.v[c * 5 + 4]) + r2.v[c * 5 + 4]) * r9;
+    const float v = (1.0f - ssim_from_means(mx, my, exx, eyy, exy)) / 2.0f;
+    if (in && v >= 0.0f && v <= 1.0f) {   // coefficients exist only at real pixels; clamp passes gradient on [0,1]
+      float d_mx, d_my, d_exx, d_eyy, d_exy;
+      ssim_partials(mx, my, exx, eyy, exy, d_mx, d_my, d_exx, d_eyy, d_exy);
+      c_my = d_my * gscale; c_eyy = d_eyy * gscale; c_exy = d_exy * gscale;
+    }
+    o.v[c * 3 + 0] = wave_nbr_sum(c_my); o.v[c * 3 + 1] = wave_nbr_sum(c_eyy); o.v[c * 3 + 2] = wave_nbr_sum(c_exy);
+  }
+  return o;
+}
+
+__device__ __forceinline__ void ssim_grad_store(const CoefH& a, const CoefH& bq, const CoefH& cq, const RowRaw& ctr, float vo,
+                                                float* __restrict__ gw, int q, int N) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float s0 = (a.v[c * 3] + bq.v[c * 3]) + cq.v[c * 3], s1 = (a.v[c * 3 + 1] + bq.v[c * 3 + 1]) + cq.v[c * 3 + 1];
+    const float s2 = (a.v[c * 3 + 2] + bq.v[c * 3 + 2]) + cq.v[c * 3 + 2];
+    gw[q + c * N] = ((s0 + 2.0f * ctr.b[c] * s1 + ctr.a[c] * s2) * (1.0f / 9.0f)) * vo;
+  }
+}
+
+__global__ void __launch_bounds__(64) k_geom_ssim_bwd_roll(GeomDev D, GeomBwd G) {
+  const unsigned nunit_total = D.rollb_start[D.S];
+  const unsigned unit = xcd_swizzle(blockIdx.x, nunit_total);
   const int b = blockIdx.y >> 1, d = blockIdx.y & 1;
-  const int s = find_scale(D.tile_start, D.S, tile);
+  const int s = find_scale(D.rollb_start, D.S, unit);
   const int H = D.H[s], W = D.W[s], N = D.N[s];
-  const int tl = tile - D.tile_start[s];
-  const int x0 = (tl % D.tiles_x[s]) * GS_TX, y0 = (tl / D.tiles_x[s]) * GS_TY;
+  const int u = unit - D.rollb_start[s];
+  const int strip = u % D.rollb_strips[s], rb = u / D.rollb_strips[s];
+  const int x = strip * RSB_COLS + static_cast<int>(threadIdx.x) - 2, y0 = rb * RSB_ROWS, yend = min(y0 + RSB_ROWS, H);
   const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
   const float* yw = D.yw[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
   const unsigned char* mk = D.mask[s] + static_cast<long>(b) * N;
   const unsigned need = (DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD) << d;
+  float* gw = G.gw[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
   const float gscale = -0.5f * G.gl[DFE_LOSS_FLOW_SSIM * D.B + b] *
                        G.coef[(static_cast<long>(b) * D.S + s) * CF_COUNT + d * CF_PER_DIR + CF_VO];
-  for (int i = threadIdx.x; i < (GS_TY + 4) * (GS_TX + 4); i += blockDim.x) {
-    const int ly = i / (GS_TX + 4), lx = i - ly * (GS_TX + 4);
-    const int gy = y0 + ly - 2, gx = x0 + lx - 2;
-    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-    const long q = static_cast<long>(gy) * W + gx;
-    const float vo = (in && (mk[q] & need) == need) ? 1.0f : 0.0f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      sx[c][ly][lx] = in ? it[q + static_cast<long>(c) * N] * vo : 0.0f;
-      sy[c][ly][lx] = in ? yw[q + static_cast<long>(c) * N] : 0.0f;
-    }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < (GS_TY + 2) * (GS_TX + 2); i += blockDim.x) {
-    const int ly = i / (GS_TX + 2), lx = i - ly * (GS_TX + 2);
-    const int gy = y0 + ly - 1, gx = x0 + lx - 1;
-    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float c_my = 0.0f, c_eyy = 0.0f, c_exy = 0.0f;
-      if (in) {
-        float a = 0, bq = 0, aa = 0, bb = 0, ab = 0;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            const float u = sx[c][ly + dy][lx + dx], w = sy[c][ly + dy][lx + dx];
-            a += u; bq += w; aa += u * u; bb += w * w; ab += u * w;
-          }
-        const float r9 = 1.0f / 9.0f, mx = a * r9, my = bq * r9, exx = aa * r9, eyy = bb * r9, exy = ab * r9;
-        const float v = (1.0f - ssim_from_means(mx, my, exx, eyy, exy)) / 2.0f;
-        if (v >= 0.0f && v <= 1.0f) {   // clamp(.,0,1) passes gradient on the closed interval
-          float d_mx, d_my, d_exx, d_eyy, d_exy;
-          ssim_partials(mx, my, exx, eyy, exy, d_mx, d_my, d_exx, d_eyy, d_exy);
-          c_my = d_my * gscale; c_eyy = d_eyy * gscale; c_exy = d_exy * gscale;
-        }
+  const bool col_in = x >= 0 && x < W;
+  const bool lane_ok = threadIdx.x >= 2 && threadIdx.x <= RSB_COLS + 1 && col_in;
+  // prologue: row sums of rows y0-2, y0-1, y0; coefficient sums of rows y0-1 (and y0 inside the loop)
+  RowRaw w0 = ssim_load(it, yw, mk, need, y0 - 2, x, H, W, N), w1 = ssim_load(it, yw, mk, need, y0 - 1, x, H, W, N);
+  RowRaw w2 = ssim_load(it, yw, mk, need, y0, x, H, W, N), w3 = ssim_load(it, yw, mk, need, y0 + 1, x, H, W, N);
+  RowSums ha = ssim_hsum(w0), hb = ssim_hsum(w1), hc = ssim_hsum(w2);
+  CoefH ca = ssim_coef_hsum(ha, hb, hc, gscale, col_in && y0 - 1 >= 0 && y0 - 1 < H);   // coefficients of row y0-1
+  RowSums hd = ssim_hsum(w3);
+  CoefH cb = ssim_coef_hsum(hb, hc, hd, gscale, col_in && y0 < H);                        // row y0
+  // invariant at the top of each third of the loop body for gradient row g:
+  //   h?,h?: row sums of rows g, g+1 ; c?,c?: coefficient sums of rows g-1, g
+  RowRaw nx = ssim_load(it, yw, mk, need, y0 + 2, x, H, W, N);
+  for (int g = y0; g < yend; g += 3) {
+    // ---- gradient row g: needs row sums g+2 -> coefficients g+1
+    {
+      const RowRaw pf = ssim_load(it, yw, mk, need, g + 3, x, H, W, N);
+      const RowRaw ctr = ssim_load(it, yw, mk, need, g, x, H, W, N);
+      ha = ssim_hsum(nx);                                                                   // rows: hc=g, hd=g+1, ha=g+2
+      CoefH cc = ssim_coef_hsum(hc, hd, ha, gscale, col_in && g + 1 < H);                   // row g+1
+      if (lane_ok && g < yend) {
+        const int q = g * W + x;
+        ssim_grad_store(ca, cb, cc, ctr, ((mk[q] & need) == need) ? 1.0f : 0.0f, gw, q, N);
       }
-      co[c * 3 + 0][ly][lx] = c_my; co[c * 3 + 1][ly][lx] = c_eyy; co[c * 3 + 2][ly][lx] = c_exy;
+      ca = cc; nx = pf;   // now: cb = row g, ca = row g+1
     }
-  }
-  __syncthreads();
-  const int tx = threadIdx.x % GS_TX, ty = threadIdx.x / GS_TX;
-  const int gx = x0 + tx, gy = y0 + ty;
-  if (gx >= W || gy >= H) return;
-  const long q = static_cast<long>(gy) * W + gx;
-  const float vo = ((mk[q] & need) == need) ? 1.0f : 0.0f;
-  float* gw = G.gw[s] + (static_cast<long>(d) * D.B + b) * 3 * N + q;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    float s0 = 0, s1 = 0, s2 = 0;
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        s0 += co[c * 3 + 0][ty + dy][tx + dx]; s1 += co[c * 3 + 1][ty + dy][tx + dx]; s2 += co[c * 3 + 2][ty + dy][tx + dx];
+    // ---- gradient row g+1
+    {
+      const RowRaw pf = ssim_load(it, yw, mk, need, g + 4, x, H, W, N);
+      const RowRaw ctr = ssim_load(it, yw, mk, need, g + 1, x, H, W, N);
+      hb = ssim_hsum(nx);                                                                   // rows: hd=g+1, ha=g+2, hb=g+3
+      CoefH cc = ssim_coef_hsum(hd, ha, hb, gscale, col_in && g + 2 < H);                   // row g+2
+      if (lane_ok && g + 1 < yend) {
+        const int q = (g + 1) * W + x;
+        ssim_grad_store(cb, ca, cc, ctr, ((mk[q] & need) == need) ? 1.0f : 0.0f, gw, q, N);
       }
-    const float xv = sx[c][ty + 2][tx + 2], yv = sy[c][ty + 2][tx + 2];
-    gw[static_cast<long>(c) * N] = ((s0 + 2.0f * yv * s1 + xv * s2) / 9.0f) * vo;
+      cb = cc; nx = pf;   // now: ca = row g+1, cb = row g+2
+    }
+    // ---- gradient row g+2
+    {
+      const RowRaw pf = ssim_load(it, yw, mk, need, g + 5, x, H, W, N);
+      const RowRaw ctr = ssim_load(it, yw, mk, need, g + 2, x, H, W, N);
+      hc = ssim_hsum(nx);                                                                   // rows: ha=g+2, hb=g+3, hc=g+4
+      CoefH cc = ssim_coef_hsum(ha, hb, hc, gscale, col_in && g + 3 < H);                   // row g+3
+      if (lane_ok && g + 2 < yend) {
+        const int q = (g + 2) * W + x;
+        ssim_grad_store(ca, cb, cc, ctr, ((mk[q] & need) == need) ? 1.0f : 0.0f, gw, q, N);
+      }
+      // rotate for the next iteration (gradient row g+3): row sums hc=g+3?? -> rename below
+      ca = cb; cb = cc; nx = pf;    // ca = row g+2, cb = row g+3
+      const RowSums t0 = hb, t1 = hc;   // rows g+3, g+4
+      hc = t0; hd = t1;                 // loop invariant: hc = row g', hd = row g'+1 with g' = g+3
+    }
   }
 }
 
@@ -498,6 +529,7 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     for (int d = 0; d < 2; ++d) G.gflow[d][s] = (s < L.S) ? a->grad_flow[d][s] : nullptr;
   }
   const unsigned nblk_total = L.blk_start[L.S], ntile_total = L.tile_start[L.S];
+  (void)ntile_total;
   int seg = 0;
 #define DFE_MARK() do { if (ev) (void)hipEventRecord(ev[++seg], st); } while (0)
   if (ev) (void)hipEventRecord(ev[0], st);
@@ -507,7 +539,7 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     DFE_LAUNCH_CHECK();
     DFE_MARK(); DFE_MARK();
   } else {
-    k_geom_ssim_bwd<<<dim3(ntile_total, L.B * 2), GS_TX * GS_TY, 0, st>>>(D, G);
+    k_geom_ssim_bwd_roll<<<dim3(L.rollb_start[L.S], L.B * 2), 64, 0, st>>>(D, G);
     DFE_LAUNCH_CHECK();
     DFE_MARK();
     k_geom_point_bwd<<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, G);

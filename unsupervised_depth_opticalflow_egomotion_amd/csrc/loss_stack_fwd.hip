@@ -6,7 +6,8 @@
 //                          rigid projection, recon, texture/dynamic masks, masked-L1 sums,
 //                          |rigid-flow| and epipolar sums, flow consistency; writes the 1-byte
 //                          mask pack and the masked warped images (stage W of SURVEY.md 8(d))
-//   k_geom_ssim_fwd        3x3 SSIM of (I*m, warped*m) from an LDS tile with halo (stage P)
+//   k_geom_ssim_fwd_roll   3x3 SSIM of (I*m, warped*m): a wave owns a 62-column strip, DPP wave shifts for the
+//                          horizontal sums, a 3-row register window for the vertical ones (stage P)
 //   k_geom_smooth_fwd      disparity (1st order, full-res) and flow (2nd order) smoothness
 //   k_geom_finalize_fwd    fixed-order reduction of block partials -> loss vectors + normalisers
 // All (sample, scale) images are batched into each launch: scale 2 alone (13 k px) cannot fill
@@ -41,6 +42,16 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
   // Measured at B=4, 256x832 (MI355X): V=1 48 us, V=2 62 us, V=4 83 us; 128-thread blocks 51 us.  Fatter threads
   // lose more occupancy / wave count than their wider streams save; the V>1 instantiations stay for large batches.
   L->V = 1;
+  L->roll_start[0] = 0;
+  for (int s = 0; s < L->S; ++s) {
+    L->roll_strips[s] = (L->W[s] + RS_COLS - 1) / RS_COLS;
+    L->roll_start[s + 1] = L->roll_start[s] + L->roll_strips[s] * ((L->H[s] + RS_ROWS - 1) / RS_ROWS);
+  }
+  L->rollb_start[0] = 0;
+  for (int s = 0; s < L->S; ++s) {
+    L->rollb_strips[s] = (L->W[s] + RSB_COLS - 1) / RSB_COLS;
+    L->rollb_start[s + 1] = L->rollb_start[s] + L->rollb_strips[s] * ((L->H[s] + RSB_ROWS - 1) / RSB_ROWS);
+  }
   L->vblk_start[0] = 0;
   for (int s = 0; s < L->S; ++s) L->vblk_start[s + 1] = L->vblk_start[s] + (L->N[s] + GS_BLOCK * L->V - 1) / (GS_BLOCK * L->V);
   const long B = L->B, S = L->S, sumN = L->off_px[S];
@@ -54,7 +65,7 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
   L->o_mask = o; o = align4(o + (B * sumN + 3) / 4);
   L->o_yw = o; o = align4(o + 2 * B * 3 * sumN);
   L->o_part = o; o = align4(o + B * nblk_total * PT_COUNT);
-  L->o_spart = o; o = align4(o + B * 2 * ntile_total);
+  L->o_spart = o; o = align4(o + B * 2 * (ntile_total > L->roll_start[S] ? ntile_total : static_cast<long>(L->roll_start[S])));
   L->o_fpart = o; o = align4(o + 2 * B * nblk_total * 2);
   L->o_dpart = o; o = align4(o + 3 * B * L->nblk0 * 2);
   L->o_sums = o; o = align4(o + B * S * SUM_COUNT);
@@ -70,9 +81,9 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
 void geom_dev(const dfe_geom_args* a, const GeomLayout& L, GeomDev* D) {
   float* ws = a->workspace;
   D->B = L.B; D->S = L.S; D->ac = a->align_corners; D->mode = a->mode; D->alpha = a->alpha; D->beta = a->beta;
-  for (int s = 0; s <= L.S; ++s) { D->blk_start[s] = L.blk_start[s]; D->tile_start[s] = L.tile_start[s]; D->vblk_start[s] = L.vblk_start[s]; }
+  for (int s = 0; s <= L.S; ++s) { D->blk_start[s] = L.blk_start[s]; D->tile_start[s] = L.tile_start[s]; D->vblk_start[s] = L.vblk_start[s]; D->roll_start[s] = L.roll_start[s]; D->rollb_start[s] = L.rollb_start[s]; }
   for (int s = 0; s < L.S; ++s) {
-    D->H[s] = L.H[s]; D->W[s] = L.W[s]; D->N[s] = L.N[s]; D->tiles_x[s] = L.tiles_x[s];
+    D->H[s] = L.H[s]; D->W[s] = L.W[s]; D->N[s] = L.N[s]; D->tiles_x[s] = L.tiles_x[s]; D->roll_strips[s] = L.roll_strips[s]; D->rollb_strips[s] = L.rollb_strips[s];
     const long lvl = static_cast<long>(L.B) * 3 * (L.off_px[s] - L.N[0]);   // offset of level s (>=1) in a frame's block
     for (int f = 0; f < 3; ++f) {
       D->pyr[f][s] = (s == 0) ? a->img[f] : ws + L.o_pyr + f * L.pyr_plane + lvl;
@@ -349,54 +360,59 @@ __global__ void __launch_bounds__(GS_BLOCK) k_depth_point_fwd(GeomDev D, float* 
   block_sum<PT_COUNT>(acc, red, part + (static_cast<long>(b) * nblk_total + blk) * PT_COUNT);
 }
 
-// ---------------------------------------------------------------------- SSIM forward (stage P)
-// grid: x = tile over all scales, y = b*2 + d.  x = I * vo (mask bits), y = yw (already masked).
-__global__ void __launch_bounds__(GS_TX * GS_TY) k_geom_ssim_fwd(GeomDev D, float* __restrict__ spart) {
-  __shared__ float sx[3][GS_TY + 2][GS_TX + 2], sy[3][GS_TY + 2][GS_TX + 2];
-  __shared__ float red[4 * GS_TX * GS_TY / 64];
-  const unsigned ntile_total = D.tile_start[D.S];
-  const unsigned tile = xcd_swizzle(blockIdx.x, ntile_total);
+// ---------------------------------------------------------------------- SSIM forward (stage P), rolling window
+// One wave owns a strip of 62 columns (lanes 1..62; lanes 0 and 63 are the halo) and marches down RS_ROWS
+// rows (+1 halo row on each side).  Horizontal 3-sums come from DPP wave shifts, the vertical 3-row window
+// lives in registers: no LDS, no barriers, and the loads of the next row are independent of the arithmetic of
+// the current one.  grid: x = units (strip x row block) over all scales, y = b*2 + d; block = one wave.
+__device__ __forceinline__ float ssim_out(const RowSums& r0, const RowSums& r1, const RowSums& r2) {
+  float v = 0.0f;
+  const float r9 = 1.0f / 9.0f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float mx = ((r0.v[c * 5] + r1.v[c * 5]) + r2.v[c * 5]) * r9, my = ((r0.v[c * 5 + 1] + r1.v[c * 5 + 1]) + r2.v[c * 5 + 1]) * r9;
+    const float exx = ((r0.v[c * 5 + 2] + r1.v[c * 5 + 2]) + r2.v[c * 5 + 2]) * r9, eyy = ((r0.v[c * 5 + 3] + r1.v[c * 5 + 3]) + r2.v[c * 5 + 3]) * r9;
+    const float exy = ((r0.v[c * 5 + 4] + r1.v[c * 5 + 4]) + r2.v[c * 5 + 4]) * r9;
+    v += fminf(fmaxf((1.0f - ssim_from_means(mx, my, exx, eyy, exy)) / 2.0f, 0.0f), 1.0f);
+  }
+  return v;
+}
+
+__global__ void __launch_bounds__(64) k_geom_ssim_fwd_roll(GeomDev D, float* __restrict__ spart) {
+  __shared__ float red[4];
+  const unsigned nunit_total = D.roll_start[D.S];
+  const unsigned unit = xcd_swizzle(blockIdx.x, nunit_total);
   const int b = blockIdx.y >> 1, d = blockIdx.y & 1;
-  const int s = find_scale(D.tile_start, D.S, tile);
+  const int s = find_scale(D.roll_start, D.S, unit);
   const int H = D.H[s], W = D.W[s], N = D.N[s];
-  const int tl = tile - D.tile_start[s];
-  const int x0 = (tl % D.tiles_x[s]) * GS_TX, y0 = (tl / D.tiles_x[s]) * GS_TY;
+  const int u = unit - D.roll_start[s];
+  const int strip = u % D.roll_strips[s], rb = u / D.roll_strips[s];
+  const int x = strip * RS_COLS + static_cast<int>(threadIdx.x) - 1, y0 = rb * RS_ROWS;
   const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
   const float* yw = D.yw[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
   const unsigned char* mk = D.mask[s] + static_cast<long>(b) * N;
   const unsigned need = (DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD) << d;
-  for (int i = threadIdx.x; i < (GS_TY + 2) * (GS_TX + 2); i += blockDim.x) {
-    const int ly = i / (GS_TX + 2), lx = i - ly * (GS_TX + 2);
-    const int gy = y0 + ly - 1, gx = x0 + lx - 1;
-    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-    const long q = static_cast<long>(gy) * W + gx;
-    const float vo = (in && (mk[q] & need) == need) ? 1.0f : 0.0f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      sx[c][ly][lx] = in ? it[q + static_cast<long>(c) * N] * vo : 0.0f;
-      sy[c][ly][lx] = in ? yw[q + static_cast<long>(c) * N] : 0.0f;
-    }
+  const bool lane_ok = threadIdx.x >= 1 && threadIdx.x <= RS_COLS && x < W;
+  float acc = 0.0f;
+  RowRaw w0 = ssim_load(it, yw, mk, need, y0 - 1, x, H, W, N);
+  RowRaw w1 = ssim_load(it, yw, mk, need, y0, x, H, W, N);
+  RowRaw w2 = ssim_load(it, yw, mk, need, y0 + 1, x, H, W, N);
+  RowSums ra = ssim_hsum(w0), rb0 = ssim_hsum(w1);
+  // rows are consumed three at a time so that the rolling window is addressed statically (registers);
+  // w2 always holds the raw values of row y+1, and two further rows are loading
+  for (int y = y0; y < y0 + RS_ROWS; y += 3) {
+    const RowRaw n2 = ssim_load(it, yw, mk, need, y + 2, x, H, W, N);
+    const RowSums rc = ssim_hsum(w2);
+    if (lane_ok && y < H && y < y0 + RS_ROWS) acc += ssim_out(ra, rb0, rc);
+    const RowRaw n3 = ssim_load(it, yw, mk, need, y + 3, x, H, W, N);
+    ra = ssim_hsum(n2);
+    if (lane_ok && y + 1 < H && y + 1 < y0 + RS_ROWS) acc += ssim_out(rb0, rc, ra);
+    w2 = ssim_load(it, yw, mk, need, y + 4, x, H, W, N);
+    rb0 = ssim_hsum(n3);
+    if (lane_ok && y + 2 < H && y + 2 < y0 + RS_ROWS) acc += ssim_out(rc, ra, rb0);
   }
-  __syncthreads();
-  const int tx = threadIdx.x % GS_TX, ty = threadIdx.x / GS_TX;
-  float v = 0.0f;
-  if (x0 + tx < W && y0 + ty < H) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float a = 0, bq = 0, aa = 0, bb = 0, ab = 0;
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const float u = sx[c][ty + dy][tx + dx], w = sy[c][ty + dy][tx + dx];
-          a += u; bq += w; aa += u * u; bb += w * w; ab += u * w;
-        }
-      const float ss = ssim_from_means(a * (1.0f / 9.0f), bq * (1.0f / 9.0f), aa * (1.0f / 9.0f), bb * (1.0f / 9.0f), ab * (1.0f / 9.0f));
-      v += fminf(fmaxf((1.0f - ss) / 2.0f, 0.0f), 1.0f);
-    }
-  }
-  float vv[1] = {v};
-  block_sum<1>(vv, red, spart + static_cast<long>(blockIdx.y) * ntile_total + tile);
+  float vv[1] = {acc};
+  block_sum<1>(vv, red, spart + static_cast<long>(blockIdx.y) * nunit_total + unit);
 }
 
 // ---------------------------------------------------------------------- smoothness forward
@@ -485,7 +501,7 @@ __global__ void __launch_bounds__(256) k_geom_finalize_fwd(GeomDev D, const floa
   __shared__ double sm[DFE_MAX_SCALES][SUM_COUNT];
   __shared__ double ds[3][2];
   const int b = blockIdx.x, S = D.S, B = D.B, t = threadIdx.x;
-  const unsigned nblk_total = D.blk_start[S], ntile_total = D.tile_start[S];
+  const unsigned nblk_total = D.blk_start[S];
   for (int s = 0; s < S; ++s) {
     double a[SUM_COUNT];
 #pragma unroll
@@ -502,9 +518,9 @@ __global__ void __launch_bounds__(256) k_geom_finalize_fwd(GeomDev D, const floa
         a[SUM_FS + 2 * d] += q[0]; a[SUM_FS + 2 * d + 1] += q[1];
       }
     }
-    if (D.mode == 0) for (int k = D.tile_start[s] + t; k < D.tile_start[s + 1]; k += 256) {
-      a[SUM_SSIM] += spart[static_cast<long>(b * 2) * ntile_total + k];
-      a[SUM_SSIM + 1] += spart[static_cast<long>(b * 2 + 1) * ntile_total + k];
+    if (D.mode == 0) for (int k = D.roll_start[s] + t; k < D.roll_start[s + 1]; k += 256) {
+      a[SUM_SSIM] += spart[static_cast<long>(b * 2) * D.roll_start[S] + k];
+      a[SUM_SSIM + 1] += spart[static_cast<long>(b * 2 + 1) * D.roll_start[S] + k];
     }
 #pragma unroll
     for (int i = 0; i < SUM_COUNT; ++i) lds[t][i] = a[i];
@@ -653,7 +669,7 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     DFE_LAUNCH_CHECK();
   }
   DFE_MARK();
-  const unsigned nblk_total = L.blk_start[L.S], ntile_total = L.tile_start[L.S];
+  const unsigned nblk_total = L.blk_start[L.S];
   if (a->mode == 1) {
     // Model_depth: rigid recon + validity*texture mask + masked L1 only (no flows, no SSIM, no flow terms)
     k_depth_point_fwd<<<dim3(L.vblk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
@@ -672,7 +688,7 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     else k_geom_point_fwd<1><<<dim3(L.vblk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
     DFE_LAUNCH_CHECK();
     DFE_MARK();
-    k_geom_ssim_fwd<<<dim3(ntile_total, L.B * 2), GS_TX * GS_TY, 0, st>>>(D, ws + L.o_spart);
+    k_geom_ssim_fwd_roll<<<dim3(L.roll_start[L.S], L.B * 2), 64, 0, st>>>(D, ws + L.o_spart);
     DFE_LAUNCH_CHECK();
     DFE_MARK();
     k_geom_flow_smooth_fwd<<<dim3(nblk_total, 2 * L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_fpart);
