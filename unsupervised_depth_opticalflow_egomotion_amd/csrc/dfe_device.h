@@ -365,6 +365,15 @@ __device__ __forceinline__ float wave_nbr_sum(float v) {
   return (v + __int_as_float(a)) + __int_as_float(b);
 }
 
+// lane l receives lane l+1 of the same wave (0 at the wave edge)
+__device__ __forceinline__ float wave_shl1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, true));
+}
+// lane l receives lane l-1
+__device__ __forceinline__ float wave_shr1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, true));
+}
+
 template <int N>
 __device__ __forceinline__ void block_sum(float (&vals)[N], float* smem, float* out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;

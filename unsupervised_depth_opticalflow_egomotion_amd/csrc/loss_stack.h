@@ -9,6 +9,8 @@ constexpr int GS_BLOCK = 256;   // threads per block of the pointwise kernels (1
 constexpr int GS_TX = 32, GS_TY = 8;  // SSIM tile (backward)
 constexpr int RS_COLS = 62, RS_ROWS = 8;   // rolling SSIM forward: valid columns per wave (64 lanes - 2 halo), rows per wave
                                             // (measured: rows 4/6/8/16/32 -> 24.2/22.8/21.9/24.0/30.3 us; LDS tile kernel 33 us)
+constexpr int FS_ROWS = 8;                  // rolling flow-smoothness kernels: rows per wave (62 valid columns);
+                                            // measured 2/4/8 rows -> 24.9/20.6/16.3 us (per-pixel kernel: 24.3 us)
 constexpr int RSB_COLS = 60, RSB_ROWS = 8;  // rolling SSIM backward: 2-lane halo on each side
                                             // (measured: rows 5/8/16 -> 49.2/44.4/48.0 us; LDS tile kernel 56.9 us)
 
@@ -37,6 +39,7 @@ struct GeomLayout {
   int nblk0;                          // full-resolution blocks (disp smoothness)
   int roll_start[DFE_MAX_SCALES + 1], roll_strips[DFE_MAX_SCALES];   // rolling-SSIM units (strip x row block) per scale
   int rollb_start[DFE_MAX_SCALES + 1], rollb_strips[DFE_MAX_SCALES]; // same for the backward kernel
+  int fs_start[DFE_MAX_SCALES + 1];                                  // flow-smoothness units (roll_strips x FS_ROWS blocks)
   int V;                              // pixels per thread of k_geom_point_fwd (4 when every W_s % 4 == 0, else 1)
   int vblk_start[DFE_MAX_SCALES + 1]; // its block table
   // workspace offsets in floats
@@ -54,6 +57,7 @@ struct GeomDev {
   int vblk_start[DFE_MAX_SCALES + 1];      // block table of the V-pixels-per-thread kernels
   int roll_start[DFE_MAX_SCALES + 1], roll_strips[DFE_MAX_SCALES];   // rolling-SSIM unit table
   int rollb_start[DFE_MAX_SCALES + 1], rollb_strips[DFE_MAX_SCALES];
+  int fs_start[DFE_MAX_SCALES + 1];
   const float* pyr[3][DFE_MAX_SCALES];    // bilinear pyramid per frame (level 0 = the frame itself)
   const float* area[2][DFE_MAX_SCALES];   // area pyramid of the left / right frame
   const float* disp[3][DFE_MAX_SCALES];

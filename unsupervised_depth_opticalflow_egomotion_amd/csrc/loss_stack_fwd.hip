@@ -47,6 +47,8 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
     L->roll_strips[s] = (L->W[s] + RS_COLS - 1) / RS_COLS;
     L->roll_start[s + 1] = L->roll_start[s] + L->roll_strips[s] * ((L->H[s] + RS_ROWS - 1) / RS_ROWS);
   }
+  L->fs_start[0] = 0;
+  for (int s = 0; s < L->S; ++s) L->fs_start[s + 1] = L->fs_start[s] + ((L->W[s] + RS_COLS - 1) / RS_COLS) * ((L->H[s] + FS_ROWS - 1) / FS_ROWS);
   L->rollb_start[0] = 0;
   for (int s = 0; s < L->S; ++s) {
     L->rollb_strips[s] = (L->W[s] + RSB_COLS - 1) / RSB_COLS;
@@ -66,7 +68,7 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
   L->o_yw = o; o = align4(o + 2 * B * 3 * sumN);
   L->o_part = o; o = align4(o + B * nblk_total * PT_COUNT);
   L->o_spart = o; o = align4(o + B * 2 * (ntile_total > L->roll_start[S] ? ntile_total : static_cast<long>(L->roll_start[S])));
-  L->o_fpart = o; o = align4(o + 2 * B * nblk_total * 2);
+  L->o_fpart = o; o = align4(o + 2 * B * (nblk_total > L->fs_start[S] ? nblk_total : static_cast<long>(L->fs_start[S])) * 2);
   L->o_dpart = o; o = align4(o + 3 * B * L->nblk0 * 2);
   L->o_sums = o; o = align4(o + B * S * SUM_COUNT);
   L->o_coef = o; o = align4(o + B * S * CF_COUNT);
@@ -81,7 +83,7 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
 void geom_dev(const dfe_geom_args* a, const GeomLayout& L, GeomDev* D) {
   float* ws = a->workspace;
   D->B = L.B; D->S = L.S; D->ac = a->align_corners; D->mode = a->mode; D->alpha = a->alpha; D->beta = a->beta;
-  for (int s = 0; s <= L.S; ++s) { D->blk_start[s] = L.blk_start[s]; D->tile_start[s] = L.tile_start[s]; D->vblk_start[s] = L.vblk_start[s]; D->roll_start[s] = L.roll_start[s]; D->rollb_start[s] = L.rollb_start[s]; }
+  for (int s = 0; s <= L.S; ++s) { D->blk_start[s] = L.blk_start[s]; D->tile_start[s] = L.tile_start[s]; D->vblk_start[s] = L.vblk_start[s]; D->roll_start[s] = L.roll_start[s]; D->rollb_start[s] = L.rollb_start[s]; D->fs_start[s] = L.fs_start[s]; }
   for (int s = 0; s < L.S; ++s) {
     D->H[s] = L.H[s]; D->W[s] = L.W[s]; D->N[s] = L.N[s]; D->tiles_x[s] = L.tiles_x[s]; D->roll_strips[s] = L.roll_strips[s]; D->rollb_strips[s] = L.rollb_strips[s];
     const long lvl = static_cast<long>(L.B) * 3 * (L.off_px[s] - L.N[0]);   // offset of level s (>=1) in a frame's block
@@ -416,40 +418,75 @@ __global__ void __launch_bounds__(64) k_geom_ssim_fwd_roll(GeomDev D, float* __r
 }
 
 // ---------------------------------------------------------------------- smoothness forward
-// Second-order flow smoothness on flow/20 (model_geometry.py:254-279).  grid.y = d*B + b.
-__global__ void __launch_bounds__(GS_BLOCK) k_geom_flow_smooth_fwd(GeomDev D, float* __restrict__ fpart) {
-  __shared__ float red[2 * 4 * (GS_BLOCK / 64)];
-  const unsigned nblk_total = D.blk_start[D.S];
-  const unsigned blk = blockIdx.x;
-  const int d = blockIdx.y / D.B, b = blockIdx.y - d * D.B;
-  const int s = find_scale(D.blk_start, D.S, blk);
-  const int H = D.H[s], W = D.W[s], N = D.N[s];
-  const int p = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
-  float acc[2] = {0.0f, 0.0f};
+// Second-order flow smoothness on flow/20 (model_geometry.py:254-279), both directions in one pass.
+// Rolling-window wave kernel like the SSIM ones: a wave owns 62 columns (lanes 0..61 produce output, the
+// x+1 / x+2 neighbours come from DPP wave shifts) and marches down RS_ROWS rows with a 3-row register window
+// for the vertical stencil; the target image rows are loaded once for both flow directions and the next
+// row is prefetched.  grid: x = units (strip x row block) over all scales, y = b; block = one wave.
+struct FRow { float i[3]; float f[4]; };   // image row values and flow/20 (bwd u, v, fwd u, v) at this lane's column
+
+__device__ __forceinline__ FRow fs_load(const float* __restrict__ it, const float* __restrict__ fb, const float* __restrict__ ff,
+                                        int y, int x, int H, int W, int N) {
+  FRow r;
+  const bool in = y < H && x < W;
+  const int q = in ? y * W + x : 0;
   const Divisor D20{20.0f, 1.0f / 20.0f};
-  if (p < N) {
-    const int py = p / W, px = p - py * W;
-    const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
-    const float* fl = D.flow[d][s] + static_cast<long>(b) * 2 * N;
-    if (px + 2 < W) {
-      const float w = expf(-10.0f * mean3_abs_diff(it[p + 2], it[p + 2 + N], it[p + 2 + 2 * N], it[p + 1], it[p + 1 + N], it[p + 1 + 2 * N]));
+  const float t0 = it[q], t1 = it[q + N], t2 = it[q + 2 * N];
+  const float u0 = fb[q], v0 = fb[q + N], u1 = ff[q], v1 = ff[q + N];
+  r.i[0] = t0; r.i[1] = t1; r.i[2] = t2;
+  r.f[0] = div_exact(u0, D20); r.f[1] = div_exact(v0, D20); r.f[2] = div_exact(u1, D20); r.f[3] = div_exact(v1, D20);
+  return r;
+}
+
+// x-term of row r at this lane (needs lanes l+1, l+2) and y-term of rows (r0, r1, r2); acc = {bwd x, bwd y, fwd x, fwd y}
+__device__ __forceinline__ void fs_terms(const FRow& r0, const FRow& r1, const FRow& r2, bool x_ok, bool y_ok, float (&acc)[4]) {
+  float i1[3], i2[3];
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const float a0 = div_exact(fl[c * N + p], D20), a1 = div_exact(fl[c * N + p + 1], D20), a2 = div_exact(fl[c * N + p + 2], D20);
-        acc[0] += w * fabsf((a2 - a1) - (a1 - a0));
-      }
-    }
-    if (py + 2 < H) {
-      const int q1 = p + W, q2 = p + 2 * W;
-      const float w = expf(-10.0f * mean3_abs_diff(it[q2], it[q2 + N], it[q2 + 2 * N], it[q1], it[q1 + N], it[q1 + 2 * N]));
+  for (int c = 0; c < 3; ++c) { i1[c] = wave_shl1(r0.i[c]); i2[c] = wave_shl1(i1[c]); }
+  const float wx = expf(-10.0f * mean3_abs_diff(i2[0], i2[1], i2[2], i1[0], i1[1], i1[2]));
+  const float wy = expf(-10.0f * mean3_abs_diff(r2.i[0], r2.i[1], r2.i[2], r1.i[0], r1.i[1], r1.i[2]));
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const float a0 = div_exact(fl[c * N + p], D20), a1 = div_exact(fl[c * N + q1], D20), a2 = div_exact(fl[c * N + q2], D20);
-        acc[1] += w * fabsf((a2 - a1) - (a1 - a0));
-      }
-    }
+  for (int k = 0; k < 4; ++k) {
+    const float a1 = wave_shl1(r0.f[k]), a2 = wave_shl1(a1);
+    const float tx = wx * fabsf((a2 - a1) - (a1 - r0.f[k]));
+    const float ty = wy * fabsf((r2.f[k] - r1.f[k]) - (r1.f[k] - r0.f[k]));
+    if (x_ok) acc[(k >> 1) * 2] += tx;
+    if (y_ok) acc[(k >> 1) * 2 + 1] += ty;
   }
-  block_sum<2>(acc, red, fpart + (static_cast<long>(blockIdx.y) * nblk_total + blk) * 2);
+}
+
+__global__ void __launch_bounds__(64) k_geom_flow_smooth_fwd(GeomDev D, float* __restrict__ fpart) {
+  __shared__ float red[4 * 4];
+  const unsigned nunit_total = D.fs_start[D.S];
+  const unsigned unit = blockIdx.x;
+  const int b = blockIdx.y;
+  const int s = find_scale(D.fs_start, D.S, unit);
+  const int H = D.H[s], W = D.W[s], N = D.N[s];
+  const int u = unit - D.fs_start[s];
+  const int strip = u % D.roll_strips[s], rb = u / D.roll_strips[s];
+  const int x = strip * RS_COLS + static_cast<int>(threadIdx.x), y0 = rb * FS_ROWS, yend = min(y0 + FS_ROWS, H);
+  const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
+  const float* fb = D.flow[0][s] + static_cast<long>(b) * 2 * N;
+  const float* ff = D.flow[1][s] + static_cast<long>(b) * 2 * N;
+  const bool lane_ok = threadIdx.x < RS_COLS && x < W;
+  const bool x_ok = lane_ok && x + 2 < W;
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  FRow ra = fs_load(it, fb, ff, y0, x, H, W, N), rb1 = fs_load(it, fb, ff, y0 + 1, x, H, W, N);
+  FRow rc = fs_load(it, fb, ff, y0 + 2, x, H, W, N), nx = fs_load(it, fb, ff, y0 + 3, x, H, W, N);
+  for (int y = y0; y < yend; y += 3) {
+    fs_terms(ra, rb1, rc, x_ok && y < yend, lane_ok && y < yend && y + 2 < H, acc);
+    ra = nx; nx = fs_load(it, fb, ff, y + 4, x, H, W, N);
+    fs_terms(rb1, rc, ra, x_ok && y + 1 < yend, lane_ok && y + 1 < yend && y + 3 < H, acc);
+    rb1 = nx; nx = fs_load(it, fb, ff, y + 5, x, H, W, N);
+    fs_terms(rc, ra, rb1, x_ok && y + 2 < yend, lane_ok && y + 2 < yend && y + 4 < H, acc);
+    rc = nx; nx = fs_load(it, fb, ff, y + 6, x, H, W, N);
+  }
+  // partial layout: [(d*B + b)][unit][2]
+  float* o0 = fpart + (static_cast<long>(0 * D.B + b) * nunit_total + unit) * 2;
+  float* o1 = fpart + (static_cast<long>(1 * D.B + b) * nunit_total + unit) * 2;
+  __shared__ float outv[4];
+  block_sum<4>(acc, red, outv);
+  if (threadIdx.x == 0) { o0[0] = outv[0]; o0[1] = outv[1]; o1[0] = outv[2]; o1[1] = outv[3]; }
 }
 
 // First-order edge-aware disparity smoothness at full resolution, all scales fused
@@ -511,10 +548,10 @@ __global__ void __launch_bounds__(256) k_geom_finalize_fwd(GeomDev D, const floa
 #pragma unroll
       for (int i = 0; i < PT_COUNT; ++i) a[i] += r[i];
     }
-    if (D.mode == 0) for (int k = D.blk_start[s] + t; k < D.blk_start[s + 1]; k += 256) {
+    if (D.mode == 0) for (int k = D.fs_start[s] + t; k < D.fs_start[s + 1]; k += 256) {
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
-        const float* q = fpart + (static_cast<long>(d * B + b) * nblk_total + k) * 2;
+        const float* q = fpart + (static_cast<long>(d * B + b) * D.fs_start[S] + k) * 2;
         a[SUM_FS + 2 * d] += q[0]; a[SUM_FS + 2 * d + 1] += q[1];
       }
     }
@@ -691,7 +728,7 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     k_geom_ssim_fwd_roll<<<dim3(L.roll_start[L.S], L.B * 2), 64, 0, st>>>(D, ws + L.o_spart);
     DFE_LAUNCH_CHECK();
     DFE_MARK();
-    k_geom_flow_smooth_fwd<<<dim3(nblk_total, 2 * L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_fpart);
+    k_geom_flow_smooth_fwd<<<dim3(L.fs_start[L.S], L.B), 64, 0, st>>>(D, ws + L.o_fpart);
     DFE_LAUNCH_CHECK();
     DFE_MARK();
   }
