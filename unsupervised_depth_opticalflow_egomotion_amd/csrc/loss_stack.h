@@ -106,6 +106,22 @@ __device__ __forceinline__ RowSums ssim_hsum(const RowRaw& w) {
   return r;
 }
 
+// ---- rolling flow-smoothness helpers
+struct FRow { float i[3]; float f[4]; };   // image row values and flow/20 (bwd u, v, fwd u, v) at this lane's column
+
+__device__ __forceinline__ FRow fs_load(const float* __restrict__ it, const float* __restrict__ fb, const float* __restrict__ ff,
+                                        int y, int x, int H, int W, int N) {
+  FRow r;
+  const bool in = y >= 0 && y < H && x >= 0 && x < W;
+  const int q = in ? y * W + x : 0;
+  const Divisor D20{20.0f, 1.0f / 20.0f};
+  const float t0 = it[q], t1 = it[q + N], t2 = it[q + 2 * N];
+  const float u0 = fb[q], v0 = fb[q + N], u1 = ff[q], v1 = ff[q + N];
+  r.i[0] = t0; r.i[1] = t1; r.i[2] = t2;
+  r.f[0] = div_exact(u0, D20); r.f[1] = div_exact(v0, D20); r.f[2] = div_exact(u1, D20); r.f[3] = div_exact(v1, D20);
+  return r;
+}
+
 __device__ __forceinline__ int find_scale(const int* starts, int S, int idx) {
   int s = 0;
 #pragma unroll

@@ -324,48 +324,94 @@ __global__ void __launch_bounds__(GS_BLOCK) k_depth_point_bwd(GeomDev D, GeomBwd
 }
 
 // ---------------------------------------------------------------------- flow smoothness backward
-// grid.y = d*B + b ; adds into grad_flow (after k_geom_point_bwd wrote it).
-__global__ void __launch_bounds__(GS_BLOCK) k_geom_flow_smooth_bwd(GeomDev D, GeomBwd G) {
-  const unsigned blk = blockIdx.x;
-  const int d = blockIdx.y / D.B, b = blockIdx.y - d * D.B;
-  const int s = find_scale(D.blk_start, D.S, blk);
-  const int H = D.H[s], W = D.W[s], N = D.N[s];
-  const int p = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
-  if (p >= N || !G.gflow[d][s]) return;
-  const int py = p / W, px = p - py * W;
-  const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
-  const float* fl = D.flow[d][s] + static_cast<long>(b) * 2 * N;
-  const float g = G.gl[DFE_LOSS_FLOW_SMOOTH * D.B + b];
-  const float cx = g / (2.0f * H * (W - 2.0f)) / 2.0f / 20.0f, cy = g / (2.0f * (H - 2.0f) * W) / 2.0f / 20.0f;
-  float out[2] = {0.0f, 0.0f};
-  const Divisor D20{20.0f, 1.0f / 20.0f};
-  const float kc[3] = {1.0f, -2.0f, 1.0f};   // coefficient of f(q) in the stencil starting at q, q-1, q-2
+// Rolling wave kernel (see k_geom_flow_smooth_fwd): per row and lane the signed, weighted second
+// differences S (x stencil starting at this lane) and T (y stencil starting at this row) are formed once;
+// the gradient of pixel (g, x) is cx (S(x) - 2 S(x-1) + S(x-2)) + cy (T(g) - 2 T(g-1) + T(g-2)), with the x
+// neighbours from DPP wave shifts and the y neighbours from a register window.  Lanes 2..61 are valid (60
+// columns per wave).  Adds into grad_flow (after k_geom_point_bwd wrote it), both directions per pass.
+struct FT { float v[4]; };
+
+__device__ __forceinline__ FT fs_S(const FRow& r, bool ok) {
+  FT o;
+  float i1[3], i2[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int i = px - k;            // stencil start along x
-    if (i >= 0 && i + 2 < W) {
-      const int q = p - k;
-      const float w = expf(-10.0f * mean3_abs_diff(it[q + 2], it[q + 2 + N], it[q + 2 + 2 * N], it[q + 1], it[q + 1 + N], it[q + 1 + 2 * N]));
+  for (int c = 0; c < 3; ++c) { i1[c] = wave_shl1(r.i[c]); i2[c] = wave_shl1(i1[c]); }
+  const float w = expf(-10.0f * mean3_abs_diff(i2[0], i2[1], i2[2], i1[0], i1[1], i1[2]));
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const float a0 = div_exact(fl[c * N + q], D20), a1 = div_exact(fl[c * N + q + 1], D20), a2 = div_exact(fl[c * N + q + 2], D20);
-        out[c] += cx * kc[k] * w * sgn((a2 - a1) - (a1 - a0));
-      }
-    }
-    const int j = py - k;            // stencil start along y
-    if (j >= 0 && j + 2 < H) {
-      const int q = p - k * W, q1 = q + W, q2 = q + 2 * W;
-      const float w = expf(-10.0f * mean3_abs_diff(it[q2], it[q2 + N], it[q2 + 2 * N], it[q1], it[q1 + N], it[q1 + 2 * N]));
+  for (int k = 0; k < 4; ++k) {
+    const float a1 = wave_shl1(r.f[k]), a2 = wave_shl1(a1);
+    o.v[k] = ok ? w * sgn((a2 - a1) - (a1 - r.f[k])) : 0.0f;
+  }
+  return o;
+}
+
+__device__ __forceinline__ FT fs_T(const FRow& r0, const FRow& r1, const FRow& r2, bool ok) {
+  FT o;
+  const float w = expf(-10.0f * mean3_abs_diff(r2.i[0], r2.i[1], r2.i[2], r1.i[0], r1.i[1], r1.i[2]));
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const float a0 = div_exact(fl[c * N + q], D20), a1 = div_exact(fl[c * N + q1], D20), a2 = div_exact(fl[c * N + q2], D20);
-        out[c] += cy * kc[k] * w * sgn((a2 - a1) - (a1 - a0));
-      }
+  for (int k = 0; k < 4; ++k) o.v[k] = ok ? w * sgn((r2.f[k] - r1.f[k]) - (r1.f[k] - r0.f[k])) : 0.0f;
+  return o;
+}
+
+__device__ __forceinline__ void fs_grad(const FRow& r, const FT& t0, const FT& t1, const FT& t2, bool s_ok, bool out_ok,
+                                        float cx, float cy, float* __restrict__ gb, float* __restrict__ gf, int q, int N) {
+  const FT s0 = fs_S(r, s_ok);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float s1 = wave_shr1(s0.v[k]), s2 = wave_shr1(s1);
+    const float g = cx * ((s0.v[k] - 2.0f * s1) + s2) + cy * ((t0.v[k] - 2.0f * t1.v[k]) + t2.v[k]);
+    if (out_ok) {
+      float* dst = (k < 2 ? gb : gf) + (k & 1) * N + q;
+      if (k < 2 ? gb != nullptr : gf != nullptr) *dst += g;
     }
   }
-  float* gf = G.gflow[d][s] + static_cast<long>(b) * 2 * N;
-  gf[p] += out[0];
-  gf[N + p] += out[1];
+}
+
+__global__ void __launch_bounds__(64) k_geom_flow_smooth_bwd(GeomDev D, GeomBwd G) {
+  const unsigned unit = blockIdx.x;
+  const int b = blockIdx.y;
+  const int s = find_scale(D.rollb_start, D.S, unit);
+  const int H = D.H[s], W = D.W[s], N = D.N[s];
+  const int u = unit - D.rollb_start[s];
+  const int strip = u % D.rollb_strips[s], rb = u / D.rollb_strips[s];
+  const int x = strip * RSB_COLS + static_cast<int>(threadIdx.x) - 2, y0 = rb * RSB_ROWS, yend = min(y0 + RSB_ROWS, H);
+  const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
+  const float* fb = D.flow[0][s] + static_cast<long>(b) * 2 * N;
+  const float* ff = D.flow[1][s] + static_cast<long>(b) * 2 * N;
+  float* gb = G.gflow[0][s] ? G.gflow[0][s] + static_cast<long>(b) * 2 * N : nullptr;
+  float* gf = G.gflow[1][s] ? G.gflow[1][s] + static_cast<long>(b) * 2 * N : nullptr;
+  const float g = G.gl[DFE_LOSS_FLOW_SMOOTH * D.B + b];
+  const float cx = g / (2.0f * H * (W - 2.0f)) / 2.0f / 20.0f, cy = g / (2.0f * (H - 2.0f) * W) / 2.0f / 20.0f;
+  const bool col_in = x >= 0 && x < W;
+  const bool lane_ok = threadIdx.x >= 2 && threadIdx.x <= RSB_COLS + 1 && col_in;
+  const bool s_ok = x >= 0 && x + 2 < W;     // an x stencil starts at this lane
+  // raw rows y0-2 .. ; T(r) uses rows r, r+1, r+2 and exists for 0 <= r, r+2 < H
+  FRow ra = fs_load(it, fb, ff, y0 - 2, x, H, W, N), rb1 = fs_load(it, fb, ff, y0 - 1, x, H, W, N);
+  FRow rc = fs_load(it, fb, ff, y0, x, H, W, N), rd = fs_load(it, fb, ff, y0 + 1, x, H, W, N);
+  FRow nx = fs_load(it, fb, ff, y0 + 2, x, H, W, N);
+  FT ta = fs_T(ra, rb1, rc, col_in && y0 - 2 >= 0 && y0 < H);          // T(y0-2)
+  FT tb = fs_T(rb1, rc, rd, col_in && y0 - 1 >= 0 && y0 + 1 < H);      // T(y0-1)
+  // invariant for gradient row gy: rc = row gy, rd = row gy+1, nx = row gy+2; ta = T(gy-2), tb = T(gy-1)
+  for (int gy = y0; gy < yend; gy += 3) {
+    {
+      const FT tc = fs_T(rc, rd, nx, col_in && gy + 2 < H);                                   // T(gy)
+      fs_grad(rc, tc, tb, ta, s_ok, lane_ok && gy < yend, cx, cy, gb, gf, gy * W + x, N);
+      ta = tc;                                                                                // ta = T(gy), tb = T(gy-1)
+      ra = nx; nx = fs_load(it, fb, ff, gy + 3, x, H, W, N);                                  // rows: rd = gy+1, ra = gy+2, nx = gy+3
+    }
+    {
+      const FT tc = fs_T(rd, ra, nx, col_in && gy + 3 < H);                                   // T(gy+1)
+      fs_grad(rd, tc, ta, tb, s_ok, lane_ok && gy + 1 < yend, cx, cy, gb, gf, (gy + 1) * W + x, N);
+      tb = tc;                                                                                // tb = T(gy+1), ta = T(gy)
+      rb1 = nx; nx = fs_load(it, fb, ff, gy + 4, x, H, W, N);                                 // rows: ra = gy+2, rb1 = gy+3, nx = gy+4
+    }
+    {
+      const FT tc = fs_T(ra, rb1, nx, col_in && gy + 4 < H);                                  // T(gy+2)
+      fs_grad(ra, tc, tb, ta, s_ok, lane_ok && gy + 2 < yend, cx, cy, gb, gf, (gy + 2) * W + x, N);
+      ta = tb; tb = tc;                                                                       // next gy' = gy+3: ta = T(gy'-2), tb = T(gy'-1)
+      rc = rb1; rd = nx; nx = fs_load(it, fb, ff, gy + 5, x, H, W, N);                        // rc = row gy', rd = gy'+1, nx = gy'+2
+    }
+  }
 }
 
 // ---------------------------------------------------------------------- disparity smoothness backward
@@ -545,7 +591,7 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     k_geom_point_bwd<<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, G);
     DFE_LAUNCH_CHECK();
     DFE_MARK();
-    k_geom_flow_smooth_bwd<<<dim3(nblk_total, 2 * L.B), GS_BLOCK, 0, st>>>(D, G);
+    k_geom_flow_smooth_bwd<<<dim3(L.rollb_start[L.S], L.B), 64, 0, st>>>(D, G);
     DFE_LAUNCH_CHECK();
     DFE_MARK();
   }

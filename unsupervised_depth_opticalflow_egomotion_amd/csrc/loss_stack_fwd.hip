@@ -423,21 +423,6 @@ __global__ void __launch_bounds__(64) k_geom_ssim_fwd_roll(GeomDev D, float* __r
 // x+1 / x+2 neighbours come from DPP wave shifts) and marches down RS_ROWS rows with a 3-row register window
 // for the vertical stencil; the target image rows are loaded once for both flow directions and the next
 // row is prefetched.  grid: x = units (strip x row block) over all scales, y = b; block = one wave.
-struct FRow { float i[3]; float f[4]; };   // image row values and flow/20 (bwd u, v, fwd u, v) at this lane's column
-
-__device__ __forceinline__ FRow fs_load(const float* __restrict__ it, const float* __restrict__ fb, const float* __restrict__ ff,
-                                        int y, int x, int H, int W, int N) {
-  FRow r;
-  const bool in = y < H && x < W;
-  const int q = in ? y * W + x : 0;
-  const Divisor D20{20.0f, 1.0f / 20.0f};
-  const float t0 = it[q], t1 = it[q + N], t2 = it[q + 2 * N];
-  const float u0 = fb[q], v0 = fb[q + N], u1 = ff[q], v1 = ff[q + N];
-  r.i[0] = t0; r.i[1] = t1; r.i[2] = t2;
-  r.f[0] = div_exact(u0, D20); r.f[1] = div_exact(v0, D20); r.f[2] = div_exact(u1, D20); r.f[3] = div_exact(v1, D20);
-  return r;
-}
-
 // x-term of row r at this lane (needs lanes l+1, l+2) and y-term of rows (r0, r1, r2); acc = {bwd x, bwd y, fwd x, fwd y}
 __device__ __forceinline__ void fs_terms(const FRow& r0, const FRow& r1, const FRow& r2, bool x_ok, bool y_ok, float (&acc)[4]) {
   float i1[3], i2[3];
