@@ -9,6 +9,7 @@ constexpr int GS_BLOCK = 256;   // threads per block of the pointwise kernels (1
 constexpr int GS_TX = 32, GS_TY = 8;  // SSIM tile (backward)
 constexpr int RS_COLS = 62, RS_ROWS = 8;   // rolling SSIM forward: valid columns per wave (64 lanes - 2 halo), rows per wave
                                             // (measured: rows 4/6/8/16/32 -> 24.2/22.8/21.9/24.0/30.3 us; LDS tile kernel 33 us)
+constexpr int DSM_ROWS = 8;                 // rolling disparity-smoothness kernels: full-res rows per wave (62 valid columns)
 constexpr int FS_ROWS = 8;                  // rolling flow-smoothness kernels: rows per wave (62 valid columns);
                                             // measured 2/4/8 rows -> 24.9/20.6/16.3 us (per-pixel kernel: 24.3 us)
 constexpr int RSB_COLS = 60, RSB_ROWS = 8;  // rolling SSIM backward: 2-lane halo on each side
@@ -40,6 +41,7 @@ struct GeomLayout {
   int roll_start[DFE_MAX_SCALES + 1], roll_strips[DFE_MAX_SCALES];   // rolling-SSIM units (strip x row block) per scale
   int rollb_start[DFE_MAX_SCALES + 1], rollb_strips[DFE_MAX_SCALES]; // same for the backward kernel
   int fs_start[DFE_MAX_SCALES + 1];                                  // flow-smoothness units (roll_strips x FS_ROWS blocks)
+  int dsm_units, dsm_strips;                                         // disparity-smoothness units at full resolution
   int V;                              // pixels per thread of k_geom_point_fwd (4 when every W_s % 4 == 0, else 1)
   int vblk_start[DFE_MAX_SCALES + 1]; // its block table
   // workspace offsets in floats
@@ -104,6 +106,28 @@ __device__ __forceinline__ RowSums ssim_hsum(const RowRaw& w) {
     r.v[c * 5 + 4] = wave_nbr_sum(w.a[c] * w.b[c]);
   }
   return r;
+}
+
+// ---- rolling disparity-smoothness helpers: bilinear up-sampling (ATen, align_corners=False) of a low-res
+// plane evaluated row by row.  UpMap is this lane's horizontal tap (fixed for the whole march); UpCache holds the
+// horizontally interpolated values of the two low-res rows the current full-res row needs, and is advanced
+// (uniformly across the wave) as the wave marches down -- so a full-res row costs ~1 pair of loads per scale.
+struct UpMap { int x0, x1; float l0, l1; };
+struct UpCache { int r0, r1; float h0, h1; };
+
+__device__ __forceinline__ float up_hrow(const float* __restrict__ dp, int Ws, int r, const UpMap& m) {
+  const float* row = dp + r * Ws;
+  return m.l0 * row[m.x0] + m.l1 * row[m.x1];
+}
+
+__device__ __forceinline__ float up_row(const float* __restrict__ dp, int Hs, int Ws, float rh, int y, const UpMap& m, UpCache& c) {
+  int a0, a1; float ly0, ly1;
+  bilinear_src(y, rh, Hs, a0, a1, ly0, ly1);          // wave-uniform
+  float n0, n1;
+  if (a0 == c.r0) n0 = c.h0; else if (a0 == c.r1) n0 = c.h1; else n0 = up_hrow(dp, Ws, a0, m);
+  if (a1 == c.r1) n1 = c.h1; else if (a1 == c.r0) n1 = c.h0; else if (a1 == a0) n1 = n0; else n1 = up_hrow(dp, Ws, a1, m);
+  c.r0 = a0; c.r1 = a1; c.h0 = n0; c.h1 = n1;
+  return ly0 * n0 + ly1 * n1;
 }
 
 // ---- rolling flow-smoothness helpers

@@ -415,43 +415,79 @@ __global__ void __launch_bounds__(64) k_geom_flow_smooth_bwd(GeomDev D, GeomBwd 
 }
 
 // ---------------------------------------------------------------------- disparity smoothness backward
-__device__ __forceinline__ float up_at(const float* __restrict__ dp, int s, int Hs, int Ws, int H, int W, int y, int x) {
-  if (s == 0) return dp[static_cast<long>(y) * W + x];
-  return resize_bilinear_at(dp, Hs, Ws, y, x, static_cast<float>(Hs) / H, static_cast<float>(Ws) / W);
-}
-
-// stage 1: per full-resolution pixel, dL/d(up_s(p)) for every scale.  grid.y = f*B + b.
-__global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_bwd1(GeomDev D, GeomBwd G) {
+// stage 1: per full-resolution pixel, dL/d(up_s(p)) for every scale.  Rolling wave kernel like
+// k_geom_disp_smooth_fwd (lanes 1..62 valid: x-1 and x+1 come from DPP wave shifts).  With
+//   A_s(y,x) = sgn(u(y,x) - u(y,x+1)) wx(y,x)   and   B_s(y,x) = sgn(u(y,x) - u(y+1,x)) wy(y,x)
+// the gradient is cx (A(y,x) - A(y,x-1)) + cy (B(y,x) - B(y-1,x)); B of the previous row stays in a register,
+// the march starts one row early to seed it.  grid: x = units (strip x row block), y = f*B + b.
+template <int NS>
+__global__ void __launch_bounds__(64) k_geom_disp_smooth_bwd1(GeomDev D, GeomBwd G, int strips) {
   const int f = blockIdx.y / D.B, b = blockIdx.y - f * D.B;
   const int H = D.H[0], W = D.W[0], N = D.N[0];
-  const int p = blockIdx.x * GS_BLOCK + threadIdx.x;
-  if (p >= N) return;
-  const int py = p / W, px = p - py * W;
+  const int strip = blockIdx.x % strips, rb = blockIdx.x / strips;
+  const int x = strip * RS_COLS + static_cast<int>(threadIdx.x) - 1, xc = min(max(x, 0), W - 1);
+  const int y0 = rb * DSM_ROWS, yend = min(y0 + DSM_ROWS, H), ys = max(y0 - 1, 0);
   const float* im = D.pyr[f][0] + static_cast<long>(b) * 3 * N;
+  const float* d0 = D.disp[f][0] + static_cast<long>(b) * N;
+  const bool col_in = x >= 0 && x < W;
+  const bool lane_ok = threadIdx.x >= 1 && threadIdx.x <= RS_COLS && col_in;
+  const bool hxp = col_in && x + 1 < W, hxm = x > 0;
   const float g = G.gl[DFE_LOSS_DEPTH_SMOOTH * D.B + b];
   const float cx = g / (static_cast<float>(H) * (W - 1.0f)), cy = g / ((H - 1.0f) * static_cast<float>(W));
-  const bool hxp = px + 1 < W, hxm = px > 0, hyp = py + 1 < H, hym = py > 0;
-  const float c0 = im[p], c1 = im[p + N], c2 = im[p + 2 * N];
-  float wxp = 0, wxm = 0, wyp = 0, wym = 0;
-  if (hxp) wxp = expf(-mean3_abs_diff(c0, c1, c2, im[p + 1], im[p + 1 + N], im[p + 1 + 2 * N]));
-  if (hxm) wxm = expf(-mean3_abs_diff(im[p - 1], im[p - 1 + N], im[p - 1 + 2 * N], c0, c1, c2));
-  if (hyp) wyp = expf(-mean3_abs_diff(c0, c1, c2, im[p + W], im[p + W + N], im[p + W + 2 * N]));
-  if (hym) wym = expf(-mean3_abs_diff(im[p - W], im[p - W + N], im[p - W + 2 * N], c0, c1, c2));
-  for (int s = 0; s < D.S; ++s) {
-    const float* dp = D.disp[f][s] + static_cast<long>(b) * D.N[s];
-    const int Hs = D.H[s], Ws = D.W[s];
-    const float u0 = up_at(dp, s, Hs, Ws, H, W, py, px);
-    float gsum = 0.0f;
-    if (hxp) gsum += cx * sgn(u0 - up_at(dp, s, Hs, Ws, H, W, py, px + 1)) * wxp;
-    if (hxm) gsum -= cx * sgn(up_at(dp, s, Hs, Ws, H, W, py, px - 1) - u0) * wxm;
-    if (hyp) gsum += cy * sgn(u0 - up_at(dp, s, Hs, Ws, H, W, py + 1, px)) * wyp;
-    if (hym) gsum -= cy * sgn(up_at(dp, s, Hs, Ws, H, W, py - 1, px) - u0) * wym;
-    if (s == 0) {
-      float* o = G.gdisp[f][0];
-      if (o) { if (f == 1) o[static_cast<long>(b) * N + p] += gsum; else o[static_cast<long>(b) * N + p] = gsum; }
-    } else {
-      G.gup[((static_cast<long>(f) * (D.S - 1) + (s - 1)) * D.B + b) * N + p] = gsum;
+  UpMap mp[NS > 1 ? NS - 1 : 1];
+  UpCache ch[NS > 1 ? NS - 1 : 1];
+  const float* dps[NS > 1 ? NS - 1 : 1];
+  float rhs[NS > 1 ? NS - 1 : 1];
+#pragma unroll
+  for (int s = 1; s < NS; ++s) {
+    bilinear_src(xc, static_cast<float>(D.W[s]) / W, D.W[s], mp[s - 1].x0, mp[s - 1].x1, mp[s - 1].l0, mp[s - 1].l1);
+    ch[s - 1].r0 = -1; ch[s - 1].r1 = -1; ch[s - 1].h0 = 0.0f; ch[s - 1].h1 = 0.0f;
+    dps[s - 1] = D.disp[f][s] + static_cast<long>(b) * D.N[s];
+    rhs[s - 1] = static_cast<float>(D.H[s]) / H;
+  }
+  int q = ys * W + xc;
+  float c0 = im[q], c1 = im[q + N], c2 = im[q + 2 * N];
+  float u[NS], bprev[NS];
+  u[0] = d0[q];
+#pragma unroll
+  for (int s = 1; s < NS; ++s) u[s] = up_row(dps[s - 1], D.H[s], D.W[s], rhs[s - 1], ys, mp[s - 1], ch[s - 1]);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) bprev[s] = 0.0f;
+  int qn = min(ys + 1, H - 1) * W + xc;
+  float n0 = im[qn], n1 = im[qn + N], n2 = im[qn + 2 * N], nd = d0[qn];
+  for (int y = ys; y < yend; ++y) {
+    const float e0 = n0, e1 = n1, e2 = n2, ed = nd;          // row y+1
+    const int qf = min(y + 2, H - 1) * W + xc;                // issue the loads of row y+2
+    n0 = im[qf]; n1 = im[qf + N]; n2 = im[qf + 2 * N]; nd = d0[qf];
+    const bool hyp = col_in && y + 1 < H;
+    const float wx = expf(-mean3_abs_diff(c0, c1, c2, wave_shl1(c0), wave_shl1(c1), wave_shl1(c2)));
+    const float wy = expf(-mean3_abs_diff(c0, c1, c2, e0, e1, e2));
+    float un[NS];
+    un[0] = ed;
+#pragma unroll
+    for (int s = 1; s < NS; ++s) un[s] = up_row(dps[s - 1], D.H[s], D.W[s], rhs[s - 1], min(y + 1, H - 1), mp[s - 1], ch[s - 1]);
+    const bool store = lane_ok && y >= y0;
+    const long p = static_cast<long>(y) * W + x;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      // DPP shifts must run with every lane enabled: a lane reading a neighbour that EXEC disabled gets 0
+      const float ur = wave_shl1(u[s]);
+      const float A = hxp ? sgn(u[s] - ur) * wx : 0.0f;
+      const float Am = wave_shr1(A);
+      const float Bv = hyp ? sgn(u[s] - un[s]) * wy : 0.0f;
+      const float gsum = cx * (A - (hxm ? Am : 0.0f)) + cy * (Bv - bprev[s]);
+      if (store) {
+        if (s == 0) {
+          float* o = G.gdisp[f][0];
+          if (o) { if (f == 1) o[static_cast<long>(b) * N + p] += gsum; else o[static_cast<long>(b) * N + p] = gsum; }
+        } else {
+          G.gup[((static_cast<long>(f) * (D.S - 1) + (s - 1)) * D.B + b) * N + p] = gsum;
+        }
+      }
+      bprev[s] = Bv;
+      u[s] = un[s];
     }
+    c0 = e0; c1 = e1; c2 = e2;
   }
 }
 
@@ -595,7 +631,19 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     DFE_LAUNCH_CHECK();
     DFE_MARK();
   }
-  k_geom_disp_smooth_bwd1<<<dim3(L.nblk0, 3 * L.B), GS_BLOCK, 0, st>>>(D, G);
+  {
+    const dim3 g(L.dsm_units, 3 * L.B);
+    switch (L.S) {
+      case 1: k_geom_disp_smooth_bwd1<1><<<g, 64, 0, st>>>(D, G, L.dsm_strips); break;
+      case 2: k_geom_disp_smooth_bwd1<2><<<g, 64, 0, st>>>(D, G, L.dsm_strips); break;
+      case 3: k_geom_disp_smooth_bwd1<3><<<g, 64, 0, st>>>(D, G, L.dsm_strips); break;
+      case 4: k_geom_disp_smooth_bwd1<4><<<g, 64, 0, st>>>(D, G, L.dsm_strips); break;
+      case 5: k_geom_disp_smooth_bwd1<5><<<g, 64, 0, st>>>(D, G, L.dsm_strips); break;
+      case 6: k_geom_disp_smooth_bwd1<6><<<g, 64, 0, st>>>(D, G, L.dsm_strips); break;
+      case 7: k_geom_disp_smooth_bwd1<7><<<g, 64, 0, st>>>(D, G, L.dsm_strips); break;
+      default: k_geom_disp_smooth_bwd1<8><<<g, 64, 0, st>>>(D, G, L.dsm_strips); break;
+    }
+  }
   DFE_LAUNCH_CHECK();
   DFE_MARK();
   if (L.S > 1) {

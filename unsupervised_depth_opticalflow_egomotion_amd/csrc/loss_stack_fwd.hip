@@ -49,6 +49,8 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
   }
   L->fs_start[0] = 0;
   for (int s = 0; s < L->S; ++s) L->fs_start[s + 1] = L->fs_start[s] + ((L->W[s] + RS_COLS - 1) / RS_COLS) * ((L->H[s] + FS_ROWS - 1) / FS_ROWS);
+  L->dsm_strips = (L->W[0] + RS_COLS - 1) / RS_COLS;
+  L->dsm_units = L->dsm_strips * ((L->H[0] + DSM_ROWS - 1) / DSM_ROWS);
   L->rollb_start[0] = 0;
   for (int s = 0; s < L->S; ++s) {
     L->rollb_strips[s] = (L->W[s] + RSB_COLS - 1) / RSB_COLS;
@@ -69,7 +71,7 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
   L->o_part = o; o = align4(o + B * nblk_total * PT_COUNT);
   L->o_spart = o; o = align4(o + B * 2 * (ntile_total > L->roll_start[S] ? ntile_total : static_cast<long>(L->roll_start[S])));
   L->o_fpart = o; o = align4(o + 2 * B * (nblk_total > L->fs_start[S] ? nblk_total : static_cast<long>(L->fs_start[S])) * 2);
-  L->o_dpart = o; o = align4(o + 3 * B * L->nblk0 * 2);
+  L->o_dpart = o; o = align4(o + 3 * B * static_cast<long>(L->dsm_units > L->nblk0 ? L->dsm_units : L->nblk0) * 2);
   L->o_sums = o; o = align4(o + B * S * SUM_COUNT);
   L->o_coef = o; o = align4(o + B * S * CF_COUNT);
   L->o_dsum = o; o = align4(o + 3 * B * 2);
@@ -475,37 +477,63 @@ __global__ void __launch_bounds__(64) k_geom_flow_smooth_fwd(GeomDev D, float* _
 }
 
 // First-order edge-aware disparity smoothness at full resolution, all scales fused
-// (model_geometry.py:225-252).  grid.y = f*B + b over the 3 frames.
-__global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_fwd(GeomDev D, float* __restrict__ dpart) {
-  __shared__ float red[2 * 4 * (GS_BLOCK / 64)];
+// (model_geometry.py:225-252).  Rolling wave kernel: a wave owns 62 full-res columns (lanes 0..61 produce
+// output; x+1 comes from a DPP wave shift) and marches down DSM_ROWS rows; the up-sampled disparity of every
+// coarser scale is evaluated row by row from a cache of horizontally interpolated low-res rows (loss_stack.h),
+// so a row costs 4 streamed loads plus ~1 pair of low-res loads per scale instead of ~36 gathers.
+// grid: x = units (strip x row block), y = f*B + b over the 3 frames; block = one wave.  NS = number of scales.
+template <int NS>
+__global__ void __launch_bounds__(64) k_geom_disp_smooth_fwd(GeomDev D, float* __restrict__ dpart, int strips) {
+  __shared__ float red[2 * 4];
   const int f = blockIdx.y / D.B, b = blockIdx.y - f * D.B;
   const int H = D.H[0], W = D.W[0], N = D.N[0];
-  const int p = blockIdx.x * GS_BLOCK + threadIdx.x;
+  const int strip = blockIdx.x % strips, rb = blockIdx.x / strips;
+  const int x = strip * RS_COLS + static_cast<int>(threadIdx.x), xc = min(x, W - 1);
+  const int y0 = rb * DSM_ROWS, yend = min(y0 + DSM_ROWS, H);
+  const float* im = D.pyr[f][0] + static_cast<long>(b) * 3 * N;
+  const float* d0 = D.disp[f][0] + static_cast<long>(b) * N;
+  const bool lane_ok = threadIdx.x < RS_COLS && x < W, hx = lane_ok && x + 1 < W;
+  UpMap mp[NS > 1 ? NS - 1 : 1];
+  UpCache ch[NS > 1 ? NS - 1 : 1];
+  const float* dps[NS > 1 ? NS - 1 : 1];
+  float rhs[NS > 1 ? NS - 1 : 1];
+#pragma unroll
+  for (int s = 1; s < NS; ++s) {
+    bilinear_src(xc, static_cast<float>(D.W[s]) / W, D.W[s], mp[s - 1].x0, mp[s - 1].x1, mp[s - 1].l0, mp[s - 1].l1);
+    ch[s - 1].r0 = -1; ch[s - 1].r1 = -1; ch[s - 1].h0 = 0.0f; ch[s - 1].h1 = 0.0f;
+    dps[s - 1] = D.disp[f][s] + static_cast<long>(b) * D.N[s];
+    rhs[s - 1] = static_cast<float>(D.H[s]) / H;
+  }
   float acc[2] = {0.0f, 0.0f};
-  if (p < N) {
-    const int py = p / W, px = p - py * W;
-    const float* im = D.pyr[f][0] + static_cast<long>(b) * 3 * N;
-    const bool hx = px + 1 < W, hy = py + 1 < H;
-    float wx = 0.0f, wy = 0.0f;
-    const float c0 = im[p], c1 = im[p + N], c2 = im[p + 2 * N];
-    if (hx) wx = expf(-mean3_abs_diff(c0, c1, c2, im[p + 1], im[p + 1 + N], im[p + 1 + 2 * N]));
-    if (hy) wy = expf(-mean3_abs_diff(c0, c1, c2, im[p + W], im[p + W + N], im[p + W + 2 * N]));
-    for (int s = 0; s < D.S; ++s) {
-      const float* dp = D.disp[f][s] + static_cast<long>(b) * D.N[s];
-      float u0, ux = 0.0f, uy = 0.0f;
-      if (s == 0) {
-        u0 = dp[p];
-        if (hx) ux = dp[p + 1];
-        if (hy) uy = dp[p + W];
-      } else {
-        const float sh = static_cast<float>(D.H[s]) / H, sw = static_cast<float>(D.W[s]) / W;
-        u0 = resize_bilinear_at(dp, D.H[s], D.W[s], py, px, sh, sw);
-        if (hx) ux = resize_bilinear_at(dp, D.H[s], D.W[s], py, px + 1, sh, sw);
-        if (hy) uy = resize_bilinear_at(dp, D.H[s], D.W[s], py + 1, px, sh, sw);
-      }
-      if (hx) acc[0] += fabsf(u0 - ux) * wx;
-      if (hy) acc[1] += fabsf(u0 - uy) * wy;
+  // current row
+  int q = y0 * W + xc;
+  float c0 = im[q], c1 = im[q + N], c2 = im[q + 2 * N];
+  float u[NS];
+  u[0] = d0[q];
+#pragma unroll
+  for (int s = 1; s < NS; ++s) u[s] = up_row(dps[s - 1], D.H[s], D.W[s], rhs[s - 1], y0, mp[s - 1], ch[s - 1]);
+  // prefetch of the next row's streamed values
+  int qn = min(y0 + 1, H - 1) * W + xc;
+  float n0 = im[qn], n1 = im[qn + N], n2 = im[qn + 2 * N], nd = d0[qn];
+  for (int y = y0; y < yend; ++y) {
+    const float e0 = n0, e1 = n1, e2 = n2, ed = nd;          // row y+1
+    const int qf = min(y + 2, H - 1) * W + xc;                // issue the loads of row y+2
+    n0 = im[qf]; n1 = im[qf + N]; n2 = im[qf + 2 * N]; nd = d0[qf];
+    const bool hy = lane_ok && y + 1 < H;
+    float wx = expf(-mean3_abs_diff(c0, c1, c2, wave_shl1(c0), wave_shl1(c1), wave_shl1(c2)));
+    float wy = expf(-mean3_abs_diff(c0, c1, c2, e0, e1, e2));
+    float un[NS];
+    un[0] = ed;
+#pragma unroll
+    for (int s = 1; s < NS; ++s) un[s] = up_row(dps[s - 1], D.H[s], D.W[s], rhs[s - 1], min(y + 1, H - 1), mp[s - 1], ch[s - 1]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float ux = wave_shl1(u[s]);
+      if (hx) acc[0] += fabsf(u[s] - ux) * wx;
+      if (hy) acc[1] += fabsf(u[s] - un[s]) * wy;
+      u[s] = un[s];
     }
+    c0 = e0; c1 = e1; c2 = e2;
   }
   block_sum<2>(acc, red, dpart + (static_cast<long>(blockIdx.y) * gridDim.x + blockIdx.x) * 2);
 }
@@ -717,10 +745,23 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     DFE_LAUNCH_CHECK();
     DFE_MARK();
   }
-  k_geom_disp_smooth_fwd<<<dim3(L.nblk0, 3 * L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_dpart);
+  {
+    const dim3 g(L.dsm_units, 3 * L.B);
+    float* dp = ws + L.o_dpart;
+    switch (L.S) {
+      case 1: k_geom_disp_smooth_fwd<1><<<g, 64, 0, st>>>(D, dp, L.dsm_strips); break;
+      case 2: k_geom_disp_smooth_fwd<2><<<g, 64, 0, st>>>(D, dp, L.dsm_strips); break;
+      case 3: k_geom_disp_smooth_fwd<3><<<g, 64, 0, st>>>(D, dp, L.dsm_strips); break;
+      case 4: k_geom_disp_smooth_fwd<4><<<g, 64, 0, st>>>(D, dp, L.dsm_strips); break;
+      case 5: k_geom_disp_smooth_fwd<5><<<g, 64, 0, st>>>(D, dp, L.dsm_strips); break;
+      case 6: k_geom_disp_smooth_fwd<6><<<g, 64, 0, st>>>(D, dp, L.dsm_strips); break;
+      case 7: k_geom_disp_smooth_fwd<7><<<g, 64, 0, st>>>(D, dp, L.dsm_strips); break;
+      default: k_geom_disp_smooth_fwd<8><<<g, 64, 0, st>>>(D, dp, L.dsm_strips); break;
+    }
+  }
   DFE_LAUNCH_CHECK();
   DFE_MARK();
-  k_geom_finalize_fwd<<<L.B, 256, 0, st>>>(D, ws + L.o_part, ws + L.o_spart, ws + L.o_fpart, ws + L.o_dpart, L.nblk0,
+  k_geom_finalize_fwd<<<L.B, 256, 0, st>>>(D, ws + L.o_part, ws + L.o_spart, ws + L.o_fpart, ws + L.o_dpart, L.dsm_units,
                                          ws + L.o_sums, ws + L.o_coef, ws + L.o_dsum, a->losses);
   DFE_LAUNCH_CHECK();
   DFE_MARK();
