@@ -491,8 +491,25 @@ __global__ void __launch_bounds__(64) k_geom_disp_smooth_bwd1(GeomDev D, GeomBwd
   }
 }
 
-// stage 2: adjoint of the bilinear up-sampling, one thread per low-res pixel of scales >= 1.
+// stage 2: adjoint of the bilinear up-sampling as a gather, one thread per low-res pixel of scales >= 1
+// (deterministic: no scatter atomics).  The adjoint is separable: the weight of full-res pixel (y, x) on low-res
+// pixel (i, j) is wy(y) * wx(x), so the (at most G2_MAX) candidate rows / columns and their weights are formed
+// once per thread and the double loop only touches the non-zero taps (16 at ratio 1/2, 64 at 1/4).
 // grid.x covers blocks [blk_start[1], blk_start[S]); grid.y = f*B + b.
+constexpr int G2_MAX = 12;   // candidates per axis: 2/ratio + 4 (ratio >= 1/4 in registers, coarser scales loop)
+
+__device__ __forceinline__ void adj_weights(int i, float r, int lowN, int fullN, int& lo, int& cnt, float (&w)[G2_MAX]) {
+  lo = max(static_cast<int>(floorf((i - 0.5f) / r - 0.5f)) - 1, 0);
+  const int hi = min(static_cast<int>(ceilf((i + 1.5f) / r - 0.5f)) + 1, fullN - 1);
+  cnt = hi - lo + 1;
+#pragma unroll
+  for (int k = 0; k < G2_MAX; ++k) {
+    int a0, a1; float l0, l1;
+    bilinear_src(min(lo + k, fullN - 1), r, lowN, a0, a1, l0, l1);
+    w[k] = (k < cnt) ? ((a0 == i ? l0 : 0.0f) + (a1 == i ? l1 : 0.0f)) : 0.0f;
+  }
+}
+
 __global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_bwd2(GeomDev D, GeomBwd G) {
   const unsigned blk = blockIdx.x + D.blk_start[1];
   const int f = blockIdx.y / D.B, b = blockIdx.y - f * D.B;
@@ -504,23 +521,39 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_bwd2(GeomDev D, G
   const int i = q / Ws, j = q - i * Ws;
   const float rh = static_cast<float>(Hs) / H, rw = static_cast<float>(Ws) / W;
   const float* gu = G.gup + ((static_cast<long>(f) * (D.S - 1) + (s - 1)) * D.B + b) * N;
-  int ylo = static_cast<int>(floorf((i - 0.5f) / rh - 0.5f)) - 1, yhi = static_cast<int>(ceilf((i + 1.5f) / rh - 0.5f)) + 1;
-  int xlo = static_cast<int>(floorf((j - 0.5f) / rw - 0.5f)) - 1, xhi = static_cast<int>(ceilf((j + 1.5f) / rw - 0.5f)) + 1;
-  ylo = max(ylo, 0); xlo = max(xlo, 0); yhi = min(yhi, H - 1); xhi = min(xhi, W - 1);
   float total = 0.0f;
-  for (int y = ylo; y <= yhi; ++y) {
-    int y0, y1; float l0, l1;
-    bilinear_src(y, rh, Hs, y0, y1, l0, l1);
-    const float wy = (y0 == i ? l0 : 0.0f) + (y1 == i ? l1 : 0.0f);
-    if (wy == 0.0f) continue;
-    float row = 0.0f;
-    for (int x = xlo; x <= xhi; ++x) {
-      int x0, x1; float m0, m1;
-      bilinear_src(x, rw, Ws, x0, x1, m0, m1);
-      const float wx = (x0 == j ? m0 : 0.0f) + (x1 == j ? m1 : 0.0f);
-      if (wx != 0.0f) row += wx * gu[static_cast<long>(y) * W + x];
+  int ylo, ny, xlo, nx;
+  float wy[G2_MAX], wx[G2_MAX];
+  adj_weights(i, rh, Hs, H, ylo, ny, wy);
+  adj_weights(j, rw, Ws, W, xlo, nx, wx);
+  if (ny <= G2_MAX && nx <= G2_MAX) {
+#pragma unroll
+    for (int ky = 0; ky < G2_MAX; ++ky) {
+      if (wy[ky] == 0.0f) continue;
+      const float* row = gu + static_cast<long>(ylo + ky) * W + xlo;
+      float acc = 0.0f;
+#pragma unroll
+      for (int kx = 0; kx < G2_MAX; ++kx)
+        if (wx[kx] != 0.0f) acc += wx[kx] * row[kx];
+      total += wy[ky] * acc;
     }
-    total += wy * row;
+  } else {
+    // coarse scales (ratio < 1/4): footprints are large but these images are tiny; plain loops
+    const int yhi = ylo + ny - 1, xhi = xlo + nx - 1;
+    for (int y = ylo; y <= yhi; ++y) {
+      int a0, a1; float l0, l1;
+      bilinear_src(y, rh, Hs, a0, a1, l0, l1);
+      const float wyy = (a0 == i ? l0 : 0.0f) + (a1 == i ? l1 : 0.0f);
+      if (wyy == 0.0f) continue;
+      float acc = 0.0f;
+      for (int x = xlo; x <= xhi; ++x) {
+        int c0, c1; float m0, m1;
+        bilinear_src(x, rw, Ws, c0, c1, m0, m1);
+        const float wxx = (c0 == j ? m0 : 0.0f) + (c1 == j ? m1 : 0.0f);
+        if (wxx != 0.0f) acc += wxx * gu[static_cast<long>(y) * W + x];
+      }
+      total += wyy * acc;
+    }
   }
   float* o = G.gdisp[f][s] + static_cast<long>(b) * Ns + q;
   if (f == 1) *o += total; else *o = total;

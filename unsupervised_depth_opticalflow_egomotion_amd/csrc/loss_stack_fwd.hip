@@ -9,7 +9,7 @@
 //   k_geom_ssim_fwd_roll   3x3 SSIM of (I*m, warped*m): a wave owns a 62-column strip, DPP wave shifts for the
 //                          horizontal sums, a 3-row register window for the vertical ones (stage P)
 //   k_geom_smooth_fwd      disparity (1st order, full-res) and flow (2nd order) smoothness
-//   k_geom_finalize_fwd    fixed-order reduction of block partials -> loss vectors + normalisers
+//   k_geom_reduce_fwd + k_geom_assemble_fwd   fixed-order reduction of block partials -> loss vectors + normalisers
 // All (sample, scale) images are batched into each launch: scale 2 alone (13 k px) cannot fill
 // 256 CUs.  Partials are reduced in a fixed order (no float atomics): bitwise reproducible.
 #include "loss_stack.h"
@@ -125,8 +125,16 @@ __global__ void k_prepare_epi(const float* __restrict__ pose, const float* __res
 }
 
 // ---------------------------------------------------------------------- pyramids
-struct PyrJob { const float* in; float* out; int outH, outW, mode; };
-struct PyrJobs { PyrJob j[5 * (DFE_MAX_SCALES - 1)]; int n, planes, inH, inW; };
+// One thread per output pixel of one (frame, scale) job; for the left / right frames the same thread also
+// produces the area (box-mean) level, whose window overlaps the bilinear taps.  Horizontally adjacent source
+// pixels are fetched with dword-aligned 8-byte loads (memory-instruction count is what these kernels pay for).
+struct PyrJob { const float* in; float* out_bilinear; float* out_area; int outH, outW; };
+struct PyrJobs { PyrJob j[3 * (DFE_MAX_SCALES - 1)]; int n, planes, inH, inW; };
+
+__device__ __forceinline__ void load2(const float* __restrict__ row, int x0, int x1, float& v0, float& v1) {
+  if (x1 == x0 + 1) { const PairF p = *reinterpret_cast<const PairF*>(row + x0); v0 = p.a; v1 = p.b; }
+  else { v0 = row[x0]; v1 = row[x1]; }
+}
 
 __global__ void k_geom_pyramids(PyrJobs jobs) {
   const PyrJob jb = jobs.j[blockIdx.y];
@@ -137,15 +145,28 @@ __global__ void k_geom_pyramids(PyrJobs jobs) {
   const long pl = i / (static_cast<long>(jb.outW) * jb.outH);
   const int inH = jobs.inH, inW = jobs.inW;
   const float* src = jb.in + pl * inH * inW;
-  if (jb.mode == 0) {
-    jb.out[i] = resize_bilinear_at(src, inH, inW, oy, ox, static_cast<float>(inH) / jb.outH, static_cast<float>(inW) / jb.outW);
-  } else {
-    int ys = (oy * inH) / jb.outH, ye = ((oy + 1) * inH + jb.outH - 1) / jb.outH;
-    int xs = (ox * inW) / jb.outW, xe = ((ox + 1) * inW + jb.outW - 1) / jb.outW;
-    float s = 0.0f;
-    for (int yy = ys; yy < ye; ++yy)
-      for (int xx = xs; xx < xe; ++xx) s += src[static_cast<long>(yy) * inW + xx];
-    jb.out[i] = s / static_cast<float>((ye - ys) * (xe - xs));
+  {
+    // F.interpolate(bilinear, align_corners=False): ly0*(lx0*v00 + lx1*v01) + ly1*(lx0*v10 + lx1*v11)
+    int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+    bilinear_src(oy, static_cast<float>(inH) / jb.outH, inH, y0, y1, ly0, ly1);
+    bilinear_src(ox, static_cast<float>(inW) / jb.outW, inW, x0, x1, lx0, lx1);
+    float v00, v01, v10, v11;
+    load2(src + static_cast<long>(y0) * inW, x0, x1, v00, v01);
+    load2(src + static_cast<long>(y1) * inW, x0, x1, v10, v11);
+    jb.out_bilinear[i] = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+  }
+  if (jb.out_area) {
+    // adaptive_avg_pool2d window [floor(o*in/out), ceil((o+1)*in/out)), row-major sequential sum / count
+    const int ys = (oy * inH) / jb.outH, ye = ((oy + 1) * inH + jb.outH - 1) / jb.outH;
+    const int xs = (ox * inW) / jb.outW, xe = ((ox + 1) * inW + jb.outW - 1) / jb.outW;
+    float sum = 0.0f;
+    for (int yy = ys; yy < ye; ++yy) {
+      const float* row = src + static_cast<long>(yy) * inW;
+      int xx = xs;
+      for (; xx + 1 < xe; xx += 2) { const PairF p = *reinterpret_cast<const PairF*>(row + xx); sum += p.a; sum += p.b; }
+      if (xx < xe) sum += row[xx];
+    }
+    jb.out_area[i] = sum / static_cast<float>((ye - ys) * (xe - xs));
   }
 }
 
@@ -539,20 +560,18 @@ __global__ void __launch_bounds__(64) k_geom_disp_smooth_fwd(GeomDev D, float* _
 }
 
 // ---------------------------------------------------------------------- finalize
-// One 256-thread block per sample.  Phase 1: thread t accumulates the partial rows k = t (mod 256)
-// of every column in double; phase 2: one thread per column adds the 256 per-thread sums in thread
-// order.  Both orders are fixed -> bitwise reproducible.  Thread 0 then assembles the eight loss
-// values and the normalisers the backward needs.
-__global__ void __launch_bounds__(256) k_geom_finalize_fwd(GeomDev D, const float* __restrict__ part,
+// k_geom_reduce_fwd: one 256-thread block per (scale, sample) plus one per sample for the disparity-smoothness
+// sums.  Phase 1: thread t accumulates the partial rows k = t (mod 256) of every column in double; phase 2: one
+// thread per column adds the 256 per-thread sums in thread order.  Both orders are fixed -> bitwise
+// reproducible.  k_geom_assemble_fwd (one thread per sample) then forms the eight loss values and the
+// normalisers the backward needs.
+__global__ void __launch_bounds__(256) k_geom_reduce_fwd(GeomDev D, const float* __restrict__ part,
                                     const float* __restrict__ spart, const float* __restrict__ fpart,
-                                    const float* __restrict__ dpart, int nblk0, float* __restrict__ sums,
-                                    float* __restrict__ coef, float* __restrict__ dsum, float* __restrict__ losses) {
+                                    const float* __restrict__ dpart, int ndunit, float* __restrict__ sums,
+                                    float* __restrict__ dsum) {
   __shared__ double lds[256][SUM_COUNT + 1];
-  __shared__ double sm[DFE_MAX_SCALES][SUM_COUNT];
-  __shared__ double ds[3][2];
-  const int b = blockIdx.x, S = D.S, B = D.B, t = threadIdx.x;
-  const unsigned nblk_total = D.blk_start[S];
-  for (int s = 0; s < S; ++s) {
+  const int s = blockIdx.x, b = blockIdx.y, S = D.S, B = D.B, t = threadIdx.x;
+  if (s < S) {
     double a[SUM_COUNT];
 #pragma unroll
     for (int i = 0; i < SUM_COUNT; ++i) a[i] = 0.0;
@@ -561,16 +580,18 @@ __global__ void __launch_bounds__(256) k_geom_finalize_fwd(GeomDev D, const floa
 #pragma unroll
       for (int i = 0; i < PT_COUNT; ++i) a[i] += r[i];
     }
-    if (D.mode == 0) for (int k = D.fs_start[s] + t; k < D.fs_start[s + 1]; k += 256) {
+    if (D.mode == 0) {
+      for (int k = D.fs_start[s] + t; k < D.fs_start[s + 1]; k += 256) {
 #pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        const float* q = fpart + (static_cast<long>(d * B + b) * D.fs_start[S] + k) * 2;
-        a[SUM_FS + 2 * d] += q[0]; a[SUM_FS + 2 * d + 1] += q[1];
+        for (int d = 0; d < 2; ++d) {
+          const float* q = fpart + (static_cast<long>(d * B + b) * D.fs_start[S] + k) * 2;
+          a[SUM_FS + 2 * d] += q[0]; a[SUM_FS + 2 * d + 1] += q[1];
+        }
       }
-    }
-    if (D.mode == 0) for (int k = D.roll_start[s] + t; k < D.roll_start[s + 1]; k += 256) {
-      a[SUM_SSIM] += spart[static_cast<long>(b * 2) * D.roll_start[S] + k];
-      a[SUM_SSIM + 1] += spart[static_cast<long>(b * 2 + 1) * D.roll_start[S] + k];
+      for (int k = D.roll_start[s] + t; k < D.roll_start[s + 1]; k += 256) {
+        a[SUM_SSIM] += spart[static_cast<long>(b * 2) * D.roll_start[S] + k];
+        a[SUM_SSIM + 1] += spart[static_cast<long>(b * 2 + 1) * D.roll_start[S] + k];
+      }
     }
 #pragma unroll
     for (int i = 0; i < SUM_COUNT; ++i) lds[t][i] = a[i];
@@ -578,17 +599,14 @@ __global__ void __launch_bounds__(256) k_geom_finalize_fwd(GeomDev D, const floa
     if (t < SUM_COUNT) {
       double v = 0.0;
       for (int k = 0; k < 256; ++k) v += lds[k][t];
-      sm[s][t] = v;
       sums[(static_cast<long>(b) * S + s) * SUM_COUNT + t] = static_cast<float>(v);
     }
-    __syncthreads();
-  }
-  {
+  } else {
     double a[6] = {0, 0, 0, 0, 0, 0};
-    for (int k = t; k < nblk0; k += 256)
+    for (int k = t; k < ndunit; k += 256)
 #pragma unroll
       for (int f = 0; f < 3; ++f) {
-        const float* q = dpart + (static_cast<long>(f * B + b) * nblk0 + k) * 2;
+        const float* q = dpart + (static_cast<long>(f * B + b) * ndunit + k) * 2;
         a[f * 2] += q[0]; a[f * 2 + 1] += q[1];
       }
 #pragma unroll
@@ -597,25 +615,29 @@ __global__ void __launch_bounds__(256) k_geom_finalize_fwd(GeomDev D, const floa
     if (t < 6) {
       double v = 0.0;
       for (int k = 0; k < 256; ++k) v += lds[k][t];
-      ds[t >> 1][t & 1] = v;
       dsum[((t >> 1) * B + b) * 2 + (t & 1)] = static_cast<float>(v);
     }
   }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
+}
+
+__global__ void k_geom_assemble_fwd(GeomDev D, const float* __restrict__ sums, const float* __restrict__ dsum,
+                                    float* __restrict__ coef, float* __restrict__ losses) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x, S = D.S, B = D.B;
+  if (b >= B) return;
   const double eps = 1e-12;
   double l_dp = 0, l_fp = 0, l_fs = 0, l_sm = 0, l_fc = 0, l_dfc = 0, l_epi = 0;
   for (int s = 0; s < S; ++s) {
     const double N = D.N[s], H = D.H[s], W = D.W[s];
+    const float* sm = sums + (static_cast<long>(b) * S + s) * SUM_COUNT;
     float* cf = coef + (static_cast<long>(b) * S + s) * CF_COUNT;
     for (int d = 0; d < 2; ++d) {
-      const double* a = sm[s] + d * PT_PER_DIR;
+      const float* a = sm + d * PT_PER_DIR;
       const double n_tex = a[PT_M_TEX] / N + eps, n_rig = a[PT_M_RIG] / N + eps, n_dyn = a[PT_M_DYN] / N + eps,
                    n_vo = a[PT_M_VO] / N + eps;
       l_dp += (a[PT_L1_DEPTH] / (3.0 * N)) / n_tex;
       l_fp += (a[PT_L1_RIG] / (3.0 * N)) / n_rig + 2.0 * (a[PT_L1_DYN] / (3.0 * N)) / n_dyn;
-      l_fs += (sm[s][SUM_SSIM + d] / (3.0 * N)) / n_vo;
-      l_sm += (sm[s][SUM_FS + 2 * d] / (2.0 * H * (W - 2.0)) + sm[s][SUM_FS + 2 * d + 1] / (2.0 * (H - 2.0) * W)) / 2.0;
+      l_fs += (sm[SUM_SSIM + d] / (3.0 * N)) / n_vo;
+      l_sm += (sm[SUM_FS + 2 * d] / (2.0 * H * (W - 2.0)) + sm[SUM_FS + 2 * d + 1] / (2.0 * (H - 2.0) * W)) / 2.0;
       cf[d * CF_PER_DIR + CF_DEPTH] = static_cast<float>(1.0 / (3.0 * N * n_tex));
       cf[d * CF_PER_DIR + CF_RIG] = static_cast<float>(1.0 / (3.0 * N * n_rig));
       cf[d * CF_PER_DIR + CF_DYN] = static_cast<float>(2.0 / (3.0 * N * n_dyn));
@@ -626,14 +648,14 @@ __global__ void __launch_bounds__(256) k_geom_finalize_fwd(GeomDev D, const floa
         l_epi += a[PT_EPI] / N;
       }
     }
-    const double n_inv = sm[s][PT_INV] / N + eps;
-    l_fc += (sm[s][PT_CONSIS] / (2.0 * N)) / n_inv;
+    const double n_inv = sm[PT_INV] / N + eps;
+    l_fc += (sm[PT_CONSIS] / (2.0 * N)) / n_inv;
     cf[CF_CONSIS] = static_cast<float>(1.0 / (2.0 * N * n_inv));
   }
   double l_ds = 0;
   {
     const double H = D.H[0], W = D.W[0];
-    for (int f = 0; f < 3; ++f) l_ds += ds[f][0] / (H * (W - 1.0)) + ds[f][1] / ((H - 1.0) * W);
+    for (int f = 0; f < 3; ++f) l_ds += dsum[(f * B + b) * 2] / (H * (W - 1.0)) + dsum[(f * B + b) * 2 + 1] / ((H - 1.0) * W);
   }
   losses[DFE_LOSS_DEPTH_PIXEL * B + b] = static_cast<float>(l_dp);
   losses[DFE_LOSS_DEPTH_SMOOTH * B + b] = static_cast<float>(l_ds);
@@ -710,8 +732,9 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     jobs.n = 0; jobs.planes = L.B * 3; jobs.inH = a->H; jobs.inW = a->W;
     int max_out = 0;
     for (int s = 1; s < L.S; ++s) {
-      for (int f = 0; f < 3; ++f) jobs.j[jobs.n++] = PyrJob{a->img[f], const_cast<float*>(D.pyr[f][s]), L.H[s], L.W[s], 0};
-      for (int d = 0; d < 2; ++d) jobs.j[jobs.n++] = PyrJob{a->img[d == 0 ? 0 : 2], const_cast<float*>(D.area[d][s]), L.H[s], L.W[s], 1};
+      for (int f = 0; f < 3; ++f)
+        jobs.j[jobs.n++] = PyrJob{a->img[f], const_cast<float*>(D.pyr[f][s]),
+                                  f == 1 ? nullptr : const_cast<float*>(D.area[f == 0 ? 0 : 1][s]), L.H[s], L.W[s]};
       if (L.N[s] > max_out) max_out = L.N[s];
     }
     dim3 g(static_cast<unsigned>((static_cast<long>(jobs.planes) * max_out + 255) / 256), jobs.n);
@@ -761,8 +784,10 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   }
   DFE_LAUNCH_CHECK();
   DFE_MARK();
-  k_geom_finalize_fwd<<<L.B, 256, 0, st>>>(D, ws + L.o_part, ws + L.o_spart, ws + L.o_fpart, ws + L.o_dpart, L.dsm_units,
-                                         ws + L.o_sums, ws + L.o_coef, ws + L.o_dsum, a->losses);
+  k_geom_reduce_fwd<<<dim3(L.S + 1, L.B), 256, 0, st>>>(D, ws + L.o_part, ws + L.o_spart, ws + L.o_fpart, ws + L.o_dpart,
+                                                     L.dsm_units, ws + L.o_sums, ws + L.o_dsum);
+  DFE_LAUNCH_CHECK();
+  k_geom_assemble_fwd<<<(L.B + 63) / 64, 64, 0, st>>>(D, ws + L.o_sums, ws + L.o_dsum, ws + L.o_coef, a->losses);
   DFE_LAUNCH_CHECK();
   DFE_MARK();
 #undef DFE_MARK
