@@ -6,7 +6,6 @@
 namespace dfe {
 
 constexpr int GS_BLOCK = 256;   // threads per block of the pointwise kernels (1 pixel / thread)
-constexpr int GS_TX = 32, GS_TY = 8;  // SSIM tile (backward)
 constexpr int RS_COLS = 62, RS_ROWS = 8;   // rolling SSIM forward: valid columns per wave (64 lanes - 2 halo), rows per wave
                                             // (measured: rows 4/6/8/16/32 -> 24.2/22.8/21.9/24.0/30.3 us; LDS tile kernel 33 us)
 constexpr int DSM_ROWS = 8;                 // rolling disparity-smoothness kernels: full-res rows per wave (62 valid columns)
@@ -36,7 +35,6 @@ struct GeomLayout {
   int H[DFE_MAX_SCALES], W[DFE_MAX_SCALES], N[DFE_MAX_SCALES];
   long off_px[DFE_MAX_SCALES + 1];   // prefix of N (per single image plane)
   int nblk[DFE_MAX_SCALES], blk_start[DFE_MAX_SCALES + 1];      // pointwise blocks per image
-  int ntile[DFE_MAX_SCALES], tile_start[DFE_MAX_SCALES + 1], tiles_x[DFE_MAX_SCALES];
   int nblk0;                          // full-resolution blocks (disp smoothness)
   int roll_start[DFE_MAX_SCALES + 1], roll_strips[DFE_MAX_SCALES];   // rolling-SSIM units (strip x row block) per scale
   int rollb_start[DFE_MAX_SCALES + 1], rollb_strips[DFE_MAX_SCALES]; // same for the backward kernel
@@ -55,7 +53,7 @@ struct GeomDev {
   int B, S, ac, mode;
   float alpha, beta;
   int H[DFE_MAX_SCALES], W[DFE_MAX_SCALES], N[DFE_MAX_SCALES];
-  int blk_start[DFE_MAX_SCALES + 1], tile_start[DFE_MAX_SCALES + 1], tiles_x[DFE_MAX_SCALES];
+  int blk_start[DFE_MAX_SCALES + 1];
   int vblk_start[DFE_MAX_SCALES + 1];      // block table of the V-pixels-per-thread kernels
   int roll_start[DFE_MAX_SCALES + 1], roll_strips[DFE_MAX_SCALES];   // rolling-SSIM unit table
   int rollb_start[DFE_MAX_SCALES + 1], rollb_strips[DFE_MAX_SCALES];

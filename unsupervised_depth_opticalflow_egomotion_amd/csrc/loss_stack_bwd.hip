@@ -643,8 +643,7 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     for (int f = 0; f < 3; ++f) G.gdisp[f][s] = (s < L.S) ? a->grad_disp[f][s] : nullptr;
     for (int d = 0; d < 2; ++d) G.gflow[d][s] = (s < L.S) ? a->grad_flow[d][s] : nullptr;
   }
-  const unsigned nblk_total = L.blk_start[L.S], ntile_total = L.tile_start[L.S];
-  (void)ntile_total;
+  const unsigned nblk_total = L.blk_start[L.S];
   int seg = 0;
 #define DFE_MARK() do { if (ev) (void)hipEventRecord(ev[++seg], st); } while (0)
   if (ev) (void)hipEventRecord(ev[0], st);

@@ -24,7 +24,7 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
   if (a->B <= 0 || a->H < 8 || a->W < 8 || a->num_scales <= 0 || a->num_scales > DFE_MAX_SCALES) return DFE_ERR_DIMS;
   if (a->mode != 0 && a->mode != 1) return DFE_ERR_UNSUPPORTED;
   L->B = a->B; L->S = a->num_scales;
-  L->off_px[0] = 0; L->blk_start[0] = 0; L->tile_start[0] = 0;
+  L->off_px[0] = 0; L->blk_start[0] = 0;
   for (int s = 0; s < L->S; ++s) {
     // int(H / 2**s) as the reference computes it (model_geometry.py:70)
     L->H[s] = static_cast<int>(static_cast<double>(a->H) / static_cast<double>(1 << s));
@@ -34,9 +34,6 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
     L->off_px[s + 1] = L->off_px[s] + L->N[s];
     L->nblk[s] = (L->N[s] + GS_BLOCK - 1) / GS_BLOCK;
     L->blk_start[s + 1] = L->blk_start[s] + L->nblk[s];
-    L->tiles_x[s] = (L->W[s] + GS_TX - 1) / GS_TX;
-    L->ntile[s] = L->tiles_x[s] * ((L->H[s] + GS_TY - 1) / GS_TY);
-    L->tile_start[s + 1] = L->tile_start[s] + L->ntile[s];
   }
   L->nblk0 = L->nblk[0];
   // Measured at B=4, 256x832 (MI355X): V=1 48 us, V=2 62 us, V=4 83 us; 128-thread blocks 51 us.  Fatter threads
@@ -59,7 +56,7 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
   L->vblk_start[0] = 0;
   for (int s = 0; s < L->S; ++s) L->vblk_start[s + 1] = L->vblk_start[s] + (L->N[s] + GS_BLOCK * L->V - 1) / (GS_BLOCK * L->V);
   const long B = L->B, S = L->S, sumN = L->off_px[S];
-  const long nblk_total = L->blk_start[S], ntile_total = L->tile_start[S];
+  const long nblk_total = L->blk_start[S];
   L->pyr_plane = B * 3 * (sumN - L->N[0]);
   long o = 0;
   L->o_cams = o; o = align4(o + B * 2 * S * static_cast<long>(sizeof(Camera) / sizeof(float)));
@@ -69,7 +66,7 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
   L->o_mask = o; o = align4(o + (B * sumN + 3) / 4);
   L->o_yw = o; o = align4(o + 2 * B * 3 * sumN);
   L->o_part = o; o = align4(o + B * nblk_total * PT_COUNT);
-  L->o_spart = o; o = align4(o + B * 2 * (ntile_total > L->roll_start[S] ? ntile_total : static_cast<long>(L->roll_start[S])));
+  L->o_spart = o; o = align4(o + B * 2 * static_cast<long>(L->roll_start[S]));
   L->o_fpart = o; o = align4(o + 2 * B * (nblk_total > L->fs_start[S] ? nblk_total : static_cast<long>(L->fs_start[S])) * 2);
   L->o_dpart = o; o = align4(o + 3 * B * static_cast<long>(L->dsm_units > L->nblk0 ? L->dsm_units : L->nblk0) * 2);
   L->o_sums = o; o = align4(o + B * S * SUM_COUNT);
@@ -85,9 +82,9 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
 void geom_dev(const dfe_geom_args* a, const GeomLayout& L, GeomDev* D) {
   float* ws = a->workspace;
   D->B = L.B; D->S = L.S; D->ac = a->align_corners; D->mode = a->mode; D->alpha = a->alpha; D->beta = a->beta;
-  for (int s = 0; s <= L.S; ++s) { D->blk_start[s] = L.blk_start[s]; D->tile_start[s] = L.tile_start[s]; D->vblk_start[s] = L.vblk_start[s]; D->roll_start[s] = L.roll_start[s]; D->rollb_start[s] = L.rollb_start[s]; D->fs_start[s] = L.fs_start[s]; }
+  for (int s = 0; s <= L.S; ++s) { D->blk_start[s] = L.blk_start[s]; D->vblk_start[s] = L.vblk_start[s]; D->roll_start[s] = L.roll_start[s]; D->rollb_start[s] = L.rollb_start[s]; D->fs_start[s] = L.fs_start[s]; }
   for (int s = 0; s < L.S; ++s) {
-    D->H[s] = L.H[s]; D->W[s] = L.W[s]; D->N[s] = L.N[s]; D->tiles_x[s] = L.tiles_x[s]; D->roll_strips[s] = L.roll_strips[s]; D->rollb_strips[s] = L.rollb_strips[s];
+    D->H[s] = L.H[s]; D->W[s] = L.W[s]; D->N[s] = L.N[s]; D->roll_strips[s] = L.roll_strips[s]; D->rollb_strips[s] = L.rollb_strips[s];
     const long lvl = static_cast<long>(L.B) * 3 * (L.off_px[s] - L.N[0]);   // offset of level s (>=1) in a frame's block
     for (int f = 0; f < 3; ++f) {
       D->pyr[f][s] = (s == 0) ? a->img[f] : ws + L.o_pyr + f * L.pyr_plane + lvl;
@@ -742,7 +739,6 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     DFE_LAUNCH_CHECK();
   }
   DFE_MARK();
-  const unsigned nblk_total = L.blk_start[L.S];
   if (a->mode == 1) {
     // Model_depth: rigid recon + validity*texture mask + masked L1 only (no flows, no SSIM, no flow terms)
     k_depth_point_fwd<<<dim3(L.vblk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
