@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--width", type=int, default=832)
     ap.add_argument("--scales", type=int, default=3)
     ap.add_argument("--workload", default="auto", choices=["auto", "train_step", "loss_stack"])
+    ap.add_argument("--mode", default="geom", choices=["geom", "depth"], help="train_step model: geom = configs[2] (default, the metric's configuration), depth = configs[1]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--miopen-benchmark", type=int, default=0, help="torch.backends.cudnn.benchmark (MIOpen exhaustive find)")
@@ -128,8 +129,9 @@ class TrainStepWorkload:
         from unsupervised_depth_opticalflow_egomotion_amd.train_step import make_cfg
         self.cfg = make_cfg(num_scales=args.scales, img_hw=(args.height, args.width))
         torch.manual_seed(1234)           # identical initial weights on every rank
-        self.model = get_model("geom")(self.cfg).to(dev)
-        if os.environ.get("DFE_CHANNELS_LAST", "0") == "1":
+        self.mode = getattr(args, "mode", "geom")
+        self.model = get_model(self.mode)(self.cfg).to(dev)
+        if self.mode == "geom" and os.environ.get("DFE_CHANNELS_LAST", "0") == "1":
             self.model.use_channels_last(True)
         self.model.train()
         self.model = ddp.wrap(self.model, dev)
@@ -167,11 +169,12 @@ class TrainStepWorkload:
 
         cfg = self.cfg
         torch.manual_seed(1234)
-        model = get_model("geom")(cfg)
-        pw = OraclePWC()
-        pw.load_state_dict(model.pwc_model.state_dict())
-        pw.corr = pw.corr_naive
-        model.pwc_model = pw
+        model = get_model(self.mode)(cfg)
+        if self.mode == "geom":
+            pw = OraclePWC()
+            pw.load_state_dict(model.pwc_model.state_dict())
+            pw.corr = pw.corr_naive
+            model.pwc_model = pw
         model.train()
         ddp.freeze_unused(model)
         opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=cfg.lr)
@@ -182,8 +185,13 @@ class TrainStepWorkload:
         def run():
             opt.zero_grad(set_to_none=True)
             img_l, img, img_r = images[:, :, :h], images[:, :, h:2 * h], images[:, :, 2 * h:]
-            dl, dt, dr, pose, fb, ff = model.run_networks(img_l, img, img_r)
-            lp, _ = oracle.geom_losses(img_l, img, img_r, dl, dt, dr, pose, fb, ff, k_ms[:, 0], ki_ms[:, 0])
+            if self.mode == "geom":
+                dl, dt, dr, pose, fb, ff = model.run_networks(img_l, img, img_r)
+                lp, _ = oracle.geom_losses(img_l, img, img_r, dl, dt, dr, pose, fb, ff, k_ms[:, 0], ki_ms[:, 0])
+            else:
+                dl, dt, dr = model.depth_net(img_l), model.depth_net(img), model.depth_net(img_r)
+                pose = model.pose_net(torch.cat([img_l, img, img_r], 1))
+                lp, _ = oracle.depth_losses(img_l, img, img_r, dl, dt, dr, pose, k_ms[:, 0])
             total_loss(lp, cfg).backward()
             opt.step()
         return run
@@ -286,11 +294,12 @@ def main():
     pairs_per_step = 2 * args.batch * world
     value = pairs_per_step * args.steps / dt
     out = {
-        "metric": "frame-pairs/sec (832x256, geom mode)", "value": round(value, 2), "unit": "frame-pairs/s",
+        "metric": "frame-pairs/sec (832x256, %s mode)" % (args.mode if wl.name == "train_step" else "geom"), "value": round(value, 2), "unit": "frame-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": wl.name + ": mode=geom, %dx%d, batch=%d/GPU, num_scales=%d, fwd+bwd%s" % (
-            args.width, args.height, args.batch, args.scales, "+Adam" if wl.name == "train_step" else ""),
+        "config": {"workload": wl.name + ": mode=%s, %dx%d, batch=%d/GPU, num_scales=%d, fwd+bwd%s" % (
+            args.mode if wl.name == "train_step" else "geom", args.width, args.height, args.batch, args.scales,
+            "+Adam" if wl.name == "train_step" else ""),
             "global_batch": args.batch * world, "parallelism": "dp%d" % world},
     }
     if rank == 0:

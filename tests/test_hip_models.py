@@ -195,3 +195,20 @@ def test_train_step_runs_and_learns():
     assert all(p.grad is None or torch.isfinite(p.grad).all() for p in model.parameters())
     assert model.depth_net.encoder.encoder.fc.weight.grad is None
     assert losses[-1] < losses[0], losses
+
+
+def test_train_cli_smoke(tmp_path):
+    """train.py with the reference's flags: 2 iterations, checkpoint written in the reference's format, resume."""
+    import subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(repo, "train.py"), "-c", os.path.join(repo, "config", "kitti_geom.yaml"),
+            "--mode", "depth", "--batch_size", "1", "--log_interval", "1", "--save_interval", "2",
+            "--model_dir", str(tmp_path)]
+    out = subprocess.run(base + ["--num_iterations", "2"], capture_output=True, text=True, cwd=repo, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "iter      1 total" in out.stdout
+    ck = torch.load(os.path.join(str(tmp_path), "depth", "last.pth"), map_location="cpu")
+    assert set(ck.keys()) == {"iteration", "model_state_dict", "optimizer_state_dict"} and ck["iteration"] == 2
+    assert any(k.startswith("depth_net.encoder.encoder.layer1.0.conv1") for k in ck["model_state_dict"])
+    out = subprocess.run(base + ["--num_iterations", "3", "--resume"], capture_output=True, text=True, cwd=repo, timeout=600)
+    assert out.returncode == 0 and "iter      2 total" in out.stdout, out.stderr[-2000:]
