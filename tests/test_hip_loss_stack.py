@@ -205,3 +205,46 @@ def test_fused_stack_argument_errors():
     with pytest.raises(DfeError):        # CPU tensors never fall back
         geom_loss_stack(il.cpu(), it.cpu(), ir.cpu(), [d.cpu() for d in disps[0]], [d.cpu() for d in disps[1]],
                         [d.cpu() for d in disps[2]], pose.cpu(), [f.cpu() for f in fb], [f.cpu() for f in ff], K.cpu(), Ki.cpu())
+
+
+def test_full_size_properties():
+    """BASELINE size (B=4, 256x832, S=3), properties that need no oracle:
+    (1) batch-shard equivalence: the stack on samples [0,1] and [2,3] separately gives bit-identical per-sample
+        losses and gradients to the full batch (what makes data-parallel sharding exact, SURVEY.md 8(e));
+    (2) the backward is linear in the upstream gradient: bwd(g1) + bwd(g2) == bwd(g1 + g2);
+    (3) every mask is {0,1} and fwd_mask == valid*occ*dyna, texture-gated mask <= fwd_mask."""
+    from unsupervised_depth_opticalflow_egomotion_amd.loss_stack import geom_loss_stack
+    inp = synthetic.make_loss_stack_inputs(4, 256, 832, 3, seed=1234)
+
+    def run(sl, gvec=None):
+        disps = [[G(a[sl], True) for a in lst] for lst in inp.disps]
+        pose, fb, ff = G(inp.pose[sl], True), [G(a[sl], True) for a in inp.flows_bwd], [G(a[sl], True) for a in inp.flows_fwd]
+        il, it, ir = [G(a[sl]) for a in inp.imgs]
+        lp, masks = geom_loss_stack(il, it, ir, disps[0], disps[1], disps[2], pose, fb, ff, G(inp.K[sl]), G(inp.K_inv[sl]),
+                                    num_scales=3, return_masks=True)
+        L = torch.stack([lp[k] for k in sorted(lp)])            # [8, B]
+        gv = torch.ones_like(L) if gvec is None else gvec
+        (L * gv).sum().backward()
+        return L.detach(), masks, disps, pose, fb, ff
+    full = run(slice(0, 4))
+    lo, hi = run(slice(0, 2)), run(slice(2, 4))
+    assert torch.equal(full[0][:, :2], lo[0]) and torch.equal(full[0][:, 2:], hi[0])
+    assert torch.equal(full[3].grad[:2], lo[3].grad) and torch.equal(full[3].grad[2:], hi[3].grad)
+    for s in range(3):
+        assert torch.equal(full[2][1][s].grad[:2], lo[2][1][s].grad) and torch.equal(full[5][s].grad[2:], hi[5][s].grad)
+    # linearity in the upstream gradient
+    g1 = torch.rand(8, 4, device=dev())
+    g2 = torch.rand(8, 4, device=dev())
+    a, b, c = run(slice(0, 4), g1), run(slice(0, 4), g2), run(slice(0, 4), g1 + g2)
+    for s in range(3):
+        ref = c[4][s].grad
+        assert float(((a[4][s].grad + b[4][s].grad) - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-9
+        ref = c[2][1][s].grad
+        assert float(((a[2][1][s].grad + b[2][1][s].grad) - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-9
+    assert float(((a[3].grad + b[3].grad) - c[3].grad).abs().max()) <= 1e-4 * float(c[3].grad.abs().max())
+    # mask algebra
+    m = full[1]
+    for s in range(3):
+        for k in m:
+            u = torch.unique(m[k][s])
+            assert set(u.tolist()) <= {0.0, 1.0}, k
