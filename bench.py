@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--scales", type=int, default=3)
     ap.add_argument("--workload", default="auto", choices=["auto", "train_step", "loss_stack"])
     ap.add_argument("--mode", default="geom", choices=["geom", "depth"], help="train_step model: geom = configs[2] (default, the metric's configuration), depth = configs[1]")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for single-GPU functional tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--miopen-benchmark", type=int, default=0, help="torch.backends.cudnn.benchmark (MIOpen exhaustive find)")
@@ -46,11 +47,16 @@ def init_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("DFE_BENCH_ALL_ON_DEVICE0") == "1":   # functional test of the N>1 path on a 1-GPU box
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
     return world, rank, local
 
 

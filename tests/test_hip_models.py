@@ -212,3 +212,21 @@ def test_train_cli_smoke(tmp_path):
     assert any(k.startswith("depth_net.encoder.encoder.layer1.0.conv1") for k in ck["model_state_dict"])
     out = subprocess.run(base + ["--num_iterations", "3", "--resume"], capture_output=True, text=True, cwd=repo, timeout=600)
     assert out.returncode == 0 and "iter      2 total" in out.stdout, out.stderr[-2000:]
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """The N>1 path of bench.py (one process per rank, DDP, barrier + max-over-ranks timing, rank-0 JSON) run
+    functionally with 2 ranks sharing this box's single GPU over gloo (RCCL refuses two ranks on one device)."""
+    import json, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DFE_BENCH_ALL_ON_DEVICE0="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--backend", "gloo", "--mode", "depth"]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=repo, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # exactly one JSON line, from rank 0
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["config"]["global_batch"] == 8
+    assert j["value"] > 0 and "roofline" in j and "cpu_baseline" not in j   # CPU baseline only at N=1
