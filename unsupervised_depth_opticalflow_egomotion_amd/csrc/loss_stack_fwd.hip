@@ -679,7 +679,7 @@ static int check_args(const dfe_geom_args* a, const GeomLayout& L, bool bwd) {
   if (a->mode == 0) for (int d = 0; d < 2; ++d) for (int s = 0; s < L.S; ++s) if (!a->flow[d][s]) return DFE_ERR_NULL;
   if (!bwd && !a->losses) return DFE_ERR_NULL;
   if (bwd && !a->grad_losses) return DFE_ERR_NULL;
-  if (a->B > 32767) return DFE_ERR_DIMS;
+  if (a->B > 21845) return DFE_ERR_DIMS;   // grid.y carries up to 3*B (frames x samples) <= 65535
   return DFE_OK;
 }
 
