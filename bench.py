@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--width", type=int, default=832)
     ap.add_argument("--scales", type=int, default=3)
     ap.add_argument("--workload", default="auto", choices=["auto", "train_step", "loss_stack"])
-    ap.add_argument("--mode", default="geom", choices=["geom", "depth"], help="train_step model: geom = configs[2] (default, the metric's configuration), depth = configs[1]")
+    ap.add_argument("--mode", default="geom", choices=["geom", "depth", "flow"], help="train_step model: geom = configs[2] (default, the metric's configuration), depth = configs[1], flow = configs[0]")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for single-GPU functional tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -133,9 +133,9 @@ class TrainStepWorkload:
         from unsupervised_depth_opticalflow_egomotion_amd import ddp, synthetic
         from unsupervised_depth_opticalflow_egomotion_amd.models import get_model
         from unsupervised_depth_opticalflow_egomotion_amd.train_step import make_cfg
-        self.cfg = make_cfg(num_scales=args.scales, img_hw=(args.height, args.width))
-        torch.manual_seed(1234)           # identical initial weights on every rank
         self.mode = getattr(args, "mode", "geom")
+        self.cfg = make_cfg(num_scales=args.scales, img_hw=(args.height, args.width), mode=self.mode)
+        torch.manual_seed(1234)           # identical initial weights on every rank
         self.model = get_model(self.mode)(self.cfg).to(dev)
         if self.mode == "geom" and os.environ.get("DFE_CHANNELS_LAST", "0") == "1":
             self.model.use_channels_last(True)
@@ -176,7 +176,7 @@ class TrainStepWorkload:
         cfg = self.cfg
         torch.manual_seed(1234)
         model = get_model(self.mode)(cfg)
-        if self.mode == "geom":
+        if self.mode in ("geom", "flow"):
             pw = OraclePWC()
             pw.load_state_dict(model.pwc_model.state_dict())
             pw.corr = pw.corr_naive
@@ -194,6 +194,10 @@ class TrainStepWorkload:
             if self.mode == "geom":
                 dl, dt, dr, pose, fb, ff = model.run_networks(img_l, img, img_r)
                 lp, _ = oracle.geom_losses(img_l, img, img_r, dl, dt, dr, pose, fb, ff, k_ms[:, 0], ki_ms[:, 0])
+            elif self.mode == "flow":
+                f_l, f_t, f_r = model.fpyramid(img_l), model.fpyramid(img), model.fpyramid(img_r)
+                hw = [img.shape[2], img.shape[3]]
+                lp, _ = oracle.flow_losses(img_l, img, img_r, model.pwc_model(f_t, f_l, hw), model.pwc_model(f_t, f_r, hw))
             else:
                 dl, dt, dr = model.depth_net(img_l), model.depth_net(img), model.depth_net(img_r)
                 pose = model.pose_net(torch.cat([img_l, img, img_r], 1))

@@ -128,7 +128,9 @@ typedef struct dfe_geom_args {
   int num_scales;            /* S <= DFE_MAX_SCALES; scale s is int(H/2^s) x int(W/2^s) */
   int align_corners;
   int mode;                  /* 0 = Model_geometry loss stack; 1 = Model_depth loss stack (model_depth.py:272-337:
-                                depth pixel + smoothness terms; flow / K_inv pointers are ignored) */
+                                depth pixel + smoothness terms; flow / K_inv pointers are ignored); 2 = Model_flow
+                                loss stack (model_flow.py:209-261: box-mean pyramids, soft occlusion weights;
+                                disp / pose / K / K_inv pointers are ignored) */
   float alpha, beta;         /* flow_consist_alpha / flow_consist_beta (model_geometry.py:25-26) */
   const float* img[3];       /* left, target, right frames [B,3,H,W] */
   const float* disp[3][DFE_MAX_SCALES]; /* depth_net outputs per frame (l,t,r) and scale [B,1,Hs,Ws] */

@@ -38,7 +38,7 @@ def test_error_strings_and_argument_checks_without_gpu():
     assert lib.dfe_geom_workspace_floats(ctypes.byref(a)) > 0
     a.num_scales = 9
     assert lib.dfe_geom_workspace_floats(ctypes.byref(a)) == -2
-    a.num_scales, a.mode = 3, 2      # modes 0 (geom) and 1 (depth) exist; the flow-only stack has no fused mode
+    a.num_scales, a.mode = 3, 3      # modes 0 (geom), 1 (depth), 2 (flow) exist
     assert lib.dfe_geom_workspace_floats(ctypes.byref(a)) == -4
 
 

@@ -121,7 +121,10 @@ def test_model_depth_and_flow_loss_stacks(golden_dir):
     mf = Model_flow.__new__(Model_flow); torch.nn.Module.__init__(mf); mf.num_scales = 3
     fb, ff = [G(a, True) for a in inp.flows_bwd], [G(a, True) for a in inp.flows_fwd]
     il, it, ir = [G(a) for a in inp.imgs]
+    lp2, _ = mf.loss_stack_per_op(il, it, ir, [f.detach() for f in fb], [f.detach() for f in ff])
     lp, _ = mf.loss_stack(il, it, ir, fb, ff)
+    for k in lp:
+        np.testing.assert_allclose(N(lp[k]), N(lp2[k]), rtol=2e-4, atol=1e-6, err_msg=k)
     (0.15 * lp["loss_flow_pixel"].mean() + 0.85 * lp["loss_flow_ssim"].mean() + 10 * lp["loss_flow_smooth"].mean()
      + 0.01 * lp["loss_flow_consis"].mean()).backward()
     for k, v in lp.items():

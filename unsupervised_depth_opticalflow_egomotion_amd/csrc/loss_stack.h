@@ -43,6 +43,7 @@ struct GeomLayout {
   int V;                              // pixels per thread of k_geom_point_fwd (4 when every W_s % 4 == 0, else 1)
   int vblk_start[DFE_MAX_SCALES + 1]; // its block table
   // workspace offsets in floats
+  long o_wgt;       // mode 2: soft occlusion weights, [scale][2][B][N_s] floats
   long o_cams, o_epi, o_pyr, o_area, o_mask, o_yw, o_part, o_spart, o_fpart, o_dpart, o_sums, o_coef, o_dsum,
       o_gw, o_gup, o_bpart, total;
   long pyr_plane;   // floats of one frame's bilinear pyramid levels >= 1 (B*3*sum_{s>=1} N_s)
@@ -66,6 +67,7 @@ struct GeomDev {
   const Epi* epi;                          // [b*2+d]
   unsigned char* mask[DFE_MAX_SCALES];     // [B][N_s]
   float* yw[DFE_MAX_SCALES];               // [2][B][3][N_s] masked warped images
+  float* wgt[DFE_MAX_SCALES];              // mode 2: [2][B][N_s] soft occlusion weights
 };
 
 int geom_layout(const dfe_geom_args* a, GeomLayout* L);
@@ -77,17 +79,24 @@ struct RowRaw { float a[3], b[3]; };   // masked target / warped values of one r
 
 // issue the 7 loads of one row (returns zeros outside the image); kept separate from the DPP sums so that
 // the loads of rows y+2.. are in flight while row y is reduced (software prefetch: ~2 waves per SIMD only)
+// The per-pixel SSIM weight is either a bit test on the mask pack (modes 0/1: valid & occ of this direction) or a
+// float soft weight (mode 2, Model_flow): `mk` then points at the float plane and `need` is 0.
+__device__ __forceinline__ float ssim_weight_at(const unsigned char* __restrict__ mk, unsigned need, int q) {
+  if (need == 0u) return reinterpret_cast<const float*>(mk)[q];
+  return ((mk[q] & need) == need) ? 1.0f : 0.0f;
+}
+
 __device__ __forceinline__ RowRaw ssim_load(const float* __restrict__ it, const float* __restrict__ yw,
                                             const unsigned char* __restrict__ mk, unsigned need, int y, int x,
                                             int H, int W, int N) {
   RowRaw r;
   const bool in = y >= 0 && y < H && x >= 0 && x < W;
   const int q = in ? y * W + x : 0;
-  const unsigned m = mk[q];
+  const float wq = ssim_weight_at(mk, need, q);
   float ta[3], tb[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) { ta[c] = it[q + c * N]; tb[c] = yw[q + c * N]; }
-  const float vo = (in && (m & need) == need) ? 1.0f : 0.0f;
+  const float vo = in ? wq : 0.0f;
 #pragma unroll
   for (int c = 0; c < 3; ++c) { r.a[c] = in ? ta[c] * vo : 0.0f; r.b[c] = in ? tb[c] : 0.0f; }
   return r;

@@ -75,8 +75,9 @@ __global__ void __launch_bounds__(64) k_geom_ssim_bwd_roll(GeomDev D, GeomBwd G)
   const int x = strip * RSB_COLS + static_cast<int>(threadIdx.x) - 2, y0 = rb * RSB_ROWS, yend = min(y0 + RSB_ROWS, H);
   const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
   const float* yw = D.yw[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
-  const unsigned char* mk = D.mask[s] + static_cast<long>(b) * N;
-  const unsigned need = (DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD) << d;
+  const unsigned char* mk = D.mode == 2 ? reinterpret_cast<const unsigned char*>(D.wgt[s] + (static_cast<long>(d) * D.B + b) * N)
+                                        : D.mask[s] + static_cast<long>(b) * N;
+  const unsigned need = D.mode == 2 ? 0u : (DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD) << d;
   float* gw = G.gw[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
   const float gscale = -0.5f * G.gl[DFE_LOSS_FLOW_SSIM * D.B + b] *
                        G.coef[(static_cast<long>(b) * D.S + s) * CF_COUNT + d * CF_PER_DIR + CF_VO];
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(64) k_geom_ssim_bwd_roll(GeomDev D, GeomBwd G)
       CoefH cc = ssim_coef_hsum(hc, hd, ha, gscale, col_in && g + 1 < H);                   // row g+1
       if (lane_ok && g < yend) {
         const int q = g * W + x;
-        ssim_grad_store(ca, cb, cc, ctr, ((mk[q] & need) == need) ? 1.0f : 0.0f, gw, q, N);
+        ssim_grad_store(ca, cb, cc, ctr, ssim_weight_at(mk, need, q), gw, q, N);
       }
       ca = cc; nx = pf;   // now: cb = row g, ca = row g+1
     }
@@ -113,7 +114,7 @@ __global__ void __launch_bounds__(64) k_geom_ssim_bwd_roll(GeomDev D, GeomBwd G)
       CoefH cc = ssim_coef_hsum(hd, ha, hb, gscale, col_in && g + 2 < H);                   // row g+2
       if (lane_ok && g + 1 < yend) {
         const int q = (g + 1) * W + x;
-        ssim_grad_store(cb, ca, cc, ctr, ((mk[q] & need) == need) ? 1.0f : 0.0f, gw, q, N);
+        ssim_grad_store(cb, ca, cc, ctr, ssim_weight_at(mk, need, q), gw, q, N);
       }
       cb = cc; nx = pf;   // now: ca = row g+1, cb = row g+2
     }
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(64) k_geom_ssim_bwd_roll(GeomDev D, GeomBwd G)
       CoefH cc = ssim_coef_hsum(ha, hb, hc, gscale, col_in && g + 3 < H);                   // row g+3
       if (lane_ok && g + 2 < yend) {
         const int q = (g + 2) * W + x;
-        ssim_grad_store(ca, cb, cc, ctr, ((mk[q] & need) == need) ? 1.0f : 0.0f, gw, q, N);
+        ssim_grad_store(ca, cb, cc, ctr, ssim_weight_at(mk, need, q), gw, q, N);
       }
       // rotate for the next iteration (gradient row g+3): row sums hc=g+3?? -> rename below
       ca = cb; cb = cc; nx = pf;    // ca = row g+2, cb = row g+3
@@ -263,6 +264,66 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomBwd 
     if (G.gdisp[1][s]) G.gdisp[1][s][o1] = gdisp;
   }
   block_sum<PB_COUNT>(acc, red, G.bpart + (static_cast<long>(b) * nblk_total + blk) * PB_COUNT);
+}
+
+// ---------------------------------------------------------------------- flow-only pointwise backward
+// Model_flow: gradient wrt the flows of the weighted L1 (1-channel mean diff), the SSIM term (gw) and the flow
+// consistency (forward flow only); the soft weights are detached (model_flow.py:124).
+__global__ void __launch_bounds__(GS_BLOCK) k_flow_point_bwd(GeomDev D, GeomBwd G) {
+  const unsigned nblk_total = D.blk_start[D.S];
+  const unsigned blk = xcd_swizzle(blockIdx.x, nblk_total);
+  const int b = blockIdx.y, B = D.B;
+  const int s = find_scale(D.blk_start, D.S, blk);
+  const int H = D.H[s], W = D.W[s], N = D.N[s];
+  const int p = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
+  if (p >= N) return;
+  const int py = p / W, px = p - py * W;
+  const long o3 = static_cast<long>(b) * 3 * N + p, o2 = static_cast<long>(b) * 2 * N + p;
+  const float* it = D.pyr[1][s];
+  const float im[3] = {it[o3], it[o3 + N], it[o3 + 2 * N]};
+  const float* cf = G.coef + (static_cast<long>(b) * D.S + s) * CF_COUNT;
+  const float g_fp = G.gl[DFE_LOSS_FLOW_PIXEL * B + b], g_fc = G.gl[DFE_LOSS_FLOW_CONSIS * B + b];
+  float fu[2], fv[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) { fu[d] = D.flow[d][s][o2]; fv[d] = D.flow[d][s][o2 + N]; }
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const float wgt = (D.wgt[s] + (static_cast<long>(d) * B + b) * N)[p];
+    float gfu = 0.0f, gfv = 0.0f;
+    float ix, iy;
+    flow_coords(px, py, fu[d], fv[d], H, W, D.ac, ix, iy);
+    Tap t = make_tap(ix, iy, H, W);
+    const float keep = (tap_cover(t) < 0.9999f) ? 0.0f : 1.0f;
+    if (keep != 0.0f) {
+      const float* src = D.pyr[d == 0 ? 0 : 2][s] + static_cast<long>(b) * 3 * N;
+      const float* gw = G.gw[s] + (static_cast<long>(d) * B + b) * 3 * N + p;
+      const float l1c = g_fp * wgt * cf[d * CF_PER_DIR + CF_RIG];
+      float gix = 0.0f, giy = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        Corners q = load_corners(src + static_cast<long>(c) * N, t, W, H);
+        float dx, dy;
+        interp_grad(q, t, dx, dy);
+        const float g = gw[static_cast<long>(c) * N] + sgn(interp(q, t) - im[c]) * l1c;
+        gix += g * dx; giy += g * dy;
+      }
+      gfu = gix * flow_coord_scale(W, D.ac);
+      gfv = giy * flow_coord_scale(H, D.ac);
+    }
+    if (d == 1) {
+      const float k = (1.0f - wgt) * cf[CF_CONSIS] * g_fc;
+      if (k != 0.0f) {
+        const float rf = sqrtf(fu[1] * fu[1] + fv[1] * fv[1]), nf = rf + 1e-12f;
+        const float nb = l2norm2(fu[0], fv[0]);
+        const float uu = fu[1] / nf, uv = fv[1] / nf;
+        const float au = sgn(uu + fu[0] / nb) * k, av = sgn(uv + fv[0] / nb) * k;
+        const float ir = (rf > 0.0f) ? 1.0f / (rf * nf * nf) : 0.0f;
+        gfu += au * (1.0f / nf - fu[1] * fu[1] * ir) + av * (-fv[1] * fu[1] * ir);
+        gfv += au * (-fu[1] * fv[1] * ir) + av * (1.0f / nf - fv[1] * fv[1] * ir);
+      }
+    }
+    if (G.gflow[d][s]) { G.gflow[d][s][o2] = gfu; G.gflow[d][s][o2 + N] = gfv; }
+  }
 }
 
 // ---------------------------------------------------------------------- depth-only pointwise backward
@@ -628,10 +689,10 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   GeomLayout L;
   int rc = geom_layout(a, &L);
   if (rc != DFE_OK) return rc;
-  if (!a->workspace || !a->grad_losses || !a->pose) return DFE_ERR_NULL;
+  if (!a->workspace || !a->grad_losses || (a->mode != 2 && !a->pose)) return DFE_ERR_NULL;
   if (a->workspace_floats < L.total) return DFE_ERR_WORKSPACE;
-  for (int f = 0; f < 3; ++f) { if (!a->img[f]) return DFE_ERR_NULL; for (int s = 0; s < L.S; ++s) if (!a->disp[f][s]) return DFE_ERR_NULL; }
-  if (a->mode == 0) for (int d = 0; d < 2; ++d) for (int s = 0; s < L.S; ++s) if (!a->flow[d][s]) return DFE_ERR_NULL;
+  for (int f = 0; f < 3; ++f) { if (!a->img[f]) return DFE_ERR_NULL; if (a->mode != 2) for (int s = 0; s < L.S; ++s) if (!a->disp[f][s]) return DFE_ERR_NULL; }
+  if (a->mode != 1) for (int d = 0; d < 2; ++d) for (int s = 0; s < L.S; ++s) if (!a->flow[d][s]) return DFE_ERR_NULL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* ws = a->workspace;
   GeomDev D;
@@ -647,6 +708,18 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   int seg = 0;
 #define DFE_MARK() do { if (ev) (void)hipEventRecord(ev[++seg], st); } while (0)
   if (ev) (void)hipEventRecord(ev[0], st);
+  if (a->mode == 2) {
+    k_geom_ssim_bwd_roll<<<dim3(L.rollb_start[L.S], L.B * 2), 64, 0, st>>>(D, G);
+    DFE_LAUNCH_CHECK();
+    DFE_MARK();
+    k_flow_point_bwd<<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, G);
+    DFE_LAUNCH_CHECK();
+    DFE_MARK();
+    k_geom_flow_smooth_bwd<<<dim3(L.rollb_start[L.S], L.B), 64, 0, st>>>(D, G);
+    DFE_LAUNCH_CHECK();
+    DFE_MARK(); DFE_MARK(); DFE_MARK(); DFE_MARK();
+    return DFE_OK;
+  }
   if (a->mode == 1) {
     DFE_MARK();
     k_depth_point_bwd<<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, G);

@@ -22,7 +22,7 @@ static inline long align4(long v) { return (v + 3) & ~3L; }
 int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
   if (!a) return DFE_ERR_NULL;
   if (a->B <= 0 || a->H < 8 || a->W < 8 || a->num_scales <= 0 || a->num_scales > DFE_MAX_SCALES) return DFE_ERR_DIMS;
-  if (a->mode != 0 && a->mode != 1) return DFE_ERR_UNSUPPORTED;
+  if (a->mode < 0 || a->mode > 2) return DFE_ERR_UNSUPPORTED;
   L->B = a->B; L->S = a->num_scales;
   L->off_px[0] = 0; L->blk_start[0] = 0;
   for (int s = 0; s < L->S; ++s) {
@@ -65,6 +65,7 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
   L->o_area = o; o = align4(o + 2 * L->pyr_plane);
   L->o_mask = o; o = align4(o + (B * sumN + 3) / 4);
   L->o_yw = o; o = align4(o + 2 * B * 3 * sumN);
+  L->o_wgt = o; o = align4(o + (a->mode == 2 ? 2 * B * sumN : 0));
   L->o_part = o; o = align4(o + B * nblk_total * PT_COUNT);
   L->o_spart = o; o = align4(o + B * 2 * static_cast<long>(L->roll_start[S]));
   L->o_fpart = o; o = align4(o + 2 * B * (nblk_total > L->fs_start[S] ? nblk_total : static_cast<long>(L->fs_start[S])) * 2);
@@ -96,6 +97,7 @@ void geom_dev(const dfe_geom_args* a, const GeomLayout& L, GeomDev* D) {
     }
     D->mask[s] = reinterpret_cast<unsigned char*>(ws + L.o_mask) + static_cast<long>(L.B) * L.off_px[s];
     D->yw[s] = ws + L.o_yw + 6L * L.B * L.off_px[s];
+    D->wgt[s] = ws + L.o_wgt + 2L * L.B * L.off_px[s];
   }
   D->cams = reinterpret_cast<const Camera*>(ws + L.o_cams);
   D->epi = reinterpret_cast<const Epi*>(ws + L.o_epi);
@@ -142,7 +144,7 @@ __global__ void k_geom_pyramids(PyrJobs jobs) {
   const long pl = i / (static_cast<long>(jb.outW) * jb.outH);
   const int inH = jobs.inH, inW = jobs.inW;
   const float* src = jb.in + pl * inH * inW;
-  {
+  if (jb.out_bilinear) {
     // F.interpolate(bilinear, align_corners=False): ly0*(lx0*v00 + lx1*v01) + ly1*(lx0*v10 + lx1*v11)
     int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
     bilinear_src(oy, static_cast<float>(inH) / jb.outH, inH, y0, y1, ly0, ly1);
@@ -382,6 +384,63 @@ __global__ void __launch_bounds__(GS_BLOCK) k_depth_point_fwd(GeomDev D, float* 
   block_sum<PT_COUNT>(acc, red, part + (static_cast<long>(b) * nblk_total + blk) * PT_COUNT);
 }
 
+// ---------------------------------------------------------------------- flow-only pointwise forward
+// Model_flow loss stack (model_flow.py:105-138,209-255): flow warps of the box-mean pyramids, validity, soft
+// Gaussian occlusion weights 2 exp(-(w - 0.5)^2 / 0.03) * valid (detached), weighted 1-channel L1 sums, flow
+// consistency on (1 - weight_fwd).  Writes the float weights and the weighted warped images.
+__global__ void __launch_bounds__(GS_BLOCK) k_flow_point_fwd(GeomDev D, float* __restrict__ part) {
+  __shared__ float red[PT_COUNT * 4 * (GS_BLOCK / 64)];
+  const unsigned nblk_total = D.vblk_start[D.S];
+  const unsigned blk = xcd_swizzle(blockIdx.x, nblk_total);
+  const int b = blockIdx.y;
+  const int s = find_scale(D.vblk_start, D.S, blk);
+  const int H = D.H[s], W = D.W[s], N = D.N[s];
+  const unsigned p = (blk - D.vblk_start[s]) * GS_BLOCK + threadIdx.x;
+  float acc[PT_COUNT];
+#pragma unroll
+  for (int i = 0; i < PT_COUNT; ++i) acc[i] = 0.0f;
+  if (p < static_cast<unsigned>(N)) {
+    const unsigned py = p / static_cast<unsigned>(W), px = p - py * W;
+    const unsigned p4 = p * 4u, N4 = static_cast<unsigned>(N) * 4u;
+    const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
+    const float i0 = ldb(it, p4), i1 = ldb(it, p4 + N4), i2 = ldb(it, p4 + 2 * N4);
+    const Divisor dw = make_divisor(static_cast<float>(W > 1 ? W - 1 : 1)), dh = make_divisor(static_cast<float>(H > 1 ? H - 1 : 1));
+    float fu[2], fv[2], wv[2][3], dif[2], vld[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const float* fl = D.flow[d][s] + static_cast<long>(b) * 2 * N;
+      fu[d] = ldb(fl, p4); fv[d] = ldb(fl, p4 + N4);
+      float ix, iy;
+      flow_coords_d(px, py, fu[d], fv[d], H, W, D.ac, dw, dh, ix, iy);
+      const FastTap t = make_fast_tap(ix, iy, H, W);
+      const float keep = (fast_cover(t) < 0.9999f) ? 0.0f : 1.0f;
+      const float* src = D.pyr[d == 0 ? 0 : 2][s] + static_cast<long>(b) * 3 * N;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) wv[d][c] = fast_sample(reinterpret_cast<const float*>(reinterpret_cast<const char*>(src) + c * N4), t) * keep;
+      vld[d] = (wv[d][0] == 0.0f && wv[d][1] == 0.0f && wv[d][2] == 0.0f) ? 0.0f : 1.0f;
+      dif[d] = mean3_abs_diff(i0, i1, i2, wv[d][0], wv[d][1], wv[d][2]);
+    }
+    float sw[2];
+    occ_weights(dif[0], dif[1], sw[0], sw[1]);
+    float wgt[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const float c = sw[d] - 0.5f;
+      wgt[d] = (2.0f * expf(-(c * c) / 0.03f)) * vld[d];
+      acc[d * PT_PER_DIR + PT_M_VO] = wgt[d];
+      acc[d * PT_PER_DIR + PT_L1_RIG] = dif[d] * wgt[d];
+      (D.wgt[s] + (static_cast<long>(d) * D.B + b) * N)[p] = wgt[d];
+      float* yw = D.yw[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
+      stb(yw, p4, wv[d][0] * wgt[d]); stb(yw, p4 + N4, wv[d][1] * wgt[d]); stb(yw, p4 + 2 * N4, wv[d][2] * wgt[d]);
+    }
+    const float nf = l2norm2(fu[1], fv[1]), nb = l2norm2(fu[0], fv[0]);
+    const float inv = 1.0f - wgt[1];
+    acc[PT_INV] = inv;
+    acc[PT_CONSIS] = (fabsf(fu[1] / nf + fu[0] / nb) + fabsf(fv[1] / nf + fv[0] / nb)) * inv;
+  }
+  block_sum<PT_COUNT>(acc, red, part + (static_cast<long>(b) * nblk_total + blk) * PT_COUNT);
+}
+
 // ---------------------------------------------------------------------- SSIM forward (stage P), rolling window
 // One wave owns a strip of 62 columns (lanes 1..62; lanes 0 and 63 are the halo) and marches down RS_ROWS
 // rows (+1 halo row on each side).  Horizontal 3-sums come from DPP wave shifts, the vertical 3-row window
@@ -412,8 +471,9 @@ __global__ void __launch_bounds__(64) k_geom_ssim_fwd_roll(GeomDev D, float* __r
   const int x = strip * RS_COLS + static_cast<int>(threadIdx.x) - 1, y0 = rb * RS_ROWS;
   const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
   const float* yw = D.yw[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
-  const unsigned char* mk = D.mask[s] + static_cast<long>(b) * N;
-  const unsigned need = (DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD) << d;
+  const unsigned char* mk = D.mode == 2 ? reinterpret_cast<const unsigned char*>(D.wgt[s] + (static_cast<long>(d) * D.B + b) * N)
+                                        : D.mask[s] + static_cast<long>(b) * N;
+  const unsigned need = D.mode == 2 ? 0u : (DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD) << d;
   const bool lane_ok = threadIdx.x >= 1 && threadIdx.x <= RS_COLS && x < W;
   float acc = 0.0f;
   RowRaw w0 = ssim_load(it, yw, mk, need, y0 - 1, x, H, W, N);
@@ -577,7 +637,7 @@ __global__ void __launch_bounds__(256) k_geom_reduce_fwd(GeomDev D, const float*
 #pragma unroll
       for (int i = 0; i < PT_COUNT; ++i) a[i] += r[i];
     }
-    if (D.mode == 0) {
+    if (D.mode != 1) {
       for (int k = D.fs_start[s] + t; k < D.fs_start[s + 1]; k += 256) {
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
@@ -600,7 +660,7 @@ __global__ void __launch_bounds__(256) k_geom_reduce_fwd(GeomDev D, const float*
     }
   } else {
     double a[6] = {0, 0, 0, 0, 0, 0};
-    for (int k = t; k < ndunit; k += 256)
+    if (D.mode != 2) for (int k = t; k < ndunit; k += 256)
 #pragma unroll
       for (int f = 0; f < 3; ++f) {
         const float* q = dpart + (static_cast<long>(f * B + b) * ndunit + k) * 2;
@@ -632,11 +692,12 @@ __global__ void k_geom_assemble_fwd(GeomDev D, const float* __restrict__ sums, c
       const double n_tex = a[PT_M_TEX] / N + eps, n_rig = a[PT_M_RIG] / N + eps, n_dyn = a[PT_M_DYN] / N + eps,
                    n_vo = a[PT_M_VO] / N + eps;
       l_dp += (a[PT_L1_DEPTH] / (3.0 * N)) / n_tex;
-      l_fp += (a[PT_L1_RIG] / (3.0 * N)) / n_rig + 2.0 * (a[PT_L1_DYN] / (3.0 * N)) / n_dyn;
+      if (D.mode == 2) l_fp += (a[PT_L1_RIG] / N) / n_vo;   // 1-channel diff broadcast over 3 channels (model_flow.py:94-103)
+      else l_fp += (a[PT_L1_RIG] / (3.0 * N)) / n_rig + 2.0 * (a[PT_L1_DYN] / (3.0 * N)) / n_dyn;
       l_fs += (sm[SUM_SSIM + d] / (3.0 * N)) / n_vo;
       l_sm += (sm[SUM_FS + 2 * d] / (2.0 * H * (W - 2.0)) + sm[SUM_FS + 2 * d + 1] / (2.0 * (H - 2.0) * W)) / 2.0;
       cf[d * CF_PER_DIR + CF_DEPTH] = static_cast<float>(1.0 / (3.0 * N * n_tex));
-      cf[d * CF_PER_DIR + CF_RIG] = static_cast<float>(1.0 / (3.0 * N * n_rig));
+      cf[d * CF_PER_DIR + CF_RIG] = static_cast<float>(1.0 / (3.0 * N * (D.mode == 2 ? n_vo : n_rig)));
       cf[d * CF_PER_DIR + CF_DYN] = static_cast<float>(2.0 / (3.0 * N * n_dyn));
       cf[d * CF_PER_DIR + CF_VO] = static_cast<float>(1.0 / (3.0 * N * n_vo));
       cf[d * CF_PER_DIR + CF_FD] = static_cast<float>(1.0 / (2.0 * N * n_rig));
@@ -669,14 +730,15 @@ __global__ void k_geom_assemble_fwd(GeomDev D, const float* __restrict__ sums, c
 using namespace dfe;
 
 static int check_args(const dfe_geom_args* a, const GeomLayout& L, bool bwd) {
-  if (!a->workspace || !a->pose || !a->K) return DFE_ERR_NULL;
+  if (!a->workspace) return DFE_ERR_NULL;
+  if (a->mode != 2 && (!a->pose || !a->K)) return DFE_ERR_NULL;
   if (a->mode == 0 && !a->K_inv) return DFE_ERR_NULL;
   if (a->workspace_floats < L.total) return DFE_ERR_WORKSPACE;
   for (int f = 0; f < 3; ++f) {
     if (!a->img[f]) return DFE_ERR_NULL;
-    for (int s = 0; s < L.S; ++s) if (!a->disp[f][s]) return DFE_ERR_NULL;
+    if (a->mode != 2) for (int s = 0; s < L.S; ++s) if (!a->disp[f][s]) return DFE_ERR_NULL;
   }
-  if (a->mode == 0) for (int d = 0; d < 2; ++d) for (int s = 0; s < L.S; ++s) if (!a->flow[d][s]) return DFE_ERR_NULL;
+  if (a->mode != 1) for (int d = 0; d < 2; ++d) for (int s = 0; s < L.S; ++s) if (!a->flow[d][s]) return DFE_ERR_NULL;
   if (!bwd && !a->losses) return DFE_ERR_NULL;
   if (bwd && !a->grad_losses) return DFE_ERR_NULL;
   if (a->B > 21845) return DFE_ERR_DIMS;   // grid.y carries up to 3*B (frames x samples) <= 65535
@@ -717,8 +779,10 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   // cameras: downscale = H / H_s as the reference computes it (float division of ints)
   float downs[DFE_MAX_SCALES];
   for (int s = 0; s < L.S; ++s) downs[s] = static_cast<float>(static_cast<double>(a->H) / static_cast<double>(L.H[s]));
-  rc = dfe_prepare_cameras(a->pose, a->K, ws + L.o_cams, L.B, 2, L.S, downs, stream);
-  if (rc != DFE_OK) return rc;
+  if (a->mode != 2) {
+    rc = dfe_prepare_cameras(a->pose, a->K, ws + L.o_cams, L.B, 2, L.S, downs, stream);
+    if (rc != DFE_OK) return rc;
+  }
   if (a->mode == 0) {
     k_prepare_epi<<<(L.B * 2 + 63) / 64, 64, 0, st>>>(a->pose, a->K_inv, reinterpret_cast<Epi*>(ws + L.o_epi), D.cams, L.B, L.S);
     DFE_LAUNCH_CHECK();
@@ -729,9 +793,13 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     jobs.n = 0; jobs.planes = L.B * 3; jobs.inH = a->H; jobs.inW = a->W;
     int max_out = 0;
     for (int s = 1; s < L.S; ++s) {
-      for (int f = 0; f < 3; ++f)
-        jobs.j[jobs.n++] = PyrJob{a->img[f], const_cast<float*>(D.pyr[f][s]),
-                                  f == 1 ? nullptr : const_cast<float*>(D.area[f == 0 ? 0 : 1][s]), L.H[s], L.W[s]};
+      for (int f = 0; f < 3; ++f) {
+        if (a->mode == 2)   // Model_flow: box-mean (adaptive_avg_pool2d) pyramid of all three frames, model_flow.py:58-64
+          jobs.j[jobs.n++] = PyrJob{a->img[f], nullptr, const_cast<float*>(D.pyr[f][s]), L.H[s], L.W[s]};
+        else
+          jobs.j[jobs.n++] = PyrJob{a->img[f], const_cast<float*>(D.pyr[f][s]),
+                                    f == 1 ? nullptr : const_cast<float*>(D.area[f == 0 ? 0 : 1][s]), L.H[s], L.W[s]};
+      }
       if (L.N[s] > max_out) max_out = L.N[s];
     }
     dim3 g(static_cast<unsigned>((static_cast<long>(jobs.planes) * max_out + 255) / 256), jobs.n);
@@ -739,7 +807,18 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     DFE_LAUNCH_CHECK();
   }
   DFE_MARK();
-  if (a->mode == 1) {
+  if (a->mode == 2) {
+    // Model_flow: flow warps + soft weights + weighted L1 / SSIM / smoothness / consistency (no depth, no pose)
+    k_flow_point_fwd<<<dim3(L.vblk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
+    DFE_LAUNCH_CHECK();
+    DFE_MARK();
+    k_geom_ssim_fwd_roll<<<dim3(L.roll_start[L.S], L.B * 2), 64, 0, st>>>(D, ws + L.o_spart);
+    DFE_LAUNCH_CHECK();
+    DFE_MARK();
+    k_geom_flow_smooth_fwd<<<dim3(L.fs_start[L.S], L.B), 64, 0, st>>>(D, ws + L.o_fpart);
+    DFE_LAUNCH_CHECK();
+    DFE_MARK();
+  } else if (a->mode == 1) {
     // Model_depth: rigid recon + validity*texture mask + masked L1 only (no flows, no SSIM, no flow terms)
     k_depth_point_fwd<<<dim3(L.vblk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
     DFE_LAUNCH_CHECK();
@@ -764,7 +843,7 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     DFE_LAUNCH_CHECK();
     DFE_MARK();
   }
-  {
+  if (a->mode != 2) {
     const dim3 g(L.dsm_units, 3 * L.B);
     float* dp = ws + L.o_dpart;
     switch (L.S) {

@@ -61,26 +61,29 @@ def _fill_args(imgs, disps, flows, pose, K, K_inv, S, alpha, beta, ac, mode=0):
         if tuple(imgs[f].shape) != (B, 3, H, W):
             raise ValueError("frames must be [B,3,H,W]")
         a.img[f] = _dp(imgs[f])
-        for s in range(S):
+        for s in range(S if mode != 2 else 0):
             hs, ws = _scale_hw(H, W, s)
             if tuple(disps[f][s].shape) != (B, 1, hs, ws):
                 raise ValueError("disp[%d][%d] must be %s, got %s" % (f, s, (B, 1, hs, ws), tuple(disps[f][s].shape)))
             a.disp[f][s] = _dp(disps[f][s])
-    for d in range(2 if mode == 0 else 0):
+    for d in range(2 if mode != 1 else 0):
         for s in range(S):
             hs, ws = _scale_hw(H, W, s)
             if tuple(flows[d][s].shape) != (B, 2, hs, ws):
                 raise ValueError("flow[%d][%d] must be %s, got %s" % (d, s, (B, 2, hs, ws), tuple(flows[d][s].shape)))
             a.flow[d][s] = _dp(flows[d][s])
-    if tuple(pose.shape) != (B, 2, 6) or tuple(K.shape) != (B, 3, 3) or (mode == 0 and tuple(K_inv.shape) != (B, 3, 3)):
-        raise ValueError("pose must be [B,2,6] and K, K_inv [B,3,3]")
-    a.pose, a.K = _dp(pose), _dp(K)
-    a.K_inv = _dp(K_inv) if mode == 0 else None
+    if mode != 2:
+        if tuple(pose.shape) != (B, 2, 6) or tuple(K.shape) != (B, 3, 3) or (mode == 0 and tuple(K_inv.shape) != (B, 3, 3)):
+            raise ValueError("pose must be [B,2,6] and K, K_inv [B,3,3]")
+        a.pose, a.K = _dp(pose), _dp(K)
+        a.K_inv = _dp(K_inv) if mode == 0 else None
     return a
 
 
 def _unpack(t, S, mode):
     imgs = t[0:3]
+    if mode == 2:
+        return imgs, None, [t[3 + d * S: 3 + (d + 1) * S] for d in range(2)], None, None, None
     disps = [t[3 + f * S: 3 + (f + 1) * S] for f in range(3)]
     if mode == 0:
         flows = [t[3 + 3 * S + d * S: 3 + 3 * S + (d + 1) * S] for d in range(2)]
@@ -125,23 +128,24 @@ class GeomLossFn(torch.autograd.Function):
         glosses = f32c(glosses)
         a.workspace, a.workspace_floats = ctx.ws.data_ptr(), ctx.ws.numel()
         a.grad_losses = glosses.data_ptr()
-        gd = [[torch.empty_like(x) for x in lst] for lst in disps]
-        gf = [[torch.empty_like(x) for x in lst] for lst in flows] if mode == 0 else []
-        gp = torch.empty_like(pose)
-        for f in range(3):
+        gd = [[torch.empty_like(x) for x in lst] for lst in disps] if mode != 2 else []
+        gf = [[torch.empty_like(x) for x in lst] for lst in flows] if mode != 1 else []
+        gp = torch.empty_like(pose) if mode != 2 else None
+        for f in range(len(gd)):
             for s in range(S):
                 a.grad_disp[f][s] = gd[f][s].data_ptr()
         for d in range(len(gf)):
             for s in range(S):
                 a.grad_flow[d][s] = gf[d][s].data_ptr()
-        a.grad_pose = gp.data_ptr()
+        if gp is not None:
+            a.grad_pose = gp.data_ptr()
         check(lib.dfe_geom_loss_bwd(ctypes.byref(a), stream_ptr()), "dfe_geom_loss_bwd")
         grads = [None] * 8          # mode, S, alpha, beta, ac, 3 frames
-        for f in range(3):
+        for f in range(len(gd)):
             grads += gd[f]
         for d in range(len(gf)):
             grads += gf[d]
-        grads += [gp, None, None] if mode == 0 else [gp, None]
+        grads += {0: [gp, None, None], 1: [gp, None], 2: []}[mode]
         return tuple(grads)
 
 
@@ -182,6 +186,17 @@ def depth_loss_stack(img_l, img, img_r, depth_l_list, depth_list, depth_r_list, 
     m = decode_masks(ws, B, H, W, S)
     return pack, {"valid_to_l": m["valid_bwd"], "valid_to_r": m["valid_fwd"], "texture_bwd": m["texture_bwd"],
                   "texture_fwd": m["texture_fwd"]}
+
+
+def flow_loss_stack(img_l, img, img_r, flows_bwd, flows_fwd, num_scales=3, align_corners=None):
+    """Active ``loss_pack`` entries of Model_flow.forward (model_flow.py:209-255) in the fused launches (mode 2):
+    box-mean pyramids, soft Gaussian occlusion weights, weighted L1 / SSIM, flow smoothness and consistency."""
+    S = int(num_scales)
+    ac = ops.get_align_corners() if align_corners is None else bool(align_corners)
+    tensors = [img_l, img, img_r] + list(flows_bwd[:S]) + list(flows_fwd[:S])
+    losses, _ws = GeomLossFn.apply(2, S, 0.0, 0.0, int(ac), *tensors)
+    return {"loss_flow_pixel": losses[2], "loss_flow_ssim": losses[3], "loss_flow_smooth": losses[4],
+            "loss_flow_consis": losses[5]}
 
 
 def decode_masks(ws, B, H, W, S):

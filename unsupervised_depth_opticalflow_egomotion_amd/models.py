@@ -10,7 +10,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .loss_stack import geom_loss_stack, depth_loss_stack
+from .loss_stack import geom_loss_stack, depth_loss_stack, flow_loss_stack
 from .loss_terms import LossTerms
 from .networks import Depth_Model, PoseCNN, FeaturePyramid, PWC_tf
 
@@ -164,7 +164,7 @@ class Model_geometry(LossTerms, nn.Module):
 
 
 class Model_depth(LossTerms, nn.Module):
-    """Depth + pose only (model_depth.py:272-337): pixel + smoothness terms; per-operator HIP kernels."""
+    """Depth + pose only (model_depth.py:272-337): pixel + smoothness terms, fused HIP launches (mode 1)."""
 
     def __init__(self, cfg):
         nn.Module.__init__(self)
@@ -221,7 +221,7 @@ class Model_depth(LossTerms, nn.Module):
 
 
 class Model_flow(LossTerms, nn.Module):
-    """Flow only (model_flow.py:14-261): soft occlusion weights, box-mean pyramid."""
+    """Flow only (model_flow.py:14-261): soft occlusion weights, box-mean pyramid, fused HIP launches (mode 2)."""
 
     def __init__(self, cfg):
         nn.Module.__init__(self)
@@ -250,6 +250,11 @@ class Model_flow(LossTerms, nn.Module):
         return self.loss_stack(img_l, img, img_r, flows_bwd, flows_fwd)
 
     def loss_stack(self, img_l, img, img_r, flows_bwd, flows_fwd):
+        """model_flow.py:224-255 in the fused HIP launches (mode 2 of dfe_geom_loss_fwd/bwd)."""
+        return flow_loss_stack(img_l, img, img_r, flows_bwd, flows_fwd, num_scales=self.num_scales), {}
+
+    def loss_stack_per_op(self, img_l, img, img_r, flows_bwd, flows_fwd):
+        """The same terms through the per-operator kernels and the per-method API (kept for cross-checking)."""
         n = len(flows_fwd)
         pl, pt, pr = (self.generate_img_pyramid_avgpool(x, n) for x in (img_l, img, img_r))
         warp_l, warp_r = self.warp_flow_pyramid(pl, flows_bwd), self.warp_flow_pyramid(pr, flows_fwd)
