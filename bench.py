@@ -304,7 +304,7 @@ def main():
     pairs_per_step = 2 * args.batch * world
     value = pairs_per_step * args.steps / dt
     out = {
-        "metric": "frame-pairs/sec (832x256, %s mode)" % (args.mode if wl.name == "train_step" else "geom"), "value": round(value, 2), "unit": "frame-pairs/s",
+        "metric": "frame-pairs/sec (%dx%d, %s mode)" % (args.width, args.height, args.mode if wl.name == "train_step" else "geom"), "value": round(value, 2), "unit": "frame-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl.name + ": mode=%s, %dx%d, batch=%d/GPU, num_scales=%d, fwd+bwd%s" % (

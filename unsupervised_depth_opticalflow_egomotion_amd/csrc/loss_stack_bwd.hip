@@ -7,7 +7,8 @@
 //                           writes grad_flow / grad_disp(target), block sums for the pose
 //   k_geom_flow_smooth_bwd  adds the 2nd-order smoothness gradient into grad_flow
 //   k_geom_disp_smooth_bwd1 dL/d(up-sampled disp) per full-res pixel (writes scale 0 directly)
-//   k_geom_disp_smooth_bwd2 adjoint of the bilinear up-sampling as a gather per low-res pixel
+//   k_geom_disp_smooth_bwd2 adjoint of the bilinear up-sampling as a gather per low-res pixel (register path for
+//                           ratios >= 1/4, k_geom_disp_smooth_bwd2_coarse = one wave per pixel below that)
 //   k_geom_pose_finalize    fixed-order reduction + closed-form 3x3 chains -> grad_pose
 // No float atomics anywhere: gradients are bitwise reproducible run to run.
 #include "loss_stack.h"
@@ -587,37 +588,133 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_bwd2(GeomDev D, G
   float wy[G2_MAX], wx[G2_MAX];
   adj_weights(i, rh, Hs, H, ylo, ny, wy);
   adj_weights(j, rw, Ws, W, xlo, nx, wx);
-  if (ny <= G2_MAX && nx <= G2_MAX) {
+  if (ny > G2_MAX || nx > G2_MAX) return;      // large footprint: k_geom_disp_smooth_bwd2_coarse owns this pixel
 #pragma unroll
-    for (int ky = 0; ky < G2_MAX; ++ky) {
-      if (wy[ky] == 0.0f) continue;
-      const float* row = gu + static_cast<long>(ylo + ky) * W + xlo;
-      float acc = 0.0f;
+  for (int ky = 0; ky < G2_MAX; ++ky) {
+    if (wy[ky] == 0.0f) continue;
+    const float* row = gu + static_cast<long>(ylo + ky) * W + xlo;
+    float acc = 0.0f;
 #pragma unroll
-      for (int kx = 0; kx < G2_MAX; ++kx)
-        if (wx[kx] != 0.0f) acc += wx[kx] * row[kx];
-      total += wy[ky] * acc;
-    }
-  } else {
-    // coarse scales (ratio < 1/4): footprints are large but these images are tiny; plain loops
-    const int yhi = ylo + ny - 1, xhi = xlo + nx - 1;
-    for (int y = ylo; y <= yhi; ++y) {
-      int a0, a1; float l0, l1;
-      bilinear_src(y, rh, Hs, a0, a1, l0, l1);
-      const float wyy = (a0 == i ? l0 : 0.0f) + (a1 == i ? l1 : 0.0f);
-      if (wyy == 0.0f) continue;
-      float acc = 0.0f;
-      for (int x = xlo; x <= xhi; ++x) {
-        int c0, c1; float m0, m1;
-        bilinear_src(x, rw, Ws, c0, c1, m0, m1);
-        const float wxx = (c0 == j ? m0 : 0.0f) + (c1 == j ? m1 : 0.0f);
-        if (wxx != 0.0f) acc += wxx * gu[static_cast<long>(y) * W + x];
-      }
-      total += wyy * acc;
-    }
+    for (int kx = 0; kx < G2_MAX; ++kx)
+      if (wx[kx] != 0.0f) acc += wx[kx] * row[kx];
+    total += wy[ky] * acc;
   }
   float* o = G.gdisp[f][s] + static_cast<long>(b) * Ns + q;
   if (f == 1) *o += total; else *o = total;
+}
+
+// Coarse scales (ratio < 1/4, footprints of up to (2^(s+1)+4)^2 full-res pixels per low-res pixel): a group of
+// g = 16 / 32 / 64 lanes per low-res pixel (g = the scale's widest footprint rounded up, so 4 / 2 / 1 pixels share a
+// wave).  Lanes stride over the footprint columns (a lane's horizontal weight is fixed for its whole march) and walk
+// the rows four at a time (four independent loads in flight); a fixed-order DPP tree adds the lane sums of a group.
+// Pixels whose clamped footprint fits the register path above are skipped here (same predicate on both sides).
+// grid.x = sum_{s >= s0} ceil(N_s * g_s / 64) wave units, 4 per block; grid.y = f*B + b.
+__device__ __forceinline__ void adj_range(int i, float r, int fullN, int& lo, int& cnt) {
+  lo = max(static_cast<int>(floorf((i - 0.5f) / r - 0.5f)) - 1, 0);
+  const int hi = min(static_cast<int>(ceilf((i + 1.5f) / r - 0.5f)) + 1, fullN - 1);
+  cnt = hi - lo + 1;
+}
+
+__host__ __device__ __forceinline__ int coarse_group(int W, int Ws) {
+  const int nxmax = (2 * W + Ws - 1) / Ws + 4;
+  return nxmax <= 16 ? 16 : nxmax <= 32 ? 32 : 64;
+}
+
+struct AdjMarch {
+  const float* gu; float rh, rw; int Hs, Ws, W, i, j, ylo, ny, xlo, nx, g, lx, gbase; float wrow; bool mine, tall;
+};
+
+template <int U>
+__device__ __forceinline__ float adj_march(const AdjMarch& m) {
+  float total = 0.0f;
+  const int yend = m.ylo + m.ny;
+  for (int x = m.xlo + m.lx; __any(x < m.xlo + m.nx); x += m.g) {
+    const bool on = m.mine && x < m.xlo + m.nx;
+    const int xc = min(x, m.W - 1);
+    int c0, c1; float m0, m1;
+    bilinear_src(xc, m.rw, m.Ws, c0, c1, m0, m1);
+    const float wxx = on ? ((c0 == m.j ? m0 : 0.0f) + (c1 == m.j ? m1 : 0.0f)) : 0.0f;
+    float col = 0.0f;
+    for (int y = 0; __any(y < m.ny); y += U) {
+      float wy[U], v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = y + u;
+        const int yy = min(m.ylo + k, yend - 1);
+        if (m.tall) {
+          int a0, a1; float l0, l1;
+          bilinear_src(yy, m.rh, m.Hs, a0, a1, l0, l1);
+          wy[u] = (k < m.ny) ? ((a0 == m.i ? l0 : 0.0f) + (a1 == m.i ? l1 : 0.0f)) : 0.0f;
+        } else {
+          const float w = __shfl(m.wrow, m.gbase + min(k, m.g - 1));     // executed by every lane of the wave
+          wy[u] = (k < m.ny) ? w : 0.0f;
+        }
+        v[u] = (wxx != 0.0f) ? m.gu[static_cast<long>(yy) * m.W + xc] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) col += wy[u] * v[u];
+    }
+    total += wxx * col;
+  }
+  return total;
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_bwd2_coarse(GeomDev D, GeomBwd G, int s0) {
+  const int f = blockIdx.y / D.B, b = blockIdx.y - f * D.B;
+  const int lane = threadIdx.x & 63;
+  int unit = blockIdx.x * (GS_BLOCK / 64) + (threadIdx.x >> 6);
+  int s = s0, g = 64;
+  for (; s < D.S; ++s) {
+    g = coarse_group(D.W[0], D.W[s]);
+    const int units = (D.N[s] * (g / 16) + 3) / 4;      // ceil(N_s / (64 / g))
+    if (unit < units) break;
+    unit -= units;
+  }
+  if (s >= D.S || !G.gdisp[f][s]) return;
+  const int Hs = D.H[s], Ws = D.W[s], Ns = D.N[s];
+  const int H = D.H[0], W = D.W[0], N = D.N[0];
+  const int lx = lane & (g - 1);
+  const int q = unit * (64 / g) + lane / g;
+  const bool live = q < Ns;
+  const int qq = live ? q : Ns - 1;
+  const int i = qq / Ws, j = qq - i * Ws;
+  const float rh = static_cast<float>(Hs) / H, rw = static_cast<float>(Ws) / W;
+  int ylo, ny, xlo, nx;
+  adj_range(i, rh, H, ylo, ny);
+  adj_range(j, rw, W, xlo, nx);
+  const bool mine = live && (ny > G2_MAX || nx > G2_MAX);
+  const float* gu = G.gup + ((static_cast<long>(f) * (D.S - 1) + (s - 1)) * D.B + b) * N;
+  float total = 0.0f;
+  // vertical weights: lane lx of the group forms the weight of footprint row ylo + lx once; the march below
+  // fetches it from that lane (ds_bpermute).  Footprints taller than the group recompute (tiny odd-shaped inputs).
+  float wrow = 0.0f;
+  {
+    int a0, a1; float l0, l1;
+    bilinear_src(min(ylo + lx, H - 1), rh, Hs, a0, a1, l0, l1);
+    wrow = (lx < ny) ? ((a0 == i ? l0 : 0.0f) + (a1 == i ? l1 : 0.0f)) : 0.0f;
+  }
+  const bool tall = __any(ny > g);
+  const int gbase = lane & ~(g - 1);
+  AdjMarch m{gu, rh, rw, Hs, Ws, W, i, j, ylo, ny, xlo, nx, g, lx, gbase, wrow, mine, tall};
+  // widest footprints (g = 64: up to 2^(s+1)+4 rows) keep 16 row loads in flight, the others 4
+  total = (g == 64) ? adj_march<16>(m) : adj_march<4>(m);
+  // re-converged: butterfly inside each 16-lane row, then the rows of a group in a fixed order
+  total = dpp_add<0xB1>(total);
+  total = dpp_add<0x4E>(total);
+  total = dpp_add<0x141>(total);
+  total = dpp_add<0x140>(total);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(total), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(total), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(total), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(total), 48));
+  float t;
+  if (g == 16) t = total;                                   // each row is one pixel
+  else if (g == 32) t = lane < 32 ? r0 + r1 : r2 + r3;
+  else t = (r0 + r1) + (r2 + r3);
+  if (mine && lx == 0) {
+    float* o = G.gdisp[f][s] + static_cast<long>(b) * Ns + q;
+    if (f == 1) *o += t; else *o = t;
+  }
 }
 
 // ---------------------------------------------------------------------- pose finalize
@@ -754,6 +851,15 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   if (L.S > 1) {
     k_geom_disp_smooth_bwd2<<<dim3(nblk_total - L.blk_start[1], 3 * L.B), GS_BLOCK, 0, st>>>(D, G);
     DFE_LAUNCH_CHECK();
+    // scales coarser than 1/4 (H_s = int(H / 2^s), so the ratio is 2^s or slightly above): wave-per-pixel gather
+    int s0 = 1;
+    while (s0 < L.S && L.H[0] <= 4 * L.H[s0] && L.W[0] <= 4 * L.W[s0]) ++s0;
+    if (s0 < L.S) {
+      long units = 0;
+      for (int s = s0; s < L.S; ++s) units += (static_cast<long>(L.N[s]) * (coarse_group(L.W[0], L.W[s]) / 16) + 3) / 4;
+      k_geom_disp_smooth_bwd2_coarse<<<dim3(static_cast<unsigned>((units + GS_BLOCK / 64 - 1) / (GS_BLOCK / 64)), 3 * L.B), GS_BLOCK, 0, st>>>(D, G, s0);
+      DFE_LAUNCH_CHECK();
+    }
   }
   DFE_MARK();
   if (a->grad_pose) {

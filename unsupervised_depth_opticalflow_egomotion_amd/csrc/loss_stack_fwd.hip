@@ -169,6 +169,65 @@ __global__ void k_geom_pyramids(PyrJobs jobs) {
   }
 }
 
+// Box means with large windows (non-divisible sizes at coarse scales: up to (2^s + 1)^2 inputs per output).  A
+// thread-per-output loop pays one memory round trip per pair of inputs; here one wave stages the window in LDS
+// with row-coalesced loads and lane 0 adds it in ATen's row-major order (the mean stays bit-identical to
+// adaptive_avg_pool2d's).  grid.x = output elements, grid.y = job; block = one wave.
+constexpr int AREA_LDS = 1280;
+constexpr int AREA_COARSE_MIN = 256;   // windows above this many inputs take the wave path
+
+__global__ void __launch_bounds__(64) k_geom_area_coarse(PyrJobs jobs) {
+  __shared__ __attribute__((aligned(16))) float buf[AREA_LDS];
+  const PyrJob jb = jobs.j[blockIdx.y];
+  const long n = static_cast<long>(jobs.planes) * jb.outH * jb.outW;
+  const long i = blockIdx.x;
+  if (i >= n) return;
+  const int lane = threadIdx.x;
+  const int ox = static_cast<int>(i % jb.outW), oy = static_cast<int>((i / jb.outW) % jb.outH);
+  const long pl = i / (static_cast<long>(jb.outW) * jb.outH);
+  const int inH = jobs.inH, inW = jobs.inW;
+  const float* src = jb.in + pl * inH * inW;
+  const int ys = (oy * inH) / jb.outH, ye = ((oy + 1) * inH + jb.outH - 1) / jb.outH;
+  const int xs = (ox * inW) / jb.outW, xe = ((ox + 1) * inW + jb.outW - 1) / jb.outW;
+  const int kw = xe - xs;
+  float sum = 0.0f;
+  if (kw > AREA_LDS) {        // wider than the staging buffer (W > 2048 * W_s): plain ordered loop
+    if (lane == 0)
+      for (int yy = ys; yy < ye; ++yy)
+        for (int xx = xs; xx < xe; ++xx) sum += src[static_cast<long>(yy) * inW + xx];
+  } else {
+    const int rows_per = AREA_LDS / kw;
+    for (int y0 = ys; y0 < ye; y0 += rows_per) {
+      const int nr = min(rows_per, ye - y0);
+      for (int c = lane; c < kw; c += 64) {
+        const float* col = src + static_cast<long>(y0) * inW + xs + c;
+        for (int r = 0; r < nr; r += 8) {       // eight independent row loads in flight
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = col[static_cast<long>(min(r + u, nr - 1)) * inW];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) if (r + u < nr) buf[(r + u) * kw + c] = v[u];
+        }
+      }
+      __syncthreads();
+      if (lane == 0) {
+        const int cnt = nr * kw;
+        int k = 0;
+        for (; k + 16 <= cnt; k += 16) {
+          float v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = buf[k + u];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) sum += v[u];
+        }
+        for (; k < cnt; ++k) sum += buf[k];
+      }
+      __syncthreads();
+    }
+  }
+  if (lane == 0) jb.out_area[i] = sum / static_cast<float>((ye - ys) * kw);
+}
+
 // ---------------------------------------------------------------------- pointwise forward
 // Bound by the number of memory instructions (TA_BUSY 80 %: the texture-address unit takes ~16 cycles per
 // wave-wide load whatever its width) and then by VALU issue (profiles/r01b_pmc_loss_stack.json).  Hence:
@@ -802,9 +861,31 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
       }
       if (L.N[s] > max_out) max_out = L.N[s];
     }
-    dim3 g(static_cast<unsigned>((static_cast<long>(jobs.planes) * max_out + 255) / 256), jobs.n);
-    k_geom_pyramids<<<g, 256, 0, st>>>(jobs);
-    DFE_LAUNCH_CHECK();
+    // box means whose window exceeds AREA_COARSE_MIN inputs move to the wave-per-output kernel
+    PyrJobs coarse;
+    coarse.n = 0; coarse.planes = jobs.planes; coarse.inH = jobs.inH; coarse.inW = jobs.inW;
+    int max_coarse = 0, kept = 0;
+    for (int k = 0; k < jobs.n; ++k) {
+      PyrJob& jb = jobs.j[k];
+      const long kh = (a->H + jb.outH - 1) / jb.outH + 1, kw = (a->W + jb.outW - 1) / jb.outW + 1;
+      if (jb.out_area && kh * kw > AREA_COARSE_MIN) {
+        coarse.j[coarse.n++] = PyrJob{jb.in, nullptr, jb.out_area, jb.outH, jb.outW};
+        if (jb.outH * jb.outW > max_coarse) max_coarse = jb.outH * jb.outW;
+        jb.out_area = nullptr;
+      }
+      if (jb.out_bilinear || jb.out_area) jobs.j[kept++] = jb;
+    }
+    jobs.n = kept;
+    if (jobs.n > 0) {
+      dim3 g(static_cast<unsigned>((static_cast<long>(jobs.planes) * max_out + 255) / 256), jobs.n);
+      k_geom_pyramids<<<g, 256, 0, st>>>(jobs);
+      DFE_LAUNCH_CHECK();
+    }
+    if (coarse.n > 0) {
+      dim3 g(static_cast<unsigned>(static_cast<long>(coarse.planes) * max_coarse), coarse.n);
+      k_geom_area_coarse<<<g, 64, 0, st>>>(coarse);
+      DFE_LAUNCH_CHECK();
+    }
   }
   DFE_MARK();
   if (a->mode == 2) {
