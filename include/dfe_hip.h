@@ -93,6 +93,18 @@ int dfe_corr_bwd(const float* f1, const float* f2, const float* gout, float* g1,
  * mode 1 = F.interpolate(area) == adaptive_avg_pool2d (model_geometry.py:91, model_flow.py:58-64). */
 int dfe_resize(const float* in, float* out, int planes, int inH, int inW, int outH, int outW, int mode, void* stream);
 
+/* ---- depth-decoder glue between the MIOpen convolutions (depth_model.py:60-211:
+ * Conv3x3 = ReflectionPad2d(1) + conv, ConvBlock = Conv3x3 + ELU, stage = ConvBlock, bilinear x2, cat(skip), ConvBlock).
+ * dfe_elu_pad:          out [B,C,H+2,W+2] = reflect_pad1(apply_elu ? elu(x) : x),  x [B,C,H,W]
+ * dfe_elu_up2_cat_pad:  out [B,C1+C2,2h+2,2w+2] = reflect_pad1(cat(bilinear_x2(elu(x)), skip)),
+ *                       x [B,C1,h,w] (the convolution output *before* its ELU), skip [B,C2,2h,2w] or NULL with C2 = 0.
+ * Backward: gout has the padded shape; gx / gskip may be NULL when not needed (gskip ignored when C2 = 0). */
+int dfe_elu_pad_fwd(const float* x, float* out, int B, int C, int H, int W, int apply_elu, void* stream);
+int dfe_elu_pad_bwd(const float* x, const float* gout, float* gx, int B, int C, int H, int W, int apply_elu, void* stream);
+int dfe_elu_up2_cat_pad_fwd(const float* x, const float* skip, float* out, int B, int C1, int C2, int h, int w, void* stream);
+int dfe_elu_up2_cat_pad_bwd(const float* x, const float* gout, float* gx, float* gskip, int B, int C1, int C2, int h, int w,
+                            void* stream);
+
 /* ---- fused loss stack: everything from model_geometry.py:797 to :951 given the nets' outputs ---
  * One call computes the active loss_pack vectors of Model_geometry.forward (mode 0) for a batch:
  * pyramids (:65-72,:91), rigid view synthesis (:80-103), texture / occlusion / validity / dynamic

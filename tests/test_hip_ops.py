@@ -34,7 +34,7 @@ def gclose(a, b, rel=1e-4, max_outliers=0, atol=0.0):
     """max |a-b| <= rel * max|b| + atol; ``max_outliers`` elements may exceed it (pixels whose
     {0,1} validity decision sits within fp32 noise of its threshold differ legitimately).
     ``atol`` is the cancellation-noise floor for gradients that are analytically ~0."""
-    a, b = N(a), (N(b) if isinstance(b, torch.Tensor) else b)
+    a, b = (N(a) if isinstance(a, torch.Tensor) else a), (N(b) if isinstance(b, torch.Tensor) else b)
     scale = max(np.abs(b).max(), 1e-12)
     bad = int((np.abs(a - b) > rel * scale + atol).sum())
     assert bad <= max_outliers, "grad mismatch: %d elements (allowed %d), max %g vs scale %g" % (
@@ -229,3 +229,96 @@ def test_degenerate_sizes():
                 y = warp_flow(G(x), G(fl), use_mask=um, align_corners=ac)
                 close(y, yo, atol=2e-6)
         close(SSIM(G(x), G(x[::-1].copy())), O.SSIM(T(x), T(x[::-1].copy())), atol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------- depth-decoder glue
+# Reference = the plain PyTorch fp32 composition on the CPU (what depth_model.py's ConvBlock / decoder stage does
+# between its convolutions).  Tolerance: 2e-6 abs on O(1) activations (expm1 / exp are within 1 ulp of ATen's),
+# gradients 1e-5 of their scale (sums of <= 16 products in a different association order).
+def _ref_elu_pad(x, apply_elu):
+    import torch.nn.functional as F
+    return F.pad(F.elu(x) if apply_elu else x, (1, 1, 1, 1), mode="reflect")
+
+
+def _ref_up2_cat_pad(x, skip):
+    import torch.nn.functional as F
+    u = F.interpolate(F.elu(x), scale_factor=2, mode="bilinear", align_corners=False)
+    if skip is not None:
+        u = torch.cat([u, skip], 1)
+    return F.pad(u, (1, 1, 1, 1), mode="reflect")
+
+
+@pytest.mark.parametrize("apply_elu", [True, False])
+@pytest.mark.parametrize("shape", [(2, 3, 5, 7), (1, 4, 2, 2), (3, 2, 3, 64), (2, 16, 33, 129)])
+def test_elu_pad(shape, apply_elu):
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+    rng = np.random.RandomState(sum(shape))
+    x = rng.randn(*shape).astype(np.float32) * 2.0
+    r = rng.randn(shape[0], shape[1], shape[2] + 2, shape[3] + 2).astype(np.float32)
+    xh, xo = G(x, True), T(x).requires_grad_(True)
+    yh = ops.elu_pad(xh, apply_elu)
+    yo = _ref_elu_pad(xo, apply_elu)
+    (yh * G(r)).sum().backward()
+    (yo * T(r)).sum().backward()
+    close(yh, yo, atol=2e-6, rtol=2e-6)
+    gclose(xh.grad, xo.grad, rel=1e-5)
+
+
+@pytest.mark.parametrize("shape,c2", [((2, 3, 4, 6), 2), ((1, 2, 1, 1), 1), ((2, 5, 8, 26), 0), ((1, 16, 33, 65), 7)])
+def test_elu_up2_cat_pad(shape, c2):
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+    b, c1, h, w = shape
+    rng = np.random.RandomState(sum(shape) + c2)
+    x = rng.randn(*shape).astype(np.float32) * 2.0
+    sk = rng.randn(b, c2, 2 * h, 2 * w).astype(np.float32) if c2 else None
+    r = rng.randn(b, c1 + c2, 2 * h + 2, 2 * w + 2).astype(np.float32)
+    xh, xo = G(x, True), T(x).requires_grad_(True)
+    sh = G(sk, True) if c2 else None
+    so = T(sk).requires_grad_(True) if c2 else None
+    yh = ops.elu_up2_cat_pad(xh, sh)
+    yo = _ref_up2_cat_pad(xo, so)
+    (yh * G(r)).sum().backward()
+    (yo * T(r)).sum().backward()
+    close(yh, yo, atol=2e-6, rtol=2e-6)
+    gclose(xh.grad, xo.grad, rel=1e-5)
+    if c2:
+        gclose(sh.grad, so.grad, rel=1e-6)
+
+
+def test_decoder_glue_argument_errors():
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+    from unsupervised_depth_opticalflow_egomotion_amd._lib import DfeError
+    x = torch.zeros(1, 2, 4, 4, device=dev())
+    with pytest.raises(ValueError):          # skip must be exactly twice the size
+        ops.elu_up2_cat_pad(x, torch.zeros(1, 2, 7, 8, device=dev()))
+    with pytest.raises(DfeError):            # 1-pixel planes cannot be reflection-padded
+        ops.elu_pad(torch.zeros(1, 1, 1, 5, device=dev()))
+    with pytest.raises(DfeError):            # no CPU fallback
+        ops.elu_pad(torch.zeros(1, 1, 4, 4))
+
+
+def test_depth_decoder_fused_matches_aten_graph():
+    """DepthDecoder.forward_fused (HIP glue) against the same module evaluated through ATen's
+    elu / interpolate / cat / ReflectionPad2d on the same device and weights: disparities and every parameter
+    gradient.  Both run MIOpen convolutions; tolerance 1e-5 abs on sigmoid outputs, 2e-4 of the gradient scale."""
+    from unsupervised_depth_opticalflow_egomotion_amd.networks.depth_model import DepthDecoder
+    torch.manual_seed(3)
+    enc_ch = np.array([64, 64, 128, 256, 512])
+    dec = DepthDecoder(enc_ch, scales=range(3)).to(dev())
+    b, h, w = 2, 64, 96
+    feats = [torch.randn(b, int(c), h // 2 ** (i + 1), w // 2 ** (i + 1), device=dev()).relu_() for i, c in enumerate(enc_ch)]
+    res = {}
+    for name in ("fused", "aten"):
+        dec.zero_grad(set_to_none=True)
+        fin = [f.clone().requires_grad_(True) for f in feats]
+        out = dec.forward_fused(fin) if name == "fused" else dec.forward_aten(fin)
+        loss = sum((out[s] * (s + 1.0)).mean() for s in out)
+        loss.backward()
+        res[name] = ({s: N(out[s]) for s in out}, {k: N(p.grad) for k, p in dec.named_parameters()}, [N(f.grad) for f in fin])
+    for s in res["aten"][0]:
+        close(res["fused"][0][s], res["aten"][0][s], atol=1e-5, rtol=1e-5)
+    for k in res["aten"][1]:
+        gclose(res["fused"][1][k], res["aten"][1][k], rel=2e-4, atol=1e-9)
+    for a, c in zip(res["fused"][2], res["aten"][2]):
+        gclose(a, c, rel=2e-4, atol=1e-9)
+

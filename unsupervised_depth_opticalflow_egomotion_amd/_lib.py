@@ -35,6 +35,10 @@ _SIGNATURES = {
     "dfe_pose_partials_floats": [_I, _I, _I],
     "dfe_inverse_warp2_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_inverse_warp2_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "dfe_elu_pad_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "dfe_elu_pad_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dfe_elu_up2_cat_pad_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dfe_elu_up2_cat_pad_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_rigid_flow_fwd": [_P, _P, _P, _I, _I, _I, _P],
     "dfe_rigid_flow_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "dfe_ssim_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],

@@ -1,0 +1,189 @@
+// Glue of the depth decoder between its MIOpen convolutions (depth_model.py:60-211 of the reference):
+//   ConvBlock = Conv3x3(ReflectionPad2d(1) + conv) + ELU;  decoder stage = ConvBlock, bilinear x2, cat(skip), ConvBlock.
+// In ATen that glue is elu -> upsample_bilinear2d -> cat -> reflection_pad2d (and the four backward kernels plus
+// the slice adds), each a full pass over the widest activations of the model.  Two fused passes replace it:
+//   dfe_elu_pad_*          p = reflect_pad1(elu(x))                               (elu optional)
+//   dfe_elu_up2_cat_pad_*  p = reflect_pad1(cat(bilinear_x2(elu(x)), skip))       (skip optional)
+// Both read the convolution output once and write the next convolution's padded input once; the backward passes
+// are gathers (no atomics: bitwise reproducible).  Bound: HBM (1 read + 1 write per element, 4 B each).
+// Arithmetic follows ATen's CPU kernels: elu(x) = x > 0 ? x : expm1(x); elu'(x) = x > 0 ? 1 : exp(x);
+// bilinear x2 with align_corners=False: src = max(0.5*(dst+0.5)-0.5, 0), (v0*l0 + v1*l1) horizontally first.
+#include "dfe_internal.h"
+#include <hip/hip_runtime.h>
+
+namespace dfe {
+
+__device__ __forceinline__ float elu1(float v) { return v > 0.0f ? v : expm1f(v); }
+__device__ __forceinline__ float elu1_grad(float v) { return v > 0.0f ? 1.0f : expf(v); }
+__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// taps of F.interpolate(scale_factor=2, bilinear, align_corners=False) at destination index d (source length n)
+__device__ __forceinline__ void up2_tap(int d, int n, int& i0, int& i1, float& l0, float& l1) {
+  const float s = fmaxf(0.5f * (static_cast<float>(d) + 0.5f) - 0.5f, 0.0f);
+  i0 = static_cast<int>(s);
+  i1 = min(i0 + 1, n - 1);
+  l1 = s - static_cast<float>(i0);
+  l0 = 1.0f - l1;
+}
+
+// adjoint of reflect_pad1 at unpadded (y, x) of an H x W plane: sum of the padded-plane entries that mirror onto it
+__device__ __forceinline__ float pad_adjoint(const float* __restrict__ gp, int y, int x, int H, int W) {
+  const int Wp = W + 2;
+  int ry[3], rx[3], ny = 1, nx = 1;
+  ry[0] = y + 1; rx[0] = x + 1;
+  if (y == 1) ry[ny++] = 0;
+  if (y == H - 2) ry[ny++] = H + 1;
+  if (x == 1) rx[nx++] = 0;
+  if (x == W - 2) rx[nx++] = W + 1;
+  float s = 0.0f;
+  for (int a = 0; a < ny; ++a)
+    for (int b = 0; b < nx; ++b) s += gp[static_cast<long>(ry[a]) * Wp + rx[b]];
+  return s;
+}
+
+// ---------------------------------------------------------------- p = pad(elu(x))
+// grid: x over the elements of one padded plane, y = plane (b*C + c)
+__global__ void __launch_bounds__(256) k_elu_pad_fwd(const float* __restrict__ x, float* __restrict__ out, int H, int W, int elu) {
+  const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= static_cast<unsigned>((H + 2) * (W + 2))) return;
+  const int oy = e / static_cast<unsigned>(W + 2), ox = e - oy * (W + 2);
+  const long pl = blockIdx.y;
+  const float v = x[(pl * H + reflect1(oy - 1, H)) * W + reflect1(ox - 1, W)];
+  out[(pl * (H + 2) + oy) * (W + 2) + ox] = elu ? elu1(v) : v;
+}
+
+__global__ void __launch_bounds__(256) k_elu_pad_bwd(const float* __restrict__ x, const float* __restrict__ gp,
+                                                     float* __restrict__ gx, int H, int W, int elu) {
+  const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= static_cast<unsigned>(H * W)) return;
+  const int iy = e / static_cast<unsigned>(W), ix = e - iy * W;
+  const long pl = blockIdx.y;
+  const float g = pad_adjoint(gp + pl * (H + 2) * (W + 2), iy, ix, H, W);
+  const long o = (pl * H + iy) * W + ix;
+  gx[o] = elu ? g * elu1_grad(x[o]) : g;
+}
+
+// ---------------------------------------------------------------- p = pad(cat(up2(elu(x)), skip))
+// x [B,C1,h,w], skip [B,C2,2h,2w] (C2 may be 0), out [B,C1+C2,2h+2,2w+2]
+// grid: x over the elements of one padded plane, y = b*(C1+C2) + c
+__global__ void __launch_bounds__(256) k_elu_up2_cat_pad_fwd(const float* __restrict__ x, const float* __restrict__ skip,
+                                                             float* __restrict__ out, int C1, int C2, int h, int w) {
+  const int H = 2 * h, W = 2 * w;
+  const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= static_cast<unsigned>((H + 2) * (W + 2))) return;
+  const int oy = e / static_cast<unsigned>(W + 2), ox = e - oy * (W + 2);
+  const int C = C1 + C2;
+  const int b = blockIdx.y / C, c = blockIdx.y - b * C;
+  const int y = reflect1(oy - 1, H), xx = reflect1(ox - 1, W);
+  float v;
+  if (c < C1) {
+    int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+    up2_tap(y, h, y0, y1, ly0, ly1);
+    up2_tap(xx, w, x0, x1, lx0, lx1);
+    const float* p = x + (static_cast<long>(b) * C1 + c) * h * w;
+    const float* r0 = p + static_cast<long>(y0) * w;
+    const float* r1 = p + static_cast<long>(y1) * w;
+    v = ly0 * (lx0 * elu1(r0[x0]) + lx1 * elu1(r0[x1])) + ly1 * (lx0 * elu1(r1[x0]) + lx1 * elu1(r1[x1]));
+  } else {
+    v = skip[((static_cast<long>(b) * C2 + (c - C1)) * H + y) * W + xx];
+  }
+  out[(static_cast<long>(blockIdx.y) * (H + 2) + oy) * (W + 2) + ox] = v;
+}
+
+// gradient wrt x: thread per low-res element; the <= 4x4 full-res outputs whose taps touch it, each through the
+// adjoint of the reflection pad.  grid: x over the low-res plane, y = b*C1 + c
+__global__ void __launch_bounds__(256) k_elu_up2_cat_pad_bwd_x(const float* __restrict__ x, const float* __restrict__ gp,
+                                                               float* __restrict__ gx, int C1, int C2, int h, int w) {
+  const int H = 2 * h, W = 2 * w;
+  const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= static_cast<unsigned>(h * w)) return;
+  const int i = e / static_cast<unsigned>(w), j = e - i * w;
+  const int b = blockIdx.y / C1, c = blockIdx.y - b * C1;
+  const float* g = gp + (static_cast<long>(b) * (C1 + C2) + c) * (H + 2) * (W + 2);
+  float wy[4], wx[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int a0, a1; float l0, l1;
+    const int y = 2 * i - 1 + k;
+    up2_tap(min(max(y, 0), H - 1), h, a0, a1, l0, l1);
+    wy[k] = (y >= 0 && y < H) ? ((a0 == i ? l0 : 0.0f) + (a1 == i ? l1 : 0.0f)) : 0.0f;
+    const int xq = 2 * j - 1 + k;
+    up2_tap(min(max(xq, 0), W - 1), w, a0, a1, l0, l1);
+    wx[k] = (xq >= 0 && xq < W) ? ((a0 == j ? l0 : 0.0f) + (a1 == j ? l1 : 0.0f)) : 0.0f;
+  }
+  float total = 0.0f;
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky) {
+    if (wy[ky] == 0.0f) continue;
+    float acc = 0.0f;
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx)
+      if (wx[kx] != 0.0f) acc += wx[kx] * pad_adjoint(g, 2 * i - 1 + ky, 2 * j - 1 + kx, H, W);
+    total += wy[ky] * acc;
+  }
+  const long o = ((static_cast<long>(b) * C1 + c) * h + i) * w + j;
+  gx[o] = total * elu1_grad(x[o]);
+}
+
+// gradient wrt skip: adjoint of the pad only.  grid: x over the plane, y = b*C2 + c
+__global__ void __launch_bounds__(256) k_cat_pad_bwd_skip(const float* __restrict__ gp, float* __restrict__ gskip,
+                                                          int C1, int C2, int H, int W) {
+  const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= static_cast<unsigned>(H * W)) return;
+  const int iy = e / static_cast<unsigned>(W), ix = e - iy * W;
+  const int b = blockIdx.y / C2, c = blockIdx.y - b * C2;
+  const float* g = gp + (static_cast<long>(b) * (C1 + C2) + C1 + c) * (H + 2) * (W + 2);
+  gskip[(static_cast<long>(blockIdx.y) * H + iy) * W + ix] = pad_adjoint(g, iy, ix, H, W);
+}
+
+}  // namespace dfe
+
+#define DFE_LAUNCH_CHECK() do { if (hipGetLastError() != hipSuccess) return DFE_ERR_LAUNCH; } while (0)
+
+using namespace dfe;
+
+static inline bool grid_ok(long plane_elems, long planes) { return plane_elems < (1L << 31) && planes <= 65535; }
+static inline unsigned nblk(long n) { return static_cast<unsigned>((n + 255) / 256); }
+
+extern "C" int dfe_elu_pad_fwd(const float* x, float* out, int B, int C, int H, int W, int apply_elu, void* stream) {
+  if (!x || !out) return DFE_ERR_NULL;
+  if (B <= 0 || C <= 0 || H < 2 || W < 2 || !grid_ok((H + 2L) * (W + 2L), static_cast<long>(B) * C)) return DFE_ERR_DIMS;
+  k_elu_pad_fwd<<<dim3(nblk((H + 2L) * (W + 2L)), B * C), 256, 0, static_cast<hipStream_t>(stream)>>>(x, out, H, W, apply_elu);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+extern "C" int dfe_elu_pad_bwd(const float* x, const float* gout, float* gx, int B, int C, int H, int W, int apply_elu,
+                               void* stream) {
+  if (!gout || !gx || (apply_elu && !x)) return DFE_ERR_NULL;
+  if (B <= 0 || C <= 0 || H < 2 || W < 2 || !grid_ok((H + 2L) * (W + 2L), static_cast<long>(B) * C)) return DFE_ERR_DIMS;
+  k_elu_pad_bwd<<<dim3(nblk(static_cast<long>(H) * W), B * C), 256, 0, static_cast<hipStream_t>(stream)>>>(x, gout, gx, H, W, apply_elu);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+extern "C" int dfe_elu_up2_cat_pad_fwd(const float* x, const float* skip, float* out, int B, int C1, int C2, int h, int w,
+                                       void* stream) {
+  if (!x || !out || (C2 > 0 && !skip)) return DFE_ERR_NULL;
+  if (B <= 0 || C1 <= 0 || C2 < 0 || h < 1 || w < 1 || !grid_ok((2L * h + 2) * (2L * w + 2), static_cast<long>(B) * (C1 + C2))) return DFE_ERR_DIMS;
+  k_elu_up2_cat_pad_fwd<<<dim3(nblk((2L * h + 2) * (2L * w + 2)), B * (C1 + C2)), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      x, skip, out, C1, C2, h, w);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+extern "C" int dfe_elu_up2_cat_pad_bwd(const float* x, const float* gout, float* gx, float* gskip, int B, int C1, int C2,
+                                       int h, int w, void* stream) {
+  if (!x || !gout || (!gx && !gskip)) return DFE_ERR_NULL;
+  if (B <= 0 || C1 <= 0 || C2 < 0 || h < 1 || w < 1 || !grid_ok((2L * h + 2) * (2L * w + 2), static_cast<long>(B) * (C1 + C2))) return DFE_ERR_DIMS;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (gx) {
+    k_elu_up2_cat_pad_bwd_x<<<dim3(nblk(static_cast<long>(h) * w), B * C1), 256, 0, st>>>(x, gout, gx, C1, C2, h, w);
+    DFE_LAUNCH_CHECK();
+  }
+  if (gskip && C2 > 0) {
+    k_cat_pad_bwd_skip<<<dim3(nblk(4L * h * w), B * C2), 256, 0, st>>>(gout, gskip, C1, C2, 2 * h, 2 * w);
+    DFE_LAUNCH_CHECK();
+  }
+  return DFE_OK;
+}

@@ -55,7 +55,7 @@ def _split_frames(images):
 
 
 def _zeros2(dev):
-    return torch.zeros([2]).to(dev).requires_grad_()
+    return torch.zeros([2], device=dev).requires_grad_()   # device-side fill (no H2D copy: capturable in a hipGraph)
 
 
 class Model_geometry(LossTerms, nn.Module):

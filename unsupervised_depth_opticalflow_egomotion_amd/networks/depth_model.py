@@ -68,6 +68,10 @@ class DepthDecoder(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     def forward(self, feats):
+        return self.forward_fused(feats) if feats[-1].is_cuda else self.forward_aten(feats)
+
+    def forward_aten(self, feats):
+        """The module graph as written (host tensors: the CPU baseline and the CPU-side tests)."""
         out = {}
         x = feats[-1]
         for scale in range(4, -1, -1):
@@ -79,6 +83,24 @@ class DepthDecoder(nn.Module):
             x = blk[1](x)
             if scale in self.scales:
                 out[scale] = self.sigmoid(self.dispconvs[self.scales.index(scale)](x))
+        return out
+
+    def forward_fused(self, feats):
+        """Same graph on the GPU: the ELU / bilinear x2 / cat / reflection-pad glue between the MIOpen convolutions
+        runs as two fused HIP passes (ops.elu_pad, ops.elu_up2_cat_pad); the convolutions are applied to the padded
+        tensors directly.  ``c`` always holds a convolution output *before* its ELU."""
+        from .. import ops
+        out = {}
+        p = ops.elu_pad(feats[-1], apply_elu=False)              # encoder output: already activated
+        for scale in range(4, -1, -1):
+            blk = self.upconvs[4 - scale]
+            a = blk[0].conv.conv(p)
+            q = ops.elu_up2_cat_pad(a, feats[scale - 1] if scale > 0 else None)
+            c = blk[1].conv.conv(q)
+            if scale in self.scales or scale > 0:
+                p = ops.elu_pad(c, apply_elu=True)               # shared by the disparity head and the next stage
+            if scale in self.scales:
+                out[scale] = self.sigmoid(self.dispconvs[self.scales.index(scale)].conv(p))
         return out
 
 

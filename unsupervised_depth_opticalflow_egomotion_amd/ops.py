@@ -254,3 +254,75 @@ def resize(img, out_hw, mode):
     check(lib.dfe_resize(ptr(img), ptr(out), B * C, H, W, oh, ow, {"bilinear": 0, "area": 1}[mode], stream_ptr()),
           "dfe_resize")
     return out
+
+
+# --------------------------------------------------------------------------- depth-decoder glue
+class EluPadFn(torch.autograd.Function):
+    """reflect_pad1(elu(x)) (elu optional): the input of a Conv3x3 whose producer is a ConvBlock (depth_model.py)."""
+
+    @staticmethod
+    def forward(ctx, x, apply_elu):
+        lib = get_lib()
+        x = f32c(x)
+        B, C, H, W = x.shape
+        out = torch.empty(B, C, H + 2, W + 2, device=x.device)
+        check(lib.dfe_elu_pad_fwd(ptr(x), ptr(out), B, C, H, W, int(apply_elu), stream_ptr()), "dfe_elu_pad_fwd")
+        ctx.apply_elu = int(apply_elu)
+        ctx.shape = (B, C, H, W)
+        ctx.save_for_backward(x if apply_elu else x.new_empty(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = get_lib()
+        (x,) = ctx.saved_tensors
+        B, C, H, W = ctx.shape
+        gout = f32c(gout)
+        gx = torch.empty(B, C, H, W, device=gout.device)
+        check(lib.dfe_elu_pad_bwd(ptr(x) if ctx.apply_elu else None, ptr(gout), ptr(gx), B, C, H, W, ctx.apply_elu,
+                                  stream_ptr()), "dfe_elu_pad_bwd")
+        return gx, None
+
+
+class EluUp2CatPadFn(torch.autograd.Function):
+    """reflect_pad1(cat(bilinear_x2(elu(x)), skip)): one decoder stage's glue (depth_model.py: upsample + cat + pad)."""
+
+    @staticmethod
+    def forward(ctx, x, skip):
+        lib = get_lib()
+        x = f32c(x)
+        B, C1, h, w = x.shape
+        C2 = 0
+        if skip is not None:
+            skip = f32c(skip)
+            C2 = skip.shape[1]
+            if tuple(skip.shape) != (B, C2, 2 * h, 2 * w):
+                raise ValueError("skip must be [B,C2,2h,2w] = %s, got %s" % ((B, C2, 2 * h, 2 * w), tuple(skip.shape)))
+        out = torch.empty(B, C1 + C2, 2 * h + 2, 2 * w + 2, device=x.device)
+        check(lib.dfe_elu_up2_cat_pad_fwd(ptr(x), ptr(skip), ptr(out), B, C1, C2, h, w, stream_ptr()),
+              "dfe_elu_up2_cat_pad_fwd")
+        ctx.save_for_backward(x)
+        ctx.dims = (B, C1, C2, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = get_lib()
+        (x,) = ctx.saved_tensors
+        B, C1, C2, h, w = ctx.dims
+        gout = f32c(gout)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gskip = torch.empty(B, C2, 2 * h, 2 * w, device=x.device) if (C2 > 0 and ctx.needs_input_grad[1]) else None
+        if gx is None and gskip is None:
+            return None, None
+        check(lib.dfe_elu_up2_cat_pad_bwd(ptr(x), ptr(gout), ptr(gx), ptr(gskip), B, C1, C2, h, w, stream_ptr()),
+              "dfe_elu_up2_cat_pad_bwd")
+        return gx, gskip
+
+
+def elu_pad(x, apply_elu=True):
+    return EluPadFn.apply(x, bool(apply_elu))
+
+
+def elu_up2_cat_pad(x, skip=None):
+    return EluUp2CatPadFn.apply(x, skip)
