@@ -105,6 +105,18 @@ int dfe_elu_up2_cat_pad_fwd(const float* x, const float* skip, float* out, int B
 int dfe_elu_up2_cat_pad_bwd(const float* x, const float* gout, float* gx, float* gskip, int B, int C1, int C2, int h, int w,
                             void* stream);
 
+/* ---- convolution epilogue of the flow nets (net_utils.py conv() = Conv2d(bias) + LeakyReLU(0.1),
+ * feature_pyramid.py:7-36, pwc_tf.py:16-95): the convolution itself runs on MIOpen *without* its bias, then
+ * dfe_bias_act_fwd: z [B,C,H,W] <- act(z + bias[c]) in place; act(v) = v > 0 ? v : slope*v (0.1 LeakyReLU, 0 ReLU, 1 none);
+ *                   bias may be NULL.
+ * dfe_bias_act_bwd: gz = gy * act'(y) (decided on the sign of the output y), gbias[c] = sum_{b,h,w} gz (gbias may be NULL).
+ *                   gy may be a channel slice of a wider tensor: element (b,c,i) at gy + b*gy_batch_stride + c*H*W + i.
+ *                   partials: dfe_bias_act_partials_floats(B,C,H,W) floats of scratch (needed when gbias != NULL). */
+long dfe_bias_act_partials_floats(int B, int C, int H, int W);
+int dfe_bias_act_fwd(float* z, const float* bias, int B, int C, int H, int W, float slope, void* stream);
+int dfe_bias_act_bwd(const float* y, const float* gy, long gy_batch_stride, float* gz, float* gbias, float* partials,
+                     int B, int C, int H, int W, float slope, void* stream);
+
 /* ---- fused loss stack: everything from model_geometry.py:797 to :951 given the nets' outputs ---
  * One call computes the active loss_pack vectors of Model_geometry.forward (mode 0) for a batch:
  * pyramids (:65-72,:91), rigid view synthesis (:80-103), texture / occlusion / validity / dynamic

@@ -322,3 +322,63 @@ def test_depth_decoder_fused_matches_aten_graph():
     for a, c in zip(res["fused"][2], res["aten"][2]):
         gclose(a, c, rel=2e-4, atol=1e-9)
 
+
+
+# ---------------------------------------------------------------------------------------------- conv epilogue
+@pytest.mark.parametrize("slope", [0.1, 0.0, 1.0])
+@pytest.mark.parametrize("shape", [(2, 5, 8, 26), (1, 3, 7, 9), (4, 16, 64, 208), (2, 2, 1, 1)])
+def test_bias_act(shape, slope):
+    """act(z + bias) in place and its backward (gz, gbias) against F.leaky_relu(z + bias) on the CPU: values are the
+    same two IEEE operations (exact), gz exact, gbias a sum in a different order (1e-5 of its scale)."""
+    import torch.nn.functional as F
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+    rng = np.random.RandomState(sum(shape))
+    z = rng.randn(*shape).astype(np.float32)
+    bias = rng.randn(shape[1]).astype(np.float32)
+    r = rng.randn(*shape).astype(np.float32)
+    zh, bh = G(z, True), G(bias, True)
+    zo, bo = T(z).requires_grad_(True), T(bias).requires_grad_(True)
+    yh = ops.bias_act(zh * 1.0, bh, slope)           # * 1.0: the op works in place on a non-leaf tensor
+    yo = F.leaky_relu(zo + bo[None, :, None, None], slope)
+    (yh * G(r)).sum().backward()
+    (yo * T(r)).sum().backward()
+    np.testing.assert_array_equal(N(yh), N(yo))
+    np.testing.assert_array_equal(N(zh.grad), N(zo.grad))
+    gclose(bh.grad, bo.grad, rel=1e-5, atol=1e-6)
+
+
+def test_bias_act_reads_cat_gradient_slices_in_place():
+    """The gradient arriving from a torch.cat is a channel slice of a wider tensor: same result as the contiguous path."""
+    import torch.nn.functional as F
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+    rng = np.random.RandomState(5)
+    z, other, bias = rng.randn(2, 4, 8, 12).astype(np.float32), rng.randn(2, 3, 8, 12).astype(np.float32), rng.randn(4).astype(np.float32)
+    r = rng.randn(2, 7, 8, 12).astype(np.float32)
+    zh, bh = G(z, True), G(bias, True)
+    yh = torch.cat([G(other), ops.bias_act(zh * 1.0, bh, 0.1)], 1)
+    (yh * G(r)).sum().backward()
+    zo, bo = T(z).requires_grad_(True), T(bias).requires_grad_(True)
+    yo = torch.cat([T(other), F.leaky_relu(zo + bo[None, :, None, None], 0.1)], 1)
+    (yo * T(r)).sum().backward()
+    np.testing.assert_array_equal(N(zh.grad), N(zo.grad))
+    gclose(bh.grad, bo.grad, rel=1e-5, atol=1e-6)
+
+
+def test_conv_act_module_matches_aten():
+    """net_utils.conv() on the GPU (MIOpen conv without bias + HIP epilogue) against the same module through ATen's
+    conv + LeakyReLU on the same device: output 1e-5, weight / bias / input gradients 2e-4 of their scale."""
+    import torch.nn as nn
+    from unsupervised_depth_opticalflow_egomotion_amd.structures.net_utils import conv
+    torch.manual_seed(1)
+    m = conv(12, 20, kernel_size=3, stride=1, padding=2, dilation=2).to(dev())
+    x = torch.randn(2, 12, 32, 52, device=dev())
+    res = []
+    for fused in (True, False):
+        m.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        y = m(xi) if fused else nn.Sequential.forward(m, xi)
+        (y * y).mean().backward()
+        res.append((N(y), N(m[0].weight.grad), N(m[0].bias.grad), N(xi.grad)))
+    close(res[0][0], res[1][0], atol=1e-5, rtol=1e-5)
+    for a, b in zip(res[0][1:], res[1][1:]):
+        gclose(a, b, rel=2e-4, atol=1e-9)

@@ -35,6 +35,9 @@ _SIGNATURES = {
     "dfe_pose_partials_floats": [_I, _I, _I],
     "dfe_inverse_warp2_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_inverse_warp2_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "dfe_bias_act_partials_floats": [_I, _I, _I, _I],
+    "dfe_bias_act_fwd": [_P, _P, _I, _I, _I, _I, ctypes.c_float, _P],
+    "dfe_bias_act_bwd": [_P, _P, ctypes.c_long, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, _P],
     "dfe_elu_pad_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_elu_pad_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_elu_up2_cat_pad_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -54,6 +57,7 @@ _SIGNATURES = {
     "dfe_geom_loss_bwd_profiled": [_P, _P, _P],
 }
 _RESTYPES = {"dfe_error_string": ctypes.c_char_p, "dfe_geom_workspace_floats": ctypes.c_long,
+             "dfe_bias_act_partials_floats": ctypes.c_long,
              "dfe_geom_maskpack_offset_bytes": ctypes.c_long}
 
 
@@ -97,8 +101,9 @@ def check(code: int, what: str = ""):
         raise DfeError("%s failed: %s (code %d)" % (what or "dfe call", msg.decode() if msg else "?", code))
 
 
-def ptr(t):
-    """Device pointer of a contiguous fp32 HIP tensor (None -> NULL)."""
+def ptr(t, strided=False):
+    """Device pointer of a contiguous fp32 HIP tensor (None -> NULL).  ``strided=True`` skips the contiguity check
+    for entry points that take explicit strides."""
     if t is None:
         return None
     if not isinstance(t, torch.Tensor):
@@ -108,7 +113,7 @@ def ptr(t):
                        "fallback in the product path" % t.device)
     if t.dtype != torch.float32 and t.dtype != torch.uint8 and t.dtype != torch.int32:
         raise DfeError("unsupported dtype %s" % t.dtype)
-    if not t.is_contiguous():
+    if not strided and not t.is_contiguous():
         raise DfeError("tensor must be contiguous")
     return ctypes.c_void_p(t.data_ptr())
 

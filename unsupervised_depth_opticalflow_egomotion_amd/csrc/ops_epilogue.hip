@@ -1,0 +1,144 @@
+// Convolution epilogue of the flow nets (reference net_utils.py conv(): Conv2d(bias=True) + LeakyReLU(0.1), used by
+// FeaturePyramid and PWC_tf).  PyTorch-ROCm runs "conv, broadcast bias add, activation" as three passes forward and
+// "activation backward, bias-gradient reduction" as two more; here the convolution is called without its bias and
+//   dfe_bias_act_fwd   y = act(z + bias[c])            in place, one read + one write
+//   dfe_bias_act_bwd   gz = gy * act'(y);  gbias[c] = sum_{b,h,w} gz     one pass + a fixed-order final sum
+// act(v) = v > 0 ? v : slope * v  (slope 0.1 = LeakyReLU, 0 = ReLU, 1 = bias only); act' is taken from the sign of
+// the output (same decision as ATen's, which tests the input: slope >= 0 preserves the sign).
+// Bound: HBM.  The bias gradient is reduced per block and finished in a fixed order (no atomics: reproducible).
+#include "dfe_internal.h"
+#include "dfe_device.h"
+#include <hip/hip_runtime.h>
+
+namespace dfe {
+
+constexpr int EP_BLOCK = 256;
+constexpr int EP_PER_THREAD = 8;                       // elements per thread (two float4)
+constexpr int EP_CHUNK = EP_BLOCK * EP_PER_THREAD;     // elements of one (b, c) plane per block
+
+// grid: x = chunk of the plane, y = b*C + c
+template <bool VEC>
+__global__ void __launch_bounds__(EP_BLOCK) k_bias_act_fwd(float* __restrict__ z, const float* __restrict__ bias,
+                                                           int C, int HW, float slope) {
+  const int c = blockIdx.y % C;
+  const float bv = bias ? bias[c] : 0.0f;
+  float* p = z + static_cast<long>(blockIdx.y) * HW;
+  const int base = blockIdx.x * EP_CHUNK;
+  if (VEC) {
+#pragma unroll
+    for (int k = 0; k < EP_PER_THREAD / 4; ++k) {
+      const int e = base + (k * EP_BLOCK + threadIdx.x) * 4;
+      if (e < HW) {
+        float4 v = *reinterpret_cast<float4*>(p + e);
+        v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+        v.x = v.x > 0.0f ? v.x : v.x * slope; v.y = v.y > 0.0f ? v.y : v.y * slope;
+        v.z = v.z > 0.0f ? v.z : v.z * slope; v.w = v.w > 0.0f ? v.w : v.w * slope;
+        *reinterpret_cast<float4*>(p + e) = v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < EP_PER_THREAD; ++k) {
+      const int e = base + k * EP_BLOCK + threadIdx.x;
+      if (e < HW) { const float v = p[e] + bv; p[e] = v > 0.0f ? v : v * slope; }
+    }
+  }
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(EP_BLOCK) k_bias_act_bwd(const float* __restrict__ y, const float* __restrict__ gy,
+                                                           float* __restrict__ gz, float* __restrict__ part,
+                                                           int HW, long gy_plane_stride, long gy_batch_stride, int C,
+                                                           float slope) {
+  __shared__ float red[4 * (EP_BLOCK / 64)];
+  const int b = blockIdx.y / C, c = blockIdx.y - b * C;
+  const float* py = y + static_cast<long>(blockIdx.y) * HW;
+  const float* pg = gy + b * gy_batch_stride + c * gy_plane_stride;
+  float* pz = gz + static_cast<long>(blockIdx.y) * HW;
+  const int base = blockIdx.x * EP_CHUNK;
+  float acc[1] = {0.0f};
+  if (VEC) {
+#pragma unroll
+    for (int k = 0; k < EP_PER_THREAD / 4; ++k) {
+      const int e = base + (k * EP_BLOCK + threadIdx.x) * 4;
+      if (e < HW) {
+        const float4 yv = *reinterpret_cast<const float4*>(py + e);
+        float4 g = *reinterpret_cast<const float4*>(pg + e);
+        g.x = yv.x > 0.0f ? g.x : g.x * slope; g.y = yv.y > 0.0f ? g.y : g.y * slope;
+        g.z = yv.z > 0.0f ? g.z : g.z * slope; g.w = yv.w > 0.0f ? g.w : g.w * slope;
+        *reinterpret_cast<float4*>(pz + e) = g;
+        acc[0] += (g.x + g.y) + (g.z + g.w);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < EP_PER_THREAD; ++k) {
+      const int e = base + k * EP_BLOCK + threadIdx.x;
+      if (e < HW) { const float g = py[e] > 0.0f ? pg[e] : pg[e] * slope; pz[e] = g; acc[0] += g; }
+    }
+  }
+  if (part) block_sum<1>(acc, red, part + static_cast<long>(blockIdx.y) * gridDim.x + blockIdx.x);
+}
+
+// gbias[c] = sum over b, chunks of part[(b*C + c)*nchunk + chunk] in a fixed order; one wave per channel
+__global__ void __launch_bounds__(64) k_bias_grad_final(const float* __restrict__ part, float* __restrict__ gbias,
+                                                        int B, int C, int nchunk) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  float s = 0.0f;
+  for (int b = 0; b < B; ++b) {
+    const float* p = part + (static_cast<long>(b) * C + c) * nchunk;
+    for (int k = lane; k < nchunk; k += 64) s += p[k];
+  }
+  s = dpp_add<0xB1>(s); s = dpp_add<0x4E>(s); s = dpp_add<0x141>(s); s = dpp_add<0x140>(s);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 48));
+  if (lane == 0) gbias[c] = (r0 + r1) + (r2 + r3);
+}
+
+}  // namespace dfe
+
+#define DFE_LAUNCH_CHECK() do { if (hipGetLastError() != hipSuccess) return DFE_ERR_LAUNCH; } while (0)
+using namespace dfe;
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" long dfe_bias_act_partials_floats(int B, int C, int H, int W) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+  const long hw = static_cast<long>(H) * W;
+  return static_cast<long>(B) * C * ((hw + EP_CHUNK - 1) / EP_CHUNK);
+}
+
+extern "C" int dfe_bias_act_fwd(float* z, const float* bias, int B, int C, int H, int W, float slope, void* stream) {
+  if (!z) return DFE_ERR_NULL;
+  const long hw = static_cast<long>(H) * W;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || hw >= (1L << 31) || static_cast<long>(B) * C > 65535) return DFE_ERR_DIMS;
+  const dim3 g(static_cast<unsigned>((hw + EP_CHUNK - 1) / EP_CHUNK), B * C);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hw % 4 == 0 && aligned16(z)) k_bias_act_fwd<true><<<g, EP_BLOCK, 0, st>>>(z, bias, C, static_cast<int>(hw), slope);
+  else k_bias_act_fwd<false><<<g, EP_BLOCK, 0, st>>>(z, bias, C, static_cast<int>(hw), slope);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+extern "C" int dfe_bias_act_bwd(const float* y, const float* gy, long gy_batch_stride, float* gz, float* gbias,
+                                float* partials, int B, int C, int H, int W, float slope, void* stream) {
+  if (!y || !gy || !gz || (gbias && !partials)) return DFE_ERR_NULL;
+  const long hw = static_cast<long>(H) * W;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || hw >= (1L << 31) || static_cast<long>(B) * C > 65535) return DFE_ERR_DIMS;
+  if (gy_batch_stride < static_cast<long>(C) * hw) return DFE_ERR_DIMS;
+  const int nchunk = static_cast<int>((hw + EP_CHUNK - 1) / EP_CHUNK);
+  const dim3 g(nchunk, B * C);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* part = gbias ? partials : nullptr;
+  const bool vec = hw % 4 == 0 && aligned16(y) && aligned16(gy) && aligned16(gz) && gy_batch_stride % 4 == 0;
+  if (vec) k_bias_act_bwd<true><<<g, EP_BLOCK, 0, st>>>(y, gy, gz, part, static_cast<int>(hw), hw, gy_batch_stride, C, slope);
+  else k_bias_act_bwd<false><<<g, EP_BLOCK, 0, st>>>(y, gy, gz, part, static_cast<int>(hw), hw, gy_batch_stride, C, slope);
+  DFE_LAUNCH_CHECK();
+  if (gbias) {
+    k_bias_grad_final<<<C, 64, 0, st>>>(partials, gbias, B, C, nchunk);
+    DFE_LAUNCH_CHECK();
+  }
+  return DFE_OK;
+}

@@ -326,3 +326,45 @@ def elu_pad(x, apply_elu=True):
 
 def elu_up2_cat_pad(x, skip=None):
     return EluUp2CatPadFn.apply(x, skip)
+
+
+# --------------------------------------------------------------------------- convolution epilogue (bias + activation)
+class BiasActFn(torch.autograd.Function):
+    """z <- act(z + bias[c]) in place on a fresh convolution output; act(v) = v > 0 ? v : slope * v."""
+
+    @staticmethod
+    def forward(ctx, z, bias, slope):
+        lib = get_lib()
+        if not z.is_contiguous() or z.dtype != torch.float32:
+            raise _lib.DfeError("bias_act expects a contiguous fp32 convolution output")
+        B, C, H, W = z.shape
+        b = f32c(bias) if bias is not None else None
+        check(lib.dfe_bias_act_fwd(ptr(z), ptr(b), B, C, H, W, float(slope), stream_ptr()), "dfe_bias_act_fwd")
+        ctx.mark_dirty(z)
+        ctx.save_for_backward(z)
+        ctx.slope = float(slope)
+        ctx.has_bias = bias is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = get_lib()
+        (y,) = ctx.saved_tensors
+        B, C, H, W = y.shape
+        if gy.dtype != torch.float32:
+            gy = gy.float()
+        # a channel slice of a wider contiguous tensor (the gradient of a torch.cat) is read in place
+        if not (gy.stride(3) == 1 and gy.stride(2) == W and gy.stride(1) == H * W and gy.stride(0) >= C * H * W):
+            gy = gy.contiguous()
+        gz = torch.empty_like(y)
+        gb = part = None
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            gb = torch.empty(C, device=y.device, dtype=torch.float32)
+            part = torch.empty(lib.dfe_bias_act_partials_floats(B, C, H, W), device=y.device, dtype=torch.float32)
+        check(lib.dfe_bias_act_bwd(ptr(y), ptr(gy, strided=True), gy.stride(0), ptr(gz), ptr(gb), ptr(part), B, C, H, W, ctx.slope,
+                                   stream_ptr()), "dfe_bias_act_bwd")
+        return gz, gb, None
+
+
+def bias_act(z, bias, slope):
+    return BiasActFn.apply(z, bias, float(slope))

@@ -1,13 +1,27 @@
 """Reference-signature shims for core/networks/structures/net_utils.py (warp_flow :16-54,
 conv :7-11, deconv :13-14).  warp_flow runs the HIP kernel k_warp_flow_fwd/bwd."""
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import ops
 
 
+class ConvAct(nn.Sequential):
+    """Conv2d(bias=True) + LeakyReLU(slope) with the reference's child names (``.0`` = the Conv2d).  On the GPU the
+    convolution runs on MIOpen without its bias and the bias + activation epilogue is one in-place HIP pass
+    (ops.bias_act; the backward pass yields the bias gradient from the same read)."""
+
+    def forward(self, x):
+        if not x.is_cuda:
+            return super().forward(x)
+        c = self[0]
+        z = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
+        return ops.bias_act(z, c.bias, self[1].negative_slope)
+
+
 def conv(in_planes, out_planes, kernel_size=3, stride=1, padding=1, dilation=1):
     """Conv2d + LeakyReLU(0.1) block (the ``.0`` in the state-dict keys is the Conv2d)."""
-    return nn.Sequential(
+    return ConvAct(
         nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride, padding=padding,
                   dilation=dilation, bias=True),
         nn.LeakyReLU(0.1))
