@@ -95,15 +95,21 @@ int dfe_resize(const float* in, float* out, int planes, int inH, int inW, int ou
 
 /* ---- depth-decoder glue between the MIOpen convolutions (depth_model.py:60-211:
  * Conv3x3 = ReflectionPad2d(1) + conv, ConvBlock = Conv3x3 + ELU, stage = ConvBlock, bilinear x2, cat(skip), ConvBlock).
- * dfe_elu_pad:          out [B,C,H+2,W+2] = reflect_pad1(apply_elu ? elu(x) : x),  x [B,C,H,W]
- * dfe_elu_up2_cat_pad:  out [B,C1+C2,2h+2,2w+2] = reflect_pad1(cat(bilinear_x2(elu(x)), skip)),
- *                       x [B,C1,h,w] (the convolution output *before* its ELU), skip [B,C2,2h,2w] or NULL with C2 = 0.
- * Backward: gout has the padded shape; gx / gskip may be NULL when not needed (gskip ignored when C2 = 0). */
-int dfe_elu_pad_fwd(const float* x, float* out, int B, int C, int H, int W, int apply_elu, void* stream);
-int dfe_elu_pad_bwd(const float* x, const float* gout, float* gx, int B, int C, int H, int W, int apply_elu, void* stream);
-int dfe_elu_up2_cat_pad_fwd(const float* x, const float* skip, float* out, int B, int C1, int C2, int h, int w, void* stream);
-int dfe_elu_up2_cat_pad_bwd(const float* x, const float* gout, float* gx, float* gskip, int B, int C1, int C2, int h, int w,
-                            void* stream);
+ * The convolutions are called without their bias; x is such an output and ``bias`` [C] (or NULL) is added on read.
+ * dfe_elu_pad:          out [B,C,H+2,W+2] = reflect_pad1(apply_elu ? elu(x + bias) : x + bias),  x [B,C,H,W]
+ * dfe_elu_up2_cat_pad:  out [B,C1+C2,2h+2,2w+2] = reflect_pad1(cat(bilinear_x2(elu(x + bias)), skip)),
+ *                       x [B,C1,h,w], skip [B,C2,2h,2w] or NULL with C2 = 0.
+ * Backward: gout has the padded shape; gx = gradient wrt x (= wrt x + bias); gbias [C] (or NULL) = its sum over
+ * (b,h,w), which needs ``partials`` = dfe_glue_partials_floats(B,C,H,W) floats of scratch (H,W of x);
+ * gskip may be NULL (ignored when C2 = 0). */
+long dfe_glue_partials_floats(int B, int C, int H, int W);
+int dfe_elu_pad_fwd(const float* x, const float* bias, float* out, int B, int C, int H, int W, int apply_elu, void* stream);
+int dfe_elu_pad_bwd(const float* x, const float* bias, const float* gout, float* gx, float* gbias, float* partials,
+                    int B, int C, int H, int W, int apply_elu, void* stream);
+int dfe_elu_up2_cat_pad_fwd(const float* x, const float* bias, const float* skip, float* out, int B, int C1, int C2,
+                            int h, int w, void* stream);
+int dfe_elu_up2_cat_pad_bwd(const float* x, const float* bias, const float* gout, float* gx, float* gskip, float* gbias,
+                            float* partials, int B, int C1, int C2, int h, int w, void* stream);
 
 /* ---- convolution epilogue of the flow nets (net_utils.py conv() = Conv2d(bias) + LeakyReLU(0.1),
  * feature_pyramid.py:7-36, pwc_tf.py:16-95): the convolution itself runs on MIOpen *without* its bias, then

@@ -235,33 +235,42 @@ def test_degenerate_sizes():
 # Reference = the plain PyTorch fp32 composition on the CPU (what depth_model.py's ConvBlock / decoder stage does
 # between its convolutions).  Tolerance: 2e-6 abs on O(1) activations (expm1 / exp are within 1 ulp of ATen's),
 # gradients 1e-5 of their scale (sums of <= 16 products in a different association order).
-def _ref_elu_pad(x, apply_elu):
+def _ref_elu_pad(x, bias, apply_elu):
     import torch.nn.functional as F
+    if bias is not None:
+        x = x + bias[None, :, None, None]
     return F.pad(F.elu(x) if apply_elu else x, (1, 1, 1, 1), mode="reflect")
 
 
-def _ref_up2_cat_pad(x, skip):
+def _ref_up2_cat_pad(x, bias, skip):
     import torch.nn.functional as F
+    if bias is not None:
+        x = x + bias[None, :, None, None]
     u = F.interpolate(F.elu(x), scale_factor=2, mode="bilinear", align_corners=False)
     if skip is not None:
         u = torch.cat([u, skip], 1)
     return F.pad(u, (1, 1, 1, 1), mode="reflect")
 
 
+@pytest.mark.parametrize("with_bias", [True, False])
 @pytest.mark.parametrize("apply_elu", [True, False])
 @pytest.mark.parametrize("shape", [(2, 3, 5, 7), (1, 4, 2, 2), (3, 2, 3, 64), (2, 16, 33, 129)])
-def test_elu_pad(shape, apply_elu):
+def test_elu_pad(shape, apply_elu, with_bias):
     from unsupervised_depth_opticalflow_egomotion_amd import ops
     rng = np.random.RandomState(sum(shape))
     x = rng.randn(*shape).astype(np.float32) * 2.0
+    bias = rng.randn(shape[1]).astype(np.float32)
     r = rng.randn(shape[0], shape[1], shape[2] + 2, shape[3] + 2).astype(np.float32)
     xh, xo = G(x, True), T(x).requires_grad_(True)
-    yh = ops.elu_pad(xh, apply_elu)
-    yo = _ref_elu_pad(xo, apply_elu)
+    bh, bo = (G(bias, True), T(bias).requires_grad_(True)) if with_bias else (None, None)
+    yh = ops.elu_pad(xh, bh, apply_elu)
+    yo = _ref_elu_pad(xo, bo, apply_elu)
     (yh * G(r)).sum().backward()
     (yo * T(r)).sum().backward()
     close(yh, yo, atol=2e-6, rtol=2e-6)
     gclose(xh.grad, xo.grad, rel=1e-5)
+    if with_bias:
+        gclose(bh.grad, bo.grad, rel=2e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("shape,c2", [((2, 3, 4, 6), 2), ((1, 2, 1, 1), 1), ((2, 5, 8, 26), 0), ((1, 16, 33, 65), 7)])
@@ -275,14 +284,18 @@ def test_elu_up2_cat_pad(shape, c2):
     xh, xo = G(x, True), T(x).requires_grad_(True)
     sh = G(sk, True) if c2 else None
     so = T(sk).requires_grad_(True) if c2 else None
-    yh = ops.elu_up2_cat_pad(xh, sh)
-    yo = _ref_up2_cat_pad(xo, so)
+    bias = rng.randn(c1).astype(np.float32)
+    bh, bo = (G(bias, True), T(bias).requires_grad_(True)) if (c1 + c2) % 2 else (None, None)   # both variants over the cases
+    yh = ops.elu_up2_cat_pad(xh, bh, sh)
+    yo = _ref_up2_cat_pad(xo, bo, so)
     (yh * G(r)).sum().backward()
     (yo * T(r)).sum().backward()
     close(yh, yo, atol=2e-6, rtol=2e-6)
     gclose(xh.grad, xo.grad, rel=1e-5)
     if c2:
         gclose(sh.grad, so.grad, rel=1e-6)
+    if bh is not None:
+        gclose(bh.grad, bo.grad, rel=2e-5, atol=1e-6)
 
 
 def test_decoder_glue_argument_errors():
@@ -290,7 +303,7 @@ def test_decoder_glue_argument_errors():
     from unsupervised_depth_opticalflow_egomotion_amd._lib import DfeError
     x = torch.zeros(1, 2, 4, 4, device=dev())
     with pytest.raises(ValueError):          # skip must be exactly twice the size
-        ops.elu_up2_cat_pad(x, torch.zeros(1, 2, 7, 8, device=dev()))
+        ops.elu_up2_cat_pad(x, None, torch.zeros(1, 2, 7, 8, device=dev()))
     with pytest.raises(DfeError):            # 1-pixel planes cannot be reflection-padded
         ops.elu_pad(torch.zeros(1, 1, 1, 5, device=dev()))
     with pytest.raises(DfeError):            # no CPU fallback

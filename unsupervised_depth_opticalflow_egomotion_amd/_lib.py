@@ -38,10 +38,11 @@ _SIGNATURES = {
     "dfe_bias_act_partials_floats": [_I, _I, _I, _I],
     "dfe_bias_act_fwd": [_P, _P, _I, _I, _I, _I, ctypes.c_float, _P],
     "dfe_bias_act_bwd": [_P, _P, ctypes.c_long, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, _P],
-    "dfe_elu_pad_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
-    "dfe_elu_pad_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "dfe_elu_up2_cat_pad_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "dfe_elu_up2_cat_pad_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dfe_glue_partials_floats": [_I, _I, _I, _I],
+    "dfe_elu_pad_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dfe_elu_pad_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dfe_elu_up2_cat_pad_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dfe_elu_up2_cat_pad_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_rigid_flow_fwd": [_P, _P, _P, _I, _I, _I, _P],
     "dfe_rigid_flow_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "dfe_ssim_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
@@ -57,7 +58,7 @@ _SIGNATURES = {
     "dfe_geom_loss_bwd_profiled": [_P, _P, _P],
 }
 _RESTYPES = {"dfe_error_string": ctypes.c_char_p, "dfe_geom_workspace_floats": ctypes.c_long,
-             "dfe_bias_act_partials_floats": ctypes.c_long,
+             "dfe_bias_act_partials_floats": ctypes.c_long, "dfe_glue_partials_floats": ctypes.c_long,
              "dfe_geom_maskpack_offset_bytes": ctypes.c_long}
 
 

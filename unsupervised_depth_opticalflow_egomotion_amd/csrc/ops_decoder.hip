@@ -2,13 +2,17 @@
 //   ConvBlock = Conv3x3(ReflectionPad2d(1) + conv) + ELU;  decoder stage = ConvBlock, bilinear x2, cat(skip), ConvBlock.
 // In ATen that glue is elu -> upsample_bilinear2d -> cat -> reflection_pad2d (and the four backward kernels plus
 // the slice adds), each a full pass over the widest activations of the model.  Two fused passes replace it:
-//   dfe_elu_pad_*          p = reflect_pad1(elu(x))                               (elu optional)
-//   dfe_elu_up2_cat_pad_*  p = reflect_pad1(cat(bilinear_x2(elu(x)), skip))       (skip optional)
+//   dfe_elu_pad_*          p = reflect_pad1(elu(x + bias))                               (elu, bias optional)
+//   dfe_elu_up2_cat_pad_*  p = reflect_pad1(cat(bilinear_x2(elu(x + bias)), skip))       (skip, bias optional)
+// x is the convolution output *without* its bias (the convolution is called bias-free): the broadcast bias add is
+// folded into these reads and the bias gradient is a by-product of the backward pass (per-block sums finished in a
+// fixed order).
 // Both read the convolution output once and write the next convolution's padded input once; the backward passes
 // are gathers (no atomics: bitwise reproducible).  Bound: HBM (1 read + 1 write per element, 4 B each).
 // Arithmetic follows ATen's CPU kernels: elu(x) = x > 0 ? x : expm1(x); elu'(x) = x > 0 ? 1 : exp(x);
 // bilinear x2 with align_corners=False: src = max(0.5*(dst+0.5)-0.5, 0), (v0*l0 + v1*l1) horizontally first.
 #include "dfe_internal.h"
+#include "dfe_device.h"
 #include <hip/hip_runtime.h>
 
 namespace dfe {
@@ -43,31 +47,40 @@ __device__ __forceinline__ float pad_adjoint(const float* __restrict__ gp, int y
 
 // ---------------------------------------------------------------- p = pad(elu(x))
 // grid: x over the elements of one padded plane, y = plane (b*C + c)
-__global__ void __launch_bounds__(256) k_elu_pad_fwd(const float* __restrict__ x, float* __restrict__ out, int H, int W, int elu) {
+__global__ void __launch_bounds__(256) k_elu_pad_fwd(const float* __restrict__ x, const float* __restrict__ bias,
+                                                     float* __restrict__ out, int C, int H, int W, int elu) {
   const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= static_cast<unsigned>((H + 2) * (W + 2))) return;
   const int oy = e / static_cast<unsigned>(W + 2), ox = e - oy * (W + 2);
   const long pl = blockIdx.y;
-  const float v = x[(pl * H + reflect1(oy - 1, H)) * W + reflect1(ox - 1, W)];
+  const float v = x[(pl * H + reflect1(oy - 1, H)) * W + reflect1(ox - 1, W)] + (bias ? bias[blockIdx.y % C] : 0.0f);
   out[(pl * (H + 2) + oy) * (W + 2) + ox] = elu ? elu1(v) : v;
 }
 
-__global__ void __launch_bounds__(256) k_elu_pad_bwd(const float* __restrict__ x, const float* __restrict__ gp,
-                                                     float* __restrict__ gx, int H, int W, int elu) {
+__global__ void __launch_bounds__(256) k_elu_pad_bwd(const float* __restrict__ x, const float* __restrict__ bias,
+                                                     const float* __restrict__ gp, float* __restrict__ gx,
+                                                     float* __restrict__ part, int C, int H, int W, int elu) {
+  __shared__ float red[4 * 4];
   const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= static_cast<unsigned>(H * W)) return;
-  const int iy = e / static_cast<unsigned>(W), ix = e - iy * W;
-  const long pl = blockIdx.y;
-  const float g = pad_adjoint(gp + pl * (H + 2) * (W + 2), iy, ix, H, W);
-  const long o = (pl * H + iy) * W + ix;
-  gx[o] = elu ? g * elu1_grad(x[o]) : g;
+  float acc[1] = {0.0f};
+  if (e < static_cast<unsigned>(H * W)) {
+    const int iy = e / static_cast<unsigned>(W), ix = e - iy * W;
+    const long pl = blockIdx.y;
+    float g = pad_adjoint(gp + pl * (H + 2) * (W + 2), iy, ix, H, W);
+    const long o = (pl * H + iy) * W + ix;
+    if (elu) g *= elu1_grad(x[o] + (bias ? bias[blockIdx.y % C] : 0.0f));
+    gx[o] = g;
+    acc[0] = g;
+  }
+  if (part) block_sum<1>(acc, red, part + static_cast<long>(blockIdx.y) * gridDim.x + blockIdx.x);
 }
 
 // ---------------------------------------------------------------- p = pad(cat(up2(elu(x)), skip))
 // x [B,C1,h,w], skip [B,C2,2h,2w] (C2 may be 0), out [B,C1+C2,2h+2,2w+2]
 // grid: x over the elements of one padded plane, y = b*(C1+C2) + c
-__global__ void __launch_bounds__(256) k_elu_up2_cat_pad_fwd(const float* __restrict__ x, const float* __restrict__ skip,
-                                                             float* __restrict__ out, int C1, int C2, int h, int w) {
+__global__ void __launch_bounds__(256) k_elu_up2_cat_pad_fwd(const float* __restrict__ x, const float* __restrict__ bias,
+                                                             const float* __restrict__ skip, float* __restrict__ out,
+                                                             int C1, int C2, int h, int w) {
   const int H = 2 * h, W = 2 * w;
   const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= static_cast<unsigned>((H + 2) * (W + 2))) return;
@@ -83,7 +96,8 @@ __global__ void __launch_bounds__(256) k_elu_up2_cat_pad_fwd(const float* __rest
     const float* p = x + (static_cast<long>(b) * C1 + c) * h * w;
     const float* r0 = p + static_cast<long>(y0) * w;
     const float* r1 = p + static_cast<long>(y1) * w;
-    v = ly0 * (lx0 * elu1(r0[x0]) + lx1 * elu1(r0[x1])) + ly1 * (lx0 * elu1(r1[x0]) + lx1 * elu1(r1[x1]));
+    const float bv = bias ? bias[c] : 0.0f;
+    v = ly0 * (lx0 * elu1(r0[x0] + bv) + lx1 * elu1(r0[x1] + bv)) + ly1 * (lx0 * elu1(r1[x0] + bv) + lx1 * elu1(r1[x1] + bv));
   } else {
     v = skip[((static_cast<long>(b) * C2 + (c - C1)) * H + y) * W + xx];
   }
@@ -92,11 +106,14 @@ __global__ void __launch_bounds__(256) k_elu_up2_cat_pad_fwd(const float* __rest
 
 // gradient wrt x: thread per low-res element; the <= 4x4 full-res outputs whose taps touch it, each through the
 // adjoint of the reflection pad.  grid: x over the low-res plane, y = b*C1 + c
-__global__ void __launch_bounds__(256) k_elu_up2_cat_pad_bwd_x(const float* __restrict__ x, const float* __restrict__ gp,
-                                                               float* __restrict__ gx, int C1, int C2, int h, int w) {
+__global__ void __launch_bounds__(256) k_elu_up2_cat_pad_bwd_x(const float* __restrict__ x, const float* __restrict__ bias,
+                                                               const float* __restrict__ gp, float* __restrict__ gx,
+                                                               float* __restrict__ part, int C1, int C2, int h, int w) {
+  __shared__ float red[4 * 4];
   const int H = 2 * h, W = 2 * w;
   const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= static_cast<unsigned>(h * w)) return;
+  float acc[1] = {0.0f};
+  if (e < static_cast<unsigned>(h * w)) {
   const int i = e / static_cast<unsigned>(w), j = e - i * w;
   const int b = blockIdx.y / C1, c = blockIdx.y - b * C1;
   const float* g = gp + (static_cast<long>(b) * (C1 + C2) + c) * (H + 2) * (W + 2);
@@ -122,7 +139,27 @@ __global__ void __launch_bounds__(256) k_elu_up2_cat_pad_bwd_x(const float* __re
     total += wy[ky] * acc;
   }
   const long o = ((static_cast<long>(b) * C1 + c) * h + i) * w + j;
-  gx[o] = total * elu1_grad(x[o]);
+  acc[0] = total * elu1_grad(x[o] + (bias ? bias[c] : 0.0f));
+  gx[o] = acc[0];
+  }
+  if (part) block_sum<1>(acc, red, part + static_cast<long>(blockIdx.y) * gridDim.x + blockIdx.x);
+}
+
+// gbias[c] = sum over b, blocks of part[(b*C + c)*nblk + k] in a fixed order; one wave per channel
+__global__ void __launch_bounds__(64) k_glue_bias_final(const float* __restrict__ part, float* __restrict__ gbias,
+                                                        int B, int C, int nblk) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  float s = 0.0f;
+  for (int b = 0; b < B; ++b) {
+    const float* p = part + (static_cast<long>(b) * C + c) * nblk;
+    for (int k = lane; k < nblk; k += 64) s += p[k];
+  }
+  s = dpp_add<0xB1>(s); s = dpp_add<0x4E>(s); s = dpp_add<0x141>(s); s = dpp_add<0x140>(s);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 48));
+  if (lane == 0) gbias[c] = (r0 + r1) + (r2 + r3);
 }
 
 // gradient wrt skip: adjoint of the pad only.  grid: x over the plane, y = b*C2 + c
@@ -145,41 +182,58 @@ using namespace dfe;
 static inline bool grid_ok(long plane_elems, long planes) { return plane_elems < (1L << 31) && planes <= 65535; }
 static inline unsigned nblk(long n) { return static_cast<unsigned>((n + 255) / 256); }
 
-extern "C" int dfe_elu_pad_fwd(const float* x, float* out, int B, int C, int H, int W, int apply_elu, void* stream) {
+extern "C" long dfe_glue_partials_floats(int B, int C, int H, int W) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+  return static_cast<long>(B) * C * nblk(static_cast<long>(H) * W);
+}
+
+extern "C" int dfe_elu_pad_fwd(const float* x, const float* bias, float* out, int B, int C, int H, int W, int apply_elu,
+                               void* stream) {
   if (!x || !out) return DFE_ERR_NULL;
   if (B <= 0 || C <= 0 || H < 2 || W < 2 || !grid_ok((H + 2L) * (W + 2L), static_cast<long>(B) * C)) return DFE_ERR_DIMS;
-  k_elu_pad_fwd<<<dim3(nblk((H + 2L) * (W + 2L)), B * C), 256, 0, static_cast<hipStream_t>(stream)>>>(x, out, H, W, apply_elu);
+  k_elu_pad_fwd<<<dim3(nblk((H + 2L) * (W + 2L)), B * C), 256, 0, static_cast<hipStream_t>(stream)>>>(x, bias, out, C, H, W, apply_elu);
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
 
-extern "C" int dfe_elu_pad_bwd(const float* x, const float* gout, float* gx, int B, int C, int H, int W, int apply_elu,
-                               void* stream) {
-  if (!gout || !gx || (apply_elu && !x)) return DFE_ERR_NULL;
+extern "C" int dfe_elu_pad_bwd(const float* x, const float* bias, const float* gout, float* gx, float* gbias, float* partials,
+                               int B, int C, int H, int W, int apply_elu, void* stream) {
+  if (!gout || !gx || (apply_elu && !x) || (gbias && !partials)) return DFE_ERR_NULL;
   if (B <= 0 || C <= 0 || H < 2 || W < 2 || !grid_ok((H + 2L) * (W + 2L), static_cast<long>(B) * C)) return DFE_ERR_DIMS;
-  k_elu_pad_bwd<<<dim3(nblk(static_cast<long>(H) * W), B * C), 256, 0, static_cast<hipStream_t>(stream)>>>(x, gout, gx, H, W, apply_elu);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned nb = nblk(static_cast<long>(H) * W);
+  k_elu_pad_bwd<<<dim3(nb, B * C), 256, 0, st>>>(x, bias, gout, gx, gbias ? partials : nullptr, C, H, W, apply_elu);
   DFE_LAUNCH_CHECK();
+  if (gbias) {
+    k_glue_bias_final<<<C, 64, 0, st>>>(partials, gbias, B, C, static_cast<int>(nb));
+    DFE_LAUNCH_CHECK();
+  }
   return DFE_OK;
 }
 
-extern "C" int dfe_elu_up2_cat_pad_fwd(const float* x, const float* skip, float* out, int B, int C1, int C2, int h, int w,
-                                       void* stream) {
+extern "C" int dfe_elu_up2_cat_pad_fwd(const float* x, const float* bias, const float* skip, float* out, int B, int C1, int C2,
+                                       int h, int w, void* stream) {
   if (!x || !out || (C2 > 0 && !skip)) return DFE_ERR_NULL;
   if (B <= 0 || C1 <= 0 || C2 < 0 || h < 1 || w < 1 || !grid_ok((2L * h + 2) * (2L * w + 2), static_cast<long>(B) * (C1 + C2))) return DFE_ERR_DIMS;
   k_elu_up2_cat_pad_fwd<<<dim3(nblk((2L * h + 2) * (2L * w + 2)), B * (C1 + C2)), 256, 0, static_cast<hipStream_t>(stream)>>>(
-      x, skip, out, C1, C2, h, w);
+      x, bias, skip, out, C1, C2, h, w);
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
 
-extern "C" int dfe_elu_up2_cat_pad_bwd(const float* x, const float* gout, float* gx, float* gskip, int B, int C1, int C2,
-                                       int h, int w, void* stream) {
-  if (!x || !gout || (!gx && !gskip)) return DFE_ERR_NULL;
+extern "C" int dfe_elu_up2_cat_pad_bwd(const float* x, const float* bias, const float* gout, float* gx, float* gskip,
+                                       float* gbias, float* partials, int B, int C1, int C2, int h, int w, void* stream) {
+  if (!x || !gout || (!gx && !gskip) || (gbias && (!partials || !gx))) return DFE_ERR_NULL;
   if (B <= 0 || C1 <= 0 || C2 < 0 || h < 1 || w < 1 || !grid_ok((2L * h + 2) * (2L * w + 2), static_cast<long>(B) * (C1 + C2))) return DFE_ERR_DIMS;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (gx) {
-    k_elu_up2_cat_pad_bwd_x<<<dim3(nblk(static_cast<long>(h) * w), B * C1), 256, 0, st>>>(x, gout, gx, C1, C2, h, w);
+    const unsigned nb = nblk(static_cast<long>(h) * w);
+    k_elu_up2_cat_pad_bwd_x<<<dim3(nb, B * C1), 256, 0, st>>>(x, bias, gout, gx, gbias ? partials : nullptr, C1, C2, h, w);
     DFE_LAUNCH_CHECK();
+    if (gbias) {
+      k_glue_bias_final<<<C1, 64, 0, st>>>(partials, gbias, B, C1, static_cast<int>(nb));
+      DFE_LAUNCH_CHECK();
+    }
   }
   if (gskip && C2 > 0) {
     k_cat_pad_bwd_skip<<<dim3(nblk(4L * h * w), B * C2), 256, 0, st>>>(gout, gskip, C1, C2, 2 * h, 2 * w);

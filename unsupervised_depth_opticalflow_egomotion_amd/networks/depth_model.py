@@ -86,19 +86,19 @@ class DepthDecoder(nn.Module):
         return out
 
     def forward_fused(self, feats):
-        """Same graph on the GPU: the ELU / bilinear x2 / cat / reflection-pad glue between the MIOpen convolutions
-        runs as two fused HIP passes (ops.elu_pad, ops.elu_up2_cat_pad); the convolutions are applied to the padded
-        tensors directly.  ``c`` always holds a convolution output *before* its ELU."""
+        """Same graph on the GPU: the bias / ELU / bilinear x2 / cat / reflection-pad glue between the MIOpen
+        convolutions runs as two fused HIP passes (ops.elu_pad, ops.elu_up2_cat_pad); the convolutions are applied
+        bias-free to the padded tensors.  ``a`` / ``c`` hold convolution outputs *before* bias and ELU."""
         from .. import ops
         out = {}
-        p = ops.elu_pad(feats[-1], apply_elu=False)              # encoder output: already activated
+        p = ops.elu_pad(feats[-1], None, apply_elu=False)        # encoder output: already activated
         for scale in range(4, -1, -1):
-            blk = self.upconvs[4 - scale]
-            a = blk[0].conv.conv(p)
-            q = ops.elu_up2_cat_pad(a, feats[scale - 1] if scale > 0 else None)
-            c = blk[1].conv.conv(q)
+            c0, c1 = self.upconvs[4 - scale][0].conv.conv, self.upconvs[4 - scale][1].conv.conv
+            a = F.conv2d(p, c0.weight)
+            q = ops.elu_up2_cat_pad(a, c0.bias, feats[scale - 1] if scale > 0 else None)
+            c = F.conv2d(q, c1.weight)
             if scale in self.scales or scale > 0:
-                p = ops.elu_pad(c, apply_elu=True)               # shared by the disparity head and the next stage
+                p = ops.elu_pad(c, c1.bias, apply_elu=True)      # shared by the disparity head and the next stage
             if scale in self.scales:
                 out[scale] = self.sigmoid(self.dispconvs[self.scales.index(scale)].conv(p))
         return out

@@ -258,39 +258,48 @@ def resize(img, out_hw, mode):
 
 # --------------------------------------------------------------------------- depth-decoder glue
 class EluPadFn(torch.autograd.Function):
-    """reflect_pad1(elu(x)) (elu optional): the input of a Conv3x3 whose producer is a ConvBlock (depth_model.py)."""
+    """reflect_pad1(elu(x + bias)) (elu, bias optional): the input of a Conv3x3 whose producer is a ConvBlock
+    (depth_model.py); x is that block's convolution output computed without its bias."""
 
     @staticmethod
-    def forward(ctx, x, apply_elu):
+    def forward(ctx, x, bias, apply_elu):
         lib = get_lib()
         x = f32c(x)
+        bias = f32c(bias) if bias is not None else None
         B, C, H, W = x.shape
         out = torch.empty(B, C, H + 2, W + 2, device=x.device)
-        check(lib.dfe_elu_pad_fwd(ptr(x), ptr(out), B, C, H, W, int(apply_elu), stream_ptr()), "dfe_elu_pad_fwd")
+        check(lib.dfe_elu_pad_fwd(ptr(x), ptr(bias), ptr(out), B, C, H, W, int(apply_elu), stream_ptr()), "dfe_elu_pad_fwd")
         ctx.apply_elu = int(apply_elu)
         ctx.shape = (B, C, H, W)
-        ctx.save_for_backward(x if apply_elu else x.new_empty(0))
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x if apply_elu else x.new_empty(0), bias if bias is not None else x.new_empty(0))
         return out
 
     @staticmethod
     def backward(ctx, gout):
         lib = get_lib()
-        (x,) = ctx.saved_tensors
+        x, bias = ctx.saved_tensors
         B, C, H, W = ctx.shape
         gout = f32c(gout)
         gx = torch.empty(B, C, H, W, device=gout.device)
-        check(lib.dfe_elu_pad_bwd(ptr(x) if ctx.apply_elu else None, ptr(gout), ptr(gx), B, C, H, W, ctx.apply_elu,
-                                  stream_ptr()), "dfe_elu_pad_bwd")
-        return gx, None
+        gb = part = None
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            gb = torch.empty(C, device=gout.device)
+            part = torch.empty(lib.dfe_glue_partials_floats(B, C, H, W), device=gout.device)
+        check(lib.dfe_elu_pad_bwd(ptr(x) if ctx.apply_elu else None, ptr(bias) if ctx.has_bias else None, ptr(gout), ptr(gx),
+                                  ptr(gb), ptr(part), B, C, H, W, ctx.apply_elu, stream_ptr()), "dfe_elu_pad_bwd")
+        return gx, gb, None
 
 
 class EluUp2CatPadFn(torch.autograd.Function):
-    """reflect_pad1(cat(bilinear_x2(elu(x)), skip)): one decoder stage's glue (depth_model.py: upsample + cat + pad)."""
+    """reflect_pad1(cat(bilinear_x2(elu(x + bias)), skip)): one decoder stage's glue (depth_model.py: ELU, upsample,
+    cat, pad); x is the stage's first convolution output computed without its bias."""
 
     @staticmethod
-    def forward(ctx, x, skip):
+    def forward(ctx, x, bias, skip):
         lib = get_lib()
         x = f32c(x)
+        bias = f32c(bias) if bias is not None else None
         B, C1, h, w = x.shape
         C2 = 0
         if skip is not None:
@@ -299,33 +308,39 @@ class EluUp2CatPadFn(torch.autograd.Function):
             if tuple(skip.shape) != (B, C2, 2 * h, 2 * w):
                 raise ValueError("skip must be [B,C2,2h,2w] = %s, got %s" % ((B, C2, 2 * h, 2 * w), tuple(skip.shape)))
         out = torch.empty(B, C1 + C2, 2 * h + 2, 2 * w + 2, device=x.device)
-        check(lib.dfe_elu_up2_cat_pad_fwd(ptr(x), ptr(skip), ptr(out), B, C1, C2, h, w, stream_ptr()),
+        check(lib.dfe_elu_up2_cat_pad_fwd(ptr(x), ptr(bias), ptr(skip), ptr(out), B, C1, C2, h, w, stream_ptr()),
               "dfe_elu_up2_cat_pad_fwd")
-        ctx.save_for_backward(x)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, bias if bias is not None else x.new_empty(0))
         ctx.dims = (B, C1, C2, h, w)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         lib = get_lib()
-        (x,) = ctx.saved_tensors
+        x, bias = ctx.saved_tensors
         B, C1, C2, h, w = ctx.dims
         gout = f32c(gout)
-        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        gskip = torch.empty(B, C2, 2 * h, 2 * w, device=x.device) if (C2 > 0 and ctx.needs_input_grad[1]) else None
+        want_b = ctx.has_bias and ctx.needs_input_grad[1]
+        gx = torch.empty_like(x) if (ctx.needs_input_grad[0] or want_b) else None
+        gskip = torch.empty(B, C2, 2 * h, 2 * w, device=x.device) if (C2 > 0 and ctx.needs_input_grad[2]) else None
         if gx is None and gskip is None:
-            return None, None
-        check(lib.dfe_elu_up2_cat_pad_bwd(ptr(x), ptr(gout), ptr(gx), ptr(gskip), B, C1, C2, h, w, stream_ptr()),
-              "dfe_elu_up2_cat_pad_bwd")
-        return gx, gskip
+            return None, None, None
+        gb = part = None
+        if want_b:
+            gb = torch.empty(C1, device=x.device)
+            part = torch.empty(lib.dfe_glue_partials_floats(B, C1, h, w), device=x.device)
+        check(lib.dfe_elu_up2_cat_pad_bwd(ptr(x), ptr(bias) if ctx.has_bias else None, ptr(gout), ptr(gx), ptr(gskip), ptr(gb),
+                                          ptr(part), B, C1, C2, h, w, stream_ptr()), "dfe_elu_up2_cat_pad_bwd")
+        return gx, gb, gskip
 
 
-def elu_pad(x, apply_elu=True):
-    return EluPadFn.apply(x, bool(apply_elu))
+def elu_pad(x, bias=None, apply_elu=True):
+    return EluPadFn.apply(x, bias, bool(apply_elu))
 
 
-def elu_up2_cat_pad(x, skip=None):
-    return EluUp2CatPadFn.apply(x, skip)
+def elu_up2_cat_pad(x, bias=None, skip=None):
+    return EluUp2CatPadFn.apply(x, bias, skip)
 
 
 # --------------------------------------------------------------------------- convolution epilogue (bias + activation)
