@@ -54,6 +54,19 @@ def _split_frames(images):
     return images[:, :, :h, :], images[:, :, h:2 * h, :], images[:, :, 2 * h:3 * h, :], h, images.shape[3]
 
 
+def _flow_branches(fpyramid, pwc_model, img_l, img, img_r):
+    """Both flow directions of a triplet (model_geometry.py:790-793, model_flow.py:214-222: three fpyramid calls and
+    two pwc_model calls).  Neither net holds batch statistics, so one pass over the 3B frames and one over the 2B
+    (target, source) pairs give the same per-sample results with a third / half of the launches and larger
+    convolutions at the coarse levels.  Returns (flows target->left, flows target->right)."""
+    B, h, w = img.shape[0], img.shape[2], img.shape[3]
+    feats = fpyramid(torch.cat([img, img_l, img_r], 0))
+    f1 = [torch.cat([f[:B], f[:B]], 0) for f in feats]        # the target's features for both directions
+    f2 = [f[B:] for f in feats]                               # left | right
+    flows = pwc_model(f1, f2, [h, w])
+    return [f[:B] for f in flows], [f[B:] for f in flows]
+
+
 def _zeros2(dev):
     return torch.zeros([2], device=dev).requires_grad_()   # device-side fill (no H2D copy: capturable in a hipGraph)
 
@@ -107,9 +120,7 @@ class Model_geometry(LossTerms, nn.Module):
         else:
             disp_l, disp_t, disp_r = self.depth_net(img_l), self.depth_net(img), self.depth_net(img_r)
             pose = self.pose_net(torch.cat([img_l, img, img_r], 1))
-        f_l, f_t, f_r = self.fpyramid(img_l), self.fpyramid(img), self.fpyramid(img_r)
-        flows_bwd = self.pwc_model(f_t, f_l, [h, w])
-        flows_fwd = self.pwc_model(f_t, f_r, [h, w])
+        flows_bwd, flows_fwd = _flow_branches(self.fpyramid, self.pwc_model, img_l, img, img_r)
         return disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd
 
     def forward(self, inputs):
@@ -244,9 +255,7 @@ class Model_flow(LossTerms, nn.Module):
         images = inputs[0]
         img_l, img, img_r, h, w = _split_frames(images)
         img_l, img, img_r = img_l.contiguous(), img.contiguous(), img_r.contiguous()
-        f_l, f_t, f_r = self.fpyramid(img_l), self.fpyramid(img), self.fpyramid(img_r)
-        flows_bwd = self.pwc_model(f_t, f_l, [h, w])
-        flows_fwd = self.pwc_model(f_t, f_r, [h, w])
+        flows_bwd, flows_fwd = _flow_branches(self.fpyramid, self.pwc_model, img_l, img, img_r)
         return self.loss_stack(img_l, img, img_r, flows_bwd, flows_fwd)
 
     def loss_stack(self, img_l, img, img_r, flows_bwd, flows_fwd):
