@@ -22,7 +22,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-POINT_FWD_BYTES_PER_PX = 105   # algorithmic bytes of k_geom_point_fwd per pixel, both directions
 
 
 def parse():
@@ -146,17 +145,10 @@ class TrainStepWorkload:
         im, k, ki = synthetic.make_triplet_batch(args.batch, args.height, args.width, args.scales, seed=seed)
         self.np_inputs = (im, k, ki)
         self.inputs = [torch.from_numpy(a).to(dev) for a in (im, k, ki)]   # resident in HBM before timing
-        self._ls = None
 
     def step(self):
         from unsupervised_depth_opticalflow_egomotion_amd.train_step import train_step
         return train_step(self.model, self.opt, self.inputs, self.cfg)[0]
-
-    def loss_stack_workload(self):
-        """Loss-stack-only view on the same shapes, for the per-kernel roofline measurement."""
-        if self._ls is None:
-            self._ls = LossStackWorkload(self.args, self.dev, seed=1234)
-        return self._ls
 
     def cpu_step_fn(self, threads):
         """CPU baseline: the same networks on the host + the oracle's loss stack + Adam."""
@@ -208,56 +200,38 @@ class TrainStepWorkload:
 
 
 # ------------------------------------------------------------------------------------------------ roofline
-def point_fwd_roofline(args, wl, steps):
-    """Average duration of k_geom_point_fwd (HIP events on the launch stream, diagnostic entry point of the
-    C ABI) over `steps` forward passes on the bench inputs -> achieved algorithmic GB/s."""
-    from unsupervised_depth_opticalflow_egomotion_amd import loss_stack as LS
-    from unsupervised_depth_opticalflow_egomotion_amd._lib import get_lib, check, stream_ptr
-    lib = get_lib()
+# dominant kernel of each mode's fused forward (segment 2 of the timed launches) and its algorithmic bytes per pixel
+# of every scale: reads + writes the kernel cannot avoid, fp32
+POINT_KERNEL = {
+    "geom": ("k_geom_point_fwd", 105),    # target 12 + 2 flows 16 + 2 bilinear sources 24 + 2 area sources 24 + disp 4; mask 1 + yw 24
+    "depth": ("k_depth_point_fwd", 65),   # target 12 + 2 area sources 24 + 2 bilinear sources 24 + disp 4; mask 1
+    "flow": ("k_flow_point_fwd", 84),     # target 12 + 2 flows 16 + 2 sources 24; weights 8 + yw 24
+}
+
+
+def point_fwd_roofline(args, mode, fwd_ms, bwd_ms):
+    """Roofline object from the HIP-event timings recorded inside the timed region (loss_stack.timing_begin /
+    timing_collect: events on the launch stream around every launch of the fused stack, read after the final sync)."""
     S = args.scales
-    det = lambda lst: [t.detach() for t in lst]
-    a = LS._fill_args(wl.imgs, [det(l[:S]) for l in wl.disps], [det(wl.fb[:S]), det(wl.ff[:S])], wl.pose.detach(),
-                      wl.K, wl.Ki, S, 0.01, 0.5, 0)
-    n = lib.dfe_geom_workspace_floats(ctypes.byref(a))
-    ws = torch.empty(n, device=wl.imgs[0].device)
-    losses = torch.empty(len(LS.LOSS_ROWS), a.B, device=ws.device)
-    a.workspace, a.workspace_floats, a.losses = ws.data_ptr(), n, losses.data_ptr()
-    glosses = torch.full_like(losses, 1.0 / a.B)
-    a.grad_losses = glosses.data_ptr()
-    keep = []
-    for f in range(3):
-        for s in range(S):
-            t = torch.empty_like(wl.disps[f][s]); keep.append(t); a.grad_disp[f][s] = t.data_ptr()
-    for d, lst in enumerate((wl.fb, wl.ff)):
-        for s in range(S):
-            t = torch.empty_like(lst[s]); keep.append(t); a.grad_flow[d][s] = t.data_ptr()
-    gp = torch.empty_like(wl.pose); a.grad_pose = gp.data_ptr()
-    fwd = (ctypes.c_float * 7)()
-    bwd = (ctypes.c_float * 6)()
-    acc_f, acc_b = np.zeros(7), np.zeros(6)
-    for i in range(steps + 2):
-        check(lib.dfe_geom_loss_fwd_profiled(ctypes.byref(a), stream_ptr(), ctypes.cast(fwd, ctypes.c_void_p)), "fwd_profiled")
-        check(lib.dfe_geom_loss_bwd_profiled(ctypes.byref(a), stream_ptr(), ctypes.cast(bwd, ctypes.c_void_p)), "bwd_profiled")
-        if i >= 2:
-            acc_f += np.array(fwd[:]); acc_b += np.array(bwd[:])
-    acc_f /= steps; acc_b /= steps
+    kernel, bpp = POINT_KERNEL[mode]
     npx = args.batch * sum(int(args.height / 2 ** s) * int(args.width / 2 ** s) for s in range(S))
-    bytes_per_launch = POINT_FWD_BYTES_PER_PX * npx
-    t_ms = float(acc_f[2])
+    bytes_per_launch = bpp * npx
+    t_ms = float(fwd_ms[:, 2].mean())
     achieved = bytes_per_launch / (t_ms * 1e-3) / 1e9
     traffic = None   # PMC-derived HBM bytes per launch: cannot be collected from inside this process; taken from
-    try:             # the committed rocprofv3 --pmc pass when it was made on exactly this workload
+    try:             # the committed rocprofv3 --pmc pass when it was made on exactly this kernel and workload
         with open(os.path.join(ROOT, "profiles", "pmc_point_fwd_traffic.json")) as fh:
             pm = json.load(fh)
         w = pm["workload"]
-        if (w["batch"], w["height"], w["width"], w["scales"]) == (args.batch, args.height, args.width, S):
+        if mode == "geom" and (w["batch"], w["height"], w["width"], w["scales"]) == (args.batch, args.height, args.width, S):
             traffic = pm["hbm_bytes_per_launch"]
     except Exception:
         traffic = None
-    roof = {"bound": "hbm", "kernel": "k_geom_point_fwd", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+    roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "bytes_per_launch": bytes_per_launch, "avg_kernel_ms": round(t_ms, 5)}
-    segs = {"fwd_ms": [round(float(x), 5) for x in acc_f], "bwd_ms": [round(float(x), 5) for x in acc_b]}
+            "bytes_per_launch": bytes_per_launch, "avg_kernel_ms": round(t_ms, 5), "launches_timed": int(fwd_ms.shape[0])}
+    segs = {"fwd_ms": [round(float(x), 5) for x in fwd_ms.mean(0)],
+            "bwd_ms": [round(float(x), 5) for x in bwd_ms.mean(0)] if len(bwd_ms) else []}
     return roof, segs
 
 
@@ -295,12 +269,15 @@ def main():
         wl = LossStackWorkload(args, dev, seed=1234 + rank)
     for _ in range(args.warmup):
         wl.step()
+    from unsupervised_depth_opticalflow_egomotion_amd import loss_stack as LS
     barrier(world)
+    LS.timing_begin()           # HIP events between the fused stack's launches (stream-ordered, no host sync)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wl.step()
     barrier(world)
     dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+    fwd_ms, bwd_ms = LS.timing_collect()
     pairs_per_step = 2 * args.batch * world
     value = pairs_per_step * args.steps / dt
     out = {
@@ -313,8 +290,7 @@ def main():
             "global_batch": args.batch * world, "parallelism": "dp%d" % world},
     }
     if rank == 0:
-        ls = wl if isinstance(wl, LossStackWorkload) else wl.loss_stack_workload()
-        roof, segs = point_fwd_roofline(args, ls, max(args.steps, 10))
+        roof, segs = point_fwd_roofline(args, args.mode if wl.name == "train_step" else "geom", fwd_ms, bwd_ms)
         out["roofline"] = roof
         out["kernel_ms"] = segs
         if world == 1 and not args.no_cpu_baseline:

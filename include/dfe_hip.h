@@ -194,6 +194,14 @@ int dfe_geom_loss_bwd(const dfe_geom_args* args, void* stream);
 int dfe_geom_loss_fwd_profiled(const dfe_geom_args* args, void* stream, float* ms_host);
 int dfe_geom_loss_bwd_profiled(const dfe_geom_args* args, void* stream, float* ms_host);
 
+/* Deferred read-out of the same events: the launches and the event records are enqueued on `stream` with no host
+ * synchronisation (usable inside a running training step); *handle owns the events.  dfe_geom_timed_collect waits
+ * for the last event of that call, writes the segment durations (7 forward / 6 backward floats) and frees the
+ * handle; every handle must be collected exactly once. */
+int dfe_geom_loss_fwd_timed(const dfe_geom_args* args, void* stream, void** handle);
+int dfe_geom_loss_bwd_timed(const dfe_geom_args* args, void* stream, void** handle);
+int dfe_geom_timed_collect(void* handle, float* ms_host);
+
 #ifdef __cplusplus
 }
 #endif

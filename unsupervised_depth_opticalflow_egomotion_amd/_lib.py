@@ -56,6 +56,9 @@ _SIGNATURES = {
     "dfe_geom_loss_bwd": [_P, _P],
     "dfe_geom_loss_fwd_profiled": [_P, _P, _P],
     "dfe_geom_loss_bwd_profiled": [_P, _P, _P],
+    "dfe_geom_loss_fwd_timed": [_P, _P, _P],
+    "dfe_geom_loss_bwd_timed": [_P, _P, _P],
+    "dfe_geom_timed_collect": [_P, _P],
 }
 _RESTYPES = {"dfe_error_string": ctypes.c_char_p, "dfe_geom_workspace_floats": ctypes.c_long,
              "dfe_bias_act_partials_floats": ctypes.c_long, "dfe_glue_partials_floats": ctypes.c_long,

@@ -885,3 +885,18 @@ extern "C" int dfe_geom_loss_bwd_profiled(const dfe_geom_args* a, void* stream, 
   for (auto& e : ev) (void)hipEventDestroy(e);
   return rc;
 }
+
+// see dfe_geom_loss_fwd_timed; the handle layout is shared (DFE_GEOM_BWD_SEGMENTS <= DFE_GEOM_FWD_SEGMENTS)
+namespace { struct GeomTimedB { int n; hipEvent_t ev[DFE_GEOM_FWD_SEGMENTS + 1]; }; }
+
+extern "C" int dfe_geom_loss_bwd_timed(const dfe_geom_args* a, void* stream, void** handle) {
+  if (!handle) return DFE_ERR_NULL;
+  static_assert(DFE_GEOM_BWD_SEGMENTS <= DFE_GEOM_FWD_SEGMENTS, "handle layout");
+  GeomTimedB* t = new GeomTimedB;
+  t->n = DFE_GEOM_BWD_SEGMENTS;
+  for (int i = 0; i <= t->n; ++i) if (hipEventCreate(&t->ev[i]) != hipSuccess) { delete t; return DFE_ERR_LAUNCH; }
+  const int rc = geom_bwd_impl(a, stream, t->ev);
+  if (rc != DFE_OK) { for (int i = 0; i <= t->n; ++i) (void)hipEventDestroy(t->ev[i]); delete t; return rc; }
+  *handle = t;
+  return DFE_OK;
+}

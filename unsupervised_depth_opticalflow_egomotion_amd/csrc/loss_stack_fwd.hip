@@ -965,4 +965,31 @@ int dfe_geom_loss_fwd_profiled(const dfe_geom_args* a, void* stream, float* ms_h
   return rc;
 }
 
+// Deferred read-out: events are recorded in stream order with no host synchronisation, so the launches can be
+// timed inside a running training step; dfe_geom_timed_collect waits for the last event of that call only.
+struct GeomTimed { int n; hipEvent_t ev[DFE_GEOM_FWD_SEGMENTS + 1]; };
+
+int dfe_geom_loss_fwd_timed(const dfe_geom_args* a, void* stream, void** handle) {
+  if (!handle) return DFE_ERR_NULL;
+  GeomTimed* t = new GeomTimed;
+  t->n = DFE_GEOM_FWD_SEGMENTS;
+  for (int i = 0; i <= t->n; ++i) if (hipEventCreate(&t->ev[i]) != hipSuccess) { delete t; return DFE_ERR_LAUNCH; }
+  const int rc = geom_fwd_impl(a, stream, t->ev);
+  if (rc != DFE_OK) { for (int i = 0; i <= t->n; ++i) (void)hipEventDestroy(t->ev[i]); delete t; return rc; }
+  *handle = t;
+  return DFE_OK;
+}
+
+int dfe_geom_timed_collect(void* handle, float* ms_host) {
+  if (!handle || !ms_host) return DFE_ERR_NULL;
+  GeomTimed* t = static_cast<GeomTimed*>(handle);
+  int rc = DFE_OK;
+  if (hipEventSynchronize(t->ev[t->n]) != hipSuccess) rc = DFE_ERR_LAUNCH;
+  for (int i = 0; i < t->n && rc == DFE_OK; ++i)
+    if (hipEventElapsedTime(&ms_host[i], t->ev[i], t->ev[i + 1]) != hipSuccess) rc = DFE_ERR_LAUNCH;
+  for (int i = 0; i <= t->n; ++i) (void)hipEventDestroy(t->ev[i]);
+  delete t;
+  return rc;
+}
+
 }  // extern "C"

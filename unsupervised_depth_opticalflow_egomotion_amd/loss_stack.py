@@ -93,6 +93,44 @@ def _unpack(t, S, mode):
     return imgs, disps, flows, pose, K, K_inv
 
 
+# ---- optional in-step kernel timing (bench.py): HIP events around the launches, read after the timed region
+_TIMING = {"on": False, "fwd": [], "bwd": []}
+
+
+def timing_begin():
+    """From now on every fused forward / backward records HIP events between its launches (no host sync)."""
+    _TIMING["on"], _TIMING["fwd"], _TIMING["bwd"] = True, [], []
+
+
+def timing_collect():
+    """Stop recording and return (fwd_ms [n,7], bwd_ms [n,6]) for the calls since timing_begin()."""
+    import numpy as np
+    lib = get_lib()
+    _TIMING["on"] = False
+    out = []
+    for key, nseg in (("fwd", 7), ("bwd", 6)):
+        rows = []
+        for h in _TIMING[key]:
+            buf = (ctypes.c_float * 7)()
+            check(lib.dfe_geom_timed_collect(h, ctypes.cast(buf, ctypes.c_void_p)), "dfe_geom_timed_collect")
+            rows.append(list(buf)[:nseg])
+        _TIMING[key] = []
+        out.append(np.array(rows, dtype=np.float64).reshape(-1, nseg))
+    return out[0], out[1]
+
+
+def _launch(kind, a):
+    lib = get_lib()
+    if _TIMING["on"]:
+        h = ctypes.c_void_p()
+        fn = lib.dfe_geom_loss_fwd_timed if kind == "fwd" else lib.dfe_geom_loss_bwd_timed
+        check(fn(ctypes.byref(a), stream_ptr(), ctypes.byref(h)), "dfe_geom_loss_%s_timed" % kind)
+        _TIMING[kind].append(h)
+    else:
+        fn = lib.dfe_geom_loss_fwd if kind == "fwd" else lib.dfe_geom_loss_bwd
+        check(fn(ctypes.byref(a), stream_ptr()), "dfe_geom_loss_%s" % kind)
+
+
 class GeomLossFn(torch.autograd.Function):
     """forward(*tensors) -> losses [8,B].  Tensor order: 3 frames, 3*S disps (frame-major), then for
     mode 0 (Model_geometry) 2*S flows (bwd scales then fwd scales), pose, K, K_inv; for mode 1 (Model_depth)
@@ -111,7 +149,7 @@ class GeomLossFn(torch.autograd.Function):
         ws = torch.empty(n, device=dev, dtype=torch.float32)
         losses = torch.empty(len(LOSS_ROWS), a.B, device=dev, dtype=torch.float32)
         a.workspace, a.workspace_floats, a.losses = ws.data_ptr(), n, losses.data_ptr()
-        check(lib.dfe_geom_loss_fwd(ctypes.byref(a), stream_ptr()), "dfe_geom_loss_fwd")
+        _launch("fwd", a)
         ctx.save_for_backward(*t)
         ctx.cfg = (mode, S, alpha, beta, ac)
         ctx.ws = ws
@@ -139,7 +177,7 @@ class GeomLossFn(torch.autograd.Function):
                 a.grad_flow[d][s] = gf[d][s].data_ptr()
         if gp is not None:
             a.grad_pose = gp.data_ptr()
-        check(lib.dfe_geom_loss_bwd(ctypes.byref(a), stream_ptr()), "dfe_geom_loss_bwd")
+        _launch("bwd", a)
         grads = [None] * 8          # mode, S, alpha, beta, ac, 3 frames
         for f in range(len(gd)):
             grads += gd[f]
