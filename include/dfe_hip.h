@@ -111,6 +111,22 @@ int dfe_elu_up2_cat_pad_fwd(const float* x, const float* bias, const float* skip
 int dfe_elu_up2_cat_pad_bwd(const float* x, const float* bias, const float* gout, float* gx, float* gskip, float* gbias,
                             float* partials, int B, int C1, int C2, int h, int w, void* stream);
 
+/* ---- grouped training-mode BatchNorm2d (+ residual + ReLU) of the depth encoder (SURVEY.md 8(f) rank 1;
+ * depth_model.py:60-95 = torchvision BasicBlock conv-bn-relu-conv-bn-(+identity)-relu; model_geometry.py:786-788 calls the
+ * depth net once per frame).  x [G*Bg,C,H,W] is G groups of Bg consecutive samples: statistics are per (group, channel)
+ * and running_mean / running_var (may be NULL) receive the G momentum updates in group order, i.e. what G sequential
+ * nn.BatchNorm2d calls on the groups do.  y = act((x - mean) * invstd * weight + bias [+ residual]), act = ReLU if relu.
+ * save_mean / save_invstd: [G*C] outputs for the backward pass; partials: dfe_bn_partials_floats floats of scratch.
+ * Backward: g' = gy masked by y > 0 when relu; gx, gres (= g', may be NULL), gweight / gbias [C] (may be NULL);
+ * scratch_means: 2*G*C floats. */
+long dfe_bn_partials_floats(int G, int Bg, int C, int H, int W);
+int dfe_bn_fwd(const float* x, const float* residual, const float* weight, const float* bias, float* running_mean,
+               float* running_var, float* y, float* save_mean, float* save_invstd, float* partials, int G, int Bg, int C,
+               int H, int W, float eps, float momentum, int relu, void* stream);
+int dfe_bn_bwd(const float* x, const float* y, const float* gy, const float* weight, const float* save_mean,
+               const float* save_invstd, float* gx, float* gres, float* gweight, float* gbias, float* partials,
+               float* scratch_means, int G, int Bg, int C, int H, int W, int relu, void* stream);
+
 /* ---- convolution epilogue of the flow nets (net_utils.py conv() = Conv2d(bias) + LeakyReLU(0.1),
  * feature_pyramid.py:7-36, pwc_tf.py:16-95): the convolution itself runs on MIOpen *without* its bias, then
  * dfe_bias_act_fwd: z [B,C,H,W] <- act(z + bias[c]) in place; act(v) = v > 0 ? v : slope*v (0.1 LeakyReLU, 0 ReLU, 1 none);

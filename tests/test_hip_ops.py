@@ -395,3 +395,87 @@ def test_conv_act_module_matches_aten():
     close(res[0][0], res[1][0], atol=1e-5, rtol=1e-5)
     for a, b in zip(res[0][1:], res[1][1:]):
         gclose(a, b, rel=2e-4, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------- grouped batch norm
+def _ref_grouped_bn(x, res, bn, groups, relu):
+    """``groups`` sequential nn.BatchNorm2d calls on the host (what the reference's per-frame calls do)."""
+    import torch.nn.functional as F
+    y = torch.cat([torch.nn.BatchNorm2d.forward(bn, c) for c in x.chunk(groups, 0)], 0)
+    if res is not None:
+        y = y + res
+    return F.relu(y) if relu else y
+
+
+@pytest.mark.parametrize("relu,with_res", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("shape,groups", [((6, 5, 8, 26), 3), ((4, 3, 7, 9), 1), ((12, 16, 64, 208), 3), ((2, 4, 1, 1), 1)])
+def test_grouped_batch_norm(shape, groups, relu, with_res):
+    """Fused grouped BatchNorm (+ residual + ReLU) against sequential nn.BatchNorm2d calls on the CPU: outputs 2e-5
+    (statistics merged in double vs ATen's accumulation), running statistics 1e-6, gradients 1e-4 of their scale."""
+    from unsupervised_depth_opticalflow_egomotion_amd.networks.resnet import FrameBatchNorm2d
+    rng = np.random.RandomState(sum(shape) + groups)
+    x = (rng.randn(*shape) * 1.5 + 0.7).astype(np.float32)
+    res = rng.randn(*shape).astype(np.float32) if with_res else None
+    r = rng.randn(*shape).astype(np.float32)
+    w, b = rng.rand(shape[1]).astype(np.float32) + 0.5, rng.randn(shape[1]).astype(np.float32)
+    mods = []
+    for device in ("cuda", "cpu"):
+        m = FrameBatchNorm2d(shape[1])
+        with torch.no_grad():
+            m.weight.copy_(torch.from_numpy(w)); m.bias.copy_(torch.from_numpy(b))
+        m.groups = groups
+        mods.append(m.to(device).train())
+    mh, mo = mods
+    xh, xo = G(x, True), T(x).requires_grad_(True)
+    rh = G(res, True) if with_res else None
+    ro = T(res).requires_grad_(True) if with_res else None
+    yh = mh(xh, residual=rh, relu=relu)
+    yo = _ref_grouped_bn(xo, ro, mo, groups, relu)
+    (yh * G(r)).sum().backward()
+    (yo * T(r)).sum().backward()
+    close(yh, yo, atol=2e-5, rtol=2e-5)
+    close(mh.running_mean, mo.running_mean, atol=1e-6, rtol=1e-6)
+    close(mh.running_var, mo.running_var, atol=1e-6, rtol=1e-5)
+    assert int(mh.num_batches_tracked) == int(mo.num_batches_tracked) == groups
+    # the ReLU mask can differ where |y| is within rounding of 0 (expected ~1 of the 2.5 M elements of the largest
+    # case): such a pixel moves its own gradient and its channel's weight / bias gradient by O(1) -- budget two
+    flips = 2 if relu else 0
+    gclose(xh.grad, xo.grad, rel=1e-4, max_outliers=flips, atol=1e-6)
+    gclose(mh.weight.grad, mo.weight.grad, rel=1e-4, atol=1e-5, max_outliers=flips)
+    gclose(mh.bias.grad, mo.bias.grad, rel=1e-4, atol=1e-5, max_outliers=flips)
+    if with_res:
+        gclose(rh.grad, ro.grad, rel=1e-6, max_outliers=2 if relu else 0)
+
+
+def test_depth_net_frames_match_sequential_calls():
+    """Depth_Model.forward_frames (one batch of 3B, grouped BatchNorm, fused glue) on the GPU against three sequential
+    calls of the same net on the CPU (the reference's call pattern): disparities 1e-4, BatchNorm running statistics
+    1e-5, parameter gradients 2e-3 of their scale (MIOpen vs host convolutions and a few ReLU decisions at rounding
+    distance from 0, through ~30 layers)."""
+    from unsupervised_depth_opticalflow_egomotion_amd.networks.depth_model import Depth_Model
+    torch.manual_seed(11)
+    net_c = Depth_Model(3).train()
+    net_g = Depth_Model(3).train()
+    net_g.load_state_dict(net_c.state_dict())
+    net_g.to(dev())
+    frames = [torch.rand(2, 3, 64, 128) for _ in range(3)]
+    out_c = [net_c(f) for f in frames]
+    out_g = net_g.forward_frames([f.to(dev()) for f in frames])
+    wts = [1.0, 0.7, 1.3]
+    sum(wts[i] * o.mean() for i in range(3) for o in out_c[i]).backward()
+    sum(wts[i] * o.mean() for i in range(3) for o in out_g[i]).backward()
+    for i in range(3):
+        for a, c in zip(out_g[i], out_c[i]):
+            close(a, c, atol=1e-4, rtol=1e-4)
+    sd_c, sd_g = net_c.state_dict(), net_g.state_dict()
+    for k in sd_c:
+        if "running_" in k:
+            close(sd_g[k], sd_c[k], atol=1e-5, rtol=1e-4)
+        if "num_batches_tracked" in k:
+            assert int(sd_g[k]) == int(sd_c[k]) == 3
+    pc, pg = dict(net_c.named_parameters()), dict(net_g.named_parameters())
+    for k in pc:
+        if pc[k].grad is None:
+            assert pg[k].grad is None, k
+            continue
+        gclose(pg[k].grad, pc[k].grad, rel=2e-3, atol=1e-6)

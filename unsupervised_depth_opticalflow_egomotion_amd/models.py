@@ -54,6 +54,15 @@ def _split_frames(images):
     return images[:, :, :h, :], images[:, :, h:2 * h, :], images[:, :, 2 * h:3 * h, :], h, images.shape[3]
 
 
+def _depth_frames(depth_net, img_l, img, img_r):
+    """Disparity pyramids of the three frames (model_geometry.py:786-788, model_depth.py:286-288: one depth_net call per
+    frame).  On the GPU the frames go through the net as one batch with per-frame BatchNorm statistics
+    (Depth_Model.forward_frames); on the host, the three calls as written."""
+    if img.is_cuda:
+        return depth_net.forward_frames([img_l, img, img_r])
+    return depth_net(img_l), depth_net(img), depth_net(img_r)
+
+
 def _flow_branches(fpyramid, pwc_model, img_l, img, img_r):
     """Both flow directions of a triplet (model_geometry.py:790-793, model_flow.py:214-222: three fpyramid calls and
     two pwc_model calls).  Neither net holds batch statistics, so one pass over the 3B frames and one over the 2B
@@ -118,7 +127,7 @@ class Model_geometry(LossTerms, nn.Module):
             disp_l, disp_t, disp_r = (self.depth_net(x.contiguous(memory_format=cl)) for x in (img_l, img, img_r))
             pose = self.pose_net(torch.cat([img_l, img, img_r], 1).contiguous(memory_format=cl))
         else:
-            disp_l, disp_t, disp_r = self.depth_net(img_l), self.depth_net(img), self.depth_net(img_r)
+            disp_l, disp_t, disp_r = _depth_frames(self.depth_net, img_l, img, img_r)
             pose = self.pose_net(torch.cat([img_l, img, img_r], 1))
         flows_bwd, flows_fwd = _flow_branches(self.fpyramid, self.pwc_model, img_l, img, img_r)
         return disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd
@@ -198,7 +207,7 @@ class Model_depth(LossTerms, nn.Module):
         K = K_ms[:, 0, :, :]
         img_l, img, img_r, h, w = _split_frames(images)
         img_l, img, img_r = img_l.contiguous(), img.contiguous(), img_r.contiguous()
-        depth_l, depth_t, depth_r = self.depth_net(img_l), self.depth_net(img), self.depth_net(img_r)
+        depth_l, depth_t, depth_r = _depth_frames(self.depth_net, img_l, img, img_r)
         pose = self.pose_net(torch.cat([img_l, img, img_r], 1))
         return self.loss_stack(img_l, img, img_r, depth_l, depth_t, depth_r, pose, K)
 

@@ -19,7 +19,7 @@ class ResnetEncoder(nn.Module):
     def forward(self, image):
         e = self.encoder
         x = (image - 0.45) / 0.225
-        f0 = e.relu(e.bn1(e.conv1(x)))
+        f0 = e.bn1(e.conv1(x), relu=True)
         f1 = e.layer1(e.maxpool(f0))
         f2 = e.layer2(f1)
         f3 = e.layer3(f2)
@@ -114,3 +114,19 @@ class Depth_Model(nn.Module):
     def forward(self, img):
         out = self.decoder(self.encoder(img))
         return [out[i] for i in range(self.depth_scale)]
+
+    def forward_frames(self, frames):
+        """The frames of a triplet in ONE pass over a batch of len(frames)*B: equivalent to calling the net once per
+        frame, in order (model_geometry.py:786-788) -- every BatchNorm normalises each frame's B samples separately and
+        updates its running statistics frame by frame (resnet.FrameBatchNorm2d) -- with a third of the launches and
+        larger convolutions.  Returns one disparity list per frame."""
+        n, B = len(frames), frames[0].shape[0]
+        bns = [m for m in self.modules() if isinstance(m, resnet.FrameBatchNorm2d)]
+        for m in bns:
+            m.groups = n
+        try:
+            out = self.forward(torch.cat(list(frames), 0))
+        finally:
+            for m in bns:
+                m.groups = 1
+        return [[o[i * B:(i + 1) * B] for o in out] for i in range(n)]

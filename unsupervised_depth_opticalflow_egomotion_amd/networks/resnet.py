@@ -3,7 +3,36 @@
 Only what the reference's ``ResnetEncoder`` touches (depth_model.py:60-95): conv1, bn1, relu, maxpool,
 layer1-4 and the never-used ``fc`` (kept so that the state-dict keys -- 513 k parameters that never
 receive a gradient -- match checkpoints)."""
+import torch
 import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+class FrameBatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d (same parameters, buffers and state-dict keys) whose batch may hold ``groups`` independently
+    normalised groups of consecutive samples -- the frames of a triplet, which the reference pushes through the depth
+    net one call at a time (model_geometry.py:786-788).  Statistics are per (group, channel) and the running statistics
+    receive the ``groups`` momentum updates in group order, i.e. the result of ``groups`` sequential calls.  An optional
+    residual add and ReLU are applied to the output.  On a HIP device in training mode this is one fused op
+    (ops.grouped_batch_norm); on the host, or in eval mode, the ATen graph."""
+    groups = 1
+
+    def forward(self, x, residual=None, relu=False):
+        if x.is_cuda and self.training:
+            if self.momentum is None or not self.track_running_stats or not self.affine:
+                raise ValueError("FrameBatchNorm2d: only affine, momentum-tracked batch norm is implemented in HIP")
+            self.num_batches_tracked.add_(self.groups)
+            return ops.grouped_batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.groups,
+                                          self.eps, self.momentum, residual=residual, relu=relu)
+        if self.training and self.groups > 1:
+            y = torch.cat([super(FrameBatchNorm2d, self).forward(c) for c in x.chunk(self.groups, 0)], 0)
+        else:
+            y = super().forward(x)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
 
 
 class BasicBlock(nn.Module):
@@ -12,18 +41,17 @@ class BasicBlock(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = FrameBatchNorm2d(planes)
         self.relu = nn.ReLU(inplace=True)
         self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = FrameBatchNorm2d(planes)
         self.downsample = downsample
         self.stride = stride
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        return self.relu(out + idt)
+        out = self.bn1(self.conv1(x), relu=True)
+        return self.bn2(self.conv2(out), residual=idt, relu=True)
 
 
 class ResNet(nn.Module):
@@ -31,7 +59,7 @@ class ResNet(nn.Module):
         super().__init__()
         self.inplanes = 64
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
+        self.bn1 = FrameBatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(3, 2, 1)
         self.layer1 = self._make_layer(block, 64, layers[0])
@@ -51,14 +79,14 @@ class ResNet(nn.Module):
         down = None
         if stride != 1 or self.inplanes != planes * block.expansion:
             down = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
-                                 nn.BatchNorm2d(planes * block.expansion))
+                                 FrameBatchNorm2d(planes * block.expansion))
         layers = [block(self.inplanes, planes, stride, down)]
         self.inplanes = planes * block.expansion
         layers += [block(self.inplanes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(self.bn1(self.conv1(x), relu=True))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return self.fc(self.avgpool(x).flatten(1))
 

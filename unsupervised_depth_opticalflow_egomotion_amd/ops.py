@@ -383,3 +383,62 @@ class BiasActFn(torch.autograd.Function):
 
 def bias_act(z, bias, slope):
     return BiasActFn.apply(z, bias, float(slope))
+
+
+# --------------------------------------------------------------------------- grouped BatchNorm (+ residual + ReLU)
+class GroupedBatchNormFn(torch.autograd.Function):
+    """Training-mode BatchNorm2d over G groups of consecutive samples (statistics per (group, channel); the running
+    statistics get the G momentum updates in group order) fused with an optional residual add and ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, groups, eps, momentum, relu):
+        lib = get_lib()
+        x = f32c(x)
+        N, C, H, W = x.shape
+        G = int(groups)
+        if N % G:
+            raise ValueError("batch %d is not divisible into %d groups" % (N, G))
+        Bg = N // G
+        residual = f32c(residual) if residual is not None else None
+        if residual is not None and residual.shape != x.shape:
+            raise ValueError("residual must have the shape of x")
+        dev = x.device
+        y = torch.empty_like(x)
+        mean = torch.empty(G * C, device=dev)
+        invstd = torch.empty(G * C, device=dev)
+        npart = lib.dfe_bn_partials_floats(G, Bg, C, H, W)
+        part = torch.empty(max(npart, 1), device=dev)
+        check(lib.dfe_bn_fwd(ptr(x), ptr(residual), ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), ptr(y),
+                             ptr(mean), ptr(invstd), ptr(part), G, Bg, C, H, W, float(eps), float(momentum), int(relu),
+                             stream_ptr()), "dfe_bn_fwd")
+        ctx.save_for_backward(x, y if relu else x.new_empty(0), weight if weight is not None else x.new_empty(0), mean, invstd)
+        ctx.cfg = (G, Bg, C, H, W, int(relu), residual is not None, weight is not None)
+        ctx.mark_non_differentiable(mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = get_lib()
+        x, y, weight, mean, invstd = ctx.saved_tensors
+        G, Bg, C, H, W, relu, has_res, has_w = ctx.cfg
+        gy = f32c(gy)
+        dev = x.device
+        gx = torch.empty_like(x)
+        # without a ReLU the residual's gradient is gy itself
+        gres = (torch.empty_like(x) if relu else None) if (has_res and ctx.needs_input_grad[1]) else None
+        gw = torch.empty(C, device=dev) if (has_w and ctx.needs_input_grad[2]) else None
+        gb = torch.empty(C, device=dev) if ctx.needs_input_grad[3] else None
+        part = torch.empty(max(lib.dfe_bn_partials_floats(G, Bg, C, H, W), 1), device=dev)
+        scratch = torch.empty(2 * G * C, device=dev)
+        check(lib.dfe_bn_bwd(ptr(x), ptr(y) if relu else None, ptr(gy), ptr(weight) if has_w else None, ptr(mean), ptr(invstd),
+                             ptr(gx), ptr(gres), ptr(gw), ptr(gb), ptr(part), ptr(scratch), G, Bg, C, H, W, relu,
+                             stream_ptr()), "dfe_bn_bwd")
+        if has_res and ctx.needs_input_grad[1] and not relu:
+            gres = gy
+        return gx, gres, gw, gb, None, None, None, None, None, None
+
+
+def grouped_batch_norm(x, weight, bias, running_mean, running_var, groups=1, eps=1e-5, momentum=0.1, residual=None,
+                       relu=False):
+    return GroupedBatchNormFn.apply(x, residual, weight, bias, running_mean, running_var, int(groups), float(eps),
+                                    float(momentum), bool(relu))
