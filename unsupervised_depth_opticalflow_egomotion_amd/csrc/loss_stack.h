@@ -40,8 +40,6 @@ struct GeomLayout {
   int rollb_start[DFE_MAX_SCALES + 1], rollb_strips[DFE_MAX_SCALES]; // same for the backward kernel
   int fs_start[DFE_MAX_SCALES + 1];                                  // flow-smoothness units (roll_strips x FS_ROWS blocks)
   int dsm_units, dsm_strips;                                         // disparity-smoothness units at full resolution
-  int V;                              // pixels per thread of k_geom_point_fwd (4 when every W_s % 4 == 0, else 1)
-  int vblk_start[DFE_MAX_SCALES + 1]; // its block table
   // workspace offsets in floats
   long o_wgt;       // mode 2: soft occlusion weights, [scale][2][B][N_s] floats
   long o_cams, o_epi, o_pyr, o_area, o_mask, o_yw, o_part, o_spart, o_fpart, o_dpart, o_sums, o_coef, o_dsum,
@@ -55,7 +53,6 @@ struct GeomDev {
   float alpha, beta;
   int H[DFE_MAX_SCALES], W[DFE_MAX_SCALES], N[DFE_MAX_SCALES];
   int blk_start[DFE_MAX_SCALES + 1];
-  int vblk_start[DFE_MAX_SCALES + 1];      // block table of the V-pixels-per-thread kernels
   int roll_start[DFE_MAX_SCALES + 1], roll_strips[DFE_MAX_SCALES];   // rolling-SSIM unit table
   int rollb_start[DFE_MAX_SCALES + 1], rollb_strips[DFE_MAX_SCALES];
   int fs_start[DFE_MAX_SCALES + 1];

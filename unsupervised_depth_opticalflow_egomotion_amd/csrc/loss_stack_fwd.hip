@@ -36,9 +36,6 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
     L->blk_start[s + 1] = L->blk_start[s] + L->nblk[s];
   }
   L->nblk0 = L->nblk[0];
-  // Measured at B=4, 256x832 (MI355X): V=1 48 us, V=2 62 us, V=4 83 us; 128-thread blocks 51 us.  Fatter threads
-  // lose more occupancy / wave count than their wider streams save; the V>1 instantiations stay for large batches.
-  L->V = 1;
   L->roll_start[0] = 0;
   for (int s = 0; s < L->S; ++s) {
     L->roll_strips[s] = (L->W[s] + RS_COLS - 1) / RS_COLS;
@@ -53,8 +50,6 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
     L->rollb_strips[s] = (L->W[s] + RSB_COLS - 1) / RSB_COLS;
     L->rollb_start[s + 1] = L->rollb_start[s] + L->rollb_strips[s] * ((L->H[s] + RSB_ROWS - 1) / RSB_ROWS);
   }
-  L->vblk_start[0] = 0;
-  for (int s = 0; s < L->S; ++s) L->vblk_start[s + 1] = L->vblk_start[s] + (L->N[s] + GS_BLOCK * L->V - 1) / (GS_BLOCK * L->V);
   const long B = L->B, S = L->S, sumN = L->off_px[S];
   const long nblk_total = L->blk_start[S];
   L->pyr_plane = B * 3 * (sumN - L->N[0]);
@@ -83,7 +78,7 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
 void geom_dev(const dfe_geom_args* a, const GeomLayout& L, GeomDev* D) {
   float* ws = a->workspace;
   D->B = L.B; D->S = L.S; D->ac = a->align_corners; D->mode = a->mode; D->alpha = a->alpha; D->beta = a->beta;
-  for (int s = 0; s <= L.S; ++s) { D->blk_start[s] = L.blk_start[s]; D->vblk_start[s] = L.vblk_start[s]; D->roll_start[s] = L.roll_start[s]; D->rollb_start[s] = L.rollb_start[s]; D->fs_start[s] = L.fs_start[s]; }
+  for (int s = 0; s <= L.S; ++s) { D->blk_start[s] = L.blk_start[s]; D->roll_start[s] = L.roll_start[s]; D->rollb_start[s] = L.rollb_start[s]; D->fs_start[s] = L.fs_start[s]; }
   for (int s = 0; s < L.S; ++s) {
     D->H[s] = L.H[s]; D->W[s] = L.W[s]; D->N[s] = L.N[s]; D->roll_strips[s] = L.roll_strips[s]; D->rollb_strips[s] = L.rollb_strips[s];
     const long lvl = static_cast<long>(L.B) * 3 * (L.off_px[s] - L.N[0]);   // offset of level s (>=1) in a frame's block
@@ -229,12 +224,11 @@ __global__ void __launch_bounds__(64) k_geom_area_coarse(PyrJobs jobs) {
 }
 
 // ---------------------------------------------------------------------- pointwise forward
-// Bound by the number of memory instructions (TA_BUSY 80 %: the texture-address unit takes ~16 cycles per
-// wave-wide load whatever its width) and then by VALU issue (profiles/r01b_pmc_loss_stack.json).  Hence:
-// V = 4 pixels per thread with 16-byte loads/stores for every non-gathered stream (target, flows, disparity,
-// sources at p, warped output, mask pack), one 8-byte load per footprint row for the gathers, block sums
-// amortised over the 4 pixels, exact 3-instruction divisions by launch constants, integer bounds tests and
-// 32-bit byte offsets from block-uniform bases.  V = 1 when some W_s is not a multiple of 4 (e.g. 1242x375).
+// Bound first by the number of memory instructions (the texture-address unit takes ~16 cycles per wave-wide load
+// whatever its width) and then by VALU issue (profiles/r01b_pmc_loss_stack.json).  Hence: one pixel per thread (2 / 4
+// pixels per thread with 8 / 16-byte streams measured slower at B = 4: too few waves), one dword-aligned 8-byte load
+// per footprint row of the gathers, exact 3-instruction divisions by launch constants, integer bounds tests and
+// 32-bit byte offsets from block-uniform bases.
 struct PointCtx {
   int b, s, H, W, ac;
   unsigned N4;
@@ -321,34 +315,19 @@ __device__ __forceinline__ void point_pixel(const PointCtx& c, int px, int py, c
   acc[PT_CONSIS] += (fabsf(in.fu[1] * rf + in.fu[0] * rb) + fabsf(in.fv[1] * rf + in.fv[0] * rb)) * inv;
 }
 
-template <int V> struct VecF;
-template <> struct VecF<1> { float v[1]; };
-template <> struct __attribute__((aligned(8))) VecF<2> { float v[2]; };
-template <> struct __attribute__((aligned(16))) VecF<4> { float v[4]; };
-
-template <int V>
-__device__ __forceinline__ VecF<V> ldv(const float* __restrict__ base, unsigned byte_off) {
-  return *reinterpret_cast<const VecF<V>*>(reinterpret_cast<const char*>(base) + byte_off);
-}
-template <int V>
-__device__ __forceinline__ void stv(float* __restrict__ base, unsigned byte_off, const VecF<V>& x) {
-  *reinterpret_cast<VecF<V>*>(reinterpret_cast<char*>(base) + byte_off) = x;
-}
-
-template <int V>
 __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, float* __restrict__ part) {
   __shared__ float red[PT_COUNT * 4 * (GS_BLOCK / 64)];
-  const unsigned nblk_total = D.vblk_start[D.S];
+  const unsigned nblk_total = D.blk_start[D.S];
   const unsigned blk = xcd_swizzle(blockIdx.x, nblk_total);
   const int b = blockIdx.y;
-  const int s = find_scale(D.vblk_start, D.S, blk);
+  const int s = find_scale(D.blk_start, D.S, blk);
   const int H = D.H[s], W = D.W[s], N = D.N[s];
-  const unsigned p = ((blk - D.vblk_start[s]) * GS_BLOCK + threadIdx.x) * V;
+  const unsigned p = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
   float acc[PT_COUNT];
 #pragma unroll
   for (int i = 0; i < PT_COUNT; ++i) acc[i] = 0.0f;
   if (p < static_cast<unsigned>(N)) {
-    const unsigned py = p / static_cast<unsigned>(W), px0 = p - py * W;
+    const unsigned py = p / static_cast<unsigned>(W), px = p - py * W;
     const unsigned p4 = p * 4u, N4 = static_cast<unsigned>(N) * 4u;
     PointCtx c;
     c.b = b; c.s = s; c.H = H; c.W = W; c.ac = D.ac; c.N4 = N4; c.alpha = D.alpha; c.beta = D.beta;
@@ -359,40 +338,22 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, float* _
     const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
     const float* flb = D.flow[0][s] + static_cast<long>(b) * 2 * N;
     const float* flf = D.flow[1][s] + static_cast<long>(b) * 2 * N;
-    const VecF<V> t0 = ldv<V>(it, p4), t1 = ldv<V>(it, p4 + N4), t2 = ldv<V>(it, p4 + 2 * N4);
-    const VecF<V> ub = ldv<V>(flb, p4), vb = ldv<V>(flb, p4 + N4), uf = ldv<V>(flf, p4), vf = ldv<V>(flf, p4 + N4);
-    const VecF<V> dd = ldv<V>(D.disp[1][s] + static_cast<long>(b) * N, p4);
-    const VecF<V> l0 = ldv<V>(c.srcL, p4), l1 = ldv<V>(c.srcL, p4 + N4), l2 = ldv<V>(c.srcL, p4 + 2 * N4);
-    const VecF<V> r0 = ldv<V>(c.srcR, p4), r1 = ldv<V>(c.srcR, p4 + N4), r2 = ldv<V>(c.srcR, p4 + 2 * N4);
-    VecF<V> yo[2][3];
-    unsigned packed = 0;
-#pragma unroll
-    for (int u = 0; u < V; ++u) {
-      PixIn in;
-      in.i0 = t0.v[u]; in.i1 = t1.v[u]; in.i2 = t2.v[u];
-      in.fu[0] = ub.v[u]; in.fv[0] = vb.v[u]; in.fu[1] = uf.v[u]; in.fv[1] = vf.v[u];
-      in.dsp = dd.v[u];
-      in.sl[0] = l0.v[u]; in.sl[1] = l1.v[u]; in.sl[2] = l2.v[u];
-      in.sr[0] = r0.v[u]; in.sr[1] = r1.v[u]; in.sr[2] = r2.v[u];
-      float yw[2][3];
-      unsigned bits;
-      point_pixel(c, static_cast<int>(px0) + u, static_cast<int>(py), in, yw, bits, acc);
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) yo[d][ch].v[u] = yw[d][ch];
-      packed |= bits << (8 * u);
-    }
+    PixIn in;
+    in.i0 = ldb(it, p4); in.i1 = ldb(it, p4 + N4); in.i2 = ldb(it, p4 + 2 * N4);
+    in.fu[0] = ldb(flb, p4); in.fv[0] = ldb(flb, p4 + N4); in.fu[1] = ldb(flf, p4); in.fv[1] = ldb(flf, p4 + N4);
+    in.dsp = ldb(D.disp[1][s] + static_cast<long>(b) * N, p4);
+    in.sl[0] = ldb(c.srcL, p4); in.sl[1] = ldb(c.srcL, p4 + N4); in.sl[2] = ldb(c.srcL, p4 + 2 * N4);
+    in.sr[0] = ldb(c.srcR, p4); in.sr[1] = ldb(c.srcR, p4 + N4); in.sr[2] = ldb(c.srcR, p4 + 2 * N4);
+    float yw[2][3];
+    unsigned bits;
+    point_pixel(c, static_cast<int>(px), static_cast<int>(py), in, yw, bits, acc);
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
       float* ywp = D.yw[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) stv<V>(ywp, p4 + ch * N4, yo[d][ch]);
+      for (int ch = 0; ch < 3; ++ch) stb(ywp, p4 + ch * N4, yw[d][ch]);
     }
-    unsigned char* mk = D.mask[s] + static_cast<long>(b) * N + p;
-    if (V == 4) *reinterpret_cast<unsigned*>(mk) = packed;
-    else if (V == 2) *reinterpret_cast<unsigned short*>(mk) = static_cast<unsigned short>(packed);
-    else *mk = static_cast<unsigned char>(packed);
+    (D.mask[s] + static_cast<long>(b) * N)[p] = static_cast<unsigned char>(bits);
   }
   block_sum<PT_COUNT>(acc, red, part + (static_cast<long>(b) * nblk_total + blk) * PT_COUNT);
 }
@@ -402,12 +363,12 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, float* _
 // validity * texture mask, masked-L1 sums.  One pixel per thread over the 1-px block table.
 __global__ void __launch_bounds__(GS_BLOCK) k_depth_point_fwd(GeomDev D, float* __restrict__ part) {
   __shared__ float red[PT_COUNT * 4 * (GS_BLOCK / 64)];
-  const unsigned nblk_total = D.vblk_start[D.S];
+  const unsigned nblk_total = D.blk_start[D.S];
   const unsigned blk = xcd_swizzle(blockIdx.x, nblk_total);
   const int b = blockIdx.y;
-  const int s = find_scale(D.vblk_start, D.S, blk);
+  const int s = find_scale(D.blk_start, D.S, blk);
   const int H = D.H[s], W = D.W[s], N = D.N[s];
-  const unsigned p = (blk - D.vblk_start[s]) * GS_BLOCK + threadIdx.x;
+  const unsigned p = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
   float acc[PT_COUNT];
 #pragma unroll
   for (int i = 0; i < PT_COUNT; ++i) acc[i] = 0.0f;
@@ -449,12 +410,12 @@ __global__ void __launch_bounds__(GS_BLOCK) k_depth_point_fwd(GeomDev D, float* 
 // consistency on (1 - weight_fwd).  Writes the float weights and the weighted warped images.
 __global__ void __launch_bounds__(GS_BLOCK) k_flow_point_fwd(GeomDev D, float* __restrict__ part) {
   __shared__ float red[PT_COUNT * 4 * (GS_BLOCK / 64)];
-  const unsigned nblk_total = D.vblk_start[D.S];
+  const unsigned nblk_total = D.blk_start[D.S];
   const unsigned blk = xcd_swizzle(blockIdx.x, nblk_total);
   const int b = blockIdx.y;
-  const int s = find_scale(D.vblk_start, D.S, blk);
+  const int s = find_scale(D.blk_start, D.S, blk);
   const int H = D.H[s], W = D.W[s], N = D.N[s];
-  const unsigned p = (blk - D.vblk_start[s]) * GS_BLOCK + threadIdx.x;
+  const unsigned p = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
   float acc[PT_COUNT];
 #pragma unroll
   for (int i = 0; i < PT_COUNT; ++i) acc[i] = 0.0f;
@@ -691,8 +652,8 @@ __global__ void __launch_bounds__(256) k_geom_reduce_fwd(GeomDev D, const float*
     double a[SUM_COUNT];
 #pragma unroll
     for (int i = 0; i < SUM_COUNT; ++i) a[i] = 0.0;
-    for (int k = D.vblk_start[s] + t; k < D.vblk_start[s + 1]; k += 256) {
-      const float* r = part + (static_cast<long>(b) * D.vblk_start[S] + k) * PT_COUNT;
+    for (int k = D.blk_start[s] + t; k < D.blk_start[s + 1]; k += 256) {
+      const float* r = part + (static_cast<long>(b) * D.blk_start[S] + k) * PT_COUNT;
 #pragma unroll
       for (int i = 0; i < PT_COUNT; ++i) a[i] += r[i];
     }
@@ -890,7 +851,7 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   DFE_MARK();
   if (a->mode == 2) {
     // Model_flow: flow warps + soft weights + weighted L1 / SSIM / smoothness / consistency (no depth, no pose)
-    k_flow_point_fwd<<<dim3(L.vblk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
+    k_flow_point_fwd<<<dim3(L.blk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
     DFE_LAUNCH_CHECK();
     DFE_MARK();
     k_geom_ssim_fwd_roll<<<dim3(L.roll_start[L.S], L.B * 2), 64, 0, st>>>(D, ws + L.o_spart);
@@ -901,20 +862,11 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     DFE_MARK();
   } else if (a->mode == 1) {
     // Model_depth: rigid recon + validity*texture mask + masked L1 only (no flows, no SSIM, no flow terms)
-    k_depth_point_fwd<<<dim3(L.vblk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
+    k_depth_point_fwd<<<dim3(L.blk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
     DFE_LAUNCH_CHECK();
     DFE_MARK(); DFE_MARK(); DFE_MARK();
   } else {
-    // the 16-byte path also needs 16-byte aligned streams (torch allocations are; views may not be)
-    bool al = true;
-    auto chk = [&](const void* q) { al = al && ((reinterpret_cast<uintptr_t>(q) & 15) == 0); };
-    for (int f = 0; f < 3; ++f) chk(a->img[f]);
-    for (int sc = 0; sc < L.S; ++sc) { chk(a->disp[1][sc]); chk(a->flow[0][sc]); chk(a->flow[1][sc]); }
-    chk(ws);
-    if (L.V == 4 && !al) return DFE_ERR_UNSUPPORTED;   // callers pass contiguous torch tensors; never hit in practice
-    if (L.V == 4) k_geom_point_fwd<4><<<dim3(L.vblk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
-    else if (L.V == 2) k_geom_point_fwd<2><<<dim3(L.vblk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
-    else k_geom_point_fwd<1><<<dim3(L.vblk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
+    k_geom_point_fwd<<<dim3(L.blk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
     DFE_LAUNCH_CHECK();
     DFE_MARK();
     k_geom_ssim_fwd_roll<<<dim3(L.roll_start[L.S], L.B * 2), 64, 0, st>>>(D, ws + L.o_spart);

@@ -9,7 +9,7 @@
 // fixed order).
 // Both read the convolution output once and write the next convolution's padded input once; the backward passes
 // are gathers (no atomics: bitwise reproducible).  Bound: HBM (1 read + 1 write per element, 4 B each).
-// Arithmetic follows ATen's CPU kernels: elu(x) = x > 0 ? x : expm1(x); elu'(x) = x > 0 ? 1 : exp(x);
+// Arithmetic: elu(x) = x > 0 ? x : exp(x) - 1; elu'(x) = x > 0 ? 1 : exp(x) (ATen: expm1 / exp);
 // bilinear x2 with align_corners=False: src = max(0.5*(dst+0.5)-0.5, 0), (v0*l0 + v1*l1) horizontally first.
 #include "dfe_internal.h"
 #include "dfe_device.h"
@@ -17,8 +17,10 @@
 
 namespace dfe {
 
-__device__ __forceinline__ float elu1(float v) { return v > 0.0f ? v : expm1f(v); }
-__device__ __forceinline__ float elu1_grad(float v) { return v > 0.0f ? 1.0f : expf(v); }
+// exp through the hardware v_exp_f32 (absolute error ~1e-7 on these O(1) activations; expm1's extra digits near 0
+// are far below the convolutions' own rounding)
+__device__ __forceinline__ float elu1(float v) { return v > 0.0f ? v : __expf(v) - 1.0f; }
+__device__ __forceinline__ float elu1_grad(float v) { return v > 0.0f ? 1.0f : __expf(v); }
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
 // taps of F.interpolate(scale_factor=2, bilinear, align_corners=False) at destination index d (source length n)
@@ -97,7 +99,12 @@ __global__ void __launch_bounds__(256) k_elu_up2_cat_pad_fwd(const float* __rest
     const float* r0 = p + static_cast<long>(y0) * w;
     const float* r1 = p + static_cast<long>(y1) * w;
     const float bv = bias ? bias[c] : 0.0f;
-    v = ly0 * (lx0 * elu1(r0[x0] + bv) + lx1 * elu1(r0[x1] + bv)) + ly1 * (lx0 * elu1(r1[x0] + bv) + lx1 * elu1(r1[x1] + bv));
+    float v00, v01, v10, v11;
+    if (x1 == x0 + 1) {       // the two taps of a row in one dword-aligned 8-byte load
+      const PairF a = *reinterpret_cast<const PairF*>(r0 + x0), d = *reinterpret_cast<const PairF*>(r1 + x0);
+      v00 = a.a; v01 = a.b; v10 = d.a; v11 = d.b;
+    } else { v00 = v01 = r0[x0]; v10 = v11 = r1[x0]; }
+    v = ly0 * (lx0 * elu1(v00 + bv) + lx1 * elu1(v01 + bv)) + ly1 * (lx0 * elu1(v10 + bv) + lx1 * elu1(v11 + bv));
   } else {
     v = skip[((static_cast<long>(b) * C2 + (c - C1)) * H + y) * W + xx];
   }
@@ -117,6 +124,19 @@ __global__ void __launch_bounds__(256) k_elu_up2_cat_pad_bwd_x(const float* __re
   const int i = e / static_cast<unsigned>(w), j = e - i * w;
   const int b = blockIdx.y / C1, c = blockIdx.y - b * C1;
   const float* g = gp + (static_cast<long>(b) * (C1 + C2) + c) * (H + 2) * (W + 2);
+  float total = 0.0f;
+  if (i >= 2 && i < h - 2 && j >= 2 && j < w - 2) {
+    // interior: the 4x4 outputs (rows 2i-1..2i+2, columns 2j-1..2j+2) map one-to-one onto the padded plane and the
+    // tent weights are (1/4, 3/4, 3/4, 1/4) on both axes; two 8-byte loads per row
+    const float* q = g + static_cast<long>(2 * i) * (W + 2) + 2 * j;
+    const float wk[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+      const PairF a = *reinterpret_cast<const PairF*>(q + static_cast<long>(ky) * (W + 2));
+      const PairF d = *reinterpret_cast<const PairF*>(q + static_cast<long>(ky) * (W + 2) + 2);
+      total += wk[ky] * (((0.25f * a.a + 0.75f * a.b) + 0.75f * d.a) + 0.25f * d.b);
+    }
+  } else {
   float wy[4], wx[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -128,7 +148,6 @@ __global__ void __launch_bounds__(256) k_elu_up2_cat_pad_bwd_x(const float* __re
     up2_tap(min(max(xq, 0), W - 1), w, a0, a1, l0, l1);
     wx[k] = (xq >= 0 && xq < W) ? ((a0 == j ? l0 : 0.0f) + (a1 == j ? l1 : 0.0f)) : 0.0f;
   }
-  float total = 0.0f;
 #pragma unroll
   for (int ky = 0; ky < 4; ++ky) {
     if (wy[ky] == 0.0f) continue;
@@ -137,6 +156,7 @@ __global__ void __launch_bounds__(256) k_elu_up2_cat_pad_bwd_x(const float* __re
     for (int kx = 0; kx < 4; ++kx)
       if (wx[kx] != 0.0f) acc += wx[kx] * pad_adjoint(g, 2 * i - 1 + ky, 2 * j - 1 + kx, H, W);
     total += wy[ky] * acc;
+  }
   }
   const long o = ((static_cast<long>(b) * C1 + c) * h + i) * w + j;
   acc[0] = total * elu1_grad(x[o] + (bias ? bias[c] : 0.0f));
