@@ -40,6 +40,22 @@ def test_error_strings_and_argument_checks_without_gpu():
     assert lib.dfe_geom_workspace_floats(ctypes.byref(a)) == -2
     a.num_scales, a.mode = 3, 3      # modes 0 (geom), 1 (depth), 2 (flow) exist
     assert lib.dfe_geom_workspace_floats(ctypes.byref(a)) == -4
+    # net-glue entry points: NULL / dimension checks, scratch sizes
+    P = ctypes.c_void_p(16)
+    assert lib.dfe_bias_act_fwd(None, None, 1, 1, 8, 8, 0.1, None) == -1
+    assert lib.dfe_bias_act_fwd(P, None, 0, 1, 8, 8, 0.1, None) == -2
+    assert lib.dfe_bias_act_bwd(P, P, 10, P, None, None, 1, 4, 8, 8, 0.1, None) == -2      # batch stride < C*H*W
+    assert lib.dfe_bias_act_partials_floats(4, 16, 64, 208) == 4 * 16 * 7                  # ceil(13312 / 2048) blocks per plane
+    assert lib.dfe_elu_pad_fwd(P, None, P, 1, 1, 1, 5, 1, None) == -2                      # 1-pixel planes cannot be reflected
+    assert lib.dfe_elu_pad_bwd(None, None, P, P, None, None, 1, 1, 4, 4, 1, None) == -1    # ELU backward needs x
+    assert lib.dfe_elu_up2_cat_pad_fwd(P, None, None, P, 1, 2, 3, 4, 4, None) == -1        # C2 > 0 without a skip tensor
+    assert lib.dfe_elu_up2_cat_pad_bwd(P, None, P, None, None, None, None, 1, 2, 0, 4, 4, None) == -1
+    assert lib.dfe_glue_partials_floats(2, 3, 16, 16) == 2 * 3 * 1
+    assert lib.dfe_bn_partials_floats(3, 4, 64, 64, 208) == 3 * 4 * 64 * 7 * 3
+    assert lib.dfe_bn_fwd(P, None, P, P, None, None, P, P, P, P, 1, 1, 4, 1, 1, 1e-5, 0.1, 0, None) == -2   # one value per channel
+    assert lib.dfe_bn_fwd(P, None, P, P, None, None, None, P, P, P, 1, 2, 4, 8, 8, 1e-5, 0.1, 0, None) == -1
+    assert lib.dfe_bn_bwd(P, None, P, P, P, P, P, None, None, None, P, P, 1, 2, 4, 8, 8, 1, None) == -1       # ReLU mask needs y
+    assert lib.dfe_geom_timed_collect(None, None) == -1
 
 
 def test_no_cpu_fallback():
