@@ -111,6 +111,16 @@ int dfe_elu_up2_cat_pad_fwd(const float* x, const float* bias, const float* skip
 int dfe_elu_up2_cat_pad_bwd(const float* x, const float* bias, const float* gout, float* gx, float* gskip, float* gbias,
                             float* partials, int B, int C1, int C2, int h, int w, void* stream);
 
+/* ---- disparity head of the depth decoder (depth_model.py: dispconv = Conv3x3(C -> 1) + Sigmoid per output scale):
+ * out [B,1,H,W] = sigmoid(conv3x3(p) + bias[0]) on the reflection-padded activation p [B,C,H+2,W+2], weight [1,C,3,3];
+ * C must be a multiple of 16 (DFE_ERR_UNSUPPORTED otherwise).  Backward: gp [B,C,H+2,W+2] (every element written),
+ * gweight [C*9] / gbias [1] (may both be NULL); partials: dfe_disp_head_partials_floats floats of scratch. */
+long dfe_disp_head_partials_floats(int B, int C, int H, int W);
+int dfe_disp_head_fwd(const float* p, const float* weight, const float* bias, float* out, int B, int C, int H, int W,
+                      void* stream);
+int dfe_disp_head_bwd(const float* p, const float* weight, const float* out, const float* gout, float* gp, float* gweight,
+                      float* gbias, float* partials, int B, int C, int H, int W, void* stream);
+
 /* ---- grouped training-mode BatchNorm2d (+ residual + ReLU) of the depth encoder (SURVEY.md 8(f) rank 1;
  * depth_model.py:60-95 = torchvision BasicBlock conv-bn-relu-conv-bn-(+identity)-relu; model_geometry.py:786-788 calls the
  * depth net once per frame).  x [G*Bg,C,H,W] is G groups of Bg consecutive samples: statistics are per (group, channel)

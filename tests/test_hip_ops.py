@@ -479,3 +479,37 @@ def test_depth_net_frames_match_sequential_calls():
             assert pg[k].grad is None, k
             continue
         gclose(pg[k].grad, pc[k].grad, rel=2e-3, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------- disparity head
+@pytest.mark.parametrize("shape", [(2, 16, 5, 7), (1, 32, 20, 130), (3, 16, 33, 61), (2, 64, 16, 52), (12, 16, 64, 208)])
+def test_disp_head(shape):
+    """sigmoid(conv3x3(p) + b) and its backward against F.conv2d + sigmoid on the CPU: disparities 2e-6, gradients
+    1e-4 of their scale (sums of 9*C products, and of all pixels for the weight gradient, in another order)."""
+    import torch.nn.functional as F
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+    B, C, H, W = shape
+    rng = np.random.RandomState(sum(shape))
+    p = rng.randn(B, C, H + 2, W + 2).astype(np.float32)
+    w = (rng.randn(1, C, 3, 3) * 0.2).astype(np.float32)
+    bias = rng.randn(1).astype(np.float32)
+    r = rng.randn(B, 1, H, W).astype(np.float32)
+    ph, wh, bh = G(p, True), G(w, True), G(bias, True)
+    po, wo, bo = T(p).requires_grad_(True), T(w).requires_grad_(True), T(bias).requires_grad_(True)
+    yh = ops.disp_head(ph, wh, bh)
+    yo = torch.sigmoid(F.conv2d(po, wo, bo))
+    (yh * G(r)).sum().backward()
+    (yo * T(r)).sum().backward()
+    close(yh, yo, atol=2e-6, rtol=2e-6)
+    gclose(ph.grad, po.grad, rel=1e-4, atol=1e-7)
+    gclose(wh.grad, wo.grad, rel=1e-4, atol=1e-5)
+    gclose(bh.grad, bo.grad, rel=1e-4, atol=1e-5)
+
+
+def test_disp_head_argument_errors():
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+    from unsupervised_depth_opticalflow_egomotion_amd._lib import DfeError
+    with pytest.raises(DfeError):            # channel count must be a multiple of 16
+        ops.disp_head(torch.zeros(1, 8, 6, 6, device=dev()), torch.zeros(1, 8, 3, 3, device=dev()), None)
+    with pytest.raises(ValueError):
+        ops.disp_head(torch.zeros(1, 16, 6, 6, device=dev()), torch.zeros(2, 16, 3, 3, device=dev()), None)

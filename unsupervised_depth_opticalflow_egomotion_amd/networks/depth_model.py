@@ -100,7 +100,8 @@ class DepthDecoder(nn.Module):
             if scale in self.scales or scale > 0:
                 p = ops.elu_pad(c, c1.bias, apply_elu=True)      # shared by the disparity head and the next stage
             if scale in self.scales:
-                out[scale] = self.sigmoid(self.dispconvs[self.scales.index(scale)].conv(p))
+                head = self.dispconvs[self.scales.index(scale)].conv
+                out[scale] = ops.disp_head(p, head.weight, head.bias)      # Conv3x3(C -> 1) + bias + sigmoid
         return out
 
 

@@ -442,3 +442,42 @@ def grouped_batch_norm(x, weight, bias, running_mean, running_var, groups=1, eps
                        relu=False):
     return GroupedBatchNormFn.apply(x, residual, weight, bias, running_mean, running_var, int(groups), float(eps),
                                     float(momentum), bool(relu))
+
+
+# --------------------------------------------------------------------------- disparity head (Conv3x3(C -> 1) + sigmoid)
+class DispHeadFn(torch.autograd.Function):
+    """sigmoid(conv3x3(p) + bias) on a reflection-padded activation p [B,C,H+2,W+2] -> [B,1,H,W]."""
+
+    @staticmethod
+    def forward(ctx, p, weight, bias):
+        lib = get_lib()
+        p, weight = f32c(p), f32c(weight)
+        bias = f32c(bias) if bias is not None else None
+        B, C, Hp, Wp = p.shape
+        if tuple(weight.shape) != (1, C, 3, 3):
+            raise ValueError("weight must be [1,%d,3,3], got %s" % (C, tuple(weight.shape)))
+        H, W = Hp - 2, Wp - 2
+        out = torch.empty(B, 1, H, W, device=p.device)
+        check(lib.dfe_disp_head_fwd(ptr(p), ptr(weight), ptr(bias), ptr(out), B, C, H, W, stream_ptr()), "dfe_disp_head_fwd")
+        ctx.save_for_backward(p, weight, out)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = get_lib()
+        p, weight, out = ctx.saved_tensors
+        B, C, Hp, Wp = p.shape
+        H, W = Hp - 2, Wp - 2
+        gout = f32c(gout)
+        gp = torch.empty_like(p)
+        gw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
+        gb = torch.empty(1, device=p.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        part = torch.empty(lib.dfe_disp_head_partials_floats(B, C, H, W), device=p.device)
+        check(lib.dfe_disp_head_bwd(ptr(p), ptr(weight), ptr(out), ptr(gout), ptr(gp), ptr(gw), ptr(gb), ptr(part), B, C, H, W,
+                                    stream_ptr()), "dfe_disp_head_bwd")
+        return gp, gw, gb
+
+
+def disp_head(p, weight, bias):
+    return DispHeadFn.apply(p, weight, bias)
