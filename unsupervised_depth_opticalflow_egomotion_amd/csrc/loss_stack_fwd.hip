@@ -315,6 +315,60 @@ __device__ __forceinline__ void point_pixel(const PointCtx& c, int px, int py, c
   acc[PT_CONSIS] += (fabsf(in.fu[1] * rf + in.fu[0] * rb) + fabsf(in.fv[1] * rf + in.fv[0] * rb)) * inv;
 }
 
+// Block sums of k_geom_point_fwd's PT_COUNT per-thread values (one pixel per thread).  Nine of them are {0,1} mask
+// indicators: their sums are wave population counts (v_cmp + s_bcnt1, exact) instead of float butterflies; the eleven
+// float entries take the DPP tree of block_sum.  smem: 11 * 4 * nwaves floats + 9 * nwaves counts.
+__device__ __forceinline__ void point_block_sums(float (&acc)[PT_COUNT], float* smem, float* out) {
+  constexpr int NF = 11, NC = 9;
+  constexpr int FI[NF] = {PT_L1_DEPTH, PT_L1_RIG, PT_L1_DYN, PT_FDIFF, PT_EPI,
+                          PT_PER_DIR + PT_L1_DEPTH, PT_PER_DIR + PT_L1_RIG, PT_PER_DIR + PT_L1_DYN, PT_PER_DIR + PT_FDIFF,
+                          PT_PER_DIR + PT_EPI, PT_CONSIS};
+  constexpr int CI[NC] = {PT_M_TEX, PT_M_RIG, PT_M_DYN, PT_M_VO, PT_PER_DIR + PT_M_TEX, PT_PER_DIR + PT_M_RIG,
+                          PT_PER_DIR + PT_M_DYN, PT_PER_DIR + PT_M_VO, PT_INV};
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NW = GS_BLOCK / 64;
+  float f[NF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i) f[i] = acc[FI[i]];
+#pragma unroll
+  for (int i = 0; i < NF; ++i) f[i] = dpp_add<0xB1>(f[i]);
+#pragma unroll
+  for (int i = 0; i < NF; ++i) f[i] = dpp_add<0x4E>(f[i]);
+#pragma unroll
+  for (int i = 0; i < NF; ++i) f[i] = dpp_add<0x141>(f[i]);
+#pragma unroll
+  for (int i = 0; i < NF; ++i) f[i] = dpp_add<0x140>(f[i]);
+  if ((lane & 15) == 0) {
+    const int slot = wave * 4 + (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < NF; ++i) smem[slot * NF + i] = f[i];
+  }
+  float* cnt = smem + NF * 4 * NW;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const unsigned long long m = __ballot(acc[CI[i]] != 0.0f);
+    if (lane == 0) cnt[wave * NC + i] = static_cast<float>(__popcll(m));
+  }
+  __syncthreads();
+  if (threadIdx.x < NF) {
+    float sum = 0.0f;
+    for (int w = 0; w < 4 * NW; ++w) sum += smem[w * NF + threadIdx.x];
+    int dst = 0;
+#pragma unroll
+    for (int i = 0; i < NF; ++i) dst = (static_cast<int>(threadIdx.x) == i) ? FI[i] : dst;
+    out[dst] = sum;
+  } else if (threadIdx.x < NF + NC) {
+    const int t = threadIdx.x - NF;
+    float sum = 0.0f;
+    for (int w = 0; w < NW; ++w) sum += cnt[w * NC + t];
+    int dst = 0;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) dst = (t == i) ? CI[i] : dst;
+    out[dst] = sum;
+  }
+  __syncthreads();
+}
+
 __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, float* __restrict__ part) {
   __shared__ float red[PT_COUNT * 4 * (GS_BLOCK / 64)];
   const unsigned nblk_total = D.blk_start[D.S];
@@ -355,7 +409,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, float* _
     }
     (D.mask[s] + static_cast<long>(b) * N)[p] = static_cast<unsigned char>(bits);
   }
-  block_sum<PT_COUNT>(acc, red, part + (static_cast<long>(b) * nblk_total + blk) * PT_COUNT);
+  point_block_sums(acc, red, part + (static_cast<long>(b) * nblk_total + blk) * PT_COUNT);
 }
 
 // ---------------------------------------------------------------------- depth-only pointwise forward
