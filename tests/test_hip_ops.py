@@ -513,3 +513,22 @@ def test_disp_head_argument_errors():
         ops.disp_head(torch.zeros(1, 8, 6, 6, device=dev()), torch.zeros(1, 8, 3, 3, device=dev()), None)
     with pytest.raises(ValueError):
         ops.disp_head(torch.zeros(1, 16, 6, 6, device=dev()), torch.zeros(2, 16, 3, 3, device=dev()), None)
+
+
+def test_net_glue_many_planes():
+    """B*C above 65535 (the grid is (chunks, C, B), not (chunks, B*C)): bias_act, elu_pad and grouped batch norm on
+    70 x 1024 planes of 2x3 pixels against the host composition."""
+    import torch.nn.functional as F
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+    rng = np.random.RandomState(9)
+    B, C = 70, 1024
+    x = rng.randn(B, C, 2, 3).astype(np.float32)
+    bias = rng.randn(C).astype(np.float32)
+    y = ops.bias_act(G(x) * 1.0, G(bias), 0.1)
+    np.testing.assert_array_equal(N(y), N(F.leaky_relu(T(x) + T(bias)[None, :, None, None], 0.1)))
+    close(ops.elu_pad(G(x), G(bias), True), _ref_elu_pad(T(x), T(bias), True), atol=2e-6, rtol=2e-6)
+    w = rng.rand(C).astype(np.float32) + 0.5
+    rm, rv = torch.zeros(C, device=dev()), torch.ones(C, device=dev())
+    yb = ops.grouped_batch_norm(G(x), G(w), G(bias), rm, rv, groups=2, relu=True)
+    ref = torch.cat([F.batch_norm(c, None, None, T(w), T(bias), True) for c in T(x).chunk(2, 0)], 0).relu()
+    close(yb, ref, atol=2e-5, rtol=2e-5)

@@ -399,6 +399,9 @@ __device__ __forceinline__ void block_sum(float (&vals)[N], float* smem, float* 
   __syncthreads();
 }
 
+// (n, c) plane of an NCHW tensor for launches with grid = (chunks, C, N): n * C + c (both limits 65535)
+__device__ __forceinline__ unsigned plane_id() { return blockIdx.z * gridDim.y + blockIdx.y; }
+
 // XCD-aware block index: consecutive logical blocks land on the same XCD (blocks are dealt
 // round-robin over the 8 XCDs; MI355X_MICROARCH.md "Workgroup dispatch").  Speed only.
 __device__ __forceinline__ unsigned xcd_swizzle(unsigned bid, unsigned nblocks) {

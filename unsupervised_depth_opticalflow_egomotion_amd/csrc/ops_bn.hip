@@ -74,13 +74,13 @@ __device__ __forceinline__ void store8(float* __restrict__ p, int base, int HW, 
   }
 }
 
-// ---- forward pass 1: per block (count, mean, M2) of its chunk of plane (n, c).  grid: (nchunk, N*C)
+// ---- forward pass 1: per block (count, mean, M2) of its chunk of plane (n, c).  grid: (nchunk, C, N)
 template <bool VEC>
 __global__ void __launch_bounds__(BN_BLOCK) k_bn_stats(const float* __restrict__ x, float* __restrict__ part, int HW) {
   __shared__ float smem[4 * (BN_BLOCK / 64)];
   const int base = blockIdx.x * BN_CHUNK;
   float v[BN_PER_THREAD]; bool ok[BN_PER_THREAD];
-  load8<VEC>(x + static_cast<long>(blockIdx.y) * HW, base, HW, v, ok);
+  load8<VEC>(x + static_cast<long>(plane_id()) * HW, base, HW, v, ok);
   float s = 0.0f;
 #pragma unroll
   for (int k = 0; k < BN_PER_THREAD; ++k) s += v[k];
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(BN_BLOCK) k_bn_stats(const float* __restrict__
   for (int k = 0; k < BN_PER_THREAD; ++k) { const float d = ok[k] ? v[k] - mean : 0.0f; m2 += d * d; }
   m2 = block_allsum(m2, smem);
   if (threadIdx.x == 0) {
-    float* o = part + (static_cast<long>(blockIdx.y) * gridDim.x + blockIdx.x) * 3;
+    float* o = part + (static_cast<long>(plane_id()) * gridDim.x + blockIdx.x) * 3;
     o[0] = cnt; o[1] = mean; o[2] = m2;
   }
 }
@@ -145,16 +145,16 @@ __global__ void __launch_bounds__(64) k_bn_finalize(const float* __restrict__ pa
   }
 }
 
-// ---- forward pass 2: y = act((x - mean) * (invstd * w) + b [+ res]).  grid: (nchunk, N*C)
+// ---- forward pass 2: y = act((x - mean) * (invstd * w) + b [+ res]).  grid: (nchunk, C, N)
 template <bool VEC>
 __global__ void __launch_bounds__(BN_BLOCK) k_bn_apply(const float* __restrict__ x, const float* __restrict__ res,
                                                        const float* __restrict__ weight, const float* __restrict__ bias,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        float* __restrict__ y, int Bg, int C, int HW, int relu) {
-  const int n = blockIdx.y / C, c = blockIdx.y - n * C, g = n / Bg;
+  const int n = plane_id() / C, c = plane_id() - n * C, g = n / Bg;
   const float mu = mean[g * C + c], sc = invstd[g * C + c] * (weight ? weight[c] : 1.0f), sh = bias ? bias[c] : 0.0f;
   const int base = blockIdx.x * BN_CHUNK;
-  const long off = static_cast<long>(blockIdx.y) * HW;
+  const long off = static_cast<long>(plane_id()) * HW;
   float v[BN_PER_THREAD], r[BN_PER_THREAD]; bool ok[BN_PER_THREAD];
   load8<VEC>(x + off, base, HW, v, ok);
   if (res) load8<VEC>(res + off, base, HW, r, ok);
@@ -167,17 +167,17 @@ __global__ void __launch_bounds__(BN_BLOCK) k_bn_apply(const float* __restrict__
   store8<VEC>(y + off, base, HW, v);
 }
 
-// ---- backward pass 1: per block sums of g' and g' * xhat (g' = gy masked by the ReLU).  grid: (nchunk, N*C)
+// ---- backward pass 1: per block sums of g' and g' * xhat (g' = gy masked by the ReLU).  grid: (nchunk, C, N)
 template <bool VEC>
 __global__ void __launch_bounds__(BN_BLOCK) k_bn_bwd_reduce(const float* __restrict__ x, const float* __restrict__ y,
                                                             const float* __restrict__ gy, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* __restrict__ part,
                                                             int Bg, int C, int HW, int relu) {
   __shared__ float red[2 * 4 * (BN_BLOCK / 64)];
-  const int n = blockIdx.y / C, c = blockIdx.y - n * C, g = n / Bg;
+  const int n = plane_id() / C, c = plane_id() - n * C, g = n / Bg;
   const float mu = mean[g * C + c], is = invstd[g * C + c];
   const int base = blockIdx.x * BN_CHUNK;
-  const long off = static_cast<long>(blockIdx.y) * HW;
+  const long off = static_cast<long>(plane_id()) * HW;
   float v[BN_PER_THREAD], gg[BN_PER_THREAD], yy[BN_PER_THREAD]; bool ok[BN_PER_THREAD];
   load8<VEC>(x + off, base, HW, v, ok);
   load8<VEC>(gy + off, base, HW, gg, ok);
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(BN_BLOCK) k_bn_bwd_reduce(const float* __restr
     acc[0] += gm;
     acc[1] += gm * ((v[k] - mu) * is);
   }
-  block_sum<2>(acc, red, part + (static_cast<long>(blockIdx.y) * gridDim.x + blockIdx.x) * 2);
+  block_sum<2>(acc, red, part + (static_cast<long>(plane_id()) * gridDim.x + blockIdx.x) * 2);
 }
 
 // ---- backward pass 1b: one wave per channel: per group means of g' and g' xhat, gw / gb over all groups (double,
@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(64) k_bn_bwd_finalize(const float* __restrict_
   }
 }
 
-// ---- backward pass 2: gx = w * invstd * (g' - mean(g') - xhat * mean(g' xhat));  gres = g'.  grid: (nchunk, N*C)
+// ---- backward pass 2: gx = w * invstd * (g' - mean(g') - xhat * mean(g' xhat));  gres = g'.  grid: (nchunk, C, N)
 template <bool VEC>
 __global__ void __launch_bounds__(BN_BLOCK) k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ gy, const float* __restrict__ weight,
@@ -229,11 +229,11 @@ __global__ void __launch_bounds__(BN_BLOCK) k_bn_bwd_apply(const float* __restri
                                                            const float* __restrict__ gmean, const float* __restrict__ gxmean,
                                                            float* __restrict__ gx, float* __restrict__ gres, int Bg, int C,
                                                            int HW, int relu) {
-  const int n = blockIdx.y / C, c = blockIdx.y - n * C, g = n / Bg;
+  const int n = plane_id() / C, c = plane_id() - n * C, g = n / Bg;
   const float mu = mean[g * C + c], is = invstd[g * C + c], ws = (weight ? weight[c] : 1.0f) * is;
   const float m0 = gmean[g * C + c], m1 = gxmean[g * C + c];
   const int base = blockIdx.x * BN_CHUNK;
-  const long off = static_cast<long>(blockIdx.y) * HW;
+  const long off = static_cast<long>(plane_id()) * HW;
   float v[BN_PER_THREAD], gg[BN_PER_THREAD], yy[BN_PER_THREAD]; bool ok[BN_PER_THREAD];
   load8<VEC>(x + off, base, HW, v, ok);
   load8<VEC>(gy + off, base, HW, gg, ok);
@@ -258,7 +258,7 @@ static inline int bn_nchunk(long hw) { return static_cast<int>((hw + BN_CHUNK - 
 
 static int bn_dims(int G, int Bg, int C, int H, int W) {
   const long hw = static_cast<long>(H) * W;
-  if (G <= 0 || Bg <= 0 || C <= 0 || H <= 0 || W <= 0 || hw >= (1L << 31) || static_cast<long>(G) * Bg * C > 65535) return DFE_ERR_DIMS;
+  if (G <= 0 || Bg <= 0 || C <= 0 || H <= 0 || W <= 0 || hw >= (1L << 31) || C > 65535 || static_cast<long>(G) * Bg > 65535) return DFE_ERR_DIMS;
   if (static_cast<long>(Bg) * hw < 2) return DFE_ERR_DIMS;      // "Expected more than 1 value per channel when training"
   return DFE_OK;
 }
@@ -275,7 +275,7 @@ extern "C" int dfe_bn_fwd(const float* x, const float* residual, const float* we
   int rc = bn_dims(G, Bg, C, H, W);
   if (rc != DFE_OK) return rc;
   const int hw = H * W, nchunk = bn_nchunk(hw);
-  const dim3 grid(nchunk, G * Bg * C);
+  const dim3 grid(nchunk, C, G * Bg);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool vec = hw % 4 == 0 && al16(x) && al16(y) && (!residual || al16(residual));
   if (vec) k_bn_stats<true><<<grid, BN_BLOCK, 0, st>>>(x, partials, hw);
@@ -296,7 +296,7 @@ extern "C" int dfe_bn_bwd(const float* x, const float* y, const float* gy, const
   int rc = bn_dims(G, Bg, C, H, W);
   if (rc != DFE_OK) return rc;
   const int hw = H * W, nchunk = bn_nchunk(hw);
-  const dim3 grid(nchunk, G * Bg * C);
+  const dim3 grid(nchunk, C, G * Bg);
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* gmean = scratch_means;
   float* gxmean = scratch_means + static_cast<long>(G) * C;

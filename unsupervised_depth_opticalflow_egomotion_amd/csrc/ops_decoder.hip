@@ -48,14 +48,14 @@ __device__ __forceinline__ float pad_adjoint(const float* __restrict__ gp, int y
 }
 
 // ---------------------------------------------------------------- p = pad(elu(x))
-// grid: x over the elements of one padded plane, y = plane (b*C + c)
+// grid: x over the elements of one padded plane, y = c, z = b
 __global__ void __launch_bounds__(256) k_elu_pad_fwd(const float* __restrict__ x, const float* __restrict__ bias,
                                                      float* __restrict__ out, int C, int H, int W, int elu) {
   const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= static_cast<unsigned>((H + 2) * (W + 2))) return;
   const int oy = e / static_cast<unsigned>(W + 2), ox = e - oy * (W + 2);
-  const long pl = blockIdx.y;
-  const float v = x[(pl * H + reflect1(oy - 1, H)) * W + reflect1(ox - 1, W)] + (bias ? bias[blockIdx.y % C] : 0.0f);
+  const long pl = plane_id();
+  const float v = x[(pl * H + reflect1(oy - 1, H)) * W + reflect1(ox - 1, W)] + (bias ? bias[plane_id() % C] : 0.0f);
   out[(pl * (H + 2) + oy) * (W + 2) + ox] = elu ? elu1(v) : v;
 }
 
@@ -67,19 +67,19 @@ __global__ void __launch_bounds__(256) k_elu_pad_bwd(const float* __restrict__ x
   float acc[1] = {0.0f};
   if (e < static_cast<unsigned>(H * W)) {
     const int iy = e / static_cast<unsigned>(W), ix = e - iy * W;
-    const long pl = blockIdx.y;
+    const long pl = plane_id();
     float g = pad_adjoint(gp + pl * (H + 2) * (W + 2), iy, ix, H, W);
     const long o = (pl * H + iy) * W + ix;
-    if (elu) g *= elu1_grad(x[o] + (bias ? bias[blockIdx.y % C] : 0.0f));
+    if (elu) g *= elu1_grad(x[o] + (bias ? bias[plane_id() % C] : 0.0f));
     gx[o] = g;
     acc[0] = g;
   }
-  if (part) block_sum<1>(acc, red, part + static_cast<long>(blockIdx.y) * gridDim.x + blockIdx.x);
+  if (part) block_sum<1>(acc, red, part + static_cast<long>(plane_id()) * gridDim.x + blockIdx.x);
 }
 
 // ---------------------------------------------------------------- p = pad(cat(up2(elu(x)), skip))
 // x [B,C1,h,w], skip [B,C2,2h,2w] (C2 may be 0), out [B,C1+C2,2h+2,2w+2]
-// grid: x over the elements of one padded plane, y = b*(C1+C2) + c
+// grid: x over the elements of one padded plane, y = c, z = b
 __global__ void __launch_bounds__(256) k_elu_up2_cat_pad_fwd(const float* __restrict__ x, const float* __restrict__ bias,
                                                              const float* __restrict__ skip, float* __restrict__ out,
                                                              int C1, int C2, int h, int w) {
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(256) k_elu_up2_cat_pad_fwd(const float* __rest
   if (e >= static_cast<unsigned>((H + 2) * (W + 2))) return;
   const int oy = e / static_cast<unsigned>(W + 2), ox = e - oy * (W + 2);
   const int C = C1 + C2;
-  const int b = blockIdx.y / C, c = blockIdx.y - b * C;
+  const int b = plane_id() / C, c = plane_id() - b * C;
   const int y = reflect1(oy - 1, H), xx = reflect1(ox - 1, W);
   float v;
   if (c < C1) {
@@ -108,11 +108,11 @@ __global__ void __launch_bounds__(256) k_elu_up2_cat_pad_fwd(const float* __rest
   } else {
     v = skip[((static_cast<long>(b) * C2 + (c - C1)) * H + y) * W + xx];
   }
-  out[(static_cast<long>(blockIdx.y) * (H + 2) + oy) * (W + 2) + ox] = v;
+  out[(static_cast<long>(plane_id()) * (H + 2) + oy) * (W + 2) + ox] = v;
 }
 
 // gradient wrt x: thread per low-res element; the <= 4x4 full-res outputs whose taps touch it, each through the
-// adjoint of the reflection pad.  grid: x over the low-res plane, y = b*C1 + c
+// adjoint of the reflection pad.  grid: x over the low-res plane, y = c, z = b
 __global__ void __launch_bounds__(256) k_elu_up2_cat_pad_bwd_x(const float* __restrict__ x, const float* __restrict__ bias,
                                                                const float* __restrict__ gp, float* __restrict__ gx,
                                                                float* __restrict__ part, int C1, int C2, int h, int w) {
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) k_elu_up2_cat_pad_bwd_x(const float* __re
   float acc[1] = {0.0f};
   if (e < static_cast<unsigned>(h * w)) {
   const int i = e / static_cast<unsigned>(w), j = e - i * w;
-  const int b = blockIdx.y / C1, c = blockIdx.y - b * C1;
+  const int b = plane_id() / C1, c = plane_id() - b * C1;
   const float* g = gp + (static_cast<long>(b) * (C1 + C2) + c) * (H + 2) * (W + 2);
   float total = 0.0f;
   if (i >= 2 && i < h - 2 && j >= 2 && j < w - 2) {
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256) k_elu_up2_cat_pad_bwd_x(const float* __re
   acc[0] = total * elu1_grad(x[o] + (bias ? bias[c] : 0.0f));
   gx[o] = acc[0];
   }
-  if (part) block_sum<1>(acc, red, part + static_cast<long>(blockIdx.y) * gridDim.x + blockIdx.x);
+  if (part) block_sum<1>(acc, red, part + static_cast<long>(plane_id()) * gridDim.x + blockIdx.x);
 }
 
 // gbias[c] = sum over b, blocks of part[(b*C + c)*nblk + k] in a fixed order; one wave per channel
@@ -182,15 +182,15 @@ __global__ void __launch_bounds__(64) k_glue_bias_final(const float* __restrict_
   if (lane == 0) gbias[c] = (r0 + r1) + (r2 + r3);
 }
 
-// gradient wrt skip: adjoint of the pad only.  grid: x over the plane, y = b*C2 + c
+// gradient wrt skip: adjoint of the pad only.  grid: x over the plane, y = c, z = b
 __global__ void __launch_bounds__(256) k_cat_pad_bwd_skip(const float* __restrict__ gp, float* __restrict__ gskip,
                                                           int C1, int C2, int H, int W) {
   const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= static_cast<unsigned>(H * W)) return;
   const int iy = e / static_cast<unsigned>(W), ix = e - iy * W;
-  const int b = blockIdx.y / C2, c = blockIdx.y - b * C2;
+  const int b = plane_id() / C2, c = plane_id() - b * C2;
   const float* g = gp + (static_cast<long>(b) * (C1 + C2) + C1 + c) * (H + 2) * (W + 2);
-  gskip[(static_cast<long>(blockIdx.y) * H + iy) * W + ix] = pad_adjoint(g, iy, ix, H, W);
+  gskip[(static_cast<long>(plane_id()) * H + iy) * W + ix] = pad_adjoint(g, iy, ix, H, W);
 }
 
 }  // namespace dfe
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256) k_cat_pad_bwd_skip(const float* __restric
 
 using namespace dfe;
 
-static inline bool grid_ok(long plane_elems, long planes) { return plane_elems < (1L << 31) && planes <= 65535; }
+static inline bool grid_ok(long plane_elems, long batch, long channels) { return plane_elems < (1L << 31) && batch <= 65535 && channels <= 65535; }
 static inline unsigned nblk(long n) { return static_cast<unsigned>((n + 255) / 256); }
 
 extern "C" long dfe_glue_partials_floats(int B, int C, int H, int W) {
@@ -210,8 +210,8 @@ extern "C" long dfe_glue_partials_floats(int B, int C, int H, int W) {
 extern "C" int dfe_elu_pad_fwd(const float* x, const float* bias, float* out, int B, int C, int H, int W, int apply_elu,
                                void* stream) {
   if (!x || !out) return DFE_ERR_NULL;
-  if (B <= 0 || C <= 0 || H < 2 || W < 2 || !grid_ok((H + 2L) * (W + 2L), static_cast<long>(B) * C)) return DFE_ERR_DIMS;
-  k_elu_pad_fwd<<<dim3(nblk((H + 2L) * (W + 2L)), B * C), 256, 0, static_cast<hipStream_t>(stream)>>>(x, bias, out, C, H, W, apply_elu);
+  if (B <= 0 || C <= 0 || H < 2 || W < 2 || !grid_ok((H + 2L) * (W + 2L), B, C)) return DFE_ERR_DIMS;
+  k_elu_pad_fwd<<<dim3(nblk((H + 2L) * (W + 2L)), C, B), 256, 0, static_cast<hipStream_t>(stream)>>>(x, bias, out, C, H, W, apply_elu);
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
@@ -219,10 +219,10 @@ extern "C" int dfe_elu_pad_fwd(const float* x, const float* bias, float* out, in
 extern "C" int dfe_elu_pad_bwd(const float* x, const float* bias, const float* gout, float* gx, float* gbias, float* partials,
                                int B, int C, int H, int W, int apply_elu, void* stream) {
   if (!gout || !gx || (apply_elu && !x) || (gbias && !partials)) return DFE_ERR_NULL;
-  if (B <= 0 || C <= 0 || H < 2 || W < 2 || !grid_ok((H + 2L) * (W + 2L), static_cast<long>(B) * C)) return DFE_ERR_DIMS;
+  if (B <= 0 || C <= 0 || H < 2 || W < 2 || !grid_ok((H + 2L) * (W + 2L), B, C)) return DFE_ERR_DIMS;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned nb = nblk(static_cast<long>(H) * W);
-  k_elu_pad_bwd<<<dim3(nb, B * C), 256, 0, st>>>(x, bias, gout, gx, gbias ? partials : nullptr, C, H, W, apply_elu);
+  k_elu_pad_bwd<<<dim3(nb, C, B), 256, 0, st>>>(x, bias, gout, gx, gbias ? partials : nullptr, C, H, W, apply_elu);
   DFE_LAUNCH_CHECK();
   if (gbias) {
     k_glue_bias_final<<<C, 64, 0, st>>>(partials, gbias, B, C, static_cast<int>(nb));
@@ -234,8 +234,8 @@ extern "C" int dfe_elu_pad_bwd(const float* x, const float* bias, const float* g
 extern "C" int dfe_elu_up2_cat_pad_fwd(const float* x, const float* bias, const float* skip, float* out, int B, int C1, int C2,
                                        int h, int w, void* stream) {
   if (!x || !out || (C2 > 0 && !skip)) return DFE_ERR_NULL;
-  if (B <= 0 || C1 <= 0 || C2 < 0 || h < 1 || w < 1 || !grid_ok((2L * h + 2) * (2L * w + 2), static_cast<long>(B) * (C1 + C2))) return DFE_ERR_DIMS;
-  k_elu_up2_cat_pad_fwd<<<dim3(nblk((2L * h + 2) * (2L * w + 2)), B * (C1 + C2)), 256, 0, static_cast<hipStream_t>(stream)>>>(
+  if (B <= 0 || C1 <= 0 || C2 < 0 || h < 1 || w < 1 || !grid_ok((2L * h + 2) * (2L * w + 2), B, C1 + C2)) return DFE_ERR_DIMS;
+  k_elu_up2_cat_pad_fwd<<<dim3(nblk((2L * h + 2) * (2L * w + 2)), C1 + C2, B), 256, 0, static_cast<hipStream_t>(stream)>>>(
       x, bias, skip, out, C1, C2, h, w);
   DFE_LAUNCH_CHECK();
   return DFE_OK;
@@ -244,11 +244,11 @@ extern "C" int dfe_elu_up2_cat_pad_fwd(const float* x, const float* bias, const 
 extern "C" int dfe_elu_up2_cat_pad_bwd(const float* x, const float* bias, const float* gout, float* gx, float* gskip,
                                        float* gbias, float* partials, int B, int C1, int C2, int h, int w, void* stream) {
   if (!x || !gout || (!gx && !gskip) || (gbias && (!partials || !gx))) return DFE_ERR_NULL;
-  if (B <= 0 || C1 <= 0 || C2 < 0 || h < 1 || w < 1 || !grid_ok((2L * h + 2) * (2L * w + 2), static_cast<long>(B) * (C1 + C2))) return DFE_ERR_DIMS;
+  if (B <= 0 || C1 <= 0 || C2 < 0 || h < 1 || w < 1 || !grid_ok((2L * h + 2) * (2L * w + 2), B, C1 + C2)) return DFE_ERR_DIMS;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (gx) {
     const unsigned nb = nblk(static_cast<long>(h) * w);
-    k_elu_up2_cat_pad_bwd_x<<<dim3(nb, B * C1), 256, 0, st>>>(x, bias, gout, gx, gbias ? partials : nullptr, C1, C2, h, w);
+    k_elu_up2_cat_pad_bwd_x<<<dim3(nb, C1, B), 256, 0, st>>>(x, bias, gout, gx, gbias ? partials : nullptr, C1, C2, h, w);
     DFE_LAUNCH_CHECK();
     if (gbias) {
       k_glue_bias_final<<<C1, 64, 0, st>>>(partials, gbias, B, C1, static_cast<int>(nb));
@@ -256,7 +256,7 @@ extern "C" int dfe_elu_up2_cat_pad_bwd(const float* x, const float* bias, const 
     }
   }
   if (gskip && C2 > 0) {
-    k_cat_pad_bwd_skip<<<dim3(nblk(4L * h * w), B * C2), 256, 0, st>>>(gout, gskip, C1, C2, 2 * h, 2 * w);
+    k_cat_pad_bwd_skip<<<dim3(nblk(4L * h * w), C2, B), 256, 0, st>>>(gout, gskip, C1, C2, 2 * h, 2 * w);
     DFE_LAUNCH_CHECK();
   }
   return DFE_OK;

@@ -16,13 +16,13 @@ constexpr int EP_BLOCK = 256;
 constexpr int EP_PER_THREAD = 8;                       // elements per thread (two float4)
 constexpr int EP_CHUNK = EP_BLOCK * EP_PER_THREAD;     // elements of one (b, c) plane per block
 
-// grid: x = chunk of the plane, y = b*C + c
+// grid: x = chunk of the plane, y = c, z = b
 template <bool VEC>
 __global__ void __launch_bounds__(EP_BLOCK) k_bias_act_fwd(float* __restrict__ z, const float* __restrict__ bias,
                                                            int C, int HW, float slope) {
-  const int c = blockIdx.y % C;
+  const int c = plane_id() % C;
   const float bv = bias ? bias[c] : 0.0f;
-  float* p = z + static_cast<long>(blockIdx.y) * HW;
+  float* p = z + static_cast<long>(plane_id()) * HW;
   const int base = blockIdx.x * EP_CHUNK;
   if (VEC) {
 #pragma unroll
@@ -51,10 +51,10 @@ __global__ void __launch_bounds__(EP_BLOCK) k_bias_act_bwd(const float* __restri
                                                            int HW, long gy_plane_stride, long gy_batch_stride, int C,
                                                            float slope) {
   __shared__ float red[4 * (EP_BLOCK / 64)];
-  const int b = blockIdx.y / C, c = blockIdx.y - b * C;
-  const float* py = y + static_cast<long>(blockIdx.y) * HW;
+  const int b = plane_id() / C, c = plane_id() - b * C;
+  const float* py = y + static_cast<long>(plane_id()) * HW;
   const float* pg = gy + b * gy_batch_stride + c * gy_plane_stride;
-  float* pz = gz + static_cast<long>(blockIdx.y) * HW;
+  float* pz = gz + static_cast<long>(plane_id()) * HW;
   const int base = blockIdx.x * EP_CHUNK;
   float acc[1] = {0.0f};
   if (VEC) {
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(EP_BLOCK) k_bias_act_bwd(const float* __restri
       if (e < HW) { const float g = py[e] > 0.0f ? pg[e] : pg[e] * slope; pz[e] = g; acc[0] += g; }
     }
   }
-  if (part) block_sum<1>(acc, red, part + static_cast<long>(blockIdx.y) * gridDim.x + blockIdx.x);
+  if (part) block_sum<1>(acc, red, part + static_cast<long>(plane_id()) * gridDim.x + blockIdx.x);
 }
 
 // gbias[c] = sum over b, chunks of part[(b*C + c)*nchunk + chunk] in a fixed order; one wave per channel
@@ -113,8 +113,8 @@ extern "C" long dfe_bias_act_partials_floats(int B, int C, int H, int W) {
 extern "C" int dfe_bias_act_fwd(float* z, const float* bias, int B, int C, int H, int W, float slope, void* stream) {
   if (!z) return DFE_ERR_NULL;
   const long hw = static_cast<long>(H) * W;
-  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || hw >= (1L << 31) || static_cast<long>(B) * C > 65535) return DFE_ERR_DIMS;
-  const dim3 g(static_cast<unsigned>((hw + EP_CHUNK - 1) / EP_CHUNK), B * C);
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || hw >= (1L << 31) || C > 65535 || B > 65535) return DFE_ERR_DIMS;
+  const dim3 g(static_cast<unsigned>((hw + EP_CHUNK - 1) / EP_CHUNK), C, B);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (hw % 4 == 0 && aligned16(z)) k_bias_act_fwd<true><<<g, EP_BLOCK, 0, st>>>(z, bias, C, static_cast<int>(hw), slope);
   else k_bias_act_fwd<false><<<g, EP_BLOCK, 0, st>>>(z, bias, C, static_cast<int>(hw), slope);
@@ -126,10 +126,10 @@ extern "C" int dfe_bias_act_bwd(const float* y, const float* gy, long gy_batch_s
                                 float* partials, int B, int C, int H, int W, float slope, void* stream) {
   if (!y || !gy || !gz || (gbias && !partials)) return DFE_ERR_NULL;
   const long hw = static_cast<long>(H) * W;
-  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || hw >= (1L << 31) || static_cast<long>(B) * C > 65535) return DFE_ERR_DIMS;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || hw >= (1L << 31) || C > 65535 || B > 65535) return DFE_ERR_DIMS;
   if (gy_batch_stride < static_cast<long>(C) * hw) return DFE_ERR_DIMS;
   const int nchunk = static_cast<int>((hw + EP_CHUNK - 1) / EP_CHUNK);
-  const dim3 g(nchunk, B * C);
+  const dim3 g(nchunk, C, B);
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* part = gbias ? partials : nullptr;
   const bool vec = hw % 4 == 0 && aligned16(y) && aligned16(gy) && aligned16(gz) && gy_batch_stride % 4 == 0;
