@@ -121,6 +121,14 @@ int dfe_disp_head_fwd(const float* p, const float* weight, const float* bias, fl
 int dfe_disp_head_bwd(const float* p, const float* weight, const float* out, const float* gout, float* gp, float* gweight,
                       float* gbias, float* partials, int B, int C, int H, int W, void* stream);
 
+/* ---- weight gradient of the thin, wide 3x3 convolutions of the depth decoder on pre-padded inputs (fp32 MFMA):
+ * gweight [Co,Ci,3,3] = sum_{b,y,x} gy[b,co,y,x] * p[b,ci,y+ky,x+kx],  p [B,Ci,H+2,W+2], gy [B,Co,H,W].
+ * Requires Ci % 16 == 0, Co % 16 == 0, W % 16 == 0, p 8-byte and gy 16-byte aligned (DFE_ERR_UNSUPPORTED otherwise: the
+ * caller then keeps MIOpen's weight gradient).  partials: dfe_wgrad3x3_partials_floats floats of scratch. */
+long dfe_wgrad3x3_partials_floats(int B, int Ci, int Co, int H, int W);
+int dfe_wgrad3x3_fwd(const float* p, const float* gy, float* gweight, float* partials, int B, int Ci, int Co, int H, int W,
+                     void* stream);
+
 /* ---- grouped training-mode BatchNorm2d (+ residual + ReLU) of the depth encoder (SURVEY.md 8(f) rank 1;
  * depth_model.py:60-95 = torchvision BasicBlock conv-bn-relu-conv-bn-(+identity)-relu; model_geometry.py:786-788 calls the
  * depth net once per frame).  x [G*Bg,C,H,W] is G groups of Bg consecutive samples: statistics are per (group, channel)

@@ -532,3 +532,50 @@ def test_net_glue_many_planes():
     yb = ops.grouped_batch_norm(G(x), G(w), G(bias), rm, rv, groups=2, relu=True)
     ref = torch.cat([F.batch_norm(c, None, None, T(w), T(bias), True) for c in T(x).chunk(2, 0)], 0).relu()
     close(yb, ref, atol=2e-5, rtol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------- MFMA weight gradient
+@pytest.mark.parametrize("shape", [(2, 16, 16, 8, 32), (1, 32, 16, 5, 16), (2, 48, 32, 7, 48), (3, 96, 32, 16, 64), (2, 16, 32, 33, 80)])
+def test_wgrad3x3_mfma(shape):
+    """dfe_wgrad3x3_fwd (fp32 MFMA, exact fma chains) against the weight gradient of F.conv2d in fp64 on the CPU:
+    1e-6 of the gradient scale (sums of up to B*H*W products in fp32)."""
+    import ctypes
+    import torch.nn.functional as F
+    from unsupervised_depth_opticalflow_egomotion_amd._lib import get_lib, ptr, stream_ptr, check
+    lib = get_lib()
+    B, Ci, Co, H, W = shape
+    rng = np.random.RandomState(sum(shape))
+    p = rng.randn(B, Ci, H + 2, W + 2).astype(np.float32)
+    gy = rng.randn(B, Co, H, W).astype(np.float32)
+    w = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(torch.from_numpy(p).double(), w) * torch.from_numpy(gy).double()).sum().backward()
+    ph, gh = G(p), G(gy)
+    gw = torch.empty(Co, Ci, 3, 3, device=dev())
+    part = torch.empty(lib.dfe_wgrad3x3_partials_floats(B, Ci, Co, H, W), device=dev())
+    check(lib.dfe_wgrad3x3_fwd(ptr(ph), ptr(gh), ptr(gw), ptr(part), B, Ci, Co, H, W, stream_ptr()), "dfe_wgrad3x3_fwd")
+    gclose(gw, w.grad.float(), rel=1e-6)
+    gw2 = torch.empty_like(gw)
+    check(lib.dfe_wgrad3x3_fwd(ptr(ph), ptr(gh), ptr(gw2), ptr(part), B, Ci, Co, H, W, stream_ptr()), "dfe_wgrad3x3_fwd")
+    assert torch.equal(gw, gw2), "the weight gradient must be bitwise reproducible"
+
+
+def test_thin_conv_function_and_eligibility():
+    """ops.conv3x3_valid: the MFMA weight gradient is used for the thin full-resolution layers only; values and both
+    gradients agree with F.conv2d on the same device (MIOpen) to 1e-5 / 2e-4 of the gradient scale."""
+    import torch.nn.functional as F
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+    torch.manual_seed(2)
+    p = torch.randn(2, 32, 130, 418, device=dev())
+    w = torch.randn(16, 32, 3, 3, device=dev()) * 0.1
+    assert ops.thin_conv3x3_eligible(p, w)
+    assert not ops.thin_conv3x3_eligible(torch.zeros(2, 64, 66, 210, device=dev()), torch.zeros(32, 64, 3, 3, device=dev()))
+    assert not ops.thin_conv3x3_eligible(p, torch.zeros(64, 32, 3, 3, device=dev()))
+    res = []
+    for fn in (ops.conv3x3_valid, F.conv2d):
+        pi, wi = p.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        y = fn(pi, wi)
+        (y * y).mean().backward()
+        res.append((N(y), N(pi.grad), N(wi.grad)))
+    close(res[0][0], res[1][0], atol=1e-5, rtol=1e-5)
+    gclose(res[0][1], res[1][1], rel=2e-4, atol=1e-9)
+    gclose(res[0][2], res[1][2], rel=2e-4, atol=1e-9)

@@ -35,6 +35,8 @@ _SIGNATURES = {
     "dfe_pose_partials_floats": [_I, _I, _I],
     "dfe_inverse_warp2_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_inverse_warp2_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "dfe_wgrad3x3_partials_floats": [_I, _I, _I, _I, _I],
+    "dfe_wgrad3x3_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_disp_head_partials_floats": [_I, _I, _I, _I],
     "dfe_disp_head_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_disp_head_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -69,6 +71,7 @@ _SIGNATURES = {
 _RESTYPES = {"dfe_error_string": ctypes.c_char_p, "dfe_geom_workspace_floats": ctypes.c_long,
              "dfe_bias_act_partials_floats": ctypes.c_long, "dfe_glue_partials_floats": ctypes.c_long,
              "dfe_bn_partials_floats": ctypes.c_long, "dfe_disp_head_partials_floats": ctypes.c_long,
+             "dfe_wgrad3x3_partials_floats": ctypes.c_long,
              "dfe_geom_maskpack_offset_bytes": ctypes.c_long}
 
 

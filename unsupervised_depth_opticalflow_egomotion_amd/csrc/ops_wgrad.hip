@@ -1,0 +1,162 @@
+// Weight gradient of the thin, wide 3x3 convolutions of the depth decoder (reference depth_model.py: the last two
+// decoder stages, 16..96 channels at 128x416 / 256x832, on reflection-padded inputs):
+//     dW[co][ci][ky][kx] = sum_{b,y,x} gy[b][co][y][x] * p[b][ci][y+ky][x+kx]        p [B,Ci,H+2,W+2], gy [B,Co,H,W]
+// This is a true dense contraction with a tiny output (Co x 9Ci) and an enormous reduction length (B*H*W, 0.6-2.6 M):
+// MIOpen's implicit-GEMM weight-gradient kernels run it at 23-56 TFLOP/s after transposing both operands to NHWC
+// (0.50 ms at 16->16 / 256x832 for 0.08 ms of HBM traffic).  Here it goes to the matrix cores directly from NCHW:
+// v_mfma_f32_16x16x4_f32 with M = 16 output channels, N = 16 input channels, K = 4 pixels per instruction; a lane's
+// A operand is one float4 of a gy row (4 consecutive pixels of its channel, 4 K-steps), its B operand three float2 of
+// the matching p row (the 4 pixels shifted by kx = 0, 1, 2).  A wave owns a slab of R image rows x a column segment,
+// one 16-channel tile of Co and one of Ci, and keeps the 9 accumulator tiles in registers for its whole slab; per-wave
+// partial sums are added in a fixed order by a second kernel (no atomics: reproducible).  fp32 MFMA is an exact fma chain.
+// Bound: MFMA (157 TFLOP/s fp32) for Ci >= 32, HBM below.
+#include "dfe_internal.h"
+#include <hip/hip_runtime.h>
+
+namespace dfe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(8))) F2 { float a, b; };
+
+// grid: x = unit = (b * nrg + row group) * nseg + column segment, y = ci tile, z = co tile; block = one wave.
+// One 16 x 16 tile pair per wave (36 accumulator registers): the latency of the 10 loads per 16-pixel step is hidden
+// by occupancy (many light waves per SIMD) rather than by software pipelining.
+__global__ void __launch_bounds__(64) k_wgrad3x3_thin(const float* __restrict__ p, const float* __restrict__ gy,
+                                                      float* __restrict__ part, int Ci, int Co, int H, int W, int R, int nrg,
+                                                      int nseg) {
+  const int lane = threadIdx.x, m = lane & 15, kq = lane >> 4;
+  const int seg = blockIdx.x % nseg, br = blockIdx.x / nseg;
+  const int b = br / nrg, rg = br - b * nrg;
+  const int ci0 = blockIdx.y * 16, co0 = blockIdx.z * 16;
+  const int Hp = H + 2, Wp = W + 2;
+  const int y0 = rg * R, y1 = min(y0 + R, H);
+  const int nch = W / 16, cps = (nch + nseg - 1) / nseg;
+  const int xa = seg * cps * 16, xb = min((seg + 1) * cps, nch) * 16;
+  const float* ga = gy + (static_cast<long>(b) * Co + co0 + m) * H * W + 4 * kq;
+  const float* pa = p + (static_cast<long>(b) * Ci + ci0 + m) * Hp * Wp + 4 * kq;
+  f32x4 acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  // software pipeline over the 16-pixel steps of the slab: the 10 loads of step i+1 are in flight while the 36 MFMAs
+  // of step i execute
+  const int per_row = (xb - xa) / 16, nsteps = max(y1 - y0, 0) * per_row;
+  f32x4 a4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  F2 e[3][3];
+  auto fetch = [&](int step, f32x4& av, F2 (&ev)[3][3]) {
+    const int yy = y0 + step / per_row, x0 = xa + (step % per_row) * 16;
+    av = *reinterpret_cast<const f32x4*>(ga + static_cast<long>(yy) * W + x0);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const float* q = pa + static_cast<long>(yy + ky) * Wp + x0;
+      ev[ky][0] = *reinterpret_cast<const F2*>(q); ev[ky][1] = *reinterpret_cast<const F2*>(q + 2); ev[ky][2] = *reinterpret_cast<const F2*>(q + 4);
+    }
+  };
+  if (nsteps > 0) fetch(0, a4, e);
+  for (int step = 0; step < nsteps; ++step) {
+    f32x4 an = a4;
+    F2 en[3][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) en[ky][j] = e[ky][j];
+    if (step + 1 < nsteps) fetch(step + 1, an, en);
+    // K-step s outermost: consecutive MFMAs go to nine different accumulators
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const float v[6] = {e[ky][0].a, e[ky][0].b, e[ky][1].a, e[ky][1].b, e[ky][2].a, e[ky][2].b};
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s], v[s + kx], acc[ky * 3 + kx], 0, 0, 0);
+      }
+    a4 = an;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) e[ky][j] = en[ky][j];
+  }
+  // D[i][j]: lane holds rows i = 4*kq + r (output channel), column j = m (input channel)
+  float* po = part + static_cast<long>(blockIdx.x) * Co * Ci * 9;
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      po[(static_cast<long>(co0 + 4 * kq + r) * Ci + ci0 + m) * 9 + k] = acc[k][r];
+}
+
+// dW[idx] = sum over units of part[u][idx].  Block = 16 consecutive idx x 64 unit lanes: every thread adds the units
+// u = lane, lane + 64, ... (four independent partial sums keep four loads in flight), then the 64 lane sums are added
+// in lane order (fixed order: reproducible).
+constexpr int WF_LANES = 64;
+__global__ void __launch_bounds__(16 * WF_LANES) k_wgrad_final(const float* __restrict__ part, float* __restrict__ gw, int n,
+                                                               int nunits) {
+  __shared__ float sm[WF_LANES][17];
+  const int ii = threadIdx.x & 15, ul = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + ii;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  if (i < n) {
+    const float* q = part + i;
+    int u = ul;
+    for (; u + 3 * WF_LANES < nunits; u += 4 * WF_LANES) {
+      s0 += q[static_cast<long>(u) * n]; s1 += q[static_cast<long>(u + WF_LANES) * n];
+      s2 += q[static_cast<long>(u + 2 * WF_LANES) * n]; s3 += q[static_cast<long>(u + 3 * WF_LANES) * n];
+    }
+    for (; u < nunits; u += WF_LANES) s0 += q[static_cast<long>(u) * n];
+  }
+  sm[ul][ii] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ul == 0 && i < n) {
+    float t = 0.0f;
+    for (int k = 0; k < WF_LANES; ++k) t += sm[k][ii];
+    gw[i] = t;
+  }
+}
+
+}  // namespace dfe
+
+#define DFE_LAUNCH_CHECK() do { if (hipGetLastError() != hipSuccess) return DFE_ERR_LAUNCH; } while (0)
+using namespace dfe;
+
+// Work split: units = B * ceil(H / R) * nseg waves per tile pair.  Aim at ~8192 waves in total (8 per SIMD) while keeping
+// the partial planes (units * Co*Ci*9 floats) small: columns are split into up to 4 segments when there are few rows,
+// rows are grouped when there are many.
+struct WgSplit { int R, nrg, nseg; long units; };
+static WgSplit wg_split(int B, int H, int W, int tiles) {
+  WgSplit s{1, H, 1, 0};
+  const long target = 8192 / tiles > 0 ? 8192 / tiles : 1;
+  while (s.R < H && static_cast<long>(B) * ((H + s.R - 1) / s.R) > target) s.R *= 2;
+  s.nrg = (H + s.R - 1) / s.R;
+  while (s.nseg < 4 && s.nseg * 2 <= W / 16 && static_cast<long>(B) * s.nrg * s.nseg * 2 <= target) s.nseg *= 2;
+  s.units = static_cast<long>(B) * s.nrg * s.nseg;
+  return s;
+}
+
+static int wg_dims(int B, int Ci, int Co, int H, int W) {
+  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return DFE_ERR_DIMS;
+  if (Ci % 16 != 0 || Co % 16 != 0 || W % 16 != 0 || Ci / 16 > 65535 || Co / 16 > 65535) return DFE_ERR_UNSUPPORTED;
+  if ((static_cast<long>(H) + 2) * (W + 2) * Ci >= (1L << 31) || static_cast<long>(H) * W * Co >= (1L << 31)) return DFE_ERR_DIMS;
+  return DFE_OK;
+}
+
+extern "C" long dfe_wgrad3x3_partials_floats(int B, int Ci, int Co, int H, int W) {
+  if (wg_dims(B, Ci, Co, H, W) != DFE_OK) return 0;
+  return wg_split(B, H, W, (Ci / 16) * (Co / 16)).units * Co * Ci * 9;
+}
+
+extern "C" int dfe_wgrad3x3_fwd(const float* p, const float* gy, float* gweight, float* partials, int B, int Ci, int Co, int H,
+                                int W, void* stream) {
+  if (!p || !gy || !gweight || !partials) return DFE_ERR_NULL;
+  const int rc = wg_dims(B, Ci, Co, H, W);
+  if (rc != DFE_OK) return rc;
+  if ((reinterpret_cast<uintptr_t>(p) & 7) || (reinterpret_cast<uintptr_t>(gy) & 15)) return DFE_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const WgSplit sp = wg_split(B, H, W, (Ci / 16) * (Co / 16));
+  k_wgrad3x3_thin<<<dim3(static_cast<unsigned>(sp.units), Ci / 16, Co / 16), 64, 0, st>>>(p, gy, partials, Ci, Co, H, W, sp.R,
+                                                                                       sp.nrg, sp.nseg);
+  DFE_LAUNCH_CHECK();
+  const int n = Co * Ci * 9;
+  k_wgrad_final<<<(n + 15) / 16, 16 * WF_LANES, 0, st>>>(partials, gweight, n, static_cast<int>(sp.units));
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}

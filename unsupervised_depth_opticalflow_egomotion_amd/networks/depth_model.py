@@ -94,9 +94,9 @@ class DepthDecoder(nn.Module):
         p = ops.elu_pad(feats[-1], None, apply_elu=False)        # encoder output: already activated
         for scale in range(4, -1, -1):
             c0, c1 = self.upconvs[4 - scale][0].conv.conv, self.upconvs[4 - scale][1].conv.conv
-            a = F.conv2d(p, c0.weight)
+            a = ops.conv3x3_valid(p, c0.weight)
             q = ops.elu_up2_cat_pad(a, c0.bias, feats[scale - 1] if scale > 0 else None)
-            c = F.conv2d(q, c1.weight)
+            c = ops.conv3x3_valid(q, c1.weight)
             if scale in self.scales or scale > 0:
                 p = ops.elu_pad(c, c1.bias, apply_elu=True)      # shared by the disparity head and the next stage
             if scale in self.scales:

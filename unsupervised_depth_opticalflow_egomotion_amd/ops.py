@@ -481,3 +481,48 @@ class DispHeadFn(torch.autograd.Function):
 
 def disp_head(p, weight, bias):
     return DispHeadFn.apply(p, weight, bias)
+
+
+# --------------------------------------------------------------------------- thin 3x3 convolution (MFMA weight gradient)
+class ThinConv3x3Fn(torch.autograd.Function):
+    """Valid 3x3 convolution of a pre-padded activation, bias-free.  Forward and data gradient run on MIOpen; the
+    weight gradient -- a (Co x 9 Ci) contraction over B*H*W pixels that MIOpen runs at a fraction of the others' rate
+    for the decoder's thin full-resolution layers -- runs the fp32-MFMA kernel dfe_wgrad3x3_fwd."""
+
+    @staticmethod
+    def forward(ctx, p, weight):
+        ctx.save_for_backward(p, weight)
+        return torch.nn.functional.conv2d(p, weight)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = get_lib()
+        p, weight = ctx.saved_tensors
+        gy = f32c(gy)
+        gp = gw = None
+        if ctx.needs_input_grad[0]:
+            gp = torch.ops.aten.convolution_backward(gy, p, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            B, Ci, Hp, Wp = p.shape
+            Co, H, W = weight.shape[0], Hp - 2, Wp - 2
+            gw = torch.empty_like(weight)
+            part = torch.empty(lib.dfe_wgrad3x3_partials_floats(B, Ci, Co, H, W), device=p.device)
+            check(lib.dfe_wgrad3x3_fwd(ptr(p), ptr(gy), ptr(gw), ptr(part), B, Ci, Co, H, W, stream_ptr()), "dfe_wgrad3x3_fwd")
+        return gp, gw
+
+
+def thin_conv3x3_eligible(p, weight):
+    """Layers the MFMA weight gradient is measured to win on: <= 32 output channels at >= 128x416 pixels (the last two
+    decoder stages), channel counts multiples of 16, width a multiple of 16."""
+    Co, Ci = weight.shape[0], weight.shape[1]
+    H, W = p.shape[2] - 2, p.shape[3] - 2
+    return (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and tuple(weight.shape[2:]) == (3, 3)
+            and Co <= 32 and Co % 16 == 0 and Ci % 16 == 0 and W % 16 == 0 and H * W >= 128 * 416)
+
+
+def conv3x3_valid(p, weight):
+    """3x3 convolution without padding or bias of a pre-padded activation (the decoder's ConvBlock convolutions)."""
+    if thin_conv3x3_eligible(p, weight):
+        return ThinConv3x3Fn.apply(p, weight)
+    return torch.nn.functional.conv2d(p, weight)
