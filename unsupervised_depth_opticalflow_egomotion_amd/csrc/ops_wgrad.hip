@@ -76,13 +76,14 @@ __global__ void __launch_bounds__(64) k_wgrad3x3_thin(const float* __restrict__ 
 #pragma unroll
       for (int j = 0; j < 3; ++j) e[ky][j] = en[ky][j];
   }
-  // D[i][j]: lane holds rows i = 4*kq + r (output channel), column j = m (input channel)
+  // D[i][j]: lane holds rows i = 4*kq + r (output channel), column j = m (input channel).  The partial plane is laid
+  // out [tap][co][ci] so that the 16 lanes of a row write 64 contiguous bytes; k_wgrad_final permutes to [co][ci][tap].
   float* po = part + static_cast<long>(blockIdx.x) * Co * Ci * 9;
 #pragma unroll
   for (int k = 0; k < 9; ++k)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      po[(static_cast<long>(co0 + 4 * kq + r) * Ci + ci0 + m) * 9 + k] = acc[k][r];
+      po[(static_cast<long>(k) * Co + co0 + 4 * kq + r) * Ci + ci0 + m] = acc[k][r];
 }
 
 // dW[idx] = sum over units of part[u][idx].  Block = 16 consecutive idx x 64 unit lanes: every thread adds the units
@@ -90,7 +91,7 @@ __global__ void __launch_bounds__(64) k_wgrad3x3_thin(const float* __restrict__ 
 // in lane order (fixed order: reproducible).
 constexpr int WF_LANES = 64;
 __global__ void __launch_bounds__(16 * WF_LANES) k_wgrad_final(const float* __restrict__ part, float* __restrict__ gw, int n,
-                                                               int nunits) {
+                                                               int nunits, int coci) {
   __shared__ float sm[WF_LANES][17];
   const int ii = threadIdx.x & 15, ul = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + ii;
@@ -109,7 +110,8 @@ __global__ void __launch_bounds__(16 * WF_LANES) k_wgrad_final(const float* __re
   if (ul == 0 && i < n) {
     float t = 0.0f;
     for (int k = 0; k < WF_LANES; ++k) t += sm[k][ii];
-    gw[i] = t;
+    const int tap = i / coci, cc = i - tap * coci;          // partial planes are [tap][co][ci]
+    gw[static_cast<long>(cc) * 9 + tap] = t;
   }
 }
 
@@ -118,13 +120,15 @@ __global__ void __launch_bounds__(16 * WF_LANES) k_wgrad_final(const float* __re
 #define DFE_LAUNCH_CHECK() do { if (hipGetLastError() != hipSuccess) return DFE_ERR_LAUNCH; } while (0)
 using namespace dfe;
 
-// Work split: units = B * ceil(H / R) * nseg waves per tile pair.  Aim at ~8192 waves in total (8 per SIMD) while keeping
-// the partial planes (units * Co*Ci*9 floats) small: columns are split into up to 4 segments when there are few rows,
-// rows are grouped when there are many.
+// Work split: units = B * ceil(H / R) * nseg waves per tile pair.  Measured on MI355X (12 images): with one or two tile
+// pairs (16->16, 32->16) ~1024 waves in total are fastest -- more waves cost more in partial-plane traffic
+// (units * Co*Ci*9 floats written and re-read) than they gain in occupancy; with many tile pairs (96->32) ~4096.
+// Columns are split into up to 4 segments when there are few rows, rows are grouped when there are many.
 struct WgSplit { int R, nrg, nseg; long units; };
 static WgSplit wg_split(int B, int H, int W, int tiles) {
   WgSplit s{1, H, 1, 0};
-  const long target = 8192 / tiles > 0 ? 8192 / tiles : 1;
+  const long total = tiles <= 2 ? 1024 : 4096;
+  const long target = total / tiles > 0 ? total / tiles : 1;
   while (s.R < H && static_cast<long>(B) * ((H + s.R - 1) / s.R) > target) s.R *= 2;
   s.nrg = (H + s.R - 1) / s.R;
   while (s.nseg < 4 && s.nseg * 2 <= W / 16 && static_cast<long>(B) * s.nrg * s.nseg * 2 <= target) s.nseg *= 2;
@@ -156,7 +160,7 @@ extern "C" int dfe_wgrad3x3_fwd(const float* p, const float* gy, float* gweight,
                                                                                        sp.nrg, sp.nseg);
   DFE_LAUNCH_CHECK();
   const int n = Co * Ci * 9;
-  k_wgrad_final<<<(n + 15) / 16, 16 * WF_LANES, 0, st>>>(partials, gweight, n, static_cast<int>(sp.units));
+  k_wgrad_final<<<(n + 15) / 16, 16 * WF_LANES, 0, st>>>(partials, gweight, n, static_cast<int>(sp.units), Co * Ci);
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
