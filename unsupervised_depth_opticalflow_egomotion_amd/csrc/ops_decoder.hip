@@ -77,6 +77,75 @@ __global__ void __launch_bounds__(256) k_elu_pad_bwd(const float* __restrict__ x
   if (part) block_sum<1>(acc, red, part + static_cast<long>(plane_id()) * gridDim.x + blockIdx.x);
 }
 
+// ---- two elements per thread (even W): these passes are pure streaming, so halving the instruction count per byte
+// is what moves them towards the HBM roofline.  Interior pairs take one 8-byte load / store per stream (the padded
+// plane's pair sits at an odd offset: a dword-aligned 8-byte load); the pairs touching a mirrored column or row
+// take the scalar path.  grid: x over H * W/2 (bwd) or (H+2) * (W+2)/2 (fwd) pairs, y = c, z = b.
+struct __attribute__((aligned(8))) AF2 { float a, b; };
+
+__global__ void __launch_bounds__(256) k_elu_pad_fwd_pair(const float* __restrict__ x, const float* __restrict__ bias,
+                                                          float* __restrict__ out, int C, int H, int W, int elu) {
+  const int Wh = (W + 2) / 2;
+  const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= static_cast<unsigned>((H + 2) * Wh)) return;
+  const int oy = e / static_cast<unsigned>(Wh), ox = 2 * (e - oy * Wh);
+  const long pl = plane_id();
+  const float bv = bias ? bias[plane_id() % C] : 0.0f;
+  const float* row = x + (pl * H + reflect1(oy - 1, H)) * W;
+  float v0, v1;
+  if (ox >= 2 && ox <= W - 2) { const PairF q = *reinterpret_cast<const PairF*>(row + ox - 1); v0 = q.a; v1 = q.b; }
+  else { v0 = row[reflect1(ox - 1, W)]; v1 = row[reflect1(ox, W)]; }
+  v0 += bv; v1 += bv;
+  AF2 o;
+  o.a = elu ? elu1(v0) : v0; o.b = elu ? elu1(v1) : v1;
+  *reinterpret_cast<AF2*>(out + (pl * (H + 2) + oy) * (W + 2) + ox) = o;
+}
+
+__global__ void __launch_bounds__(256) k_elu_pad_bwd_pair(const float* __restrict__ x, const float* __restrict__ bias,
+                                                          const float* __restrict__ gp, float* __restrict__ gx,
+                                                          float* __restrict__ part, int C, int H, int W, int elu) {
+  __shared__ float red[4 * 4];
+  const int Wh = W / 2;
+  const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+  float acc[1] = {0.0f};
+  if (e < static_cast<unsigned>(H * Wh)) {
+    const int iy = e / static_cast<unsigned>(Wh), ix = 2 * (e - iy * Wh);
+    const long pl = plane_id();
+    const float* g = gp + pl * (H + 2) * (W + 2);
+    float g0, g1;
+    if (iy != 1 && iy != H - 2 && ix != 0 && ix != W - 2) {
+      const PairF q = *reinterpret_cast<const PairF*>(g + static_cast<long>(iy + 1) * (W + 2) + ix + 1);
+      g0 = q.a; g1 = q.b;
+    } else { g0 = pad_adjoint(g, iy, ix, H, W); g1 = pad_adjoint(g, iy, ix + 1, H, W); }
+    const long o = (pl * H + iy) * W + ix;
+    if (elu) {
+      const AF2 xv = *reinterpret_cast<const AF2*>(x + o);
+      const float bv = bias ? bias[plane_id() % C] : 0.0f;
+      g0 *= elu1_grad(xv.a + bv); g1 *= elu1_grad(xv.b + bv);
+    }
+    AF2 r; r.a = g0; r.b = g1;
+    *reinterpret_cast<AF2*>(gx + o) = r;
+    acc[0] = g0 + g1;
+  }
+  if (part) block_sum<1>(acc, red, part + static_cast<long>(plane_id()) * gridDim.x + blockIdx.x);
+}
+
+__global__ void __launch_bounds__(256) k_cat_pad_bwd_skip_pair(const float* __restrict__ gp, float* __restrict__ gskip,
+                                                               int C1, int C2, int H, int W) {
+  const int Wh = W / 2;
+  const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= static_cast<unsigned>(H * Wh)) return;
+  const int iy = e / static_cast<unsigned>(Wh), ix = 2 * (e - iy * Wh);
+  const int b = plane_id() / C2, c = plane_id() - b * C2;
+  const float* g = gp + (static_cast<long>(b) * (C1 + C2) + C1 + c) * (H + 2) * (W + 2);
+  AF2 r;
+  if (iy != 1 && iy != H - 2 && ix != 0 && ix != W - 2) {
+    const PairF q = *reinterpret_cast<const PairF*>(g + static_cast<long>(iy + 1) * (W + 2) + ix + 1);
+    r.a = q.a; r.b = q.b;
+  } else { r.a = pad_adjoint(g, iy, ix, H, W); r.b = pad_adjoint(g, iy, ix + 1, H, W); }
+  *reinterpret_cast<AF2*>(gskip + (static_cast<long>(plane_id()) * H + iy) * W + ix) = r;
+}
+
 // ---------------------------------------------------------------- p = pad(cat(up2(elu(x)), skip))
 // x [B,C1,h,w], skip [B,C2,2h,2w] (C2 may be 0), out [B,C1+C2,2h+2,2w+2]
 // grid: x over the elements of one padded plane, y = c, z = b
@@ -200,6 +269,7 @@ __global__ void __launch_bounds__(256) k_cat_pad_bwd_skip(const float* __restric
 using namespace dfe;
 
 static inline bool grid_ok(long plane_elems, long batch, long channels) { return plane_elems < (1L << 31) && batch <= 65535 && channels <= 65535; }
+static inline bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
 static inline unsigned nblk(long n) { return static_cast<unsigned>((n + 255) / 256); }
 
 extern "C" long dfe_glue_partials_floats(int B, int C, int H, int W) {
@@ -211,7 +281,9 @@ extern "C" int dfe_elu_pad_fwd(const float* x, const float* bias, float* out, in
                                void* stream) {
   if (!x || !out) return DFE_ERR_NULL;
   if (B <= 0 || C <= 0 || H < 2 || W < 2 || !grid_ok((H + 2L) * (W + 2L), B, C)) return DFE_ERR_DIMS;
-  k_elu_pad_fwd<<<dim3(nblk((H + 2L) * (W + 2L)), C, B), 256, 0, static_cast<hipStream_t>(stream)>>>(x, bias, out, C, H, W, apply_elu);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (W % 2 == 0 && W >= 4 && al8(out)) k_elu_pad_fwd_pair<<<dim3(nblk((H + 2L) * ((W + 2L) / 2)), C, B), 256, 0, st>>>(x, bias, out, C, H, W, apply_elu);
+  else k_elu_pad_fwd<<<dim3(nblk((H + 2L) * (W + 2L)), C, B), 256, 0, st>>>(x, bias, out, C, H, W, apply_elu);
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
@@ -221,8 +293,10 @@ extern "C" int dfe_elu_pad_bwd(const float* x, const float* bias, const float* g
   if (!gout || !gx || (apply_elu && !x) || (gbias && !partials)) return DFE_ERR_NULL;
   if (B <= 0 || C <= 0 || H < 2 || W < 2 || !grid_ok((H + 2L) * (W + 2L), B, C)) return DFE_ERR_DIMS;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const unsigned nb = nblk(static_cast<long>(H) * W);
-  k_elu_pad_bwd<<<dim3(nb, C, B), 256, 0, st>>>(x, bias, gout, gx, gbias ? partials : nullptr, C, H, W, apply_elu);
+  const bool pair = W % 2 == 0 && W >= 4 && al8(gx) && (!apply_elu || al8(x));
+  const unsigned nb = nblk(pair ? static_cast<long>(H) * (W / 2) : static_cast<long>(H) * W);   // <= the scratch size
+  if (pair) k_elu_pad_bwd_pair<<<dim3(nb, C, B), 256, 0, st>>>(x, bias, gout, gx, gbias ? partials : nullptr, C, H, W, apply_elu);
+  else k_elu_pad_bwd<<<dim3(nb, C, B), 256, 0, st>>>(x, bias, gout, gx, gbias ? partials : nullptr, C, H, W, apply_elu);
   DFE_LAUNCH_CHECK();
   if (gbias) {
     k_glue_bias_final<<<C, 64, 0, st>>>(partials, gbias, B, C, static_cast<int>(nb));
@@ -256,7 +330,8 @@ extern "C" int dfe_elu_up2_cat_pad_bwd(const float* x, const float* bias, const 
     }
   }
   if (gskip && C2 > 0) {
-    k_cat_pad_bwd_skip<<<dim3(nblk(4L * h * w), C2, B), 256, 0, st>>>(gout, gskip, C1, C2, 2 * h, 2 * w);
+    if (w >= 2 && al8(gskip)) k_cat_pad_bwd_skip_pair<<<dim3(nblk(2L * h * w), C2, B), 256, 0, st>>>(gout, gskip, C1, C2, 2 * h, 2 * w);
+    else k_cat_pad_bwd_skip<<<dim3(nblk(4L * h * w), C2, B), 256, 0, st>>>(gout, gskip, C1, C2, 2 * h, 2 * w);
     DFE_LAUNCH_CHECK();
   }
   return DFE_OK;

@@ -24,18 +24,18 @@ constexpr int DH_NACC = DH_CI * 9 + 1;
 // grid: x = strip + nstrips * rowblock, y = b; block = one wave
 __global__ void __launch_bounds__(64) k_disp_head_fwd(const float* __restrict__ p, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ out, int C, int H,
-                                                      int W, int nstrips) {
+                                                      int W, int nstrips, int R) {
   const int lane = threadIdx.x, b = blockIdx.y;
   const int strip = blockIdx.x % nstrips, rb = blockIdx.x / nstrips;
   const int Hp = H + 2, Wp = W + 2;
   const int xx = strip * DH_COLS + lane;              // padded column loaded by this lane = output column it produces
   const bool ld = xx < Wp, st = lane < DH_COLS && xx < W;
-  const int y0 = rb * DH_ROWS;
+  const int y0 = rb * R;
   const float bv = bias ? bias[0] : 0.0f;
   const long plane = static_cast<long>(Hp) * Wp;
   const float* pb = p + static_cast<long>(b) * C * plane + (ld ? xx : 0);
   float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;      // output rows r, r-1, r-2 while padded row r is consumed
-  const int rend = min(y0 + DH_ROWS + 2, Hp);
+  const int rend = min(y0 + R + 2, Hp);
   for (int r = y0; r < rend; ++r) {
     const float* pr = pb + static_cast<long>(r) * Wp;
     for (int c0 = 0; c0 < C; c0 += DH_CI) {
@@ -181,7 +181,9 @@ extern "C" int dfe_disp_head_fwd(const float* p, const float* weight, const floa
   const int rc = dh_dims(B, C, H, W);
   if (rc != DFE_OK) return rc;
   const int ns = dh_strips(W);
-  k_disp_head_fwd<<<dim3(ns * dh_rowblocks(H), B), 64, 0, static_cast<hipStream_t>(stream)>>>(p, weight, bias, out, C, H, W, ns);
+  int R = DH_ROWS;                       // fewer rows per wave on small images: at least ~2048 waves (2-row halo per wave)
+  while (R > 2 && static_cast<long>(B) * ns * ((H + R - 1) / R) < 2048) R /= 2;
+  k_disp_head_fwd<<<dim3(ns * ((H + R - 1) / R), B), 64, 0, static_cast<hipStream_t>(stream)>>>(p, weight, bias, out, C, H, W, ns, R);
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
