@@ -180,6 +180,51 @@ __global__ void __launch_bounds__(256) k_elu_up2_cat_pad_fwd(const float* __rest
   out[(static_cast<long>(plane_id()) * (H + 2) + oy) * (W + 2) + ox] = v;
 }
 
+// two padded output columns (ox, ox+1), ox even, per thread.  In the interior both come from the same two source
+// columns j = ox/2 - 1 and j + 1 (weights 3/4, 1/4 and 1/4, 3/4): 4 ELUs and 2 pair loads for 2 outputs.
+__global__ void __launch_bounds__(256) k_elu_up2_cat_pad_fwd_pair(const float* __restrict__ x, const float* __restrict__ bias,
+                                                                  const float* __restrict__ skip, float* __restrict__ out,
+                                                                  int C1, int C2, int h, int w) {
+  const int H = 2 * h, W = 2 * w, Wh = w + 1;
+  const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= static_cast<unsigned>((H + 2) * Wh)) return;
+  const int oy = e / static_cast<unsigned>(Wh), ox = 2 * (e - oy * Wh);
+  const int C = C1 + C2;
+  const int b = plane_id() / C, c = plane_id() - b * C;
+  const int y = reflect1(oy - 1, H);
+  const bool inner = ox >= 2 && ox <= W - 2;
+  AF2 o;
+  if (c < C1) {
+    int y0, y1; float ly0, ly1;
+    up2_tap(y, h, y0, y1, ly0, ly1);
+    const float* p = x + (static_cast<long>(b) * C1 + c) * h * w;
+    const float* r0 = p + static_cast<long>(y0) * w;
+    const float* r1 = p + static_cast<long>(y1) * w;
+    const float bv = bias ? bias[c] : 0.0f;
+    if (inner) {
+      const int j = ox / 2 - 1;
+      const PairF a = *reinterpret_cast<const PairF*>(r0 + j), d = *reinterpret_cast<const PairF*>(r1 + j);
+      const float e00 = elu1(a.a + bv), e01 = elu1(a.b + bv), e10 = elu1(d.a + bv), e11 = elu1(d.b + bv);
+      o.a = ly0 * (0.75f * e00 + 0.25f * e01) + ly1 * (0.75f * e10 + 0.25f * e11);
+      o.b = ly0 * (0.25f * e00 + 0.75f * e01) + ly1 * (0.25f * e10 + 0.75f * e11);
+    } else {
+      float v[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        int x0, x1; float lx0, lx1;
+        up2_tap(reflect1(ox - 1 + k, W), w, x0, x1, lx0, lx1);
+        v[k] = ly0 * (lx0 * elu1(r0[x0] + bv) + lx1 * elu1(r0[x1] + bv)) + ly1 * (lx0 * elu1(r1[x0] + bv) + lx1 * elu1(r1[x1] + bv));
+      }
+      o.a = v[0]; o.b = v[1];
+    }
+  } else {
+    const float* row = skip + ((static_cast<long>(b) * C2 + (c - C1)) * H + y) * W;
+    if (inner) { const PairF q = *reinterpret_cast<const PairF*>(row + ox - 1); o.a = q.a; o.b = q.b; }
+    else { o.a = row[reflect1(ox - 1, W)]; o.b = row[reflect1(ox, W)]; }
+  }
+  *reinterpret_cast<AF2*>(out + (static_cast<long>(plane_id()) * (H + 2) + oy) * (W + 2) + ox) = o;
+}
+
 // gradient wrt x: thread per low-res element; the <= 4x4 full-res outputs whose taps touch it, each through the
 // adjoint of the reflection pad.  grid: x over the low-res plane, y = c, z = b
 __global__ void __launch_bounds__(256) k_elu_up2_cat_pad_bwd_x(const float* __restrict__ x, const float* __restrict__ bias,
@@ -309,8 +354,9 @@ extern "C" int dfe_elu_up2_cat_pad_fwd(const float* x, const float* bias, const 
                                        int h, int w, void* stream) {
   if (!x || !out || (C2 > 0 && !skip)) return DFE_ERR_NULL;
   if (B <= 0 || C1 <= 0 || C2 < 0 || h < 1 || w < 1 || !grid_ok((2L * h + 2) * (2L * w + 2), B, C1 + C2)) return DFE_ERR_DIMS;
-  k_elu_up2_cat_pad_fwd<<<dim3(nblk((2L * h + 2) * (2L * w + 2)), C1 + C2, B), 256, 0, static_cast<hipStream_t>(stream)>>>(
-      x, bias, skip, out, C1, C2, h, w);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (w >= 2 && al8(out)) k_elu_up2_cat_pad_fwd_pair<<<dim3(nblk((2L * h + 2) * (w + 1L)), C1 + C2, B), 256, 0, st>>>(x, bias, skip, out, C1, C2, h, w);
+  else k_elu_up2_cat_pad_fwd<<<dim3(nblk((2L * h + 2) * (2L * w + 2)), C1 + C2, B), 256, 0, st>>>(x, bias, skip, out, C1, C2, h, w);
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
