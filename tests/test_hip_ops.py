@@ -568,7 +568,7 @@ def test_thin_conv_function_and_eligibility():
     p = torch.randn(2, 32, 130, 418, device=dev())
     w = torch.randn(16, 32, 3, 3, device=dev()) * 0.1
     assert ops.thin_conv3x3_eligible(p, w)
-    assert not ops.thin_conv3x3_eligible(torch.zeros(2, 64, 66, 210, device=dev()), torch.zeros(32, 64, 3, 3, device=dev()))
+    assert not ops.thin_conv3x3_eligible(torch.zeros(2, 64, 34, 106, device=dev()), torch.zeros(32, 64, 3, 3, device=dev()))
     assert not ops.thin_conv3x3_eligible(p, torch.zeros(64, 32, 3, 3, device=dev()))
     res = []
     for fn in (ops.conv3x3_valid, F.conv2d):

@@ -175,6 +175,7 @@ static void wg_group(int Ci, int Co, int& nco, int& nci) {
   const int tci = Ci / 16, tco = Co / 16;
   nco = 1; nci = 1;
   if (tci * tco >= 6 && tco % 2 == 0 && tci % 3 == 0) { nco = 2; nci = 3; }
+  else if (tci * tco >= 4 && tco % 2 == 0 && tci % 2 == 0) { nco = 2; nci = 2; }
 }
 
 extern "C" long dfe_wgrad3x3_partials_floats(int B, int Ci, int Co, int H, int W) {
@@ -195,7 +196,8 @@ extern "C" int dfe_wgrad3x3_fwd(const float* p, const float* gy, float* gweight,
   wg_group(Ci, Co, nco, nci);
   const WgSplit sp = wg_split(B, H, W, (Ci / (16 * nci)) * (Co / (16 * nco)));
   const dim3 grid(static_cast<unsigned>(sp.units), Ci / (16 * nci), Co / (16 * nco));
-  if (nco == 2) k_wgrad3x3_thin<2, 3><<<grid, 64, 0, st>>>(p, gy, partials, Ci, Co, H, W, sp.R, sp.nrg, sp.nseg);
+  if (nco == 2 && nci == 3) k_wgrad3x3_thin<2, 3><<<grid, 64, 0, st>>>(p, gy, partials, Ci, Co, H, W, sp.R, sp.nrg, sp.nseg);
+  else if (nco == 2) k_wgrad3x3_thin<2, 2><<<grid, 64, 0, st>>>(p, gy, partials, Ci, Co, H, W, sp.R, sp.nrg, sp.nseg);
   else k_wgrad3x3_thin<1, 1><<<grid, 64, 0, st>>>(p, gy, partials, Ci, Co, H, W, sp.R, sp.nrg, sp.nseg);
   DFE_LAUNCH_CHECK();
   const int n = Co * Ci * 9;

@@ -513,12 +513,12 @@ class ThinConv3x3Fn(torch.autograd.Function):
 
 
 def thin_conv3x3_eligible(p, weight):
-    """Layers the MFMA weight gradient is measured to win on: <= 32 output channels at >= 128x416 pixels (the last two
-    decoder stages), channel counts multiples of 16, width a multiple of 16."""
+    """Layers the MFMA weight gradient is measured to win on: <= 32 output channels at >= 64x208 pixels (the decoder's
+    last stages), channel counts multiples of 16, width a multiple of 16."""
     Co, Ci = weight.shape[0], weight.shape[1]
     H, W = p.shape[2] - 2, p.shape[3] - 2
     return (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and tuple(weight.shape[2:]) == (3, 3)
-            and Co <= 32 and Co % 16 == 0 and Ci % 16 == 0 and W % 16 == 0 and H * W >= 128 * 416)
+            and Co <= 32 and Co % 16 == 0 and Ci % 16 == 0 and W % 16 == 0 and H * W >= 64 * 208)
 
 
 def conv3x3_valid(p, weight):
