@@ -129,6 +129,15 @@ long dfe_wgrad3x3_partials_floats(int B, int Ci, int Co, int H, int W);
 int dfe_wgrad3x3_fwd(const float* p, const float* gy, float* gweight, float* partials, int B, int Ci, int Co, int H, int W,
                      void* stream);
 
+/* ---- forward / data-gradient pass of the decoder's thinnest 3x3 convolutions on the matrix cores (fp32 MFMA):
+ * out [B,16,Ho,Wo][co][y][x] = sum_{ci,ky,kx} weight[co][ci][ky][kx] * in[b][ci][y+ky-P][x+kx-P] (zero outside in),
+ * in [B,Ci,Hi,Wi], Ho = Hi + 2P - 2, Wo = Wi + 2P - 2.  P = 0: valid convolution of a pre-padded activation (forward);
+ * P = 2: full correlation = the data gradient with transposed_weight = 1: ``weight`` is then the forward kernel
+ * w [16,16,3,3] and is read as weight'[co'][ci'][ky][kx] = w[ci'][co'][2-ky][2-kx].  Output channels must be 16, Ci 16 or
+ * 32 (16 when transposed) (DFE_ERR_UNSUPPORTED otherwise: the caller keeps MIOpen); out 16-byte aligned. */
+int dfe_thin_conv3x3(const float* in, const float* weight, float* out, int B, int Ci, int Co, int Hi, int Wi, int P,
+                     int transposed_weight, void* stream);
+
 /* ---- grouped training-mode BatchNorm2d (+ residual + ReLU) of the depth encoder (SURVEY.md 8(f) rank 1;
  * depth_model.py:60-95 = torchvision BasicBlock conv-bn-relu-conv-bn-(+identity)-relu; model_geometry.py:786-788 calls the
  * depth net once per frame).  x [G*Bg,C,H,W] is G groups of Bg consecutive samples: statistics are per (group, channel)

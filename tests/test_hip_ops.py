@@ -570,12 +570,39 @@ def test_thin_conv_function_and_eligibility():
     assert ops.thin_conv3x3_eligible(p, w)
     assert not ops.thin_conv3x3_eligible(torch.zeros(2, 64, 34, 106, device=dev()), torch.zeros(32, 64, 3, 3, device=dev()))
     assert not ops.thin_conv3x3_eligible(p, torch.zeros(64, 32, 3, 3, device=dev()))
-    res = []
-    for fn in (ops.conv3x3_valid, F.conv2d):
-        pi, wi = p.clone().requires_grad_(True), w.clone().requires_grad_(True)
-        y = fn(pi, wi)
-        (y * y).mean().backward()
-        res.append((N(y), N(pi.grad), N(wi.grad)))
-    close(res[0][0], res[1][0], atol=1e-5, rtol=1e-5)
-    gclose(res[0][1], res[1][1], rel=2e-4, atol=1e-9)
-    gclose(res[0][2], res[1][2], rel=2e-4, atol=1e-9)
+    for pp, ww in ((p, w), (torch.randn(2, 16, 66, 210, device=dev()), torch.randn(16, 16, 3, 3, device=dev()) * 0.1)):
+        res = []                      # 32 -> 16: MFMA weight gradient only; 16 -> 16: all three passes on the matrix cores
+        for fn in (ops.conv3x3_valid, F.conv2d):
+            pi, wi = pp.clone().requires_grad_(True), ww.clone().requires_grad_(True)
+            y = fn(pi, wi)
+            (y * y).mean().backward()
+            res.append((N(y), N(pi.grad), N(wi.grad)))
+        close(res[0][0], res[1][0], atol=1e-5, rtol=1e-5)
+        gclose(res[0][1], res[1][1], rel=2e-4, atol=1e-9)
+        gclose(res[0][2], res[1][2], rel=2e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 7, 32), (1, 32, 5, 48), (2, 16, 9, 40), (3, 16, 33, 61)])
+def test_thin_conv3x3_mfma(shape):
+    """dfe_thin_conv3x3 (fp32 MFMA): the forward pass on a pre-padded input and, for 16 -> 16, the data gradient with
+    the weights read transposed, against F.conv2d and its input gradient in fp64 on the CPU (2e-6 of the scale);
+    widths that are not multiples of 16 or 4 exercise the partial-tile and narrow-store paths."""
+    import torch.nn.functional as F
+    from unsupervised_depth_opticalflow_egomotion_amd._lib import get_lib, ptr, stream_ptr, check
+    lib = get_lib()
+    B, Ci, H, W = shape
+    rng = np.random.RandomState(sum(shape))
+    p = rng.randn(B, Ci, H + 2, W + 2).astype(np.float32)
+    w = (rng.randn(16, Ci, 3, 3) * 0.2).astype(np.float32)
+    gy = rng.randn(B, 16, H, W).astype(np.float32)
+    pd = torch.from_numpy(p).double().requires_grad_(True)
+    ref = F.conv2d(pd, torch.from_numpy(w).double())
+    (ref * torch.from_numpy(gy).double()).sum().backward()
+    ph, wh, gh = G(p), G(w), G(gy)         # keep the device tensors alive across the raw-pointer calls
+    out = torch.empty(B, 16, H, W, device=dev())
+    check(lib.dfe_thin_conv3x3(ptr(ph), ptr(wh), ptr(out), B, Ci, 16, H + 2, W + 2, 0, 0, stream_ptr()), "fwd")
+    gclose(out, ref.detach().float(), rel=2e-6)
+    if Ci == 16:
+        gp = torch.empty(B, 16, H + 2, W + 2, device=dev())
+        check(lib.dfe_thin_conv3x3(ptr(gh), ptr(wh), ptr(gp), B, 16, 16, H, W, 2, 1, stream_ptr()), "dgrad")
+        gclose(gp, pd.grad.float(), rel=2e-6)

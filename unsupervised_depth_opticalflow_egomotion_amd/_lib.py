@@ -35,6 +35,7 @@ _SIGNATURES = {
     "dfe_pose_partials_floats": [_I, _I, _I],
     "dfe_inverse_warp2_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_inverse_warp2_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "dfe_thin_conv3x3": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dfe_wgrad3x3_partials_floats": [_I, _I, _I, _I, _I],
     "dfe_wgrad3x3_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_disp_head_partials_floats": [_I, _I, _I, _I],

@@ -485,27 +485,44 @@ def disp_head(p, weight, bias):
 
 # --------------------------------------------------------------------------- thin 3x3 convolution (MFMA weight gradient)
 class ThinConv3x3Fn(torch.autograd.Function):
-    """Valid 3x3 convolution of a pre-padded activation, bias-free.  Forward and data gradient run on MIOpen; the
-    weight gradient -- a (Co x 9 Ci) contraction over B*H*W pixels that MIOpen runs at a fraction of the others' rate
-    for the decoder's thin full-resolution layers -- runs the fp32-MFMA kernel dfe_wgrad3x3_fwd."""
+    """Valid 3x3 convolution of a pre-padded activation, bias-free, for the decoder's thin full-resolution layers.
+    The weight gradient -- a (Co x 9 Ci) contraction over B*H*W pixels -- always runs the fp32-MFMA kernel
+    dfe_wgrad3x3_fwd; the 16 -> 16 layer (256x832, where MIOpen reaches 40 TFLOP/s) also runs its forward and data
+    gradient on dfe_thin_conv3x3, the other layers keep MIOpen for those two passes."""
+
+    @staticmethod
+    def _mfma_passes(p, weight):
+        return weight.shape[0] == 16 and weight.shape[1] == 16
 
     @staticmethod
     def forward(ctx, p, weight):
         ctx.save_for_backward(p, weight)
-        return torch.nn.functional.conv2d(p, weight)
+        if not ThinConv3x3Fn._mfma_passes(p, weight):
+            return torch.nn.functional.conv2d(p, weight)
+        lib = get_lib()
+        weight = f32c(weight)
+        B, Ci, Hp, Wp = p.shape
+        out = torch.empty(B, 16, Hp - 2, Wp - 2, device=p.device)
+        check(lib.dfe_thin_conv3x3(ptr(p), ptr(weight), ptr(out), B, Ci, 16, Hp, Wp, 0, 0, stream_ptr()), "dfe_thin_conv3x3")
+        return out
 
     @staticmethod
     def backward(ctx, gy):
         lib = get_lib()
         p, weight = ctx.saved_tensors
         gy = f32c(gy)
+        B, Ci, Hp, Wp = p.shape
+        Co, H, W = weight.shape[0], Hp - 2, Wp - 2
         gp = gw = None
         if ctx.needs_input_grad[0]:
-            gp = torch.ops.aten.convolution_backward(gy, p, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
-                                                     [True, False, False])[0]
+            if ThinConv3x3Fn._mfma_passes(p, weight):
+                gp = torch.empty_like(p)
+                check(lib.dfe_thin_conv3x3(ptr(gy), ptr(f32c(weight)), ptr(gp), B, Co, Ci, H, W, 2, 1, stream_ptr()),
+                      "dfe_thin_conv3x3 (data gradient)")
+            else:
+                gp = torch.ops.aten.convolution_backward(gy, p, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                         [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            B, Ci, Hp, Wp = p.shape
-            Co, H, W = weight.shape[0], Hp - 2, Wp - 2
             gw = torch.empty_like(weight)
             part = torch.empty(lib.dfe_wgrad3x3_partials_floats(B, Ci, Co, H, W), device=p.device)
             check(lib.dfe_wgrad3x3_fwd(ptr(p), ptr(gy), ptr(gw), ptr(part), B, Ci, Co, H, W, stream_ptr()), "dfe_wgrad3x3_fwd")
