@@ -78,6 +78,21 @@ int dfe_rigid_flow_fwd(const float* depth, const float* cams, float* out, int B,
 int dfe_rigid_flow_bwd(const float* depth, const float* cams, const float* gout, float* g_depth, float* g_pose,
                        float* partials, int B, int H, int W, void* stream);
 
+/* ---- mask decisions of the per-method API -----------------------------------------------------
+ * compute_occ_weight (model_geometry.py:105-132): from_l/tgt/from_r [B,3,H,W] (masked flow warps and the
+ *   target level) -> occ_bwd/occ_fwd = (1 - softmax([dl, dr]) > 0.48), valid_bwd/valid_fwd = 1 - prod_c(warp == 0),
+ *   all [B,1,H,W] in {0,1};
+ * compute_texture_mask (model_geometry.py:134-140): (mean_c|img - warped| < mean_c|img - source|) -> [B,1,H,W];
+ * compute_dynamic_mask (model_geometry.py:699-711): flow, rigid [B,2,H,W] -> mask = (n(|rigid-flow|)^2 <
+ *   alpha (n(flow)^2 + n(rigid)^2) + beta), score = 1 / (1e-4 + n(|rigid-flow|)) (score may be NULL).
+ * Same device arithmetic as the fused stack: masks are bit-identical to dfe_geom_loss_fwd's mask pack. */
+int dfe_occ_masks(const float* from_l, const float* tgt, const float* from_r, float* occ_bwd, float* occ_fwd,
+                  float* valid_bwd, float* valid_fwd, int B, int H, int W, void* stream);
+int dfe_texture_mask(const float* img, const float* warped, const float* source, float* out, int B, int H, int W,
+                     void* stream);
+int dfe_dynamic_mask(const float* flow, const float* rigid, float* mask, float* score, float alpha, float beta, int B,
+                     int H, int W, void* stream);
+
 /* ---- SSIM(x, y)  pytorch_ssim/ssim.py:4-19 -------------------------------------------------- */
 int dfe_ssim_fwd(const float* x, const float* y, float* out, int B, int C, int H, int W, void* stream);
 int dfe_ssim_bwd(const float* x, const float* y, const float* gout, float* gx, float* gy, int B, int C, int H, int W,

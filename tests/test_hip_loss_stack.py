@@ -1,10 +1,17 @@
 """GPU parity of the fused loss stack (dfe_geom_loss_fwd/bwd through the C ABI) against the oracle's
 restatement of model_geometry.py:797-951 and against the golden vectors captured from the reference.
 
-Tolerances (fp32): loss vectors 2e-5 relative (reduction order + <=1e-4 of the pixels whose mask
-decision sits within fp32 noise of its threshold); masks: bit-exact except pixels whose decision
-margin in the oracle is below 1e-5 -- the test counts mismatches and requires them to be < 2e-4 of
-the pixels; gradients 2e-4 of the gradient scale except at most a few elements per flipped pixel."""
+Contract (fp32), measured headroom in brackets (MI355X, EPYC host, profiles/r02_parity_report.txt):
+  * masks: BIT-EXACT.  The kernels evaluate the reference's expressions in the reference's association order
+    (incl. the FMA patterns of its BLAS / ATen kernels) on identical inputs, so every mask decision is taken on
+    identical bits; the one transcendental feeding a decision is the softmax's exp (<= 1-2 ulp between libraries),
+    so an occlusion bit may differ only at a pixel whose margin |w - 0.48| < 2e-7 (tests/_margins.py).  The seeds in
+    STRICT are margin-checked (no pixel inside that floor, re-checked on the host in every run): for them all eight
+    masks at every scale must EQUAL the oracle's.  Elsewhere a differing pixel must lie inside the floor.  [0 flips
+    in every case tried, also at B=4 256x832 and B=2 375x1242 S=6]
+  * loss vectors: 5e-6 relative on all eight rows (reduction order only) [<= 7e-7]
+  * gradients: 1e-4 of the gradient's scale, element-wise, no outliers on STRICT seeds [<= 2e-5];
+    pose gradient 2e-5 [<= 3e-6]."""
 import os
 
 import numpy as np
@@ -12,11 +19,15 @@ import pytest
 import torch
 
 from oracle import loss_stack_oracle as O
+from tests import _margins as M
 from tests.golden import make_golden as MG
 from unsupervised_depth_opticalflow_egomotion_amd import synthetic
 
 pytestmark = pytest.mark.gpu
 T, N = MG.T, MG.N
+
+# margin-checked seeds per (B, H, W) at S = 3, valid for both align_corners modes (tests/test_api_cpu.py re-derives this)
+STRICT = {(2, 32, 96): 932, (2, 64, 208): 77, (2, 128, 448): 600, (1, 256, 832): 1219}
 
 
 def dev():
@@ -57,43 +68,44 @@ def run_oracle(inp, ac, S, weights=None):
     return lp, masks, total, (disps, pose, fb, ff)
 
 
-MASK_MAP = dict(valid_bwd="valid_bwd", valid_fwd="valid_fwd", occ_bwd="occ_bwd", occ_fwd="occ_fwd",
-                dyna_bwd="dyna_bwd", dyna_fwd="dyna_fwd", texture_bwd="texture_bwd", texture_fwd="texture_fwd")
+MASKS = ("valid_bwd", "valid_fwd", "occ_bwd", "occ_fwd", "dyna_bwd", "dyna_fwd", "texture_bwd", "texture_fwd")
 
 
-def compare(inp, ac, S, weights=None):
+def check_masks(mk_h, mk_o, margins, S, strict, names=MASKS):
+    """Every differing pixel must lie inside its mask's fp32 noise floor; returns (nflip, npx, within)."""
+    within = M.within_counts({k: margins[k] for k in names})
+    nflip, npx = 0, 0
+    for k in names:
+        tau = M.TAU[M.family(k)]
+        for s in range(S):
+            a, b = N(mk_h[k][s]), N(mk_o[k][s])
+            assert a.shape == b.shape
+            f = a != b
+            nflip += int(f.sum())
+            npx += a.size
+            assert (margins[k][s][f] < tau).all(), "%s scale %d: %d differing pixel(s) outside the noise floor %g " \
+                "(largest margin %g)" % (k, s, int(f.sum()), tau, float(margins[k][s][f].max()))
+    print("masks: %d differing of %d decisions; %d pixel(s) inside the noise floor" % (nflip, npx, sum(within.values())))
+    if strict:
+        assert sum(within.values()) == 0, "seed is not margin-checked: %r" % (within,)
+        assert nflip == 0
+    return nflip, npx, within
+
+
+def compare(inp, ac, S, weights=None, strict=False):
     lp_h, mk_h, tot_h, (dh, ph, fbh, ffh) = run_hip(inp, ac, S, weights)
     lp_o, mk_o, tot_o, (do, po, fbo, ffo) = run_oracle(inp, ac, S, weights)
-    # masks
-    nflip, npx = 0, 0
-    for k, ko in MASK_MAP.items():
-        for s in range(S):
-            a, b = N(mk_h[k][s]), N(mk_o[ko][s])
-            assert a.shape == b.shape
-            nflip += int((a != b).sum())
-            npx += a.size
-    assert nflip <= 2e-4 * npx, "mask mismatches %d of %d" % (nflip, npx)
-    # losses
-    # loss_depth_flow_consis / loss_epipolar are means of absolute pixel coordinates differences: with
-    # coordinates up to ~1e3 px one fp32 ulp of K^-1 (LAPACK LU in the reference, closed form in the
-    # kernel) is a *systematic* ~5e-5 px, i.e. up to 1e-4 relative on an O(1) loss value.
+    nflip, npx, _ = check_masks(mk_h, mk_o, M.geom_margins(inp, ac, S), S, strict)
     for k in lp_h:
-        rt = 1e-4 if k in ("loss_depth_flow_consis", "loss_epipolar") else 2e-5
-        np.testing.assert_allclose(N(lp_h[k]), N(lp_o[k]), rtol=rt + 4.0 * nflip / npx, atol=1e-7, err_msg=k)
-    np.testing.assert_allclose(N(tot_h), N(tot_o), rtol=5e-5 + 4.0 * nflip / npx)
+        np.testing.assert_allclose(N(lp_h[k]), N(lp_o[k]), rtol=5e-6 + 4.0 * nflip / npx, atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(N(tot_h), N(tot_o), rtol=5e-6 + 4.0 * nflip / npx)
 
-    # Per-pixel gradients.  Besides mask flips, a pixel whose bilinear sample coordinate lands within
-    # fp32 noise of an integer is differentiated in adjacent cells by the two implementations (the value
-    # is continuous there, the derivative is not): such "kink" pixels are budgeted at 1e-4 of the pixels.
-    kink_budget = 2 + int(1e-4 * npx)
-    nbad = [0]
-
-    def gcmp(a, b, name, rel=2e-4, per_flip=12):
+    # element-wise gradients: 1e-4 of the gradient's scale; only a flipped pixel may move its neighbourhood
+    def gcmp(a, b, name, rel=1e-4, per_flip=12, extra=0):
         a, b = N(a.grad), N(b.grad)
         scale = max(np.abs(b).max(), 1e-12)
         bad = int((np.abs(a - b) > rel * scale + 1e-9).sum())
-        nbad[0] += bad
-        assert bad <= per_flip * nflip + kink_budget, "%s: %d bad elements (nflip=%d) max diff %g scale %g" % (
+        assert bad <= per_flip * nflip + extra, "%s: %d bad elements (nflip=%d) max diff %g scale %g" % (
             name, bad, nflip, np.abs(a - b).max(), scale)
     for f in range(3):
         for s in range(S):
@@ -101,20 +113,26 @@ def compare(inp, ac, S, weights=None):
     for s in range(S):
         gcmp(fbh[s], fbo[s], "gflow_b_%d" % s)
         gcmp(ffh[s], ffo[s], "gflow_f_%d" % s)
-    # the pose gradient is a sum over all pixels: exact to 2e-4 when no pixel flipped, and within 2%
-    # of its scale when a few kink / threshold pixels (each O(1/N) of the sum) differ
     gp_h, gp_o = N(ph.grad), N(po.grad)
-    tol = 2e-4 if (nflip == 0 and nbad[0] == 0) else 2e-2
-    assert np.abs(gp_h - gp_o).max() <= tol * max(np.abs(gp_o).max(), 1e-12) + 1e-6, (gp_h, gp_o, nflip, nbad[0])
+    tol = 2e-5 if nflip == 0 else 2e-2
+    assert np.abs(gp_h - gp_o).max() <= tol * max(np.abs(gp_o).max(), 1e-12) + 1e-7, (gp_h, gp_o, nflip)
     return nflip, npx
 
 
 @pytest.mark.parametrize("ac", [False, True])
 @pytest.mark.parametrize("shape", [(2, 32, 96), (2, 128, 448), (1, 256, 832)])
 def test_fused_stack_vs_oracle(shape, ac):
+    """Margin-checked seeds: masks EQUAL, losses 5e-6, gradients 1e-4 / 2e-5 (pose)."""
     b, h, w = shape
-    inp = synthetic.make_loss_stack_inputs(b, h, w, 3, seed=900 + h)
-    compare(inp, ac, 3)
+    inp = synthetic.make_loss_stack_inputs(b, h, w, 3, seed=STRICT[shape])
+    compare(inp, ac, 3, strict=True)
+
+
+@pytest.mark.parametrize("ac", [False, True])
+def test_fused_stack_baseline_batch(ac):
+    """BASELINE configs[2] size, B=4 256x832 S=3, against the oracle (1.1 M decisions per mask family: a few pixels
+    always sit inside the occlusion noise floor, so the per-pixel rule applies instead of a margin-checked seed)."""
+    compare(synthetic.make_loss_stack_inputs(4, 256, 832, 3, seed=1234), ac, 3)
 
 
 def test_fused_stack_each_loss_gradient():
@@ -124,12 +142,13 @@ def test_fused_stack_each_loss_gradient():
         if k in ("loss_depth_ssim", "loss_depth_consis", "loss_triangle", "loss_pnp", "loss_eight_point"):
             continue
         w = {q: (1.0 if q == k else 0.0) for q in MG.GEOM_WEIGHTS}
-        compare(inp, False, 3, weights=w)
+        compare(inp, False, 3, weights=w, strict=True)
 
 
 def test_fused_stack_full_res_six_scales():
-    """Config 5 shape: 375x1242 with the general (non /2) bilinear pyramid path, 6 scales."""
-    inp = synthetic.make_loss_stack_inputs(1, 375, 1242, 6, seed=55, num_flow_scales=6)
+    """BASELINE configs[4] shape at its per-GPU batch: B=2, 375x1242, 6 scales -- the general (non /2) bilinear
+    pyramid, box-mean and adjoint paths."""
+    inp = synthetic.make_loss_stack_inputs(2, 375, 1242, 6, seed=55, num_flow_scales=6)
     compare(inp, False, 6)
 
 
@@ -142,29 +161,35 @@ def test_fused_stack_vs_golden(golden_dir, ac, case):
     inp = synthetic.make_loss_stack_inputs(b, h, w, 3, seed=seed)
     lp, masks, total, (disps, pose, fb, ff) = run_hip(inp, ac, 3)
     key = "%dx%dx%d" % (b, h, w)
+    assert int(g[key + "_within"][0]) == 0          # the fixture's seed is margin-checked (make_golden.store_margins)
     for k, v in lp.items():
-        np.testing.assert_allclose(N(v), g[key + "_" + k], rtol=1e-4, atol=1e-7, err_msg=k)
-    np.testing.assert_allclose(N(total), g[key + "_total"], rtol=1e-4)
+        np.testing.assert_allclose(N(v), g[key + "_" + k], rtol=5e-6, atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(N(total), g[key + "_total"], rtol=5e-6)
+    # the masks the reference exports in mask_pack (sample 0, scale 0): bit-exact
+    # (mask_pack['valid_fwd_mask'] is inverse_warp2's validity towards the right frame, model_geometry.py:875)
+    from unsupervised_depth_opticalflow_egomotion_amd.structures import inverse_warp2
+    valid_to_r = inverse_warp2(G(inp.imgs[2]), disps[1][0].detach(), disps[2][0].detach(),
+                               pose.detach()[:, 1].contiguous(), G(inp.K), align_corners=ac)[1]
     for nm, t in (("occ_fwd_mask", masks["occ_fwd"][0][0]), ("dyna_fwd_mask", masks["dyna_fwd"][0][0]),
-                  ("texture_mask_fwd", masks["texture_fwd"][0][0])):
+                  ("texture_mask_fwd", masks["texture_fwd"][0][0]), ("valid_fwd_mask", valid_to_r[0]),
+                  ("fwd_mask", (masks["valid_fwd"][0] * masks["occ_fwd"][0] * masks["dyna_fwd"][0])[0])):
         ref = np.unpackbits(g[key + "_mp_" + nm])[: h * w]
-        mism = (N(t).reshape(-1).astype(np.uint8) != ref).sum()
-        assert mism <= 2e-4 * h * w, (nm, mism)
-    # one flipped / kink pixel moves the pose gradient by ~1e-2 (K/Z ~ 1e3 times a per-pixel gradient of
-    # ~1e-5) while the total is a heavily cancelling sum of O(1): 2% of the scale is the honest bound here;
-    # test_fused_stack_each_loss_gradient holds it to 2e-4 on inputs without flips.
+        assert np.array_equal(N(t).reshape(-1).astype(np.uint8), ref), nm
     gp = g[key + "_gpose"]
-    assert np.abs(N(pose.grad) - gp).max() <= 2e-2 * np.abs(gp).max()
+    assert np.abs(N(pose.grad) - gp).max() <= 2e-5 * np.abs(gp).max()
+    # per-pixel gradients: strided samples element-wise (1e-4 of the scale) and the L1 norm (1e-5)
+    def gsub(t, prefix):
+        ref_sub, ref_sum = g[prefix + "_sub"], g[prefix + "_sum"]
+        flat = N(t.grad).reshape(-1)
+        scale = max(np.abs(flat).max(), 1e-12)
+        assert np.abs(flat[::97] - ref_sub).max() <= 1e-4 * scale, prefix
+        assert abs(np.abs(flat.astype(np.float64)).sum() - ref_sum[1]) <= 1e-5 * ref_sum[1], prefix
     for f in range(3):
         for s in range(3):
-            ref = g[key + "_gdisp_%d_%d_sum" % (f, s)]
-            flat = N(disps[f][s].grad).reshape(-1).astype(np.float64)
-            assert abs(np.abs(flat).sum() - ref[1]) <= 2e-3 * ref[1], (f, s)
+            gsub(disps[f][s], key + "_gdisp_%d_%d" % (f, s))
     for s in range(3):
-        for nm, lst in (("b", fb), ("f", ff)):
-            ref = g[key + "_gflow_%s_%d_sum" % (nm, s)]
-            flat = N(lst[s].grad).reshape(-1).astype(np.float64)
-            assert abs(np.abs(flat).sum() - ref[1]) <= 2e-3 * ref[1], (nm, s)
+        gsub(fb[s], key + "_gflow_b_%d" % s)
+        gsub(ff[s], key + "_gflow_f_%d" % s)
     assert fb[3].grad is None or float(fb[3].grad.abs().sum()) == 0.0   # the 1/8 flow is dropped
 
 
@@ -218,8 +243,7 @@ def _grad_close(a, b, name, rel=2e-4, budget=0):
 @pytest.mark.parametrize("shape,S", [((2, 128, 448), 3), ((3, 70, 100), 2), ((1, 256, 832), 4)])
 def test_flow_mode_vs_oracle(shape, S, ac):
     """mode 2 (Model_flow stack, model_flow.py:209-255): no hard masks on this path -- the occlusion weights are
-    smooth Gaussians -- so losses agree to 2e-5 and flow gradients to 2e-4 of their scale, except kink pixels
-    (bilinear coordinate within fp32 noise of an integer), budgeted at 1e-4 of the pixels."""
+    smooth Gaussians -- losses agree to 5e-6 and flow gradients to 1e-4 of their scale, element-wise."""
     from unsupervised_depth_opticalflow_egomotion_amd.loss_stack import flow_loss_stack
     b, h, w = shape
     inp = synthetic.make_loss_stack_inputs(b, h, w, S, seed=1300 + h)
@@ -232,18 +256,18 @@ def test_flow_mode_vs_oracle(shape, S, ac):
     sum(wts[k] * v.mean() for k, v in lp_o.items()).backward()
     assert set(lp_h) == set(lp_o)
     for k in lp_h:
-        np.testing.assert_allclose(N(lp_h[k]), N(lp_o[k]), rtol=2e-5, atol=1e-7, err_msg=k)
+        np.testing.assert_allclose(N(lp_h[k]), N(lp_o[k]), rtol=5e-6, atol=1e-7, err_msg=k)
     for s in range(S):
-        budget = 2 + int(1e-4 * fbo[s].numel())
-        _grad_close(fbh[s], fbo[s], "gflow_b_%d" % s, budget=budget)
-        _grad_close(ffh[s], ffo[s], "gflow_f_%d" % s, budget=budget)
+        _grad_close(fbh[s], fbo[s], "gflow_b_%d" % s, rel=1e-4)
+        _grad_close(ffh[s], ffo[s], "gflow_f_%d" % s, rel=1e-4)
 
 
 @pytest.mark.parametrize("ac", [False, True])
 @pytest.mark.parametrize("shape,S", [((2, 128, 448), 3), ((3, 70, 100), 2), ((1, 256, 832), 4)])
 def test_depth_mode_vs_oracle(shape, S, ac):
-    """mode 1 (Model_depth stack, model_depth.py:272-337): validity / texture masks bit-exact up to threshold
-    flips (< 2e-4 of the pixels), losses 2e-5 (+ flips), gradients 2e-4 of their scale away from flips / kinks."""
+    """mode 1 (Model_depth stack, model_depth.py:272-337): the inverse_warp2 validity and texture masks are exact IEEE
+    arithmetic on identical inputs -> they must EQUAL the oracle's (no noise floor on this path: no transcendental
+    feeds a decision); losses 5e-6, gradients 1e-4 of their scale element-wise, pose gradient 2e-5."""
     from unsupervised_depth_opticalflow_egomotion_amd.loss_stack import depth_loss_stack
     b, h, w = shape
     inp = synthetic.make_loss_stack_inputs(b, h, w, S, seed=1700 + h)
@@ -258,25 +282,18 @@ def test_depth_mode_vs_oracle(shape, S, ac):
     lp_o, mk_o = O.GeomLossOracle(num_scales=S, align_corners=ac).depth_losses(
         *[T(a) for a in inp.imgs], do[0], do[1], do[2], po, T(inp.K))
     sum(wts[k] * lp_o[k].mean() for k in wts).backward()
-    nflip, npx = 0, 0
     for k in ("valid_to_l", "valid_to_r", "texture_bwd", "texture_fwd"):
         for s in range(S):
-            a, c = N(mk_h[k][s]), N(mk_o[k][s])
-            nflip += int((a != c).sum())
-            npx += a.size
-    assert nflip <= 2e-4 * npx, "mask mismatches %d of %d" % (nflip, npx)
+            assert np.array_equal(N(mk_h[k][s]), N(mk_o[k][s])), (k, s)
     for k in lp_h:
-        np.testing.assert_allclose(N(lp_h[k]), N(lp_o[k]), rtol=2e-5 + 4.0 * nflip / npx, atol=1e-7, err_msg=k)
-    nbad = 0
+        np.testing.assert_allclose(N(lp_h[k]), N(lp_o[k]), rtol=5e-6, atol=1e-7, err_msg=k)
     for f in range(3):
         for s in range(S):
             a, c = N(dh[f][s].grad), N(do[f][s].grad)
-            bad = int((np.abs(a - c) > 2e-4 * max(np.abs(c).max(), 1e-12) + 1e-9).sum())
-            nbad += bad
-            assert bad <= 12 * nflip + 2 + int(1e-4 * a.size), ("gdisp_%d_%d" % (f, s), bad, nflip)
-    tol = 2e-4 if (nflip == 0 and nbad == 0) else 2e-2
+            bad = int((np.abs(a - c) > 1e-4 * max(np.abs(c).max(), 1e-12) + 1e-9).sum())
+            assert bad == 0, ("gdisp_%d_%d" % (f, s), bad, np.abs(a - c).max(), np.abs(c).max())
     gp_h, gp_o = N(ph.grad), N(po.grad)
-    assert np.abs(gp_h - gp_o).max() <= tol * max(np.abs(gp_o).max(), 1e-12) + 1e-6, (gp_h, gp_o, nflip, nbad)
+    assert np.abs(gp_h - gp_o).max() <= 2e-5 * max(np.abs(gp_o).max(), 1e-12) + 1e-7, (gp_h, gp_o)
 
 
 def test_flow_mode_argument_errors():

@@ -99,31 +99,42 @@ def test_rigid_golden(golden_dir, ac):
     from unsupervised_depth_opticalflow_egomotion_amd.structures import (
         inverse_warp2, calculate_rigid_flow, pose_vec2mat, compute_essential_matrix)
     g = load(golden_dir, "G2_ac%d" % ac)
-    close(pose_vec2mat(G(g["vec"])), g["pose_mat"], atol=1e-6)
-    close(compute_essential_matrix(G(g["vec"])), g["essential"], atol=1e-6)
+    # the kernels evaluate the reference's own fp32 arithmetic (k_prepare_cameras, project(): ATen's small-bmm loops,
+    # LAPACK's 3x3 inverse, sgemm's FMA order, grid_sample's FMA chain) -> forward outputs are BIT-IDENTICAL to the
+    # values the reference produced (poses are robust_pose'd: cos / sin unambiguous)
+    assert np.array_equal(N(pose_vec2mat(G(g["vec"]))), g["pose_mat"])
+    assert np.array_equal(N(compute_essential_matrix(G(g["vec"]))), g["essential"])
     for i, (h, w, case) in enumerate(MG.G2_CASES):
         img, depth, ref_depth, pose, k, wi, wd, wf = MG.g2_inputs(h, w, 210 + i, case)
         key = "%dx%d_%s" % (h, w, case)
         dt, rdt, pt = G(depth, True), G(ref_depth, True), G(pose, True)
         pi, valid, pd, cd = inverse_warp2(G(img), dt, rdt, pt, G(k), align_corners=ac)
         ((pi * G(wi)).sum() + (pd * G(wd)).sum() + (cd * G(wd)).sum() * 0.5).backward()
-        mism = N(valid) != g[key + "_valid"]
-        assert mism.mean() <= 2e-3, (key, mism.sum())   # validity flips only within fp32 noise of |grid|==1
-        ok = ~np.broadcast_to(mism, N(pi).shape)
-        close(N(pi)[ok], g[key + "_img"][ok], atol=2e-4)
-        close(N(pd)[~mism], g[key + "_pdepth"][~mism], atol=2e-4)
-        close(cd, g[key + "_cdepth"], atol=1e-5, rtol=1e-5)
-        nflip = int(mism.sum())
-        gclose(dt.grad, g[key + "_gdepth"], rel=2e-3, max_outliers=nflip, atol=1e-3)
-        gclose(rdt.grad, g[key + "_grefdepth"], rel=2e-3, max_outliers=4 * nflip)
-        if nflip == 0:
-            gclose(pt.grad, g[key + "_gpose"], rel=2e-3, atol=1e-2)
+        for got, name in ((valid, "_valid"), (pi, "_img"), (pd, "_pdepth"), (cd, "_cdepth")):
+            assert np.array_equal(N(got), g[key + name]), (key, name, float(np.abs(N(got) - g[key + name]).max()))
+        # gradients: 2e-4 of the gradient's scale; atol covers analytically-zero gradients that are cancellation noise
+        # in the reference itself (identity pose)
+        gclose(dt.grad, g[key + "_gdepth"], rel=2e-4, atol=1e-4)
+        gclose(rdt.grad, g[key + "_grefdepth"], rel=2e-4)
+        gclose(pt.grad, g[key + "_gpose"], rel=2e-4, atol=1e-3)
         dt3, pt3 = G(depth, True), G(pose, True)
         rf = calculate_rigid_flow(dt3, pt3, G(k))
         (rf * G(wf)).sum().backward()
-        close(rf, g[key + "_rflow"], atol=2e-3, rtol=1e-5)
-        gclose(dt3.grad, g[key + "_rflow_gdepth"], rel=1e-3, atol=1e-3)
-        gclose(pt3.grad, g[key + "_rflow_gpose"], rel=1e-3, atol=1e-2)
+        assert np.array_equal(N(rf), g[key + "_rflow"]), key
+        gclose(dt3.grad, g[key + "_rflow_gdepth"], rel=2e-4, atol=1e-4)
+        gclose(pt3.grad, g[key + "_rflow_gpose"], rel=2e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("ac", [False, True])
+def test_rigid_ops_full_size_vs_oracle(ac):
+    """inverse_warp2 / calculate_rigid_flow at 256x832 (BASELINE size) against the oracle: every output EQUAL."""
+    from unsupervised_depth_opticalflow_egomotion_amd.structures import inverse_warp2, calculate_rigid_flow
+    img, depth, ref_depth, pose, k, wi, wd, wf = MG.g2_inputs(256, 832, 777, "rand")
+    pi, valid, pd, cd = inverse_warp2(G(img), G(depth), G(ref_depth), G(pose), G(k), align_corners=ac)
+    po, vo, pdo, cdo = O.inverse_warp2(T(img), T(depth), T(ref_depth), T(pose), T(k), align_corners=ac)
+    for got, ref, name in ((valid, vo, "valid"), (pi, po, "img"), (pd, pdo, "pdepth"), (cd, cdo, "cdepth")):
+        assert np.array_equal(N(got), N(ref)), (name, float(np.abs(N(got) - N(ref)).max()))
+    assert np.array_equal(N(calculate_rigid_flow(G(depth), G(pose), G(k))), N(O.calculate_rigid_flow(T(depth), T(pose), T(k))))
 
 
 def test_pose_mats_backward():

@@ -59,27 +59,53 @@ def test_warp_flow_shape_error():
 def test_g2_rigid(golden_dir, ac):
     g = load(golden_dir, "G2_ac%d" % ac)
     vec = T(g["vec"])
-    close(N(O.pose_vec2mat(vec)), g["pose_mat"], atol=1e-7)
-    close(N(O.compute_essential_matrix(vec)), g["essential"], atol=1e-7)
+    assert np.array_equal(N(O.pose_vec2mat(vec)), g["pose_mat"])
+    assert np.array_equal(N(O.compute_essential_matrix(vec)), g["essential"])
     for i, (h, w, case) in enumerate(MG.G2_CASES):
         img, depth, ref_depth, pose, k, wi, wd, wf = MG.g2_inputs(h, w, 210 + i, case)
         key = "%dx%d_%s" % (h, w, case)
         dt, rdt, pt = T(depth, True), T(ref_depth, True), T(pose, True)
         pi, valid, pd, cd = O.inverse_warp2(T(img), dt, rdt, pt, T(k), align_corners=ac)
         ((pi * T(wi)).sum() + (pd * T(wd)).sum() + (cd * T(wd)).sum() * 0.5).backward()
-        close(N(pi), g[key + "_img"])
-        assert np.array_equal(N(valid), g[key + "_valid"])
-        close(N(pd), g[key + "_pdepth"])
-        close(N(cd), g[key + "_cdepth"])
-        close(N(dt.grad), g[key + "_gdepth"], atol=1e-5, rtol=1e-5)
+        # forward: the oracle states the reference's accumulation orders explicitly (oracle._bmm3, _inverse3), so it
+        # reproduces the captured reference outputs bit for bit on any host
+        for got, name in ((pi, "_img"), (valid, "_valid"), (pd, "_pdepth"), (cd, "_cdepth")):
+            assert np.array_equal(N(got), g[key + name]), (key, name)
+        # backward: autograd runs through the oracle's fp64-emulated FMA chain instead of sgemm's own backward --
+        # same mathematics, rounding differs: 5e-4 of the gradient scale
+        gscale(N(dt.grad), g[key + "_gdepth"])
         close(N(rdt.grad), g[key + "_grefdepth"], atol=1e-6)
-        close(N(pt.grad), g[key + "_gpose"], atol=1e-4, rtol=1e-5)
+        gscale(N(pt.grad), g[key + "_gpose"])
         dt3, pt3 = T(depth, True), T(pose, True)
         rf = O.calculate_rigid_flow(dt3, pt3, T(k))
         (rf * T(wf)).sum().backward()
-        close(N(rf), g[key + "_rflow"], atol=1e-5)
-        close(N(dt3.grad), g[key + "_rflow_gdepth"], atol=1e-4, rtol=1e-5)
-        close(N(pt3.grad), g[key + "_rflow_gpose"], atol=1e-3, rtol=1e-5)
+        assert np.array_equal(N(rf), g[key + "_rflow"]), key
+        gscale(N(dt3.grad), g[key + "_rflow_gdepth"])
+        gscale(N(pt3.grad), g[key + "_rflow_gpose"])
+
+
+def gscale(a, b, rel=5e-4, atol=1e-4):
+    """atol: gradients that are analytically zero (identity pose: d rigid_flow / d depth) are pure cancellation noise
+    of ~3e-5 in the reference itself."""
+    assert np.abs(a - b).max() <= rel * np.abs(b).max() + atol, (np.abs(a - b).max(), np.abs(b).max())
+
+
+def test_inverse3_matches_torch_inverse():
+    """oracle._inverse3 (explicit LAPACK arithmetic) == torch.inverse in this container for every pyramid level of the
+    KITTI-like intrinsics the configs use (no row exchange: fx >= cx, fy >= cy)."""
+    from unsupervised_depth_opticalflow_egomotion_amd import synthetic
+    for (h, w) in [(256, 832), (375, 1242), (128, 448), (64, 208), (70, 100), (32, 96)]:
+        for ds in [1, 2, 4, 8, 375 / 187, 375 / 93, 375 / 46, 375 / 23, 375 / 11]:
+            K = torch.from_numpy(synthetic.kitti_like_intrinsics(h, w).astype(np.float32))[None].clone()
+            K[:, :2] = K[:, :2] / ds
+            assert torch.equal(O._inverse3(K), K.inverse()), (h, w, ds)
+
+
+def test_bmm3_is_the_golden_run_order():
+    """oracle._bmm3 == the reference's ``a @ b`` as evaluated in the container that generated the goldens."""
+    torch.manual_seed(3)
+    a, b = torch.randn(4, 3, 3), torch.randn(4, 3, 53248)
+    assert torch.equal(O._bmm3(a, b), a @ b)
 
 
 def test_g3_ssim(golden_dir):
@@ -111,7 +137,7 @@ def test_g4_corr(golden_dir):
 @pytest.mark.parametrize("ac", ACS)
 def test_g5_methods(golden_dir, ac):
     g = load(golden_dir, "G5_ac%d" % ac)
-    inp = synthetic.make_loss_stack_inputs(2, 32, 96, 3, seed=505)
+    inp = synthetic.make_loss_stack_inputs(*MG.G5_SHAPE, 3, seed=MG.G5_SEED)
     m = O.GeomLossOracle(align_corners=ac)
     il, it, ir = [T(a) for a in inp.imgs]
     disps, pose, fb, ff = MG.lists_to_t(inp, False)

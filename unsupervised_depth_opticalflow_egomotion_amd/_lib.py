@@ -54,6 +54,9 @@ _SIGNATURES = {
     "dfe_elu_up2_cat_pad_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_rigid_flow_fwd": [_P, _P, _P, _I, _I, _I, _P],
     "dfe_rigid_flow_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "dfe_occ_masks": [_P] * 7 + [_I, _I, _I, _P],
+    "dfe_texture_mask": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "dfe_dynamic_mask": [_P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _I, _I, _I, _P],
     "dfe_ssim_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_ssim_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_corr_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -209,16 +209,18 @@ struct Proj {
 __device__ __forceinline__ Proj project(const Camera& c, int x, int y, float depth) {
   Proj p;
   float fx = static_cast<float>(x), fy = static_cast<float>(y);
-  // Plain multiply-add association, no FMA: with an identity pose the border pixels must project EXACTLY
-  // onto |grid| = 1 as they do in the reference (golden G2 "identity"); an FMA chain lands 1 ulp outside and
-  // flips the validity of the whole border ring.
-  p.r0 = c.kinv[0] * fx + c.kinv[1] * fy + c.kinv[2];
-  p.r1 = c.kinv[3] * fx + c.kinv[4] * fy + c.kinv[5];
-  p.r2 = c.kinv[6] * fx + c.kinv[7] * fy + c.kinv[8];
+  // The reference evaluates K^-1 @ pix and (K R) @ cam as large bmm calls: MKL sgemm accumulates the three
+  // products of an output element as fma(a2, b2, fma(a1, b1, a0 * b0)) (probed bit for bit, torch 2.10 CPU);
+  // the translation is a separate add (inverse_warp.py:238).  With the camera block of k_prepare_cameras this
+  // reproduces the reference's X, Y, Z exactly, so border pixels of an identity pose land on |grid| = 1 as they
+  // do there (golden G2 "identity") and every mask fed by the projection is decided on identical bits.
+  p.r0 = __fmaf_rn(c.kinv[1], fy, c.kinv[0] * fx) + c.kinv[2];
+  p.r1 = __fmaf_rn(c.kinv[4], fy, c.kinv[3] * fx) + c.kinv[5];
+  p.r2 = __fmaf_rn(c.kinv[7], fy, c.kinv[6] * fx) + c.kinv[8];
   float c0 = p.r0 * depth, c1 = p.r1 * depth, c2 = p.r2 * depth;
-  float X = (c.A[0] * c0 + c.A[1] * c1 + c.A[2] * c2) + c.b[0];
-  float Y = (c.A[3] * c0 + c.A[4] * c1 + c.A[5] * c2) + c.b[1];
-  float Zr = (c.A[6] * c0 + c.A[7] * c1 + c.A[8] * c2) + c.b[2];
+  float X = __fmaf_rn(c.A[2], c2, __fmaf_rn(c.A[1], c1, c.A[0] * c0)) + c.b[0];
+  float Y = __fmaf_rn(c.A[5], c2, __fmaf_rn(c.A[4], c1, c.A[3] * c0)) + c.b[1];
+  float Zr = __fmaf_rn(c.A[8], c2, __fmaf_rn(c.A[7], c1, c.A[6] * c0)) + c.b[2];
   p.q0 = c.A[0] * p.r0 + c.A[1] * p.r1 + c.A[2] * p.r2;
   p.q1 = c.A[3] * p.r0 + c.A[4] * p.r1 + c.A[5] * p.r2;
   p.q2 = c.A[6] * p.r0 + c.A[7] * p.r1 + c.A[8] * p.r2;
@@ -336,14 +338,39 @@ __device__ __forceinline__ void bilinear_src(int dst, float scale, int in_size, 
   l0 = 1.0f - l1;
 }
 
+// ATen's upsample_bilinear2d inner loop (UpSampleKernel.cpp, `output = t0 * w0; output += t1 * w1` per dimension) is
+// compiled to fma(t0, w0, t1 * w1) -- probed bit for bit (torch 2.10 CPU, up- and down-sampling, exact and
+// non-exact ratios): horizontally t = fma(v_x0, lx0, v_x1 * lx1), then out = fma(t_y0, ly0, t_y1 * ly1).
+__device__ __forceinline__ float lerp_aten(float v0, float v1, float l0, float l1) { return __fmaf_rn(v0, l0, v1 * l1); }
+__device__ __forceinline__ float lerp2_aten(float v00, float v01, float v10, float v11, float lx0, float lx1,
+                                            float ly0, float ly1) {
+  return lerp_aten(lerp_aten(v00, v01, lx0, lx1), lerp_aten(v10, v11, lx0, lx1), ly0, ly1);
+}
+
+// When the OUTPUT of the resize has H + W <= 128, ATen dispatches to another kernel (UpSampleKernel.cpp,
+// _use_vectorized_kernel_cond_2d -> cpu_upsample_linear) whose four products are associated differently:
+// w_ij = ly_i * lx_j (rounded), out = fma(w11, v11, fma(w10, v10, fma(w00, v00, w01 * v01))) -- also probed bit for
+// bit, with the switch at exactly 128.  (Levels 4-5 of the 375x1242 six-scale pyramid and tiny test images.)
+__device__ __forceinline__ bool aten_small_resize(int outH, int outW) { return outH + outW <= 128; }
+__device__ __forceinline__ float lerp2_aten_small(float v00, float v01, float v10, float v11, float lx0, float lx1,
+                                                  float ly0, float ly1) {
+  const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
+  return __fmaf_rn(w11, v11, __fmaf_rn(w10, v10, __fmaf_rn(w00, v00, w01 * v01)));
+}
+__device__ __forceinline__ float lerp2_aten_sel(bool small, float v00, float v01, float v10, float v11, float lx0,
+                                                float lx1, float ly0, float ly1) {
+  return small ? lerp2_aten_small(v00, v01, v10, v11, lx0, lx1, ly0, ly1)
+               : lerp2_aten(v00, v01, v10, v11, lx0, lx1, ly0, ly1);
+}
+
 __device__ __forceinline__ float resize_bilinear_at(const float* __restrict__ plane, int inH, int inW,
-                                                    int y, int x, float sh, float sw) {
+                                                    int y, int x, float sh, float sw, bool small) {
   int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
   bilinear_src(y, sh, inH, y0, y1, ly0, ly1);
   bilinear_src(x, sw, inW, x0, x1, lx0, lx1);
   const float* r0 = plane + static_cast<long>(y0) * inW;
   const float* r1 = plane + static_cast<long>(y1) * inW;
-  return ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
+  return lerp2_aten_sel(small, r0[x0], r0[x1], r1[x0], r1[x1], lx0, lx1, ly0, ly1);
 }
 
 // ---------------------------------------------------------------- reductions

@@ -121,17 +121,25 @@ struct UpCache { int r0, r1; float h0, h1; };
 
 __device__ __forceinline__ float up_hrow(const float* __restrict__ dp, int Ws, int r, const UpMap& m) {
   const float* row = dp + r * Ws;
-  return m.l0 * row[m.x0] + m.l1 * row[m.x1];
+  return lerp_aten(row[m.x0], row[m.x1], m.l0, m.l1);
 }
 
-__device__ __forceinline__ float up_row(const float* __restrict__ dp, int Hs, int Ws, float rh, int y, const UpMap& m, UpCache& c) {
+// `small`: the full-resolution output has H + W <= 128 (tiny images only) -> ATen's non-separable association
+// (lerp2_aten_small), evaluated directly from the four taps; wave-uniform branch.
+__device__ __forceinline__ float up_row(const float* __restrict__ dp, int Hs, int Ws, float rh, int y, const UpMap& m, UpCache& c,
+                                        bool small = false) {
   int a0, a1; float ly0, ly1;
   bilinear_src(y, rh, Hs, a0, a1, ly0, ly1);          // wave-uniform
+  if (small) {
+    const float* r0 = dp + a0 * Ws;
+    const float* r1 = dp + a1 * Ws;
+    return lerp2_aten_small(r0[m.x0], r0[m.x1], r1[m.x0], r1[m.x1], m.l0, m.l1, ly0, ly1);
+  }
   float n0, n1;
   if (a0 == c.r0) n0 = c.h0; else if (a0 == c.r1) n0 = c.h1; else n0 = up_hrow(dp, Ws, a0, m);
   if (a1 == c.r1) n1 = c.h1; else if (a1 == c.r0) n1 = c.h0; else if (a1 == a0) n1 = n0; else n1 = up_hrow(dp, Ws, a1, m);
   c.r0 = a0; c.r1 = a1; c.h0 = n0; c.h1 = n1;
-  return ly0 * n0 + ly1 * n1;
+  return lerp_aten(n0, n1, ly0, ly1);
 }
 
 // ---- rolling flow-smoothness helpers

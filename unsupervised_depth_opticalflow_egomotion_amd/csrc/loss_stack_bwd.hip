@@ -228,9 +228,9 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomBwd 
         // epipolar distance (plain mean; model_geometry.py:413-418)
         const Epi& e = D.epi[b * 2 + d];
         const float x1 = static_cast<float>(px), y1 = static_cast<float>(py);
-        const float l0 = e.F[0] * x1 + e.F[1] * y1 + e.F[2];
-        const float l1 = e.F[3] * x1 + e.F[4] * y1 + e.F[5];
-        const float l2 = e.F[6] * x1 + e.F[7] * y1 + e.F[8];
+        const float l0 = __fmaf_rn(e.F[1], y1, e.F[0] * x1) + e.F[2];
+        const float l1 = __fmaf_rn(e.F[4], y1, e.F[3] * x1) + e.F[5];
+        const float l2 = __fmaf_rn(e.F[7], y1, e.F[6] * x1) + e.F[8];
         const float r = sqrtf(l0 * l0 + l1 * l1), div = r + 1e-6f;
         const float x2 = x1 + fu[d], y2 = y1 + fv[d];
         const float n = (x2 * l0 + y2 * l1) + l2;
@@ -498,6 +498,7 @@ __global__ void __launch_bounds__(64) k_geom_disp_smooth_bwd1(GeomDev D, GeomBwd
   const float cx = g / (static_cast<float>(H) * (W - 1.0f)), cy = g / ((H - 1.0f) * static_cast<float>(W));
   UpMap mp[NS > 1 ? NS - 1 : 1];
   UpCache ch[NS > 1 ? NS - 1 : 1];
+  const bool small_out = aten_small_resize(H, W);   // tiny full-resolution images only (see up_row)
   const float* dps[NS > 1 ? NS - 1 : 1];
   float rhs[NS > 1 ? NS - 1 : 1];
 #pragma unroll
@@ -512,7 +513,7 @@ __global__ void __launch_bounds__(64) k_geom_disp_smooth_bwd1(GeomDev D, GeomBwd
   float u[NS], bprev[NS];
   u[0] = d0[q];
 #pragma unroll
-  for (int s = 1; s < NS; ++s) u[s] = up_row(dps[s - 1], D.H[s], D.W[s], rhs[s - 1], ys, mp[s - 1], ch[s - 1]);
+  for (int s = 1; s < NS; ++s) u[s] = up_row(dps[s - 1], D.H[s], D.W[s], rhs[s - 1], ys, mp[s - 1], ch[s - 1], small_out);
 #pragma unroll
   for (int s = 0; s < NS; ++s) bprev[s] = 0.0f;
   int qn = min(ys + 1, H - 1) * W + xc;
@@ -527,7 +528,7 @@ __global__ void __launch_bounds__(64) k_geom_disp_smooth_bwd1(GeomDev D, GeomBwd
     float un[NS];
     un[0] = ed;
 #pragma unroll
-    for (int s = 1; s < NS; ++s) un[s] = up_row(dps[s - 1], D.H[s], D.W[s], rhs[s - 1], min(y + 1, H - 1), mp[s - 1], ch[s - 1]);
+    for (int s = 1; s < NS; ++s) un[s] = up_row(dps[s - 1], D.H[s], D.W[s], rhs[s - 1], min(y + 1, H - 1), mp[s - 1], ch[s - 1], small_out);
     const bool store = lane_ok && y >= y0;
     const long p = static_cast<long>(y) * W + x;
 #pragma unroll

@@ -100,6 +100,15 @@ void geom_dev(const dfe_geom_args* a, const GeomLayout& L, GeomDev* D) {
 
 // ---------------------------------------------------------------------- epipolar geometry
 // F = K_inv^T (E K_inv), E = [t]x R (model_geometry.py:375-378, inverse_warp.py:344-364).
+__device__ inline void mat3_small_bmm(const float* a, const float* b, float* o) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      float acc = 0.0f;
+      for (int k = 0; k < 3; ++k) acc = __fadd_rn(acc, __fmul_rn(a[i * 3 + k], b[k * 3 + j]));
+      o[i * 3 + j] = acc;
+    }
+}
+
 __global__ void k_prepare_epi(const float* __restrict__ pose, const float* __restrict__ Kinv, Epi* __restrict__ epi,
                               const Camera* __restrict__ cams, int B, int S) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -107,14 +116,16 @@ __global__ void k_prepare_epi(const float* __restrict__ pose, const float* __res
   const int b = i / 2;
   const float* v = pose + i * 6;
   const Camera& c = cams[i * S];    // R is scale independent
-  double Sk[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
-  double E[9], M[9], F[9], Ki[9];
+  // fp32 small-bmm arithmetic of the reference (acc = 0; acc += a*b in k order, no FMA; see k_prepare_cameras)
+  const float Sk[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+  float E[9], M[9], Ki[9], KiT[9];
   for (int k = 0; k < 9; ++k) Ki[k] = Kinv[b * 9 + k];
-  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) E[r * 3 + q] = Sk[r * 3] * c.R[q] + Sk[r * 3 + 1] * c.R[3 + q] + Sk[r * 3 + 2] * c.R[6 + q];
-  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) M[r * 3 + q] = E[r * 3] * Ki[q] + E[r * 3 + 1] * Ki[3 + q] + E[r * 3 + 2] * Ki[6 + q];
-  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) F[r * 3 + q] = Ki[r] * M[q] + Ki[3 + r] * M[3 + q] + Ki[6 + r] * M[6 + q];
+  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) KiT[r * 3 + q] = Ki[q * 3 + r];
   Epi e;
-  for (int k = 0; k < 9; ++k) { e.F[k] = static_cast<float>(F[k]); e.Kinv[k] = static_cast<float>(Ki[k]); e.S[k] = static_cast<float>(Sk[k]); }
+  mat3_small_bmm(Sk, c.R, E);
+  mat3_small_bmm(E, Ki, M);
+  mat3_small_bmm(KiT, M, e.F);
+  for (int k = 0; k < 9; ++k) { e.Kinv[k] = Ki[k]; e.S[k] = Sk[k]; }
   epi[i] = e;
 }
 
@@ -140,14 +151,14 @@ __global__ void k_geom_pyramids(PyrJobs jobs) {
   const int inH = jobs.inH, inW = jobs.inW;
   const float* src = jb.in + pl * inH * inW;
   if (jb.out_bilinear) {
-    // F.interpolate(bilinear, align_corners=False): ly0*(lx0*v00 + lx1*v01) + ly1*(lx0*v10 + lx1*v11)
+    // F.interpolate(bilinear, align_corners=False), ATen's contraction (lerp2_aten, dfe_device.h)
     int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
     bilinear_src(oy, static_cast<float>(inH) / jb.outH, inH, y0, y1, ly0, ly1);
     bilinear_src(ox, static_cast<float>(inW) / jb.outW, inW, x0, x1, lx0, lx1);
     float v00, v01, v10, v11;
     load2(src + static_cast<long>(y0) * inW, x0, x1, v00, v01);
     load2(src + static_cast<long>(y1) * inW, x0, x1, v10, v11);
-    jb.out_bilinear[i] = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+    jb.out_bilinear[i] = lerp2_aten_sel(aten_small_resize(jb.outH, jb.outW), v00, v01, v10, v11, lx0, lx1, ly0, ly1);
   }
   if (jb.out_area) {
     // adaptive_avg_pool2d window [floor(o*in/out), ceil((o+1)*in/out)), row-major sequential sum / count
@@ -295,9 +306,10 @@ __device__ __forceinline__ void point_pixel(const PointCtx& c, int px, int py, c
       a[PT_FDIFF] += (du + dv) * m_rig;
       const Epi& e = c.epi[d];
       const float x1 = static_cast<float>(px), y1 = static_cast<float>(py);
-      const float l0 = e.F[0] * x1 + e.F[1] * y1 + e.F[2];
-      const float l1 = e.F[3] * x1 + e.F[4] * y1 + e.F[5];
-      const float l2 = e.F[6] * x1 + e.F[7] * y1 + e.F[8];
+      // f_mat.bmm(p1) is a large bmm: fma(F2, 1, fma(F1, y, F0 * x)) (MKL sgemm order, see project())
+      const float l0 = __fmaf_rn(e.F[1], y1, e.F[0] * x1) + e.F[2];
+      const float l1 = __fmaf_rn(e.F[4], y1, e.F[3] * x1) + e.F[5];
+      const float l2 = __fmaf_rn(e.F[7], y1, e.F[6] * x1) + e.F[8];
       // feeds a loss value only (no mask): 1-ulp sqrt / reciprocal instead of the IEEE sequences
       const float div = __builtin_amdgcn_sqrtf(l0 * l0 + l1 * l1) + 1e-6f;
       a[PT_EPI] += fabsf(((x1 + in.fu[d]) * l0 + (y1 + in.fv[d]) * l1) + l2) * __builtin_amdgcn_rcpf(div);
@@ -647,6 +659,7 @@ __global__ void __launch_bounds__(64) k_geom_disp_smooth_fwd(GeomDev D, float* _
   const bool lane_ok = threadIdx.x < RS_COLS && x < W, hx = lane_ok && x + 1 < W;
   UpMap mp[NS > 1 ? NS - 1 : 1];
   UpCache ch[NS > 1 ? NS - 1 : 1];
+  const bool small_out = aten_small_resize(H, W);   // tiny full-resolution images only (see up_row)
   const float* dps[NS > 1 ? NS - 1 : 1];
   float rhs[NS > 1 ? NS - 1 : 1];
 #pragma unroll
@@ -663,7 +676,7 @@ __global__ void __launch_bounds__(64) k_geom_disp_smooth_fwd(GeomDev D, float* _
   float u[NS];
   u[0] = d0[q];
 #pragma unroll
-  for (int s = 1; s < NS; ++s) u[s] = up_row(dps[s - 1], D.H[s], D.W[s], rhs[s - 1], y0, mp[s - 1], ch[s - 1]);
+  for (int s = 1; s < NS; ++s) u[s] = up_row(dps[s - 1], D.H[s], D.W[s], rhs[s - 1], y0, mp[s - 1], ch[s - 1], small_out);
   // prefetch of the next row's streamed values
   int qn = min(y0 + 1, H - 1) * W + xc;
   float n0 = im[qn], n1 = im[qn + N], n2 = im[qn + 2 * N], nd = d0[qn];
@@ -677,7 +690,7 @@ __global__ void __launch_bounds__(64) k_geom_disp_smooth_fwd(GeomDev D, float* _
     float un[NS];
     un[0] = ed;
 #pragma unroll
-    for (int s = 1; s < NS; ++s) un[s] = up_row(dps[s - 1], D.H[s], D.W[s], rhs[s - 1], min(y + 1, H - 1), mp[s - 1], ch[s - 1]);
+    for (int s = 1; s < NS; ++s) un[s] = up_row(dps[s - 1], D.H[s], D.W[s], rhs[s - 1], min(y + 1, H - 1), mp[s - 1], ch[s - 1], small_out);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const float ux = wave_shl1(u[s]);

@@ -33,6 +33,80 @@ __device__ inline void euler_mats(double rx, double ry, double rz, double* X, do
   for (int i = 0; i < 9; ++i) { X[i] = x[i]; Y[i] = y[i]; Z[i] = z[i]; dX[i] = dx[i]; dY[i] = dy[i]; dZ[i] = dz[i]; }
 }
 
+// ---- the reference's own fp32 arithmetic for the camera block (probed bit for bit against ATen CPU, torch 2.10):
+//  * xmat @ ymat @ zmat, intrinsics @ pose_mat and the 3x3 products of the essential / fundamental matrix are
+//    "small" bmm calls (contraction * rows * cols < 400): ATen's scalar loop acc = 0; acc += a[k] * b[k][j]
+//    in k order, every product and sum rounded to fp32, no FMA (aten/src/ATen/native/LinearAlgebra.cpp
+//    baddbmm_cpu_kernel);
+//  * intrinsics.inverse() (inverse_warp.py:284,329) = LAPACK getrf + getrs on the transposed storage: partial
+//    pivoting, first column scaled by the reciprocal of the pivot, second column divided, FMA Schur updates,
+//    reciprocal diagonal in the triangular solve.  Bit-identical for intrinsics that need no row exchange
+//    (|fx| >= |cx|, |fy| >= |cy|: every pinhole camera with a field of view below 90 degrees, KITTI: 0.58 W vs
+//    0.5 W); within a few ulp otherwise (the exchange path of MKL was not pinned);
+//  * cos / sin: ATen uses MKL VML (HA mode, <= 0.6 ulp, proprietary); here the correctly rounded value
+//    (double evaluation rounded once).  The two agree whenever the exact value is not within 0.1 ulp of a
+//    rounding boundary; the parity tests use poses for which that holds (synthetic.robust_pose).
+__device__ inline void mat3_mul_f32(const float* a, const float* b, float* o, int ncol = 3, int ldb = 3) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < ncol; ++j) {
+      float acc = 0.0f;
+      for (int k = 0; k < 3; ++k) acc = __fadd_rn(acc, __fmul_rn(a[i * 3 + k], b[k * ldb + j]));
+      o[i * ncol + j] = acc;
+    }
+}
+
+__device__ inline void inverse3_lapack_f32(const float* A, float* X) {
+  float M[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) M[i * 3 + j] = A[j * 3 + i];   // M = A^T
+  int perm[3] = {0, 1, 2};
+  for (int j = 0; j < 2; ++j) {
+    int p = j;
+    for (int i = j + 1; i < 3; ++i) if (fabsf(M[i * 3 + j]) > fabsf(M[p * 3 + j])) p = i;
+    if (p != j) {
+      for (int k = 0; k < 3; ++k) { const float t = M[j * 3 + k]; M[j * 3 + k] = M[p * 3 + k]; M[p * 3 + k] = t; }
+      const int t = perm[j]; perm[j] = perm[p]; perm[p] = t;
+    }
+    if (j == 0) {
+      const float r = __fdiv_rn(1.0f, M[0]);
+      M[3] = __fmul_rn(M[3], r); M[6] = __fmul_rn(M[6], r);
+    } else {
+      M[7] = __fdiv_rn(M[7], M[4]);
+    }
+    for (int i = j + 1; i < 3; ++i)
+      for (int k = j + 1; k < 3; ++k) M[i * 3 + k] = __fmaf_rn(-M[i * 3 + j], M[j * 3 + k], M[i * 3 + k]);
+  }
+  // A = U^T L^T P: U^T Y = I (forward), L^T W = Y (backward, unit diagonal), X = P^T W
+  float Y[9], Wm[9];
+  for (int c = 0; c < 3; ++c)
+    for (int i = 0; i < 3; ++i) {
+      float s = (i == c) ? 1.0f : 0.0f;
+      for (int k = 0; k < i; ++k) s = __fsub_rn(s, __fmul_rn(M[k * 3 + i], Y[k * 3 + c]));
+      Y[i * 3 + c] = __fmul_rn(s, __fdiv_rn(1.0f, M[i * 3 + i]));
+    }
+  for (int c = 0; c < 3; ++c)
+    for (int i = 2; i >= 0; --i) {
+      float s = Y[i * 3 + c];
+      for (int k = i + 1; k < 3; ++k) s = __fsub_rn(s, __fmul_rn(M[k * 3 + i], Wm[k * 3 + c]));
+      Wm[i * 3 + c] = s;
+    }
+  for (int i = 0; i < 3; ++i) for (int c = 0; c < 3; ++c) X[perm[i] * 3 + c] = Wm[i * 3 + c];
+}
+
+// correctly rounded fp32 cos / sin (double evaluation, one rounding)
+__device__ inline float cos_cr(float x) { return static_cast<float>(cos(static_cast<double>(x))); }
+__device__ inline float sin_cr(float x) { return static_cast<float>(sin(static_cast<double>(x))); }
+
+// R = Rx Ry Rz exactly as euler2mat evaluates it (inverse_warp.py:110-145)
+__device__ inline void euler_rotation_f32(float rx, float ry, float rz, float* R) {
+  const float cx = cos_cr(rx), sx = sin_cr(rx), cy = cos_cr(ry), sy = sin_cr(ry), cz = cos_cr(rz), sz = sin_cr(rz);
+  const float x[9] = {1, 0, 0, 0, cx, -sx, 0, sx, cx};
+  const float y[9] = {cy, 0, sy, 0, 1, 0, -sy, 0, cy};
+  const float z[9] = {cz, -sz, 0, sz, cz, 0, 0, 0, 1};
+  float xy[9];
+  mat3_mul_f32(x, y, xy);
+  mat3_mul_f32(xy, z, R);
+}
+
 // One thread per camera.  cams[(b*ndir + d)*nscale + s]; pose laid out [B, ndir, 6];
 // K [B,3,3]; K_s = K with rows 0-1 divided by downscale[s] (model_geometry.py:92-93).
 __global__ void k_prepare_cameras(const float* __restrict__ pose, const float* __restrict__ K,
@@ -41,34 +115,23 @@ __global__ void k_prepare_cameras(const float* __restrict__ pose, const float* _
   if (idx >= B * ndir * nscale) return;
   int s = idx % nscale, d = (idx / nscale) % ndir, b = idx / (nscale * ndir);
   const float* pv = pose + (static_cast<long>(b) * ndir + d) * 6;
-  double Ks[9];
+  Camera c;
   // the reference divides in fp32: intrinsics[:,0:2]/downscale
   for (int i = 0; i < 9; ++i) {
-    float k = K[b * 9 + i];
-    Ks[i] = (i < 6) ? static_cast<double>(k / downs.v[s]) : static_cast<double>(k);
+    const float k = K[b * 9 + i];
+    c.K[i] = (i < 6) ? __fdiv_rn(k, downs.v[s]) : k;
   }
-  double X[9], Y[9], Z[9], dX[9], dY[9], dZ[9], XY[9], R[9], T1[9], T2[9];
+  euler_rotation_f32(pv[3], pv[4], pv[5], c.R);
+  // proj = K_s @ [R | t]  (inverse_warp.py:289): A = proj[:, :3], b = proj[:, 3]
+  float T34[12], P[12];
+  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) T34[i * 4 + j] = c.R[i * 3 + j]; T34[i * 4 + 3] = pv[i]; }
+  mat3_mul_f32(c.K, T34, P, 4, 4);
+  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) c.A[i * 3 + j] = P[i * 4 + j]; c.b[i] = P[i * 4 + 3]; }
+  inverse3_lapack_f32(c.K, c.kinv);
+  // dR/d(rx) = dX Y Z ; dR/d(ry) = X dY Z ; dR/d(rz) = X Y dZ  (backward only: double, rounded once)
+  double X[9], Y[9], Z[9], dX[9], dY[9], dZ[9], XY[9], T1[9], T2[9];
   euler_mats(pv[3], pv[4], pv[5], X, Y, Z, dX, dY, dZ);
-  mat3_mul(X, Y, XY); mat3_mul(XY, Z, R);
-  Camera c;
-  double A[9]; mat3_mul(Ks, R, A);
-  for (int i = 0; i < 9; ++i) { c.A[i] = static_cast<float>(A[i]); c.K[i] = static_cast<float>(Ks[i]); c.R[i] = static_cast<float>(R[i]); }
-  for (int i = 0; i < 3; ++i)
-    c.b[i] = static_cast<float>(Ks[i * 3] * pv[0] + Ks[i * 3 + 1] * pv[1] + Ks[i * 3 + 2] * pv[2]);
-  // general 3x3 inverse (adjugate / determinant) in double
-  double det = Ks[0] * (Ks[4] * Ks[8] - Ks[5] * Ks[7]) - Ks[1] * (Ks[3] * Ks[8] - Ks[5] * Ks[6]) +
-               Ks[2] * (Ks[3] * Ks[7] - Ks[4] * Ks[6]);
-  double id = 1.0 / det;
-  c.kinv[0] = static_cast<float>((Ks[4] * Ks[8] - Ks[5] * Ks[7]) * id);
-  c.kinv[1] = static_cast<float>((Ks[2] * Ks[7] - Ks[1] * Ks[8]) * id);
-  c.kinv[2] = static_cast<float>((Ks[1] * Ks[5] - Ks[2] * Ks[4]) * id);
-  c.kinv[3] = static_cast<float>((Ks[5] * Ks[6] - Ks[3] * Ks[8]) * id);
-  c.kinv[4] = static_cast<float>((Ks[0] * Ks[8] - Ks[2] * Ks[6]) * id);
-  c.kinv[5] = static_cast<float>((Ks[2] * Ks[3] - Ks[0] * Ks[5]) * id);
-  c.kinv[6] = static_cast<float>((Ks[3] * Ks[7] - Ks[4] * Ks[6]) * id);
-  c.kinv[7] = static_cast<float>((Ks[1] * Ks[6] - Ks[0] * Ks[7]) * id);
-  c.kinv[8] = static_cast<float>((Ks[0] * Ks[4] - Ks[1] * Ks[3]) * id);
-  // dR/d(rx) = dX Y Z ; dR/d(ry) = X dY Z ; dR/d(rz) = X Y dZ
+  mat3_mul(X, Y, XY);
   mat3_mul(dX, Y, T1); mat3_mul(T1, Z, T2);
   for (int i = 0; i < 9; ++i) c.dR[i] = static_cast<float>(T2[i]);
   mat3_mul(X, dY, T1); mat3_mul(T1, Z, T2);
@@ -118,16 +181,13 @@ __global__ void k_pose_mats(const float* __restrict__ vec, float* __restrict__ T
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float* v = vec + i * 6;
-  // fp32 like the reference (torch.cos/sin on fp32, R = (X@Y)@Z)
-  float cx = cosf(v[3]), sx = sinf(v[3]), cy = cosf(v[4]), sy = sinf(v[4]), cz = cosf(v[5]), sz = sinf(v[5]);
-  float X[9] = {1, 0, 0, 0, cx, -sx, 0, sx, cx}, Y[9] = {cy, 0, sy, 0, 1, 0, -sy, 0, cy}, Z[9] = {cz, -sz, 0, sz, cz, 0, 0, 0, 1};
-  float XY[9], R[9];
-  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) XY[r * 3 + c] = X[r * 3] * Y[c] + X[r * 3 + 1] * Y[3 + c] + X[r * 3 + 2] * Y[6 + c];
-  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[r * 3 + c] = XY[r * 3] * Z[c] + XY[r * 3 + 1] * Z[3 + c] + XY[r * 3 + 2] * Z[6 + c];
+  // the reference's fp32 arithmetic (see k_prepare_cameras): R = (X @ Y) @ Z and E = [t]x @ R as small bmm loops
+  float R[9];
+  euler_rotation_f32(v[3], v[4], v[5], R);
   if (T34) for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T34[i * 12 + r * 4 + c] = R[r * 3 + c]; T34[i * 12 + r * 4 + 3] = v[r]; }
   if (E) {
-    float S[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) E[i * 9 + r * 3 + c] = S[r * 3] * R[c] + S[r * 3 + 1] * R[3 + c] + S[r * 3 + 2] * R[6 + c];
+    const float S[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+    mat3_mul_f32(S, R, E + i * 9);
   }
 }
 
@@ -632,7 +692,8 @@ __global__ void k_resize(const float* __restrict__ in, float* __restrict__ out, 
   const long pl = i / (static_cast<long>(outW) * outH);
   const float* src = in + pl * inH * inW;
   if (mode == 0) {
-    out[i] = resize_bilinear_at(src, inH, inW, oy, ox, static_cast<float>(inH) / outH, static_cast<float>(inW) / outW);
+    out[i] = resize_bilinear_at(src, inH, inW, oy, ox, static_cast<float>(inH) / outH, static_cast<float>(inW) / outW,
+                                aten_small_resize(outH, outW));
   } else {
     // adaptive_avg_pool2d window: [floor(o*in/out), ceil((o+1)*in/out))
     int ys = (oy * inH) / outH, ye = ((oy + 1) * inH + outH - 1) / outH;

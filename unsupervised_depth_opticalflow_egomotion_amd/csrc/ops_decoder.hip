@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256) k_elu_up2_cat_pad_fwd(const float* __rest
       const PairF a = *reinterpret_cast<const PairF*>(r0 + x0), d = *reinterpret_cast<const PairF*>(r1 + x0);
       v00 = a.a; v01 = a.b; v10 = d.a; v11 = d.b;
     } else { v00 = v01 = r0[x0]; v10 = v11 = r1[x0]; }
-    v = ly0 * (lx0 * elu1(v00 + bv) + lx1 * elu1(v01 + bv)) + ly1 * (lx0 * elu1(v10 + bv) + lx1 * elu1(v11 + bv));
+    v = lerp2_aten(elu1(v00 + bv), elu1(v01 + bv), elu1(v10 + bv), elu1(v11 + bv), lx0, lx1, ly0, ly1);
   } else {
     v = skip[((static_cast<long>(b) * C2 + (c - C1)) * H + y) * W + xx];
   }
@@ -205,15 +205,15 @@ __global__ void __launch_bounds__(256) k_elu_up2_cat_pad_fwd_pair(const float* _
       const int j = ox / 2 - 1;
       const PairF a = *reinterpret_cast<const PairF*>(r0 + j), d = *reinterpret_cast<const PairF*>(r1 + j);
       const float e00 = elu1(a.a + bv), e01 = elu1(a.b + bv), e10 = elu1(d.a + bv), e11 = elu1(d.b + bv);
-      o.a = ly0 * (0.75f * e00 + 0.25f * e01) + ly1 * (0.75f * e10 + 0.25f * e11);
-      o.b = ly0 * (0.25f * e00 + 0.75f * e01) + ly1 * (0.25f * e10 + 0.75f * e11);
+      o.a = lerp2_aten(e00, e01, e10, e11, 0.75f, 0.25f, ly0, ly1);
+      o.b = lerp2_aten(e00, e01, e10, e11, 0.25f, 0.75f, ly0, ly1);
     } else {
       float v[2];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         int x0, x1; float lx0, lx1;
         up2_tap(reflect1(ox - 1 + k, W), w, x0, x1, lx0, lx1);
-        v[k] = ly0 * (lx0 * elu1(r0[x0] + bv) + lx1 * elu1(r0[x1] + bv)) + ly1 * (lx0 * elu1(r1[x0] + bv) + lx1 * elu1(r1[x1] + bv));
+        v[k] = lerp2_aten(elu1(r0[x0] + bv), elu1(r0[x1] + bv), elu1(r1[x0] + bv), elu1(r1[x1] + bv), lx0, lx1, ly0, ly1);
       }
       o.a = v[0]; o.b = v[1];
     }

@@ -3,7 +3,8 @@
 ``Model_geometry`` / ``Model_depth`` / ``Model_flow`` inherit these so that every ``compute_*`` /
 ``fusion_*`` method of the reference (model_geometry.py:46-765, model_flow.py:94-152) can still be called
 one at a time.  The gathers / stencils run the per-operator HIP kernels (warp_flow, inverse_warp2,
-calculate_rigid_flow, SSIM, resize); the thin element-wise glue between them stays in torch device ops.
+calculate_rigid_flow, SSIM, resize); every {0,1} mask decision runs the fused stack's own decision code
+(ops.occ_masks / texture_mask / dynamic_mask), the differentiable element-wise glue stays in torch device ops.
 ``Model_geometry.forward`` does NOT go through these: it calls the fused stack (loss_stack.py)."""
 import torch
 import torch.nn.functional as F
@@ -58,14 +59,8 @@ class LossTerms:
         """Hard occlusion masks (model_geometry.py:105-132): (1 - softmax([dl, dr])) > 0.48."""
         w_bwd, w_fwd, v_bwd, v_fwd = [], [], [], []
         for s in range(self.num_scales):
-            il, it, ir = from_l[s], tgt[s], from_r[s]
-            v_fwd.append(1 - (ir == 0).prod(1, keepdim=True).type_as(ir))
-            v_bwd.append(1 - (il == 0).prod(1, keepdim=True).type_as(il))
-            dl = torch.abs(it - il).mean(1, True)
-            dr = torch.abs(it - ir).mean(1, True)
-            with torch.no_grad():
-                hard = ((1 - F.softmax(torch.cat((dl, dr), 1), 1)) > 0.48).float()
-            w_bwd.append(hard[:, 0:1]); w_fwd.append(hard[:, 1:2])
+            ob, of, vb, vf = ops.occ_masks(from_l[s], tgt[s], from_r[s])   # the fused stack's own decision code
+            w_bwd.append(ob); w_fwd.append(of); v_bwd.append(vb); v_fwd.append(vf)
         return w_bwd, w_fwd, v_bwd, v_fwd
 
     def compute_diff_weight(self, from_l, tgt, from_r):
@@ -84,9 +79,7 @@ class LossTerms:
         return d_bwd, d_fwd, w_bwd, w_fwd
 
     def compute_texture_mask(self, img_list, img_warped_list, img_list_source):
-        return [(torch.abs(img_list[s] - img_warped_list[s]).mean(1, keepdim=True)
-                 < torch.abs(img_list[s] - img_list_source[s]).mean(1, keepdim=True)).float()
-                for s in range(self.num_scales)]
+        return [ops.texture_mask(img_list[s], img_warped_list[s], img_list_source[s]) for s in range(self.num_scales)]
 
     def compute_dynamic_mask(self, intrinsics, depth, pose, flow):
         """(model_geometry.py:685-713) -> flow_diffs, dynamic masks, scores."""
@@ -96,13 +89,9 @@ class LossTerms:
             down = h0 / depth[s].size(2)
             k_s = torch.cat((intrinsics[:, 0:2] / down, intrinsics[:, 2:]), dim=1)
             rigid = calculate_rigid_flow(depth[s], pose, k_s)
-            bound = self.flow_consist_alpha * (torch.pow(self.get_flow_norm(flow[s]), 2)
-                                               + torch.pow(self.get_flow_norm(rigid), 2)) + self.flow_consist_beta
-            diff = torch.abs(rigid - flow[s])
-            diffs.append(diff)
-            with torch.no_grad():
-                masks.append((torch.pow(self.get_flow_norm(diff), 2) < bound).float())
-                scores.append(1.0 / (1e-4 + self.get_flow_norm(diff)))
+            diffs.append(torch.abs(rigid - flow[s]))
+            m, sc = ops.dynamic_mask(flow[s], rigid, self.flow_consist_alpha, self.flow_consist_beta)
+            masks.append(m); scores.append(sc)
         return diffs, masks, scores
 
     def get_rigid_mask(self, dist_map):

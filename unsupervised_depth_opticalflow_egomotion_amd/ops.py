@@ -256,6 +256,44 @@ def resize(img, out_hw, mode):
     return out
 
 
+# --------------------------------------------------------------------------- mask decisions (no grad)
+def occ_masks(from_l, tgt, from_r):
+    """compute_occ_weight's decisions (model_geometry.py:105-132) -> occ_bwd, occ_fwd, valid_bwd, valid_fwd [B,1,H,W]."""
+    lib = get_lib()
+    il, it, ir = (f32c(t.detach()) for t in (from_l, tgt, from_r))
+    B, C, H, W = it.shape
+    if C != 3 or il.shape != it.shape or ir.shape != it.shape:
+        raise ValueError("occ_masks expects three [B,3,H,W] tensors")
+    outs = [torch.empty(B, 1, H, W, device=it.device) for _ in range(4)]
+    check(lib.dfe_occ_masks(ptr(il), ptr(it), ptr(ir), *[ptr(o) for o in outs], B, H, W, stream_ptr()), "dfe_occ_masks")
+    return outs
+
+
+def texture_mask(img, warped, source):
+    """compute_texture_mask's decision (model_geometry.py:134-140) -> [B,1,H,W] in {0,1}."""
+    lib = get_lib()
+    a, b, c = (f32c(t.detach()) for t in (img, warped, source))
+    B, C, H, W = a.shape
+    if C != 3 or b.shape != a.shape or c.shape != a.shape:
+        raise ValueError("texture_mask expects three [B,3,H,W] tensors")
+    out = torch.empty(B, 1, H, W, device=a.device)
+    check(lib.dfe_texture_mask(ptr(a), ptr(b), ptr(c), ptr(out), B, H, W, stream_ptr()), "dfe_texture_mask")
+    return out
+
+
+def dynamic_mask(flow, rigid, alpha, beta):
+    """compute_dynamic_mask's decision and score (model_geometry.py:699-711) -> mask, score [B,1,H,W]."""
+    lib = get_lib()
+    f, r = f32c(flow.detach()), f32c(rigid.detach())
+    B, C, H, W = f.shape
+    if C != 2 or r.shape != f.shape:
+        raise ValueError("dynamic_mask expects two [B,2,H,W] tensors")
+    mask, score = torch.empty(B, 1, H, W, device=f.device), torch.empty(B, 1, H, W, device=f.device)
+    check(lib.dfe_dynamic_mask(ptr(f), ptr(r), ptr(mask), ptr(score), float(alpha), float(beta), B, H, W, stream_ptr()),
+          "dfe_dynamic_mask")
+    return mask, score
+
+
 # --------------------------------------------------------------------------- depth-decoder glue
 class EluPadFn(torch.autograd.Function):
     """reflect_pad1(elu(x + bias)) (elu, bias optional): the input of a Conv3x3 whose producer is a ConvBlock

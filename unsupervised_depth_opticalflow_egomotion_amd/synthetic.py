@@ -108,6 +108,47 @@ def _bilinear_np(img: np.ndarray, x: np.ndarray, y: np.ndarray) -> np.ndarray:
             + img[:, y1, x0] * (1 - fx) * fy + img[:, y1, x1] * fx * fy)
 
 
+def robust_pose(pose: np.ndarray, max_steps: int = 400) -> np.ndarray:
+    """Nudge every rotation angle (last three entries of each 6-vector) by a few float32 ulps until the exact
+    values of cos and sin are at most 0.3 ulp from their nearest float32.
+
+    The reference evaluates ``torch.cos/sin`` through MKL VML (HA mode, <= 0.6 ulp); the kernels round a double
+    evaluation (<= 0.5 ulp).  Two implementations with those error bounds must both return the nearest float
+    when the exact value is less than 0.4 ulp from it, so for poses treated this way the rotation matrices -- and
+    with them every projected coordinate and every mask fed by it -- are decided on identical bits.  This is
+    test-input conditioning in the sense of SURVEY.md A.5 (decision margins), not a change of the model."""
+    out = np.array(pose, dtype=np.float32, copy=True)
+    flat = out.reshape(-1, 6)
+
+    def safe(x32):
+        for fn in (np.cos, np.sin):
+            v = fn(np.float64(x32))
+            r = np.float32(v)
+            ulp = np.float64(np.spacing(np.abs(r))) if r != 0 else np.float64(np.finfo(np.float32).tiny)
+            if abs(v - np.float64(r)) / ulp >= 0.3:
+                return False
+        return True
+
+    for row in flat:
+        for k in (3, 4, 5):
+            x0 = np.float64(row[k])
+            # cos moves by |sin x| dx: step so that it advances ~0.07 ulp of cos per unit (never less than 1 ulp of
+            # x; below 1e-4 rad cos is 1 - O(1e-9) and safe as it stands).  Triangular multiples of the step break
+            # the aliasing of "k ulps of x = almost an integer number of ulps of sin x".
+            step = np.float64(np.spacing(np.abs(np.float32(x0)))) if x0 != 0 else 1e-12
+            if abs(x0) >= 1e-4:
+                step = max(step, 0.07 * np.float64(np.spacing(np.float32(np.abs(np.cos(x0))))) / abs(np.sin(x0)))
+            x = np.float32(x0)
+            for i in range(max_steps):
+                x = np.float32(x0 + (i * (i + 1) // 2) * step)
+                if safe(x):
+                    break
+            else:
+                raise RuntimeError("robust_pose: no safe angle near %r" % float(x0))
+            row[k] = x
+    return out
+
+
 @dataclass
 class LossStackInputs:
     """Everything the loss stack consumes for one batch (numpy, float32).
@@ -148,6 +189,7 @@ def make_loss_stack_inputs(batch: int, h: int, w: int, num_scales: int = 3, seed
         disps.append(lst)
     pose = (pose_sigma * rng.standard_normal((batch, 2, 6))).astype(np.float32)
     pose[:, :, 3:] *= 0.25  # rotations smaller than translations
+    pose = robust_pose(pose)  # cos / sin unambiguous for every <= 0.6-ulp implementation (see robust_pose)
     flows = [[], []]
     for d in range(2):
         for s in range(num_flow_scales):
