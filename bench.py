@@ -42,6 +42,33 @@ def parse():
     return ap.parse_args()
 
 
+def launch_ranks_if_needed(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start N fresh ranks ourselves (one process
+    per GPU, the reference's multi-GPU entry is one command too: train.py:59-60,277-283) and relay their exit code.
+    Runs BEFORE anything initialises the GPU in this process (torch.cuda.device_count() does not, on this image); the
+    parent never touches the device and never execs -- it only waits for `python -m torch.distributed.run`."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            sys.stderr.write("bench.py: --gpus %d contradicts WORLD_SIZE=%s of the launcher\n" % (args.gpus, env_world))
+            sys.exit(2)
+        return
+    if args.gpus <= 1:
+        return
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and os.environ.get("DFE_BENCH_ALL_ON_DEVICE0") != "1":
+        sys.stderr.write("bench.py: --gpus %d requested but only %d HIP device(s) are visible\n" % (args.gpus, ndev))
+        sys.exit(3)
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
 def init_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -136,8 +163,6 @@ class TrainStepWorkload:
         self.cfg = make_cfg(num_scales=args.scales, img_hw=(args.height, args.width), mode=self.mode)
         torch.manual_seed(1234)           # identical initial weights on every rank
         self.model = get_model(self.mode)(self.cfg).to(dev)
-        if self.mode == "geom" and os.environ.get("DFE_CHANNELS_LAST", "0") == "1":
-            self.model.use_channels_last(True)
         self.model.train()
         self.model = ddp.wrap(self.model, dev)
         params = [p for p in self.model.parameters() if p.requires_grad]
@@ -153,7 +178,6 @@ class TrainStepWorkload:
     def cpu_step_fn(self, threads):
         """CPU baseline: the same networks on the host + the oracle's loss stack + Adam."""
         from oracle import loss_stack_oracle as O
-        from unsupervised_depth_opticalflow_egomotion_amd import ddp
         from unsupervised_depth_opticalflow_egomotion_amd.models import get_model
         from unsupervised_depth_opticalflow_egomotion_amd.networks import pwc_tf
         from unsupervised_depth_opticalflow_egomotion_amd.train_step import total_loss
@@ -174,7 +198,6 @@ class TrainStepWorkload:
             pw.corr = pw.corr_naive
             model.pwc_model = pw
         model.train()
-        ddp.freeze_unused(model)
         opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=cfg.lr)
         oracle = O.GeomLossOracle(num_scales=cfg.num_scales)
         images, k_ms, ki_ms = [torch.from_numpy(a) for a in self.np_inputs]
@@ -257,6 +280,7 @@ def cpu_baseline(wl, args, unit_pairs):
 
 def main():
     args = parse()
+    launch_ranks_if_needed(args)
     torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
     world, rank, local = init_dist(args)
     dev = torch.device("cuda", local)

@@ -52,7 +52,8 @@ int dfe_pose_vec2mat_bwd(const float* vec, const float* gT34, const float* gE, f
 
 /* ---- warp_flow(x, flow, use_mask)  net_utils.py:16-54 --------------------------------------
  * x [B,C,H,W], flow [B,2,H,W] -> out [B,C,H,W].  Backward: gflow [B,2,H,W] (NULL to skip),
- * gx [B,C,H,W] scatter-added with atomics, must be zero-initialised by the caller (NULL to skip). */
+ * gx [B,C,H,W] scatter-added with float atomics, must be zero-initialised by the caller (NULL to skip);
+ * gflow is written once per pixel from fixed-order partial sums (bitwise reproducible). */
 int dfe_warp_flow_fwd(const float* x, const float* flow, float* out, int B, int C, int H, int W, int use_mask,
                       int align_corners, void* stream);
 int dfe_warp_flow_bwd(const float* x, const float* flow, const float* gout, float* gflow, float* gx, int B, int C,

@@ -184,6 +184,90 @@ def test_two_process_gloo_matches_single_process(tmp_path):
     np.testing.assert_allclose(g2.numpy(), g1.numpy(), rtol=2e-5, atol=1e-7)
 
 
+class _RealDepthNets(torch.nn.Module):
+    """The product's own Depth_Model (ResNet-18 encoder incl. the never-used fc, grouped BatchNorm, fused-decoder
+    modules on their host path) under a ``depth_net.`` prefix like Model_depth, plus a learnable pose."""
+
+    def __init__(self):
+        super().__init__()
+        from unsupervised_depth_opticalflow_egomotion_amd.networks import Depth_Model
+        self.depth_net = Depth_Model(3)
+        self.pose = torch.nn.Parameter(0.01 * torch.randn(2, 6))
+
+    def forward(self, il, it, ir):
+        dl, dt, dr = self.depth_net.forward_frames([il, it, ir])
+        return dl, dt, dr, self.pose.unsqueeze(0).expand(il.shape[0], 2, 6)
+
+
+def _real_loss(model, batch):
+    from oracle import loss_stack_oracle as O
+    from unsupervised_depth_opticalflow_egomotion_amd.train_step import total_loss, make_cfg
+    il, it, ir, K = batch
+    dl, dt, dr, pose = model(il, it, ir)
+    lp, _ = O.GeomLossOracle(3).depth_losses(il, it, ir, dl, dt, dr, pose, K)
+    return total_loss(lp, make_cfg())
+
+
+def _real_batch(n):
+    from unsupervised_depth_opticalflow_egomotion_amd import synthetic
+    inp = synthetic.make_loss_stack_inputs(n, 64, 192, 3, seed=654)
+    return [torch.from_numpy(a) for a in inp.imgs] + [torch.from_numpy(inp.K)]
+
+
+def _real_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    from unsupervised_depth_opticalflow_egomotion_amd import ddp
+    torch.set_num_threads(2)
+    ddp.init_process_group("gloo")
+    torch.manual_seed(0)
+    net = _RealDepthNets()
+    net.eval()                        # BatchNorm on running statistics: sharding-invariant, so gradients can be compared
+    model = ddp.wrap(net)
+    assert type(model).__name__ == "DistributedDataParallel"
+    full = _real_batch(2)
+    idx = ddp.shard_indices(2, world, rank)
+    _real_loss(model, [t[idx] for t in full]).backward()
+    named = dict(net.named_parameters())
+    fc = [n for n in named if ".fc." in n]
+    assert len(fc) == 2 and all(named[n].grad is None and named[n].requires_grad for n in fc)   # ignored, not frozen
+    grads = torch.cat([p.grad.reshape(-1) for n, p in named.items() if n not in fc])
+    # one train-mode step under DDP as well (per-replica grouped BatchNorm statistics, buffers broadcast)
+    net.train()
+    net.zero_grad()
+    _real_loss(model, [t[idx] for t in full]).backward()
+    assert all(torch.isfinite(p.grad).all() for n, p in named.items() if n not in fc)
+    if rank == 0:
+        torch.save(grads, out)
+    torch.distributed.destroy_process_group()
+
+
+def test_two_process_gloo_real_depth_nets(tmp_path):
+    """world_size 2 over gloo with the PRODUCT's networks (not a stand-in): DDP reproduces the single-process gradient,
+    and the never-used ``encoder.fc`` parameters are excluded from the reducer while staying in the optimizer's
+    parameter list (reference optimizer-state compatibility, train.py:85-87)."""
+    import torch.multiprocessing as mp
+    from unsupervised_depth_opticalflow_egomotion_amd import ddp
+    out = str(tmp_path / "g.pt")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_real_worker, args=(2, port, out), nprocs=2, join=True)
+    g2 = torch.load(out)
+    torch.manual_seed(0)
+    net = _RealDepthNets()
+    net.eval()
+    _real_loss(net, _real_batch(2)).backward()
+    fc = set(ddp.unused_parameter_names(net))
+    assert fc == {"depth_net.encoder.encoder.fc.weight", "depth_net.encoder.encoder.fc.bias"}
+    g1 = torch.cat([p.grad.reshape(-1) for n, p in net.named_parameters() if n not in fc])
+    scale = float(g1.abs().max())
+    assert float((g2 - g1).abs().max()) <= 2e-5 * scale + 1e-7
+    # optimizer parameter group = every parameter, in order, like the reference's Adam (fc included)
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=1e-4)
+    assert len(opt.param_groups[0]["params"]) == len(list(net.parameters()))
+    ref_like = torch.optim.Adam(list(net.parameters()), lr=1e-4).state_dict()
+    opt.load_state_dict(ref_like)     # a reference-layout optimizer state loads (same group size and indexing)
+
+
 def test_strict_seeds_are_margin_checked():
     """The seeds the GPU parity tests demand EXACT mask equality on have no pixel inside any mask's fp32 noise floor
     (tests/_margins.py), in both align_corners modes; robust_pose makes cos / sin unambiguous."""

@@ -223,19 +223,45 @@ def test_train_cli_smoke(tmp_path):
     assert out.returncode == 0 and "iter      2 total" in out.stdout, out.stderr[-2000:]
 
 
-def test_bench_two_ranks_on_one_gpu():
+def _bench_json(out):
+    import json
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("mode", ["depth", "geom"])
+def test_bench_two_ranks_on_one_gpu(mode):
     """The N>1 path of bench.py (one process per rank, DDP, barrier + max-over-ranks timing, rank-0 JSON) run
-    functionally with 2 ranks sharing this box's single GPU over gloo (RCCL refuses two ranks on one device)."""
-    import json, subprocess, sys
+    functionally with 2 ranks sharing this box's single GPU over gloo (RCCL refuses two ranks on one device).
+    mode=geom puts the whole joint model -- in-place bias/activation epilogues, grouped BatchNorm, the fused loss stack,
+    gradient buckets as views, the never-used fc parameters excluded from the reducer -- under DistributedDataParallel."""
+    import subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DFE_BENCH_ALL_ON_DEVICE0="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29533", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--backend", "gloo", "--mode", "depth"]
-    out = subprocess.run(cmd, capture_output=True, text=True, cwd=repo, env=env, timeout=900)
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]          # exactly one JSON line, from rank 0
-    j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["config"]["global_batch"] == 8
+           "--warmup", "1", "--backend", "gloo", "--mode", mode, "--batch", "2"]
+    j = _bench_json(subprocess.run(cmd, capture_output=True, text=True, cwd=repo, env=env, timeout=900))
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["config"]["global_batch"] == 4
     assert j["value"] > 0 and "roofline" in j and "cpu_baseline" not in j   # CPU baseline only at N=1
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it starts the two ranks itself (fresh child processes, the
+    parent never touches the GPU) and prints rank 0's single JSON line with n_gpus = 2; a --gpus that contradicts the
+    launcher's WORLD_SIZE, or more GPUs than are visible, exits non-zero with a message instead of silently running on 1."""
+    import subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(repo, "bench.py"), "--steps", "2", "--warmup", "1", "--mode", "depth", "--batch", "2"]
+    clean = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    j = _bench_json(subprocess.run(base + ["--gpus", "2", "--backend", "gloo"], capture_output=True, text=True, cwd=repo,
+                                   env=dict(clean, DFE_BENCH_ALL_ON_DEVICE0="1"), timeout=900))
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2"
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run(base + ["--gpus", "2"], capture_output=True, text=True, cwd=repo, env=clean, timeout=300)
+        assert out.returncode != 0 and "HIP device" in out.stderr
+    out = subprocess.run(base + ["--gpus", "2"], capture_output=True, text=True, cwd=repo,
+                         env=dict(clean, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert out.returncode != 0 and "contradicts" in out.stderr

@@ -94,6 +94,23 @@ def test_warp_flow_oracle(shape, ac):
         gclose(xt.grad, xo.grad)
 
 
+def test_warp_flow_backward_flow_gradient_is_deterministic():
+    """grad wrt flow sums over all channels in a fixed order (per-group register sums met in LDS): bitwise equal from
+    run to run at the PWC feature-warp shapes.  (grad wrt x scatters with float atomics and is not.)"""
+    from unsupervised_depth_opticalflow_egomotion_amd.structures import warp_flow
+    r = MG.rng(99)
+    for shape in [(2, 128, 8, 26), (2, 64, 32, 104), (1, 196, 4, 13)]:
+        b, c, h, w = shape
+        x, fl = r.standard_normal(shape).astype(np.float32), (2.0 * r.standard_normal((b, 2, h, w))).astype(np.float32)
+        wgt = r.standard_normal(shape).astype(np.float32)
+        grads = []
+        for _ in range(3):
+            xt, ft = G(x, True), G(fl, True)
+            (warp_flow(xt, ft) * G(wgt)).sum().backward()
+            grads.append(ft.grad.clone())
+        assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2]), shape
+
+
 @pytest.mark.parametrize("ac", [False, True])
 def test_rigid_golden(golden_dir, ac):
     from unsupervised_depth_opticalflow_egomotion_amd.structures import (

@@ -248,51 +248,68 @@ __global__ void __launch_bounds__(64) k_warp_flow_fwd(const float* __restrict__ 
     if (c < nch) out[(static_cast<long>(b) * C + c0 + c) * HW + p] = interp(q[c], t) * keep;
 }
 
-// grad wrt flow (sum over channels: float atomics across the channel chunks when C > WF_CK; gflow is
-// zero-filled by the launcher in that case) and optionally wrt x (scatter-add; gx pre-zeroed by the caller).
-__global__ void __launch_bounds__(64) k_warp_flow_bwd(const float* __restrict__ x, const float* __restrict__ flow,
+// grad wrt flow (a sum over all channels) and optionally wrt x (scatter-add; gx pre-zeroed by the caller).
+// Block = 64 pixels x WF_GROUPS channel groups: group g walks the channel chunks g, g + WF_GROUPS, ... and keeps its
+// partial (d/dix, d/diy) sums in registers; the groups' partials meet in LDS and are added in group order, so gflow
+// is written once per pixel and is bitwise reproducible (no float atomics, no zero-fill).  Only the scatter into gx
+// (PWC feature warps) uses atomics.  grid: x = pixel blocks of 64, y = 1, z = sample.
+constexpr int WF_GROUPS = 4;
+
+__global__ void __launch_bounds__(64 * WF_GROUPS) k_warp_flow_bwd(const float* __restrict__ x, const float* __restrict__ flow,
                                                       const float* __restrict__ gout, float* __restrict__ gflow,
                                                       float* __restrict__ gx, int C, int H, int W, int use_mask, int ac) {
-  const int b = blockIdx.z, c0 = blockIdx.y * WF_CK, HW = H * W;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= HW) return;
-  const int py = p / W, px = p - py * W;
+  __shared__ float red[WF_GROUPS][2][64];
+  const int b = blockIdx.z, HW = H * W;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + lane;
+  const bool live = p < HW;
+  const int pc = live ? p : HW - 1;
+  const int py = pc / W, px = pc - py * W;
   const float* f = flow + static_cast<long>(b) * 2 * HW;
   float ix, iy;
-  flow_coords(px, py, f[p], f[HW + p], H, W, ac, ix, iy);
+  flow_coords(px, py, f[pc], f[HW + pc], H, W, ac, ix, iy);
   Tap t = make_tap(ix, iy, H, W);
-  float keep = 1.0f;
-  if (use_mask) keep = (tap_cover(t) < 0.9999f) ? 0.0f : 1.0f;
-  const int nch = min(WF_CK, C - c0);
-  float g[WF_CK];
+  float keep = live ? 1.0f : 0.0f;
+  if (use_mask && tap_cover(t) < 0.9999f) keep = 0.0f;
+  float gix = 0.0f, giy = 0.0f;
+  for (int c0 = grp * WF_CK; c0 < C; c0 += WF_GROUPS * WF_CK) {
+    const int nch = min(WF_CK, C - c0);
+    float g[WF_CK];
 #pragma unroll
-  for (int c = 0; c < WF_CK; ++c) g[c] = (c < nch) ? gout[(static_cast<long>(b) * C + c0 + c) * HW + p] * keep : 0.0f;
-  if (gflow) {
-    Corners q[WF_CK];
+    for (int c = 0; c < WF_CK; ++c) g[c] = (c < nch) ? gout[(static_cast<long>(b) * C + c0 + c) * HW + pc] * keep : 0.0f;
+    if (gflow) {
+      Corners q[WF_CK];
 #pragma unroll
-    for (int c = 0; c < WF_CK; ++c) q[c] = load_corners(x + (static_cast<long>(b) * C + c0 + (c < nch ? c : 0)) * HW, t, W, H);
-    float gix = 0.0f, giy = 0.0f;
+      for (int c = 0; c < WF_CK; ++c) q[c] = load_corners(x + (static_cast<long>(b) * C + c0 + (c < nch ? c : 0)) * HW, t, W, H);
 #pragma unroll
-    for (int c = 0; c < WF_CK; ++c) {
-      float dx, dy;
-      interp_grad(q[c], t, dx, dy);
-      gix += g[c] * dx; giy += g[c] * dy;
-    }
-    float* gf = gflow + static_cast<long>(b) * 2 * HW;
-    const float vx = gix * flow_coord_scale(W, ac), vy = giy * flow_coord_scale(H, ac);
-    if (gridDim.y == 1) { gf[p] = vx; gf[HW + p] = vy; }
-    else { atomicAdd(gf + p, vx); atomicAdd(gf + HW + p, vy); }
-  }
-  if (gx) {
-#pragma unroll
-    for (int c = 0; c < WF_CK; ++c) {
-      if (c < nch && g[c] != 0.0f) {
-        float* base = gx + (static_cast<long>(b) * C + c0 + c) * HW + static_cast<long>(t.y0) * W + t.x0;
-        if (t.in_nw) atomicAdd(base, g[c] * t.nw);
-        if (t.in_ne) atomicAdd(base + 1, g[c] * t.ne);
-        if (t.in_sw) atomicAdd(base + W, g[c] * t.sw);
-        if (t.in_se) atomicAdd(base + W + 1, g[c] * t.se);
+      for (int c = 0; c < WF_CK; ++c) {
+        float dx, dy;
+        interp_grad(q[c], t, dx, dy);
+        gix += g[c] * dx; giy += g[c] * dy;
       }
+    }
+    if (gx) {
+#pragma unroll
+      for (int c = 0; c < WF_CK; ++c) {
+        if (c < nch && g[c] != 0.0f) {
+          float* base = gx + (static_cast<long>(b) * C + c0 + c) * HW + static_cast<long>(t.y0) * W + t.x0;
+          if (t.in_nw) atomicAdd(base, g[c] * t.nw);
+          if (t.in_ne) atomicAdd(base + 1, g[c] * t.ne);
+          if (t.in_sw) atomicAdd(base + W, g[c] * t.sw);
+          if (t.in_se) atomicAdd(base + W + 1, g[c] * t.se);
+        }
+      }
+    }
+  }
+  if (gflow) {
+    red[grp][0][lane] = gix; red[grp][1][lane] = giy;
+    __syncthreads();
+    if (grp == 0 && live) {
+      float sx = red[0][0][lane], sy = red[0][1][lane];
+#pragma unroll
+      for (int k = 1; k < WF_GROUPS; ++k) { sx += red[k][0][lane]; sy += red[k][1][lane]; }
+      float* gf = gflow + static_cast<long>(b) * 2 * HW;
+      gf[p] = sx * flow_coord_scale(W, ac); gf[HW + p] = sy * flow_coord_scale(H, ac);
     }
   }
 }
@@ -763,10 +780,9 @@ int dfe_warp_flow_bwd(const float* x, const float* flow, const float* gout, floa
   DFE_REQUIRE(x && flow && gout && (gflow || gx), DFE_ERR_NULL);
   DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
   DFE_REQUIRE(B <= 65535 && (C + WF_CK - 1) / WF_CK <= 65535, DFE_ERR_DIMS);
-  dim3 g(static_cast<unsigned>((static_cast<long>(H) * W + 63) / 64), (C + WF_CK - 1) / WF_CK, B);
+  dim3 g(static_cast<unsigned>((static_cast<long>(H) * W + 63) / 64), 1, B);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (gflow && g.y > 1 && hipMemsetAsync(gflow, 0, static_cast<size_t>(B) * 2 * H * W * sizeof(float), st) != hipSuccess) return DFE_ERR_LAUNCH;
-  k_warp_flow_bwd<<<g, 64, 0, st>>>(x, flow, gout, gflow, gx, C, H, W, use_mask, align_corners);
+  k_warp_flow_bwd<<<g, 64 * WF_GROUPS, 0, st>>>(x, flow, gout, gflow, gx, C, H, W, use_mask, align_corners);
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }

@@ -205,6 +205,8 @@ def geom_loss_stack(img_l, img, img_r, disp_l_list, disp_list, disp_r_list, pose
     if not return_masks:
         return pack
     B, _, H, W = img.shape
+    if return_masks == "lazy":       # (workspace, dims): decode single masks on demand with decode_mask()
+        return pack, (ws, B, H, W, S)
     return pack, decode_masks(ws, B, H, W, S)
 
 
@@ -235,6 +237,19 @@ def flow_loss_stack(img_l, img, img_r, flows_bwd, flows_fwd, num_scales=3, align
     losses, _ws = GeomLossFn.apply(2, S, 0.0, 0.0, int(ac), *tensors)
     return {"loss_flow_pixel": losses[2], "loss_flow_ssim": losses[3], "loss_flow_smooth": losses[4],
             "loss_flow_consis": losses[5]}
+
+
+def decode_mask(handle, name, scale=0):
+    """One float {0,1} mask [B,1,Hs,Ws] out of the 1-byte mask pack kept in the forward workspace
+    (``handle`` = the second return value of ``geom_loss_stack(..., return_masks="lazy")``)."""
+    ws, B, H, W, S = handle
+    lib = get_lib()
+    a = GeomArgs()
+    a.B, a.H, a.W, a.num_scales, a.mode = B, H, W, S, 0
+    off = lib.dfe_geom_maskpack_offset_bytes(ctypes.byref(a), scale)
+    hs, ws_ = _scale_hw(H, W, scale)
+    m = ws.view(torch.uint8)[off: off + B * hs * ws_].view(B, 1, hs, ws_)
+    return ((m & MASK_BITS[name]) != 0).float()
 
 
 def decode_masks(ws, B, H, W, S):

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .loss_stack import geom_loss_stack, depth_loss_stack, flow_loss_stack
+from .loss_stack import geom_loss_stack, depth_loss_stack, flow_loss_stack, decode_mask
 from .loss_terms import LossTerms
 from .networks import Depth_Model, PoseCNN, FeaturePyramid, PWC_tf
 
@@ -99,15 +99,6 @@ class Model_geometry(LossTerms, nn.Module):
         self.num = getattr(cfg, "geometric_num", 6000)
         self.beta = getattr(cfg, "pose_beta", 1)
 
-    def use_channels_last(self, flag=True):
-        """Run DepthNet / PoseNet in NHWC (MIOpen's igemm kernels are NHWC; avoids their transposes).  The loss
-        stack and the PWC warp/correlation kernels stay NCHW; C=1 disparities are layout-neutral."""
-        self._channels_last = bool(flag)
-        fmt = torch.channels_last if flag else torch.contiguous_format
-        self.depth_net.to(memory_format=fmt)
-        self.pose_net.to(memory_format=fmt)
-        return self
-
     # ---- inference API (model_geometry.py:282-302)
     def infer_depth(self, img):
         return self.disp2depth(self.depth_net(img)[0])
@@ -122,13 +113,8 @@ class Model_geometry(LossTerms, nn.Module):
     def run_networks(self, img_l, img, img_r):
         """model_geometry.py:781-795.  depth_net is called once per frame (BatchNorm statistics per call)."""
         h, w = img.shape[2], img.shape[3]
-        if getattr(self, "_channels_last", False):
-            cl = torch.channels_last
-            disp_l, disp_t, disp_r = (self.depth_net(x.contiguous(memory_format=cl)) for x in (img_l, img, img_r))
-            pose = self.pose_net(torch.cat([img_l, img, img_r], 1).contiguous(memory_format=cl))
-        else:
-            disp_l, disp_t, disp_r = _depth_frames(self.depth_net, img_l, img, img_r)
-            pose = self.pose_net(torch.cat([img_l, img, img_r], 1))
+        disp_l, disp_t, disp_r = _depth_frames(self.depth_net, img_l, img, img_r)
+        pose = self.pose_net(torch.cat([img_l, img, img_r], 1))
         flows_bwd, flows_fwd = _flow_branches(self.fpyramid, self.pwc_model, img_l, img, img_r)
         return disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd
 
@@ -146,12 +132,19 @@ class Model_geometry(LossTerms, nn.Module):
         active, masks = geom_loss_stack(img_l, img, img_r, disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd,
                                         K.contiguous(), K_inv.contiguous(), num_scales=S,
                                         flow_consist_alpha=self.flow_consist_alpha,
-                                        flow_consist_beta=self.flow_consist_beta, return_masks=True)
+                                        flow_consist_beta=self.flow_consist_beta, return_masks="lazy")
         dev = img.device
         loss_pack = {k: (active[k] if k in active else _zeros2(dev)) for k in LOSS_ORDER_GEOM}
 
-        def u8(t):
-            return lambda: 255 * t.detach().cpu().numpy().astype(np.uint8)
+        def u8(*names):
+            """sample 0, scale 0 of the product of the named masks, decoded from the 1-byte mask pack only when the
+            entry is read (the reference materialises all of them, with a device sync, every iteration)."""
+            def run():
+                t = decode_mask(masks, names[0])
+                for n in names[1:]:
+                    t = t * decode_mask(masks, n)
+                return 255 * t[0].cpu().numpy().astype(np.uint8)
+            return run
 
         def epi_masks(which):
             def run():
@@ -167,15 +160,14 @@ class Model_geometry(LossTerms, nn.Module):
                 v = inverse_warp2(img_r, disp_t[0].detach(), disp_r[0].detach(), pose[:, 1].detach().contiguous(), K)[1]
             return 255 * v[0].cpu().numpy().astype(np.uint8)
 
-        fwd_mask = masks["valid_fwd"][0] * masks["occ_fwd"][0] * masks["dyna_fwd"][0]
         mask_pack = LazyPack({
-            "occ_fwd_mask": u8(masks["occ_fwd"][0][0]),
+            "occ_fwd_mask": u8("occ_fwd"),
             "rigid_fwd_mask": epi_masks(0),
             "inlier_fwd_mask": epi_masks(1),
-            "dyna_fwd_mask": u8(masks["dyna_fwd"][0][0]),
+            "dyna_fwd_mask": u8("dyna_fwd"),
             "valid_fwd_mask": valid_to_r,
-            "fwd_mask": u8(fwd_mask[0]),
-            "texture_mask_fwd": u8(masks["texture_fwd"][0][0]),
+            "fwd_mask": u8("valid_fwd", "occ_fwd", "dyna_fwd"),
+            "texture_mask_fwd": u8("texture_fwd"),
             "pred_depth_img": lambda: disp_t[0][0],
             "pred_flow_img": lambda: flows_fwd[0][0].detach().cpu().numpy().transpose([1, 2, 0]),
             "origin_middle_image": lambda: img[0].cpu().detach().numpy(),
