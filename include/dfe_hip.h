@@ -94,6 +94,14 @@ int dfe_texture_mask(const float* img, const float* warped, const float* source,
 int dfe_dynamic_mask(const float* flow, const float* rigid, float* mask, float* score, float alpha, float beta, int B,
                      int H, int W, void* stream);
 
+/* ---- self-test of the short correctly rounded fp32 sequences (csrc/loss_stack_exact.h) ------------------------
+ * The mask-deciding expressions of the reference use IEEE division and square root (torch CPU); the pointwise kernels
+ * evaluate them with 3 / 5-instruction sequences that must return the SAME bits.  This entry point checks that
+ * exhaustively on the device: counts (4 device uint64) receive the numbers of mismatches of
+ *   [0] RN(1/z) over every fp32 z whose reciprocal is normal, [1] sqrt over every non-negative finite fp32,
+ *   [2] x/z over `npairs` pseudo-random pairs, [3] the same with all-ones divisor significands.  All must be 0. */
+int dfe_exact_math_selftest(unsigned long long* counts, unsigned long long npairs, void* stream);
+
 /* ---- SSIM(x, y)  pytorch_ssim/ssim.py:4-19 -------------------------------------------------- */
 int dfe_ssim_fwd(const float* x, const float* y, float* out, int B, int C, int H, int W, void* stream);
 int dfe_ssim_bwd(const float* x, const float* y, const float* gout, float* gx, float* gy, int B, int C, int H, int W,

@@ -94,6 +94,17 @@ def test_warp_flow_oracle(shape, ac):
         gclose(xt.grad, xo.grad)
 
 
+def test_exact_math_sequences_exhaustive():
+    """The 3 / 5-instruction reciprocal, division and square-root sequences the mask-deciding expressions use return the
+    IEEE results bit for bit: every fp32 reciprocal and square root, 2^32 random quotients + 2^32 with all-ones divisors."""
+    from unsupervised_depth_opticalflow_egomotion_amd import _lib
+    lib = _lib.get_lib()
+    counts = torch.full((4,), -1, dtype=torch.int64, device=dev())
+    _lib.check(lib.dfe_exact_math_selftest(_lib.ptr(counts), 1 << 32, _lib.stream_ptr()), "dfe_exact_math_selftest")
+    torch.cuda.synchronize()
+    assert counts.tolist() == [0, 0, 0, 0], counts.tolist()
+
+
 def test_warp_flow_backward_flow_gradient_is_deterministic():
     """grad wrt flow sums over all channels in a fixed order (per-group register sums met in LDS): bitwise equal from
     run to run at the PWC feature-warp shapes.  (grad wrt x scatters with float atomics and is not.)"""

@@ -57,6 +57,7 @@ _SIGNATURES = {
     "dfe_occ_masks": [_P] * 7 + [_I, _I, _I, _P],
     "dfe_texture_mask": [_P, _P, _P, _P, _I, _I, _I, _P],
     "dfe_dynamic_mask": [_P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _I, _I, _I, _P],
+    "dfe_exact_math_selftest": [_P, ctypes.c_ulonglong, _P],
     "dfe_ssim_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_ssim_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_corr_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -129,7 +130,7 @@ def ptr(t, strided=False):
     if not t.is_cuda:
         raise DfeError("the HIP loss stack only accepts tensors on a HIP device (got %s); there is no CPU "
                        "fallback in the product path" % t.device)
-    if t.dtype != torch.float32 and t.dtype != torch.uint8 and t.dtype != torch.int32:
+    if t.dtype not in (torch.float32, torch.uint8, torch.int32, torch.int64):
         raise DfeError("unsupported dtype %s" % t.dtype)
     if not strided and not t.is_contiguous():
         raise DfeError("tensor must be contiguous")

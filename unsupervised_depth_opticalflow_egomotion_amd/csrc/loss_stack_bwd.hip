@@ -11,7 +11,7 @@
 //                           ratios >= 1/4, k_geom_disp_smooth_bwd2_coarse = one wave per pixel below that)
 //   k_geom_pose_finalize    fixed-order reduction + closed-form 3x3 chains -> grad_pose
 // No float atomics anywhere: gradients are bitwise reproducible run to run.
-#include "loss_stack.h"
+#include "loss_stack_exact.h"
 
 namespace dfe {
 
@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(64) k_geom_ssim_bwd_roll(GeomDev D, GeomBwd G)
 }
 
 // ---------------------------------------------------------------------- pointwise backward
-__global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomBwd G) {
+__global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomT T, GeomBwd G) {
   __shared__ float red[PB_COUNT * 4 * (GS_BLOCK / 64)];
   const unsigned nblk_total = D.blk_start[D.S];
   const unsigned blk = xcd_swizzle(blockIdx.x, nblk_total);
@@ -150,7 +150,10 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomBwd 
 #pragma unroll
   for (int i = 0; i < PB_COUNT; ++i) acc[i] = 0.0f;
   if (p < N) {
-    const int py = p / W, px = p - py * W;
+    unsigned upx, upy;
+    split_pixel(static_cast<unsigned>(p), W, T.rW[s], upx, upy);
+    const int px = static_cast<int>(upx), py = static_cast<int>(upy);
+    const Divisor dw = T.dw[s], dh = T.dh[s];
     const long o3 = static_cast<long>(b) * 3 * N + p, o2 = static_cast<long>(b) * 2 * N + p, o1 = static_cast<long>(b) * N + p;
     const float* it = D.pyr[1][s];
     const float im[3] = {it[o3], it[o3 + N], it[o3 + 2 * N]};
@@ -174,7 +177,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomBwd 
       // ---- flow warp: L1 (rigid + 2x dynamic masks) and SSIM gradients wrt the warped image
       {
         float ix, iy;
-        flow_coords(px, py, fu[d], fv[d], H, W, D.ac, ix, iy);
+        flow_coords_d(px, py, fu[d], fv[d], H, W, D.ac, dw, dh, ix, iy);
         Tap t = make_tap(ix, iy, H, W);
         const float keep = (tap_cover(t) < 0.9999f) ? 0.0f : 1.0f;
         if (keep != 0.0f) {
@@ -197,11 +200,11 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomBwd 
       }
       // ---- rigid branch
       const Camera& cam = D.cams[(b * 2 + d) * D.S + s];
-      Proj pr = project(cam, px, py, dsp);
+      Proj pr = project_fast(cam, px, py, dsp);
       float gU = 0.0f, gV = 0.0f;
       if (m_tex != 0.0f) {
         float xn, yn; bool lx, ly;
-        rigid_grid(pr, H, W, xn, yn, lx, ly);
+        rigid_grid_d(pr, dw, dh, xn, yn, lx, ly);
         Tap t = make_tap(unnormalize(xn, W, D.ac), unnormalize(yn, H, D.ac), H, W);
         const float* ar = D.area[d][s] + static_cast<long>(b) * 3 * N;
         const float gc = g_dp * cf[d * CF_PER_DIR + CF_DEPTH];
@@ -795,6 +798,8 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   float* ws = a->workspace;
   GeomDev D;
   geom_dev(a, L, &D);
+  GeomT T{};
+  tile_dev(L, &T);
   GeomBwd G;
   G.gl = a->grad_losses; G.coef = ws + L.o_coef; G.gup = ws + L.o_gup; G.bpart = ws + L.o_bpart;
   for (int s = 0; s < DFE_MAX_SCALES; ++s) {
@@ -827,7 +832,7 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     k_geom_ssim_bwd_roll<<<dim3(L.rollb_start[L.S], L.B * 2), 64, 0, st>>>(D, G);
     DFE_LAUNCH_CHECK();
     DFE_MARK();
-    k_geom_point_bwd<<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, G);
+    k_geom_point_bwd<<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, T, G);
     DFE_LAUNCH_CHECK();
     DFE_MARK();
     k_geom_flow_smooth_bwd<<<dim3(L.rollb_start[L.S], L.B), 64, 0, st>>>(D, G);

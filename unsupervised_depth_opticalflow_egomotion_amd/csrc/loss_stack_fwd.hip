@@ -12,8 +12,9 @@
 //   k_geom_reduce_fwd + k_geom_assemble_fwd   fixed-order reduction of block partials -> loss vectors + normalisers
 // All (sample, scale) images are batched into each launch: scale 2 alone (13 k px) cannot fill
 // 256 CUs.  Partials are reduced in a fixed order (no float atomics): bitwise reproducible.
-#include "loss_stack.h"
+#include "loss_stack_exact.h"
 #include <cstdint>
+#include <cstdlib>
 
 namespace dfe {
 
@@ -73,6 +74,14 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
   L->o_bpart = o; o = align4(o + B * nblk_total * PB_COUNT);
   L->total = o;
   return DFE_OK;
+}
+
+void tile_dev(const GeomLayout& L, GeomT* T) {
+  for (int s = 0; s < L.S; ++s) {
+    T->rW[s] = 1.0f / static_cast<float>(L.W[s]);
+    T->dw[s] = make_divisor(static_cast<float>(L.W[s] > 1 ? L.W[s] - 1 : 1));
+    T->dh[s] = make_divisor(static_cast<float>(L.H[s] > 1 ? L.H[s] - 1 : 1));
+  }
 }
 
 void geom_dev(const dfe_geom_args* a, const GeomLayout& L, GeomDev* D) {
@@ -235,11 +244,14 @@ __global__ void __launch_bounds__(64) k_geom_area_coarse(PyrJobs jobs) {
 }
 
 // ---------------------------------------------------------------------- pointwise forward
-// Bound first by the number of memory instructions (the texture-address unit takes ~16 cycles per wave-wide load
-// whatever its width) and then by VALU issue (profiles/r01b_pmc_loss_stack.json).  Hence: one pixel per thread (2 / 4
-// pixels per thread with 8 / 16-byte streams measured slower at B = 4: too few waves), one dword-aligned 8-byte load
-// per footprint row of the gathers, exact 3-instruction divisions by launch constants, integer bounds tests and
-// 32-bit byte offsets from block-uniform bases.
+// Bound by instruction issue: ~860 VALU and 45 vector-memory instructions per pixel (24 of them the bilinear
+// gathers), texture addresser and VALU each ~55 % busy (profiles/r02_pmc_point_kernels.md).  What the measurements
+// selected: one pixel per thread in 256-thread blocks, one dword-aligned 8-byte load per footprint row, correctly
+// rounded 3/5-instruction division / square-root sequences (loss_stack_exact.h), host-side divisors, integer bounds
+// tests and 32-bit byte offsets from block-uniform bases.  Measured and rejected in round 2:
+// RGBA-texel zero-bordered source planes with wave-persistent accumulation (fewer, wider gathers: the addresser cost
+// follows bytes, VGPRs double -> 54-60 us vs 48), 32x8 LDS-staged source tiles with a +-6 px halo around the
+// tile-centre flow (hit rate too low on rough flow fields: 59 us), LDS-transposed streamed loads / stores (53 us).
 struct PointCtx {
   int b, s, H, W, ac;
   unsigned N4;
@@ -270,17 +282,16 @@ __device__ __forceinline__ void point_pixel(const PointCtx& c, int px, int py, c
     valid[d] = !(wv[d][0] == 0.0f && wv[d][1] == 0.0f && wv[d][2] == 0.0f);
     dif[d] = mean3_abs_diff(in.i0, in.i1, in.i2, wv[d][0], wv[d][1], wv[d][2]);
   }
-  float wb, wf;
-  occ_weights(dif[0], dif[1], wb, wf);
-  const bool occ[2] = {wb > 0.48f, wf > 0.48f};
+  bool occ[2];
+  occ_decide(dif[0], dif[1], occ[0], occ[1]);
   bits = 0;
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
     const Camera& cam = c.cam[d * c.cam_stride];
-    const Proj pr = project(cam, px, py, in.dsp);
+    const Proj pr = project_fast(cam, px, py, in.dsp);
     const float ru = pr.U - static_cast<float>(px), rv = pr.V - static_cast<float>(py);
     const float du = fabsf(ru - in.fu[d]), dv = fabsf(rv - in.fv[d]);
-    const bool dyna = dyna_decision(in.fu[d], in.fv[d], ru, rv, du, dv, c.alpha, c.beta);
+    const bool dyna = dyna_decide(in.fu[d], in.fv[d], ru, rv, du, dv, c.alpha, c.beta);
     float xn, yn; bool lx, ly;
     rigid_grid_d(pr, c.dw, c.dh, xn, yn, lx, ly);
     const FastTap t = make_fast_tap(unnormalize(xn, W, c.ac), unnormalize(yn, H, c.ac), H, W);
@@ -381,7 +392,7 @@ __device__ __forceinline__ void point_block_sums(float (&acc)[PT_COUNT], float* 
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, float* __restrict__ part) {
+__global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, GeomT T, float* __restrict__ part) {
   __shared__ float red[PT_COUNT * 4 * (GS_BLOCK / 64)];
   const unsigned nblk_total = D.blk_start[D.S];
   const unsigned blk = xcd_swizzle(blockIdx.x, nblk_total);
@@ -393,14 +404,15 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, float* _
 #pragma unroll
   for (int i = 0; i < PT_COUNT; ++i) acc[i] = 0.0f;
   if (p < static_cast<unsigned>(N)) {
-    const unsigned py = p / static_cast<unsigned>(W), px = p - py * W;
+    unsigned px, py;
+    split_pixel(p, W, T.rW[s], px, py);
     const unsigned p4 = p * 4u, N4 = static_cast<unsigned>(N) * 4u;
     PointCtx c;
     c.b = b; c.s = s; c.H = H; c.W = W; c.ac = D.ac; c.N4 = N4; c.alpha = D.alpha; c.beta = D.beta;
     c.srcL = D.pyr[0][s] + static_cast<long>(b) * 3 * N; c.srcR = D.pyr[2][s] + static_cast<long>(b) * 3 * N;
     c.areaL = D.area[0][s] + static_cast<long>(b) * 3 * N; c.areaR = D.area[1][s] + static_cast<long>(b) * 3 * N;
     c.cam = D.cams + (b * 2) * D.S + s; c.cam_stride = D.S; c.epi = D.epi + b * 2;
-    c.dw = make_divisor(static_cast<float>(W > 1 ? W - 1 : 1)); c.dh = make_divisor(static_cast<float>(H > 1 ? H - 1 : 1));
+    c.dw = T.dw[s]; c.dh = T.dh[s];
     const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
     const float* flb = D.flow[0][s] + static_cast<long>(b) * 2 * N;
     const float* flf = D.flow[1][s] + static_cast<long>(b) * 2 * N;
@@ -860,6 +872,8 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   float* ws = a->workspace;
   GeomDev D;
   geom_dev(a, L, &D);
+  GeomT T{};
+  tile_dev(L, &T);
   int seg = 0;
 #define DFE_MARK() do { if (ev) (void)hipEventRecord(ev[++seg], st); } while (0)
   if (ev) (void)hipEventRecord(ev[0], st);
@@ -933,7 +947,7 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     DFE_LAUNCH_CHECK();
     DFE_MARK(); DFE_MARK(); DFE_MARK();
   } else {
-    k_geom_point_fwd<<<dim3(L.blk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
+    k_geom_point_fwd<<<dim3(L.blk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, T, ws + L.o_part);
     DFE_LAUNCH_CHECK();
     DFE_MARK();
     k_geom_ssim_fwd_roll<<<dim3(L.roll_start[L.S], L.B * 2), 64, 0, st>>>(D, ws + L.o_spart);
