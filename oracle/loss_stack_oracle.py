@@ -390,6 +390,20 @@ class GeomLossOracle:
             terms.append((val / (div + 1e-12))[:, None])
         return torch.cat(terms, 1).sum(1)
 
+    def compute_consis_loss(self, predicted_depth_list, computed_depth_list, mask_list=None):
+        """|c - p| / |c + p| clamped to [0,1], masked mean (model_geometry.py:182-193; model_depth.py:154-163 is the
+        same without a mask).  Disabled in the reference's forward (:897-899) -- SURVEY.md 8(f) rank 3."""
+        terms = []
+        for s in range(self.num_scales):
+            p, c = predicted_depth_list[s], computed_depth_list[s]
+            diff = ((c - p).abs() / (c + p).abs()).clamp(0, 1)
+            if mask_list is None:
+                terms.append(diff.mean((1, 2, 3))[:, None])
+            else:
+                m = mask_list[s]
+                terms.append(((diff * m).mean((1, 2, 3)) / (m.mean((1, 2, 3)) + 1e-12))[:, None])
+        return torch.cat(terms, 1).sum(1)
+
     # a16 / a17 / a18 -------------------------------------------------------
     def compute_smooth_loss(self, img, disps):
         """First-order edge-aware disparity smoothness at full resolution (model_geometry.py:225-252)."""
@@ -553,7 +567,7 @@ class GeomLossOracle:
 
     # a21 geom ----------------------------------------------------------------
     def geom_losses(self, img_l, img, img_r, disp_l_list, disp_list, disp_r_list, pose_vectors,
-                    flows_bwd, flows_fwd, K, K_inv):
+                    flows_bwd, flows_fwd, K, K_inv, enable_depth_ssim=False, enable_depth_consis=False):
         """Everything from model_geometry.py:797 to :951 given the nets' outputs.
 
         Returns ``(loss_pack, masks)`` where ``masks`` holds the full-batch float masks the
@@ -563,8 +577,8 @@ class GeomLossOracle:
         img_list = self.generate_img_pyramid(img, S)
         img_l_list = self.generate_img_pyramid(img_l, S)
         img_r_list = self.generate_img_pyramid(img_r, S)
-        rec_l, valid_to_l, _, _ = self.reconstruction(img_l, K, disp_list, disp_l_list, pose_bwd)
-        rec_r, valid_to_r, _, _ = self.reconstruction(img_r, K, disp_list, disp_r_list, pose_fwd)
+        rec_l, valid_to_l, pd_l, cd_l = self.reconstruction(img_l, K, disp_list, disp_l_list, pose_bwd)
+        rec_r, valid_to_r, pd_r, cd_r = self.reconstruction(img_r, K, disp_list, disp_r_list, pose_fwd)
         tex_bwd = self.compute_texture_mask(img_list, rec_l, img_l_list)
         tex_fwd = self.compute_texture_mask(img_list, rec_r, img_r_list)
         warp_l = self.warp_flow_pyramid(img_l_list, flows_bwd)
@@ -591,10 +605,15 @@ class GeomLossOracle:
         lp = {}
         lp["loss_depth_pixel"] = self.compute_photometric_loss(img_list, rec_l, bwd_tex) + \
             self.compute_photometric_loss(img_list, rec_r, fwd_tex)
-        lp["loss_depth_ssim"] = torch.zeros([2]).to(dev).requires_grad_()
+        # the two terms the reference keeps commented (model_geometry.py:889-891,897-899), as written there
+        lp["loss_depth_ssim"] = (self.compute_ssim_loss(img_list, rec_l, bwd_tex) +
+                                 self.compute_ssim_loss(img_list, rec_r, fwd_tex)) if enable_depth_ssim \
+            else torch.zeros([2]).to(dev).requires_grad_()
         lp["loss_depth_smooth"] = self.compute_smooth_loss(img, disp_list) + \
             self.compute_smooth_loss(img_l, disp_l_list) + self.compute_smooth_loss(img_r, disp_r_list)
-        lp["loss_depth_consis"] = torch.zeros([2]).to(dev).requires_grad_()
+        lp["loss_depth_consis"] = (self.compute_consis_loss(pd_l, cd_l, bwd_tex) +
+                                   self.compute_consis_loss(pd_r, cd_r, fwd_tex)) if enable_depth_consis \
+            else torch.zeros([2]).to(dev).requires_grad_()
         lp["loss_flow_pixel"] = self.compute_photometric_loss(img_list, warp_l, bwd_vo_rigid) + \
             self.compute_photometric_loss(img_list, warp_r, fwd_vo_rigid) + \
             2 * self.compute_photometric_loss(img_list, warp_l, bwd_vo_dyna) + \

@@ -412,6 +412,40 @@ def gen_g8(ref, out):
         grad_summary(out, "flow_gflow_f_%d" % s, ff[s], stride=31)
 
 
+# ------------------------------------------------------------------------------------ G9 (disabled depth terms)
+G9_SHAPE, G9_SEED = (2, 64, 208), 77     # margin-checked (tests/test_hip_loss_stack.STRICT)
+
+
+def gen_g9(ref, out):
+    """The depth SSIM / depth consistency terms the reference keeps commented (model_geometry.py:889-891,897-899),
+    evaluated exactly as those lines read, by calling the reference's own methods on a bare Model_geometry."""
+    inp = synthetic.make_loss_stack_inputs(*G9_SHAPE, 3, seed=G9_SEED)
+    m = bare_geometry(ref)
+    il, it, ir = [T(a) for a in inp.imgs]
+    disps, pose, fb, ff = lists_to_t(inp, True)
+    K = T(inp.K)
+    pyr_l, pyr_t, pyr_r = (m.generate_img_pyramid(x, 3) for x in (il, it, ir))
+    rec_l, vl, pdl, cdl = m.reconstruction(il, K, disps[1], disps[0], pose[:, 0])
+    rec_r, vr, pdr, cdr = m.reconstruction(ir, K, disps[1], disps[2], pose[:, 1])
+    with torch.no_grad():
+        wl, wr = m.warp_flow_pyramid(pyr_l, fb), m.warp_flow_pyramid(pyr_r, ff)
+        occ_b, occ_f, val_b, val_f = m.compute_occ_weight(wl, pyr_t, wr)
+        tex_b, tex_f = m.compute_texture_mask(pyr_t, rec_l, pyr_l), m.compute_texture_mask(pyr_t, rec_r, pyr_r)
+        _, dyn_b, _ = m.compute_dynamic_mask(K, disps[1], pose[:, 0], fb)
+        _, dyn_f, _ = m.compute_dynamic_mask(K, disps[1], pose[:, 1], ff)
+        bwd_tex = m.fusion_mask_2item(m.fusion_mask(val_b, occ_b, dyn_b), tex_b)
+        fwd_tex = m.fusion_mask_2item(m.fusion_mask(val_f, occ_f, dyn_f), tex_f)
+    l_ssim = m.compute_ssim_loss(pyr_t, rec_l, bwd_tex) + m.compute_ssim_loss(pyr_t, rec_r, fwd_tex)
+    l_cons = m.compute_consis_loss(pdl, cdl, bwd_tex) + m.compute_consis_loss(pdr, cdr, fwd_tex)
+    (0.85 * l_ssim.mean() + 0.1 * l_cons.mean()).backward()
+    out["loss_depth_ssim"], out["loss_depth_consis"] = N(l_ssim), N(l_cons)
+    out["gpose"] = N(pose.grad)
+    for f in range(3):
+        for s in range(3):
+            out["gdisp_%d_%d" % (f, s)] = N(disps[f][s].grad) if disps[f][s].grad is not None else np.zeros(tuple(disps[f][s].shape), np.float32)
+    store_margins(out, "g9", inp, CURRENT_AC[0])
+
+
 # ------------------------------------------------------------------------------------ G7 (real nets)
 def closed_form_state(model, scale=0.02):
     """Fill every parameter/buffer with a closed-form function of (key, flat index) so that the reference
@@ -474,7 +508,7 @@ def gen_g7(ref, out):
     out["eval_flow_crop"] = N(f[0, :, 100:108, 400:408])
 
 
-GENERATORS = dict(G1=gen_g1, G2=gen_g2, G3=gen_g3, G4=gen_g4, G5=gen_g5, G6=gen_g6, G7=gen_g7, G8=gen_g8)
+GENERATORS = dict(G1=gen_g1, G2=gen_g2, G3=gen_g3, G4=gen_g4, G5=gen_g5, G6=gen_g6, G7=gen_g7, G8=gen_g8, G9=gen_g9)
 AC_INDEPENDENT = {"G3", "G4"}   # no grid_sample inside
 
 

@@ -284,3 +284,29 @@ def test_strict_seeds_are_margin_checked():
         for ac in (False, True):
             within = M.within_counts(M.geom_margins(inp, ac, 3))
             assert sum(within.values()) == 0, ((b, h, w), seed, ac, within)
+
+
+def test_evaluation_metrics_match_the_reference_formulas():
+    """Device-side eval_flow_avg / eval_depth against the numpy restatement of
+    evaluate_flow.py:85-174 and evaluate_depth.py:13-52, same signatures and return formats (run on CPU tensors here)."""
+    from oracle import eval_oracle as EO
+    from core.evaluation import eval_flow_avg, eval_depth
+    r = np.random.default_rng(5)
+    cfg = types.SimpleNamespace(img_hw=(64, 208))
+    gts, nocs, preds, moves = [], [], [], []
+    for _ in range(3):
+        H, W = 93, 310
+        gt = np.concatenate([6 * r.standard_normal((H, W, 2)), (r.random((H, W, 1)) > 0.3)], 2).astype(np.float32)
+        noc = (gt[:, :, 2] * (r.random((H, W)) > 0.2)).astype(np.float32)
+        gts.append(gt); nocs.append(noc); moves.append((r.random((H, W)) > 0.7).astype(np.float32))
+        preds.append((2 * r.standard_normal((64, 208, 2))).astype(np.float32))
+    ref = EO.eval_flow_avg(gts, nocs, preds, cfg.img_hw, moves)
+    out = eval_flow_avg(gts, nocs, [torch.from_numpy(p) for p in preds], cfg, moving_masks=moves)
+    vals = [float(v) for v in out.strip().split("\n")[1].split(",")]
+    # table order: epe, noc, occ, move, static, move_rate, static_rate, err_rate
+    np.testing.assert_allclose(vals, [ref[0], ref[1], ref[2], ref[4], ref[5], ref[6], ref[7], ref[3]], atol=6e-5, rtol=1e-4)
+    out4 = eval_flow_avg(gts, nocs, preds, cfg)
+    assert out4.split("\n")[0].split(",")[-1].strip() == "err_rate" and len(out4.strip().split("\n")[1].split(",")) == 4
+    gtd = [np.where(r.random((375, 1242)) > 0.9, r.uniform(1, 90, (375, 1242)), 0).astype(np.float32) for _ in range(2)]
+    prd = [r.uniform(0.5, 60, (375, 1242)).astype(np.float32) for _ in range(2)]
+    np.testing.assert_allclose(eval_depth(gtd, [torch.from_numpy(p) for p in prd]), EO.eval_depth(gtd, prd), rtol=2e-5)

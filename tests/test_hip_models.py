@@ -185,6 +185,44 @@ def test_per_method_api_vs_golden(golden_dir):
     np.testing.assert_allclose(N(m.compute_epipolar_loss(dist_f, dyn_f[0])), g["epipolar_loss"], rtol=5e-6)
 
 
+@pytest.mark.parametrize("ac", [False, True])
+def test_disabled_depth_terms_vs_reference(golden_dir, ac):
+    """cfg.enable_depth_ssim / enable_depth_consis: the two terms the reference keeps commented
+    (model_geometry.py:889-891,897-899) against golden set G9 (the reference's own methods called unbound) and against
+    the oracle: values 5e-6, gradients wrt the target AND source disparities 1e-4 of their scale, pose gradient 2e-5."""
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+    from unsupervised_depth_opticalflow_egomotion_amd.models import Model_geometry
+    g = np.load(os.path.join(golden_dir, "G9_ac%d.npz" % ac))
+    assert int(g["g9_within"][0]) == 0
+    inp = synthetic.make_loss_stack_inputs(*MG.G9_SHAPE, 3, seed=MG.G9_SEED)
+    m = Model_geometry.__new__(Model_geometry); torch.nn.Module.__init__(m)
+    m.num_scales, m.flow_consist_alpha, m.flow_consist_beta = 3, 0.01, 0.5
+    m.enable_depth_ssim = m.enable_depth_consis = True
+    disps = [[G(a, True) for a in lst] for lst in inp.disps]
+    pose, fb, ff = G(inp.pose, True), [G(a) for a in inp.flows_bwd], [G(a) for a in inp.flows_fwd]
+    prev = ops.get_align_corners()
+    ops.set_align_corners(ac)
+    try:
+        lp, _ = m.loss_stack(*[G(a) for a in inp.imgs], disps[0], disps[1], disps[2], pose, fb, ff, G(inp.K), G(inp.K_inv))
+        (0.85 * lp["loss_depth_ssim"].mean() + 0.1 * lp["loss_depth_consis"].mean()).backward()
+    finally:
+        ops.set_align_corners(prev)
+    for k in ("loss_depth_ssim", "loss_depth_consis"):
+        assert lp[k].shape == (2,)
+        np.testing.assert_allclose(N(lp[k]), g[k], rtol=5e-6, atol=1e-7, err_msg=k)
+    gp = g["gpose"]
+    assert np.abs(N(pose.grad) - gp).max() <= 2e-5 * np.abs(gp).max()
+    for f in range(3):
+        for s in range(3):
+            ref = g["gdisp_%d_%d" % (f, s)]
+            got = N(disps[f][s].grad) if disps[f][s].grad is not None else np.zeros_like(ref)
+            assert np.abs(got - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-12) + 1e-9, (f, s)
+    # with the flags off the two entries are the reference's (2,)-shaped placeholders
+    m.enable_depth_ssim = m.enable_depth_consis = False
+    lp0, _ = m.loss_stack(*[G(a) for a in inp.imgs], disps[0], disps[1], disps[2], pose, fb, ff, G(inp.K), G(inp.K_inv))
+    assert float(lp0["loss_depth_ssim"].abs().sum()) == 0.0 and lp0["loss_depth_consis"].shape == (2,)
+
+
 def test_train_step_runs_and_learns():
     from unsupervised_depth_opticalflow_egomotion_amd.train_step import make_cfg, train_step
     from unsupervised_depth_opticalflow_egomotion_amd.models import get_model
@@ -265,3 +303,23 @@ def test_bench_gpus_flag_launches_the_ranks_itself():
     out = subprocess.run(base + ["--gpus", "2"], capture_output=True, text=True, cwd=repo,
                          env=dict(clean, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), timeout=300)
     assert out.returncode != 0 and "contradicts" in out.stderr
+
+
+def test_test_py_cli_surface(tmp_path):
+    """test.py (reference test.py:314-377): same flags, model construction, strict=False checkpoint loading and eval();
+    --task demo runs infer_depth / infer_pose / inference_flow on synthetic triplets and prints both metric tables; a KITTI
+    task without its data directory fails with a clear error."""
+    import subprocess, sys
+    from unsupervised_depth_opticalflow_egomotion_amd.models import get_model
+    from unsupervised_depth_opticalflow_egomotion_amd.train_step import make_cfg
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ckpt = str(tmp_path / "last.pth")
+    torch.manual_seed(0)
+    sd = get_model("geom")(make_cfg()).state_dict()
+    torch.save({"iteration": 1, "model_state_dict": {"module." + k: v for k, v in sd.items()}, "optimizer_state_dict": {}}, ckpt)
+    base = [sys.executable, os.path.join(repo, "test.py"), "-c", os.path.join(repo, "config", "kitti_geom.yaml"), "--mode", "geom"]
+    out = subprocess.run(base + ["--task", "demo", "--pretrained_model", ckpt], capture_output=True, text=True, cwd=repo, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Model Loaded." in out.stdout and "[EVAL] [synthetic flow]" in out.stdout and "abs_rel" in out.stdout
+    out = subprocess.run(base + ["--task", "kitti_flow_2015"], capture_output=True, text=True, cwd=repo, timeout=600)
+    assert out.returncode != 0 and "gt_2015_dir" in out.stderr

@@ -262,3 +262,22 @@ def test_g8_depth_and_flow_modes(golden_dir, ac):
     for s in range(4):
         check_grad_summary(g, "flow_gflow_b_%d" % s, fb[s], stride=31)
         check_grad_summary(g, "flow_gflow_f_%d" % s, ff[s], stride=31)
+
+
+@pytest.mark.parametrize("ac", ACS)
+def test_g9_disabled_depth_terms(golden_dir, ac):
+    """The oracle's restatement of the commented depth SSIM / depth consistency terms against the reference's own methods."""
+    g = load(golden_dir, "G9_ac%d" % ac)
+    inp = synthetic.make_loss_stack_inputs(*MG.G9_SHAPE, 3, seed=MG.G9_SEED)
+    m = O.GeomLossOracle(3, align_corners=ac)
+    d, p, fb, ff = MG.lists_to_t(inp, True)
+    lp, _ = m.geom_losses(*[T(a) for a in inp.imgs], d[0], d[1], d[2], p, fb, ff, T(inp.K), T(inp.K_inv),
+                          enable_depth_ssim=True, enable_depth_consis=True)
+    (0.85 * lp["loss_depth_ssim"].mean() + 0.1 * lp["loss_depth_consis"].mean()).backward()
+    close(N(lp["loss_depth_ssim"]), g["loss_depth_ssim"])
+    close(N(lp["loss_depth_consis"]), g["loss_depth_consis"])
+    gscale(N(p.grad), g["gpose"], rel=5e-5, atol=1e-6)
+    for f in range(3):
+        for s in range(3):
+            got = N(d[f][s].grad) if d[f][s].grad is not None else np.zeros_like(g["gdisp_%d_%d" % (f, s)])
+            gscale(got, g["gdisp_%d_%d" % (f, s)], rel=5e-5, atol=1e-9)

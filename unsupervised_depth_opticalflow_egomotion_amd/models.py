@@ -98,6 +98,9 @@ class Model_geometry(LossTerms, nn.Module):
         self.ratio = getattr(cfg, "geometric_ratio", 0.3)
         self.num = getattr(cfg, "geometric_num", 6000)
         self.beta = getattr(cfg, "pose_beta", 1)
+        # the two depth terms the reference keeps commented (model_geometry.py:889-891,897-899); off = placeholders
+        self.enable_depth_ssim = bool(getattr(cfg, "enable_depth_ssim", False))
+        self.enable_depth_consis = bool(getattr(cfg, "enable_depth_consis", False))
 
     # ---- inference API (model_geometry.py:282-302)
     def infer_depth(self, img):
@@ -126,6 +129,32 @@ class Model_geometry(LossTerms, nn.Module):
         disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd = self.run_networks(img_l, img, img_r)
         return self.loss_stack(img_l, img, img_r, disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd, K, K_inv)
 
+    def disabled_depth_terms(self, img_l, img, img_r, disp_l, disp_t, disp_r, pose, K, mask_handle):
+        """``loss_depth_ssim`` / ``loss_depth_consis`` exactly as the commented lines of the reference read
+        (model_geometry.py:889-891,897-899), enabled by ``cfg.enable_depth_ssim`` /
+        ``cfg.enable_depth_consis``.  They run on the per-operator HIP kernels (inverse_warp2 with projected / computed
+        depth and its gradients wrt the target disparity, the SOURCE disparity and the pose; SSIM forward / backward;
+        resize) under autograd; the texture-gated masks are decoded from the fused stack's mask pack, so the mask
+        decisions are the fused stack's own.  Not yet part of the fused launches."""
+        S = self.num_scales
+        img_list = self.generate_img_pyramid(img, S)
+        rec_l, _, pd_l, cd_l = self.reconstruction(img_l, K, disp_t, disp_l, pose[:, 0].contiguous())
+        rec_r, _, pd_r, cd_r = self.reconstruction(img_r, K, disp_t, disp_r, pose[:, 1].contiguous())
+        with torch.no_grad():
+            def gated(d):
+                return [decode_mask(mask_handle, "valid_" + d, s) * decode_mask(mask_handle, "occ_" + d, s) *
+                        decode_mask(mask_handle, "dyna_" + d, s) * decode_mask(mask_handle, "texture_" + d, s)
+                        for s in range(S)]
+            bwd_tex, fwd_tex = gated("bwd"), gated("fwd")
+        out = {}
+        if self.enable_depth_ssim:
+            out["loss_depth_ssim"] = self.compute_ssim_loss(img_list, rec_l, bwd_tex) + \
+                self.compute_ssim_loss(img_list, rec_r, fwd_tex)
+        if self.enable_depth_consis:
+            out["loss_depth_consis"] = self.compute_consis_loss(pd_l, cd_l, bwd_tex) + \
+                self.compute_consis_loss(pd_r, cd_r, fwd_tex)
+        return out
+
     def loss_stack(self, img_l, img, img_r, disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd, K, K_inv):
         """Everything from model_geometry.py:797 to :951 -> (loss_pack, mask_pack)."""
         S = self.num_scales
@@ -135,6 +164,8 @@ class Model_geometry(LossTerms, nn.Module):
                                         flow_consist_beta=self.flow_consist_beta, return_masks="lazy")
         dev = img.device
         loss_pack = {k: (active[k] if k in active else _zeros2(dev)) for k in LOSS_ORDER_GEOM}
+        if self.enable_depth_ssim or self.enable_depth_consis:
+            loss_pack.update(self.disabled_depth_terms(img_l, img, img_r, disp_l, disp_t, disp_r, pose, K, masks))
 
         def u8(*names):
             """sample 0, scale 0 of the product of the named masks, decoded from the 1-byte mask pack only when the

@@ -8,7 +8,7 @@ DEFAULT_CFG = dict(
     h_flow_consist_alpha=0.01, h_flow_consist_beta=0.5, geometric_ratio=0.3, geometric_num=6000, pose_beta=1,
     w_flow_pixel=0.15, w_flow_ssim=0.85, w_flow_smooth=10.0, w_flow_consis=0.01, w_depth_pixel=1.0, w_depth_ssim=0.85,
     w_depth_smooth=0.5, w_depth_consis=0.1, w_depth_flow_consis=1.0, w_epipolar=0.1, w_triangle=0.001, w_pnp=0.1,
-    w_8point=0.1, img_hw=(256, 832), lr=1e-4, mode="geom")
+    w_8point=0.1, img_hw=(256, 832), lr=1e-4, mode="geom", enable_depth_ssim=False, enable_depth_consis=False)
 
 LOSS_WEIGHT_ATTR = {
     "loss_flow_pixel": "w_flow_pixel", "loss_flow_ssim": "w_flow_ssim", "loss_flow_smooth": "w_flow_smooth",
