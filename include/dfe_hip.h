@@ -94,6 +94,13 @@ int dfe_texture_mask(const float* img, const float* warped, const float* source,
 int dfe_dynamic_mask(const float* flow, const float* rigid, float* mask, float* score, float alpha, float beta, int B,
                      int H, int W, void* stream);
 
+/* ---- device-side input pipeline  core/dataset/kitti_prepared.py:63-90,132-152, train.py:171 ------------------
+ * in_u8: uint8 [B][3*H0][W0][3] raw stacked triplets (left / target / right along H, channel order as stored);
+ * flip: B device bytes (non-zero = horizontal flip of that sample, NULL = none); out: fp32 [B][3][3*H][W] in [0,1]:
+ * per frame bilinear resize (half-pixel centres, edge replication) to H x W, flip, / 255, HWC -> CHW. */
+int dfe_prepare_triplets(const unsigned char* in_u8, const unsigned char* flip, float* out, int B, int H0, int W0,
+                         int H, int W, void* stream);
+
 /* ---- self-test of the short correctly rounded fp32 sequences (csrc/loss_stack_exact.h) ------------------------
  * The mask-deciding expressions of the reference use IEEE division and square root (torch CPU); the pointwise kernels
  * evaluate them with 3 / 5-instruction sequences that must return the SAME bits.  This entry point checks that

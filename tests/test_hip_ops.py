@@ -94,6 +94,29 @@ def test_warp_flow_oracle(shape, ac):
         gclose(xt.grad, xo.grad)
 
 
+def test_device_input_pipeline():
+    """ops.prepare_triplets against a numpy statement of KITTI_Prepared's image path
+    (kitti_prepared.py:63-90: per-frame cv2.resize INTER_LINEAR geometry, flip, / 255, HWC -> CHW), fp32 resize: 2e-6."""
+    from oracle import eval_oracle as EO
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+    r = MG.rng(31)
+    B, H0, W0, H, W = 3, 37, 122, 32, 96
+    raw = r.integers(0, 256, (B, 3 * H0, W0, 3), dtype=np.uint8)
+    flip = np.array([0, 1, 0], np.uint8)
+    got = N(ops.prepare_triplets(torch.from_numpy(raw).to(dev()), (H, W), torch.from_numpy(flip)))
+    assert got.shape == (B, 3, 3 * H, W)
+    for b in range(B):
+        frames = [EO.resize_linear(raw[b, f * H0:(f + 1) * H0].astype(np.float32), (H, W)) for f in range(3)]
+        img = np.concatenate(frames, 0)
+        if flip[b]:
+            img = img[:, ::-1]
+        ref = (img / 255.0).transpose(2, 0, 1)
+        np.testing.assert_allclose(got[b], ref, atol=2e-6)
+    ks, kis = ops.rescale_intrinsics(np.array([[721.5, 0, 609.6], [0, 721.5, 172.9], [0, 0, 1]]), (375, 1242), (256, 832), 3)
+    assert ks.shape == (3, 3, 3) and abs(float(ks[1, 0, 0]) - 721.5 * 832 / 1242 / 2) < 1e-3
+    np.testing.assert_allclose((ks[2] @ kis[2]).numpy(), np.eye(3), atol=1e-5)
+
+
 def test_exact_math_sequences_exhaustive():
     """The 3 / 5-instruction reciprocal, division and square-root sequences the mask-deciding expressions use return the
     IEEE results bit for bit: every fp32 reciprocal and square root, 2^32 random quotients + 2^32 with all-ones divisors."""

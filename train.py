@@ -78,12 +78,22 @@ def train(cfg):
     weights = {k: getattr(cfg, a) for k, a in LOSS_WEIGHT_ATTR.items()}
     h, w = cfg.img_hw
     n_iter = cfg.num_iterations - start
-    dataset = synthetic.SyntheticTriplets(n_iter * cfg.batch_size * world, (h, w), cfg.num_scales, seed=1234)
+    raw_pipeline = bool(getattr(cfg, "device_pipeline", False))
+    if raw_pipeline:   # raw uint8 triplets at KITTI's native size; resize / flip / normalise run on the device
+        dataset = synthetic.SyntheticRawTriplets(n_iter * cfg.batch_size * world, (375, 1242), (h, w), cfg.num_scales, seed=1234)
+    else:
+        dataset = synthetic.SyntheticTriplets(n_iter * cfg.batch_size * world, (h, w), cfg.num_scales, seed=1234)
     t0 = time.time()
     for it in range(start, cfg.num_iterations):
         base = (it - start) * cfg.batch_size * world + rank * cfg.batch_size
         samples = [dataset[base + j] for j in range(cfg.batch_size)]
-        inputs = [torch.stack([s[i] for s in samples]).to(dev, non_blocking=True) for i in range(3)]
+        if raw_pipeline:
+            raw = torch.stack([s[0] for s in samples]).pin_memory().to(dev, non_blocking=True)
+            flip = torch.tensor([s[3] for s in samples], dtype=torch.uint8)
+            inputs = [ops.prepare_triplets(raw, (h, w), flip)] + \
+                [torch.stack([s[i] for s in samples]).to(dev, non_blocking=True) for i in (1, 2)]
+        else:
+            inputs = [torch.stack([s[i] for s in samples]).to(dev, non_blocking=True) for i in range(3)]
         loss, loss_pack, mask_pack = train_step(model, optimizer, inputs, cfg)
         if rank == 0 and it % cfg.log_interval == 0:
             print_loss(it, loss_pack, weights, loss)
@@ -120,6 +130,8 @@ if __name__ == "__main__":
     ap.add_argument("--fix_pose", action="store_true")
     ap.add_argument("--fix_flow", action="store_true")
     ap.add_argument("--num_iterations", type=int, default=None)
+    ap.add_argument("--device_pipeline", action="store_true",
+                    help="feed raw uint8 triplets and run resize / flip / normalise on the device (ops.prepare_triplets)")
     args = ap.parse_args()
     with open(args.config_file) as fh:
         cfg = yaml.safe_load(fh)

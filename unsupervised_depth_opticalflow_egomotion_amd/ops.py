@@ -256,6 +256,40 @@ def resize(img, out_hw, mode):
     return out
 
 
+# --------------------------------------------------------------------------- device-side input pipeline
+def prepare_triplets(raw_u8, img_hw, flip=None):
+    """KITTI_Prepared.__getitem__'s image half (kitti_prepared.py:63-90,132-152) for a whole batch on the device.
+
+    raw_u8: uint8 [B, 3*H0, W0, 3] stacked triplets as stored (pin + ``.to(device, non_blocking=True)`` it); flip: optional
+    uint8 / bool [B]; returns fp32 [B, 3, 3*H, W] in [0,1] -- the ``images`` entry of the models' ``inputs``."""
+    lib = get_lib()
+    if raw_u8.dtype != torch.uint8 or raw_u8.dim() != 4 or raw_u8.shape[3] != 3 or raw_u8.shape[1] % 3:
+        raise ValueError("raw_u8 must be uint8 [B, 3*H0, W0, 3]")
+    raw_u8 = raw_u8.contiguous()
+    B, H0, W0 = raw_u8.shape[0], raw_u8.shape[1] // 3, raw_u8.shape[2]
+    H, W = int(img_hw[0]), int(img_hw[1])
+    fl = None if flip is None else flip.to(device=raw_u8.device, dtype=torch.uint8).contiguous()
+    out = torch.empty(B, 3, 3 * H, W, device=raw_u8.device)
+    check(lib.dfe_prepare_triplets(ptr(raw_u8), ptr(fl), ptr(out), B, H0, W0, H, W, stream_ptr()), "dfe_prepare_triplets")
+    return out
+
+
+def rescale_intrinsics(K, img_hw_orig, img_hw_new, num_scales):
+    """rescale_intrinsics + get_multiscale_intrinsics (kitti_prepared.py:110-130): K [3,3] float64 numpy ->
+    (K_ms, K_inv_ms) float32 tensors [S,3,3] (host side: a few dozen flops per sample)."""
+    import numpy as np
+    K = np.array(K, dtype=np.float64, copy=True)
+    K[0, :] = K[0, :] * img_hw_new[1] / img_hw_orig[1]
+    K[1, :] = K[1, :] * img_hw_new[0] / img_hw_orig[0]
+    ks, kis = [], []
+    for s in range(num_scales):
+        k = K.copy()
+        k[0, :] /= 2 ** s
+        k[1, :] /= 2 ** s
+        ks.append(k); kis.append(np.linalg.inv(k))
+    return torch.from_numpy(np.stack(ks)).float(), torch.from_numpy(np.stack(kis)).float()
+
+
 # --------------------------------------------------------------------------- mask decisions (no grad)
 def occ_masks(from_l, tgt, from_r):
     """compute_occ_weight's decisions (model_geometry.py:105-132) -> occ_bwd, occ_fwd, valid_bwd, valid_fwd [B,1,H,W]."""

@@ -253,3 +253,25 @@ class SyntheticTriplets:
         import torch
         im, k, ki = make_triplet_batch(1, self.hw[0], self.hw[1], self.s, seed=self.seed + int(idx))
         return torch.from_numpy(im[0]), torch.from_numpy(k[0]), torch.from_numpy(ki[0])
+
+
+class SyntheticRawTriplets:
+    """Raw counterpart of ``SyntheticTriplets`` for the device-side input pipeline (ops.prepare_triplets): what
+    ``cv2.imread`` hands ``KITTI_Prepared.__getitem__`` (kitti_prepared.py:143) -- a uint8 [3*H0, W0, 3] stacked
+    triplet at the dataset's native size -- plus the multiscale intrinsics for the training size and the flip draw.
+    ``ds[i] -> (raw_u8, K_ms, K_inv_ms, flip)``."""
+
+    def __init__(self, num_samples: int, raw_hw=(375, 1242), img_hw=(256, 832), num_scales: int = 3, seed: int = 1234):
+        self.n, self.raw_hw, self.hw, self.s, self.seed = int(num_samples), tuple(raw_hw), tuple(img_hw), int(num_scales), int(seed)
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, idx):
+        import torch
+        h0, w0 = self.raw_hw
+        im, _, _ = make_triplet_batch(1, h0, w0, 1, seed=self.seed + int(idx))
+        raw = np.clip(np.rint(im[0] * 255.0), 0, 255).astype(np.uint8).transpose(1, 2, 0)      # [3*H0, W0, 3]
+        k_ms, k_inv_ms = multiscale_intrinsics(self.hw[0], self.hw[1], self.s)
+        flip = int(_rng(self.seed * 7919 + int(idx)).random() > 0.5)
+        return torch.from_numpy(np.ascontiguousarray(raw)), torch.from_numpy(k_ms), torch.from_numpy(k_inv_ms), flip
