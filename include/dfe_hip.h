@@ -101,6 +101,11 @@ int dfe_dynamic_mask(const float* flow, const float* rigid, float* mask, float* 
 int dfe_prepare_triplets(const unsigned char* in_u8, const unsigned char* flip, float* out, int B, int H0, int W0,
                          int H, int W, void* stream);
 
+/* ---- forward-splat occlusion map  core/networks/model_flow.py:33-39 (get_occlusion_mask_from_flow) -----------
+ * The reference calls an undefined `transformerFwd`; this is its TrianFlow meaning: out [B,1,H,W] = bilinear forward
+ * warp of a ones image by flow [B,2,H,W] (optionally clamped to [0,1]).  out is zeroed here; scatter with float atomics. */
+int dfe_forward_splat_ones(const float* flow, float* out, int B, int H, int W, int clamp01, void* stream);
+
 /* ---- self-test of the short correctly rounded fp32 sequences (csrc/loss_stack_exact.h) ------------------------
  * The mask-deciding expressions of the reference use IEEE division and square root (torch CPU); the pointwise kernels
  * evaluate them with 3 / 5-instruction sequences that must return the SAME bits.  This entry point checks that

@@ -94,6 +94,38 @@ def test_warp_flow_oracle(shape, ac):
         gclose(xt.grad, xo.grad)
 
 
+def test_forward_splat_occlusion_properties():
+    """Model_flow.get_occlusion_mask_from_flow (model_flow.py:33-39; no oracle exists -- the reference's transformerFwd is
+    undefined): zero flow -> ones; an integer shift -> shifted ones with the vacated columns at 0; mass conservation
+    before the clamp while every footprint stays inside; clamp to [0,1]; agreement with a numpy scatter."""
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+    from unsupervised_depth_opticalflow_egomotion_amd.models import Model_flow
+    B, H, W = 2, 24, 40
+    z = torch.zeros(B, 2, H, W, device=dev())
+    assert torch.equal(ops.forward_splat_ones(z), torch.ones(B, 1, H, W, device=dev()))
+    sh = z.clone(); sh[:, 0] = 3.0
+    o = N(ops.forward_splat_ones(sh))
+    assert (o[:, :, :, :3] == 0).all() and (o[:, :, :, 3:] == 1).all()
+    r = MG.rng(12)
+    fl = (0.4 * r.standard_normal((B, 2, H, W))).astype(np.float32)
+    fl[:, :, :2] = 0; fl[:, :, -2:] = 0; fl[:, :, :, :2] = 0; fl[:, :, :, -2:] = 0      # footprints stay inside
+    raw = N(ops.forward_splat_ones(G(fl), clamp=False))
+    np.testing.assert_allclose(raw.sum((1, 2, 3)), H * W, rtol=1e-5)
+    ref = np.zeros((B, H, W), np.float64)
+    for b in range(B):
+        for y in range(H):
+            for x in range(W):
+                tx, ty = x + float(fl[b, 0, y, x]), y + float(fl[b, 1, y, x])
+                x0, y0 = int(np.floor(tx)), int(np.floor(ty)); wx, wy = tx - x0, ty - y0
+                for (yy, xx, wgt) in ((y0, x0, (1 - wx) * (1 - wy)), (y0, x0 + 1, wx * (1 - wy)), (y0 + 1, x0, (1 - wx) * wy), (y0 + 1, x0 + 1, wx * wy)):
+                    if 0 <= yy < H and 0 <= xx < W:
+                        ref[b, yy, xx] += wgt
+    np.testing.assert_allclose(raw[:, 0], ref, atol=2e-6)
+    mf = Model_flow.__new__(Model_flow)
+    m = mf.get_occlusion_mask_from_flow((B, 3, H, W), G(fl))
+    assert m.shape == (B, 3, H, W) and float(m.max()) <= 1.0 and float(m.min()) >= 0.0
+
+
 def test_device_input_pipeline():
     """ops.prepare_triplets against a numpy statement of KITTI_Prepared's image path
     (kitti_prepared.py:63-90: per-frame cv2.resize INTER_LINEAR geometry, flip, / 255, HWC -> CHW), fp32 resize: 2e-6."""

@@ -59,6 +59,7 @@ _SIGNATURES = {
     "dfe_dynamic_mask": [_P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _I, _I, _I, _P],
     "dfe_exact_math_selftest": [_P, ctypes.c_ulonglong, _P],
     "dfe_prepare_triplets": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dfe_forward_splat_ones": [_P, _P, _I, _I, _I, _I, _P],
     "dfe_ssim_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_ssim_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_corr_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],

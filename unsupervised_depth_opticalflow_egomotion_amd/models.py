@@ -283,6 +283,15 @@ class Model_flow(LossTerms, nn.Module):
         hw = [img1.shape[2], img1.shape[3]]
         return self.pwc_model(self.fpyramid(img1), self.fpyramid(img2), hw)[0]
 
+    def get_occlusion_mask_from_flow(self, tensor_size, flow):
+        """model_flow.py:33-39 -- dead in the reference (it calls an undefined ``transformerFwd``); here the bilinear
+        forward splat of a ones image by ``flow``, clamped to [0,1], broadcast to ``tensor_size`` [B,C,H,W]."""
+        from . import ops
+        b, c, h, w = tensor_size
+        if tuple(flow.shape) != (b, 2, h, w):
+            raise ValueError("flow must be [B,2,H,W] matching tensor_size")
+        return ops.forward_splat_ones(flow, clamp=True).expand(b, c, h, w)
+
     def forward(self, inputs):
         images = inputs[0]
         img_l, img, img_r, h, w = _split_frames(images)

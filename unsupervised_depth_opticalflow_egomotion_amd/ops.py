@@ -290,6 +290,19 @@ def rescale_intrinsics(K, img_hw_orig, img_hw_new, num_scales):
     return torch.from_numpy(np.stack(ks)).float(), torch.from_numpy(np.stack(kis)).float()
 
 
+# --------------------------------------------------------------------------- forward splat (no grad)
+def forward_splat_ones(flow, clamp=True):
+    """Bilinear forward warp of a ones image by ``flow`` [B,2,H,W] -> [B,1,H,W] (model_flow.py:33-39's intent)."""
+    lib = get_lib()
+    fl = f32c(flow.detach())
+    B, C, H, W = fl.shape
+    if C != 2:
+        raise ValueError("flow must be [B,2,H,W]")
+    out = torch.empty(B, 1, H, W, device=fl.device)
+    check(lib.dfe_forward_splat_ones(ptr(fl), ptr(out), B, H, W, int(bool(clamp)), stream_ptr()), "dfe_forward_splat_ones")
+    return out
+
+
 # --------------------------------------------------------------------------- mask decisions (no grad)
 def occ_masks(from_l, tgt, from_r):
     """compute_occ_weight's decisions (model_geometry.py:105-132) -> occ_bwd, occ_fwd, valid_bwd, valid_fwd [B,1,H,W]."""
