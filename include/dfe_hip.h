@@ -125,6 +125,20 @@ int dfe_corr_fwd(const float* f1, const float* f2, float* out, int B, int C, int
 int dfe_corr_bwd(const float* f1, const float* f2, const float* gout, float* g1, float* g2, int B, int C, int H, int W,
                  int d, void* stream);
 
+/* ---- one PWC decoder level's input  pwc_tf.py:119-121 (and :131-133, :143-145, :155-157) --------
+ *   warp = self.warp(c2, up_flow); corr = self.corr(c1, warp); x = torch.cat((corr, c1, up_flow), 1)
+ * as ONE operator: the cost volume is written straight into planes [0,81) of x [B, 81+C+2, H, W] (caller-allocated),
+ * c1 and the flow are copied behind it; `warped` [B,C,H,W] is kept for the backward pass.  The backward pass reads
+ * the three channel slices of gx = dL/dx in place and returns complete gradients:
+ *   g_c1 = dcorr/dc1 + gx[:,81:81+C];  g_flow = dwarp/dflow + gx[:,81+C:];  g_c2 (scatter; zero-filled here).
+ * g_warped [B,C,H,W] is scratch.  g_c2 or g_flow may be NULL (not both). */
+int dfe_pwc_level_channels(int C);   /* 81 + C + 2 */
+int dfe_pwc_level_fwd(const float* c1, const float* c2, const float* flow, float* warped, float* x, int B, int C, int H,
+                      int W, int align_corners, void* stream);
+int dfe_pwc_level_bwd(const float* c1, const float* c2, const float* flow, const float* warped, const float* gx,
+                      float* g_warped, float* g_c1, float* g_c2, float* g_flow, int B, int C, int H, int W,
+                      int align_corners, void* stream);
+
 /* ---- pyramids: mode 0 = F.interpolate(bilinear, align_corners=False) (model_geometry.py:65-72),
  * mode 1 = F.interpolate(area) == adaptive_avg_pool2d (model_geometry.py:91, model_flow.py:58-64). */
 int dfe_resize(const float* in, float* out, int planes, int inH, int inW, int outH, int outW, int mode, void* stream);

@@ -120,7 +120,7 @@ def test_forward_splat_occlusion_properties():
                 for (yy, xx, wgt) in ((y0, x0, (1 - wx) * (1 - wy)), (y0, x0 + 1, wx * (1 - wy)), (y0 + 1, x0, (1 - wx) * wy), (y0 + 1, x0 + 1, wx * wy)):
                     if 0 <= yy < H and 0 <= xx < W:
                         ref[b, yy, xx] += wgt
-    np.testing.assert_allclose(raw[:, 0], ref, atol=2e-6)
+    np.testing.assert_allclose(raw[:, 0], ref, atol=2e-5)     # the device forms x + u in fp32 (ulp(40) = 3.8e-6)
     mf = Model_flow.__new__(Model_flow)
     m = mf.get_occlusion_mask_from_flow((B, 3, H, W), G(fl))
     assert m.shape == (B, 3, H, W) and float(m.max()) <= 1.0 and float(m.min()) >= 0.0
@@ -128,7 +128,9 @@ def test_forward_splat_occlusion_properties():
 
 def test_device_input_pipeline():
     """ops.prepare_triplets against a numpy statement of KITTI_Prepared's image path
-    (kitti_prepared.py:63-90: per-frame cv2.resize INTER_LINEAR geometry, flip, / 255, HWC -> CHW), fp32 resize: 2e-6."""
+    (kitti_prepared.py:63-90: per-frame cv2.resize INTER_LINEAR geometry, flip, / 255, HWC -> CHW).  Tolerance 1e-5 of
+    the [0,1] range: the device forms the source coordinate in fp32 (ATen's fma(scale, dst + 0.5, -0.5)), the numpy
+    statement in double -- at W0 = 122 that is 7e-6 px, times a slope of up to 255 grey levels per pixel, / 255."""
     from oracle import eval_oracle as EO
     from unsupervised_depth_opticalflow_egomotion_amd import ops
     r = MG.rng(31)
@@ -143,7 +145,7 @@ def test_device_input_pipeline():
         if flip[b]:
             img = img[:, ::-1]
         ref = (img / 255.0).transpose(2, 0, 1)
-        np.testing.assert_allclose(got[b], ref, atol=2e-6)
+        np.testing.assert_allclose(got[b], ref, atol=1e-5)
     ks, kis = ops.rescale_intrinsics(np.array([[721.5, 0, 609.6], [0, 721.5, 172.9], [0, 0, 1]]), (375, 1242), (256, 832), 3)
     assert ks.shape == (3, 3, 3) and abs(float(ks[1, 0, 0]) - 721.5 * 832 / 1242 / 2) < 1e-3
     np.testing.assert_allclose((ks[2] @ kis[2]).numpy(), np.eye(3), atol=1e-5)
@@ -293,6 +295,43 @@ def test_corr_oracle(shape):
     close(cv, co, atol=1e-5)
     gclose(a.grad, ao.grad)
     gclose(b.grad, bo.grad)
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 8, 26), (2, 96, 16, 52), (3, 32, 64, 208), (1, 20, 7, 10)])
+def test_pwc_level_input(shape):
+    """One PWC decoder level's input (pwc_tf.py:119-121) as one operator: equal to the composition of the per-op HIP
+    operators (forward bit for bit; g_c1 / g_flow bit for bit -- two-term sums; g_c2 is an atomic scatter) and to the
+    oracle's warp_flow + corr_naive + cat on the host."""
+    from unsupervised_depth_opticalflow_egomotion_amd.ops import corr81, pwc_level_input, warp_flow
+    B, C, H, W = shape
+    r = MG.rng(57)
+    c1 = r.standard_normal(shape).astype(np.float32)
+    c2 = r.standard_normal(shape).astype(np.float32)
+    flow = (r.standard_normal((B, 2, H, W)) * 2.5).astype(np.float32)
+    wgt = r.standard_normal((B, 81 + C + 2, H, W)).astype(np.float32)
+    a, b, f = G(c1, True), G(c2, True), G(flow, True)
+    x = pwc_level_input(a, b, f)
+    assert tuple(x.shape) == (B, 81 + C + 2, H, W)
+    (x * G(wgt)).sum().backward()
+    a2, b2, f2 = G(c1, True), G(c2, True), G(flow, True)
+    x2 = torch.cat((corr81(a2, warp_flow(b2, f2, use_mask=False)), a2, f2), 1)
+    (x2 * G(wgt)).sum().backward()
+    assert torch.equal(x, x2)
+    assert torch.equal(a.grad, a2.grad)
+    assert torch.equal(f.grad, f2.grad)
+    gclose(b.grad, b2.grad)
+    ao, bo, fo = T(c1, True), T(c2, True), T(flow, True)
+    xo = torch.cat((O.corr_naive(ao, O.warp_flow(bo, fo, use_mask=False)), ao, fo), 1)
+    (xo * T(wgt)).sum().backward()
+    close(x, xo, atol=1e-5)
+    gclose(a.grad, ao.grad)
+    gclose(b.grad, bo.grad)
+    gclose(f.grad, fo.grad)
+    # flow only (features detached): the g_c2 scatter is skipped
+    f3 = G(flow, True)
+    x3 = pwc_level_input(G(c1), G(c2), f3)
+    (x3 * G(wgt)).sum().backward()
+    assert torch.equal(f3.grad, f.grad)
 
 
 @pytest.mark.parametrize("hw", [(256, 832), (375, 1242), (64, 208)])

@@ -64,6 +64,9 @@ _SIGNATURES = {
     "dfe_ssim_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_corr_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_corr_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dfe_pwc_level_channels": [_I],
+    "dfe_pwc_level_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dfe_pwc_level_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_resize": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dfe_geom_workspace_floats": [_P],
     "dfe_geom_maskpack_offset_bytes": [_P, _I],

@@ -257,7 +257,8 @@ constexpr int WF_GROUPS = 4;
 
 __global__ void __launch_bounds__(64 * WF_GROUPS) k_warp_flow_bwd(const float* __restrict__ x, const float* __restrict__ flow,
                                                       const float* __restrict__ gout, float* __restrict__ gflow,
-                                                      float* __restrict__ gx, int C, int H, int W, int use_mask, int ac) {
+                                                      float* __restrict__ gx, const float* __restrict__ gflow_add, long gfa_bs,
+                                                      int C, int H, int W, int use_mask, int ac) {
   __shared__ float red[WF_GROUPS][2][64];
   const int b = blockIdx.z, HW = H * W;
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -309,7 +310,12 @@ __global__ void __launch_bounds__(64 * WF_GROUPS) k_warp_flow_bwd(const float* _
 #pragma unroll
       for (int k = 1; k < WF_GROUPS; ++k) { sx += red[k][0][lane]; sy += red[k][1][lane]; }
       float* gf = gflow + static_cast<long>(b) * 2 * HW;
-      gf[p] = sx * flow_coord_scale(W, ac); gf[HW + p] = sy * flow_coord_scale(H, ac);
+      float vx = sx * flow_coord_scale(W, ac), vy = sy * flow_coord_scale(H, ac);
+      if (gflow_add) {   // a second gradient of the same flow (the concatenated copy of a PWC level), added here
+        const float* ga = gflow_add + static_cast<long>(b) * gfa_bs;
+        vx += ga[p]; vy += ga[HW + p];
+      }
+      gf[p] = vx; gf[HW + p] = vy;
     }
   }
 }
@@ -541,7 +547,7 @@ __device__ __forceinline__ void load_window(const float* __restrict__ row, int x
 
 template <int V>
 __global__ void __launch_bounds__(256) k_corr_fwd(const float* __restrict__ f1, const float* __restrict__ f2,
-                                                  float* __restrict__ out, int B, int C, int H, int W) {
+                                                  float* __restrict__ out, long obs, int B, int C, int H, int W) {
   const int WQ = (W + V - 1) / V;
   const long total = static_cast<long>(B) * CR_K * H * WQ;
   const long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -572,7 +578,7 @@ __global__ void __launch_bounds__(256) k_corr_fwd(const float* __restrict__ f1, 
     }
   }
   const float fc = static_cast<float>(C);
-  float* o = out + (static_cast<long>(b) * CR_K * CR_K + i * CR_K) * HW + static_cast<long>(y) * W + x0;
+  float* o = out + static_cast<long>(b) * obs + static_cast<long>(i * CR_K) * HW + static_cast<long>(y) * W + x0;   // obs: batch stride of out (the 81 planes may be a slice of a wider tensor)
 #pragma unroll
   for (int j = 0; j < CR_K; ++j) {
     if (V == 4) *reinterpret_cast<float4*>(o + j * HW) = make_float4(acc[0][j] / fc, acc[1][j] / fc, acc[2][j] / fc, acc[3][j] / fc);
@@ -584,7 +590,7 @@ __global__ void __launch_bounds__(256) k_corr_fwd(const float* __restrict__ f1, 
 // with the most channels (128/196); a thread per (b, k, y, x) gives 81x the threads of a per-pixel mapping and
 // two independent, coalesced loads per channel (4-way unrolled), instead of 52 px * 9 threads looping 196 channels.
 __global__ void __launch_bounds__(256) k_corr_fwd_naive(const float* __restrict__ f1, const float* __restrict__ f2,
-                                                        float* __restrict__ out, int B, int C, int H, int W) {
+                                                        float* __restrict__ out, long obs, int B, int C, int H, int W) {
   const long HW = static_cast<long>(H) * W, total = static_cast<long>(B) * CR_K * CR_K * HW;
   const long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= total) return;
@@ -598,12 +604,13 @@ __global__ void __launch_bounds__(256) k_corr_fwd_naive(const float* __restrict_
 #pragma unroll 4
     for (int c = 0; c < C; ++c) acc += p1[c * HW] * p2[c * HW];
   }
-  out[t] = acc / static_cast<float>(C);
+  out[static_cast<long>(b) * obs + static_cast<long>(k) * HW + static_cast<long>(y) * W + x] = acc / static_cast<float>(C);
 }
 
 // one thread per (b, c, y, x); MODE as in k_corr_bwd below
 template <int MODE>
-__global__ void __launch_bounds__(256) k_corr_bwd_naive(const float* __restrict__ other, const float* __restrict__ gout,
+__global__ void __launch_bounds__(256) k_corr_bwd_naive(const float* __restrict__ other, const float* __restrict__ gout, long gbs,
+                                                        const float* __restrict__ addend, long abs_,
                                                         float* __restrict__ gin, int B, int C, int H, int W) {
   const long HW = static_cast<long>(H) * W, total = static_cast<long>(B) * C * HW;
   const long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -611,7 +618,7 @@ __global__ void __launch_bounds__(256) k_corr_bwd_naive(const float* __restrict_
   const int x = static_cast<int>(t % W), y = static_cast<int>((t / W) % H);
   const int c = static_cast<int>((t / HW) % C), b = static_cast<int>(t / (HW * C));
   const float* ob = other + (static_cast<long>(b) * C + c) * HW;
-  const float* gb = gout + static_cast<long>(b) * CR_K * CR_K * HW;
+  const float* gb = gout + static_cast<long>(b) * gbs;
   float acc = 0.0f;
 #pragma unroll 3
   for (int i = 0; i < CR_K; ++i) {
@@ -626,7 +633,9 @@ __global__ void __launch_bounds__(256) k_corr_bwd_naive(const float* __restrict_
       acc += g * ob[static_cast<long>(r) * W + q];
     }
   }
-  gin[t] = acc / static_cast<float>(C);
+  float v = acc / static_cast<float>(C);
+  if (addend) v += addend[static_cast<long>(b) * abs_ + static_cast<long>(c) * HW + static_cast<long>(y) * W + x];
+  gin[t] = v;
 }
 
 // g1[c,p] = 1/C sum_{i,j} g[i*9+j, p] * f2[c, p + (i-4, j-4)]          (MODE 0, other = f2)
@@ -636,7 +645,8 @@ __global__ void __launch_bounds__(256) k_corr_bwd_naive(const float* __restrict_
 constexpr int CR_CK = 8;
 
 template <int V, int MODE>
-__global__ void __launch_bounds__(256) k_corr_bwd(const float* __restrict__ other, const float* __restrict__ gout,
+__global__ void __launch_bounds__(256) k_corr_bwd(const float* __restrict__ other, const float* __restrict__ gout, long gbs,
+                                                  const float* __restrict__ addend, long abs_,
                                                   float* __restrict__ gin, int B, int C, int H, int W) {
   const int WQ = (W + V - 1) / V, NCH = (C + CR_CK - 1) / CR_CK;
   const long total = static_cast<long>(B) * NCH * H * WQ;
@@ -647,7 +657,7 @@ __global__ void __launch_bounds__(256) k_corr_bwd(const float* __restrict__ othe
   const int x0 = xq * V, c0 = ch * CR_CK, nch = min(CR_CK, C - c0);
   const long HW = static_cast<long>(H) * W;
   const float* ob = other + (static_cast<long>(b) * C + c0) * HW;
-  const float* gb = gout + static_cast<long>(b) * CR_K * CR_K * HW;
+  const float* gb = gout + static_cast<long>(b) * gbs;
   float acc[CR_CK][V];
 #pragma unroll
   for (int c = 0; c < CR_CK; ++c)
@@ -693,8 +703,12 @@ __global__ void __launch_bounds__(256) k_corr_bwd(const float* __restrict__ othe
   const float fc = static_cast<float>(C);
   for (int c = 0; c < nch; ++c) {
     float* o = gin + (static_cast<long>(b) * C + c0 + c) * HW + static_cast<long>(y) * W + x0;
-    if (V == 4) *reinterpret_cast<float4*>(o) = make_float4(acc[c][0] / fc, acc[c][1] / fc, acc[c][2] / fc, acc[c][3] / fc);
-    else o[0] = acc[c][0] / fc;
+    const float* ad = addend ? addend + static_cast<long>(b) * abs_ + static_cast<long>(c0 + c) * HW + static_cast<long>(y) * W + x0 : nullptr;
+    if (V == 4) {
+      float4 v = make_float4(acc[c][0] / fc, acc[c][1] / fc, acc[c][2] / fc, acc[c][3] / fc);
+      if (ad) { const float4 a4 = *reinterpret_cast<const float4*>(ad); v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w; }
+      *reinterpret_cast<float4*>(o) = v;
+    } else { float v = acc[c][0] / fc; if (ad) v += ad[0]; o[0] = v; }
   }
 }
 
@@ -782,7 +796,7 @@ int dfe_warp_flow_bwd(const float* x, const float* flow, const float* gout, floa
   DFE_REQUIRE(B <= 65535 && (C + WF_CK - 1) / WF_CK <= 65535, DFE_ERR_DIMS);
   dim3 g(static_cast<unsigned>((static_cast<long>(H) * W + 63) / 64), 1, B);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  k_warp_flow_bwd<<<g, 64 * WF_GROUPS, 0, st>>>(x, flow, gout, gflow, gx, C, H, W, use_mask, align_corners);
+  k_warp_flow_bwd<<<g, 64 * WF_GROUPS, 0, st>>>(x, flow, gout, gflow, gx, nullptr, 0, C, H, W, use_mask, align_corners);
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
@@ -869,18 +883,37 @@ static inline bool corr_vec_ok(const void* a, const void* b, const void* c, int 
   return (W % 4 == 0) && al(a) && al(b) && al(c);
 }
 
+static void launch_corr_fwd(const float* f1, const float* f2, float* out, long obs, int B, int C, int H, int W, hipStream_t st) {
+  if (corr_vec_ok(f1, f2, out, W) && obs % 4 == 0) {
+    long n = static_cast<long>(B) * CR_K * H * (W / 4);
+    k_corr_fwd<4><<<grid1d(n, 256), 256, 0, st>>>(f1, f2, out, obs, B, C, H, W);
+  } else {
+    long n = static_cast<long>(B) * CR_K * CR_K * H * W;
+    k_corr_fwd_naive<<<grid1d(n, 256), 256, 0, st>>>(f1, f2, out, obs, B, C, H, W);
+  }
+}
+
+// gout: 81 planes per sample with batch stride gbs; add1 (batch stride abs1) is added to g1 when given
+static void launch_corr_bwd(const float* f1, const float* f2, const float* gout, long gbs, const float* add1, long abs1,
+                            float* g1, float* g2, int B, int C, int H, int W, hipStream_t st) {
+  const int nchunk = (C + CR_CK - 1) / CR_CK;
+  const bool vec = corr_vec_ok(f1, f2, gout, W) && corr_vec_ok(g1, g2, add1, W) && gbs % 4 == 0 && abs1 % 4 == 0;
+  const long n = static_cast<long>(B) * nchunk * H * (W / 4), nn = static_cast<long>(B) * C * H * W;
+  if (g1) {
+    if (vec) k_corr_bwd<4, 0><<<grid1d(n, 256), 256, 0, st>>>(f2, gout, gbs, add1, abs1, g1, B, C, H, W);
+    else k_corr_bwd_naive<0><<<grid1d(nn, 256), 256, 0, st>>>(f2, gout, gbs, add1, abs1, g1, B, C, H, W);
+  }
+  if (g2) {
+    if (vec) k_corr_bwd<4, 1><<<grid1d(n, 256), 256, 0, st>>>(f1, gout, gbs, nullptr, 0, g2, B, C, H, W);
+    else k_corr_bwd_naive<1><<<grid1d(nn, 256), 256, 0, st>>>(f1, gout, gbs, nullptr, 0, g2, B, C, H, W);
+  }
+}
+
 int dfe_corr_fwd(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int d, void* stream) {
   DFE_REQUIRE(f1 && f2 && out, DFE_ERR_NULL);
   DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
   DFE_REQUIRE(d == CR_D, DFE_ERR_UNSUPPORTED);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (corr_vec_ok(f1, f2, out, W)) {
-    long n = static_cast<long>(B) * CR_K * H * (W / 4);
-    k_corr_fwd<4><<<grid1d(n, 256), 256, 0, st>>>(f1, f2, out, B, C, H, W);
-  } else {
-    long n = static_cast<long>(B) * CR_K * CR_K * H * W;
-    k_corr_fwd_naive<<<grid1d(n, 256), 256, 0, st>>>(f1, f2, out, B, C, H, W);
-  }
+  launch_corr_fwd(f1, f2, out, static_cast<long>(CR_K) * CR_K * H * W, B, C, H, W, static_cast<hipStream_t>(stream));
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
@@ -890,20 +923,76 @@ int dfe_corr_bwd(const float* f1, const float* f2, const float* gout, float* g1,
   DFE_REQUIRE(f1 && f2 && gout && (g1 || g2), DFE_ERR_NULL);
   DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
   DFE_REQUIRE(d == CR_D, DFE_ERR_UNSUPPORTED);
+  launch_corr_bwd(f1, f2, gout, static_cast<long>(CR_K) * CR_K * H * W, nullptr, 0, g1, g2, B, C, H, W, static_cast<hipStream_t>(stream));
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+// ---------------------------------------------------------------- one PWC decoder level's input (pwc_tf.py:119-121)
+// x = cat(corr(c1, warp(c2, flow)), c1, flow): the cost volume is written straight into its slice of x and the
+// backward pass reads the three slices of dL/dx in place (no cat / slice copies, no gradient-accumulation passes).
+__global__ void __launch_bounds__(256) k_pwc_cat_tail(const float* __restrict__ c1, const float* __restrict__ flow,
+                                                      float* __restrict__ x, int C, long HW, long xbs, int vec) {
+  // planes 81 .. 81+C-1 <- c1, 81+C .. 81+C+1 <- flow; grid.y = sample
+  const int b = blockIdx.y;
+  const long n = static_cast<long>(C + 2) * HW;
+  float* dst = x + static_cast<long>(b) * xbs + static_cast<long>(CR_K) * CR_K * HW;
+  const float* s1 = c1 + static_cast<long>(b) * C * HW;
+  const float* s2 = flow + static_cast<long>(b) * 2 * HW;
+  const long split = static_cast<long>(C) * HW;
+  if (vec) {
+    const long i = (static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float4 v = (i < split) ? *reinterpret_cast<const float4*>(s1 + i) : *reinterpret_cast<const float4*>(s2 + (i - split));
+    *reinterpret_cast<float4*>(dst + i) = v;
+  } else {
+    const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    dst[i] = (i < split) ? s1[i] : s2[i - split];
+  }
+}
+
+int dfe_pwc_level_channels(int C) { return CR_K * CR_K + C + 2; }
+
+int dfe_pwc_level_fwd(const float* c1, const float* c2, const float* flow, float* warped, float* x, int B, int C, int H,
+                      int W, int align_corners, void* stream) {
+  DFE_REQUIRE(c1 && c2 && flow && warped && x, DFE_ERR_NULL);
+  DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
+  DFE_REQUIRE(B <= 65535 && (C + WF_CK - 1) / WF_CK <= 65535, DFE_ERR_DIMS);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int nchunk = (C + CR_CK - 1) / CR_CK;
-  const bool vec = corr_vec_ok(f1, f2, gout, W) && corr_vec_ok(g1, g2, nullptr, W);
-  const long n = static_cast<long>(B) * nchunk * H * (W / 4), nn = static_cast<long>(B) * C * H * W;
-  if (g1) {
-    if (vec) k_corr_bwd<4, 0><<<grid1d(n, 256), 256, 0, st>>>(f2, gout, g1, B, C, H, W);
-    else k_corr_bwd_naive<0><<<grid1d(nn, 256), 256, 0, st>>>(f2, gout, g1, B, C, H, W);
-    DFE_LAUNCH_CHECK();
-  }
-  if (g2) {
-    if (vec) k_corr_bwd<4, 1><<<grid1d(n, 256), 256, 0, st>>>(f1, gout, g2, B, C, H, W);
-    else k_corr_bwd_naive<1><<<grid1d(nn, 256), 256, 0, st>>>(f1, gout, g2, B, C, H, W);
-    DFE_LAUNCH_CHECK();
-  }
+  const long HW = static_cast<long>(H) * W, xbs = static_cast<long>(dfe_pwc_level_channels(C)) * HW;
+  dim3 gw(static_cast<unsigned>((HW + 63) / 64), (C + WF_CK - 1) / WF_CK, B);
+  k_warp_flow_fwd<<<gw, 64, 0, st>>>(c2, flow, warped, C, H, W, 0, align_corners);
+  DFE_LAUNCH_CHECK();
+  launch_corr_fwd(c1, warped, x, xbs, B, C, H, W, st);
+  DFE_LAUNCH_CHECK();
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const int vec = (HW % 4 == 0) && al(c1) && al(flow) && al(x);
+  const long n = static_cast<long>(C + 2) * HW;
+  dim3 gt(static_cast<unsigned>(((vec ? (n + 3) / 4 : n) + 255) / 256), B);
+  k_pwc_cat_tail<<<gt, 256, 0, st>>>(c1, flow, x, C, HW, xbs, vec);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+int dfe_pwc_level_bwd(const float* c1, const float* c2, const float* flow, const float* warped, const float* gx,
+                      float* g_warped, float* g_c1, float* g_c2, float* g_flow, int B, int C, int H, int W,
+                      int align_corners, void* stream) {
+  DFE_REQUIRE(c1 && c2 && flow && warped && gx && g_warped && g_c1, DFE_ERR_NULL);
+  DFE_REQUIRE(g_c2 || g_flow, DFE_ERR_NULL);
+  DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
+  DFE_REQUIRE(B <= 65535, DFE_ERR_DIMS);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long HW = static_cast<long>(H) * W, xbs = static_cast<long>(dfe_pwc_level_channels(C)) * HW;
+  const float* gx_c1 = gx + static_cast<long>(CR_K) * CR_K * HW;
+  const float* gx_flow = gx_c1 + static_cast<long>(C) * HW;
+  // dL/dc1 = correlation gradient + the concatenated copy's slice; dL/dwarped
+  launch_corr_bwd(c1, warped, gx, xbs, gx_c1, xbs, g_c1, g_warped, B, C, H, W, st);
+  DFE_LAUNCH_CHECK();
+  if (g_c2 && hipMemsetAsync(g_c2, 0, sizeof(float) * B * C * HW, st) != hipSuccess) return DFE_ERR_LAUNCH;
+  dim3 g(static_cast<unsigned>((HW + 63) / 64), 1, B);
+  k_warp_flow_bwd<<<g, 64 * WF_GROUPS, 0, st>>>(c2, flow, g_warped, g_flow, g_c2, g_flow ? gx_flow : nullptr, xbs, C, H, W, 0, align_corners);
+  DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
 

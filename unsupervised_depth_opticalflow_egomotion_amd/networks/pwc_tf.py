@@ -1,5 +1,6 @@
-"""PWC-style coarse-to-fine flow decoder (reference pwc_tf.py:16-179).  The per-level feature warp and
-the 81-tap cost volume run the HIP kernels (k_warp_flow_*, k_corr_*); the convolutions run on MIOpen.
+"""PWC-style coarse-to-fine flow decoder (reference pwc_tf.py:16-179).  The per-level feature warp, the 81-tap
+cost volume and the concatenation behind them run as one HIP operator per level (k_warp_flow_*, k_corr_*,
+k_pwc_cat_tail); the convolutions run on MIOpen.
 Needs H and W divisible by 64."""
 import torch
 import torch.nn as nn
@@ -44,6 +45,16 @@ class PWC_tf(nn.Module):
         """81-displacement channel-mean correlation [B,(2d+1)^2,H,W] (HIP)."""
         return ops.corr81(input1, input2, d)
 
+    def level_input(self, c1, c2, up_flow):
+        """``torch.cat((self.corr(c1, self.warp(c2, up_flow)), c1, up_flow), 1)`` (pwc_tf.py:119-121, repeated per level).
+        On the GPU the triple is one operator (``dfe_pwc_level_fwd/bwd``): the cost volume is written into its slice
+        of the concatenated tensor and the backward pass reads the slices of its gradient in place.  A subclass that
+        replaces ``warp`` / ``corr_naive`` (the CPU baseline does) gets the plain composition of its own methods."""
+        own = type(self).warp is PWC_tf.warp and getattr(self.corr, "__func__", None) is PWC_tf.corr_naive
+        if own and c1.is_cuda:
+            return ops.pwc_level_input(c1, c2, up_flow)
+        return torch.cat((self.corr(c1, self.warp(c2, up_flow)), c1, up_flow), 1)
+
     def _decode(self, lvl, x):
         x0 = getattr(self, "conv%d_0" % lvl)(x)
         x1 = getattr(self, "conv%d_1" % lvl)(x0)
@@ -60,8 +71,7 @@ class PWC_tf(nn.Module):
         x4 = None
         for lvl in (5, 4, 3, 2):
             up = F.interpolate(flows[lvl + 1], scale_factor=2.0, mode="bilinear", align_corners=False) * 2.0
-            cv = self.corr(c1[lvl], self.warp(c2[lvl], up))
-            delta, x4 = self._decode(lvl, torch.cat((cv, c1[lvl], up), 1))
+            delta, x4 = self._decode(lvl, self.level_input(c1[lvl], c2[lvl], up))
             flows[lvl] = delta + up
         x = self.dc_conv4(self.dc_conv3(self.dc_conv2(self.dc_conv1(torch.cat([flows[2], x4], 1)))))
         flows[2] = flows[2] + self.dc_conv7(self.dc_conv6(self.dc_conv5(x)))

@@ -243,6 +243,44 @@ def corr81(f1, f2, d=4):
     return CorrFn.apply(f1, f2, int(d))
 
 
+class PwcLevelInputFn(torch.autograd.Function):
+    """x = cat(corr(c1, warp(c2, flow)), c1, flow) of one PWC decoder level (pwc_tf.py:119-121) as one operator."""
+
+    @staticmethod
+    def forward(ctx, c1, c2, flow, align_corners):
+        lib = get_lib()
+        c1, c2, flow = f32c(c1), f32c(c2), f32c(flow)
+        B, C, H, W = c1.shape
+        warped = torch.empty_like(c2)
+        x = torch.empty(B, lib.dfe_pwc_level_channels(C), H, W, device=c1.device, dtype=torch.float32)
+        check(lib.dfe_pwc_level_fwd(ptr(c1), ptr(c2), ptr(flow), ptr(warped), ptr(x), B, C, H, W, align_corners,
+                                    stream_ptr()), "dfe_pwc_level_fwd")
+        ctx.save_for_backward(c1, c2, flow, warped)
+        ctx.ac = align_corners
+        return x
+
+    @staticmethod
+    def backward(ctx, gx):
+        lib = get_lib()
+        c1, c2, flow, warped = ctx.saved_tensors
+        B, C, H, W = c1.shape
+        gx = f32c(gx)
+        g_c1 = torch.empty_like(c1)
+        g_c2 = torch.empty_like(c2) if ctx.needs_input_grad[1] else None    # zero-filled by the library
+        g_flow = torch.empty_like(flow) if (ctx.needs_input_grad[2] or g_c2 is None) else None
+        g_warped = torch.empty_like(c2)
+        check(lib.dfe_pwc_level_bwd(ptr(c1), ptr(c2), ptr(flow), ptr(warped), ptr(gx), ptr(g_warped), ptr(g_c1),
+                                    ptr(g_c2), ptr(g_flow), B, C, H, W, ctx.ac, stream_ptr()), "dfe_pwc_level_bwd")
+        return g_c1, g_c2, (g_flow if ctx.needs_input_grad[2] else None), None
+
+
+def pwc_level_input(c1, c2, flow, align_corners=None):
+    """``torch.cat((corr(c1, warp(c2, flow)), c1, flow), 1)`` [B, 81+C+2, H, W]."""
+    if c1.shape != c2.shape or tuple(flow.shape) != (c1.shape[0], 2, c1.shape[2], c1.shape[3]):
+        raise ValueError("pwc_level_input: c1 %s, c2 %s, flow %s" % (tuple(c1.shape), tuple(c2.shape), tuple(flow.shape)))
+    return PwcLevelInputFn.apply(c1, c2, flow, _ac(align_corners))
+
+
 # --------------------------------------------------------------------------- resize (no grad)
 def resize(img, out_hw, mode):
     """mode 'bilinear' (align_corners=False) or 'area'; images carry no gradient on this path."""
