@@ -234,7 +234,13 @@ int dfe_bias_act_bwd(const float* y, const float* gy, long gy_batch_stride, floa
 #define DFE_LOSS_FLOW_CONSIS 5
 #define DFE_LOSS_DEPTH_FLOW_CONSIS 6
 #define DFE_LOSS_EPIPOLAR 7
-#define DFE_NUM_LOSSES 8
+/* the two depth terms the reference ships commented out (model_geometry.py:889-891,897-899):
+ * rows 8 / 9 are written (and differentiated) only when the matching bit of dfe_geom_args.depth_terms is set, 0 otherwise */
+#define DFE_LOSS_DEPTH_SSIM 8
+#define DFE_LOSS_DEPTH_CONSIS 9
+#define DFE_NUM_LOSSES 10
+#define DFE_DEPTH_TERM_SSIM 1    /* compute_ssim_loss(img_list, reconstructed_imgs_from_{l,r}, {bwd,fwd}_mask_texture) */
+#define DFE_DEPTH_TERM_CONSIS 2  /* compute_consis_loss(predicted_depths_to_{l,r}, computed_depths_to_{l,r}, ..._mask_texture), model_geometry.py:182-193 */
 
 /* mask pack: one byte per pixel of every scale, [scale][B][Hs*Ws] */
 #define DFE_MASK_VALID_BWD 0x01
@@ -268,6 +274,10 @@ typedef struct dfe_geom_args {
   float* grad_disp[3][DFE_MAX_SCALES]; /* backward out, same shapes as disp (NULL = skip) */
   float* grad_flow[2][DFE_MAX_SCALES]; /* backward out, same shapes as flow (NULL = skip) */
   float* grad_pose;          /* backward out [B,2,6] (NULL = skip) */
+  int depth_terms;           /* mode 0 only: DFE_DEPTH_TERM_* bits; 0 = the reference as shipped.  With
+                                DFE_DEPTH_TERM_CONSIS the SOURCE disparities grad_disp[0], grad_disp[2] also receive the
+                                gradient of the projected depth (a bilinear scatter: float atomics, reproducible to
+                                rounding only); everything else stays bitwise reproducible. */
 } dfe_geom_args;
 
 long dfe_geom_workspace_floats(const dfe_geom_args* args);

@@ -45,23 +45,25 @@ def to_dev(inp, grad=True):
     return disps, G(inp.pose, grad), [G(a, grad) for a in inp.flows_bwd], [G(a, grad) for a in inp.flows_fwd]
 
 
-def run_hip(inp, ac, S, weights=None):
+def run_hip(inp, ac, S, weights=None, depth_terms=False):
     from unsupervised_depth_opticalflow_egomotion_amd.loss_stack import geom_loss_stack
     disps, pose, fb, ff = to_dev(inp)
     il, it, ir = [G(a) for a in inp.imgs]
     lp, masks = geom_loss_stack(il, it, ir, disps[0], disps[1], disps[2], pose, fb, ff, G(inp.K), G(inp.K_inv),
-                                num_scales=S, align_corners=ac, return_masks=True)
+                                num_scales=S, align_corners=ac, return_masks=True, enable_depth_ssim=depth_terms,
+                                enable_depth_consis=depth_terms)
     w = weights or MG.GEOM_WEIGHTS
     total = sum(w[k] * v.mean() for k, v in lp.items())
     total.backward()
     return lp, masks, total, (disps, pose, fb, ff)
 
 
-def run_oracle(inp, ac, S, weights=None):
+def run_oracle(inp, ac, S, weights=None, depth_terms=False):
     m = O.GeomLossOracle(num_scales=S, align_corners=ac)
     disps, pose, fb, ff = MG.lists_to_t(inp, True)
     il, it, ir = [T(a) for a in inp.imgs]
-    lp, masks = m.geom_losses(il, it, ir, disps[0], disps[1], disps[2], pose, fb, ff, T(inp.K), T(inp.K_inv))
+    lp, masks = m.geom_losses(il, it, ir, disps[0], disps[1], disps[2], pose, fb, ff, T(inp.K), T(inp.K_inv),
+                              enable_depth_ssim=depth_terms, enable_depth_consis=depth_terms)
     w = weights or MG.GEOM_WEIGHTS
     total = sum(w[k] * v.mean() for k, v in lp.items())
     total.backward()
@@ -92,9 +94,10 @@ def check_masks(mk_h, mk_o, margins, S, strict, names=MASKS):
     return nflip, npx, within
 
 
-def compare(inp, ac, S, weights=None, strict=False):
-    lp_h, mk_h, tot_h, (dh, ph, fbh, ffh) = run_hip(inp, ac, S, weights)
-    lp_o, mk_o, tot_o, (do, po, fbo, ffo) = run_oracle(inp, ac, S, weights)
+def compare(inp, ac, S, weights=None, strict=False, depth_terms=False):
+    lp_h, mk_h, tot_h, (dh, ph, fbh, ffh) = run_hip(inp, ac, S, weights, depth_terms)
+    lp_o, mk_o, tot_o, (do, po, fbo, ffo) = run_oracle(inp, ac, S, weights, depth_terms)
+    assert ("loss_depth_ssim" in lp_h) == depth_terms and ("loss_depth_consis" in lp_h) == depth_terms
     nflip, npx, _ = check_masks(mk_h, mk_o, M.geom_margins(inp, ac, S), S, strict)
     for k in lp_h:
         np.testing.assert_allclose(N(lp_h[k]), N(lp_o[k]), rtol=5e-6 + 4.0 * nflip / npx, atol=1e-7, err_msg=k)
@@ -126,6 +129,19 @@ def test_fused_stack_vs_oracle(shape, ac):
     b, h, w = shape
     inp = synthetic.make_loss_stack_inputs(b, h, w, 3, seed=STRICT[shape])
     compare(inp, ac, 3, strict=True)
+
+
+@pytest.mark.parametrize("ac", [False, True])
+@pytest.mark.parametrize("shape", [(2, 128, 448), (4, 256, 832)])
+def test_fused_stack_with_depth_terms_vs_oracle(shape, ac):
+    """dfe_geom_args.depth_terms: all ten loss vectors -- the eight active ones plus the depth
+    SSIM and depth-consistency terms the reference keeps commented (model_geometry.py:889-891,897-899), weighted as
+    the reference's config weights them -- and the gradients of their sum (incl. the source disparities, which only
+    the consistency term reaches through the sampled projected depth) against the oracle, same tolerances."""
+    b, h, w = shape
+    strict = shape in STRICT
+    inp = synthetic.make_loss_stack_inputs(b, h, w, 3, seed=STRICT.get(shape, 1234))
+    compare(inp, ac, 3, strict=strict, depth_terms=True)
 
 
 @pytest.mark.parametrize("ac", [False, True])

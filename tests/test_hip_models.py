@@ -217,10 +217,45 @@ def test_disabled_depth_terms_vs_reference(golden_dir, ac):
             ref = g["gdisp_%d_%d" % (f, s)]
             got = N(disps[f][s].grad) if disps[f][s].grad is not None else np.zeros_like(ref)
             assert np.abs(got - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-12) + 1e-9, (f, s)
-    # with the flags off the two entries are the reference's (2,)-shaped placeholders
+    # with the flags off the two entries are the reference's (2,)-shaped placeholders, and switching the flags on
+    # leaves every other loss vector bit-identical (the terms ride along in the same launches)
     m.enable_depth_ssim = m.enable_depth_consis = False
-    lp0, _ = m.loss_stack(*[G(a) for a in inp.imgs], disps[0], disps[1], disps[2], pose, fb, ff, G(inp.K), G(inp.K_inv))
-    assert float(lp0["loss_depth_ssim"].abs().sum()) == 0.0 and lp0["loss_depth_consis"].shape == (2,)
+    ops.set_align_corners(ac)
+    try:
+        lp0, _ = m.loss_stack(*[G(a) for a in inp.imgs], disps[0], disps[1], disps[2], pose, fb, ff, G(inp.K), G(inp.K_inv))
+        assert float(lp0["loss_depth_ssim"].detach().abs().sum()) == 0.0 and lp0["loss_depth_consis"].shape == (2,)
+        for k in lp0:
+            if k not in ("loss_depth_ssim", "loss_depth_consis"):
+                assert torch.equal(lp0[k], lp[k]), k
+        # each flag alone, and the per-operator composition (inverse_warp2 + SSIM + resize kernels under autograd,
+        # Model_geometry.disabled_depth_terms) as a cross-check of values and of all three gradients
+        from unsupervised_depth_opticalflow_egomotion_amd.loss_stack import geom_loss_stack
+        for ssim_on, consis_on in ((True, False), (False, True)):
+            d1 = [[G(a, True) for a in lst] for lst in inp.disps]
+            p1 = G(inp.pose, True)
+            pk, handle = geom_loss_stack(*[G(a) for a in inp.imgs], d1[0], d1[1], d1[2], p1, fb, ff, G(inp.K), G(inp.K_inv),
+                                         num_scales=3, return_masks="lazy", enable_depth_ssim=ssim_on,
+                                         enable_depth_consis=consis_on)
+            key = "loss_depth_ssim" if ssim_on else "loss_depth_consis"
+            assert ("loss_depth_ssim" in pk) == ssim_on and ("loss_depth_consis" in pk) == consis_on
+            assert torch.equal(pk[key], lp[key])
+            pk[key].mean().backward()
+            d2 = [[G(a, True) for a in lst] for lst in inp.disps]
+            p2 = G(inp.pose, True)
+            m.enable_depth_ssim, m.enable_depth_consis = ssim_on, consis_on
+            po = m.disabled_depth_terms(*[G(a) for a in inp.imgs], d2[0], d2[1], d2[2], p2, G(inp.K), handle)
+            po[key].mean().backward()
+            np.testing.assert_allclose(N(pk[key]), N(po[key]), rtol=5e-6, atol=1e-7)
+            assert float((p1.grad - p2.grad).abs().max()) <= 2e-5 * float(p2.grad.abs().max())
+            for f in range(3):
+                for sc in range(3):
+                    a_, b_ = d1[f][sc].grad, d2[f][sc].grad
+                    if b_ is None:
+                        assert a_ is None or float(a_.abs().max()) == 0.0
+                        continue
+                    assert float((a_ - b_).abs().max()) <= 1e-4 * max(float(b_.abs().max()), 1e-12) + 1e-9, (key, f, sc)
+    finally:
+        ops.set_align_corners(prev)
 
 
 def test_train_step_runs_and_learns():

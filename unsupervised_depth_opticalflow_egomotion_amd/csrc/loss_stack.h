@@ -45,6 +45,10 @@ struct GeomLayout {
   long o_cams, o_epi, o_pyr, o_area, o_mask, o_yw, o_part, o_spart, o_fpart, o_dpart, o_sums, o_coef, o_dsum,
       o_gw, o_gup, o_bpart, total;
   long pyr_plane;   // floats of one frame's bilinear pyramid levels >= 1 (B*3*sum_{s>=1} N_s)
+  // optional depth terms (dfe_geom_args.depth_terms, mode 0): regions appended after `o_bpart` so that every other
+  // offset (the mask pack's in particular) does not depend on the flag
+  int dt;
+  long o_yr, o_gyr, o_part2, o_spart2, o_sums2;   // masked rigid warps, their SSIM gradient, block / strip partials, sums
 };
 
 // Kernel-argument tables (passed by value).
@@ -65,6 +69,8 @@ struct GeomDev {
   unsigned char* mask[DFE_MAX_SCALES];     // [B][N_s]
   float* yw[DFE_MAX_SCALES];               // [2][B][3][N_s] masked warped images
   float* wgt[DFE_MAX_SCALES];              // mode 2: [2][B][N_s] soft occlusion weights
+  int dt;                                  // DFE_DEPTH_TERM_* bits (mode 0)
+  float* yr[DFE_MAX_SCALES];               // dt & SSIM: [2][B][3][N_s] rigid reconstructions x texture-gated mask
 };
 
 int geom_layout(const dfe_geom_args* a, GeomLayout* L);

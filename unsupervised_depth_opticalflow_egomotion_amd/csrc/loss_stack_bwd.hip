@@ -23,6 +23,9 @@ struct GeomBwd {
   float* gdisp[3][DFE_MAX_SCALES];
   float* gflow[2][DFE_MAX_SCALES];
   float* bpart;         // [B][nblk_total][PB_COUNT]
+  float* gyr[DFE_MAX_SCALES];    // depth-SSIM term: dL/d(masked rigid reconstruction) [2][B][3][N_s]
+  int rmw_all;          // depth-consistency term: grad_disp of the SOURCE frames already holds the projected-depth
+                        // scatter when the smoothness kernels run -> they add instead of store
 };
 
 __device__ __forceinline__ float sgn(float v) { return static_cast<float>(v > 0.0f) - static_cast<float>(v < 0.0f); }
@@ -65,7 +68,7 @@ __device__ __forceinline__ void ssim_grad_store(const CoefH& a, const CoefH& bq,
   }
 }
 
-__global__ void __launch_bounds__(64) k_geom_ssim_bwd_roll(GeomDev D, GeomBwd G) {
+__global__ void __launch_bounds__(64) k_geom_ssim_bwd_roll(GeomDev D, GeomBwd G, int rigid) {
   const unsigned nunit_total = D.rollb_start[D.S];
   const unsigned unit = xcd_swizzle(blockIdx.x, nunit_total);
   const int b = blockIdx.y >> 1, d = blockIdx.y & 1;
@@ -75,13 +78,14 @@ __global__ void __launch_bounds__(64) k_geom_ssim_bwd_roll(GeomDev D, GeomBwd G)
   const int strip = u % D.rollb_strips[s], rb = u / D.rollb_strips[s];
   const int x = strip * RSB_COLS + static_cast<int>(threadIdx.x) - 2, y0 = rb * RSB_ROWS, yend = min(y0 + RSB_ROWS, H);
   const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
-  const float* yw = D.yw[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
+  const float* yw = (rigid ? D.yr[s] : D.yw[s]) + (static_cast<long>(d) * D.B + b) * 3 * N;
   const unsigned char* mk = D.mode == 2 ? reinterpret_cast<const unsigned char*>(D.wgt[s] + (static_cast<long>(d) * D.B + b) * N)
                                         : D.mask[s] + static_cast<long>(b) * N;
-  const unsigned need = D.mode == 2 ? 0u : (DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD) << d;
-  float* gw = G.gw[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
-  const float gscale = -0.5f * G.gl[DFE_LOSS_FLOW_SSIM * D.B + b] *
-                       G.coef[(static_cast<long>(b) * D.S + s) * CF_COUNT + d * CF_PER_DIR + CF_VO];
+  const unsigned need = D.mode == 2 ? 0u : (rigid ? DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD | DFE_MASK_DYNA_BWD | DFE_MASK_TEX_BWD
+                                                   : DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD) << d;
+  float* gw = (rigid ? G.gyr[s] : G.gw[s]) + (static_cast<long>(d) * D.B + b) * 3 * N;
+  const float gscale = -0.5f * G.gl[(rigid ? DFE_LOSS_DEPTH_SSIM : DFE_LOSS_FLOW_SSIM) * D.B + b] *
+                       G.coef[(static_cast<long>(b) * D.S + s) * CF_COUNT + d * CF_PER_DIR + (rigid ? CF_DEPTH : CF_VO)];
   const bool col_in = x >= 0 && x < W;
   const bool lane_ok = threadIdx.x >= 2 && threadIdx.x <= RSB_COLS + 1 && col_in;
   // prologue: row sums of rows y0-2, y0-1, y0; coefficient sums of rows y0-1 (and y0 inside the loop)
@@ -138,6 +142,10 @@ __global__ void __launch_bounds__(64) k_geom_ssim_bwd_roll(GeomDev D, GeomBwd G)
 }
 
 // ---------------------------------------------------------------------- pointwise backward
+// DT: + the two optional depth terms (dfe_geom_args.depth_terms): dL/d(rigid reconstruction) of the SSIM launch over
+// the rigid warps (G.gyr), and the depth-consistency term's gradient wrt the computed depth (the projection's Z), the
+// rigid coordinate (through the sampled source disparity) and the source disparity itself (bilinear scatter, atomics).
+template <bool DT>
 __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomT T, GeomBwd G) {
   __shared__ float red[PB_COUNT * 4 * (GS_BLOCK / 64)];
   const unsigned nblk_total = D.blk_start[D.S];
@@ -201,7 +209,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomT T,
       // ---- rigid branch
       const Camera& cam = D.cams[(b * 2 + d) * D.S + s];
       Proj pr = project_fast(cam, px, py, dsp);
-      float gU = 0.0f, gV = 0.0f;
+      float gU = 0.0f, gV = 0.0f, gZ = 0.0f;
       if (m_tex != 0.0f) {
         float xn, yn; bool lx, ly;
         rigid_grid_d(pr, dw, dh, xn, yn, lx, ly);
@@ -214,8 +222,33 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomT T,
           Corners q = load_corners(ar + static_cast<long>(c) * N, t, W, H);
           float dx, dy;
           interp_grad(q, t, dx, dy);
-          const float g = sgn(interp(q, t) - im[c]) * gc;
+          float g = sgn(interp(q, t) - im[c]) * gc;
+          if (DT && (D.dt & DFE_DEPTH_TERM_SSIM)) g += G.gyr[s][(static_cast<long>(d) * B + b) * 3 * N + static_cast<long>(c) * N + p];
           gix += g * dx; giy += g * dy;
+        }
+        if (DT && (D.dt & DFE_DEPTH_TERM_CONSIS)) {
+          // q = |cd - pd| / |cd + pd| clamped to [0,1] (gradient passes on the closed interval, like torch.clamp)
+          const int fs = d == 0 ? 0 : 2;
+          const Corners qd = load_corners(D.disp[fs][s] + static_cast<long>(b) * N, t, W, H);
+          const float v = interp(qd, t);
+          const float pd = (v >= 1e-3f || v != v) ? v : 1e-3f, cd = pr.Z;
+          const float num = cd - pd, den = cd + pd, qv = fabsf(num) / fabsf(den);
+          if (qv >= 0.0f && qv <= 1.0f) {
+            const float gq = G.gl[DFE_LOSS_DEPTH_CONSIS * B + b] * 3.0f * cf[d * CF_PER_DIR + CF_DEPTH];   // 1 / (N n_tex)
+            const float a = sgn(num) / fabsf(den), bq = qv * sgn(den) / fabsf(den);
+            gZ = gq * (a - bq);                       // d q / d cd
+            const float gp = (v >= 1e-3f) ? gq * (-a - bq) : 0.0f;   // d q / d pd, cut by the clamp(min=1e-3)
+            float dx, dy;
+            interp_grad(qd, t, dx, dy);
+            gix += gp * dx; giy += gp * dy;
+            if (G.gdisp[fs][s] && gp != 0.0f) {
+              float* base = G.gdisp[fs][s] + static_cast<long>(b) * N + static_cast<long>(t.y0) * W + t.x0;
+              if (t.in_nw) atomicAdd(base, gp * t.nw);
+              if (t.in_ne) atomicAdd(base + 1, gp * t.ne);
+              if (t.in_sw) atomicAdd(base + W, gp * t.sw);
+              if (t.in_se) atomicAdd(base + W + 1, gp * t.se);
+            }
+          }
         }
         const float sx = D.ac ? static_cast<float>(W - 1) / 2.0f : static_cast<float>(W) / 2.0f;
         const float sy = D.ac ? static_cast<float>(H - 1) / 2.0f : static_cast<float>(H) / 2.0f;
@@ -247,7 +280,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomT T,
         aF[6] = dl2 * x1; aF[7] = dl2 * y1; aF[8] = dl2;
       }
       float gd;
-      project_backward(pr, dsp, gU, gV, 0.0f, gd, acc + d * PB_PER_DIR);
+      project_backward(pr, dsp, gU, gV, gZ, gd, acc + d * PB_PER_DIR);
       gdisp += gd;
       if (d == 1) {
         // flow consistency: only the forward flow carries gradient (bwd is detached)
@@ -545,7 +578,7 @@ __global__ void __launch_bounds__(64) k_geom_disp_smooth_bwd1(GeomDev D, GeomBwd
       if (store) {
         if (s == 0) {
           float* o = G.gdisp[f][0];
-          if (o) { if (f == 1) o[static_cast<long>(b) * N + p] += gsum; else o[static_cast<long>(b) * N + p] = gsum; }
+          if (o) { if (f == 1 || G.rmw_all) o[static_cast<long>(b) * N + p] += gsum; else o[static_cast<long>(b) * N + p] = gsum; }
         } else {
           G.gup[((static_cast<long>(f) * (D.S - 1) + (s - 1)) * D.B + b) * N + p] = gsum;
         }
@@ -604,7 +637,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_bwd2(GeomDev D, G
     total += wy[ky] * acc;
   }
   float* o = G.gdisp[f][s] + static_cast<long>(b) * Ns + q;
-  if (f == 1) *o += total; else *o = total;
+  if (f == 1 || G.rmw_all) *o += total; else *o = total;
 }
 
 // Coarse scales (ratio < 1/4, footprints of up to (2^(s+1)+4)^2 full-res pixels per low-res pixel): a group of
@@ -717,7 +750,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_bwd2_coarse(GeomD
   else t = (r0 + r1) + (r2 + r3);
   if (mine && lx == 0) {
     float* o = G.gdisp[f][s] + static_cast<long>(b) * Ns + q;
-    if (f == 1) *o += t; else *o = t;
+    if (f == 1 || G.rmw_all) *o += t; else *o = t;
   }
 }
 
@@ -807,12 +840,18 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     for (int f = 0; f < 3; ++f) G.gdisp[f][s] = (s < L.S) ? a->grad_disp[f][s] : nullptr;
     for (int d = 0; d < 2; ++d) G.gflow[d][s] = (s < L.S) ? a->grad_flow[d][s] : nullptr;
   }
+  for (int s = 0; s < DFE_MAX_SCALES; ++s) G.gyr[s] = (s < L.S) ? ws + L.o_gyr + 6L * L.B * L.off_px[s] : nullptr;
+  G.rmw_all = (L.dt & DFE_DEPTH_TERM_CONSIS) ? 1 : 0;
   const unsigned nblk_total = L.blk_start[L.S];
   int seg = 0;
 #define DFE_MARK() do { if (ev) (void)hipEventRecord(ev[++seg], st); } while (0)
   if (ev) (void)hipEventRecord(ev[0], st);
+  if (G.rmw_all)   // the projected-depth scatter accumulates into the source frames' disparity gradients
+    for (int f = 0; f < 3; f += 2)
+      for (int s = 0; s < L.S; ++s)
+        if (a->grad_disp[f][s] && hipMemsetAsync(a->grad_disp[f][s], 0, sizeof(float) * L.B * L.N[s], st) != hipSuccess) return DFE_ERR_LAUNCH;
   if (a->mode == 2) {
-    k_geom_ssim_bwd_roll<<<dim3(L.rollb_start[L.S], L.B * 2), 64, 0, st>>>(D, G);
+    k_geom_ssim_bwd_roll<<<dim3(L.rollb_start[L.S], L.B * 2), 64, 0, st>>>(D, G, 0);
     DFE_LAUNCH_CHECK();
     DFE_MARK();
     k_flow_point_bwd<<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, G);
@@ -829,10 +868,15 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     DFE_LAUNCH_CHECK();
     DFE_MARK(); DFE_MARK();
   } else {
-    k_geom_ssim_bwd_roll<<<dim3(L.rollb_start[L.S], L.B * 2), 64, 0, st>>>(D, G);
+    k_geom_ssim_bwd_roll<<<dim3(L.rollb_start[L.S], L.B * 2), 64, 0, st>>>(D, G, 0);
     DFE_LAUNCH_CHECK();
+    if (L.dt & DFE_DEPTH_TERM_SSIM) {
+      k_geom_ssim_bwd_roll<<<dim3(L.rollb_start[L.S], L.B * 2), 64, 0, st>>>(D, G, 1);
+      DFE_LAUNCH_CHECK();
+    }
     DFE_MARK();
-    k_geom_point_bwd<<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, T, G);
+    if (L.dt) k_geom_point_bwd<true><<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, T, G);
+    else k_geom_point_bwd<false><<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, T, G);
     DFE_LAUNCH_CHECK();
     DFE_MARK();
     k_geom_flow_smooth_bwd<<<dim3(L.rollb_start[L.S], L.B), 64, 0, st>>>(D, G);

@@ -72,6 +72,12 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
   L->o_gw = o; o = align4(o + 2 * B * 3 * sumN);
   L->o_gup = o; o = align4(o + 3 * (S - 1) * B * static_cast<long>(L->N[0]));
   L->o_bpart = o; o = align4(o + B * nblk_total * PB_COUNT);
+  L->dt = (a->mode == 0) ? (a->depth_terms & (DFE_DEPTH_TERM_SSIM | DFE_DEPTH_TERM_CONSIS)) : 0;
+  L->o_yr = o; o = align4(o + ((L->dt & DFE_DEPTH_TERM_SSIM) ? 2 * B * 3 * sumN : 0));
+  L->o_gyr = o; o = align4(o + ((L->dt & DFE_DEPTH_TERM_SSIM) ? 2 * B * 3 * sumN : 0));
+  L->o_part2 = o; o = align4(o + (L->dt ? B * nblk_total * 2 : 0));
+  L->o_spart2 = o; o = align4(o + ((L->dt & DFE_DEPTH_TERM_SSIM) ? B * 2 * static_cast<long>(L->roll_start[S]) : 0));
+  L->o_sums2 = o; o = align4(o + (L->dt ? B * S * 4 : 0));
   L->total = o;
   return DFE_OK;
 }
@@ -102,7 +108,9 @@ void geom_dev(const dfe_geom_args* a, const GeomLayout& L, GeomDev* D) {
     D->mask[s] = reinterpret_cast<unsigned char*>(ws + L.o_mask) + static_cast<long>(L.B) * L.off_px[s];
     D->yw[s] = ws + L.o_yw + 6L * L.B * L.off_px[s];
     D->wgt[s] = ws + L.o_wgt + 2L * L.B * L.off_px[s];
+    D->yr[s] = ws + L.o_yr + 6L * L.B * L.off_px[s];
   }
+  D->dt = L.dt;
   D->cams = reinterpret_cast<const Camera*>(ws + L.o_cams);
   D->epi = reinterpret_cast<const Epi*>(ws + L.o_epi);
 }
@@ -257,6 +265,7 @@ struct PointCtx {
   unsigned N4;
   float alpha, beta;
   const float *srcL, *srcR, *areaL, *areaR;   // block-uniform plane bases of this sample
+  const float *dispL, *dispR;                  // DT: the source frames' disparity planes of this sample and scale
   const Camera* cam;                           // cams[(b*2+0)*S + s], direction stride S
   int cam_stride;
   const Epi* epi;                              // epi[b*2]
@@ -265,8 +274,13 @@ struct PointCtx {
 
 struct PixIn { float i0, i1, i2, fu[2], fv[2], dsp, sl[3], sr[3]; };
 
+// DT: also the two depth terms the reference keeps commented (model_geometry.py:889-891,897-899): yr = rigid
+// reconstruction x texture-gated mask (for the SSIM launch over it) and dc = clamp(|cd - pd| / |cd + pd|, 0, 1) x mask
+// with cd = the projection's Z and pd = the source disparity sampled at the rigid coordinate, clamp(min=1e-3)
+// (inverse_warp.py:259-262; the reference passes its disparities as "depth", model_geometry.py:807-810).
+template <bool DT>
 __device__ __forceinline__ void point_pixel(const PointCtx& c, int px, int py, const PixIn& in, float (&yw)[2][3],
-                                            unsigned& bits, float (&acc)[PT_COUNT]) {
+                                            unsigned& bits, float (&acc)[PT_COUNT], float (&yr)[2][3], float (&dc)[2]) {
   const int H = c.H, W = c.W;
   float wv[2][3], dif[2];
   bool valid[2];
@@ -306,6 +320,13 @@ __device__ __forceinline__ void point_pixel(const PointCtx& c, int px, int py, c
     const float vo = (valid[d] && occ[d]) ? 1.0f : 0.0f;
     const float m_rig = dyna ? vo : 0.0f, m_dyn = dyna ? 0.0f : vo;
     const float m_tex = tex ? m_rig : 0.0f;
+    if (DT) {
+      yr[d][0] = rec[0] * m_tex; yr[d][1] = rec[1] * m_tex; yr[d][2] = rec[2] * m_tex;
+      const float v = fast_sample(d == 0 ? c.dispL : c.dispR, t);
+      const float pd = (v >= 1e-3f || v != v) ? v : 1e-3f;
+      const float q = fabsf(pr.Z - pd) / fabsf(pr.Z + pd);
+      dc[d] = fminf(fmaxf(q, 0.0f), 1.0f) * m_tex;
+    }
     const float l1_rec = (fabsf(in.i0 - rec[0]) + fabsf(in.i1 - rec[1])) + fabsf(in.i2 - rec[2]);
     const float l1_wrp = (fabsf(in.i0 - wv[d][0]) + fabsf(in.i1 - wv[d][1])) + fabsf(in.i2 - wv[d][2]);
     float* a = acc + d * PT_PER_DIR;
@@ -392,7 +413,8 @@ __device__ __forceinline__ void point_block_sums(float (&acc)[PT_COUNT], float* 
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, GeomT T, float* __restrict__ part) {
+template <bool DT>
+__global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, GeomT T, float* __restrict__ part, float* __restrict__ part2) {
   __shared__ float red[PT_COUNT * 4 * (GS_BLOCK / 64)];
   const unsigned nblk_total = D.blk_start[D.S];
   const unsigned blk = xcd_swizzle(blockIdx.x, nblk_total);
@@ -403,6 +425,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, GeomT T,
   float acc[PT_COUNT];
 #pragma unroll
   for (int i = 0; i < PT_COUNT; ++i) acc[i] = 0.0f;
+  float dc[2] = {0.0f, 0.0f};
   if (p < static_cast<unsigned>(N)) {
     unsigned px, py;
     split_pixel(p, W, T.rW[s], px, py);
@@ -413,6 +436,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, GeomT T,
     c.areaL = D.area[0][s] + static_cast<long>(b) * 3 * N; c.areaR = D.area[1][s] + static_cast<long>(b) * 3 * N;
     c.cam = D.cams + (b * 2) * D.S + s; c.cam_stride = D.S; c.epi = D.epi + b * 2;
     c.dw = T.dw[s]; c.dh = T.dh[s];
+    c.dispL = D.disp[0][s] + static_cast<long>(b) * N; c.dispR = D.disp[2][s] + static_cast<long>(b) * N;
     const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
     const float* flb = D.flow[0][s] + static_cast<long>(b) * 2 * N;
     const float* flf = D.flow[1][s] + static_cast<long>(b) * 2 * N;
@@ -422,18 +446,24 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, GeomT T,
     in.dsp = ldb(D.disp[1][s] + static_cast<long>(b) * N, p4);
     in.sl[0] = ldb(c.srcL, p4); in.sl[1] = ldb(c.srcL, p4 + N4); in.sl[2] = ldb(c.srcL, p4 + 2 * N4);
     in.sr[0] = ldb(c.srcR, p4); in.sr[1] = ldb(c.srcR, p4 + N4); in.sr[2] = ldb(c.srcR, p4 + 2 * N4);
-    float yw[2][3];
+    float yw[2][3], yr[2][3];
     unsigned bits;
-    point_pixel(c, static_cast<int>(px), static_cast<int>(py), in, yw, bits, acc);
+    point_pixel<DT>(c, static_cast<int>(px), static_cast<int>(py), in, yw, bits, acc, yr, dc);
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
       float* ywp = D.yw[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) stb(ywp, p4 + ch * N4, yw[d][ch]);
+      if (DT && (D.dt & DFE_DEPTH_TERM_SSIM)) {
+        float* yrp = D.yr[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) stb(yrp, p4 + ch * N4, yr[d][ch]);
+      }
     }
     (D.mask[s] + static_cast<long>(b) * N)[p] = static_cast<unsigned char>(bits);
   }
   point_block_sums(acc, red, part + (static_cast<long>(b) * nblk_total + blk) * PT_COUNT);
+  if (DT) block_sum<2>(dc, red, part2 + (static_cast<long>(b) * nblk_total + blk) * 2);
 }
 
 // ---------------------------------------------------------------------- depth-only pointwise forward
@@ -557,7 +587,8 @@ __device__ __forceinline__ float ssim_out(const RowSums& r0, const RowSums& r1, 
   return v;
 }
 
-__global__ void __launch_bounds__(64) k_geom_ssim_fwd_roll(GeomDev D, float* __restrict__ spart) {
+// rigid = 1: the depth-SSIM term (dfe_geom_args.depth_terms): rigid reconstructions, mask = valid & occ & dyna & texture
+__global__ void __launch_bounds__(64) k_geom_ssim_fwd_roll(GeomDev D, float* __restrict__ spart, int rigid) {
   __shared__ float red[4];
   const unsigned nunit_total = D.roll_start[D.S];
   const unsigned unit = xcd_swizzle(blockIdx.x, nunit_total);
@@ -568,10 +599,11 @@ __global__ void __launch_bounds__(64) k_geom_ssim_fwd_roll(GeomDev D, float* __r
   const int strip = u % D.roll_strips[s], rb = u / D.roll_strips[s];
   const int x = strip * RS_COLS + static_cast<int>(threadIdx.x) - 1, y0 = rb * RS_ROWS;
   const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
-  const float* yw = D.yw[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
+  const float* yw = (rigid ? D.yr[s] : D.yw[s]) + (static_cast<long>(d) * D.B + b) * 3 * N;
   const unsigned char* mk = D.mode == 2 ? reinterpret_cast<const unsigned char*>(D.wgt[s] + (static_cast<long>(d) * D.B + b) * N)
                                         : D.mask[s] + static_cast<long>(b) * N;
-  const unsigned need = D.mode == 2 ? 0u : (DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD) << d;
+  const unsigned need = D.mode == 2 ? 0u : (rigid ? DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD | DFE_MASK_DYNA_BWD | DFE_MASK_TEX_BWD
+                                                   : DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD) << d;
   const bool lane_ok = threadIdx.x >= 1 && threadIdx.x <= RS_COLS && x < W;
   float acc = 0.0f;
   RowRaw w0 = ssim_load(it, yw, mk, need, y0 - 1, x, H, W, N);
@@ -776,12 +808,39 @@ __global__ void __launch_bounds__(256) k_geom_reduce_fwd(GeomDev D, const float*
   }
 }
 
+// depth terms: fixed-order sums of the consistency block partials and the rigid-SSIM strip partials of one
+// (sample, scale): sums2[(b*S+s)*4 + {0,1}] = SSIM bwd / fwd, + {2,3} = consistency bwd / fwd
+__global__ void __launch_bounds__(256) k_geom_reduce_dt(GeomDev D, const float* __restrict__ part2,
+                                                        const float* __restrict__ spart2, float* __restrict__ sums2) {
+  __shared__ double lds[256][5];
+  const int s = blockIdx.x, b = blockIdx.y, S = D.S, t = threadIdx.x;
+  double a[4] = {0, 0, 0, 0};
+  if (D.dt & DFE_DEPTH_TERM_SSIM)
+    for (int k = D.roll_start[s] + t; k < D.roll_start[s + 1]; k += 256) {
+      a[0] += spart2[static_cast<long>(b * 2) * D.roll_start[S] + k];
+      a[1] += spart2[static_cast<long>(b * 2 + 1) * D.roll_start[S] + k];
+    }
+  if (D.dt & DFE_DEPTH_TERM_CONSIS)
+    for (int k = D.blk_start[s] + t; k < D.blk_start[s + 1]; k += 256) {
+      const float* r = part2 + (static_cast<long>(b) * D.blk_start[S] + k) * 2;
+      a[2] += r[0]; a[3] += r[1];
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) lds[t][i] = a[i];
+  __syncthreads();
+  if (t < 4) {
+    double v = 0.0;
+    for (int k = 0; k < 256; ++k) v += lds[k][t];
+    sums2[(static_cast<long>(b) * S + s) * 4 + t] = static_cast<float>(v);
+  }
+}
+
 __global__ void k_geom_assemble_fwd(GeomDev D, const float* __restrict__ sums, const float* __restrict__ dsum,
-                                    float* __restrict__ coef, float* __restrict__ losses) {
+                                    const float* __restrict__ sums2, float* __restrict__ coef, float* __restrict__ losses) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x, S = D.S, B = D.B;
   if (b >= B) return;
   const double eps = 1e-12;
-  double l_dp = 0, l_fp = 0, l_fs = 0, l_sm = 0, l_fc = 0, l_dfc = 0, l_epi = 0;
+  double l_dp = 0, l_fp = 0, l_fs = 0, l_sm = 0, l_fc = 0, l_dfc = 0, l_epi = 0, l_dss = 0, l_dcs = 0;
   for (int s = 0; s < S; ++s) {
     const double N = D.N[s], H = D.H[s], W = D.W[s];
     const float* sm = sums + (static_cast<long>(b) * S + s) * SUM_COUNT;
@@ -791,6 +850,11 @@ __global__ void k_geom_assemble_fwd(GeomDev D, const float* __restrict__ sums, c
       const double n_tex = a[PT_M_TEX] / N + eps, n_rig = a[PT_M_RIG] / N + eps, n_dyn = a[PT_M_DYN] / N + eps,
                    n_vo = a[PT_M_VO] / N + eps;
       l_dp += (a[PT_L1_DEPTH] / (3.0 * N)) / n_tex;
+      if (sums2) {   // same texture-gated mask and normaliser as the depth pixel term
+        const float* q = sums2 + (static_cast<long>(b) * S + s) * 4;
+        l_dss += (q[d] / (3.0 * N)) / n_tex;
+        l_dcs += (q[2 + d] / N) / n_tex;
+      }
       if (D.mode == 2) l_fp += (a[PT_L1_RIG] / N) / n_vo;   // 1-channel diff broadcast over 3 channels (model_flow.py:94-103)
       else l_fp += (a[PT_L1_RIG] / (3.0 * N)) / n_rig + 2.0 * (a[PT_L1_DYN] / (3.0 * N)) / n_dyn;
       l_fs += (sm[SUM_SSIM + d] / (3.0 * N)) / n_vo;
@@ -822,6 +886,8 @@ __global__ void k_geom_assemble_fwd(GeomDev D, const float* __restrict__ sums, c
   losses[DFE_LOSS_FLOW_CONSIS * B + b] = static_cast<float>(l_fc);
   losses[DFE_LOSS_DEPTH_FLOW_CONSIS * B + b] = static_cast<float>(l_dfc);
   losses[DFE_LOSS_EPIPOLAR * B + b] = static_cast<float>(l_epi);
+  losses[DFE_LOSS_DEPTH_SSIM * B + b] = static_cast<float>(l_dss);
+  losses[DFE_LOSS_DEPTH_CONSIS * B + b] = static_cast<float>(l_dcs);
 }
 
 }  // namespace dfe
@@ -935,7 +1001,7 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     k_flow_point_fwd<<<dim3(L.blk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
     DFE_LAUNCH_CHECK();
     DFE_MARK();
-    k_geom_ssim_fwd_roll<<<dim3(L.roll_start[L.S], L.B * 2), 64, 0, st>>>(D, ws + L.o_spart);
+    k_geom_ssim_fwd_roll<<<dim3(L.roll_start[L.S], L.B * 2), 64, 0, st>>>(D, ws + L.o_spart, 0);
     DFE_LAUNCH_CHECK();
     DFE_MARK();
     k_geom_flow_smooth_fwd<<<dim3(L.fs_start[L.S], L.B), 64, 0, st>>>(D, ws + L.o_fpart);
@@ -947,11 +1013,16 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     DFE_LAUNCH_CHECK();
     DFE_MARK(); DFE_MARK(); DFE_MARK();
   } else {
-    k_geom_point_fwd<<<dim3(L.blk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, T, ws + L.o_part);
+    if (L.dt) k_geom_point_fwd<true><<<dim3(L.blk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, T, ws + L.o_part, ws + L.o_part2);
+    else k_geom_point_fwd<false><<<dim3(L.blk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, T, ws + L.o_part, nullptr);
     DFE_LAUNCH_CHECK();
     DFE_MARK();
-    k_geom_ssim_fwd_roll<<<dim3(L.roll_start[L.S], L.B * 2), 64, 0, st>>>(D, ws + L.o_spart);
+    k_geom_ssim_fwd_roll<<<dim3(L.roll_start[L.S], L.B * 2), 64, 0, st>>>(D, ws + L.o_spart, 0);
     DFE_LAUNCH_CHECK();
+    if (L.dt & DFE_DEPTH_TERM_SSIM) {
+      k_geom_ssim_fwd_roll<<<dim3(L.roll_start[L.S], L.B * 2), 64, 0, st>>>(D, ws + L.o_spart2, 1);
+      DFE_LAUNCH_CHECK();
+    }
     DFE_MARK();
     k_geom_flow_smooth_fwd<<<dim3(L.fs_start[L.S], L.B), 64, 0, st>>>(D, ws + L.o_fpart);
     DFE_LAUNCH_CHECK();
@@ -976,7 +1047,12 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   k_geom_reduce_fwd<<<dim3(L.S + 1, L.B), 256, 0, st>>>(D, ws + L.o_part, ws + L.o_spart, ws + L.o_fpart, ws + L.o_dpart,
                                                      L.dsm_units, ws + L.o_sums, ws + L.o_dsum);
   DFE_LAUNCH_CHECK();
-  k_geom_assemble_fwd<<<(L.B + 63) / 64, 64, 0, st>>>(D, ws + L.o_sums, ws + L.o_dsum, ws + L.o_coef, a->losses);
+  if (L.dt) {
+    k_geom_reduce_dt<<<dim3(L.S, L.B), 256, 0, st>>>(D, ws + L.o_part2, ws + L.o_spart2, ws + L.o_sums2);
+    DFE_LAUNCH_CHECK();
+  }
+  k_geom_assemble_fwd<<<(L.B + 63) / 64, 64, 0, st>>>(D, ws + L.o_sums, ws + L.o_dsum, L.dt ? ws + L.o_sums2 : nullptr,
+                                                      ws + L.o_coef, a->losses);
   DFE_LAUNCH_CHECK();
   DFE_MARK();
 #undef DFE_MARK

@@ -931,6 +931,7 @@ int dfe_corr_bwd(const float* f1, const float* f2, const float* gout, float* g1,
 // ---------------------------------------------------------------- one PWC decoder level's input (pwc_tf.py:119-121)
 // x = cat(corr(c1, warp(c2, flow)), c1, flow): the cost volume is written straight into its slice of x and the
 // backward pass reads the three slices of dL/dx in place (no cat / slice copies, no gradient-accumulation passes).
+namespace dfe {
 __global__ void __launch_bounds__(256) k_pwc_cat_tail(const float* __restrict__ c1, const float* __restrict__ flow,
                                                       float* __restrict__ x, int C, long HW, long xbs, int vec) {
   // planes 81 .. 81+C-1 <- c1, 81+C .. 81+C+1 <- flow; grid.y = sample
@@ -951,6 +952,7 @@ __global__ void __launch_bounds__(256) k_pwc_cat_tail(const float* __restrict__ 
     dst[i] = (i < split) ? s1[i] : s2[i - split];
   }
 }
+}  // namespace dfe
 
 int dfe_pwc_level_channels(int C) { return CR_K * CR_K + C + 2; }
 

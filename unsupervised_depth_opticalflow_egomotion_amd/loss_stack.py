@@ -15,7 +15,8 @@ from ._lib import DfeError, check, f32c, get_lib, stream_ptr
 
 MAX_SCALES = 8
 LOSS_ROWS = ("loss_depth_pixel", "loss_depth_smooth", "loss_flow_pixel", "loss_flow_ssim", "loss_flow_smooth",
-             "loss_flow_consis", "loss_depth_flow_consis", "loss_epipolar")
+             "loss_flow_consis", "loss_depth_flow_consis", "loss_epipolar", "loss_depth_ssim", "loss_depth_consis")
+DEPTH_TERM_SSIM, DEPTH_TERM_CONSIS = 1, 2     # dfe_geom_args.depth_terms bits (rows 8 / 9 of the loss buffer)
 MASK_BITS = dict(valid_bwd=0x01, valid_fwd=0x02, occ_bwd=0x04, occ_fwd=0x08, dyna_bwd=0x10, dyna_fwd=0x20,
                  texture_bwd=0x40, texture_fwd=0x80)
 
@@ -37,6 +38,7 @@ class GeomArgs(ctypes.Structure):
         ("grad_disp", (_FP * MAX_SCALES) * 3),
         ("grad_flow", (_FP * MAX_SCALES) * 2),
         ("grad_pose", _FP),
+        ("depth_terms", ctypes.c_int),
     ]
 
 
@@ -52,10 +54,11 @@ def _scale_hw(h, w, s):
     return int(h / (2 ** s)), int(w / (2 ** s))
 
 
-def _fill_args(imgs, disps, flows, pose, K, K_inv, S, alpha, beta, ac, mode=0):
+def _fill_args(imgs, disps, flows, pose, K, K_inv, S, alpha, beta, ac, mode=0, depth_terms=0):
     a = GeomArgs()
     B, _, H, W = imgs[0].shape
     a.B, a.H, a.W, a.num_scales, a.align_corners, a.mode = B, H, W, S, int(ac), int(mode)
+    a.depth_terms = int(depth_terms) if mode == 0 else 0
     a.alpha, a.beta = float(alpha), float(beta)
     for f in range(3):
         if tuple(imgs[f].shape) != (B, 3, H, W):
@@ -132,16 +135,16 @@ def _launch(kind, a):
 
 
 class GeomLossFn(torch.autograd.Function):
-    """forward(*tensors) -> losses [8,B].  Tensor order: 3 frames, 3*S disps (frame-major), then for
+    """forward(*tensors) -> losses [10,B].  Tensor order: 3 frames, 3*S disps (frame-major), then for
     mode 0 (Model_geometry) 2*S flows (bwd scales then fwd scales), pose, K, K_inv; for mode 1 (Model_depth)
-    pose, K."""
+    pose, K.  ``dt``: DEPTH_TERM_* bits (mode 0; rows 8 / 9 are zero without them)."""
 
     @staticmethod
-    def forward(ctx, mode, S, alpha, beta, ac, *t):
+    def forward(ctx, mode, S, alpha, beta, ac, dt, *t):
         lib = get_lib()
         t = [f32c(x) for x in t]
         imgs, disps, flows, pose, K, K_inv = _unpack(t, S, mode)
-        a = _fill_args(imgs, disps, flows, pose, K, K_inv, S, alpha, beta, ac, mode)
+        a = _fill_args(imgs, disps, flows, pose, K, K_inv, S, alpha, beta, ac, mode, dt)
         n = lib.dfe_geom_workspace_floats(ctypes.byref(a))
         if n < 0:
             check(int(n), "dfe_geom_workspace_floats")
@@ -151,7 +154,7 @@ class GeomLossFn(torch.autograd.Function):
         a.workspace, a.workspace_floats, a.losses = ws.data_ptr(), n, losses.data_ptr()
         _launch("fwd", a)
         ctx.save_for_backward(*t)
-        ctx.cfg = (mode, S, alpha, beta, ac)
+        ctx.cfg = (mode, S, alpha, beta, ac, dt)
         ctx.ws = ws
         ctx.mark_non_differentiable(ws)
         return losses, ws
@@ -159,10 +162,10 @@ class GeomLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, glosses, _gws=None):
         lib = get_lib()
-        mode, S, alpha, beta, ac = ctx.cfg
+        mode, S, alpha, beta, ac, dt = ctx.cfg
         t = list(ctx.saved_tensors)
         imgs, disps, flows, pose, K, K_inv = _unpack(t, S, mode)
-        a = _fill_args(imgs, disps, flows, pose, K, K_inv, S, alpha, beta, ac, mode)
+        a = _fill_args(imgs, disps, flows, pose, K, K_inv, S, alpha, beta, ac, mode, dt)
         glosses = f32c(glosses)
         a.workspace, a.workspace_floats = ctx.ws.data_ptr(), ctx.ws.numel()
         a.grad_losses = glosses.data_ptr()
@@ -178,7 +181,7 @@ class GeomLossFn(torch.autograd.Function):
         if gp is not None:
             a.grad_pose = gp.data_ptr()
         _launch("bwd", a)
-        grads = [None] * 8          # mode, S, alpha, beta, ac, 3 frames
+        grads = [None] * 9          # mode, S, alpha, beta, ac, dt, 3 frames
         for f in range(len(gd)):
             grads += gd[f]
         for d in range(len(gf)):
@@ -189,8 +192,13 @@ class GeomLossFn(torch.autograd.Function):
 
 def geom_loss_stack(img_l, img, img_r, disp_l_list, disp_list, disp_r_list, pose_vectors, flows_bwd, flows_fwd,
                     K, K_inv, num_scales=3, flow_consist_alpha=0.01, flow_consist_beta=0.5, align_corners=None,
-                    return_masks=False):
+                    return_masks=False, enable_depth_ssim=False, enable_depth_consis=False):
     """Active ``loss_pack`` entries of Model_geometry.forward as a dict of (B,) tensors.
+
+    ``enable_depth_ssim`` / ``enable_depth_consis`` add the two terms the reference keeps commented
+    (model_geometry.py:889-891,897-899) to the same launches: ``loss_depth_ssim`` =
+    compute_ssim_loss over the rigid reconstructions, ``loss_depth_consis`` = compute_consis_loss (:182-193) over the
+    projected / computed depths, both on the texture-gated masks; they appear in the returned dict only when enabled.
 
     ``flows_*`` may hold more scales than ``num_scales`` (the reference's zip() drops the 1/8
     flow, model_geometry.py:74-78); extra scales receive no gradient.  With ``return_masks`` the
@@ -200,8 +208,13 @@ def geom_loss_stack(img_l, img, img_r, disp_l_list, disp_list, disp_r_list, pose
     ac = ops.get_align_corners() if align_corners is None else bool(align_corners)
     tensors = [img_l, img, img_r] + list(disp_l_list[:S]) + list(disp_list[:S]) + list(disp_r_list[:S]) \
         + list(flows_bwd[:S]) + list(flows_fwd[:S]) + [pose_vectors, K, K_inv]
-    losses, ws = GeomLossFn.apply(0, S, float(flow_consist_alpha), float(flow_consist_beta), int(ac), *tensors)
-    pack = {name: losses[i] for i, name in enumerate(LOSS_ROWS)}
+    dt = (DEPTH_TERM_SSIM if enable_depth_ssim else 0) | (DEPTH_TERM_CONSIS if enable_depth_consis else 0)
+    losses, ws = GeomLossFn.apply(0, S, float(flow_consist_alpha), float(flow_consist_beta), int(ac), dt, *tensors)
+    pack = {name: losses[i] for i, name in enumerate(LOSS_ROWS[:8])}
+    if enable_depth_ssim:
+        pack["loss_depth_ssim"] = losses[8]
+    if enable_depth_consis:
+        pack["loss_depth_consis"] = losses[9]
     if not return_masks:
         return pack
     B, _, H, W = img.shape
@@ -218,7 +231,7 @@ def depth_loss_stack(img_l, img, img_r, depth_l_list, depth_list, depth_r_list, 
     ac = ops.get_align_corners() if align_corners is None else bool(align_corners)
     tensors = [img_l, img, img_r] + list(depth_l_list[:S]) + list(depth_list[:S]) + list(depth_r_list[:S]) \
         + [pose_vectors, K]
-    losses, ws = GeomLossFn.apply(1, S, 0.0, 0.0, int(ac), *tensors)
+    losses, ws = GeomLossFn.apply(1, S, 0.0, 0.0, int(ac), 0, *tensors)
     pack = {"loss_depth_pixel": losses[0], "loss_depth_smooth": losses[1]}
     if not return_masks:
         return pack
@@ -234,7 +247,7 @@ def flow_loss_stack(img_l, img, img_r, flows_bwd, flows_fwd, num_scales=3, align
     S = int(num_scales)
     ac = ops.get_align_corners() if align_corners is None else bool(align_corners)
     tensors = [img_l, img, img_r] + list(flows_bwd[:S]) + list(flows_fwd[:S])
-    losses, _ws = GeomLossFn.apply(2, S, 0.0, 0.0, int(ac), *tensors)
+    losses, _ws = GeomLossFn.apply(2, S, 0.0, 0.0, int(ac), 0, *tensors)
     return {"loss_flow_pixel": losses[2], "loss_flow_ssim": losses[3], "loss_flow_smooth": losses[4],
             "loss_flow_consis": losses[5]}
 

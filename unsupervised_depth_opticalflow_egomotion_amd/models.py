@@ -135,7 +135,9 @@ class Model_geometry(LossTerms, nn.Module):
         ``cfg.enable_depth_consis``.  They run on the per-operator HIP kernels (inverse_warp2 with projected / computed
         depth and its gradients wrt the target disparity, the SOURCE disparity and the pose; SSIM forward / backward;
         resize) under autograd; the texture-gated masks are decoded from the fused stack's mask pack, so the mask
-        decisions are the fused stack's own.  Not yet part of the fused launches."""
+        decisions are the fused stack's own.  ``loss_stack`` computes the same two terms inside the fused launches
+        (``dfe_geom_args.depth_terms``); this per-operator composition is kept as its cross-check
+        (tests/test_hip_models.py::test_disabled_depth_terms_vs_reference)."""
         S = self.num_scales
         img_list = self.generate_img_pyramid(img, S)
         rec_l, _, pd_l, cd_l = self.reconstruction(img_l, K, disp_t, disp_l, pose[:, 0].contiguous())
@@ -161,11 +163,11 @@ class Model_geometry(LossTerms, nn.Module):
         active, masks = geom_loss_stack(img_l, img, img_r, disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd,
                                         K.contiguous(), K_inv.contiguous(), num_scales=S,
                                         flow_consist_alpha=self.flow_consist_alpha,
-                                        flow_consist_beta=self.flow_consist_beta, return_masks="lazy")
+                                        flow_consist_beta=self.flow_consist_beta, return_masks="lazy",
+                                        enable_depth_ssim=self.enable_depth_ssim,
+                                        enable_depth_consis=self.enable_depth_consis)
         dev = img.device
         loss_pack = {k: (active[k] if k in active else _zeros2(dev)) for k in LOSS_ORDER_GEOM}
-        if self.enable_depth_ssim or self.enable_depth_consis:
-            loss_pack.update(self.disabled_depth_terms(img_l, img, img_r, disp_l, disp_t, disp_r, pose, K, masks))
 
         def u8(*names):
             """sample 0, scale 0 of the product of the named masks, decoded from the 1-byte mask pack only when the
