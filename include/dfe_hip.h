@@ -125,6 +125,14 @@ int dfe_corr_fwd(const float* f1, const float* f2, float* out, int B, int C, int
 int dfe_corr_bwd(const float* f1, const float* f2, const float* gout, float* g1, float* g2, int B, int C, int H, int W,
                  int d, void* stream);
 
+/* ---- ResNet stem max pooling  nn.MaxPool2d(3, 2, 1) of torchvision's resnet as ResnetEncoder runs it
+ * (core/networks/structures/depth_model.py:60-95).  x [planes,H,W] -> y [planes,Ho,Wo], Ho = (H-1)/2+1; `idx` keeps the
+ * winning window position (0..8, row-major) as one byte per output.  Values, tie-breaking (first maximum in window
+ * scan order, NaN wins) and the gradient's accumulation order are ATen's: bit-identical to F.max_pool2d. */
+int dfe_maxpool3x3s2_out(int n);
+int dfe_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* idx, int planes, int H, int W, void* stream);
+int dfe_maxpool3x3s2_bwd(const float* gy, const unsigned char* idx, float* gx, int planes, int H, int W, void* stream);
+
 /* ---- one PWC decoder level's input  pwc_tf.py:119-121 (and :131-133, :143-145, :155-157) --------
  *   warp = self.warp(c2, up_flow); corr = self.corr(c1, warp); x = torch.cat((corr, c1, up_flow), 1)
  * as ONE operator: the cost volume is written straight into planes [0,81) of x [B, 81+C+2, H, W] (caller-allocated),

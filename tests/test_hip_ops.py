@@ -297,6 +297,28 @@ def test_corr_oracle(shape):
     gclose(b.grad, bo.grad)
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 128, 416), (2, 5, 37, 131), (1, 3, 8, 9), (2, 2, 1, 1), (1, 4, 2, 130)])
+def test_stem_maxpool_is_aten_bit_for_bit(shape):
+    """ops.maxpool3x3s2 (ResNet stem, depth_model.py:60-95) against F.max_pool2d(x, 3, 2, 1) on the host: values and
+    gradients EQUAL, on post-ReLU inputs (whole windows of tied zeros: ATen keeps the first maximum in window scan
+    order), odd sizes, windows cut by every border, -inf and NaN entries."""
+    import torch.nn.functional as F
+    from unsupervised_depth_opticalflow_egomotion_amd.ops import maxpool3x3s2
+    r = MG.rng(91)
+    x = np.maximum(r.standard_normal(shape), 0).astype(np.float32)          # ~half the entries are exactly 0
+    x[r.random(shape) < 0.01] = -np.inf
+    if x.size > 50:
+        x.reshape(-1)[r.integers(0, x.size, 5)] = np.nan
+    wgt = r.standard_normal((shape[0], shape[1], (shape[2] - 1) // 2 + 1, (shape[3] - 1) // 2 + 1)).astype(np.float32)
+    a, b = G(x, True), T(x, True)
+    ya, yb = maxpool3x3s2(a), F.max_pool2d(b, 3, 2, 1)
+    assert ya.shape == yb.shape
+    np.testing.assert_array_equal(N(ya), N(yb))
+    (ya * G(wgt)).sum().backward()
+    (yb * T(wgt)).sum().backward()
+    np.testing.assert_array_equal(N(a.grad), N(b.grad))
+
+
 @pytest.mark.parametrize("shape", [(2, 128, 8, 26), (2, 96, 16, 52), (3, 32, 64, 208), (1, 20, 7, 10)])
 def test_pwc_level_input(shape):
     """One PWC decoder level's input (pwc_tf.py:119-121) as one operator: equal to the composition of the per-op HIP

@@ -64,6 +64,9 @@ _SIGNATURES = {
     "dfe_ssim_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_corr_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_corr_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dfe_maxpool3x3s2_out": [_I],
+    "dfe_maxpool3x3s2_fwd": [_P, _P, _P, _I, _I, _I, _P],
+    "dfe_maxpool3x3s2_bwd": [_P, _P, _P, _I, _I, _I, _P],
     "dfe_pwc_level_channels": [_I],
     "dfe_pwc_level_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_pwc_level_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -35,6 +35,17 @@ class FrameBatchNorm2d(nn.BatchNorm2d):
         return F.relu(y) if relu else y
 
 
+class StemMaxPool(nn.MaxPool2d):
+    """nn.MaxPool2d(3, 2, 1); on a HIP device the 1-byte-index kernels of ops.maxpool3x3s2 (same values and gradients
+    bit for bit), on the host the ATen operator."""
+
+    def forward(self, x):
+        if x.is_cuda and (self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode) == (3, 2, 1, 1, False) \
+                and x.dim() == 4 and x.shape[0] * x.shape[1] <= 65535:
+            return ops.maxpool3x3s2(x)
+        return super().forward(x)
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -61,7 +72,7 @@ class ResNet(nn.Module):
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
         self.bn1 = FrameBatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
-        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.maxpool = StemMaxPool(3, 2, 1)
         self.layer1 = self._make_layer(block, 64, layers[0])
         self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
         self.layer3 = self._make_layer(block, 256, layers[2], stride=2)

@@ -243,6 +243,42 @@ def corr81(f1, f2, d=4):
     return CorrFn.apply(f1, f2, int(d))
 
 
+class MaxPool3x3s2Fn(torch.autograd.Function):
+    """F.max_pool2d(x, 3, 2, 1) (the ResNet stem, depth_model.py:60-95) with a 1-byte window position instead of
+    int64 indices; values and gradients bit-identical to ATen's."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = get_lib()
+        x = f32c(x)
+        B, C, H, W = x.shape
+        Ho, Wo = lib.dfe_maxpool3x3s2_out(H), lib.dfe_maxpool3x3s2_out(W)
+        y = torch.empty(B, C, Ho, Wo, device=x.device, dtype=torch.float32)
+        idx = torch.empty(B, C, Ho, Wo, device=x.device, dtype=torch.uint8)
+        check(lib.dfe_maxpool3x3s2_fwd(ptr(x), ptr(y), ptr(idx), B * C, H, W, stream_ptr()), "dfe_maxpool3x3s2_fwd")
+        ctx.save_for_backward(idx)
+        ctx.hw = (H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = get_lib()
+        idx, = ctx.saved_tensors
+        B, C = idx.shape[:2]
+        H, W = ctx.hw
+        gx = torch.empty(B, C, H, W, device=gy.device, dtype=torch.float32)
+        check(lib.dfe_maxpool3x3s2_bwd(ptr(f32c(gy)), ptr(idx), ptr(gx), B * C, H, W, stream_ptr()), "dfe_maxpool3x3s2_bwd")
+        return gx
+
+
+def maxpool3x3s2(x):
+    if x.dim() != 4:
+        raise ValueError("maxpool3x3s2: x must be [B,C,H,W]")
+    if x.shape[0] * x.shape[1] > 65535:
+        raise _lib.DfeError("maxpool3x3s2: more than 65535 planes")
+    return MaxPool3x3s2Fn.apply(x)
+
+
 class PwcLevelInputFn(torch.autograd.Function):
     """x = cat(corr(c1, warp(c2, flow)), c1, flow) of one PWC decoder level (pwc_tf.py:119-121) as one operator."""
 
