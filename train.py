@@ -21,7 +21,7 @@ import yaml
 
 from unsupervised_depth_opticalflow_egomotion_amd import ddp, ops, synthetic
 from unsupervised_depth_opticalflow_egomotion_amd.models import get_model
-from unsupervised_depth_opticalflow_egomotion_amd.train_step import train_step, LOSS_WEIGHT_ATTR
+from unsupervised_depth_opticalflow_egomotion_amd.train_step import train_step, make_optimizer, LOSS_WEIGHT_ATTR
 
 
 class pObject(object):
@@ -70,7 +70,7 @@ def train(cfg):
                     p.requires_grad = False
     model.train()
     model = ddp.wrap(model, dev)
-    optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=cfg.lr)
+    optimizer = make_optimizer(model, cfg.lr)
     start = 0
     if cfg.resume:
         fn = "iter_{}.pth".format(cfg.iter_start) if cfg.iter_start > 0 else "last.pth"
