@@ -416,7 +416,7 @@ static inline unsigned nblk(long n) { return static_cast<unsigned>((n + 255) / 2
 
 extern "C" long dfe_glue_partials_floats(int B, int C, int H, int W) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
-  const long roll = static_cast<long>((W + 63) / 64) * ((H + UB_ROWS - 1) / UB_ROWS);   // units of the rolling kernels
+  const long roll = W >= 256 ? static_cast<long>((W + 63) / 64) * ((H + UB_ROWS - 1) / UB_ROWS) : 0;   // units of the rolling kernel (wide planes only)
   const long blocks = nblk(static_cast<long>(H) * W);
   return static_cast<long>(B) * C * (roll > blocks ? roll : blocks);
 }
