@@ -564,7 +564,9 @@ def _ref_grouped_bn(x, res, bn, groups, relu):
 
 
 @pytest.mark.parametrize("relu,with_res", [(True, True), (True, False), (False, True), (False, False)])
-@pytest.mark.parametrize("shape,groups", [((6, 5, 8, 26), 3), ((4, 3, 7, 9), 1), ((12, 16, 64, 208), 3), ((2, 4, 1, 1), 1)])
+@pytest.mark.parametrize("shape,groups", [((6, 5, 8, 26), 3), ((4, 3, 7, 9), 1), ((12, 16, 64, 208), 3), ((2, 4, 1, 1), 1),
+                                          ((12, 8, 32, 104), 3), ((12, 6, 16, 52), 3), ((4, 7, 64, 64), 1),   # single-kernel small-plane path
+                                          ((15, 4, 8, 28), 3), ((4, 3, 64, 68), 2)])                         # Bg = 5 / HW > 4096: three-kernel path
 def test_grouped_batch_norm(shape, groups, relu, with_res):
     """Fused grouped BatchNorm (+ residual + ReLU) against sequential nn.BatchNorm2d calls on the CPU: outputs 2e-5
     (statistics merged in double vs ATen's accumulation), running statistics 1e-6, gradients 1e-4 of their scale."""
