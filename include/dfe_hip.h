@@ -224,6 +224,17 @@ int dfe_bias_act_fwd(float* z, const float* bias, int B, int C, int H, int W, fl
 int dfe_bias_act_bwd(const float* y, const float* gy, long gy_batch_stride, float* gz, float* gbias, float* partials,
                      int B, int C, int H, int W, float slope, void* stream);
 
+/* The same epilogue inside a DenseNet-style block (PWC_tf's decoder levels, pwc_tf.py:113-117 and the same five lines
+ * per level: x2 = conv(cat(x0, x1)), x3 = conv(cat(x1, x2)) ...): act(z + bias) is written straight into the channel
+ * slices of the concatenated buffers that consume it (dst2 optional; dst1 may be z), and the backward pass sums the
+ * matching slices of the consumers' input gradients (g2 optional) and reads y from its slice.  Every slice is a base
+ * pointer + a batch stride in floats; channel planes are contiguous inside a sample. */
+int dfe_bias_act_fwd2(const float* z, const float* bias, float* dst1, long dst1_batch_stride, float* dst2,
+                      long dst2_batch_stride, int B, int C, int H, int W, float slope, void* stream);
+int dfe_bias_act_bwd2(const float* y, long y_batch_stride, const float* g1, long g1_batch_stride, const float* g2,
+                      long g2_batch_stride, float* gz, float* gbias, float* partials, int B, int C, int H, int W,
+                      float slope, void* stream);
+
 /* ---- fused loss stack: everything from model_geometry.py:797 to :951 given the nets' outputs ---
  * One call computes the active loss_pack vectors of Model_geometry.forward (mode 0) for a batch:
  * pyramids (:65-72,:91), rigid view synthesis (:80-103), texture / occlusion / validity / dynamic

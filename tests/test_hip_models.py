@@ -58,6 +58,41 @@ def test_g7_full_model_vs_reference(golden_dir):
     np.testing.assert_allclose(float(f.mean()), g["eval_flow_stats"][0], rtol=1e-3)
 
 
+@pytest.mark.parametrize("lvl,hw,B", [(6, (4, 13), 8), (4, (16, 52), 3), (2, (64, 208), 2)])
+def test_pwc_dense_block_matches_composition(lvl, hw, B):
+    """PWC_tf._decode as one operator (ops.dense_decode: epilogues writing into the concatenated buffers, manual
+    convolution backward) against the plain module composition of the same level on the same device: outputs and
+    every gradient (input, five conv weights / biases, flow head) to 1e-6 of their scale (same MIOpen calls; only the
+    order of the two-term gradient sums can differ)."""
+    from unsupervised_depth_opticalflow_egomotion_amd.networks.pwc_tf import PWC_tf
+    torch.manual_seed(5 + lvl)
+    pw = PWC_tf().to(dev())
+    cin = getattr(pw, "conv%d_0" % lvl)[0].in_channels
+    x = torch.randn(B, cin, *hw, device=dev())
+    wf, w4 = torch.randn(B, 2, *hw, device=dev()), torch.randn(B, 32, *hw, device=dev())
+
+    def run(fused):
+        pw.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        if fused:
+            flow, x4 = pw._decode(lvl, xi)
+        else:
+            c = [getattr(pw, "conv%d_%d" % (lvl, k)) for k in range(5)]
+            x0 = c[0](xi); x1 = c[1](x0); x2 = c[2](torch.cat((x0, x1), 1)); x3 = c[3](torch.cat((x1, x2), 1))
+            x4 = c[4](torch.cat((x2, x3), 1))
+            flow = getattr(pw, "predict_flow%d" % lvl)(torch.cat((x3, x4), 1))
+        ((flow * wf).sum() + (0.5 if lvl == 2 else 0.0) * (x4 * w4).sum()).backward()
+        names = ["conv%d_%d.0.%s" % (lvl, k, t) for k in range(5) for t in ("weight", "bias")] + \
+                ["predict_flow%d.%s" % (lvl, t) for t in ("weight", "bias")]
+        params = dict(pw.named_parameters())
+        return [flow.detach(), x4.detach(), xi.grad] + [params[n].grad.clone() for n in names]
+
+    a, b = run(True), run(False)
+    for i, (u, v) in enumerate(zip(a, b)):
+        scale = float(v.abs().max())
+        assert float((u - v).abs().max()) <= 1e-6 * scale + 1e-9, (i, float((u - v).abs().max()), scale)
+
+
 def test_pwc_hip_vs_oracle_ops():
     """PWC_tf with the HIP warp + 81-tap correlation against the same weights with the oracle's ops (CPU)."""
     from unsupervised_depth_opticalflow_egomotion_amd.networks import PWC_tf, FeaturePyramid

@@ -97,6 +97,87 @@ __global__ void __launch_bounds__(64) k_bias_grad_final(const float* __restrict_
   if (lane == 0) gbias[c] = (r0 + r1) + (r2 + r3);
 }
 
+// ---- the same epilogue for a DenseNet-style block (PWC_tf's decoder, pwc_tf.py:113-117: every layer output is
+// consumed through torch.cat by the next two layers).  Forward: read the bias-free convolution output z once and write
+// act(z + bias) straight into the channel slices of the (up to two) concatenated buffers that consume it -- dst1 may
+// be z itself (in place).  Backward: the output's gradient is the sum of the matching channel slices of the consumers'
+// input gradients (g2 optional); y is read from the slice it was written to.  All slices are given by a base pointer
+// and a batch stride (channel planes are contiguous inside a sample).
+template <bool VEC>
+__global__ void __launch_bounds__(EP_BLOCK) k_bias_act_fwd2(const float* __restrict__ z, const float* __restrict__ bias,
+                                                            float* __restrict__ d1, long d1_bs, float* __restrict__ d2,
+                                                            long d2_bs, int C, int HW, float slope) {
+  const int b = plane_id() / C, c = plane_id() - b * C;
+  const float bv = bias ? bias[c] : 0.0f;
+  const float* p = z + static_cast<long>(plane_id()) * HW;
+  float* o1 = d1 + b * d1_bs + static_cast<long>(c) * HW;
+  float* o2 = d2 ? d2 + b * d2_bs + static_cast<long>(c) * HW : nullptr;
+  const int base = blockIdx.x * EP_CHUNK;
+  if (VEC) {
+#pragma unroll
+    for (int k = 0; k < EP_PER_THREAD / 4; ++k) {
+      const int e = base + (k * EP_BLOCK + threadIdx.x) * 4;
+      if (e < HW) {
+        float4 v = *reinterpret_cast<const float4*>(p + e);
+        v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+        v.x = v.x > 0.0f ? v.x : v.x * slope; v.y = v.y > 0.0f ? v.y : v.y * slope;
+        v.z = v.z > 0.0f ? v.z : v.z * slope; v.w = v.w > 0.0f ? v.w : v.w * slope;
+        *reinterpret_cast<float4*>(o1 + e) = v;
+        if (o2) *reinterpret_cast<float4*>(o2 + e) = v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < EP_PER_THREAD; ++k) {
+      const int e = base + k * EP_BLOCK + threadIdx.x;
+      if (e < HW) { float v = p[e] + bv; v = v > 0.0f ? v : v * slope; o1[e] = v; if (o2) o2[e] = v; }
+    }
+  }
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(EP_BLOCK) k_bias_act_bwd2(const float* __restrict__ y, long y_bs, const float* __restrict__ g1,
+                                                            long g1_bs, const float* __restrict__ g2, long g2_bs,
+                                                            float* __restrict__ gz, float* __restrict__ part, int C, int HW,
+                                                            float slope) {
+  __shared__ float red[4 * (EP_BLOCK / 64)];
+  const int b = plane_id() / C, c = plane_id() - b * C;
+  const long co = static_cast<long>(c) * HW;
+  const float* py = y + b * y_bs + co;
+  const float* pa = g1 + b * g1_bs + co;
+  const float* pb = g2 ? g2 + b * g2_bs + co : nullptr;
+  float* pz = gz + static_cast<long>(plane_id()) * HW;
+  const int base = blockIdx.x * EP_CHUNK;
+  float acc[1] = {0.0f};
+  if (VEC) {
+#pragma unroll
+    for (int k = 0; k < EP_PER_THREAD / 4; ++k) {
+      const int e = base + (k * EP_BLOCK + threadIdx.x) * 4;
+      if (e < HW) {
+        const float4 yv = *reinterpret_cast<const float4*>(py + e);
+        float4 g = *reinterpret_cast<const float4*>(pa + e);
+        if (pb) { const float4 h = *reinterpret_cast<const float4*>(pb + e); g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w; }
+        g.x = yv.x > 0.0f ? g.x : g.x * slope; g.y = yv.y > 0.0f ? g.y : g.y * slope;
+        g.z = yv.z > 0.0f ? g.z : g.z * slope; g.w = yv.w > 0.0f ? g.w : g.w * slope;
+        *reinterpret_cast<float4*>(pz + e) = g;
+        acc[0] += (g.x + g.y) + (g.z + g.w);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < EP_PER_THREAD; ++k) {
+      const int e = base + k * EP_BLOCK + threadIdx.x;
+      if (e < HW) {
+        float g = pa[e];
+        if (pb) g += pb[e];
+        g = py[e] > 0.0f ? g : g * slope;
+        pz[e] = g; acc[0] += g;
+      }
+    }
+  }
+  if (part) block_sum<1>(acc, red, part + static_cast<long>(plane_id()) * gridDim.x + blockIdx.x);
+}
+
 }  // namespace dfe
 
 #define DFE_LAUNCH_CHECK() do { if (hipGetLastError() != hipSuccess) return DFE_ERR_LAUNCH; } while (0)
@@ -135,6 +216,45 @@ extern "C" int dfe_bias_act_bwd(const float* y, const float* gy, long gy_batch_s
   const bool vec = hw % 4 == 0 && aligned16(y) && aligned16(gy) && aligned16(gz) && gy_batch_stride % 4 == 0;
   if (vec) k_bias_act_bwd<true><<<g, EP_BLOCK, 0, st>>>(y, gy, gz, part, static_cast<int>(hw), hw, gy_batch_stride, C, slope);
   else k_bias_act_bwd<false><<<g, EP_BLOCK, 0, st>>>(y, gy, gz, part, static_cast<int>(hw), hw, gy_batch_stride, C, slope);
+  DFE_LAUNCH_CHECK();
+  if (gbias) {
+    k_bias_grad_final<<<C, 64, 0, st>>>(partials, gbias, B, C, nchunk);
+    DFE_LAUNCH_CHECK();
+  }
+  return DFE_OK;
+}
+
+extern "C" int dfe_bias_act_fwd2(const float* z, const float* bias, float* dst1, long dst1_batch_stride, float* dst2,
+                                 long dst2_batch_stride, int B, int C, int H, int W, float slope, void* stream) {
+  if (!z || !dst1) return DFE_ERR_NULL;
+  const long hw = static_cast<long>(H) * W;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || hw >= (1L << 31) || C > 65535 || B > 65535) return DFE_ERR_DIMS;
+  if (dst1_batch_stride < C * hw || (dst2 && dst2_batch_stride < C * hw)) return DFE_ERR_DIMS;
+  const dim3 g(static_cast<unsigned>((hw + EP_CHUNK - 1) / EP_CHUNK), C, B);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool vec = hw % 4 == 0 && aligned16(z) && aligned16(dst1) && dst1_batch_stride % 4 == 0 &&
+                   (!dst2 || (aligned16(dst2) && dst2_batch_stride % 4 == 0));
+  if (vec) k_bias_act_fwd2<true><<<g, EP_BLOCK, 0, st>>>(z, bias, dst1, dst1_batch_stride, dst2, dst2_batch_stride, C, static_cast<int>(hw), slope);
+  else k_bias_act_fwd2<false><<<g, EP_BLOCK, 0, st>>>(z, bias, dst1, dst1_batch_stride, dst2, dst2_batch_stride, C, static_cast<int>(hw), slope);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+extern "C" int dfe_bias_act_bwd2(const float* y, long y_batch_stride, const float* g1, long g1_batch_stride, const float* g2,
+                                 long g2_batch_stride, float* gz, float* gbias, float* partials, int B, int C, int H, int W,
+                                 float slope, void* stream) {
+  if (!y || !g1 || !gz || (gbias && !partials)) return DFE_ERR_NULL;
+  const long hw = static_cast<long>(H) * W;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || hw >= (1L << 31) || C > 65535 || B > 65535) return DFE_ERR_DIMS;
+  if (y_batch_stride < C * hw || g1_batch_stride < C * hw || (g2 && g2_batch_stride < C * hw)) return DFE_ERR_DIMS;
+  const int nchunk = static_cast<int>((hw + EP_CHUNK - 1) / EP_CHUNK);
+  const dim3 g(nchunk, C, B);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* part = gbias ? partials : nullptr;
+  const bool vec = hw % 4 == 0 && aligned16(y) && aligned16(g1) && aligned16(gz) && y_batch_stride % 4 == 0 &&
+                   g1_batch_stride % 4 == 0 && (!g2 || (aligned16(g2) && g2_batch_stride % 4 == 0));
+  if (vec) k_bias_act_bwd2<true><<<g, EP_BLOCK, 0, st>>>(y, y_batch_stride, g1, g1_batch_stride, g2, g2_batch_stride, gz, part, C, static_cast<int>(hw), slope);
+  else k_bias_act_bwd2<false><<<g, EP_BLOCK, 0, st>>>(y, y_batch_stride, g1, g1_batch_stride, g2, g2_batch_stride, gz, part, C, static_cast<int>(hw), slope);
   DFE_LAUNCH_CHECK();
   if (gbias) {
     k_bias_grad_final<<<C, 64, 0, st>>>(partials, gbias, B, C, nchunk);

@@ -7,7 +7,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..structures.net_utils import conv, warp_flow
+from ..structures.net_utils import ConvAct, conv, warp_flow
 
 
 class PWC_tf(nn.Module):
@@ -55,7 +55,24 @@ class PWC_tf(nn.Module):
             return ops.pwc_level_input(c1, c2, up_flow)
         return torch.cat((self.corr(c1, self.warp(c2, up_flow)), c1, up_flow), 1)
 
+    def _dense_block_is_standard(self, lvl):
+        for k in range(5):
+            m = getattr(self, "conv%d_%d" % (lvl, k))
+            c = m[0]
+            if type(m) is not ConvAct or not isinstance(m[1], nn.LeakyReLU) or \
+                    (c.kernel_size, c.stride, c.padding, c.dilation, c.groups) != ((3, 3), (1, 1), (1, 1), (1, 1), 1) or c.bias is None:
+                return False
+        p = getattr(self, "predict_flow%d" % lvl)
+        return (p.kernel_size, p.stride, p.padding, p.dilation, p.groups) == ((3, 3), (1, 1), (1, 1), (1, 1), 1) and p.bias is not None
+
     def _decode(self, lvl, x):
+        """pwc_tf.py:113-118 (level 6) and the same six lines of every other level -> (flow, x4).  On the GPU the block is
+        one operator around its six MIOpen convolutions (ops.dense_decode): no torch.cat copies, no slice copies or
+        gradient-accumulation adds in the backward pass."""
+        if x.is_cuda and self._dense_block_is_standard(lvl):
+            convs = [getattr(self, "conv%d_%d" % (lvl, k))[0] for k in range(5)]
+            return ops.dense_decode(x, convs, getattr(self, "predict_flow%d" % lvl),
+                                    getattr(self, "conv%d_0" % lvl)[1].negative_slope)
         x0 = getattr(self, "conv%d_0" % lvl)(x)
         x1 = getattr(self, "conv%d_1" % lvl)(x0)
         x2 = getattr(self, "conv%d_2" % lvl)(torch.cat((x0, x1), 1))

@@ -544,6 +544,116 @@ def bias_act(z, bias, slope):
     return BiasActFn.apply(z, bias, float(slope))
 
 
+class DenseDecodeFn(torch.autograd.Function):
+    """One PWC decoder level's DenseNet-style block (pwc_tf.py:113-118 and the same six lines per level)::
+
+        x0 = conv_0(x); x1 = conv_1(x0); x2 = conv_2(cat(x0, x1)); x3 = conv_3(cat(x1, x2)); x4 = conv_4(cat(x2, x3))
+        flow = predict_flow(cat(x3, x4))                                      -> (flow, x4)
+
+    with every ``conv_k`` = Conv2d(3x3, pad 1, bias) + LeakyReLU(slope).  The convolutions stay MIOpen calls (bias-free);
+    the bias + activation epilogue writes each layer output straight into the channel slices of the two concatenated
+    buffers that consume it (``dfe_bias_act_fwd2``), so no ``torch.cat`` copies exist; the backward pass calls
+    ``aten::convolution_backward`` layer by layer and the epilogue's backward sums the two consumers' gradient slices in
+    place (``dfe_bias_act_bwd2``): no slice copies, no gradient-accumulation adds.  Same arithmetic as the composition."""
+
+    @staticmethod
+    def forward(ctx, slope, x, *wb):
+        import torch.nn.functional as F
+        lib = get_lib()
+        x = f32c(x)
+        w, b = list(wb[0:12:2]), list(wb[1:12:2])          # conv_0..conv_4, predict_flow
+        B, _, H, W = x.shape
+        HW = H * W
+        co = [int(t.shape[0]) for t in w[:5]]              # 128, 128, 96, 64, 32
+        dev = x.device
+        cat = [torch.empty(B, co[k] + co[k + 1], H, W, device=dev, dtype=torch.float32) for k in range(4)]   # [x_k | x_k+1]
+        st = stream_ptr()
+
+        def epilogue(z, k, d1, d1_off, d2, d2_off):
+            c = co[k]
+            p1 = ctypes.c_void_p(d1.data_ptr() + 4 * d1_off * HW)
+            p2 = ctypes.c_void_p(d2.data_ptr() + 4 * d2_off * HW) if d2 is not None else None
+            check(lib.dfe_bias_act_fwd2(ptr(z), ptr(b[k]), p1, d1.stride(0), p2, d2.stride(0) if d2 is not None else 0,
+                                        B, c, H, W, slope, st), "dfe_bias_act_fwd2")
+
+        z0 = F.conv2d(x, w[0], None, 1, 1)
+        epilogue(z0, 0, z0, 0, cat[0], 0)                                   # x0: in place (conv_1's input) + cat0[:, :128]
+        z = F.conv2d(z0, w[1], None, 1, 1)
+        epilogue(z, 1, cat[0], co[0], cat[1], 0)                            # x1
+        z = F.conv2d(cat[0], w[2], None, 1, 1)
+        epilogue(z, 2, cat[1], co[1], cat[2], 0)                            # x2
+        z = F.conv2d(cat[1], w[3], None, 1, 1)
+        epilogue(z, 3, cat[2], co[2], cat[3], 0)                            # x3
+        x4 = F.conv2d(cat[2], w[4], None, 1, 1)
+        epilogue(x4, 4, x4, 0, cat[3], co[3])                               # x4: in place (returned) + cat3[:, 64:]
+        flow = F.conv2d(cat[3], w[5], b[5], 1, 1)
+        ctx.save_for_backward(x, z0, *cat, *w)
+        ctx.slope, ctx.co = slope, co
+        ctx.set_materialize_grads(False)
+        return flow, x4
+
+    @staticmethod
+    def backward(ctx, g_flow, g_x4):
+        lib = get_lib()
+        saved = ctx.saved_tensors
+        x, x0, cat, w = saved[0], saved[1], list(saved[2:6]), list(saved[6:12])
+        co, slope = ctx.co, ctx.slope
+        B, _, H, W = x.shape
+        HW = H * W
+        dev = x.device
+        st = stream_ptr()
+        need = ctx.needs_input_grad          # (slope, x, w0, b0, ..., wp, bp)
+        nw = lambda k: bool(need[2 + 2 * k])
+        nb = lambda k: bool(need[3 + 2 * k])
+        conv_bwd = torch.ops.aten.convolution_backward
+
+        def cb(g, inp, wt, want_in, want_w, bias_sizes=None, want_b=False):
+            return conv_bwd(g, inp, wt, bias_sizes, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [want_in, want_w, want_b])
+
+        def epilogue_bwd(k, ysrc, y_off, g1, g1_off, g2, g2_off):
+            c = co[k]
+            gz = torch.empty(B, c, H, W, device=dev, dtype=torch.float32)
+            gb = part = None
+            if nb(k):
+                gb = torch.empty(c, device=dev, dtype=torch.float32)
+                part = torch.empty(lib.dfe_bias_act_partials_floats(B, c, H, W), device=dev, dtype=torch.float32)
+            sl = lambda t, off: ctypes.c_void_p(t.data_ptr() + 4 * off * HW)
+            check(lib.dfe_bias_act_bwd2(sl(ysrc, y_off), ysrc.stride(0), sl(g1, g1_off), g1.stride(0),
+                                        sl(g2, g2_off) if g2 is not None else None, g2.stride(0) if g2 is not None else 0,
+                                        ptr(gz), ptr(gb), ptr(part), B, c, H, W, slope, st), "dfe_bias_act_bwd2")
+            return gz, gb
+
+        gw, gbias = [None] * 6, [None] * 6
+        if g_flow is not None:
+            g_flow = f32c(g_flow)
+            g3, gw[5], gbias[5] = cb(g_flow, cat[3], w[5], True, nw(5), [2], nb(5))       # d/d cat(x3, x4)
+        else:
+            g3 = torch.zeros_like(cat[3])
+        g_x4 = f32c(g_x4) if g_x4 is not None else None
+        gz, gbias[4] = epilogue_bwd(4, cat[3], co[3], g3, co[3], g_x4, 0)                 # x4: cat3 slice + the returned copy
+        g2, gw[4], _ = cb(gz, cat[2], w[4], True, nw(4))                                  # d/d cat(x2, x3)
+        gz, gbias[3] = epilogue_bwd(3, cat[3], 0, g3, 0, g2, co[2])                       # x3
+        g1, gw[3], _ = cb(gz, cat[1], w[3], True, nw(3))                                  # d/d cat(x1, x2)
+        gz, gbias[2] = epilogue_bwd(2, cat[2], 0, g2, 0, g1, co[1])                       # x2
+        g0, gw[2], _ = cb(gz, cat[0], w[2], True, nw(2))                                  # d/d cat(x0, x1)
+        gz, gbias[1] = epilogue_bwd(1, cat[1], 0, g1, 0, g0, co[0])                       # x1
+        gx0, gw[1], _ = cb(gz, x0, w[1], True, nw(1))                                     # d/d x0 through conv_1
+        gz, gbias[0] = epilogue_bwd(0, cat[0], 0, g0, 0, gx0, 0)                          # x0
+        gx, gw[0], _ = cb(gz, x, w[0], bool(need[1]), nw(0))
+        out = [None, gx]
+        for k in range(6):
+            out += [gw[k], gbias[k]]
+        return tuple(out)
+
+
+def dense_decode(x, convs, predict_flow, slope=0.1):
+    """(flow, x4) of one PWC decoder level; ``convs``: the five Conv2d modules, ``predict_flow``: the 3x3 flow head."""
+    wb = []
+    for c in list(convs) + [predict_flow]:
+        wb += [c.weight, c.bias]
+    return DenseDecodeFn.apply(float(slope), x, *wb)
+
+
 # --------------------------------------------------------------------------- grouped BatchNorm (+ residual + ReLU)
 class GroupedBatchNormFn(torch.autograd.Function):
     """Training-mode BatchNorm2d over G groups of consecutive samples (statistics per (group, channel); the running
