@@ -157,6 +157,7 @@ class GeomLossFn(torch.autograd.Function):
         ctx.cfg = (mode, S, alpha, beta, ac, dt)
         ctx.ws = ws
         ctx.mark_non_differentiable(ws)
+        ctx.set_materialize_grads(False)     # no zero-filled "gradient" of the 92 MB workspace output
         return losses, ws
 
     @staticmethod
@@ -166,6 +167,8 @@ class GeomLossFn(torch.autograd.Function):
         t = list(ctx.saved_tensors)
         imgs, disps, flows, pose, K, K_inv = _unpack(t, S, mode)
         a = _fill_args(imgs, disps, flows, pose, K, K_inv, S, alpha, beta, ac, mode, dt)
+        if glosses is None:
+            return (None,) * (6 + len(t))
         glosses = f32c(glosses)
         a.workspace, a.workspace_floats = ctx.ws.data_ptr(), ctx.ws.numel()
         a.grad_losses = glosses.data_ptr()
@@ -210,11 +213,12 @@ def geom_loss_stack(img_l, img, img_r, disp_l_list, disp_list, disp_r_list, pose
         + list(flows_bwd[:S]) + list(flows_fwd[:S]) + [pose_vectors, K, K_inv]
     dt = (DEPTH_TERM_SSIM if enable_depth_ssim else 0) | (DEPTH_TERM_CONSIS if enable_depth_consis else 0)
     losses, ws = GeomLossFn.apply(0, S, float(flow_consist_alpha), float(flow_consist_beta), int(ac), dt, *tensors)
-    pack = {name: losses[i] for i, name in enumerate(LOSS_ROWS[:8])}
+    rows = losses.unbind(0)          # one stack in the backward pass instead of a zero-filled [10,B] per selected row
+    pack = {name: rows[i] for i, name in enumerate(LOSS_ROWS[:8])}
     if enable_depth_ssim:
-        pack["loss_depth_ssim"] = losses[8]
+        pack["loss_depth_ssim"] = rows[8]
     if enable_depth_consis:
-        pack["loss_depth_consis"] = losses[9]
+        pack["loss_depth_consis"] = rows[9]
     if not return_masks:
         return pack
     B, _, H, W = img.shape
@@ -232,7 +236,8 @@ def depth_loss_stack(img_l, img, img_r, depth_l_list, depth_list, depth_r_list, 
     tensors = [img_l, img, img_r] + list(depth_l_list[:S]) + list(depth_list[:S]) + list(depth_r_list[:S]) \
         + [pose_vectors, K]
     losses, ws = GeomLossFn.apply(1, S, 0.0, 0.0, int(ac), 0, *tensors)
-    pack = {"loss_depth_pixel": losses[0], "loss_depth_smooth": losses[1]}
+    rows = losses.unbind(0)
+    pack = {"loss_depth_pixel": rows[0], "loss_depth_smooth": rows[1]}
     if not return_masks:
         return pack
     B, _, H, W = img.shape
@@ -248,8 +253,8 @@ def flow_loss_stack(img_l, img, img_r, flows_bwd, flows_fwd, num_scales=3, align
     ac = ops.get_align_corners() if align_corners is None else bool(align_corners)
     tensors = [img_l, img, img_r] + list(flows_bwd[:S]) + list(flows_fwd[:S])
     losses, _ws = GeomLossFn.apply(2, S, 0.0, 0.0, int(ac), 0, *tensors)
-    return {"loss_flow_pixel": losses[2], "loss_flow_ssim": losses[3], "loss_flow_smooth": losses[4],
-            "loss_flow_consis": losses[5]}
+    rows = losses.unbind(0)
+    return {"loss_flow_pixel": rows[2], "loss_flow_ssim": rows[3], "loss_flow_smooth": rows[4], "loss_flow_consis": rows[5]}
 
 
 def decode_mask(handle, name, scale=0):

@@ -70,14 +70,22 @@ def _flow_branches(fpyramid, pwc_model, img_l, img, img_r):
     convolutions at the coarse levels.  Returns (flows target->left, flows target->right)."""
     B, h, w = img.shape[0], img.shape[2], img.shape[3]
     feats = fpyramid(torch.cat([img, img_l, img_r], 0))
-    f1 = [torch.cat([f[:B], f[:B]], 0) for f in feats]        # the target's features for both directions
-    f2 = [f[B:] for f in feats]                               # left | right
-    flows = pwc_model(f1, f2, [h, w])
-    return [f[:B] for f in flows], [f[B:] for f in flows]
+    # split() instead of slices: its backward is one concatenation of the parts' gradients, where every slice would
+    # zero-fill a full-size gradient, copy its part in and leave the sum to a chain of adds
+    parts = [f.split([B, 2 * B]) for f in feats]              # target | (left, right)
+    f1 = [torch.cat([t, t], 0) for t, _ in parts]             # the target's features for both directions
+    f2 = [lr for _, lr in parts]
+    flows = [f.split(B) for f in pwc_model(f1, f2, [h, w])]
+    return [f[0] for f in flows], [f[1] for f in flows]
 
 
 def _zeros2(dev):
-    return torch.zeros([2], device=dev).requires_grad_()   # device-side fill (no H2D copy: capturable in a hipGraph)
+    """The reference's ``torch.zeros([2]).to(device).requires_grad_()`` placeholder of a disabled loss term
+    (model_geometry.py:891,899,943-951).  Tagged so that train_step.total_loss can leave its exact-zero contribution
+    (three tiny kernels forward, three backward per placeholder) out of the sum."""
+    t = torch.zeros([2], device=dev).requires_grad_()   # device-side fill (no H2D copy: capturable in a hipGraph)
+    t._dfe_zero_placeholder = True
+    return t
 
 
 class Model_geometry(LossTerms, nn.Module):

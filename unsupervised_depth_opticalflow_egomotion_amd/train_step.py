@@ -35,8 +35,10 @@ def make_optimizer(model, lr):
 
 
 def total_loss(loss_pack, cfg):
-    """train.py:211-214: sum_k w_k * mean(loss_k)."""
-    return sum(getattr(cfg, LOSS_WEIGHT_ATTR[k]) * v.mean() for k, v in loss_pack.items())
+    """train.py:211-214: sum_k w_k * mean(loss_k).  The (2,)-shaped zero placeholders of the disabled terms
+    (models._zeros2) contribute exactly +0.0 and are left out."""
+    return sum(getattr(cfg, LOSS_WEIGHT_ATTR[k]) * v.mean() for k, v in loss_pack.items()
+               if not getattr(v, "_dfe_zero_placeholder", False))
 
 
 def train_step(model, optimizer, inputs, cfg):
