@@ -3,6 +3,9 @@ index 0 = target->left ("bwd"), 1 = target->right ("fwd").  The three Linear(14,
 H/128 * W/128 positions, i.e. the net only accepts 256x832-like inputs (pose_cnn.py:37-39)."""
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
 
 
 class PoseCNN(nn.Module):
@@ -25,6 +28,14 @@ class PoseCNN(nn.Module):
                                          nn.Conv2d(n, n, 3, 1, 1), nn.Conv2d(n, n, 3, 1, 1)])
         self.refine_pose_conv = nn.Conv2d(n, n, 1)
 
+    def conv_relu(self, conv, x):
+        """``self.relu(conv(x))`` (pose_cnn.py:68-69, 84-85).  On the GPU the convolution runs without its bias and the bias +
+        ReLU epilogue is one in-place HIP pass whose backward also yields the bias gradient (ops.bias_act, slope 0)."""
+        if x.is_cuda:
+            return ops.bias_act(F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups),
+                                conv.bias, 0.0)
+        return self.relu(conv(x))
+
     def atten_refine(self, x):
         B, C, H, W = x.size()
         flat = x.view(B, C, H * W)
@@ -32,13 +43,13 @@ class PoseCNN(nn.Module):
         attn = torch.softmax(torch.bmm(q, k.permute(0, 2, 1)), 1)
         out = torch.cat([flat, torch.bmm(attn, v)], 1).view(B, 2 * C, H, W)
         for conv in self.refine_net:
-            out = self.relu(conv(out))
+            out = self.conv_relu(conv, out)
         out = self.refine_pose_conv(out).mean(3).mean(2)
         return 0.01 * out.view(-1, self.num_input_frames - 1, 6)
 
     def forward(self, x):
         for conv in self.net:
-            x = self.relu(conv(x))
+            x = self.conv_relu(conv, x)
         x = self.pose_conv(x)
         delta = self.atten_refine(x)
         x = x.mean(3).mean(2)
