@@ -739,6 +739,30 @@ __global__ void k_resize(const float* __restrict__ in, float* __restrict__ out, 
 }  // namespace dfe
 
 // ====================================================================== C ABI
+// tail of one PWC level's concatenated input (dfe_pwc_level_fwd below): planes 81.. <- c1, then the flow
+namespace dfe {
+__global__ void __launch_bounds__(256) k_pwc_cat_tail(const float* __restrict__ c1, const float* __restrict__ flow,
+                                                      float* __restrict__ x, int C, long HW, long xbs, int vec) {
+  // planes 81 .. 81+C-1 <- c1, 81+C .. 81+C+1 <- flow; grid.y = sample
+  const int b = blockIdx.y;
+  const long n = static_cast<long>(C + 2) * HW;
+  float* dst = x + static_cast<long>(b) * xbs + static_cast<long>(CR_K) * CR_K * HW;
+  const float* s1 = c1 + static_cast<long>(b) * C * HW;
+  const float* s2 = flow + static_cast<long>(b) * 2 * HW;
+  const long split = static_cast<long>(C) * HW;
+  if (vec) {
+    const long i = (static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float4 v = (i < split) ? *reinterpret_cast<const float4*>(s1 + i) : *reinterpret_cast<const float4*>(s2 + (i - split));
+    *reinterpret_cast<float4*>(dst + i) = v;
+  } else {
+    const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    dst[i] = (i < split) ? s1[i] : s2[i - split];
+  }
+}
+}  // namespace dfe
+
 using namespace dfe;
 
 #define DFE_REQUIRE(cond, code) do { if (!(cond)) return (code); } while (0)
@@ -931,29 +955,6 @@ int dfe_corr_bwd(const float* f1, const float* f2, const float* gout, float* g1,
 // ---------------------------------------------------------------- one PWC decoder level's input (pwc_tf.py:119-121)
 // x = cat(corr(c1, warp(c2, flow)), c1, flow): the cost volume is written straight into its slice of x and the
 // backward pass reads the three slices of dL/dx in place (no cat / slice copies, no gradient-accumulation passes).
-namespace dfe {
-__global__ void __launch_bounds__(256) k_pwc_cat_tail(const float* __restrict__ c1, const float* __restrict__ flow,
-                                                      float* __restrict__ x, int C, long HW, long xbs, int vec) {
-  // planes 81 .. 81+C-1 <- c1, 81+C .. 81+C+1 <- flow; grid.y = sample
-  const int b = blockIdx.y;
-  const long n = static_cast<long>(C + 2) * HW;
-  float* dst = x + static_cast<long>(b) * xbs + static_cast<long>(CR_K) * CR_K * HW;
-  const float* s1 = c1 + static_cast<long>(b) * C * HW;
-  const float* s2 = flow + static_cast<long>(b) * 2 * HW;
-  const long split = static_cast<long>(C) * HW;
-  if (vec) {
-    const long i = (static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x) * 4;
-    if (i >= n) return;
-    const float4 v = (i < split) ? *reinterpret_cast<const float4*>(s1 + i) : *reinterpret_cast<const float4*>(s2 + (i - split));
-    *reinterpret_cast<float4*>(dst + i) = v;
-  } else {
-    const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    dst[i] = (i < split) ? s1[i] : s2[i - split];
-  }
-}
-}  // namespace dfe
-
 int dfe_pwc_level_channels(int C) { return CR_K * CR_K + C + 2; }
 
 int dfe_pwc_level_fwd(const float* c1, const float* c2, const float* flow, float* warped, float* x, int B, int C, int H,
