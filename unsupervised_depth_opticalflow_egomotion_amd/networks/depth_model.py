@@ -123,12 +123,17 @@ class Depth_Model(nn.Module):
         larger convolutions.  Returns one disparity list per frame."""
         n, B = len(frames), frames[0].shape[0]
         bns = [m for m in self.modules() if isinstance(m, resnet.FrameBatchNorm2d)]
+        batched = self.training and frames[0].is_cuda
         for m in bns:
             m.groups = n
+            m.count_deferred = batched
         try:
+            if batched:     # one multi-tensor kernel instead of one tiny add per layer
+                torch._foreach_add_([m.num_batches_tracked for m in bns], n)
             out = self.forward(torch.cat(list(frames), 0))
         finally:
             for m in bns:
                 m.groups = 1
+                m.count_deferred = False
         parts = [o.split(B) for o in out]          # one concatenation in the backward pass instead of n zero-filled slices
         return [[q[i] for q in parts] for i in range(n)]

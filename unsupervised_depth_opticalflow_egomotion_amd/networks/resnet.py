@@ -18,12 +18,14 @@ class FrameBatchNorm2d(nn.BatchNorm2d):
     residual add and ReLU are applied to the output.  On a HIP device in training mode this is one fused op
     (ops.grouped_batch_norm); on the host, or in eval mode, the ATen graph."""
     groups = 1
+    count_deferred = False     # Depth_Model.forward_frames bumps every layer's num_batches_tracked in one foreach call
 
     def forward(self, x, residual=None, relu=False):
         if x.is_cuda and self.training:
             if self.momentum is None or not self.track_running_stats or not self.affine:
                 raise ValueError("FrameBatchNorm2d: only affine, momentum-tracked batch norm is implemented in HIP")
-            self.num_batches_tracked.add_(self.groups)
+            if not self.count_deferred:
+                self.num_batches_tracked.add_(self.groups)
             return ops.grouped_batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.groups,
                                           self.eps, self.momentum, residual=residual, relu=relu)
         if self.training and self.groups > 1:

@@ -629,7 +629,10 @@ class DenseDecodeFn(torch.autograd.Function):
             g3, gw[5], gbias[5] = cb(g_flow, cat[3], w[5], True, nw(5), [2], nb(5))       # d/d cat(x3, x4)
         else:
             g3 = torch.zeros_like(cat[3])
-        g_x4 = f32c(g_x4) if g_x4 is not None else None
+        if g_x4 is not None:     # usually a channel slice of the gradient of torch.cat([flow, x4]): read in place
+            if g_x4.dtype != torch.float32 or not (g_x4.stride(3) == 1 and g_x4.stride(2) == W and g_x4.stride(1) == HW
+                                                   and g_x4.stride(0) >= co[4] * HW):
+                g_x4 = f32c(g_x4)
         gz, gbias[4] = epilogue_bwd(4, cat[3], co[3], g3, co[3], g_x4, 0)                 # x4: cat3 slice + the returned copy
         g2, gw[4], _ = cb(gz, cat[2], w[4], True, nw(4))                                  # d/d cat(x2, x3)
         gz, gbias[3] = epilogue_bwd(3, cat[3], 0, g3, 0, g2, co[2])                       # x3
