@@ -35,7 +35,17 @@ __global__ void __launch_bounds__(64) k_thin_conv3x3(const float* __restrict__ i
     for (int t = 0; t < 9; ++t)
       w[c][t] = flip ? wgt[(static_cast<long>(4 * c + kq) * Co + m) * 9 + (8 - t)]      // w'[co'=m][ci'=4c+kq][t] of the data gradient
                      : wgt[(static_cast<long>(m) * Ci + 4 * c + kq) * 9 + t];
-  const float* ib = in + static_cast<long>(b) * Ci * Hi * Wi + static_cast<long>(kq) * Hi * Wi;
+  // wave-uniform sample bases + 32-bit per-lane offsets: the loads are plain `global_load v, voff, s[base]` with no
+  // 64-bit address arithmetic, and they are unconditional (clamped address, value zeroed afterwards) -- predicating
+  // each load with an exec-mask branch (66 s_and_saveexec / s_cbranch per tile) serialised their issue and cost
+  // 168 VGPRs (3 waves per SIMD): MFMA pipe 46 % busy, 74 % of wave-cycles waiting for issue (PMC, round 2).
+  // Measured and rejected in round 2: a 64-pixel-tile variant (a lane loads six consecutive pixels with three 8-byte
+  // loads, MFMA #j takes the pixel set {x0 + 4m + j}, kx operands are registers j + kx of the same lane: no DPP, wider
+  // loads, interior / border tiles in separate instantiations) -- 158-169 us against 157 us here at 16 -> 16, 256x832:
+  // 156-224 VGPRs leave 2-3 waves per SIMD, and rows of the padded activation are only 8-byte aligned, so the load
+  // count per output row does not drop.  Ablation of this kernel: no loads 134 us, no MFMA 146 us, neither 44 us.
+  const float* sb = in + static_cast<long>(b) * Ci * Hi * Wi;
+  const unsigned plane = static_cast<unsigned>(Hi) * static_cast<unsigned>(Wi);
   float* ob = out + static_cast<long>(b) * Co * Ho * Wo;
   const int ntx = (Wo + 15) / 16;
   const int t0 = seg * tiles_per_seg, t1 = min(t0 + tiles_per_seg, ntx);
@@ -46,13 +56,18 @@ __global__ void __launch_bounds__(64) k_thin_conv3x3(const float* __restrict__ i
   auto fetch = [&](int tx, float (&v)[NC4][TC_ROWS + 2]) {
     const int xx = tx * 16 + m - P;
     const bool colok = xx >= 0 && xx < Wi;
+    const unsigned xo = static_cast<unsigned>(min(max(xx, 0), Wi - 1)) + static_cast<unsigned>(kq) * plane;
 #pragma unroll
-    for (int c = 0; c < NC4; ++c)
+    for (int iy = 0; iy < TC_ROWS + 2; ++iy) {
+      const int yy = y0 + iy - P;
+      const bool ok = colok && yy >= 0 && yy < Hi;
+      const unsigned off = (static_cast<unsigned>(min(max(yy, 0), Hi - 1)) * static_cast<unsigned>(Wi) + xo) * 4u;
 #pragma unroll
-      for (int iy = 0; iy < TC_ROWS + 2; ++iy) {
-        const int yy = y0 + iy - P;
-        v[c][iy] = (colok && yy >= 0 && yy < Hi) ? ib[(static_cast<long>(4 * c) * Hi + yy) * Wi + xx] : 0.0f;
+      for (int c = 0; c < NC4; ++c) {
+        const float t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(sb + static_cast<long>(4 * c) * plane) + off);
+        v[c][iy] = ok ? t : 0.0f;
       }
+    }
   };
   float cur[NC4][TC_ROWS + 2], nxt[NC4][TC_ROWS + 2];
   if (t0 < t1) fetch(t0, cur);
@@ -86,7 +101,7 @@ __global__ void __launch_bounds__(64) k_thin_conv3x3(const float* __restrict__ i
     for (int r = 0; r < TC_ROWS; ++r) {
       const int y = y0 + r;
       if (y >= Ho) continue;
-      float* o = ob + (static_cast<long>(m) * Ho + y) * Wo + x0 + 4 * kq;
+      float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(ob) + ((static_cast<unsigned>(m) * Ho + y) * static_cast<unsigned>(Wo) + x0 + 4 * kq) * 4u);
       if (x0 + 16 <= Wo && (Wo & 3) == 0) *reinterpret_cast<tc_f32x4*>(o) = acc[r];
       else if (x0 + 16 <= Wo && (Wo & 1) == 0) {       // rows of the padded gradient start 8-byte aligned
         *reinterpret_cast<TcF2*>(o) = TcF2{acc[r][0], acc[r][1]};
@@ -115,7 +130,7 @@ extern "C" int dfe_thin_conv3x3(const float* in, const float* weight, float* out
   if (Co != 16 || (Ci != 16 && Ci != 32)) return DFE_ERR_UNSUPPORTED;
   if (transposed_weight && Ci != 16) return DFE_ERR_UNSUPPORTED;      // weight [16 (= Ci here)][16 (= Co here)][3][3] read transposed
   const int Ho = Hi + 2 * P - 2, Wo = Wi + 2 * P - 2;
-  if (Ho <= 0 || Wo <= 0 || static_cast<long>(Hi) * Wi * Ci >= (1L << 31) || static_cast<long>(Ho) * Wo * Co >= (1L << 31)) return DFE_ERR_DIMS;
+  if (Ho <= 0 || Wo <= 0 || static_cast<long>(Hi) * Wi * Ci >= (1L << 30) || static_cast<long>(Ho) * Wo * Co >= (1L << 30)) return DFE_ERR_DIMS;   // 32-bit byte offsets per sample
   if (reinterpret_cast<uintptr_t>(out) & 15) return DFE_ERR_UNSUPPORTED;
   const int nrb = (Ho + TC_ROWS - 1) / TC_ROWS, ntx = (Wo + 15) / 16;
   int nseg = 1;                 // ~4096 waves: split the rows of tiles into segments when there are few row blocks
