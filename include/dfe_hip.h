@@ -293,7 +293,9 @@ typedef struct dfe_geom_args {
   float* grad_disp[3][DFE_MAX_SCALES]; /* backward out, same shapes as disp (NULL = skip) */
   float* grad_flow[2][DFE_MAX_SCALES]; /* backward out, same shapes as flow (NULL = skip) */
   float* grad_pose;          /* backward out [B,2,6] (NULL = skip) */
-  int depth_terms;           /* mode 0 only: DFE_DEPTH_TERM_* bits; 0 = the reference as shipped.  With
+  int depth_terms;           /* modes 0 and 1: DFE_DEPTH_TERM_* bits; 0 = the reference as shipped (mode 1 = the same two
+                                lines of Model_depth, model_depth.py:326-327,332-333: mask = validity x texture, the
+                                consistency term unmasked).  With
                                 DFE_DEPTH_TERM_CONSIS the SOURCE disparities grad_disp[0], grad_disp[2] also receive the
                                 gradient of the projected depth (a bilinear scatter: float atomics, reproducible to
                                 rounding only); everything else stays bitwise reproducible. */

@@ -638,14 +638,15 @@ class GeomLossOracle:
         return lp, masks
 
     # Model_depth.forward loss stack (model_depth.py:272-337) ----------------------
-    def depth_losses(self, img_l, img, img_r, depth_l_list, depth_list, depth_r_list, pose_vectors, K):
+    def depth_losses(self, img_l, img, img_r, depth_l_list, depth_list, depth_r_list, pose_vectors, K,
+                     enable_depth_ssim=False, enable_depth_consis=False):
         S = self.num_scales
         pose_bwd, pose_fwd = pose_vectors[:, 0, :], pose_vectors[:, 1, :]
         img_list = self.generate_img_pyramid(img, S)
         img_l_list = self.generate_img_pyramid(img_l, S)
         img_r_list = self.generate_img_pyramid(img_r, S)
-        rec_l, valid_l, _, _ = self.reconstruction(img_l, K, depth_list, depth_l_list, pose_bwd)
-        rec_r, valid_r, _, _ = self.reconstruction(img_r, K, depth_list, depth_r_list, pose_fwd)
+        rec_l, valid_l, pd_l, cd_l = self.reconstruction(img_l, K, depth_list, depth_l_list, pose_bwd)
+        rec_r, valid_r, pd_r, cd_r = self.reconstruction(img_r, K, depth_list, depth_r_list, pose_fwd)
         tex_bwd = self.compute_texture_mask(img_list, rec_l, img_l_list)
         tex_fwd = self.compute_texture_mask(img_list, rec_r, img_r_list)
         m_bwd = self.fusion_mask_2item(valid_l, tex_bwd)
@@ -654,10 +655,14 @@ class GeomLossOracle:
         lp = {}
         lp["loss_depth_pixel"] = self.compute_photometric_loss(img_list, rec_l, m_bwd) + \
             self.compute_photometric_loss(img_list, rec_r, m_fwd)
-        lp["loss_depth_ssim"] = torch.zeros([2]).to(dev).requires_grad_()
+        # the two terms the reference keeps commented (model_depth.py:326-327,332-333), as written there
+        lp["loss_depth_ssim"] = (self.compute_ssim_loss(img_list, rec_l, m_bwd) +
+                                 self.compute_ssim_loss(img_list, rec_r, m_fwd)) if enable_depth_ssim \
+            else torch.zeros([2]).to(dev).requires_grad_()
         lp["loss_depth_smooth"] = self.compute_smooth_loss(img, depth_list) + \
             self.compute_smooth_loss(img_l, depth_l_list) + self.compute_smooth_loss(img_r, depth_r_list)
-        lp["loss_depth_consis"] = torch.zeros([2]).to(dev).requires_grad_()
+        lp["loss_depth_consis"] = (self.compute_consis_loss(pd_l, cd_l) + self.compute_consis_loss(pd_r, cd_r)) \
+            if enable_depth_consis else torch.zeros([2]).to(dev).requires_grad_()
         return lp, dict(mask_bwd=m_bwd, mask_fwd=m_fwd, texture_bwd=tex_bwd, texture_fwd=tex_fwd,
                         valid_to_l=valid_l, valid_to_r=valid_r)
 

@@ -444,6 +444,26 @@ def gen_g9(ref, out):
         for s in range(3):
             out["gdisp_%d_%d" % (f, s)] = N(disps[f][s].grad) if disps[f][s].grad is not None else np.zeros(tuple(disps[f][s].shape), np.float32)
     store_margins(out, "g9", inp, CURRENT_AC[0])
+    # Model_depth's commented terms (model_depth.py:326-327,332-333): SSIM on validity x texture, the consistency term
+    # without a mask (model_depth.py:154-163) -- the reference's own methods on a bare Model_depth, same inputs
+    md = ref["Model_depth"].__new__(ref["Model_depth"])
+    nn.Module.__init__(md)
+    md.num_scales, md.dataset = 3, "kitti_depth"
+    disps, pose, _, _ = lists_to_t(inp, True)
+    pyr_l, pyr_t, pyr_r = (md.generate_img_pyramid(x, 3) for x in (il, it, ir))
+    rec_l, vl, pdl, cdl = md.reconstruction(il, K, disps[1], disps[0], pose[:, 0])
+    rec_r, vr, pdr, cdr = md.reconstruction(ir, K, disps[1], disps[2], pose[:, 1])
+    with torch.no_grad():
+        m_b = md.fusion_mask(vl, md.compute_texture_mask(pyr_t, rec_l, pyr_l))
+        m_f = md.fusion_mask(vr, md.compute_texture_mask(pyr_t, rec_r, pyr_r))
+    l_ssim = md.compute_ssim_loss(pyr_t, rec_l, m_b) + md.compute_ssim_loss(pyr_t, rec_r, m_f)
+    l_cons = md.compute_consis_loss(pdl, cdl) + md.compute_consis_loss(pdr, cdr)
+    (0.85 * l_ssim.mean() + 0.1 * l_cons.mean()).backward()
+    out["md_loss_depth_ssim"], out["md_loss_depth_consis"] = N(l_ssim), N(l_cons)
+    out["md_gpose"] = N(pose.grad)
+    for f in range(3):
+        for s in range(3):
+            out["md_gdisp_%d_%d" % (f, s)] = N(disps[f][s].grad) if disps[f][s].grad is not None else np.zeros(tuple(disps[f][s].shape), np.float32)
 
 
 # ------------------------------------------------------------------------------------ G7 (real nets)

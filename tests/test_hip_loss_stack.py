@@ -280,7 +280,8 @@ def test_flow_mode_vs_oracle(shape, S, ac):
 
 @pytest.mark.parametrize("ac", [False, True])
 @pytest.mark.parametrize("shape,S", [((2, 128, 448), 3), ((3, 70, 100), 2), ((1, 256, 832), 4)])
-def test_depth_mode_vs_oracle(shape, S, ac):
+@pytest.mark.parametrize("depth_terms", [False, True])
+def test_depth_mode_vs_oracle(shape, S, ac, depth_terms):
     """mode 1 (Model_depth stack, model_depth.py:272-337): the inverse_warp2 validity and texture masks are exact IEEE
     arithmetic on identical inputs -> they must EQUAL the oracle's (no noise floor on this path: no transcendental
     feeds a decision); losses 5e-6, gradients 1e-4 of their scale element-wise, pose gradient 2e-5."""
@@ -288,15 +289,20 @@ def test_depth_mode_vs_oracle(shape, S, ac):
     b, h, w = shape
     inp = synthetic.make_loss_stack_inputs(b, h, w, S, seed=1700 + h)
     wts = dict(loss_depth_pixel=1.0, loss_depth_smooth=0.1)
+    if depth_terms:   # the terms the reference keeps commented (model_depth.py:326-327,332-333), config weights
+        wts.update(loss_depth_ssim=0.85, loss_depth_consis=0.1)
     dh = [[G(a, True) for a in lst] for lst in inp.disps]
     ph = G(inp.pose, True)
     lp_h, mk_h = depth_loss_stack(*[G(a) for a in inp.imgs], dh[0], dh[1], dh[2], ph, G(inp.K), num_scales=S,
-                                  align_corners=ac, return_masks=True)
+                                  align_corners=ac, return_masks=True, enable_depth_ssim=depth_terms,
+                                  enable_depth_consis=depth_terms)
+    assert set(lp_h) == set(wts)
     sum(wts[k] * v.mean() for k, v in lp_h.items()).backward()
     do = [[T(a).requires_grad_(True) for a in lst] for lst in inp.disps]
     po = T(inp.pose).requires_grad_(True)
     lp_o, mk_o = O.GeomLossOracle(num_scales=S, align_corners=ac).depth_losses(
-        *[T(a) for a in inp.imgs], do[0], do[1], do[2], po, T(inp.K))
+        *[T(a) for a in inp.imgs], do[0], do[1], do[2], po, T(inp.K), enable_depth_ssim=depth_terms,
+        enable_depth_consis=depth_terms)
     sum(wts[k] * lp_o[k].mean() for k in wts).backward()
     for k in ("valid_to_l", "valid_to_r", "texture_bwd", "texture_fwd"):
         for s in range(S):

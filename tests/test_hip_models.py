@@ -293,6 +293,44 @@ def test_disabled_depth_terms_vs_reference(golden_dir, ac):
         ops.set_align_corners(prev)
 
 
+@pytest.mark.parametrize("ac", [False, True])
+def test_model_depth_disabled_terms_vs_reference(golden_dir, ac):
+    """Model_depth with cfg.enable_depth_ssim / enable_depth_consis: the two terms model_depth.py:326-327,332-333 keeps
+    commented (SSIM on the validity x texture mask, the unmasked consistency term of model_depth.py:154-163) in the fused
+    mode-1 launches, against golden G9's md_* arrays (the reference's own Model_depth methods): values 5e-6, gradients
+    wrt target and source disparities 1e-4 of their scale, pose gradient 2e-5."""
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+    from unsupervised_depth_opticalflow_egomotion_amd.models import Model_depth
+    g = np.load(os.path.join(golden_dir, "G9_ac%d.npz" % ac))
+    inp = synthetic.make_loss_stack_inputs(*MG.G9_SHAPE, 3, seed=MG.G9_SEED)
+    m = Model_depth.__new__(Model_depth); torch.nn.Module.__init__(m)
+    m.num_scales = 3
+    m.enable_depth_ssim = m.enable_depth_consis = True
+    disps = [[G(a, True) for a in lst] for lst in inp.disps]
+    pose = G(inp.pose, True)
+    prev = ops.get_align_corners()
+    ops.set_align_corners(ac)
+    try:
+        lp, _ = m.loss_stack(*[G(a) for a in inp.imgs], disps[0], disps[1], disps[2], pose, G(inp.K))
+        (0.85 * lp["loss_depth_ssim"].mean() + 0.1 * lp["loss_depth_consis"].mean()).backward()
+        m.enable_depth_ssim = m.enable_depth_consis = False
+        lp0, _ = m.loss_stack(*[G(a) for a in inp.imgs], disps[0], disps[1], disps[2], pose, G(inp.K))
+    finally:
+        ops.set_align_corners(prev)
+    for k in ("loss_depth_ssim", "loss_depth_consis"):
+        np.testing.assert_allclose(N(lp[k]), g["md_" + k], rtol=5e-6, atol=1e-7, err_msg=k)
+        assert float(lp0[k].detach().abs().sum()) == 0.0 and lp0[k].shape == (2,)
+    for k in ("loss_depth_pixel", "loss_depth_smooth"):
+        assert torch.equal(lp[k], lp0[k])
+    gp = g["md_gpose"]
+    assert np.abs(N(pose.grad) - gp).max() <= 2e-5 * np.abs(gp).max()
+    for f in range(3):
+        for s in range(3):
+            ref = g["md_gdisp_%d_%d" % (f, s)]
+            got = N(disps[f][s].grad) if disps[f][s].grad is not None else np.zeros_like(ref)
+            assert np.abs(got - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-12) + 1e-9, (f, s)
+
+
 def test_train_step_runs_and_learns():
     from unsupervised_depth_opticalflow_egomotion_amd.train_step import make_cfg, train_step
     from unsupervised_depth_opticalflow_egomotion_amd.models import get_model

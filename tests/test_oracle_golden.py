@@ -281,3 +281,15 @@ def test_g9_disabled_depth_terms(golden_dir, ac):
         for s in range(3):
             got = N(d[f][s].grad) if d[f][s].grad is not None else np.zeros_like(g["gdisp_%d_%d" % (f, s)])
             gscale(got, g["gdisp_%d_%d" % (f, s)], rel=5e-5, atol=1e-9)
+    # Model_depth's variants (model_depth.py:326-327,332-333: validity x texture mask; consistency without a mask)
+    d, p, _, _ = MG.lists_to_t(inp, True)
+    lp, _ = m.depth_losses(*[T(a) for a in inp.imgs], d[0], d[1], d[2], p, T(inp.K), enable_depth_ssim=True,
+                           enable_depth_consis=True)
+    (0.85 * lp["loss_depth_ssim"].mean() + 0.1 * lp["loss_depth_consis"].mean()).backward()
+    close(N(lp["loss_depth_ssim"]), g["md_loss_depth_ssim"])
+    close(N(lp["loss_depth_consis"]), g["md_loss_depth_consis"])
+    gscale(N(p.grad), g["md_gpose"], rel=5e-5, atol=1e-6)
+    for f in range(3):
+        for s in range(3):
+            got = N(d[f][s].grad) if d[f][s].grad is not None else np.zeros_like(g["md_gdisp_%d_%d" % (f, s)])
+            gscale(got, g["md_gdisp_%d_%d" % (f, s)], rel=5e-5, atol=1e-9)

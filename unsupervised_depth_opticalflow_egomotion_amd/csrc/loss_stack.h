@@ -84,6 +84,12 @@ struct RowRaw { float a[3], b[3]; };   // masked target / warped values of one r
 // the loads of rows y+2.. are in flight while row y is reduced (software prefetch: ~2 waves per SIMD only)
 // The per-pixel SSIM weight is either a bit test on the mask pack (modes 0/1: valid & occ of this direction) or a
 // float soft weight (mode 2, Model_flow): `mk` then points at the float plane and `need` is 0.
+// mask bits (direction 0) of the depth-SSIM term: Model_geometry gates it with valid & occ & dyna & texture
+// (model_geometry.py:889-891), Model_depth with inverse_warp2-validity & texture (model_depth.py:326-327)
+__device__ __forceinline__ unsigned rigid_ssim_mask(int mode) {
+  return mode == 1 ? (DFE_MASK_VALID_BWD | DFE_MASK_TEX_BWD) : (DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD | DFE_MASK_DYNA_BWD | DFE_MASK_TEX_BWD);
+}
+
 __device__ __forceinline__ float ssim_weight_at(const unsigned char* __restrict__ mk, unsigned need, int q) {
   if (need == 0u) return reinterpret_cast<const float*>(mk)[q];
   return ((mk[q] & need) == need) ? 1.0f : 0.0f;

@@ -81,8 +81,7 @@ __global__ void __launch_bounds__(64) k_geom_ssim_bwd_roll(GeomDev D, GeomBwd G,
   const float* yw = (rigid ? D.yr[s] : D.yw[s]) + (static_cast<long>(d) * D.B + b) * 3 * N;
   const unsigned char* mk = D.mode == 2 ? reinterpret_cast<const unsigned char*>(D.wgt[s] + (static_cast<long>(d) * D.B + b) * N)
                                         : D.mask[s] + static_cast<long>(b) * N;
-  const unsigned need = D.mode == 2 ? 0u : (rigid ? DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD | DFE_MASK_DYNA_BWD | DFE_MASK_TEX_BWD
-                                                   : DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD) << d;
+  const unsigned need = D.mode == 2 ? 0u : (rigid ? rigid_ssim_mask(D.mode) : DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD) << d;
   float* gw = (rigid ? G.gyr[s] : G.gw[s]) + (static_cast<long>(d) * D.B + b) * 3 * N;
   const float gscale = -0.5f * G.gl[(rigid ? DFE_LOSS_DEPTH_SSIM : DFE_LOSS_FLOW_SSIM) * D.B + b] *
                        G.coef[(static_cast<long>(b) * D.S + s) * CF_COUNT + d * CF_PER_DIR + (rigid ? CF_DEPTH : CF_VO)];
@@ -365,6 +364,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_flow_point_bwd(GeomDev D, GeomBwd 
 
 // ---------------------------------------------------------------------- depth-only pointwise backward
 // Model_depth: gradient of the masked L1 on the rigid recon wrt the target disparity and the camera sums.
+template <bool DT>
 __global__ void __launch_bounds__(GS_BLOCK) k_depth_point_bwd(GeomDev D, GeomBwd G) {
   __shared__ float red[PB_COUNT * 4 * (GS_BLOCK / 64)];
   const unsigned nblk_total = D.blk_start[D.S];
@@ -391,21 +391,48 @@ __global__ void __launch_bounds__(GS_BLOCK) k_depth_point_bwd(GeomDev D, GeomBwd
       const bool m = (bits & (DFE_MASK_VALID_BWD << d)) && (bits & (DFE_MASK_TEX_BWD << d));
       const Camera& cam = D.cams[(b * 2 + d) * D.S + s];
       Proj pr = project(cam, px, py, dsp);
-      float gU = 0.0f, gV = 0.0f;
-      if (m) {
+      float gU = 0.0f, gV = 0.0f, gZ = 0.0f;
+      const bool consis = DT && (D.dt & DFE_DEPTH_TERM_CONSIS);      // unmasked in Model_depth: every pixel
+      if (m || consis) {
         float xn, yn; bool lx, ly;
         rigid_grid(pr, H, W, xn, yn, lx, ly);
         Tap t = make_tap(unnormalize(xn, W, D.ac), unnormalize(yn, H, D.ac), H, W);
-        const float* ar = D.area[d][s] + static_cast<long>(b) * 3 * N;
-        const float gc = g_dp * cf[d * CF_PER_DIR + CF_DEPTH];
         float gix = 0.0f, giy = 0.0f;
+        if (m) {
+          const float* ar = D.area[d][s] + static_cast<long>(b) * 3 * N;
+          const float gc = g_dp * cf[d * CF_PER_DIR + CF_DEPTH];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          Corners q = load_corners(ar + static_cast<long>(c) * N, t, W, H);
-          float dx, dy;
-          interp_grad(q, t, dx, dy);
-          const float g = sgn(interp(q, t) - im[c]) * gc;
-          gix += g * dx; giy += g * dy;
+          for (int c = 0; c < 3; ++c) {
+            Corners q = load_corners(ar + static_cast<long>(c) * N, t, W, H);
+            float dx, dy;
+            interp_grad(q, t, dx, dy);
+            float g = sgn(interp(q, t) - im[c]) * gc;
+            if (DT && (D.dt & DFE_DEPTH_TERM_SSIM)) g += G.gyr[s][(static_cast<long>(d) * B + b) * 3 * N + static_cast<long>(c) * N + p];
+            gix += g * dx; giy += g * dy;
+          }
+        }
+        if (consis) {
+          const int fs = d == 0 ? 0 : 2;
+          const Corners qd = load_corners(D.disp[fs][s] + static_cast<long>(b) * N, t, W, H);
+          const float v = interp(qd, t);
+          const float pd = (v >= 1e-3f || v != v) ? v : 1e-3f, cd = pr.Z;
+          const float num = cd - pd, den = cd + pd, qv = fabsf(num) / fabsf(den);
+          if (qv >= 0.0f && qv <= 1.0f) {
+            const float gq = G.gl[DFE_LOSS_DEPTH_CONSIS * B + b] / static_cast<float>(N);
+            const float a = sgn(num) / fabsf(den), bq = qv * sgn(den) / fabsf(den);
+            gZ = gq * (a - bq);
+            const float gp = (v >= 1e-3f) ? gq * (-a - bq) : 0.0f;
+            float dx, dy;
+            interp_grad(qd, t, dx, dy);
+            gix += gp * dx; giy += gp * dy;
+            if (G.gdisp[fs][s] && gp != 0.0f) {
+              float* base = G.gdisp[fs][s] + static_cast<long>(b) * N + static_cast<long>(t.y0) * W + t.x0;
+              if (t.in_nw) atomicAdd(base, gp * t.nw);
+              if (t.in_ne) atomicAdd(base + 1, gp * t.ne);
+              if (t.in_sw) atomicAdd(base + W, gp * t.sw);
+              if (t.in_se) atomicAdd(base + W + 1, gp * t.se);
+            }
+          }
         }
         const float sx = D.ac ? static_cast<float>(W - 1) / 2.0f : static_cast<float>(W) / 2.0f;
         const float sy = D.ac ? static_cast<float>(H - 1) / 2.0f : static_cast<float>(H) / 2.0f;
@@ -413,7 +440,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_depth_point_bwd(GeomDev D, GeomBwd
         if (ly) gV = giy * sy * (2.0f / static_cast<float>(H - 1));
       }
       float gd;
-      project_backward(pr, dsp, gU, gV, 0.0f, gd, acc + d * PB_PER_DIR);
+      project_backward(pr, dsp, gU, gV, gZ, gd, acc + d * PB_PER_DIR);
       gdisp += gd;
     }
     if (G.gdisp[1][s]) G.gdisp[1][s][o1] = gdisp;
@@ -863,8 +890,13 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     return DFE_OK;
   }
   if (a->mode == 1) {
+    if (L.dt & DFE_DEPTH_TERM_SSIM) {
+      k_geom_ssim_bwd_roll<<<dim3(L.rollb_start[L.S], L.B * 2), 64, 0, st>>>(D, G, 1);
+      DFE_LAUNCH_CHECK();
+    }
     DFE_MARK();
-    k_depth_point_bwd<<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, G);
+    if (L.dt) k_depth_point_bwd<true><<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, G);
+    else k_depth_point_bwd<false><<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, G);
     DFE_LAUNCH_CHECK();
     DFE_MARK(); DFE_MARK();
   } else {

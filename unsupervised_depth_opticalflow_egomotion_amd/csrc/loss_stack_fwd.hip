@@ -72,7 +72,7 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
   L->o_gw = o; o = align4(o + 2 * B * 3 * sumN);
   L->o_gup = o; o = align4(o + 3 * (S - 1) * B * static_cast<long>(L->N[0]));
   L->o_bpart = o; o = align4(o + B * nblk_total * PB_COUNT);
-  L->dt = (a->mode == 0) ? (a->depth_terms & (DFE_DEPTH_TERM_SSIM | DFE_DEPTH_TERM_CONSIS)) : 0;
+  L->dt = (a->mode != 2) ? (a->depth_terms & (DFE_DEPTH_TERM_SSIM | DFE_DEPTH_TERM_CONSIS)) : 0;
   L->o_yr = o; o = align4(o + ((L->dt & DFE_DEPTH_TERM_SSIM) ? 2 * B * 3 * sumN : 0));
   L->o_gyr = o; o = align4(o + ((L->dt & DFE_DEPTH_TERM_SSIM) ? 2 * B * 3 * sumN : 0));
   L->o_part2 = o; o = align4(o + (L->dt ? B * nblk_total * 2 : 0));
@@ -469,7 +469,10 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, GeomT T,
 // ---------------------------------------------------------------------- depth-only pointwise forward
 // Model_depth loss stack (model_depth.py:296-323): rigid recon of both sources, mask = inverse_warp2
 // validity * texture mask, masked-L1 sums.  One pixel per thread over the 1-px block table.
-__global__ void __launch_bounds__(GS_BLOCK) k_depth_point_fwd(GeomDev D, float* __restrict__ part) {
+// DT: + the commented terms of Model_depth.forward (model_depth.py:326-335): SSIM over the rigid reconstructions on the
+// validity x texture mask, and compute_consis_loss (model_depth.py:154-163) -- here WITHOUT a mask (plain mean).
+template <bool DT>
+__global__ void __launch_bounds__(GS_BLOCK) k_depth_point_fwd(GeomDev D, float* __restrict__ part, float* __restrict__ part2) {
   __shared__ float red[PT_COUNT * 4 * (GS_BLOCK / 64)];
   const unsigned nblk_total = D.blk_start[D.S];
   const unsigned blk = xcd_swizzle(blockIdx.x, nblk_total);
@@ -480,6 +483,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_depth_point_fwd(GeomDev D, float* 
   float acc[PT_COUNT];
 #pragma unroll
   for (int i = 0; i < PT_COUNT; ++i) acc[i] = 0.0f;
+  float dc[2] = {0.0f, 0.0f};
   if (p < static_cast<unsigned>(N)) {
     const unsigned py = p / static_cast<unsigned>(W), px = p - py * W;
     const unsigned p4 = p * 4u, N4 = static_cast<unsigned>(N) * 4u;
@@ -506,10 +510,21 @@ __global__ void __launch_bounds__(GS_BLOCK) k_depth_point_fwd(GeomDev D, float* 
       acc[d * PT_PER_DIR + PT_M_TEX] = m;
       acc[d * PT_PER_DIR + PT_L1_DEPTH] = ((fabsf(i0 - rec[0]) + fabsf(i1 - rec[1])) + fabsf(i2 - rec[2])) * m;
       bits |= (valid ? (DFE_MASK_VALID_BWD << d) : 0u) | (tex ? (DFE_MASK_TEX_BWD << d) : 0u);
+      if (DT) {
+        if (D.dt & DFE_DEPTH_TERM_SSIM) {
+          float* yrp = D.yr[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) stb(yrp, p4 + ch * N4, rec[ch] * m);
+        }
+        const float v = fast_sample(D.disp[d == 0 ? 0 : 2][s] + static_cast<long>(b) * N, t);
+        const float pd = (v >= 1e-3f || v != v) ? v : 1e-3f;
+        dc[d] = fminf(fmaxf(fabsf(pr.Z - pd) / fabsf(pr.Z + pd), 0.0f), 1.0f);
+      }
     }
     (D.mask[s] + static_cast<long>(b) * N)[p] = static_cast<unsigned char>(bits);
   }
   block_sum<PT_COUNT>(acc, red, part + (static_cast<long>(b) * nblk_total + blk) * PT_COUNT);
+  if (DT) block_sum<2>(dc, red, part2 + (static_cast<long>(b) * nblk_total + blk) * 2);
 }
 
 // ---------------------------------------------------------------------- flow-only pointwise forward
@@ -602,8 +617,7 @@ __global__ void __launch_bounds__(64) k_geom_ssim_fwd_roll(GeomDev D, float* __r
   const float* yw = (rigid ? D.yr[s] : D.yw[s]) + (static_cast<long>(d) * D.B + b) * 3 * N;
   const unsigned char* mk = D.mode == 2 ? reinterpret_cast<const unsigned char*>(D.wgt[s] + (static_cast<long>(d) * D.B + b) * N)
                                         : D.mask[s] + static_cast<long>(b) * N;
-  const unsigned need = D.mode == 2 ? 0u : (rigid ? DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD | DFE_MASK_DYNA_BWD | DFE_MASK_TEX_BWD
-                                                   : DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD) << d;
+  const unsigned need = D.mode == 2 ? 0u : (rigid ? rigid_ssim_mask(D.mode) : DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD) << d;
   const bool lane_ok = threadIdx.x >= 1 && threadIdx.x <= RS_COLS && x < W;
   float acc = 0.0f;
   RowRaw w0 = ssim_load(it, yw, mk, need, y0 - 1, x, H, W, N);
@@ -853,7 +867,7 @@ __global__ void k_geom_assemble_fwd(GeomDev D, const float* __restrict__ sums, c
       if (sums2) {   // same texture-gated mask and normaliser as the depth pixel term
         const float* q = sums2 + (static_cast<long>(b) * S + s) * 4;
         l_dss += (q[d] / (3.0 * N)) / n_tex;
-        l_dcs += (q[2 + d] / N) / n_tex;
+        l_dcs += (D.mode == 1) ? q[2 + d] / N : (q[2 + d] / N) / n_tex;   // Model_depth's consistency term carries no mask
       }
       if (D.mode == 2) l_fp += (a[PT_L1_RIG] / N) / n_vo;   // 1-channel diff broadcast over 3 channels (model_flow.py:94-103)
       else l_fp += (a[PT_L1_RIG] / (3.0 * N)) / n_rig + 2.0 * (a[PT_L1_DYN] / (3.0 * N)) / n_dyn;
@@ -1009,9 +1023,15 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     DFE_MARK();
   } else if (a->mode == 1) {
     // Model_depth: rigid recon + validity*texture mask + masked L1 only (no flows, no SSIM, no flow terms)
-    k_depth_point_fwd<<<dim3(L.blk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part);
+    if (L.dt) k_depth_point_fwd<true><<<dim3(L.blk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part, ws + L.o_part2);
+    else k_depth_point_fwd<false><<<dim3(L.blk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, ws + L.o_part, nullptr);
     DFE_LAUNCH_CHECK();
-    DFE_MARK(); DFE_MARK(); DFE_MARK();
+    DFE_MARK();
+    if (L.dt & DFE_DEPTH_TERM_SSIM) {
+      k_geom_ssim_fwd_roll<<<dim3(L.roll_start[L.S], L.B * 2), 64, 0, st>>>(D, ws + L.o_spart2, 1);
+      DFE_LAUNCH_CHECK();
+    }
+    DFE_MARK(); DFE_MARK();
   } else {
     if (L.dt) k_geom_point_fwd<true><<<dim3(L.blk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, T, ws + L.o_part, ws + L.o_part2);
     else k_geom_point_fwd<false><<<dim3(L.blk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, T, ws + L.o_part, nullptr);

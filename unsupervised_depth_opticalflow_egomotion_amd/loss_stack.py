@@ -58,7 +58,7 @@ def _fill_args(imgs, disps, flows, pose, K, K_inv, S, alpha, beta, ac, mode=0, d
     a = GeomArgs()
     B, _, H, W = imgs[0].shape
     a.B, a.H, a.W, a.num_scales, a.align_corners, a.mode = B, H, W, S, int(ac), int(mode)
-    a.depth_terms = int(depth_terms) if mode == 0 else 0
+    a.depth_terms = int(depth_terms) if mode != 2 else 0
     a.alpha, a.beta = float(alpha), float(beta)
     for f in range(3):
         if tuple(imgs[f].shape) != (B, 3, H, W):
@@ -228,16 +228,23 @@ def geom_loss_stack(img_l, img, img_r, disp_l_list, disp_list, disp_r_list, pose
 
 
 def depth_loss_stack(img_l, img, img_r, depth_l_list, depth_list, depth_r_list, pose_vectors, K, num_scales=3,
-                     align_corners=None, return_masks=False):
+                     align_corners=None, return_masks=False, enable_depth_ssim=False, enable_depth_consis=False):
     """Active ``loss_pack`` entries of Model_depth.forward (model_depth.py:272-337): ``loss_depth_pixel`` with
-    the inverse_warp2-validity x texture mask and ``loss_depth_smooth``, in the fused launches (mode 1)."""
+    the inverse_warp2-validity x texture mask and ``loss_depth_smooth``, in the fused launches (mode 1).
+    ``enable_depth_ssim`` / ``enable_depth_consis`` add the two terms the reference keeps commented there
+    (model_depth.py:326-327,332-333: SSIM on the same mask, compute_consis_loss :154-163 without a mask)."""
     S = int(num_scales)
     ac = ops.get_align_corners() if align_corners is None else bool(align_corners)
     tensors = [img_l, img, img_r] + list(depth_l_list[:S]) + list(depth_list[:S]) + list(depth_r_list[:S]) \
         + [pose_vectors, K]
-    losses, ws = GeomLossFn.apply(1, S, 0.0, 0.0, int(ac), 0, *tensors)
+    dt = (DEPTH_TERM_SSIM if enable_depth_ssim else 0) | (DEPTH_TERM_CONSIS if enable_depth_consis else 0)
+    losses, ws = GeomLossFn.apply(1, S, 0.0, 0.0, int(ac), dt, *tensors)
     rows = losses.unbind(0)
     pack = {"loss_depth_pixel": rows[0], "loss_depth_smooth": rows[1]}
+    if enable_depth_ssim:
+        pack["loss_depth_ssim"] = rows[8]
+    if enable_depth_consis:
+        pack["loss_depth_consis"] = rows[9]
     if not return_masks:
         return pack
     B, _, H, W = img.shape

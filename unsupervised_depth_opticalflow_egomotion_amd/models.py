@@ -225,6 +225,9 @@ class Model_depth(LossTerms, nn.Module):
         self.num_scales = cfg.num_scales
         self.depth_net = Depth_Model(cfg.num_scales)
         self.pose_net = PoseCNN(cfg.num_input_frames)
+        # the two depth terms the reference keeps commented (model_depth.py:326-327,332-333); off = placeholders
+        self.enable_depth_ssim = bool(getattr(cfg, "enable_depth_ssim", False))
+        self.enable_depth_consis = bool(getattr(cfg, "enable_depth_consis", False))
 
     def infer_depth(self, img):
         return self.disp2depth(self.depth_net(img)[0])
@@ -247,10 +250,14 @@ class Model_depth(LossTerms, nn.Module):
     def loss_stack(self, img_l, img, img_r, depth_l, depth_t, depth_r, pose, K):
         """model_depth.py:296-335 in the fused HIP launches (mode 1 of dfe_geom_loss_fwd/bwd)."""
         active = depth_loss_stack(img_l, img, img_r, depth_l, depth_t, depth_r, pose, K.contiguous(),
-                                  num_scales=self.num_scales)
+                                  num_scales=self.num_scales,
+                                  enable_depth_ssim=getattr(self, "enable_depth_ssim", False),
+                                  enable_depth_consis=getattr(self, "enable_depth_consis", False))
         dev = img.device
-        loss_pack = {"loss_depth_pixel": active["loss_depth_pixel"], "loss_depth_ssim": _zeros2(dev),
-                     "loss_depth_smooth": active["loss_depth_smooth"], "loss_depth_consis": _zeros2(dev)}
+        loss_pack = {"loss_depth_pixel": active["loss_depth_pixel"],
+                     "loss_depth_ssim": active["loss_depth_ssim"] if "loss_depth_ssim" in active else _zeros2(dev),
+                     "loss_depth_smooth": active["loss_depth_smooth"],
+                     "loss_depth_consis": active["loss_depth_consis"] if "loss_depth_consis" in active else _zeros2(dev)}
         return loss_pack, {}
 
     def loss_stack_per_op(self, img_l, img, img_r, depth_l, depth_t, depth_r, pose, K):
