@@ -23,6 +23,13 @@ MASK_BITS = dict(valid_bwd=0x01, valid_fwd=0x02, occ_bwd=0x04, occ_fwd=0x08, dyn
 _FP = ctypes.c_void_p
 
 
+class LossRows(dict):
+    """dict of per-term (B,) loss vectors that also carries the fused stack's whole [rows, B] loss tensor
+    (``rows`` = (tensor, {term name: row index})), so that the weighted total can be formed from that one tensor
+    (train_step.total_loss) instead of a mean, a multiply and an add per term."""
+    rows = None
+
+
 class GeomArgs(ctypes.Structure):
     """Mirror of ``dfe_geom_args`` (include/dfe_hip.h)."""
     _fields_ = [
@@ -214,11 +221,12 @@ def geom_loss_stack(img_l, img, img_r, disp_l_list, disp_list, disp_r_list, pose
     dt = (DEPTH_TERM_SSIM if enable_depth_ssim else 0) | (DEPTH_TERM_CONSIS if enable_depth_consis else 0)
     losses, ws = GeomLossFn.apply(0, S, float(flow_consist_alpha), float(flow_consist_beta), int(ac), dt, *tensors)
     rows = losses.unbind(0)          # one stack in the backward pass instead of a zero-filled [10,B] per selected row
-    pack = {name: rows[i] for i, name in enumerate(LOSS_ROWS[:8])}
+    pack = LossRows({name: rows[i] for i, name in enumerate(LOSS_ROWS[:8])})
     if enable_depth_ssim:
         pack["loss_depth_ssim"] = rows[8]
     if enable_depth_consis:
         pack["loss_depth_consis"] = rows[9]
+    pack.rows = (losses, {name: LOSS_ROWS.index(name) for name in pack})
     if not return_masks:
         return pack
     B, _, H, W = img.shape
@@ -240,11 +248,12 @@ def depth_loss_stack(img_l, img, img_r, depth_l_list, depth_list, depth_r_list, 
     dt = (DEPTH_TERM_SSIM if enable_depth_ssim else 0) | (DEPTH_TERM_CONSIS if enable_depth_consis else 0)
     losses, ws = GeomLossFn.apply(1, S, 0.0, 0.0, int(ac), dt, *tensors)
     rows = losses.unbind(0)
-    pack = {"loss_depth_pixel": rows[0], "loss_depth_smooth": rows[1]}
+    pack = LossRows({"loss_depth_pixel": rows[0], "loss_depth_smooth": rows[1]})
     if enable_depth_ssim:
         pack["loss_depth_ssim"] = rows[8]
     if enable_depth_consis:
         pack["loss_depth_consis"] = rows[9]
+    pack.rows = (losses, {name: LOSS_ROWS.index(name) for name in pack})
     if not return_masks:
         return pack
     B, _, H, W = img.shape
@@ -261,7 +270,9 @@ def flow_loss_stack(img_l, img, img_r, flows_bwd, flows_fwd, num_scales=3, align
     tensors = [img_l, img, img_r] + list(flows_bwd[:S]) + list(flows_fwd[:S])
     losses, _ws = GeomLossFn.apply(2, S, 0.0, 0.0, int(ac), 0, *tensors)
     rows = losses.unbind(0)
-    return {"loss_flow_pixel": rows[2], "loss_flow_ssim": rows[3], "loss_flow_smooth": rows[4], "loss_flow_consis": rows[5]}
+    pack = LossRows({"loss_flow_pixel": rows[2], "loss_flow_ssim": rows[3], "loss_flow_smooth": rows[4], "loss_flow_consis": rows[5]})
+    pack.rows = (losses, {name: LOSS_ROWS.index(name) for name in pack})
+    return pack
 
 
 def decode_mask(handle, name, scale=0):

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .loss_stack import geom_loss_stack, depth_loss_stack, flow_loss_stack, decode_mask
+from .loss_stack import LossRows, geom_loss_stack, depth_loss_stack, flow_loss_stack, decode_mask
 from .loss_terms import LossTerms
 from .networks import Depth_Model, PoseCNN, FeaturePyramid, PWC_tf
 
@@ -175,7 +175,8 @@ class Model_geometry(LossTerms, nn.Module):
                                         enable_depth_ssim=self.enable_depth_ssim,
                                         enable_depth_consis=self.enable_depth_consis)
         dev = img.device
-        loss_pack = {k: (active[k] if k in active else _zeros2(dev)) for k in LOSS_ORDER_GEOM}
+        loss_pack = LossRows({k: (active[k] if k in active else _zeros2(dev)) for k in LOSS_ORDER_GEOM})
+        loss_pack.rows = active.rows
 
         def u8(*names):
             """sample 0, scale 0 of the product of the named masks, decoded from the 1-byte mask pack only when the
@@ -254,10 +255,11 @@ class Model_depth(LossTerms, nn.Module):
                                   enable_depth_ssim=getattr(self, "enable_depth_ssim", False),
                                   enable_depth_consis=getattr(self, "enable_depth_consis", False))
         dev = img.device
-        loss_pack = {"loss_depth_pixel": active["loss_depth_pixel"],
-                     "loss_depth_ssim": active["loss_depth_ssim"] if "loss_depth_ssim" in active else _zeros2(dev),
-                     "loss_depth_smooth": active["loss_depth_smooth"],
-                     "loss_depth_consis": active["loss_depth_consis"] if "loss_depth_consis" in active else _zeros2(dev)}
+        loss_pack = LossRows({"loss_depth_pixel": active["loss_depth_pixel"],
+                              "loss_depth_ssim": active["loss_depth_ssim"] if "loss_depth_ssim" in active else _zeros2(dev),
+                              "loss_depth_smooth": active["loss_depth_smooth"],
+                              "loss_depth_consis": active["loss_depth_consis"] if "loss_depth_consis" in active else _zeros2(dev)})
+        loss_pack.rows = active.rows
         return loss_pack, {}
 
     def loss_stack_per_op(self, img_l, img, img_r, depth_l, depth_t, depth_r, pose, K):

@@ -34,11 +34,34 @@ def make_optimizer(model, lr):
     return torch.optim.Adam(params, lr=lr, fused=True) if fused else torch.optim.Adam(params, lr=lr)
 
 
+_WEIGHT_ROWS = {}
+
+
 def total_loss(loss_pack, cfg):
     """train.py:211-214: sum_k w_k * mean(loss_k).  The (2,)-shaped zero placeholders of the disabled terms
-    (models._zeros2) contribute exactly +0.0 and are left out."""
-    return sum(getattr(cfg, LOSS_WEIGHT_ATTR[k]) * v.mean() for k, v in loss_pack.items()
-               if not getattr(v, "_dfe_zero_placeholder", False))
+    (models._zeros2) contribute exactly +0.0 and are left out.  When the pack carries the fused stack's whole
+    [rows, B] loss tensor (loss_stack.LossRows) the terms living in it are summed as one weighted reduction of that
+    tensor -- sum_k (w_k / B) * sum_b L[k, b] -- instead of a mean, a multiply and an add per term (and their three
+    backward kernels)."""
+    import torch
+    rows = getattr(loss_pack, "rows", None)
+    total, fused = None, {}
+    if rows is not None:
+        losses, fused = rows
+        key = (losses.device, losses.shape, tuple(sorted((i, float(getattr(cfg, LOSS_WEIGHT_ATTR[k]))) for k, i in fused.items())))
+        w = _WEIGHT_ROWS.get(key)
+        if w is None:
+            host = torch.zeros(losses.shape[0])
+            for k, i in fused.items():
+                host[i] = float(getattr(cfg, LOSS_WEIGHT_ATTR[k])) / losses.shape[1]
+            w = _WEIGHT_ROWS[key] = host.to(losses.device)
+        total = torch.dot(losses.sum(1), w)
+    for k, v in loss_pack.items():
+        if k in fused or getattr(v, "_dfe_zero_placeholder", False):
+            continue
+        term = getattr(cfg, LOSS_WEIGHT_ATTR[k]) * v.mean()
+        total = term if total is None else total + term
+    return total
 
 
 def train_step(model, optimizer, inputs, cfg):
