@@ -73,7 +73,9 @@ def _flow_branches(fpyramid, pwc_model, img_l, img, img_r):
     # split() instead of slices: its backward is one concatenation of the parts' gradients, where every slice would
     # zero-fill a full-size gradient, copy its part in and leave the sum to a chain of adds
     parts = [f.split([B, 2 * B]) for f in feats]              # target | (left, right)
-    f1 = [torch.cat([t, t], 0) for t, _ in parts]             # the target's features for both directions
+    # the target's features for both directions; the finest level is never read by the decoder (pwc_tf.py:108-179
+    # uses levels 2..6), so its 27 MB are not duplicated
+    f1 = [t if k == 0 else torch.cat([t, t], 0) for k, (t, _) in enumerate(parts)]
     f2 = [lr for _, lr in parts]
     flows = [f.split(B) for f in pwc_model(f1, f2, [h, w])]
     return [f[0] for f in flows], [f[1] for f in flows]
