@@ -150,6 +150,15 @@ int dfe_pwc_level_bwd(const float* c1, const float* c2, const float* flow, const
 /* ---- pyramids: mode 0 = F.interpolate(bilinear, align_corners=False) (model_geometry.py:65-72),
  * mode 1 = F.interpolate(area) == adaptive_avg_pool2d (model_geometry.py:91, model_flow.py:58-64). */
 int dfe_resize(const float* in, float* out, int planes, int inH, int inW, int outH, int outW, int mode, void* stream);
+/* Differentiable bilinear resize with the scalar PWC_tf puts on either side of F.interpolate (pwc_tf.py:118-119:
+ * `F.interpolate(flow6, scale_factor=2.0, mode='bilinear') * 2.0`; :175-178: `F.interpolate(flow2 * 4.0, [h, w])`):
+ * pre_scale = 1: out = resize(in * mult); 0: out = resize(in) * mult -- each rounded like the ATen (CPU) composition.
+ * The backward pass is the adjoint as a gather per input element (no atomics, unlike ATen's upsample backward);
+ * DFE_ERR_UNSUPPORTED when the up-sampling ratio exceeds 4 per axis. */
+int dfe_resize_bilinear_fwd(const float* in, float* out, int planes, int inH, int inW, int outH, int outW, float mult,
+                            int pre_scale, void* stream);
+int dfe_resize_bilinear_bwd(const float* gout, float* gin, int planes, int inH, int inW, int outH, int outW, float mult,
+                            int pre_scale, void* stream);
 
 /* ---- depth-decoder glue between the MIOpen convolutions (depth_model.py:60-211:
  * Conv3x3 = ReflectionPad2d(1) + conv, ConvBlock = Conv3x3 + ELU, stage = ConvBlock, bilinear x2, cat(skip), ConvBlock).

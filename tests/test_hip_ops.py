@@ -356,6 +356,31 @@ def test_pwc_level_input(shape):
     assert torch.equal(f3.grad, f.grad)
 
 
+@pytest.mark.parametrize("shape,out_hw,mult,pre", [((8, 2, 4, 13), (8, 26), 2.0, False), ((8, 2, 32, 104), (64, 208), 2.0, False),
+                                                   ((2, 2, 64, 208), (256, 832), 4.0, True), ((2, 2, 8, 26), (32, 104), 4.0, True),
+                                                   ((1, 3, 7, 9), (10, 31), 1.5, True), ((2, 1, 16, 20), (16, 20), 4.0, False)])
+def test_resize_bilinear_differentiable(shape, out_hw, mult, pre):
+    """ops.resize_bilinear (PWC_tf's flow up-sampling, pwc_tf.py:118-119,175-178) against F.interpolate on the host with
+    the scalar on the same side: forward EQUAL (ATen-CPU association incl. the scalar's rounding), gradient 1e-6 of its
+    scale (a gather in fixed order here, autograd's scatter there), and reproducible bit for bit run to run."""
+    import torch.nn.functional as F
+    from unsupervised_depth_opticalflow_egomotion_amd.ops import resize_bilinear
+    r = MG.rng(61)
+    x = r.standard_normal(shape).astype(np.float32)
+    wgt = r.standard_normal((shape[0], shape[1]) + tuple(out_hw)).astype(np.float32)
+    a, b = G(x, True), T(x, True)
+    ya = resize_bilinear(a, out_hw, mult, pre)
+    yb = F.interpolate(b * mult, list(out_hw), mode="bilinear", align_corners=False) if pre else \
+        F.interpolate(b, list(out_hw), mode="bilinear", align_corners=False) * mult
+    np.testing.assert_array_equal(N(ya), N(yb))
+    (ya * G(wgt)).sum().backward()
+    (yb * T(wgt)).sum().backward()
+    gclose(a.grad, b.grad, rel=1e-6, atol=1e-7)
+    a2 = G(x, True)
+    (resize_bilinear(a2, out_hw, mult, pre) * G(wgt)).sum().backward()
+    assert torch.equal(a2.grad, a.grad)
+
+
 @pytest.mark.parametrize("hw", [(256, 832), (375, 1242), (64, 208)])
 def test_resize_oracle(hw):
     from unsupervised_depth_opticalflow_egomotion_amd.ops import resize

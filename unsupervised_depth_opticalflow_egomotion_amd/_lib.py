@@ -73,6 +73,8 @@ _SIGNATURES = {
     "dfe_pwc_level_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_pwc_level_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_resize": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "dfe_resize_bilinear_fwd": [_P, _P, _I, _I, _I, _I, _I, ctypes.c_float, _I, _P],
+    "dfe_resize_bilinear_bwd": [_P, _P, _I, _I, _I, _I, _I, ctypes.c_float, _I, _P],
     "dfe_geom_workspace_floats": [_P],
     "dfe_geom_maskpack_offset_bytes": [_P, _I],
     "dfe_geom_loss_fwd": [_P, _P],

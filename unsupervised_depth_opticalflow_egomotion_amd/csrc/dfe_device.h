@@ -373,6 +373,22 @@ __device__ __forceinline__ float resize_bilinear_at(const float* __restrict__ pl
   return lerp2_aten_sel(small, r0[x0], r0[x1], r1[x0], r1[x1], lx0, lx1, ly0, ly1);
 }
 
+// ---------------------------------------------------------------- adjoint of the bilinear resize (gather form)
+// weights of the (at most G2_MAX) output indices lo .. lo+cnt-1 whose taps touch input index i (scale r = in / out)
+constexpr int G2_MAX = 12;   // candidates per axis: 2/ratio + 4 (ratio >= 1/4 in registers, coarser scales loop)
+
+__device__ __forceinline__ void adj_weights(int i, float r, int lowN, int fullN, int& lo, int& cnt, float (&w)[G2_MAX]) {
+  lo = max(static_cast<int>(floorf((i - 0.5f) / r - 0.5f)) - 1, 0);
+  const int hi = min(static_cast<int>(ceilf((i + 1.5f) / r - 0.5f)) + 1, fullN - 1);
+  cnt = hi - lo + 1;
+#pragma unroll
+  for (int k = 0; k < G2_MAX; ++k) {
+    int a0, a1; float l0, l1;
+    bilinear_src(min(lo + k, fullN - 1), r, lowN, a0, a1, l0, l1);
+    w[k] = (k < cnt) ? ((a0 == i ? l0 : 0.0f) + (a1 == i ? l1 : 0.0f)) : 0.0f;
+  }
+}
+
 // ---------------------------------------------------------------- reductions
 // Block-wide sums of N per-thread values with DPP adds.  The N reductions are interleaved step-major (all
 // values take butterfly step k before any takes step k+1) so that the DPP read-after-write hazards are

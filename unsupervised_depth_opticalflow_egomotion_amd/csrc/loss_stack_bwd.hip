@@ -622,20 +622,6 @@ __global__ void __launch_bounds__(64) k_geom_disp_smooth_bwd1(GeomDev D, GeomBwd
 // pixel (i, j) is wy(y) * wx(x), so the (at most G2_MAX) candidate rows / columns and their weights are formed
 // once per thread and the double loop only touches the non-zero taps (16 at ratio 1/2, 64 at 1/4).
 // grid.x covers blocks [blk_start[1], blk_start[S]); grid.y = f*B + b.
-constexpr int G2_MAX = 12;   // candidates per axis: 2/ratio + 4 (ratio >= 1/4 in registers, coarser scales loop)
-
-__device__ __forceinline__ void adj_weights(int i, float r, int lowN, int fullN, int& lo, int& cnt, float (&w)[G2_MAX]) {
-  lo = max(static_cast<int>(floorf((i - 0.5f) / r - 0.5f)) - 1, 0);
-  const int hi = min(static_cast<int>(ceilf((i + 1.5f) / r - 0.5f)) + 1, fullN - 1);
-  cnt = hi - lo + 1;
-#pragma unroll
-  for (int k = 0; k < G2_MAX; ++k) {
-    int a0, a1; float l0, l1;
-    bilinear_src(min(lo + k, fullN - 1), r, lowN, a0, a1, l0, l1);
-    w[k] = (k < cnt) ? ((a0 == i ? l0 : 0.0f) + (a1 == i ? l1 : 0.0f)) : 0.0f;
-  }
-}
-
 // exact 1/2 and 1/4 pyramids (every power-of-two image size), interior low-res pixels: the footprint is the dense
 // 2n x 2n block starting at (n i - n/2, n j - n/2) with the tent weights (2k + 1) / 2n mirrored -- the same non-zero
 // taps, weights and summation order as the general path below, without forming 24 candidate weights and issuing 144

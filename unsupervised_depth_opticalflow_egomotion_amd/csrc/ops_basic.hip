@@ -714,8 +714,10 @@ __global__ void __launch_bounds__(256) k_corr_bwd(const float* __restrict__ othe
 
 // ====================================================================== resize (pyramids)
 // mode 0: bilinear align_corners=False (F.interpolate); mode 1: area (adaptive average pool)
+// mult / pre: out = resize(in * mult) (pre) or resize(in) * mult (post), each rounded like the ATen composition
+// (PWC_tf scales its flows on either side of F.interpolate, pwc_tf.py:118,175-178)
 __global__ void k_resize(const float* __restrict__ in, float* __restrict__ out, int planes, int inH, int inW,
-                         int outH, int outW, int mode) {
+                         int outH, int outW, int mode, float mult, int pre) {
   const long n = static_cast<long>(planes) * outH * outW;
   const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -723,8 +725,19 @@ __global__ void k_resize(const float* __restrict__ in, float* __restrict__ out, 
   const long pl = i / (static_cast<long>(outW) * outH);
   const float* src = in + pl * inH * inW;
   if (mode == 0) {
-    out[i] = resize_bilinear_at(src, inH, inW, oy, ox, static_cast<float>(inH) / outH, static_cast<float>(inW) / outW,
-                                aten_small_resize(outH, outW));
+    if (mult == 1.0f) {
+      out[i] = resize_bilinear_at(src, inH, inW, oy, ox, static_cast<float>(inH) / outH, static_cast<float>(inW) / outW,
+                                  aten_small_resize(outH, outW));
+    } else {
+      int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+      bilinear_src(oy, static_cast<float>(inH) / outH, inH, y0, y1, ly0, ly1);
+      bilinear_src(ox, static_cast<float>(inW) / outW, inW, x0, x1, lx0, lx1);
+      const float* r0 = src + static_cast<long>(y0) * inW;
+      const float* r1 = src + static_cast<long>(y1) * inW;
+      const float pm = pre ? mult : 1.0f;
+      const float v = lerp2_aten_sel(aten_small_resize(outH, outW), r0[x0] * pm, r0[x1] * pm, r1[x0] * pm, r1[x1] * pm, lx0, lx1, ly0, ly1);
+      out[i] = pre ? v : v * mult;
+    }
   } else {
     // adaptive_avg_pool2d window: [floor(o*in/out), ceil((o+1)*in/out))
     int ys = (oy * inH) / outH, ye = ((oy + 1) * inH + outH - 1) / outH;
@@ -734,6 +747,36 @@ __global__ void k_resize(const float* __restrict__ in, float* __restrict__ out, 
       for (int xx = xs; xx < xe; ++xx) s += src[static_cast<long>(yy) * inW + xx];
     out[i] = s / static_cast<float>((ye - ys) * (xe - xs));
   }
+}
+
+// Adjoint of the bilinear resize as a gather (no atomics: reproducible, unlike ATen's upsample backward): one thread
+// per INPUT element collects the <= G2_MAX x G2_MAX outputs whose taps touch it.  gin = adjoint(gout) * mult (pre) or
+// adjoint(gout * mult) (post), mirroring the order of the autograd chain.
+__global__ void __launch_bounds__(256) k_resize_bilinear_bwd(const float* __restrict__ gout, float* __restrict__ gin, int planes,
+                                                             int inH, int inW, int outH, int outW, float mult, int pre) {
+  const long n = static_cast<long>(planes) * inH * inW;
+  const long e = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int j = static_cast<int>(e % inW), i = static_cast<int>((e / inW) % inH);
+  const long pl = e / (static_cast<long>(inW) * inH);
+  const float* g = gout + pl * outH * outW;
+  int ylo, ny, xlo, nx;
+  float wy[G2_MAX], wx[G2_MAX];
+  adj_weights(i, static_cast<float>(inH) / outH, inH, outH, ylo, ny, wy);
+  adj_weights(j, static_cast<float>(inW) / outW, inW, outW, xlo, nx, wx);
+  const float gm = pre ? 1.0f : mult;
+  float total = 0.0f;
+#pragma unroll
+  for (int ky = 0; ky < G2_MAX; ++ky) {
+    if (wy[ky] == 0.0f) continue;
+    const float* row = g + static_cast<long>(ylo + ky) * outW + xlo;
+    float acc = 0.0f;
+#pragma unroll
+    for (int kx = 0; kx < G2_MAX; ++kx)
+      if (wx[kx] != 0.0f) acc += wx[kx] * (row[kx] * gm);
+    total += wy[ky] * acc;
+  }
+  gin[e] = pre ? total * mult : total;
 }
 
 }  // namespace dfe
@@ -1004,7 +1047,29 @@ int dfe_resize(const float* in, float* out, int planes, int inH, int inW, int ou
   DFE_REQUIRE(planes > 0 && inH > 0 && inW > 0 && outH > 0 && outW > 0, DFE_ERR_DIMS);
   DFE_REQUIRE(mode == 0 || mode == 1, DFE_ERR_UNSUPPORTED);
   long n = static_cast<long>(planes) * outH * outW;
-  k_resize<<<grid1d(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(in, out, planes, inH, inW, outH, outW, mode);
+  k_resize<<<grid1d(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(in, out, planes, inH, inW, outH, outW, mode, 1.0f, 0);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+int dfe_resize_bilinear_fwd(const float* in, float* out, int planes, int inH, int inW, int outH, int outW, float mult,
+                            int pre_scale, void* stream) {
+  DFE_REQUIRE(in && out, DFE_ERR_NULL);
+  DFE_REQUIRE(planes > 0 && inH > 0 && inW > 0 && outH > 0 && outW > 0, DFE_ERR_DIMS);
+  long n = static_cast<long>(planes) * outH * outW;
+  k_resize<<<grid1d(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(in, out, planes, inH, inW, outH, outW, 0, mult, pre_scale);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+int dfe_resize_bilinear_bwd(const float* gout, float* gin, int planes, int inH, int inW, int outH, int outW, float mult,
+                            int pre_scale, void* stream) {
+  DFE_REQUIRE(gout && gin, DFE_ERR_NULL);
+  DFE_REQUIRE(planes > 0 && inH > 0 && inW > 0 && outH > 0 && outW > 0, DFE_ERR_DIMS);
+  // footprint of one input element: 2 * out / in + 4 outputs per axis must fit the register path
+  DFE_REQUIRE(2L * outH <= static_cast<long>(G2_MAX - 4) * inH && 2L * outW <= static_cast<long>(G2_MAX - 4) * inW, DFE_ERR_UNSUPPORTED);
+  long n = static_cast<long>(planes) * inH * inW;
+  k_resize_bilinear_bwd<<<grid1d(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(gout, gin, planes, inH, inW, outH, outW, mult, pre_scale);
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }

@@ -45,6 +45,17 @@ class PWC_tf(nn.Module):
         """81-displacement channel-mean correlation [B,(2d+1)^2,H,W] (HIP)."""
         return ops.corr81(input1, input2, d)
 
+    @staticmethod
+    def resize(x, out_hw, mult, pre):
+        """``F.interpolate(x * mult, out_hw, mode='bilinear')`` (pre) / ``F.interpolate(x, out_hw, ...) * mult`` as written
+        in pwc_tf.py:118-119 and :175-178.  On the GPU one HIP kernel each way (ATen-CPU association forward, gather
+        adjoint backward: the flow gradients do not depend on atomics order); ratios above 4 keep the ATen operators."""
+        if x.is_cuda and out_hw[0] <= 4 * x.shape[2] and out_hw[1] <= 4 * x.shape[3]:
+            return ops.resize_bilinear(x, out_hw, mult, pre)
+        if pre:
+            return F.interpolate(x * mult, list(out_hw), mode="bilinear", align_corners=False)
+        return F.interpolate(x, list(out_hw), mode="bilinear", align_corners=False) * mult
+
     def level_input(self, c1, c2, up_flow):
         """``torch.cat((self.corr(c1, self.warp(c2, up_flow)), c1, up_flow), 1)`` (pwc_tf.py:119-121, repeated per level).
         On the GPU the triple is one operator (``dfe_pwc_level_fwd/bwd``): the cost volume is written into its slice
@@ -87,13 +98,11 @@ class PWC_tf(nn.Module):
         flows = {6: flow}
         x4 = None
         for lvl in (5, 4, 3, 2):
-            up = F.interpolate(flows[lvl + 1], scale_factor=2.0, mode="bilinear", align_corners=False) * 2.0
+            up = self.resize(flows[lvl + 1], [2 * flows[lvl + 1].shape[2], 2 * flows[lvl + 1].shape[3]], 2.0, pre=False)
             delta, x4 = self._decode(lvl, self.level_input(c1[lvl], c2[lvl], up))
             flows[lvl] = delta + up
         x = self.dc_conv4(self.dc_conv3(self.dc_conv2(self.dc_conv1(torch.cat([flows[2], x4], 1)))))
         flows[2] = flows[2] + self.dc_conv7(self.dc_conv6(self.dc_conv5(x)))
         h, w = img_hw[0], img_hw[1]
-        return [F.interpolate(flows[2] * 4.0, [h, w], mode="bilinear", align_corners=False),
-                F.interpolate(flows[3] * 4.0, [h // 2, w // 2], mode="bilinear", align_corners=False),
-                F.interpolate(flows[4] * 4.0, [h // 4, w // 4], mode="bilinear", align_corners=False),
-                F.interpolate(flows[5] * 4.0, [h // 8, w // 8], mode="bilinear", align_corners=False)]
+        return [self.resize(flows[2], [h, w], 4.0, pre=True), self.resize(flows[3], [h // 2, w // 2], 4.0, pre=True),
+                self.resize(flows[4], [h // 4, w // 4], 4.0, pre=True), self.resize(flows[5], [h // 8, w // 8], 4.0, pre=True)]

@@ -331,6 +331,39 @@ def resize(img, out_hw, mode):
 
 
 # --------------------------------------------------------------------------- device-side input pipeline
+class ResizeBilinearFn(torch.autograd.Function):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False) with a scalar on one side of it, as PWC_tf writes
+    it (pwc_tf.py:118-119, 175-178): ``pre`` -> resize(x * mult), else resize(x) * mult.  Forward in ATen's (CPU)
+    association, backward as a gather (reproducible)."""
+
+    @staticmethod
+    def forward(ctx, x, out_hw, mult, pre):
+        lib = get_lib()
+        x = f32c(x)
+        B, C, H, W = x.shape
+        oh, ow = int(out_hw[0]), int(out_hw[1])
+        out = torch.empty(B, C, oh, ow, device=x.device, dtype=torch.float32)
+        check(lib.dfe_resize_bilinear_fwd(ptr(x), ptr(out), B * C, H, W, oh, ow, float(mult), int(pre), stream_ptr()),
+              "dfe_resize_bilinear_fwd")
+        ctx.cfg = (B, C, H, W, oh, ow, float(mult), int(pre))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = get_lib()
+        B, C, H, W, oh, ow, mult, pre = ctx.cfg
+        gin = torch.empty(B, C, H, W, device=gout.device, dtype=torch.float32)
+        check(lib.dfe_resize_bilinear_bwd(ptr(f32c(gout)), ptr(gin), B * C, H, W, oh, ow, mult, pre, stream_ptr()),
+              "dfe_resize_bilinear_bwd")
+        return gin, None, None, None
+
+
+def resize_bilinear(x, out_hw, mult=1.0, pre=False):
+    """Differentiable ``F.interpolate(x * mult if pre else x, out_hw, mode='bilinear') * (1 if pre else mult)``;
+    up-sampling ratios of at most 4 per axis (DfeError beyond that in the backward pass)."""
+    return ResizeBilinearFn.apply(x, (int(out_hw[0]), int(out_hw[1])), float(mult), bool(pre))
+
+
 def prepare_triplets(raw_u8, img_hw, flip=None):
     """KITTI_Prepared.__getitem__'s image half (kitti_prepared.py:63-90,132-152) for a whole batch on the device.
 
