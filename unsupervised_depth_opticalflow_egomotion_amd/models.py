@@ -54,12 +54,24 @@ def _split_frames(images):
     return images[:, :, :h, :], images[:, :, h:2 * h, :], images[:, :, 2 * h:3 * h, :], h, images.shape[3]
 
 
-def _depth_frames(depth_net, img_l, img, img_r):
+def _contiguous_frames(images):
+    """The three frames of the [B,3,3h,W] strip (train.py:171-175) as contiguous tensors.  On the GPU one strided
+    copy produces the [3,B,3,h,W] block whose slices are the frames -- and whose flat view is the depth net's batch
+    of 3B (no further concatenation); otherwise three plain copies."""
+    img_l, img, img_r, h, w = _split_frames(images)
+    if images.is_cuda and images.shape[2] == 3 * h:
+        B = images.shape[0]
+        x = images.reshape(B, 3, 3, h, w).permute(2, 0, 1, 3, 4).contiguous()
+        return x[0], x[1], x[2], x.view(3 * B, 3, h, w)
+    return img_l.contiguous(), img.contiguous(), img_r.contiguous(), None
+
+
+def _depth_frames(depth_net, img_l, img, img_r, batched=None):
     """Disparity pyramids of the three frames (model_geometry.py:786-788, model_depth.py:286-288: one depth_net call per
     frame).  On the GPU the frames go through the net as one batch with per-frame BatchNorm statistics
     (Depth_Model.forward_frames); on the host, the three calls as written."""
     if img.is_cuda:
-        return depth_net.forward_frames([img_l, img, img_r])
+        return depth_net.forward_frames([img_l, img, img_r], batched=batched)
     return depth_net(img_l), depth_net(img), depth_net(img_r)
 
 
@@ -81,12 +93,20 @@ def _flow_branches(fpyramid, pwc_model, img_l, img, img_r):
     return [f[0] for f in flows], [f[1] for f in flows]
 
 
+_PLACEHOLDERS = {}
+
+
 def _zeros2(dev):
     """The reference's ``torch.zeros([2]).to(device).requires_grad_()`` placeholder of a disabled loss term
     (model_geometry.py:891,899,943-951).  Tagged so that train_step.total_loss can leave its exact-zero contribution
-    (three tiny kernels forward, three backward per placeholder) out of the sum."""
-    t = torch.zeros([2], device=dev).requires_grad_()   # device-side fill (no H2D copy: capturable in a hipGraph)
-    t._dfe_zero_placeholder = True
+    (three tiny kernels forward, three backward per placeholder) out of the sum; one tensor per device is created once
+    and handed out again (nothing ever writes to it or accumulates a gradient in it through total_loss)."""
+    key = (dev.type, dev.index)
+    t = _PLACEHOLDERS.get(key)
+    if t is None:
+        t = torch.zeros([2], device=dev).requires_grad_()   # device-side fill (no H2D copy: capturable in a hipGraph)
+        t._dfe_zero_placeholder = True
+        _PLACEHOLDERS[key] = t
     return t
 
 
@@ -123,10 +143,10 @@ class Model_geometry(LossTerms, nn.Module):
     def infer_pose(self, imgs):
         return self.pose_net(imgs)
 
-    def run_networks(self, img_l, img, img_r):
+    def run_networks(self, img_l, img, img_r, batched=None):
         """model_geometry.py:781-795.  depth_net is called once per frame (BatchNorm statistics per call)."""
         h, w = img.shape[2], img.shape[3]
-        disp_l, disp_t, disp_r = _depth_frames(self.depth_net, img_l, img, img_r)
+        disp_l, disp_t, disp_r = _depth_frames(self.depth_net, img_l, img, img_r, batched)
         pose = self.pose_net(torch.cat([img_l, img, img_r], 1))
         flows_bwd, flows_fwd = _flow_branches(self.fpyramid, self.pwc_model, img_l, img, img_r)
         return disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd
@@ -134,9 +154,8 @@ class Model_geometry(LossTerms, nn.Module):
     def forward(self, inputs):
         images, K_ms, K_inv_ms = inputs
         K, K_inv = K_ms[:, 0, :, :], K_inv_ms[:, 0, :, :]
-        img_l, img, img_r, h, w = _split_frames(images)
-        img_l, img, img_r = img_l.contiguous(), img.contiguous(), img_r.contiguous()
-        disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd = self.run_networks(img_l, img, img_r)
+        img_l, img, img_r, batched = _contiguous_frames(images)
+        disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd = self.run_networks(img_l, img, img_r, batched)
         return self.loss_stack(img_l, img, img_r, disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd, K, K_inv)
 
     def disabled_depth_terms(self, img_l, img, img_r, disp_l, disp_t, disp_r, pose, K, mask_handle):
@@ -244,9 +263,8 @@ class Model_depth(LossTerms, nn.Module):
     def forward(self, inputs):
         images, K_ms, K_inv_ms = inputs
         K = K_ms[:, 0, :, :]
-        img_l, img, img_r, h, w = _split_frames(images)
-        img_l, img, img_r = img_l.contiguous(), img.contiguous(), img_r.contiguous()
-        depth_l, depth_t, depth_r = _depth_frames(self.depth_net, img_l, img, img_r)
+        img_l, img, img_r, batched = _contiguous_frames(images)
+        depth_l, depth_t, depth_r = _depth_frames(self.depth_net, img_l, img, img_r, batched)
         pose = self.pose_net(torch.cat([img_l, img, img_r], 1))
         return self.loss_stack(img_l, img, img_r, depth_l, depth_t, depth_r, pose, K)
 
@@ -315,8 +333,7 @@ class Model_flow(LossTerms, nn.Module):
 
     def forward(self, inputs):
         images = inputs[0]
-        img_l, img, img_r, h, w = _split_frames(images)
-        img_l, img, img_r = img_l.contiguous(), img.contiguous(), img_r.contiguous()
+        img_l, img, img_r, _ = _contiguous_frames(images)
         flows_bwd, flows_fwd = _flow_branches(self.fpyramid, self.pwc_model, img_l, img, img_r)
         return self.loss_stack(img_l, img, img_r, flows_bwd, flows_fwd)
 

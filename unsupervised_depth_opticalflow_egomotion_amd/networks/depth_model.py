@@ -116,21 +116,22 @@ class Depth_Model(nn.Module):
         out = self.decoder(self.encoder(img))
         return [out[i] for i in range(self.depth_scale)]
 
-    def forward_frames(self, frames):
+    def forward_frames(self, frames, batched=None):
         """The frames of a triplet in ONE pass over a batch of len(frames)*B: equivalent to calling the net once per
         frame, in order (model_geometry.py:786-788) -- every BatchNorm normalises each frame's B samples separately and
         updates its running statistics frame by frame (resnet.FrameBatchNorm2d) -- with a third of the launches and
-        larger convolutions.  Returns one disparity list per frame."""
+        larger convolutions.  ``batched``: the frames already stacked along the batch ([n*B,3,H,W]), when the caller has
+        them in that layout.  Returns one disparity list per frame."""
         n, B = len(frames), frames[0].shape[0]
         bns = [m for m in self.modules() if isinstance(m, resnet.FrameBatchNorm2d)]
-        batched = self.training and frames[0].is_cuda
+        defer = self.training and frames[0].is_cuda
         for m in bns:
             m.groups = n
-            m.count_deferred = batched
+            m.count_deferred = defer
         try:
-            if batched:     # one multi-tensor kernel instead of one tiny add per layer
+            if defer:     # one multi-tensor kernel instead of one tiny add per layer
                 torch._foreach_add_([m.num_batches_tracked for m in bns], n)
-            out = self.forward(torch.cat(list(frames), 0))
+            out = self.forward(batched if batched is not None else torch.cat(list(frames), 0))   # batched: the frames already stacked along the batch
         finally:
             for m in bns:
                 m.groups = 1
