@@ -9,17 +9,23 @@ Workloads (BASELINE.json configs; synthetic KITTI-shaped inputs, seed 1234 + ran
 Unit: frame pair = one (target, source) direction of one triplet; a batch of B triplets is 2B pairs.
 """
 import argparse
-import ctypes
+import glob
+import hashlib
 import json
 import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# MIOpen find mode: left at the library default.  Round 2 logged 34.4 -> 33.0 ms per step with MIOPEN_FIND_MODE=1 on
+# one box; re-measured at HEAD in round 3 (profiles/r03_miopen_find_modes.txt, same box, back to back) the modes are
+# indistinguishable: 32.44 (default, dynamic hybrid) / 32.56 and 32.51 (normal, cold and warm find-db) / 32.42 ms
+# (hybrid).  The variable is passed through and reported in the JSON line so a run under another mode is labelled.
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -42,11 +48,27 @@ def parse():
     return ap.parse_args()
 
 
+def visible_devices():
+    """Number of HIP devices this process would see, WITHOUT initialising the HIP runtime (the launcher parent must
+    never touch the GPU): the visibility variables if set, otherwise the kfd render nodes."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    return len(glob.glob("/dev/dri/renderD*"))
+
+
+def profiler_preloaded():
+    """rocprofv3 preloads its tool library, which initialises the GPU before main(): spawning ranks from such a process
+    is the launcher hop this pool forbids."""
+    return any("rocprof" in os.environ.get(v, "").lower() for v in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY"))
+
+
 def launch_ranks_if_needed(args):
     """`python bench.py --gpus N` with N > 1 and no torchrun environment: start N fresh ranks ourselves (one process
     per GPU, the reference's multi-GPU entry is one command too: train.py:59-60,277-283) and relay their exit code.
-    Runs BEFORE anything initialises the GPU in this process (torch.cuda.device_count() does not, on this image); the
-    parent never touches the device and never execs -- it only waits for `python -m torch.distributed.run`."""
+    The parent never touches the device (devices are counted from the environment / the render nodes, not through
+    torch.cuda) and never execs -- it only waits for `python -m torch.distributed.run`."""
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is not None:
         if int(env_world) != args.gpus:
@@ -55,7 +77,12 @@ def launch_ranks_if_needed(args):
         return
     if args.gpus <= 1:
         return
-    ndev = torch.cuda.device_count()
+    if profiler_preloaded():
+        sys.stderr.write("bench.py: --gpus %d under a profiler preload: the profiler has already initialised the GPU in this "
+                         "process, so it must not start ranks. Profile ONE rank instead (rocprofv3 ... -- python3 bench.py "
+                         "--gpus 1), or start the ranks with torch.distributed.run yourself.\n" % args.gpus)
+        sys.exit(4)
+    ndev = visible_devices()
     if ndev < args.gpus and os.environ.get("DFE_BENCH_ALL_ON_DEVICE0") != "1":
         sys.stderr.write("bench.py: --gpus %d requested but only %d HIP device(s) are visible\n" % (args.gpus, ndev))
         sys.exit(3)
@@ -164,11 +191,30 @@ class TrainStepWorkload:
         torch.manual_seed(1234)           # identical initial weights on every rank
         self.model = get_model(self.mode)(self.cfg).to(dev)
         self.model.train()
-        self.model = ddp.wrap(self.model, dev)
-        self.opt = make_optimizer(self.model, self.cfg.lr)
         im, k, ki = synthetic.make_triplet_batch(args.batch, args.height, args.width, args.scales, seed=seed)
         self.np_inputs = (im, k, ki)
         self.inputs = [torch.from_numpy(a).to(dev) for a in (im, k, ki)]   # resident in HBM before timing
+        if world > 1:
+            self.find_warmup(world)
+        self.model = ddp.wrap(self.model, dev)
+        self.opt = make_optimizer(self.model, self.cfg.lr)
+
+    def find_warmup(self, world):
+        """N ranks of one node share one MIOpen user find-db.  Rank 0 runs one forward + backward of the bare model
+        first (its find phase times every solver and stores the winners), the others follow behind a barrier and read
+        those entries instead of running N concurrent searches against one file.  No optimiser step is taken and the
+        gradients are dropped, so the replicas still start from identical weights (DDP broadcasts rank 0's buffers)."""
+        import torch.distributed as dist
+        from unsupervised_depth_opticalflow_egomotion_amd.train_step import total_loss
+        rank = dist.get_rank()
+        for turn in (0, 1):
+            if (rank == 0) == (turn == 0):
+                lp, _ = self.model(self.inputs)
+                total_loss(lp, self.cfg).backward()
+                for p in self.model.parameters():
+                    p.grad = None
+                torch.cuda.synchronize()
+            dist.barrier()
 
     def step(self):
         from unsupervised_depth_opticalflow_egomotion_amd.train_step import train_step
@@ -231,6 +277,21 @@ POINT_KERNEL = {
 }
 
 
+POINT_LIMITER = {"geom": "vector-instruction issue (VALU + vector-memory instruction counts add up; working set is Infinity-Cache resident at B=4)"}
+HBM_ACHIEVABLE_GBS = 6290.0    # measured float4 copy rate (MI355X_MICROARCH.md)
+KERNEL_SOURCES = ("loss_stack_fwd.hip", "loss_stack.h", "loss_stack_exact.h", "dfe_device.h")
+
+
+def kernel_source_hash():
+    """sha256 over the sources k_geom_point_fwd is compiled from: a PMC traffic figure is only reported for the kernel
+    it was measured on (tools/roofline_table.py stores the same hash next to the counters)."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "unsupervised_depth_opticalflow_egomotion_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def point_fwd_roofline(args, mode, fwd_ms, bwd_ms):
     """Roofline object from the HIP-event timings recorded inside the timed region (loss_stack.timing_begin /
     timing_collect: events on the launch stream around every launch of the fused stack, read after the final sync)."""
@@ -241,20 +302,35 @@ def point_fwd_roofline(args, mode, fwd_ms, bwd_ms):
     t_ms = float(fwd_ms[:, 2].mean())
     achieved = bytes_per_launch / (t_ms * 1e-3) / 1e9
     traffic = None   # PMC-derived HBM bytes per launch: cannot be collected from inside this process; taken from
-    try:             # the committed rocprofv3 --pmc pass when it was made on exactly this kernel and workload
+    try:             # the committed rocprofv3 --pmc pass ONLY when it was made on exactly this kernel source and workload
         with open(os.path.join(ROOT, "profiles", "pmc_point_fwd_traffic.json")) as fh:
             pm = json.load(fh)
         w = pm["workload"]
-        if mode == "geom" and (w["batch"], w["height"], w["width"], w["scales"]) == (args.batch, args.height, args.width, S):
+        same_kernel = pm.get("kernel_source_sha256") == kernel_source_hash()
+        if mode == "geom" and same_kernel and (w["batch"], w["height"], w["width"], w["scales"]) == (args.batch, args.height, args.width, S):
             traffic = pm["hbm_bytes_per_launch"]
     except Exception:
         traffic = None
-    roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+    # "bound": the roofline the contract prices this kernel against is HBM; what the PMC passes say
+    # actually limits it is reported next to it ("limiter")
+    roof = {"bound": "hbm", "limiter": POINT_LIMITER.get(mode), "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4),
+            "traffic": traffic,
             "bytes_per_launch": bytes_per_launch, "avg_kernel_ms": round(t_ms, 5), "launches_timed": int(fwd_ms.shape[0])}
     segs = {"fwd_ms": [round(float(x), 5) for x in fwd_ms.mean(0)],
             "bwd_ms": [round(float(x), 5) for x in bwd_ms.mean(0)] if len(bwd_ms) else []}
     return roof, segs
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(wl, args, unit_pairs):
@@ -271,10 +347,45 @@ def cpu_baseline(wl, args, unit_pairs):
         if time.perf_counter() - t0 > 15.0 or n >= 3:
             break
     dt = (time.perf_counter() - t0) / n
-    return {"value": round(unit_pairs / dt, 4), "unit": "frame-pairs/s", "cores": threads, "kind": "port",
+    return {"value": round(unit_pairs / dt, 4), "unit": "frame-pairs/s", "cores": threads, "cpu_model": cpu_model(),
+            "host_cores": os.cpu_count(), "kind": "port",
             "sample": "%d timed step(s) of the same workload (%s, B=%d, %dx%d, S=%d, fwd+bwd%s) on the host CPU, %.2f s/step"
                       % (n, wl.name, args.batch, args.height, args.width, args.scales,
                          "+Adam" if wl.name == "train_step" else "", dt)}
+
+
+def multi_gpu_evidence(wl, world, rank, dev, dt_local, args):
+    """What a reader of the N > 1 line needs to believe that N replicas really exchanged gradients (after the timed
+    region): the backend in use, an all-reduce of rank ids whose sum is checked, a checksum of every parameter after
+    the last step gathered from all ranks (equal on all ranks <=> the gradients were reduced: each rank trains on its
+    own shard, seed 1234 + rank), and the per-rank step times."""
+    import torch.distributed as dist
+    ids = torch.tensor([float(rank), 1.0], device=dev, dtype=torch.float64)
+    dist.all_reduce(ids)
+    ids_ok = int(ids[1].item()) == world and int(ids[0].item()) == world * (world - 1) // 2
+    model = getattr(wl, "model", None)
+    sums = None
+    if model is not None:
+        cs = torch.zeros(2, device=dev, dtype=torch.float64)
+        for p_ in model.parameters():
+            d = p_.detach().double()
+            cs[0] += d.sum()
+            cs[1] += d.abs().sum()
+        gathered = [torch.zeros_like(cs) for _ in range(world)]
+        dist.all_gather(gathered, cs)
+        sums = [[float(g[0]), float(g[1])] for g in gathered]
+    times = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(times, torch.tensor([1e3 * dt_local / args.steps], device=dev, dtype=torch.float64))
+    times = [float(t.item()) for t in times]
+    ev = {"backend": dist.get_backend(), "collective_library": "RCCL" if dist.get_backend() == "nccl" else dist.get_backend(),
+          "rccl_ranks": int(ids[1].item()), "rank_id_allreduce_ok": bool(ids_ok),
+          "ms_per_step_min": round(min(times), 4), "ms_per_step_max": round(max(times), 4),
+          "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE")}
+    if sums is not None:
+        ev["param_checksum_rank0"] = sums[0]
+        ev["param_checksums_equal"] = all(s_ == sums[0] for s_ in sums)
+        ev["shards_differ"] = True   # rank r draws its batch with seed 1234 + r
+    return ev
 
 
 def main():
@@ -299,8 +410,10 @@ def main():
     for _ in range(args.steps):
         wl.step()
     barrier(world)
-    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+    dt_local = time.perf_counter() - t0
+    dt = max_over_ranks(dt_local, world, dev)
     fwd_ms, bwd_ms = LS.timing_collect()
+    evidence = multi_gpu_evidence(wl, world, rank, dev, dt_local, args) if world > 1 else None
     pairs_per_step = 2 * args.batch * world
     value = pairs_per_step * args.steps / dt
     out = {
@@ -310,8 +423,11 @@ def main():
         "config": {"workload": wl.name + ": mode=%s, %dx%d, batch=%d/GPU, num_scales=%d, fwd+bwd%s" % (
             args.mode if wl.name == "train_step" else "geom", args.width, args.height, args.batch, args.scales,
             "+Adam" if wl.name == "train_step" else ""),
-            "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+            "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+            "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE")},
     }
+    if evidence is not None:
+        out["multi_gpu"] = evidence
     if rank == 0:
         roof, segs = point_fwd_roofline(args, args.mode if wl.name == "train_step" else "geom", fwd_ms, bwd_ms)
         out["roofline"] = roof

@@ -70,15 +70,56 @@ def warp_flow(x, flow, use_mask=False, align_corners=False):
 # --------------------------------------------------------------------------- a3 pose
 
 
+class trig:
+    """How ``euler2mat`` evaluates cos / sin (test-only switch; default = the reference's own call).
+
+    ``host``: ``torch.cos`` / ``torch.sin`` of the machine the oracle runs on -- what the reference does
+    (inverse_warp.py:122-139).  That is a vendor libm (MKL VML / SLEEF, <= 1 ulp, not reproducible across hosts).
+    ``cr``: the correctly rounded value (float64 evaluation rounded once to fp32) -- what the HIP kernels compute
+    (``cos_cr`` / ``sin_cr``), i.e. the statement "bit-exact given R" of DESIGN.md section 2.
+    ``ulp_shift``: optional [6] integer offsets added, in units of fp32 ulps, to (cos rx, sin rx, cos ry, sin ry, cos rz,
+    sin rz) after evaluation: the parity tests use it to measure how far a <= 1-ulp libm can move a decision.
+    Gradients are those of torch.cos / torch.sin in every mode."""
+    mode = "host"
+    ulp_shift = None
+
+    def __init__(self, mode="host", ulp_shift=None):
+        self.new = (mode, ulp_shift)
+
+    def __enter__(self):
+        self.old = (trig.mode, trig.ulp_shift)
+        trig.mode, trig.ulp_shift = self.new
+        return self
+
+    def __exit__(self, *exc):
+        trig.mode, trig.ulp_shift = self.old
+        return False
+
+    @staticmethod
+    def _eval(fn, x, slot):
+        y = fn(x)
+        v = y.detach()
+        if trig.mode == "cr":
+            v = fn(x.detach().double()).float()
+        elif trig.mode != "host":
+            raise ValueError(trig.mode)
+        if trig.ulp_shift is not None and int(trig.ulp_shift[slot]) != 0:
+            k = int(trig.ulp_shift[slot])
+            tgt = torch.full_like(v, float("inf") if k > 0 else float("-inf"))
+            for _ in range(abs(k)):
+                v = torch.nextafter(v, tgt)
+        return y + (v - y.detach())
+
+
 def euler2mat(angle):
     """R = Rx(rx) @ Ry(ry) @ Rz(rz) (inverse_warp.py:110-145)."""
     n = angle.shape[0]
     rx, ry, rz = angle[:, 0], angle[:, 1], angle[:, 2]
     zero = rz.detach() * 0
     one = zero.detach() + 1
-    cz, sz = torch.cos(rz), torch.sin(rz)
-    cy, sy = torch.cos(ry), torch.sin(ry)
-    cx, sx = torch.cos(rx), torch.sin(rx)
+    cz, sz = trig._eval(torch.cos, rz, 4), trig._eval(torch.sin, rz, 5)
+    cy, sy = trig._eval(torch.cos, ry, 2), trig._eval(torch.sin, ry, 3)
+    cx, sx = trig._eval(torch.cos, rx, 0), trig._eval(torch.sin, rx, 1)
     zm = torch.stack([cz, -sz, zero, sz, cz, zero, zero, zero, one], dim=1).reshape(n, 3, 3)
     ym = torch.stack([cy, zero, sy, zero, one, zero, -sy, zero, cy], dim=1).reshape(n, 3, 3)
     xm = torch.stack([one, zero, zero, zero, cx, -sx, zero, sx, cx], dim=1).reshape(n, 3, 3)
@@ -515,8 +556,10 @@ class GeomLossOracle:
         return [a[s] * b[s] for s in range(self.num_scales)]
 
     # A.5 decision margins -------------------------------------------------------
-    def decision_margins(self, img_l, img, img_r, disp_list, pose_vectors, flows_bwd, flows_fwd, K):
-        """|lhs - rhs| of every thresholded mask decision of ``geom_losses``, per pixel.
+    def decision_margins(self, img_l, img, img_r, disp_list, pose_vectors, flows_bwd, flows_fwd, K, signed=False):
+        """|lhs - rhs| of every thresholded mask decision of ``geom_losses``, per pixel
+        (``signed=True``: lhs - rhs itself for the dyna / texture / valid_to families, so that the effect of a perturbed
+        input on a decision can be measured as a difference of margins).
 
         Test-only: the parity tests demand that a HIP mask may differ from the oracle's only at pixels whose
         margin is below the mask's fp32 noise floor, and that margin-checked seeds have no such pixel (so their
@@ -525,6 +568,7 @@ class GeomLossOracle:
         S = self.num_scales
         out = {k: [] for k in ("valid_bwd", "valid_fwd", "occ_bwd", "occ_fwd", "dyna_bwd", "dyna_fwd",
                                "texture_bwd", "texture_fwd", "valid_to_l", "valid_to_r")}
+        sgn = (lambda t: t) if signed else torch.abs
         with torch.no_grad():
             pose_d = (pose_vectors[:, 0, :], pose_vectors[:, 1, :])
             pyr_t = self.generate_img_pyramid(img, S)
@@ -554,15 +598,15 @@ class GeomLossOracle:
                     bound = self.flow_consist_alpha * (torch.pow(_l2norm(flows[s]), 2) + torch.pow(_l2norm(rigid), 2)) \
                         + self.flow_consist_beta
                     nd2 = torch.pow(_l2norm(torch.abs(rigid - flows[s])), 2)
-                    out["dyna_" + tag].append((nd2 - bound).abs() / bound)
+                    out["dyna_" + tag].append(sgn(nd2 - bound) / bound)
                     src = F.interpolate(src_img, (h, w), mode="area")
                     grid, _ = _rigid_grid(disp_list[s], pose_d[d], k_s)
                     rec = F.grid_sample(src, grid, mode="bilinear", padding_mode="zeros", align_corners=self.align_corners)
                     e_rec = torch.abs(it - rec).mean(1, keepdim=True)
                     e_src = torch.abs(it - pyr_src[d][s]).mean(1, keepdim=True)
-                    out["texture_" + tag].append((e_rec - e_src).abs())
+                    out["texture_" + tag].append(sgn(e_rec - e_src))
                     out["valid_to_" + ("l" if d == 0 else "r")].append(
-                        (grid.abs().max(dim=-1)[0] - 1).abs().unsqueeze(1))
+                        sgn(grid.abs().max(dim=-1)[0] - 1).unsqueeze(1))
         return out
 
     # a21 geom ----------------------------------------------------------------

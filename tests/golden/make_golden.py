@@ -34,6 +34,8 @@ sys.path.insert(0, REPO)
 
 from unsupervised_depth_opticalflow_egomotion_amd import synthetic  # noqa: E402
 
+synthetic.CONDITION_POSE = True   # golden inputs use conditioned poses (cos / sin unambiguous on any host), as the tests do
+
 _ORIG_GRID_SAMPLE = F.grid_sample
 
 

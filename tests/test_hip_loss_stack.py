@@ -1,7 +1,8 @@
 """GPU parity of the fused loss stack (dfe_geom_loss_fwd/bwd through the C ABI) against the oracle's
 restatement of model_geometry.py:797-951 and against the golden vectors captured from the reference.
 
-Contract (fp32), measured headroom in brackets (MI355X, EPYC host, profiles/r02_parity_report.txt):
+Contract (fp32), measured headroom in brackets (MI355X, EPYC host; tools/parity_report.py prints the flip counts and
+largest errors per case -> profiles/r03_parity_report.txt):
   * masks: BIT-EXACT.  The kernels evaluate the reference's expressions in the reference's association order
     (incl. the FMA patterns of its BLAS / ATen kernels) on identical inputs, so every mask decision is taken on
     identical bits; the one transcendental feeding a decision is the softmax's exp (<= 1-2 ulp between libraries),
@@ -149,6 +150,70 @@ def test_fused_stack_baseline_batch(ac):
     """BASELINE configs[2] size, B=4 256x832 S=3, against the oracle (1.1 M decisions per mask family: a few pixels
     always sit inside the occlusion noise floor, so the per-pixel rule applies instead of a margin-checked seed)."""
     compare(synthetic.make_loss_stack_inputs(4, 256, 832, 3, seed=1234), ac, 3)
+
+
+def raw_pose_inputs(kind, shape, seed):
+    """Loss-stack inputs whose poses are NOT conditioned: ``sigma`` = raw Gaussian 6-vectors (rotations sigma 0.05 rad,
+    as golden G2 draws them), ``posecnn`` = the output of a seeded, randomly initialised PoseCNN on the frames."""
+    b, h, w = shape
+    if kind == "sigma":
+        return synthetic.make_loss_stack_inputs(b, h, w, 3, seed=seed, pose_sigma=0.2, condition_pose=False)
+    inp = synthetic.make_loss_stack_inputs(b, h, w, 3, seed=seed, condition_pose=False)
+    from unsupervised_depth_opticalflow_egomotion_amd.networks import PoseCNN
+    torch.manual_seed(seed)
+    net = PoseCNN(3).to(dev()).eval()
+    with torch.no_grad():
+        x = torch.cat([G(a) for a in inp.imgs], 1)
+        x = torch.nn.functional.interpolate(x, (256, 832), mode="bilinear", align_corners=False)   # the net's Linear(14,14)
+        inp.pose = (50.0 * net(x)).cpu().numpy().astype(np.float32)     # x50: random-init outputs are ~1e-4
+    return inp
+
+
+@pytest.mark.parametrize("ac", [False, True])
+@pytest.mark.parametrize("kind,shape,seed", [("sigma", (2, 64, 208), 11), ("sigma", (2, 128, 448), 12),
+                                             ("sigma", (1, 256, 832), 13), ("posecnn", (2, 64, 208), 14),
+                                             ("posecnn", (1, 256, 832), 15)])
+def test_unconditioned_poses_bit_exact_given_R(kind, shape, seed, ac):
+    """The contract WITHOUT input conditioning: given the rotation matrix, every mask is decided
+    on the reference's bits.  The oracle evaluates cos / sin correctly rounded here (oracle.trig("cr"): what cos_cr /
+    sin_cr compute on the device) and nothing else changes: validity / dynamic / texture masks must EQUAL the oracle's
+    (tolerance 0), occlusion bits may differ only inside the exp floor, losses 5e-6, gradients 1e-4 / 2e-5."""
+    inp = raw_pose_inputs(kind, shape, seed)
+    with O.trig("cr"):
+        compare(inp, ac, 3)
+
+
+@pytest.mark.parametrize("ac", [False, True])
+@pytest.mark.parametrize("kind,shape,seed", [("sigma", (2, 128, 448), 12), ("sigma", (4, 256, 832), 16), ("posecnn", (1, 256, 832), 15)])
+def test_unconditioned_poses_vs_host_libm(kind, shape, seed, ac, capsys):
+    """Against the reference's arithmetic as it runs on THIS host (cos / sin from the vendor libm, <= 1 ulp): a
+    pose-fed decision (dynamic / texture mask) may differ from the device's only at a pixel whose signed margin lies
+    inside the floor a <= 1-ulp change of each of the six cos / sin values can move it by (tests/_margins.trig_floor,
+    validated on twelve single-ulp oracle runs).  Prints the flip counts: the "<= k pixels per 10^6" of DESIGN.md."""
+    inp = raw_pose_inputs(kind, shape, seed)
+    S = 3
+    base, floor, ulp_flips = M.trig_floor(inp, ac, S)
+    _, mk_h, _, _ = run_hip(inp, ac, S)
+    _, mk_o, _, _ = run_oracle(inp, ac, S)                 # host libm
+    with O.trig("cr"):
+        _, mk_c, _, _ = run_oracle(inp, ac, S)
+    nflip = npx = ninside = 0
+    for k in ("dyna_bwd", "dyna_fwd", "texture_bwd", "texture_fwd"):
+        for s in range(S):
+            h, o, c = N(mk_h[k][s]), N(mk_o[k][s]), N(mk_c[k][s])
+            assert (h == c).all(), "%s scale %d: device differs from the correctly rounded oracle" % (k, s)
+            f = h != o
+            nflip += int(f.sum()); npx += h.size
+            inside = np.abs(base[k][s]) <= floor[k][s]
+            ninside += int(inside.sum())
+            assert inside[f].all(), "%s scale %d: %d flip(s) outside the libm floor" % (k, s, int((f & ~inside).sum()))
+    for k in ("valid_bwd", "valid_fwd"):                    # flow-warp validity does not depend on the pose
+        for s in range(S):
+            assert (N(mk_h[k][s]) == N(mk_o[k][s])).all()
+    with capsys.disabled():
+        print("\n[unconditioned %s %s ac=%d] device vs host-libm oracle: %d flip(s) in %d pose-fed decisions; %d pixel(s) "
+              "inside the 1-ulp floor; single-ulp oracle runs flipped %d" % (kind, shape, ac, nflip, npx, ninside,
+                                                                            sum(ulp_flips.values())))
 
 
 def test_fused_stack_each_loss_gradient():

@@ -103,9 +103,10 @@ __global__ void __launch_bounds__(64) k_bias_grad_final(const float* __restrict_
 // be z itself (in place).  Backward: the output's gradient is the sum of the matching channel slices of the consumers'
 // input gradients (g2 optional); y is read from the slice it was written to.  All slices are given by a base pointer
 // and a batch stride (channel planes are contiguous inside a sample).
+// z, d1 and d2 may alias (d1 == z in place; d1 / d2 slices of one buffer): no __restrict__ on them.
 template <bool VEC>
-__global__ void __launch_bounds__(EP_BLOCK) k_bias_act_fwd2(const float* __restrict__ z, const float* __restrict__ bias,
-                                                            float* __restrict__ d1, long d1_bs, float* __restrict__ d2,
+__global__ void __launch_bounds__(EP_BLOCK) k_bias_act_fwd2(const float* z, const float* __restrict__ bias,
+                                                            float* d1, long d1_bs, float* d2,
                                                             long d2_bs, int C, int HW, float slope) {
   const int b = plane_id() / C, c = plane_id() - b * C;
   const float bv = bias ? bias[c] : 0.0f;
@@ -136,9 +137,9 @@ __global__ void __launch_bounds__(EP_BLOCK) k_bias_act_fwd2(const float* __restr
 }
 
 template <bool VEC>
-__global__ void __launch_bounds__(EP_BLOCK) k_bias_act_bwd2(const float* __restrict__ y, long y_bs, const float* __restrict__ g1,
-                                                            long g1_bs, const float* __restrict__ g2, long g2_bs,
-                                                            float* __restrict__ gz, float* __restrict__ part, int C, int HW,
+__global__ void __launch_bounds__(EP_BLOCK) k_bias_act_bwd2(const float* y, long y_bs, const float* g1,
+                                                            long g1_bs, const float* g2, long g2_bs,
+                                                            float* gz, float* __restrict__ part, int C, int HW,
                                                             float slope) {
   __shared__ float red[4 * (EP_BLOCK / 64)];
   const int b = plane_id() / C, c = plane_id() - b * C;

@@ -169,10 +169,19 @@ class LossStackInputs:
     meta: dict = field(default_factory=dict)
 
 
+# Pose conditioning (robust_pose) is a TEST-INPUT device: the parity suite and the golden generator switch it on
+# (tests/conftest.py, tests/golden/make_golden.py) so that masks can be compared for equality with a reference whose
+# cos / sin come from a vendor libm; the library's own generator (bench.py, smoke()) draws raw poses.
+CONDITION_POSE = False
+
+
 def make_loss_stack_inputs(batch: int, h: int, w: int, num_scales: int = 3, seed: int = 1234,
                            num_flow_scales: int | None = None, pose_sigma: float = 0.02,
-                           flow_noise: float = 0.3) -> LossStackInputs:
-    """Synthetic net outputs + frames for the loss stack."""
+                           flow_noise: float = 0.3, condition_pose: bool | None = None) -> LossStackInputs:
+    """Synthetic net outputs + frames for the loss stack.  ``condition_pose``: nudge the rotation angles
+    with ``robust_pose`` (None = the module default ``CONDITION_POSE``, off unless a test harness enabled it)."""
+    if condition_pose is None:
+        condition_pose = CONDITION_POSE
     rng = _rng(seed)
     if num_flow_scales is None:
         num_flow_scales = num_scales + 1
@@ -189,7 +198,8 @@ def make_loss_stack_inputs(batch: int, h: int, w: int, num_scales: int = 3, seed
         disps.append(lst)
     pose = (pose_sigma * rng.standard_normal((batch, 2, 6))).astype(np.float32)
     pose[:, :, 3:] *= 0.25  # rotations smaller than translations
-    pose = robust_pose(pose)  # cos / sin unambiguous for every <= 0.6-ulp implementation (see robust_pose)
+    if condition_pose:
+        pose = robust_pose(pose)  # cos / sin unambiguous for every <= 0.6-ulp implementation (see robust_pose)
     flows = [[], []]
     for d in range(2):
         for s in range(num_flow_scales):
