@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--miopen-benchmark", type=int, default=0, help="torch.backends.cudnn.benchmark (MIOpen exhaustive find)")
+    ap.add_argument("--amp", default="off", choices=["off", "bf16"], help="opt-in mixed precision of the networks' convolutions (SURVEY 8(f) "
+                    "rank 1): bf16 MIOpen kernels with fp32 accumulation; glue, loss stack and optimiser stay fp32. The default line is fp32")
+    ap.add_argument("--net-streams", type=int, default=None, help="1 = the three networks one after the other on one stream; 3 = flow / pose "
+                    "nets on side streams (default: the package default)")
     return ap.parse_args()
 
 
@@ -136,7 +140,8 @@ class LossStackWorkload:
     def __init__(self, args, dev, seed):
         from unsupervised_depth_opticalflow_egomotion_amd import synthetic
         self.S = args.scales
-        inp = synthetic.make_loss_stack_inputs(args.batch, args.height, args.width, self.S, seed=seed)
+        inp = synthetic.make_loss_stack_inputs(args.batch, args.height, args.width, self.S, seed=seed,
+                                               num_flow_scales=max(self.S, 4))
         self.inp = inp
         g = lambda a, grad=False: torch.from_numpy(np.ascontiguousarray(a)).to(dev).requires_grad_(grad)
         self.imgs = [g(a) for a in inp.imgs]
@@ -268,14 +273,9 @@ class TrainStepWorkload:
 
 
 # ------------------------------------------------------------------------------------------------ roofline
-# dominant kernel of each mode's fused forward (segment 2 of the timed launches) and its algorithmic bytes per pixel
-# of every scale: reads + writes the kernel cannot avoid, fp32
-POINT_KERNEL = {
-    "geom": ("k_geom_point_fwd", 105),    # target 12 + 2 flows 16 + 2 bilinear sources 24 + 2 area sources 24 + disp 4; mask 1 + yw 24
-    "depth": ("k_depth_point_fwd", 65),   # target 12 + 2 area sources 24 + 2 bilinear sources 24 + disp 4; mask 1
-    "flow": ("k_flow_point_fwd", 84),     # target 12 + 2 flows 16 + 2 sources 24; weights 8 + yw 24
-}
-
+# dominant kernel of each mode's fused forward (segment 2 of the timed launches); its algorithmic bytes per launch come
+# from tools/byte_models.py, the same table tools/roofline_table.py prices the rocprof runs with
+from tools import byte_models  # noqa: E402
 
 POINT_LIMITER = {"geom": "vector-instruction issue (VALU + vector-memory instruction counts add up; working set is Infinity-Cache resident at B=4)"}
 HBM_ACHIEVABLE_GBS = 6290.0    # measured float4 copy rate (MI355X_MICROARCH.md)
@@ -296,9 +296,8 @@ def point_fwd_roofline(args, mode, fwd_ms, bwd_ms):
     """Roofline object from the HIP-event timings recorded inside the timed region (loss_stack.timing_begin /
     timing_collect: events on the launch stream around every launch of the fused stack, read after the final sync)."""
     S = args.scales
-    kernel, bpp = POINT_KERNEL[mode]
-    npx = args.batch * sum(int(args.height / 2 ** s) * int(args.width / 2 ** s) for s in range(S))
-    bytes_per_launch = bpp * npx
+    kernel = byte_models.POINT_KERNEL[mode]
+    bytes_per_launch, byte_model = byte_models.models(args.batch, args.height, args.width, S)[kernel]
     t_ms = float(fwd_ms[:, 2].mean())
     achieved = bytes_per_launch / (t_ms * 1e-3) / 1e9
     traffic = None   # PMC-derived HBM bytes per launch: cannot be collected from inside this process; taken from
@@ -316,7 +315,7 @@ def point_fwd_roofline(args, mode, fwd_ms, bwd_ms):
     roof = {"bound": "hbm", "limiter": POINT_LIMITER.get(mode), "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4),
             "traffic": traffic,
-            "bytes_per_launch": bytes_per_launch, "avg_kernel_ms": round(t_ms, 5), "launches_timed": int(fwd_ms.shape[0])}
+            "bytes_per_launch": bytes_per_launch, "byte_model": byte_model, "avg_kernel_ms": round(t_ms, 5), "launches_timed": int(fwd_ms.shape[0])}
     segs = {"fwd_ms": [round(float(x), 5) for x in fwd_ms.mean(0)],
             "bwd_ms": [round(float(x), 5) for x in bwd_ms.mean(0)] if len(bwd_ms) else []}
     return roof, segs
@@ -392,6 +391,12 @@ def main():
     args = parse()
     launch_ranks_if_needed(args)
     torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
+    if args.amp == "bf16":
+        from unsupervised_depth_opticalflow_egomotion_amd import convs
+        convs.set_compute_dtype(torch.bfloat16)
+    if args.net_streams is not None:
+        from unsupervised_depth_opticalflow_egomotion_amd import models
+        models._DEFAULT_NET_STREAMS = args.net_streams
     world, rank, local = init_dist(args)
     dev = torch.device("cuda", local)
     wl_name = args.workload
@@ -419,10 +424,11 @@ def main():
     out = {
         "metric": "frame-pairs/sec (%dx%d, %s mode)" % (args.width, args.height, args.mode if wl.name == "train_step" else "geom"), "value": round(value, 2), "unit": "frame-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.amp == "off" else args.amp, "data": "synthetic",
         "config": {"workload": wl.name + ": mode=%s, %dx%d, batch=%d/GPU, num_scales=%d, fwd+bwd%s" % (
             args.mode if wl.name == "train_step" else "geom", args.width, args.height, args.batch, args.scales,
-            "+Adam" if wl.name == "train_step" else ""),
+            "+Adam" if wl.name == "train_step" else "") + ("" if args.amp == "off" else
+            " [OPT-IN mixed precision, not the headline: convolutions in %s with fp32 accumulation; glue, loss stack, optimiser fp32]" % args.amp),
             "global_batch": args.batch * world, "parallelism": "dp%d" % world,
             "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE")},
     }

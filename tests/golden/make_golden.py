@@ -530,8 +530,80 @@ def gen_g7(ref, out):
     out["eval_flow_crop"] = N(f[0, :, 100:108, 400:408])
 
 
-GENERATORS = dict(G1=gen_g1, G2=gen_g2, G3=gen_g3, G4=gen_g4, G5=gen_g5, G6=gen_g6, G7=gen_g7, G8=gen_g8, G9=gen_g9)
-AC_INDEPENDENT = {"G3", "G4"}   # no grid_sample inside
+# ------------------------------------------------------------------------------------ G10
+def g10_inputs():
+    """Seeded flow / depth evaluation cases.  Predictions have the ground truth's size and cfg.img_hw equals it, so the
+    reference's cv2.resize is the identity and only the metric arithmetic is pinned (cv2 itself cannot be imported)."""
+    r = rng(1010)
+    H, W, n = 40, 64, 3
+    gt_flows, nocs, movs, preds = [], [], [], []
+    for _ in range(n):
+        valid = (r.random((H, W)) > 0.3).astype(np.float64)
+        gt = np.zeros((H, W, 3), np.float64)
+        gt[:, :, 0:2] = r.normal(0, 12, (H, W, 2)) * valid[:, :, None]
+        gt[:, :, 2] = valid
+        noc = valid * (r.random((H, W)) > 0.2)
+        mov = (r.random((H, W)) > 0.6).astype(np.float64)
+        pred = (gt[:, :, 0:2] + r.normal(0, 3.0, (H, W, 2)) * (r.random((H, W, 1)) > 0.5)).astype(np.float32)
+        gt_flows.append(gt); nocs.append(noc); movs.append(mov); preds.append(pred)
+    gt_depths, pred_depths = [], []
+    for _ in range(n):
+        g = (r.random((60, 200)) * 90.0).astype(np.float32)
+        g[r.random((60, 200)) > 0.4] = 0.0                      # sparse LiDAR ground truth
+        p = (np.abs(g + r.normal(0, 4, g.shape)) * 0.37 + 0.5).astype(np.float32)
+        gt_depths.append(g); pred_depths.append(p)
+    return dict(hw=(H, W), gt_flows=gt_flows, nocs=nocs, movs=movs, preds=preds, gt_depths=gt_depths, pred_depths=pred_depths)
+
+
+def load_reference_evaluation():
+    """core/evaluation/{evaluate_flow, evaluate_depth, evaluation_utils}.py loaded by path; cv2 / png / skimage / imageio
+    are stand-in modules (cv2.resize = identity for an unchanged size, anything else raises)."""
+    import importlib.util
+    ev = os.path.join(REF, "core", "evaluation")
+    cv2 = sys.modules.get("cv2") or types.ModuleType("cv2")
+
+    def resize(img, size, interpolation=None):
+        if (img.shape[1], img.shape[0]) != tuple(size):
+            raise RuntimeError("cv2 stand-in: only the identity resize exists here")
+        return img
+    cv2.resize, cv2.INTER_LINEAR = resize, 1
+    sys.modules["cv2"] = cv2
+    for name in ("png", "skimage", "skimage.io", "imageio"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    if ev not in sys.path:
+        sys.path.insert(0, ev)
+    mods = {}
+    for name in ("evaluation_utils", "evaluate_depth", "evaluate_flow"):
+        spec = importlib.util.spec_from_file_location("ref_" + name, os.path.join(ev, name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        mods[name] = m
+    return mods
+
+
+def gen_g10(ref, out):
+    ev = load_reference_evaluation()
+    c = g10_inputs()
+    cfg = types.SimpleNamespace(img_hw=c["hw"], model_dir=None)
+    copy = lambda lst: [np.array(a, copy=True) for a in lst]   # noqa: E731  (the reference's eval_depth writes into its inputs)
+    out["flow_table"] = np.array(ev["evaluate_flow"].eval_flow_avg(copy(c["gt_flows"]), copy(c["nocs"]), copy(c["preds"]), cfg))
+    out["flow_table_moving"] = np.array(ev["evaluate_flow"].eval_flow_avg(copy(c["gt_flows"]), copy(c["nocs"]), copy(c["preds"]), cfg,
+                                                                          moving_masks=copy(c["movs"])))
+    rates = []
+    for gt, pred in zip(c["gt_flows"], c["preds"]):
+        epe = np.sqrt(np.sum(np.square(pred - gt[:, :, 0:2]), axis=2))
+        rates.append(ev["evaluate_flow"].calculate_error_rate(epe, gt[:, :, 0:2], gt[:, :, 2]))
+    out["error_rates"] = np.array(rates, np.float64)
+    out["depth_metrics"] = np.array(ev["evaluate_depth"].eval_depth(copy(c["gt_depths"]), copy(c["pred_depths"])), np.float64)
+    errs = []
+    for g, p in zip(c["gt_depths"], c["pred_depths"]):
+        m = g > 0
+        errs.append(ev["evaluation_utils"].compute_errors(g[m].astype(np.float64), p[m].astype(np.float64)))
+    out["compute_errors"] = np.array(errs, np.float64)
+
+
+GENERATORS = dict(G1=gen_g1, G2=gen_g2, G3=gen_g3, G4=gen_g4, G5=gen_g5, G6=gen_g6, G7=gen_g7, G8=gen_g8, G9=gen_g9, G10=gen_g10)
+AC_INDEPENDENT = {"G3", "G4", "G10"}   # no grid_sample inside
 
 
 def main():

@@ -310,3 +310,72 @@ def test_evaluation_metrics_match_the_reference_formulas():
     gtd = [np.where(r.random((375, 1242)) > 0.9, r.uniform(1, 90, (375, 1242)), 0).astype(np.float32) for _ in range(2)]
     prd = [r.uniform(0.5, 60, (375, 1242)).astype(np.float32) for _ in range(2)]
     np.testing.assert_allclose(eval_depth(gtd, [torch.from_numpy(p) for p in prd]), EO.eval_depth(gtd, prd), rtol=2e-5)
+
+
+def test_evaluation_metrics_vs_reference_golden(golden_dir):
+    """core.evaluation (the product's eval_flow_avg / eval_depth, here on CPU tensors) against golden G10 -- the tables the
+    reference's own evaluate_flow / evaluate_depth printed for the same inputs."""
+    from core.evaluation import eval_flow_avg, eval_depth
+    from tests.golden import make_golden as MG
+    g = np.load(os.path.join(golden_dir, "G10.npz"))
+    c = MG.g10_inputs()
+    cfg = types.SimpleNamespace(img_hw=c["hw"])
+    vals = lambda t: [float(v) for v in str(t).strip().split("\n")[1].split(",")]   # noqa: E731
+    out = eval_flow_avg(c["gt_flows"], c["nocs"], [torch.from_numpy(p) for p in c["preds"]], cfg, moving_masks=c["movs"])
+    assert out.split("\n")[0] == str(g["flow_table_moving"]).split("\n")[0]          # same header line
+    np.testing.assert_allclose(vals(out), vals(g["flow_table_moving"]), atol=1.01e-4)
+    out = eval_flow_avg(c["gt_flows"], c["nocs"], c["preds"], cfg)
+    np.testing.assert_allclose(vals(out), vals(g["flow_table"]), atol=1.01e-4)
+    np.testing.assert_allclose(eval_depth(c["gt_depths"], [torch.from_numpy(p) for p in c["pred_depths"]]), g["depth_metrics"], rtol=2e-5)
+
+
+def test_kitti_png_codec_and_readers(tmp_path):
+    """kitti_io: the own PNG codec (16-bit RGB is what KITTI's flow ground truth uses and PIL truncates) against PIL on
+    what PIL can write, every row filter type on hand-encoded files, and the flow / mask / calibration readers."""
+    import struct, zlib
+    from PIL import Image
+    from unsupervised_depth_opticalflow_egomotion_amd import kitti_io as K
+    r = np.random.default_rng(0)
+    yy, xx = np.mgrid[0:60, 0:90]
+    smooth = ((np.sin(xx / 9.0) + np.cos(yy / 7.0)) * 60 + 128).astype(np.uint8)
+    for name, arr in (("noise8", (r.random((37, 53, 3)) * 255).astype(np.uint8)), ("smooth8", np.stack([smooth, smooth // 2, 255 - smooth], 2)),
+                      ("grey16", (np.sin(xx / 30.0) * 20000 + 30000).astype(np.uint16)), ("grey8", smooth)):
+        Image.fromarray(arr).save(str(tmp_path / (name + ".png")), optimize=True)      # PIL picks row filters adaptively
+        assert np.array_equal(K.read_png(str(tmp_path / (name + ".png"))), arr), name
+
+    def encode16(img, ftypes):
+        h, w, ch = img.shape
+        bpp, stride = ch * 2, w * ch * 2
+        raw = img.astype(">u2").tobytes()
+        prev, out = np.zeros(stride, np.int32), b""
+        for y in range(h):
+            row = np.frombuffer(raw[y * stride:(y + 1) * stride], np.uint8).astype(np.int32)
+            left = np.concatenate([np.zeros(bpp, np.int32), row[:-bpp]])
+            ul = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+            ft = ftypes[y % len(ftypes)]
+            p = left + prev - ul
+            pa, pb, pc = abs(p - left), abs(p - prev), abs(p - ul)
+            pred = [0, left, prev, (left + prev) >> 1, np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))][ft]
+            out += bytes([ft]) + ((row - pred) & 255).astype(np.uint8).tobytes()
+            prev = row
+        ck = lambda k, b: struct.pack(">I", len(b)) + k + b + struct.pack(">I", zlib.crc32(k + b) & 0xFFFFFFFF)   # noqa: E731
+        return b"\x89PNG\r\n\x1a\n" + ck(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 2, 0, 0, 0)) + ck(b"IDAT", zlib.compress(out)) + ck(b"IEND", b"")
+    img = (r.random((23, 31, 3)) * 65535).astype(np.uint16)
+    for fts in ([0], [1], [2], [3], [4], [0, 1, 2, 3, 4], [4, 3, 1]):
+        (tmp_path / "e.png").write_bytes(encode16(img, fts))
+        assert np.array_equal(K.read_png(str(tmp_path / "e.png")), img), fts
+    K.write_png(str(tmp_path / "w.png"), img)
+    assert np.array_equal(K.read_png(str(tmp_path / "w.png")), img)
+    flow = r.normal(0, 20, (20, 30, 2))
+    valid = r.random((20, 30)) > 0.3
+    K.write_flow_png(str(tmp_path / "f.png"), flow, valid)
+    back = K.read_flow_png(str(tmp_path / "f.png"))
+    assert np.array_equal(back[:, :, 2] > 0, valid) and np.abs(back[:, :, :2] - flow * valid[:, :, None]).max() <= 1 / 64
+    (tmp_path / "c.txt").write_text("calib_time: 09-Jan-2012 13:57:47\nP_rect_02: 7.2e+02 0 6.1e+02 4.4e+01 0 7.2e+02 1.7e+02 2.1e-01 0 0 1 2.7e-03\n")
+    assert np.allclose(K.load_intrinsics_raw(str(tmp_path / "c.txt")), [[720, 0, 610], [0, 720, 170], [0, 0, 1]])
+    up = K.resize_bilinear_u8(np.arange(12, dtype=np.uint8).reshape(3, 4), (6, 8))
+    ref = torch.nn.functional.interpolate(torch.arange(12.).reshape(1, 1, 3, 4), (6, 8), mode="bilinear", align_corners=False)[0, 0].numpy()
+    assert np.allclose(up, ref, atol=1e-5)
+    gt = np.stack([np.eye(3, 4)] * 3); gt[1, 0, 3] = 1.0; gt[2, 0, 3] = 2.0
+    ate, re = K.compute_pose_error(gt, gt * np.array([1, 1, 1, 0.5]))
+    assert ate < 1e-12 and re < 1e-12          # the ATE is invariant to the prediction's scale

@@ -352,6 +352,51 @@ def test_train_step_runs_and_learns():
     assert losses[-1] < losses[0], losses
 
 
+def _three_steps(net_streams=1, amp=None, B=2):
+    """Loss values and the flat gradient of three optimiser steps of the joint model from fixed seeds."""
+    from unsupervised_depth_opticalflow_egomotion_amd import convs
+    from unsupervised_depth_opticalflow_egomotion_amd.train_step import make_cfg, make_optimizer, train_step
+    from unsupervised_depth_opticalflow_egomotion_amd.models import get_model
+    cfg = make_cfg()
+    torch.manual_seed(0)
+    model = get_model("geom")(cfg).to(dev()).train()
+    model.net_streams = net_streams
+    opt = make_optimizer(model, 1e-4)
+    inputs = [torch.from_numpy(a).to(dev()) for a in synthetic.make_triplet_batch(B, 256, 832, 3, seed=1)]
+    losses = []
+    with convs.compute_dtype(amp):
+        for _ in range(3):
+            loss, lp, _ = train_step(model, opt, inputs, cfg)
+            losses.append(float(loss))
+    torch.cuda.synchronize()
+    flat = torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
+    return losses, flat
+
+
+def test_network_streams_do_not_change_results():
+    """Model_geometry.run_networks with the flow / pose nets on side streams (net_streams = 3): the same kernels in
+    the same order inside every net, so losses and gradients of three steps equal the single-stream run's to the
+    atomics' noise (warp_flow's feature-gradient scatter is the one non-deterministic kernel of the step)."""
+    l1, g1 = _three_steps(1)
+    l3, g3 = _three_steps(3)
+    np.testing.assert_allclose(l3, l1, rtol=2e-5)
+    assert float((g3 - g1).abs().max()) <= 1e-4 * float(g1.abs().max())
+
+
+def test_amp_bf16_mode_is_opt_in_and_close_to_fp32():
+    """convs.compute_dtype(torch.bfloat16) (train.py / bench.py --amp bf16): the convolutions run in bf16, everything else
+    in fp32.  Off by default; the first step's loss stays within 2 % of fp32's (bf16 has 8 significant bits, the loss is
+    a mean over 10^5..10^6 pixels) and training still reduces the loss."""
+    from unsupervised_depth_opticalflow_egomotion_amd import convs
+    assert convs.get_compute_dtype() is None
+    l32, _ = _three_steps(1)
+    l16, g16 = _three_steps(1, amp=torch.bfloat16)
+    assert convs.get_compute_dtype() is None
+    assert torch.isfinite(g16).all()
+    assert abs(l16[0] - l32[0]) <= 0.02 * abs(l32[0]), (l16, l32)
+    assert l16[-1] < l16[0], l16
+
+
 def test_train_cli_smoke(tmp_path):
     """train.py with the reference's flags: 2 iterations, checkpoint written in the reference's format, resume."""
     import subprocess, sys
@@ -431,3 +476,118 @@ def test_test_py_cli_surface(tmp_path):
     assert "Model Loaded." in out.stdout and "[EVAL] [synthetic flow]" in out.stdout and "abs_rel" in out.stdout
     out = subprocess.run(base + ["--task", "kitti_flow_2015"], capture_output=True, text=True, cwd=repo, timeout=600)
     assert out.returncode != 0 and "gt_2015_dir" in out.stderr
+
+
+def _mini_kitti(root):
+    """Miniature KITTI-shaped trees (2 flow pairs, 2 Eigen frames, one 5-frame odometry sequence) + a YAML naming them."""
+    import yaml
+    from PIL import Image
+    from unsupervised_depth_opticalflow_egomotion_amd import kitti_io as K
+    r = np.random.default_rng(7)
+    H, W = 120, 400
+
+    def image(seed):
+        a = synthetic.smooth_texture(np.random.default_rng(seed), (1, 3, H, W))[0]
+        return (np.clip(a, 0, 1) * 255).astype(np.uint8).transpose(1, 2, 0)
+    calib = "P_rect_02: 2.3e+02 0 2.0e+02 0 0 2.3e+02 6.0e+01 0 0 0 1 0\nP2: 2.3e+02 0 2.0e+02 0 0 2.3e+02 6.0e+01 0 0 0 1 0\n"
+    for year in (2012, 2015):
+        d = os.path.join(root, "flow%d" % year)
+        for sub in ("image_2", "flow_occ", "flow_noc", "obj_map", "calib_cam_to_cam"):
+            os.makedirs(os.path.join(d, sub), exist_ok=True)
+        for i in range(2):
+            stem = "%06d" % i
+            Image.fromarray(image(10 * i)).save(os.path.join(d, "image_2", stem + "_10.png"))
+            Image.fromarray(image(10 * i + 1)).save(os.path.join(d, "image_2", stem + "_11.png"))
+            flow = r.normal(0, 4, (H, W, 2))
+            valid = r.random((H, W)) > 0.4
+            K.write_flow_png(os.path.join(d, "flow_occ", stem + "_10.png"), flow, valid)
+            K.write_flow_png(os.path.join(d, "flow_noc", stem + "_10.png"), flow, valid & (r.random((H, W)) > 0.2))
+            Image.fromarray(((r.random((H, W)) > 0.7) * 3).astype(np.uint8)).save(os.path.join(d, "obj_map", stem + "_10.png"))
+            open(os.path.join(d, "calib_cam_to_cam", stem + ".txt"), "w").write(calib)
+    raw, eig = os.path.join(root, "raw"), os.path.join(root, "eigen")
+    os.makedirs(os.path.join(raw, "2011_09_26/drive_0001/image_02/data"), exist_ok=True)
+    os.makedirs(eig, exist_ok=True)
+    lines, gts = [], []
+    for i in range(2):
+        Image.fromarray(image(50 + i)).save(os.path.join(raw, "2011_09_26/drive_0001/image_02/data/%010d.png" % i))
+        lines.append("2011_09_26/drive_0001 %010d l" % i)
+        g = r.uniform(2, 60, (H, W)).astype(np.float32)
+        g[r.random((H, W)) > 0.3] = 0
+        gts.append(g)
+    open(os.path.join(eig, "test_files.txt"), "w").write("\n".join(lines) + "\n")
+    np.savez(os.path.join(eig, "gt_depths.npz"), data=np.array(gts))
+    odo = os.path.join(root, "odom")
+    os.makedirs(os.path.join(odo, "sequences/09/image_2"), exist_ok=True)
+    os.makedirs(os.path.join(odo, "poses"), exist_ok=True)
+    rows = []
+    for i in range(5):
+        Image.fromarray(image(80 + i)).save(os.path.join(odo, "sequences/09/image_2/%06d.png" % i))
+        T = np.eye(4)[:3]
+        T[2, 3] = 0.8 * i
+        rows.append(" ".join("%.6e" % v for v in T.reshape(-1)))
+    open(os.path.join(odo, "poses/09.txt"), "w").write("\n".join(rows) + "\n")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(repo, "config", "kitti_geom.yaml")))
+    cfg.update(gt_2012_dir=os.path.join(root, "flow2012"), gt_2015_dir=os.path.join(root, "flow2015"), raw_base_dir=raw,
+               eigen_dir=eig, kitti_odom_dir=odo, sequences=["09"])
+    path = os.path.join(root, "mini.yaml")
+    yaml.safe_dump(cfg, open(path, "w"))
+    return path
+
+
+def test_test_py_kitti_tasks_on_miniature_trees(tmp_path):
+    """test.py --task kitti_flow_2012 / kitti_flow_2015 / kitti_depth / kitti_pose / demo --image_path (reference
+    test.py:21-283, 365-377) end to end on miniature KITTI-shaped directory trees: files read by kitti_io, networks on the
+    GPU, metrics by core.evaluation, predictions written under --result_dir."""
+    import subprocess, sys
+    from unsupervised_depth_opticalflow_egomotion_amd import kitti_io as K
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    yml = _mini_kitti(str(tmp_path))
+    res = str(tmp_path / "out")
+    base = [sys.executable, os.path.join(repo, "test.py"), "-c", yml, "--mode", "geom", "--result_dir", res]
+
+    def run(*extra):
+        out = subprocess.run(base + list(extra), capture_output=True, text=True, cwd=repo, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        return out.stdout
+    o = run("--task", "kitti_flow_2015")
+    assert "[EVAL] [KITTI 2015]" in o and "move_err_rate" in o
+    f = K.read_flow_png(os.path.join(res, "flow_2015", "000001_10.png"))
+    assert f.shape == (120, 400, 3) and np.isfinite(f).all()
+    o = run("--task", "kitti_flow_2012")
+    assert "[EVAL] [KITTI 2012]" in o and "epe_noc" in o
+    o = run("--task", "kitti_depth")
+    assert "abs_rel" in o and os.path.exists(os.path.join(res, "depth", "0001.npy"))
+    o = run("--task", "kitti_pose")
+    assert "3 snippets to test" in o and "ATE" in o
+    img = os.path.join(str(tmp_path), "raw/2011_09_26/drive_0001/image_02/data/0000000000.png")
+    o = run("--task", "demo", "--image_path", img)
+    d = np.load(os.path.join(res, "demo_disp.npy"))
+    assert d.shape == (120, 400) and K.read_png(os.path.join(res, "demo_disp.png")).dtype == np.uint16
+
+
+def test_device_side_evaluation_at_kitti_size(golden_dir):
+    """core.evaluation on HIP tensors: golden G10 (the reference's own tables) and, at KITTI's
+    375 x 1242 with a 256 x 832 prediction (the resize included), the numpy oracle."""
+    import types
+    from oracle import eval_oracle as EO
+    from core.evaluation import eval_flow_avg, eval_depth
+    g = np.load(os.path.join(golden_dir, "G10.npz"))
+    c = MG.g10_inputs()
+    vals = lambda t: [float(v) for v in str(t).strip().split("\n")[1].split(",")]   # noqa: E731
+    out = eval_flow_avg(c["gt_flows"], c["nocs"], [G(p) for p in c["preds"]], types.SimpleNamespace(img_hw=c["hw"]), moving_masks=c["movs"])
+    np.testing.assert_allclose(vals(out), vals(g["flow_table_moving"]), atol=1.01e-4)
+    np.testing.assert_allclose(eval_depth(c["gt_depths"], [G(p) for p in c["pred_depths"]]), g["depth_metrics"], rtol=2e-5)
+    r = np.random.default_rng(11)
+    H, W = 375, 1242
+    gts, nocs, movs, preds = [], [], [], []
+    for _ in range(2):
+        gt = np.concatenate([8 * r.standard_normal((H, W, 2)), (r.random((H, W, 1)) > 0.3)], 2).astype(np.float32)
+        gts.append(gt); nocs.append((gt[:, :, 2] * (r.random((H, W)) > 0.2)).astype(np.float32))
+        movs.append((r.random((H, W)) > 0.7).astype(np.float32)); preds.append((3 * r.standard_normal((256, 832, 2))).astype(np.float32))
+    ref = EO.eval_flow_avg(gts, nocs, preds, (256, 832), movs)
+    out = eval_flow_avg(gts, nocs, [G(p) for p in preds], types.SimpleNamespace(img_hw=(256, 832)), moving_masks=movs)
+    np.testing.assert_allclose(vals(out), [ref[0], ref[1], ref[2], ref[4], ref[5], ref[6], ref[7], ref[3]], atol=1.01e-4, rtol=1e-4)
+    gtd = [np.where(r.random((H, W)) > 0.9, r.uniform(1, 90, (H, W)), 0).astype(np.float32) for _ in range(2)]
+    prd = [r.uniform(0.5, 60, (H, W)).astype(np.float32) for _ in range(2)]
+    np.testing.assert_allclose(eval_depth(gtd, [G(p) for p in prd]), EO.eval_depth(gtd, prd), rtol=3e-5)

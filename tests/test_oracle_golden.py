@@ -293,3 +293,28 @@ def test_g9_disabled_depth_terms(golden_dir, ac):
         for s in range(3):
             got = N(d[f][s].grad) if d[f][s].grad is not None else np.zeros_like(g["md_gdisp_%d_%d" % (f, s)])
             gscale(got, g["md_gdisp_%d_%d" % (f, s)], rel=5e-5, atol=1e-9)
+
+
+def _table_values(table):
+    return [float(v) for v in str(table).strip().split("\n")[1].split(",")]
+
+
+def test_g10_evaluation_metrics(golden_dir):
+    """oracle/eval_oracle.py against the reference's own evaluate_flow.eval_flow_avg / calculate_error_rate and
+    evaluate_depth.eval_depth / compute_errors (G10: identity-size cases, so cv2.resize plays no part): the metric
+    arithmetic of the evaluation oracle is pinned; its resize_linear stays a statement of cv2's published definition."""
+    from oracle import eval_oracle as EO
+    g = load(golden_dir, "G10")
+    c = MG.g10_inputs()
+    acc = EO.eval_flow_avg(c["gt_flows"], c["nocs"], c["preds"], c["hw"], c["movs"])
+    # table order of the reference: epe, noc, occ, move, static, move_rate, static_rate, err_rate
+    np.testing.assert_allclose([acc[0], acc[1], acc[2], acc[4], acc[5], acc[6], acc[7], acc[3]], _table_values(g["flow_table_moving"]), atol=5.1e-5)
+    acc4 = EO.eval_flow_avg(c["gt_flows"], c["nocs"], c["preds"], c["hw"])
+    np.testing.assert_allclose(acc4[:4], _table_values(g["flow_table"]), atol=5.1e-5)
+    for gt, pred, want in zip(c["gt_flows"], c["preds"], g["error_rates"]):
+        epe = np.sqrt(np.sum(np.square(pred - gt[:, :, 0:2]), axis=2))
+        assert EO.calculate_error_rate(epe, gt[:, :, 0:2], gt[:, :, 2]) == want
+    np.testing.assert_allclose(EO.eval_depth(c["gt_depths"], c["pred_depths"]), g["depth_metrics"], rtol=1e-6)
+    for gd, pd, want in zip(c["gt_depths"], c["pred_depths"], g["compute_errors"]):
+        m = gd > 0
+        np.testing.assert_allclose(EO.compute_errors(gd[m].astype(np.float64), pd[m].astype(np.float64)), want, rtol=1e-12)

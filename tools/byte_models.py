@@ -1,0 +1,36 @@
+"""Algorithmic byte models of the fused loss stack's kernels: the reads and writes a launch cannot
+avoid, fp32, for a batch of B triplets at H x W with S scales.  Used by bench.py (the `roofline` object) and by
+tools/roofline_table.py (the per-kernel table), so both always price a kernel with the same figure.
+
+Level 0 of the bilinear and of the area pyramid of a source frame is the frame itself -- one tensor, read for both
+purposes -- so it is counted once there (round 2 counted it twice: 105 B/px at every level)."""
+
+
+def scale_pixels(H, W, S):
+    return [int(H / 2 ** s) * int(W / 2 ** s) for s in range(S)]
+
+
+def models(B, H, W, S, mode="geom"):
+    N = scale_pixels(H, W, S)
+    SN, N0, NL = sum(N), N[0], sum(N[1:])
+    m = {
+        "k_geom_pyramids": (3 * B * 3 * N0 * 4 + 3 * B * 3 * NL * 4 + 2 * B * 3 * NL * 4,
+                            "read 3 frames 12 B/px + write bilinear levels>=1 of 3 frames + area levels>=1 of 2 frames"),
+        "k_geom_point_fwd": (B * (81 * N0 + 105 * NL),
+                             "per px: target 12 + 2 flows 16 + 2 bilinear sources 24 + 2 area sources 24 (level 0: the same tensor, counted once) + disp 4; mask 1 + masked warps 24 = 105 (81 at level 0)"),
+        "k_depth_point_fwd": (B * (41 * N0 + 65 * NL), "per px: target 12 + 2 area sources 24 + 2 bilinear sources 24 (level 0: once) + disp 4; mask 1 = 65 (41 at level 0)"),
+        "k_flow_point_fwd": (B * 84 * SN, "84 B/px: target 12 + 2 flows 16 + 2 sources 24; weights 8 + weighted warps 24"),
+        "k_geom_ssim_fwd_roll": (2 * 25 * B * SN, "25 B/px/dir: target 12 + warp 12 + mask 1"),
+        "k_geom_flow_smooth_fwd": (28 * B * SN, "28 B/px: target 12 + 2 flows 16"),
+        "k_geom_disp_smooth_fwd": (3 * B * (16 * N0 + 4 * NL), "3 frames: image 12 + disp 4 per full-res px + the low-res disparities"),
+        "k_geom_ssim_bwd_roll": (2 * 37 * B * SN, "37 B/px/dir: 25 + write dL/dwarp 12"),
+        "k_geom_point_bwd": (B * (100 * N0 + 124 * NL), "per px: forward reads 80 (56 at level 0) + dL/dwarp 24; write grad_flow 16 + grad_disp 4"),
+        "k_geom_flow_smooth_bwd": (60 * B * SN, "60 B/px: 28 + read-modify-write of grad_flow 32"),
+        "k_geom_disp_smooth_bwd1": (3 * B * N0 * (12 + 4 + 2 + 4 + 4 * (S - 1)),
+                                    "3 frames per full-res px: image 12 + disp 4 + up-sampled rows ~2; write grad_disp0 4 + up-sampled grads 4(S-1)"),
+        "k_geom_disp_smooth_bwd2": (3 * B * (4 * (S - 1) * N0 + 4 * NL), "read the up-sampled grads once, write grad_disp of levels >= 1"),
+    }
+    return m
+
+
+POINT_KERNEL = {"geom": "k_geom_point_fwd", "depth": "k_depth_point_fwd", "flow": "k_flow_point_fwd"}

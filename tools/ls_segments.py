@@ -9,7 +9,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=4); ap.add_argument("--height", type=int, default=256)
 ap.add_argument("--width", type=int, default=832); ap.add_argument("--scales", type=int, default=3)
 ap.add_argument("--iters", type=int, default=200); ap.add_argument("--tag", default="")
+ap.add_argument("--lib", default="", help="another build of libdfe_hip.so (tools/ablate_point_fwd.sh) instead of the in-tree one")
 a = ap.parse_args()
+if a.lib:
+    from unsupervised_depth_opticalflow_egomotion_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(a.lib)
 dev = torch.device("cuda:0")
 inp = synthetic.make_loss_stack_inputs(a.batch, a.height, a.width, a.scales, seed=1234, num_flow_scales=max(a.scales, 4) if a.scales > 3 else None)
 g = lambda x, grad=False: torch.from_numpy(np.ascontiguousarray(x)).to(dev).requires_grad_(grad)

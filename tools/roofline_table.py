@@ -8,23 +8,13 @@ coalesced read stream (MI355X_MICROARCH.md, HBM section); dword-per-lane streams
 read side); the 90 MB working set sits in the 256 MB Infinity Cache, so fabric-side counters also see cache hits."""
 import collections, csv, json, os, sys
 
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
-B, H, W, S = 4, 256, 832, 3
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import byte_models  # noqa: E402
+
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+B, H, W, S = (int(x) for x in sys.argv[2:6]) if len(sys.argv) >= 6 else (4, 256, 832, 3)
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-N = [int(H / 2 ** s) * int(W / 2 ** s) for s in range(S)]
-SN, N0, NL = sum(N), N[0], sum(N[1:])
-MODEL = {   # kernel -> (bytes per launch, formula)
-    "k_geom_pyramids": (3 * B * 3 * N0 * 4 + 3 * B * 3 * NL * 4 + 2 * B * 3 * NL * 4, "read 3 frames 12 B/px + write bilinear levels>=1 of 3 frames + area levels>=1 of 2 frames"),
-    "k_geom_point_fwd": (105 * B * SN, "105 B/px: target 12 + 2 flows 16 + 2 bilinear sources 24 + 2 area sources 24 + disp 4; mask 1 + masked warps 24"),
-    "k_geom_ssim_fwd_roll": (2 * 25 * B * SN, "25 B/px/dir: target 12 + warp 12 + mask 1"),
-    "k_geom_flow_smooth_fwd": (28 * B * SN, "28 B/px: target 12 + 2 flows 16"),
-    "k_geom_disp_smooth_fwd": (3 * B * (16 * N0 + 4 * NL), "3 frames: image 12 + disp 4 per full-res px + the low-res disparities"),
-    "k_geom_ssim_bwd_roll": (2 * 37 * B * SN, "37 B/px/dir: 25 + write dL/dwarp 12"),
-    "k_geom_point_bwd": (124 * B * SN, "124 B/px: forward reads 80 + dL/dwarp 24; write grad_flow 16 + grad_disp 4"),
-    "k_geom_flow_smooth_bwd": (60 * B * SN, "60 B/px: 28 + read-modify-write of grad_flow 32"),
-    "k_geom_disp_smooth_bwd1": (3 * B * N0 * (12 + 4 + 2 + 4 + 4 * (S - 1)), "3 frames per full-res px: image 12 + disp 4 + up-sampled rows ~2; write grad_disp0 4 + up-sampled grads 4(S-1)"),
-    "k_geom_disp_smooth_bwd2": (3 * B * (4 * (S - 1) * N0 + 4 * NL), "read the up-sampled grads once, write grad_disp of levels >= 1"),
-}
+MODEL = byte_models.models(B, H, W, S)   # kernel -> (bytes per launch, formula)
 
 
 def short(name):
@@ -83,7 +73,8 @@ json.dump(res, open(os.path.join(OUT, TAG + "_pmc_loss_stack.json"), "w"), inden
 with open(os.path.join(OUT, TAG + "_roofline_table.md"), "w") as fh:
     fh.write("# %s: fused loss stack, per-kernel roofline table (loss_stack workload, B=%d %dx%d S=%d, idle-GPU loop)\n\n" % (TAG, B, H, W, S))
     fh.write("`rocprofv3 --kernel-trace --stats` + separate `--pmc` passes (tools/pmc_loss_stack.sh); peak 8 TB/s (spec).\n"
-             "PMC bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction); the working set is Infinity-Cache resident.\n\n")
+             "PMC bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction; calibration of the other access shapes: "
+             "profiles/r03_fetch_calib.md).  Working set of the stack: %.0f MB (Infinity Cache: 256 MiB).\n\n" % (sum(v[0] for v in MODEL.values()) / 1e6 / 2))
     fh.write("| kernel | avg us | algorithmic MB | achieved GB/s | frac of 8 TB/s | PMC MB | PMC / alg | VALU / wave | VMEM rd+wr / wave | TA busy | wait-mem | wait-issue |\n|---|---|---|---|---|---|---|---|---|---|---|---|\n")
     for k, e in rows:
         fh.write("| %s | %.1f | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s |\n" % (
@@ -94,5 +85,22 @@ with open(os.path.join(OUT, TAG + "_roofline_table.md"), "w") as fh:
             e.get("frac_wait_mem", "-"), e.get("frac_wait_issue", "-")))
     fh.write("\nByte models:\n\n")
     for k, (bts, why) in MODEL.items():
-        fh.write("* `%s`: %.1f MB = %s\n" % (k, bts / 1e6, why))
+        if k in stats:
+            fh.write("* `%s`: %.1f MB = %s\n" % (k, bts / 1e6, why))
+# the traffic figure bench.py may quote for k_geom_point_fwd: tied to the kernel sources it was measured on
+e = res["kernels"].get("k_geom_point_fwd", {})
+if "pmc_bytes" in e:
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(os.path.dirname(OUT), "unsupervised_depth_opticalflow_egomotion_amd", "csrc")
+    for name in ("loss_stack_fwd.hip", "loss_stack.h", "loss_stack_exact.h", "dfe_device.h"):   # == bench.KERNEL_SOURCES
+        h.update(open(os.path.join(csrc, name), "rb").read())
+    json.dump({"note": "HBM-side bytes per launch of k_geom_point_fwd from rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, "
+                       "tools/pmc_loss_stack.sh): (2*FETCH_SIZE + WRITE_SIZE)*1024. bench.py reports it as roofline.traffic only "
+                       "when its workload AND the sha256 of the kernel sources match.",
+               "kernel": "k_geom_point_fwd", "kernel_source_sha256": h.hexdigest(),
+               "workload": {"batch": B, "height": H, "width": W, "scales": S},
+               "FETCH_SIZE_KB": e["FETCH_SIZE_KB"], "WRITE_SIZE_KB": e["WRITE_SIZE_KB"], "hbm_bytes_per_launch": e["pmc_bytes"],
+               "algorithmic_bytes_per_launch": e.get("algorithmic_bytes"), "source": TAG + "_pmc_loss_stack.json"},
+              open(os.path.join(OUT, TAG + "_pmc_point_fwd_traffic.json"), "w"), indent=1)
 print(open(os.path.join(OUT, TAG + "_roofline_table.md")).read())

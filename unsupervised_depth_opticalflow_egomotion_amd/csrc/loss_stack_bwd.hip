@@ -539,6 +539,62 @@ __global__ void __launch_bounds__(64) k_geom_flow_smooth_bwd(GeomDev D, GeomBwd 
   }
 }
 
+// ---------------------------------------------------------------------- pose finalize
+// grad_pose of one camera (b, d) by ONE wave: per scale, lane t accumulates rows k = t (mod 64) of the 21 columns
+// (12 camera sums + 9 dF sums, the latter only at scale 0) in double; a fixed butterfly (xor 32, 16, ... 1) adds the
+// 64 lane sums -- a fixed order, so the result is bitwise reproducible -- and lane 0 runs the closed-form 3x3 chains.
+// (Round 2: a 256-thread block per camera with an LDS pass and two barriers per scale, 15 us.)  Measured and rejected in
+// round 3: running it as an extra block row of k_geom_disp_smooth_bwd1, which it does not depend on -- its 21 double
+// accumulators lift that kernel from 58 to 145 VGPRs (8 -> 3 waves per SIMD).
+__device__ __forceinline__ double wave_xor_add(double v, int m) {
+  const int lo = __shfl_xor(__double2loint(v), m), hi = __shfl_xor(__double2hiint(v), m);
+  return v + __hiloint2double(hi, lo);
+}
+
+__device__ void pose_finalize_wave(const GeomDev& D, const GeomBwd& G, float* __restrict__ gpose, int cam) {
+  const int b = cam >> 1, d = cam & 1, S = D.S, t = threadIdx.x & 63;
+  const unsigned nblk_total = D.blk_start[S];
+  double g[6] = {0, 0, 0, 0, 0, 0}, gR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int s = 0; s < S; ++s) {
+    double a[PB_PER_DIR];
+#pragma unroll
+    for (int i = 0; i < PB_PER_DIR; ++i) a[i] = 0.0;
+    for (int k = D.blk_start[s] + t; k < D.blk_start[s + 1]; k += 64) {
+      const float* r = G.bpart + (static_cast<long>(b) * nblk_total + k) * PB_COUNT + d * PB_PER_DIR;
+#pragma unroll
+      for (int i = 0; i < PB_PER_DIR; ++i) a[i] += r[i];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+      for (int i = 0; i < PB_PER_DIR; ++i) a[i] = wave_xor_add(a[i], m);
+    const Camera& c = D.cams[cam * S + s];
+    for (int j = 0; j < 3; ++j) g[j] += c.K[j] * a[0] + c.K[3 + j] * a[1] + c.K[6 + j] * a[2];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) gR[i * 3 + j] += c.K[i] * a[3 + j] + c.K[3 + i] * a[6 + j] + c.K[6 + i] * a[9 + j];
+    if (s == 0)
+      for (int i = 0; i < 9; ++i) gF[i] = a[12 + i];
+  }
+  if (t != 0) return;
+  const Camera& c0 = D.cams[cam * S];
+  if (D.mode == 0) {
+    // epipolar: F = Ki^T E Ki, E = S R
+    const Epi& e = D.epi[cam];
+    double T[9], gE[9];
+    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) T[r * 3 + q] = e.Kinv[r * 3] * gF[q] + e.Kinv[r * 3 + 1] * gF[3 + q] + e.Kinv[r * 3 + 2] * gF[6 + q];
+    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) gE[r * 3 + q] = T[r * 3] * e.Kinv[q * 3] + T[r * 3 + 1] * e.Kinv[q * 3 + 1] + T[r * 3 + 2] * e.Kinv[q * 3 + 2];
+    double gS[9];
+    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) {
+      double aa = 0, bq = 0;
+      for (int k = 0; k < 3; ++k) { aa += e.S[k * 3 + r] * gE[k * 3 + q]; bq += gE[r * 3 + k] * c0.R[q * 3 + k]; }
+      gR[r * 3 + q] += aa; gS[r * 3 + q] = bq;
+    }
+    g[0] += gS[7] - gS[5]; g[1] += gS[2] - gS[6]; g[2] += gS[3] - gS[1];
+  }
+  for (int k = 0; k < 3; ++k) { double tt = 0; for (int i = 0; i < 9; ++i) tt += gR[i] * c0.dR[k * 9 + i]; g[3 + k] += tt; }
+  for (int i = 0; i < 6; ++i) gpose[cam * 6 + i] = static_cast<float>(g[i]);
+}
+
 // ---------------------------------------------------------------------- disparity smoothness backward
 // stage 1: per full-resolution pixel, dL/d(up_s(p)) for every scale.  Rolling wave kernel like
 // k_geom_disp_smooth_fwd (lanes 1..62 valid: x-1 and x+1 come from DPP wave shifts).  With
@@ -816,63 +872,8 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_bwd2_coarse(GeomD
   }
 }
 
-// ---------------------------------------------------------------------- pose finalize
-// One 256-thread block per (b, d).  Per scale, thread t accumulates rows k = t (mod 256) of the 21
-// columns (12 camera sums + 9 dF sums, the latter only at scale 0) in double; one thread per column
-// then adds the 256 per-thread sums in thread order (fixed order -> reproducible).
-__global__ void __launch_bounds__(256) k_geom_pose_finalize(GeomDev D, GeomBwd G, float* __restrict__ gpose) {
-  __shared__ double lds[256][PB_PER_DIR + 1];
-  __shared__ double sm[DFE_MAX_SCALES * 12 + 9];
-  const int cam = blockIdx.x, b = cam >> 1, d = cam & 1, S = D.S, t = threadIdx.x;
-  const unsigned nblk_total = D.blk_start[S];
-  for (int s = 0; s < S; ++s) {
-    double a[PB_PER_DIR];
-#pragma unroll
-    for (int i = 0; i < PB_PER_DIR; ++i) a[i] = 0.0;
-    for (int k = D.blk_start[s] + t; k < D.blk_start[s + 1]; k += 256) {
-      const float* r = G.bpart + (static_cast<long>(b) * nblk_total + k) * PB_COUNT + d * PB_PER_DIR;
-#pragma unroll
-      for (int i = 0; i < PB_PER_DIR; ++i) a[i] += r[i];
-    }
-#pragma unroll
-    for (int i = 0; i < PB_PER_DIR; ++i) lds[t][i] = a[i];
-    __syncthreads();
-    if (t < PB_PER_DIR) {
-      double v = 0.0;
-      for (int k = 0; k < 256; ++k) v += lds[k][t];
-      if (t < 12) sm[s * 12 + t] = v;
-      else if (s == 0) sm[S * 12 + (t - 12)] = v;
-    }
-    __syncthreads();
-  }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  double g[6] = {0, 0, 0, 0, 0, 0}, gR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int s = 0; s < S; ++s) {
-    const double* acc = sm + s * 12;
-    const Camera& c = D.cams[cam * S + s];
-    for (int j = 0; j < 3; ++j) g[j] += c.K[j] * acc[0] + c.K[3 + j] * acc[1] + c.K[6 + j] * acc[2];
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) gR[i * 3 + j] += c.K[i] * acc[3 + j] + c.K[3 + i] * acc[6 + j] + c.K[6 + i] * acc[9 + j];
-  }
-  const Camera& c0 = D.cams[cam * S];
-  if (D.mode == 0) {
-  // epipolar: F = Ki^T E Ki, E = S R
-  const Epi& e = D.epi[cam];
-  const double* gF = sm + S * 12;
-  double T[9], gE[9];
-  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) T[r * 3 + q] = e.Kinv[r * 3] * gF[q] + e.Kinv[r * 3 + 1] * gF[3 + q] + e.Kinv[r * 3 + 2] * gF[6 + q];
-  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) gE[r * 3 + q] = T[r * 3] * e.Kinv[q * 3] + T[r * 3 + 1] * e.Kinv[q * 3 + 1] + T[r * 3 + 2] * e.Kinv[q * 3 + 2];
-  double gS[9];
-  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) {
-    double a = 0, bq = 0;
-    for (int k = 0; k < 3; ++k) { a += e.S[k * 3 + r] * gE[k * 3 + q]; bq += gE[r * 3 + k] * c0.R[q * 3 + k]; }
-    gR[r * 3 + q] += a; gS[r * 3 + q] = bq;
-  }
-  g[0] += gS[7] - gS[5]; g[1] += gS[2] - gS[6]; g[2] += gS[3] - gS[1];
-  }
-  for (int k = 0; k < 3; ++k) { double t = 0; for (int i = 0; i < 9; ++i) t += gR[i] * c0.dR[k * 9 + i]; g[3 + k] += t; }
-  for (int i = 0; i < 6; ++i) gpose[cam * 6 + i] = static_cast<float>(g[i]);
+__global__ void __launch_bounds__(64) k_geom_pose_finalize(GeomDev D, GeomBwd G, float* __restrict__ gpose) {
+  pose_finalize_wave(D, G, gpose, blockIdx.x);
 }
 
 }  // namespace dfe
@@ -980,7 +981,7 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   }
   DFE_MARK();
   if (a->grad_pose) {
-    k_geom_pose_finalize<<<L.B * 2, 256, 0, st>>>(D, G, a->grad_pose);
+    k_geom_pose_finalize<<<L.B * 2, 64, 0, st>>>(D, G, a->grad_pose);
     DFE_LAUNCH_CHECK();
   }
   DFE_MARK();

@@ -13,6 +13,7 @@
 // All (sample, scale) images are batched into each launch: scale 2 alone (13 k px) cannot fill
 // 256 CUs.  Partials are reduced in a fixed order (no float atomics): bitwise reproducible.
 #include "loss_stack_exact.h"
+#include "dfe_camera.h"
 #include <cstdint>
 #include <cstdlib>
 
@@ -126,24 +127,39 @@ __device__ inline void mat3_small_bmm(const float* a, const float* b, float* o) 
     }
 }
 
-__global__ void k_prepare_epi(const float* __restrict__ pose, const float* __restrict__ Kinv, Epi* __restrict__ epi,
-                              const Camera* __restrict__ cams, int B, int S) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * 2) return;
-  const int b = i / 2;
-  const float* v = pose + i * 6;
-  const Camera& c = cams[i * S];    // R is scale independent
-  // fp32 small-bmm arithmetic of the reference (acc = 0; acc += a*b in k order, no FMA; see k_prepare_cameras)
+// Epi block of one (sample, direction) from the pose vector, the camera's rotation and K^-1.
+__device__ inline void make_epi(const float* v, const float* R, const float* Kinv_b, Epi& e) {
+  // fp32 small-bmm arithmetic of the reference (acc = 0; acc += a*b in k order, no FMA; see dfe_camera.h)
   const float Sk[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
   float E[9], M[9], Ki[9], KiT[9];
-  for (int k = 0; k < 9; ++k) Ki[k] = Kinv[b * 9 + k];
+  for (int k = 0; k < 9; ++k) Ki[k] = Kinv_b[k];
   for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) KiT[r * 3 + q] = Ki[q * 3 + r];
-  Epi e;
-  mat3_small_bmm(Sk, c.R, E);
+  mat3_small_bmm(Sk, R, E);
   mat3_small_bmm(E, Ki, M);
   mat3_small_bmm(KiT, M, e.F);
   for (int k = 0; k < 9; ++k) { e.Kinv[k] = Ki[k]; e.S[k] = Sk[k]; }
-  epi[i] = e;
+}
+
+// The camera and epipolar blocks of a forward call in ONE launch (round 2: k_prepare_cameras 8-10 us + k_prepare_epi 4 us
+// + a launch gap): one thread per (b, d, s); the thread of scale 0 also forms the (b, d) epipolar block from its rotation.
+// Measured and rejected in round 3: running this job as an extra block row of k_geom_pyramids (nothing there depends on
+// it) -- the double-precision trigonometry lifts that kernel from 24 to 78 VGPRs and gives every one of its waves a
+// 320-byte scratch frame.
+struct PrepJob { const float* pose; const float* K; const float* Kinv; Camera* cams; Epi* epi; int B, S, mode; ScaleList downs; };
+
+__global__ void __launch_bounds__(64) k_geom_prepare(PrepJob pj) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= pj.B * 2 * pj.S) return;
+  const int s = idx % pj.S, bd = idx / pj.S, b = bd >> 1;
+  const float* pv = pj.pose + static_cast<long>(bd) * 6;
+  Camera c;
+  make_camera(pv, pj.K + b * 9, pj.downs.v[s], c);
+  pj.cams[idx] = c;
+  if (s == 0 && pj.mode == 0) {
+    Epi e;
+    make_epi(pv, c.R, pj.Kinv + b * 9, e);
+    pj.epi[bd] = e;
+  }
 }
 
 // ---------------------------------------------------------------------- pyramids
@@ -260,9 +276,18 @@ __global__ void __launch_bounds__(64) k_geom_area_coarse(PyrJobs jobs) {
 // RGBA-texel zero-bordered source planes with wave-persistent accumulation (fewer, wider gathers: the addresser cost
 // follows bytes, VGPRs double -> 54-60 us vs 48), 32x8 LDS-staged source tiles with a +-6 px halo around the
 // tile-centre flow (hit rate too low on rough flow fields: 59 us), LDS-transposed streamed loads / stores (53 us).
+// DFE_ABL: compile-time ablation switches of k_geom_point_fwd for the cost study of profiles/r03_point_fwd_ablation.md
+// (tools/ablate_point_fwd.sh builds one library per value; 0 = the shipped kernel, no code depends on it then).
+//   1 no block reductions   2 gathers at the pixel's own position (coherent)   4 no stores   8 rigid branch without gathers
+//  16 flow-warp branch without gathers   32 no epipolar / flow-consistency terms   64 no projection arithmetic
+// 128 no streamed source-pyramid loads
+#ifndef DFE_ABL
+#define DFE_ABL 0
+#endif
+
 struct PointCtx {
   int b, s, H, W, ac;
-  unsigned N4;
+  unsigned N4, p4;
   float alpha, beta;
   const float *srcL, *srcR, *areaL, *areaR;   // block-uniform plane bases of this sample
   const float *dispL, *dispR;                  // DT: the source frames' disparity planes of this sample and scale
@@ -288,11 +313,15 @@ __device__ __forceinline__ void point_pixel(const PointCtx& c, int px, int py, c
   for (int d = 0; d < 2; ++d) {
     float ix, iy;
     flow_coords_d(px, py, in.fu[d], in.fv[d], H, W, c.ac, c.dw, c.dh, ix, iy);
-    const FastTap t = make_fast_tap(ix, iy, H, W);
+    FastTap t = make_fast_tap(ix, iy, H, W);
+    if (DFE_ABL & 2) { t.o0 = min(c.p4, c.N4 - 8u); t.o1 = t.o0; }
     const float keep = (fast_cover(t) < 0.9999f) ? 0.0f : 1.0f;
     const float* src = d == 0 ? c.srcL : c.srcR;
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) wv[d][ch] = fast_sample(reinterpret_cast<const float*>(reinterpret_cast<const char*>(src) + ch * c.N4), t) * keep;
+    for (int ch = 0; ch < 3; ++ch) {
+      if (DFE_ABL & 16) wv[d][ch] = (d == 0 ? in.sl[ch] : in.sr[ch]) * (keep + t.wa0);
+      else wv[d][ch] = fast_sample(reinterpret_cast<const float*>(reinterpret_cast<const char*>(src) + ch * c.N4), t) * keep;
+    }
     valid[d] = !(wv[d][0] == 0.0f && wv[d][1] == 0.0f && wv[d][2] == 0.0f);
     dif[d] = mean3_abs_diff(in.i0, in.i1, in.i2, wv[d][0], wv[d][1], wv[d][2]);
   }
@@ -302,18 +331,24 @@ __device__ __forceinline__ void point_pixel(const PointCtx& c, int px, int py, c
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
     const Camera& cam = c.cam[d * c.cam_stride];
-    const Proj pr = project_fast(cam, px, py, in.dsp);
+    Proj pr;
+    if (DFE_ABL & 64) { pr.U = static_cast<float>(px) + in.dsp; pr.V = static_cast<float>(py) + in.dsp * cam.b[0]; pr.Z = 1.0f; }
+    else pr = project_fast(cam, px, py, in.dsp);
     const float ru = pr.U - static_cast<float>(px), rv = pr.V - static_cast<float>(py);
     const float du = fabsf(ru - in.fu[d]), dv = fabsf(rv - in.fv[d]);
     const bool dyna = dyna_decide(in.fu[d], in.fv[d], ru, rv, du, dv, c.alpha, c.beta);
     float xn, yn; bool lx, ly;
     rigid_grid_d(pr, c.dw, c.dh, xn, yn, lx, ly);
-    const FastTap t = make_fast_tap(unnormalize(xn, W, c.ac), unnormalize(yn, H, c.ac), H, W);
+    FastTap t = make_fast_tap(unnormalize(xn, W, c.ac), unnormalize(yn, H, c.ac), H, W);
+    if (DFE_ABL & 2) { t.o0 = min(c.p4, c.N4 - 8u); t.o1 = t.o0; }
     const float* ar = d == 0 ? c.areaL : c.areaR;
+    const float* sp = d == 0 ? in.sl : in.sr;
     float rec[3];
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) rec[ch] = fast_sample(reinterpret_cast<const float*>(reinterpret_cast<const char*>(ar) + ch * c.N4), t);
-    const float* sp = d == 0 ? in.sl : in.sr;
+    for (int ch = 0; ch < 3; ++ch) {
+      if (DFE_ABL & 8) rec[ch] = sp[ch] * (t.wa0 + t.wb1);
+      else rec[ch] = fast_sample(reinterpret_cast<const float*>(reinterpret_cast<const char*>(ar) + ch * c.N4), t);
+    }
     const float e_rec = mean3_abs_diff(in.i0, in.i1, in.i2, rec[0], rec[1], rec[2]);
     const float e_src = mean3_abs_diff(in.i0, in.i1, in.i2, sp[0], sp[1], sp[2]);
     const bool tex = e_rec < e_src;
@@ -334,7 +369,7 @@ __device__ __forceinline__ void point_pixel(const PointCtx& c, int px, int py, c
     a[PT_M_RIG] += m_rig;       a[PT_L1_RIG] += l1_wrp * m_rig;
     a[PT_M_DYN] += m_dyn;       a[PT_L1_DYN] += l1_wrp * m_dyn;
     a[PT_M_VO] += vo;
-    if (c.s == 0) {
+    if (c.s == 0 && !(DFE_ABL & 32)) {
       a[PT_FDIFF] += (du + dv) * m_rig;
       const Epi& e = c.epi[d];
       const float x1 = static_cast<float>(px), y1 = static_cast<float>(py);
@@ -352,6 +387,7 @@ __device__ __forceinline__ void point_pixel(const PointCtx& c, int px, int py, c
   }
   // flow consistency (model_geometry.py:195-210): |unit(fwd) + unit(bwd)| on (1 - occ_fwd)
   // loss-only: 1-ulp sqrt / reciprocal
+  if (DFE_ABL & 32) return;
   const float rf = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(in.fu[1] * in.fu[1] + in.fv[1] * in.fv[1]) + 1e-12f);
   const float rb = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(in.fu[0] * in.fu[0] + in.fv[0] * in.fv[0]) + 1e-12f);
   const float inv = occ[1] ? 0.0f : 1.0f;
@@ -431,7 +467,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, GeomT T,
     split_pixel(p, W, T.rW[s], px, py);
     const unsigned p4 = p * 4u, N4 = static_cast<unsigned>(N) * 4u;
     PointCtx c;
-    c.b = b; c.s = s; c.H = H; c.W = W; c.ac = D.ac; c.N4 = N4; c.alpha = D.alpha; c.beta = D.beta;
+    c.b = b; c.s = s; c.H = H; c.W = W; c.ac = D.ac; c.N4 = N4; c.p4 = p4; c.alpha = D.alpha; c.beta = D.beta;
     c.srcL = D.pyr[0][s] + static_cast<long>(b) * 3 * N; c.srcR = D.pyr[2][s] + static_cast<long>(b) * 3 * N;
     c.areaL = D.area[0][s] + static_cast<long>(b) * 3 * N; c.areaR = D.area[1][s] + static_cast<long>(b) * 3 * N;
     c.cam = D.cams + (b * 2) * D.S + s; c.cam_stride = D.S; c.epi = D.epi + b * 2;
@@ -444,11 +480,16 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, GeomT T,
     in.i0 = ldb(it, p4); in.i1 = ldb(it, p4 + N4); in.i2 = ldb(it, p4 + 2 * N4);
     in.fu[0] = ldb(flb, p4); in.fv[0] = ldb(flb, p4 + N4); in.fu[1] = ldb(flf, p4); in.fv[1] = ldb(flf, p4 + N4);
     in.dsp = ldb(D.disp[1][s] + static_cast<long>(b) * N, p4);
-    in.sl[0] = ldb(c.srcL, p4); in.sl[1] = ldb(c.srcL, p4 + N4); in.sl[2] = ldb(c.srcL, p4 + 2 * N4);
-    in.sr[0] = ldb(c.srcR, p4); in.sr[1] = ldb(c.srcR, p4 + N4); in.sr[2] = ldb(c.srcR, p4 + 2 * N4);
+    if (DFE_ABL & 128) { in.sl[0] = in.i1; in.sl[1] = in.i2; in.sl[2] = in.i0; in.sr[0] = in.i2; in.sr[1] = in.i0; in.sr[2] = in.i1; }
+    else {
+      in.sl[0] = ldb(c.srcL, p4); in.sl[1] = ldb(c.srcL, p4 + N4); in.sl[2] = ldb(c.srcL, p4 + 2 * N4);
+      in.sr[0] = ldb(c.srcR, p4); in.sr[1] = ldb(c.srcR, p4 + N4); in.sr[2] = ldb(c.srcR, p4 + 2 * N4);
+    }
     float yw[2][3], yr[2][3];
     unsigned bits;
     point_pixel<DT>(c, static_cast<int>(px), static_cast<int>(py), in, yw, bits, acc, yr, dc);
+    if (DFE_ABL & 4) { if (yw[0][0] + yw[0][1] + yw[0][2] + yw[1][0] + yw[1][1] + yw[1][2] == 1234.5f) D.mask[s][0] = 1; }
+    else
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
       float* ywp = D.yw[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
@@ -460,7 +501,15 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, GeomT T,
         for (int ch = 0; ch < 3; ++ch) stb(yrp, p4 + ch * N4, yr[d][ch]);
       }
     }
-    (D.mask[s] + static_cast<long>(b) * N)[p] = static_cast<unsigned char>(bits);
+    if (!(DFE_ABL & 4)) (D.mask[s] + static_cast<long>(b) * N)[p] = static_cast<unsigned char>(bits);
+    else if (bits == 0x12345u) D.mask[s][1] = 1;
+  }
+  if (DFE_ABL & 1) {
+    float tot = 0.0f;
+#pragma unroll
+    for (int i = 0; i < PT_COUNT; ++i) tot += acc[i];
+    if (tot == 1234.5f) part[0] = tot;
+    return;
   }
   point_block_sums(acc, red, part + (static_cast<long>(b) * nblk_total + blk) * PT_COUNT);
   if (DT) block_sum<2>(dc, red, part2 + (static_cast<long>(b) * nblk_total + blk) * 2);
@@ -762,18 +811,23 @@ __global__ void __launch_bounds__(64) k_geom_disp_smooth_fwd(GeomDev D, float* _
 }
 
 // ---------------------------------------------------------------------- finalize
-// k_geom_reduce_fwd: one 256-thread block per (scale, sample) plus one per sample for the disparity-smoothness
-// sums.  Phase 1: thread t accumulates the partial rows k = t (mod 256) of every column in double; phase 2: one
-// thread per column adds the 256 per-thread sums in thread order.  Both orders are fixed -> bitwise
-// reproducible.  k_geom_assemble_fwd (one thread per sample) then forms the eight loss values and the
-// normalisers the backward needs.
-__global__ void __launch_bounds__(256) k_geom_reduce_fwd(GeomDev D, const float* __restrict__ part,
+// k_geom_finalize_fwd: ONE 256-thread block per sample (round 2 ran a (scale, sample) reduction grid and a second
+// one-thread-per-sample assembly launch: 7 + 9.5 us and a launch gap for < 1 MB of partials).  Per scale, phase 1:
+// thread t accumulates the partial rows k = t (mod 256) of every column in double; phase 2: one thread per column adds
+// the 256 per-thread sums in thread order.  Both orders are fixed -> bitwise reproducible.  The sums stay in LDS and
+// thread 0 forms the loss values and the normalisers the backward needs (assemble_sample).
+__device__ void assemble_sample(const GeomDev& D, int b, const float* sums, const float* dsum, const float* __restrict__ sums2,
+                                float* __restrict__ coef, float* __restrict__ losses);
+
+__global__ void __launch_bounds__(256) k_geom_finalize_fwd(GeomDev D, const float* __restrict__ part,
                                     const float* __restrict__ spart, const float* __restrict__ fpart,
-                                    const float* __restrict__ dpart, int ndunit, float* __restrict__ sums,
-                                    float* __restrict__ dsum) {
+                                    const float* __restrict__ dpart, int ndunit, const float* __restrict__ sums2,
+                                    float* __restrict__ sums_out, float* __restrict__ coef, float* __restrict__ losses) {
   __shared__ double lds[256][SUM_COUNT + 1];
-  const int s = blockIdx.x, b = blockIdx.y, S = D.S, B = D.B, t = threadIdx.x;
-  if (s < S) {
+  __shared__ float s_sums[DFE_MAX_SCALES * SUM_COUNT];
+  __shared__ float s_dsum[6];
+  const int b = blockIdx.x, S = D.S, B = D.B, t = threadIdx.x;
+  for (int s = 0; s < S; ++s) {
     double a[SUM_COUNT];
 #pragma unroll
     for (int i = 0; i < SUM_COUNT; ++i) a[i] = 0.0;
@@ -801,9 +855,12 @@ __global__ void __launch_bounds__(256) k_geom_reduce_fwd(GeomDev D, const float*
     if (t < SUM_COUNT) {
       double v = 0.0;
       for (int k = 0; k < 256; ++k) v += lds[k][t];
-      sums[(static_cast<long>(b) * S + s) * SUM_COUNT + t] = static_cast<float>(v);
+      s_sums[s * SUM_COUNT + t] = static_cast<float>(v);
+      sums_out[(static_cast<long>(b) * S + s) * SUM_COUNT + t] = static_cast<float>(v);
     }
-  } else {
+    __syncthreads();
+  }
+  {
     double a[6] = {0, 0, 0, 0, 0, 0};
     if (D.mode != 2) for (int k = t; k < ndunit; k += 256)
 #pragma unroll
@@ -817,9 +874,11 @@ __global__ void __launch_bounds__(256) k_geom_reduce_fwd(GeomDev D, const float*
     if (t < 6) {
       double v = 0.0;
       for (int k = 0; k < 256; ++k) v += lds[k][t];
-      dsum[((t >> 1) * B + b) * 2 + (t & 1)] = static_cast<float>(v);
+      s_dsum[t] = static_cast<float>(v);
     }
+    __syncthreads();
   }
+  if (t == 0) assemble_sample(D, b, s_sums, s_dsum, sums2, coef, losses);
 }
 
 // depth terms: fixed-order sums of the consistency block partials and the rigid-SSIM strip partials of one
@@ -849,15 +908,15 @@ __global__ void __launch_bounds__(256) k_geom_reduce_dt(GeomDev D, const float* 
   }
 }
 
-__global__ void k_geom_assemble_fwd(GeomDev D, const float* __restrict__ sums, const float* __restrict__ dsum,
-                                    const float* __restrict__ sums2, float* __restrict__ coef, float* __restrict__ losses) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x, S = D.S, B = D.B;
-  if (b >= B) return;
+// sums: [S][SUM_COUNT] of this sample; dsum: [3 frames][2] of this sample
+__device__ void assemble_sample(const GeomDev& D, int b, const float* sums, const float* dsum, const float* __restrict__ sums2,
+                                float* __restrict__ coef, float* __restrict__ losses) {
+  const int S = D.S, B = D.B;
   const double eps = 1e-12;
   double l_dp = 0, l_fp = 0, l_fs = 0, l_sm = 0, l_fc = 0, l_dfc = 0, l_epi = 0, l_dss = 0, l_dcs = 0;
   for (int s = 0; s < S; ++s) {
     const double N = D.N[s], H = D.H[s], W = D.W[s];
-    const float* sm = sums + (static_cast<long>(b) * S + s) * SUM_COUNT;
+    const float* sm = sums + s * SUM_COUNT;
     float* cf = coef + (static_cast<long>(b) * S + s) * CF_COUNT;
     for (int d = 0; d < 2; ++d) {
       const float* a = sm + d * PT_PER_DIR;
@@ -890,7 +949,7 @@ __global__ void k_geom_assemble_fwd(GeomDev D, const float* __restrict__ sums, c
   double l_ds = 0;
   {
     const double H = D.H[0], W = D.W[0];
-    for (int f = 0; f < 3; ++f) l_ds += dsum[(f * B + b) * 2] / (H * (W - 1.0)) + dsum[(f * B + b) * 2 + 1] / ((H - 1.0) * W);
+    for (int f = 0; f < 3; ++f) l_ds += dsum[f * 2] / (H * (W - 1.0)) + dsum[f * 2 + 1] / ((H - 1.0) * W);
   }
   losses[DFE_LOSS_DEPTH_PIXEL * B + b] = static_cast<float>(l_dp);
   losses[DFE_LOSS_DEPTH_SMOOTH * B + b] = static_cast<float>(l_ds);
@@ -961,11 +1020,9 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   float downs[DFE_MAX_SCALES];
   for (int s = 0; s < L.S; ++s) downs[s] = static_cast<float>(static_cast<double>(a->H) / static_cast<double>(L.H[s]));
   if (a->mode != 2) {
-    rc = dfe_prepare_cameras(a->pose, a->K, ws + L.o_cams, L.B, 2, L.S, downs, stream);
-    if (rc != DFE_OK) return rc;
-  }
-  if (a->mode == 0) {
-    k_prepare_epi<<<(L.B * 2 + 63) / 64, 64, 0, st>>>(a->pose, a->K_inv, reinterpret_cast<Epi*>(ws + L.o_epi), D.cams, L.B, L.S);
+    PrepJob pj{a->pose, a->K, a->K_inv, reinterpret_cast<Camera*>(ws + L.o_cams), reinterpret_cast<Epi*>(ws + L.o_epi), L.B, L.S, a->mode, {}};
+    for (int s = 0; s < L.S; ++s) pj.downs.v[s] = downs[s];
+    k_geom_prepare<<<(L.B * 2 * L.S + 63) / 64, 64, 0, st>>>(pj);
     DFE_LAUNCH_CHECK();
   }
   DFE_MARK();
@@ -1064,15 +1121,12 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   }
   DFE_LAUNCH_CHECK();
   DFE_MARK();
-  k_geom_reduce_fwd<<<dim3(L.S + 1, L.B), 256, 0, st>>>(D, ws + L.o_part, ws + L.o_spart, ws + L.o_fpart, ws + L.o_dpart,
-                                                     L.dsm_units, ws + L.o_sums, ws + L.o_dsum);
-  DFE_LAUNCH_CHECK();
   if (L.dt) {
     k_geom_reduce_dt<<<dim3(L.S, L.B), 256, 0, st>>>(D, ws + L.o_part2, ws + L.o_spart2, ws + L.o_sums2);
     DFE_LAUNCH_CHECK();
   }
-  k_geom_assemble_fwd<<<(L.B + 63) / 64, 64, 0, st>>>(D, ws + L.o_sums, ws + L.o_dsum, L.dt ? ws + L.o_sums2 : nullptr,
-                                                      ws + L.o_coef, a->losses);
+  k_geom_finalize_fwd<<<L.B, 256, 0, st>>>(D, ws + L.o_part, ws + L.o_spart, ws + L.o_fpart, ws + L.o_dpart, L.dsm_units,
+                                           L.dt ? ws + L.o_sums2 : nullptr, ws + L.o_sums, ws + L.o_coef, a->losses);
   DFE_LAUNCH_CHECK();
   DFE_MARK();
 #undef DFE_MARK

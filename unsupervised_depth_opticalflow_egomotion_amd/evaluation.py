@@ -38,7 +38,7 @@ def eval_flow_avg(gt_flows, noc_masks, pred_flows, cfg, moving_masks=None, write
     if write_img:
         raise NotImplementedError("write_img needs cv2 / flow_to_image (visualisation is out of scope)")
     num = len(gt_flows)
-    acc = torch.zeros(8, dtype=torch.float64)
+    acc = None          # [8] float64 on the predictions' device; ONE host transfer after the loop
     for i, (gt_flow, noc_mask, pred_flow) in enumerate(zip(gt_flows, noc_masks, pred_flows)):
         dev = pred_flow.device if isinstance(pred_flow, torch.Tensor) else None
         gt, noc, pred = _t(gt_flow, dev), _t(noc_mask, dev), _t(pred_flow, dev).clone()
@@ -59,9 +59,10 @@ def eval_flow_avg(gt_flows, noc_masks, pred_flows, cfg, moving_masks=None, write
                     calculate_error_rate(epe, gt[:, :, 0:2], valid * mv),
                     calculate_error_rate(epe, gt[:, :, 0:2], valid * (1.0 - mv))]
         else:
-            row += [torch.zeros((), dtype=torch.float64)] * 4
-        acc += torch.stack([r.to("cpu") if isinstance(r, torch.Tensor) else torch.tensor(r) for r in row]).double()
-    error, error_noc, error_occ, error_rate, error_move, error_static, move_rate, static_rate = (acc / num).tolist()
+            row += [torch.zeros((), dtype=torch.float64, device=epe.device)] * 4
+        row = torch.stack([r.double() for r in row])
+        acc = row if acc is None else acc + row.to(acc.device)
+    error, error_noc, error_occ, error_rate, error_move, error_static, move_rate, static_rate = (acc / num).cpu().tolist()
     if moving_masks:
         result = "{:>10}, {:>10}, {:>10}, {:>10}, {:>10}, {:>10}, {:>10}, {:>10} \n".format(
             "epe", "epe_noc", "epe_occ", "epe_move", "epe_static", "move_err_rate", "static_err_rate", "err_rate")
@@ -109,5 +110,6 @@ def eval_depth(gt_depths, pred_depths, min_depth=1e-3, max_depth=80, nyu=False):
         p = p * (_median_np(g) / _median_np(p))
         p = torch.clamp(p, min_depth, max_depth)
         g = torch.clamp(g, min_depth, max_depth)
-        rows.append(torch.stack([v.float() for v in compute_errors(g, p, nyu=nyu)]).to("cpu"))
-    return [float(v) for v in torch.stack(rows).float().mean(0)]
+        rows.append(torch.stack([v.float() for v in compute_errors(g, p, nyu=nyu)]))
+    dev0 = rows[0].device
+    return [float(v) for v in torch.stack([r.to(dev0) for r in rows]).float().mean(0).cpu()]

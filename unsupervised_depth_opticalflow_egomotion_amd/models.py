@@ -94,6 +94,16 @@ def _flow_branches(fpyramid, pwc_model, img_l, img, img_r):
 
 
 _PLACEHOLDERS = {}
+_SIDE_STREAMS = {}
+_DEFAULT_NET_STREAMS = int(__import__("os").environ.get("DFE_NET_STREAMS", "1"))
+
+
+def _side_streams(dev):
+    key = (dev.type, dev.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+    return _SIDE_STREAMS[key]
+
 
 
 def _zeros2(dev):
@@ -144,11 +154,36 @@ class Model_geometry(LossTerms, nn.Module):
         return self.pose_net(imgs)
 
     def run_networks(self, img_l, img, img_r, batched=None):
-        """model_geometry.py:781-795.  depth_net is called once per frame (BatchNorm statistics per call)."""
-        h, w = img.shape[2], img.shape[3]
+        """model_geometry.py:781-795.  depth_net is called once per frame (BatchNorm statistics per call).
+
+        The three networks are independent until the loss stack.  On a HIP device (``net_streams`` > 1, the default) the
+        flow branch and the pose net are enqueued on side streams while the depth net runs on the current one: the
+        coarse pyramid levels launch grids far smaller than 256 CUs (512->512 at 8x26 x 12 images: 80 workgroups) and
+        leave most of the chip idle when the nets run one after the other.  autograd replays every backward node on
+        the stream of its forward op, so the backward passes overlap the same way.  Results are identical (same
+        kernels, same order within a net)."""
+        n_streams = int(getattr(self, "net_streams", _DEFAULT_NET_STREAMS)) if img.is_cuda else 1
+        if n_streams <= 1:
+            disp_l, disp_t, disp_r = _depth_frames(self.depth_net, img_l, img, img_r, batched)
+            pose = self.pose_net(torch.cat([img_l, img, img_r], 1))
+            flows_bwd, flows_fwd = _flow_branches(self.fpyramid, self.pwc_model, img_l, img, img_r)
+            return disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd
+        main = torch.cuda.current_stream(img.device)
+        s_flow, s_pose = _side_streams(img.device)
+        s_flow.wait_stream(main)
+        s_pose.wait_stream(main)
+        for t in (img_l, img, img_r):
+            t.record_stream(s_flow)
+            t.record_stream(s_pose)
+        with torch.cuda.stream(s_flow):
+            flows_bwd, flows_fwd = _flow_branches(self.fpyramid, self.pwc_model, img_l, img, img_r)
+        with torch.cuda.stream(s_pose):
+            pose = self.pose_net(torch.cat([img_l, img, img_r], 1))
         disp_l, disp_t, disp_r = _depth_frames(self.depth_net, img_l, img, img_r, batched)
-        pose = self.pose_net(torch.cat([img_l, img, img_r], 1))
-        flows_bwd, flows_fwd = _flow_branches(self.fpyramid, self.pwc_model, img_l, img, img_r)
+        main.wait_stream(s_flow)
+        main.wait_stream(s_pose)
+        for t in list(flows_bwd) + list(flows_fwd) + [pose]:
+            t.record_stream(main)       # produced on a side stream, consumed by the loss stack on this one
         return disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd
 
     def forward(self, inputs):

@@ -5,7 +5,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+from .. import convs, ops
+from ..convs import Conv2d
 
 
 class PoseCNN(nn.Module):
@@ -15,24 +16,24 @@ class PoseCNN(nn.Module):
         n = 6 * (num_input_frames - 1)
         chans = [(3 * num_input_frames, 16, 7), (16, 32, 5), (32, 64, 3), (64, 128, 3), (128, 256, 3),
                  (256, 256, 3), (256, 256, 3)]
-        convs = [nn.Conv2d(ci, co, k, 2, k // 2) for ci, co, k in chans]
+        net = [Conv2d(ci, co, k, 2, k // 2) for ci, co, k in chans]
         # registration order follows the reference (pose_conv before net): parameter order is what
         # optimizer_state_dict indexes, so resumed checkpoints stay compatible
-        self.pose_conv = nn.Conv2d(256, n, 1)
+        self.pose_conv = Conv2d(256, n, 1)
         self.relu = nn.ReLU(True)
-        self.net = nn.ModuleList(convs)
+        self.net = nn.ModuleList(net)
         self.query_fc = nn.Linear(14, 14)
         self.key_fc = nn.Linear(14, 14)
         self.value_fc = nn.Linear(14, 14)
-        self.refine_net = nn.ModuleList([nn.Conv2d(2 * n, n, 1, 1, 0), nn.Conv2d(n, n, 3, 1, 1),
-                                         nn.Conv2d(n, n, 3, 1, 1), nn.Conv2d(n, n, 3, 1, 1)])
-        self.refine_pose_conv = nn.Conv2d(n, n, 1)
+        self.refine_net = nn.ModuleList([Conv2d(2 * n, n, 1, 1, 0), Conv2d(n, n, 3, 1, 1),
+                                         Conv2d(n, n, 3, 1, 1), Conv2d(n, n, 3, 1, 1)])
+        self.refine_pose_conv = Conv2d(n, n, 1)
 
     def conv_relu(self, conv, x):
         """``self.relu(conv(x))`` (pose_cnn.py:68-69, 84-85).  On the GPU the convolution runs without its bias and the bias +
         ReLU epilogue is one in-place HIP pass whose backward also yields the bias gradient (ops.bias_act, slope 0)."""
         if x.is_cuda:
-            return ops.bias_act(F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups),
+            return ops.bias_act(convs.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups),
                                 conv.bias, 0.0)
         return self.relu(conv(x))
 

@@ -7,6 +7,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from ..convs import Conv2d
 from ..structures.net_utils import ConvAct, conv, warp_flow
 
 
@@ -36,7 +37,7 @@ class PWC_tf(nn.Module):
         self.dc_conv7 = self.predict_flow(32)
 
     def predict_flow(self, in_planes):
-        return nn.Conv2d(in_planes, 2, kernel_size=3, stride=1, padding=1, bias=True)
+        return Conv2d(in_planes, 2, kernel_size=3, stride=1, padding=1, bias=True)
 
     def warp(self, x, flow):
         return warp_flow(x, flow, use_mask=False)

@@ -8,6 +8,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from ..convs import Conv2d
 
 
 class FrameBatchNorm2d(nn.BatchNorm2d):
@@ -53,10 +54,10 @@ class BasicBlock(nn.Module):
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.conv1 = Conv2d(inplanes, planes, 3, stride, 1, bias=False)
         self.bn1 = FrameBatchNorm2d(planes)
         self.relu = nn.ReLU(inplace=True)
-        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.conv2 = Conv2d(planes, planes, 3, 1, 1, bias=False)
         self.bn2 = FrameBatchNorm2d(planes)
         self.downsample = downsample
         self.stride = stride
@@ -71,7 +72,7 @@ class ResNet(nn.Module):
     def __init__(self, block, layers, num_classes=1000):
         super().__init__()
         self.inplanes = 64
-        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.conv1 = Conv2d(3, 64, 7, 2, 3, bias=False)
         self.bn1 = FrameBatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = StemMaxPool(3, 2, 1)
@@ -91,7 +92,7 @@ class ResNet(nn.Module):
     def _make_layer(self, block, planes, blocks, stride=1):
         down = None
         if stride != 1 or self.inplanes != planes * block.expansion:
-            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
+            down = nn.Sequential(Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
                                  FrameBatchNorm2d(planes * block.expansion))
         layers = [block(self.inplanes, planes, stride, down)]
         self.inplanes = planes * block.expansion

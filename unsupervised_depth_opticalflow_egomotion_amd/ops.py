@@ -10,7 +10,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, convs
 from ._lib import check, f32c, get_lib, ptr, stream_ptr
 
 _ALIGN_CORNERS = False
@@ -609,17 +609,18 @@ class DenseDecodeFn(torch.autograd.Function):
             check(lib.dfe_bias_act_fwd2(ptr(z), ptr(b[k]), p1, d1.stride(0), p2, d2.stride(0) if d2 is not None else 0,
                                         B, c, H, W, slope, st), "dfe_bias_act_fwd2")
 
-        z0 = F.conv2d(x, w[0], None, 1, 1)
+        z0 = convs.raw_forward(x, w[0], 1, 1)
         epilogue(z0, 0, z0, 0, cat[0], 0)                                   # x0: in place (conv_1's input) + cat0[:, :128]
-        z = F.conv2d(z0, w[1], None, 1, 1)
+        z = convs.raw_forward(z0, w[1], 1, 1)
         epilogue(z, 1, cat[0], co[0], cat[1], 0)                            # x1
-        z = F.conv2d(cat[0], w[2], None, 1, 1)
+        z = convs.raw_forward(cat[0], w[2], 1, 1)
         epilogue(z, 2, cat[1], co[1], cat[2], 0)                            # x2
-        z = F.conv2d(cat[1], w[3], None, 1, 1)
+        z = convs.raw_forward(cat[1], w[3], 1, 1)
         epilogue(z, 3, cat[2], co[2], cat[3], 0)                            # x3
-        x4 = F.conv2d(cat[2], w[4], None, 1, 1)
+        x4 = convs.raw_forward(cat[2], w[4], 1, 1)
         epilogue(x4, 4, x4, 0, cat[3], co[3])                               # x4: in place (returned) + cat3[:, 64:]
-        flow = F.conv2d(cat[3], w[5], b[5], 1, 1)
+        flow = F.conv2d(cat[3], w[5], b[5], 1, 1) if convs.get_compute_dtype() is None else \
+            convs.raw_forward(cat[3], w[5], 1, 1) + b[5].view(1, -1, 1, 1)
         ctx.save_for_backward(x, z0, *cat, *w)
         ctx.slope, ctx.co = slope, co
         ctx.set_materialize_grads(False)
@@ -638,10 +639,8 @@ class DenseDecodeFn(torch.autograd.Function):
         need = ctx.needs_input_grad          # (slope, x, w0, b0, ..., wp, bp)
         nw = lambda k: bool(need[2 + 2 * k])
         nb = lambda k: bool(need[3 + 2 * k])
-        conv_bwd = torch.ops.aten.convolution_backward
-
         def cb(g, inp, wt, want_in, want_w, bias_sizes=None, want_b=False):
-            return conv_bwd(g, inp, wt, bias_sizes, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [want_in, want_w, want_b])
+            return convs.raw_backward(g, inp, wt, 1, 1, 1, want_in, want_w, want_b)
 
         def epilogue_bwd(k, ysrc, y_off, g1, g1_off, g2, g2_off):
             c = co[k]
@@ -803,7 +802,7 @@ class ThinConv3x3Fn(torch.autograd.Function):
     def forward(ctx, p, weight):
         ctx.save_for_backward(p, weight)
         if not ThinConv3x3Fn._mfma_passes(p, weight):
-            return torch.nn.functional.conv2d(p, weight)
+            return convs.raw_forward(p, weight)
         lib = get_lib()
         weight = f32c(weight)
         B, Ci, Hp, Wp = p.shape
@@ -825,8 +824,7 @@ class ThinConv3x3Fn(torch.autograd.Function):
                 check(lib.dfe_thin_conv3x3(ptr(gy), ptr(f32c(weight)), ptr(gp), B, Co, Ci, H, W, 2, 1, stream_ptr()),
                       "dfe_thin_conv3x3 (data gradient)")
             else:
-                gp = torch.ops.aten.convolution_backward(gy, p, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
-                                                         [True, False, False])[0]
+                gp = convs.raw_backward(gy, p, weight, 1, 0, 1, True, False)[0]
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(weight)
             part = torch.empty(lib.dfe_wgrad3x3_partials_floats(B, Ci, Co, H, W), device=p.device)
@@ -847,4 +845,4 @@ def conv3x3_valid(p, weight):
     """3x3 convolution without padding or bias of a pre-padded activation (the decoder's ConvBlock convolutions)."""
     if thin_conv3x3_eligible(p, weight):
         return ThinConv3x3Fn.apply(p, weight)
-    return torch.nn.functional.conv2d(p, weight)
+    return convs.conv2d(p, weight)

@@ -3,7 +3,7 @@ conv :7-11, deconv :13-14).  warp_flow runs the HIP kernel k_warp_flow_fwd/bwd."
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+from .. import convs, ops
 
 
 class ConvAct(nn.Sequential):
@@ -15,7 +15,7 @@ class ConvAct(nn.Sequential):
         if not x.is_cuda:
             return super().forward(x)
         c = self[0]
-        z = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
+        z = convs.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
         return ops.bias_act(z, c.bias, self[1].negative_slope)
 
 
