@@ -493,7 +493,7 @@ __device__ __forceinline__ void fs_grad(const FRow& r, const FT& t0, const FT& t
 }
 
 __global__ void __launch_bounds__(64) k_geom_flow_smooth_bwd(GeomDev D, GeomBwd G) {
-  const unsigned unit = blockIdx.x;
+  const unsigned unit = xcd_swizzle(blockIdx.x, D.rollb_start[D.S]);    // halo-sharing neighbours on one XCD (see k_geom_flow_smooth_fwd)
   const int b = blockIdx.y;
   const int s = find_scale(D.rollb_start, D.S, unit);
   const int H = D.H[s], W = D.W[s], N = D.N[s];
@@ -605,7 +605,8 @@ template <int NS>
 __global__ void __launch_bounds__(64) k_geom_disp_smooth_bwd1(GeomDev D, GeomBwd G, int strips) {
   const int f = blockIdx.y / D.B, b = blockIdx.y - f * D.B;
   const int H = D.H[0], W = D.W[0], N = D.N[0];
-  const int strip = blockIdx.x % strips, rb = blockIdx.x / strips;
+  const unsigned unit = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int strip = unit % strips, rb = unit / strips;
   const int x = strip * RS_COLS + static_cast<int>(threadIdx.x) - 1, xc = min(max(x, 0), W - 1);
   const int y0 = rb * DSM_ROWS, yend = min(y0 + DSM_ROWS, H), ys = max(y0 - 1, 0);
   const float* im = D.pyr[f][0] + static_cast<long>(b) * 3 * N;

@@ -177,7 +177,7 @@ __device__ __forceinline__ void load2(const float* __restrict__ row, int x0, int
 __global__ void k_geom_pyramids(PyrJobs jobs) {
   const PyrJob jb = jobs.j[blockIdx.y];
   const long n = static_cast<long>(jobs.planes) * jb.outH * jb.outW;
-  const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const long i = static_cast<long>(xcd_swizzle(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;   // output rows share input rows: keep neighbours on one XCD
   if (i >= n) return;
   const int ox = static_cast<int>(i % jb.outW), oy = static_cast<int>((i / jb.outW) % jb.outH);
   const long pl = i / (static_cast<long>(jb.outW) * jb.outH);
@@ -716,7 +716,10 @@ __device__ __forceinline__ void fs_terms(const FRow& r0, const FRow& r1, const F
 __global__ void __launch_bounds__(64) k_geom_flow_smooth_fwd(GeomDev D, float* __restrict__ fpart) {
   __shared__ float red[4 * 4];
   const unsigned nunit_total = D.fs_start[D.S];
-  const unsigned unit = blockIdx.x;
+  // XCD-aware unit order: neighbouring strips / row blocks re-read each other's halo rows and share 128-byte lines
+  // (62-column strips are not line-aligned); dealt round-robin over the 8 XCDs they missed in 8 different L2s and the
+  // fabric saw 2.3x the algorithmic bytes (profiles/r03_fetch_calib.md: the same shape re-fetches 1.9x)
+  const unsigned unit = xcd_swizzle(blockIdx.x, nunit_total);
   const int b = blockIdx.y;
   const int s = find_scale(D.fs_start, D.S, unit);
   const int H = D.H[s], W = D.W[s], N = D.N[s];
@@ -758,7 +761,8 @@ __global__ void __launch_bounds__(64) k_geom_disp_smooth_fwd(GeomDev D, float* _
   __shared__ float red[2 * 4];
   const int f = blockIdx.y / D.B, b = blockIdx.y - f * D.B;
   const int H = D.H[0], W = D.W[0], N = D.N[0];
-  const int strip = blockIdx.x % strips, rb = blockIdx.x / strips;
+  const unsigned unit = xcd_swizzle(blockIdx.x, gridDim.x);      // neighbouring strips / row blocks on one XCD (see k_geom_flow_smooth_fwd)
+  const int strip = unit % strips, rb = unit / strips;
   const int x = strip * RS_COLS + static_cast<int>(threadIdx.x), xc = min(x, W - 1);
   const int y0 = rb * DSM_ROWS, yend = min(y0 + DSM_ROWS, H);
   const float* im = D.pyr[f][0] + static_cast<long>(b) * 3 * N;
@@ -807,7 +811,7 @@ __global__ void __launch_bounds__(64) k_geom_disp_smooth_fwd(GeomDev D, float* _
     }
     c0 = e0; c1 = e1; c2 = e2;
   }
-  block_sum<2>(acc, red, dpart + (static_cast<long>(blockIdx.y) * gridDim.x + blockIdx.x) * 2);
+  block_sum<2>(acc, red, dpart + (static_cast<long>(blockIdx.y) * gridDim.x + unit) * 2);
 }
 
 // ---------------------------------------------------------------------- finalize
