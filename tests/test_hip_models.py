@@ -374,13 +374,32 @@ def _three_steps(net_streams=1, amp=None, B=2):
 
 
 def test_network_streams_do_not_change_results():
-    """Model_geometry.run_networks with the flow / pose nets on side streams (net_streams = 3): the same kernels in
-    the same order inside every net, so losses and gradients of three steps equal the single-stream run's to the
-    atomics' noise (warp_flow's feature-gradient scatter is the one non-deterministic kernel of the step)."""
-    l1, g1 = _three_steps(1)
-    l3, g3 = _three_steps(3)
+    """Model_geometry.run_networks with the flow / pose nets on side streams (net_streams = 3) runs the same kernels in the
+    same order inside every net.  The step is not bitwise reproducible even on one stream (MIOpen's split-K weight
+    gradients and warp_flow's feature-gradient scatter use float atomics), so the yardstick is the run-to-run noise of the
+    single-stream step itself: after ONE step the two-stream gradients may differ from a single-stream run by no more than
+    a few times what two single-stream runs differ by, and three-step losses agree to 2e-5."""
+    def one_step(streams):
+        from unsupervised_depth_opticalflow_egomotion_amd.train_step import make_cfg, total_loss
+        from unsupervised_depth_opticalflow_egomotion_amd.models import get_model
+        cfg = make_cfg()
+        torch.manual_seed(0)
+        model = get_model("geom")(cfg).to(dev()).train()
+        model.net_streams = streams
+        inputs = [torch.from_numpy(a).to(dev()) for a in synthetic.make_triplet_batch(2, 256, 832, 3, seed=1)]
+        lp, _ = model(inputs)
+        total_loss(lp, cfg).backward()
+        torch.cuda.synchronize()
+        return torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
+    a, a2, b = one_step(1), one_step(1), one_step(3)
+    scale = float(a.abs().max())
+    noise = float((a2 - a).abs().max())
+    diff = float((b - a).abs().max())
+    print("\nstreams: grad scale %.3e, single-stream run-to-run %.3e, 3 streams vs 1 %.3e" % (scale, noise, diff))
+    assert diff <= max(4.0 * noise, 2e-6 * scale), (diff, noise, scale)
+    l1, _ = _three_steps(1)
+    l3, _ = _three_steps(3)
     np.testing.assert_allclose(l3, l1, rtol=2e-5)
-    assert float((g3 - g1).abs().max()) <= 1e-4 * float(g1.abs().max())
 
 
 def test_amp_bf16_mode_is_opt_in_and_close_to_fp32():
@@ -437,6 +456,11 @@ def test_bench_two_ranks_on_one_gpu(mode):
     j = _bench_json(subprocess.run(cmd, capture_output=True, text=True, cwd=repo, env=env, timeout=900))
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["config"]["global_batch"] == 4
     assert j["value"] > 0 and "roofline" in j and "cpu_baseline" not in j   # CPU baseline only at N=1
+    # the N > 1 line carries its own evidence that the replicas exchanged gradients (bench.multi_gpu_evidence)
+    mg = j["multi_gpu"]
+    assert mg["backend"] == "gloo" and mg["rccl_ranks"] == 2 and mg["rank_id_allreduce_ok"] is True
+    assert mg["param_checksums_equal"] is True and mg["shards_differ"] is True
+    assert 0 < mg["ms_per_step_min"] <= mg["ms_per_step_max"] <= j["ms_per_step"] * 1.001 + 1e-6
 
 
 def test_bench_gpus_flag_launches_the_ranks_itself():
@@ -450,6 +474,11 @@ def test_bench_gpus_flag_launches_the_ranks_itself():
     j = _bench_json(subprocess.run(base + ["--gpus", "2", "--backend", "gloo"], capture_output=True, text=True, cwd=repo,
                                    env=dict(clean, DFE_BENCH_ALL_ON_DEVICE0="1"), timeout=900))
     assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2"
+    assert j["multi_gpu"]["rccl_ranks"] == 2 and j["multi_gpu"]["param_checksums_equal"] is True
+    # under a profiler preload the GPU is already initialised in this process: it must not start ranks
+    out = subprocess.run(base + ["--gpus", "2", "--backend", "gloo"], capture_output=True, text=True, cwd=repo,
+                         env=dict(clean, DFE_BENCH_ALL_ON_DEVICE0="1", ROCP_TOOL_LIBRARIES="/opt/rocm/lib/librocprofiler-sdk-tool.so"), timeout=300)
+    assert out.returncode == 4 and "profiler" in out.stderr
     if torch.cuda.device_count() < 2:
         out = subprocess.run(base + ["--gpus", "2"], capture_output=True, text=True, cwd=repo, env=clean, timeout=300)
         assert out.returncode != 0 and "HIP device" in out.stderr

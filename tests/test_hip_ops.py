@@ -791,33 +791,6 @@ def test_thin_conv3x3_mfma(shape):
         gclose(gp, pd.grad.float(), rel=2e-6)
 
 
-@pytest.mark.parametrize("cfg", [(2, 24, 16, 20, 36, 3, 1, 1), (2, 16, 24, 20, 36, 3, 1, 8), (1, 32, 16, 24, 40, 3, 1, 16), (2, 8, 12, 17, 23, 3, 1, 2)])
-def test_conv_algo_swaps_match_direct_convolution(cfg):
-    """convs.ALGO_SWAPS: a stride-1 "same" convolution's forward pass through MIOpen's backward-data kernel (flipped,
-    channel-transposed weights) and its data gradient through the forward kernel give the direct results (fp32
-    summation order only: 1e-5), for every dilation the table may route."""
-    from unsupervised_depth_opticalflow_egomotion_amd import convs
-    B, ci, co, H, W, k, s, d = cfg
-    torch.manual_seed(3)
-    x = torch.randn(B, ci, H, W, device=dev(), requires_grad=True)
-    w = (0.1 * torch.randn(co, ci, k, k, device=dev())).requires_grad_(True)
-    b = torch.randn(co, device=dev(), requires_grad=True)
-    r = torch.randn(B, co, H, W, device=dev())
-    y0 = torch.nn.functional.conv2d(x, w, b, s, d, d)
-    g0 = torch.autograd.grad((y0 * r).sum(), (x, w, b))
-    old = dict(convs.ALGO_SWAPS)
-    try:
-        for swaps in ((True, False), (False, True), (True, True)):
-            convs.ALGO_SWAPS[(k, d)] = swaps
-            y1 = convs.conv2d(x, w, b, s, d, d)
-            g1 = torch.autograd.grad((y1 * r).sum(), (x, w, b))
-            for a, c in zip((y1,) + g1, (y0,) + g0):
-                assert float((a - c).abs().max()) <= 1e-5 * max(float(c.abs().max()), 1.0), swaps
-    finally:
-        convs.ALGO_SWAPS.clear()
-        convs.ALGO_SWAPS.update(old)
-
-
 def test_conv_bf16_compute_dtype():
     """convs.compute_dtype(torch.bfloat16): fp32 in, fp32 out, bf16 inside -- values and gradients within bf16 rounding
     of the fp32 convolution (relative 2e-2 of the tensor's scale), parameters' gradients fp32."""

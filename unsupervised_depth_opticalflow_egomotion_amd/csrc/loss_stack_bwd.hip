@@ -12,6 +12,7 @@
 //   k_geom_pose_finalize    fixed-order reduction + closed-form 3x3 chains -> grad_pose
 // No float atomics anywhere: gradients are bitwise reproducible run to run.
 #include "loss_stack_exact.h"
+#include <cstdlib>
 
 namespace dfe {
 
@@ -539,62 +540,6 @@ __global__ void __launch_bounds__(64) k_geom_flow_smooth_bwd(GeomDev D, GeomBwd 
   }
 }
 
-// ---------------------------------------------------------------------- pose finalize
-// grad_pose of one camera (b, d) by ONE wave: per scale, lane t accumulates rows k = t (mod 64) of the 21 columns
-// (12 camera sums + 9 dF sums, the latter only at scale 0) in double; a fixed butterfly (xor 32, 16, ... 1) adds the
-// 64 lane sums -- a fixed order, so the result is bitwise reproducible -- and lane 0 runs the closed-form 3x3 chains.
-// (Round 2: a 256-thread block per camera with an LDS pass and two barriers per scale, 15 us.)  Measured and rejected in
-// round 3: running it as an extra block row of k_geom_disp_smooth_bwd1, which it does not depend on -- its 21 double
-// accumulators lift that kernel from 58 to 145 VGPRs (8 -> 3 waves per SIMD).
-__device__ __forceinline__ double wave_xor_add(double v, int m) {
-  const int lo = __shfl_xor(__double2loint(v), m), hi = __shfl_xor(__double2hiint(v), m);
-  return v + __hiloint2double(hi, lo);
-}
-
-__device__ void pose_finalize_wave(const GeomDev& D, const GeomBwd& G, float* __restrict__ gpose, int cam) {
-  const int b = cam >> 1, d = cam & 1, S = D.S, t = threadIdx.x & 63;
-  const unsigned nblk_total = D.blk_start[S];
-  double g[6] = {0, 0, 0, 0, 0, 0}, gR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int s = 0; s < S; ++s) {
-    double a[PB_PER_DIR];
-#pragma unroll
-    for (int i = 0; i < PB_PER_DIR; ++i) a[i] = 0.0;
-    for (int k = D.blk_start[s] + t; k < D.blk_start[s + 1]; k += 64) {
-      const float* r = G.bpart + (static_cast<long>(b) * nblk_total + k) * PB_COUNT + d * PB_PER_DIR;
-#pragma unroll
-      for (int i = 0; i < PB_PER_DIR; ++i) a[i] += r[i];
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-#pragma unroll
-      for (int i = 0; i < PB_PER_DIR; ++i) a[i] = wave_xor_add(a[i], m);
-    const Camera& c = D.cams[cam * S + s];
-    for (int j = 0; j < 3; ++j) g[j] += c.K[j] * a[0] + c.K[3 + j] * a[1] + c.K[6 + j] * a[2];
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) gR[i * 3 + j] += c.K[i] * a[3 + j] + c.K[3 + i] * a[6 + j] + c.K[6 + i] * a[9 + j];
-    if (s == 0)
-      for (int i = 0; i < 9; ++i) gF[i] = a[12 + i];
-  }
-  if (t != 0) return;
-  const Camera& c0 = D.cams[cam * S];
-  if (D.mode == 0) {
-    // epipolar: F = Ki^T E Ki, E = S R
-    const Epi& e = D.epi[cam];
-    double T[9], gE[9];
-    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) T[r * 3 + q] = e.Kinv[r * 3] * gF[q] + e.Kinv[r * 3 + 1] * gF[3 + q] + e.Kinv[r * 3 + 2] * gF[6 + q];
-    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) gE[r * 3 + q] = T[r * 3] * e.Kinv[q * 3] + T[r * 3 + 1] * e.Kinv[q * 3 + 1] + T[r * 3 + 2] * e.Kinv[q * 3 + 2];
-    double gS[9];
-    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) {
-      double aa = 0, bq = 0;
-      for (int k = 0; k < 3; ++k) { aa += e.S[k * 3 + r] * gE[k * 3 + q]; bq += gE[r * 3 + k] * c0.R[q * 3 + k]; }
-      gR[r * 3 + q] += aa; gS[r * 3 + q] = bq;
-    }
-    g[0] += gS[7] - gS[5]; g[1] += gS[2] - gS[6]; g[2] += gS[3] - gS[1];
-  }
-  for (int k = 0; k < 3; ++k) { double tt = 0; for (int i = 0; i < 9; ++i) tt += gR[i] * c0.dR[k * 9 + i]; g[3 + k] += tt; }
-  for (int i = 0; i < 6; ++i) gpose[cam * 6 + i] = static_cast<float>(g[i]);
-}
-
 // ---------------------------------------------------------------------- disparity smoothness backward
 // stage 1: per full-resolution pixel, dL/d(up_s(p)) for every scale.  Rolling wave kernel like
 // k_geom_disp_smooth_fwd (lanes 1..62 valid: x-1 and x+1 come from DPP wave shifts).  With
@@ -709,7 +654,71 @@ __device__ __forceinline__ float adj_pow2(const float* __restrict__ gu, int W, i
   return total;
 }
 
-__global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_bwd2(GeomDev D, GeomBwd G) {
+// Rolling form of the same adjoint for the INTERIOR low-res pixels of an exact 1/NR pyramid level (NR = 2, 4): a wave
+// owns 64 full-resolution columns and marches down the rows, reading every up-sampled gradient ONCE with one coalesced
+// dword per lane (the thread-per-low-res-pixel gather above requests every value four times through strided loads:
+// 16 / 32 vector-memory instructions per output).  Horizontal tent sums by DPP wave shifts -- valid at every NR-th
+// lane --, vertical tent sums in two rolling accumulators (a full-res row feeds the lower half of one output row and the
+// upper half of the previous one).  Same taps, weights and summation order as adj_pow2: bit-identical results.
+// grid: x = strips x row blocks, y = f*B + b; block = one wave; one launch per eligible scale.
+constexpr int DSR_OUT_ROWS = 8;      // low-res output rows per wave
+
+template <int NR>
+__global__ void __launch_bounds__(64) k_geom_disp_smooth_bwd2_roll(GeomDev D, GeomBwd G, int s, int strips) {
+  constexpr int NT = 2 * NR, NJ = 64 / NR - 1;
+  const int f = blockIdx.y / D.B, b = blockIdx.y - f * D.B;
+  if (!G.gdisp[f][s]) return;
+  const unsigned unit = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int strip = unit % strips, rbk = unit / strips;
+  const int Hs = D.H[s], Ws = D.W[s], Ns = D.N[s], W = D.W[0], N = D.N[0];
+  const int lane = threadIdx.x;
+  const int J0 = 1 + strip * NJ, I0 = 1 + rbk * DSR_OUT_ROWS;
+  const int I1 = min(I0 + DSR_OUT_ROWS, Hs - 1);                 // interior rows [I0, I1)
+  const int x = min(NR * J0 - NR / 2 + lane, W - 1);              // clamped: lanes past the image feed no valid output
+  const int j = J0 + lane / NR;
+  const bool out_lane = (lane % NR == 0) && (lane / NR < NJ) && j <= Ws - 2;
+  const float* gu = G.gup + ((static_cast<long>(f) * (D.S - 1) + (s - 1)) * D.B + b) * N + x;
+  float* o = G.gdisp[f][s] + static_cast<long>(b) * Ns + j;
+  const bool rmw = f == 1 || G.rmw_all;
+  float w[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) w[k] = (k < NR) ? (2.0f * k + 1.0f) / (2.0f * NR) : (2.0f * (NT - 1 - k) + 1.0f) / (2.0f * NR);
+  // rows y = NR * i - NR/2 + ky; group r holds the NR rows NR * i' - NR/2 .. + NR - 1 with i' = I0 + r (r = 0 .. I1-I0)
+  auto load_group = [&](int ip, float (&v)[NR]) {
+    const int y0 = NR * ip - NR / 2;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) v[k] = gu[static_cast<long>(y0 + k) * W];
+  };
+  float cur = 0.0f, nxt = 0.0f;
+  float g[NR], gn[NR];
+  load_group(I0, g);
+  const int ngroups = I1 - I0 + 1;           // the last group only completes output I1 - 1
+  for (int r = 0; r < ngroups; ++r) {
+    const int ip = I0 + r;
+    if (r + 1 < ngroups) load_group(ip + 1, gn);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      // horizontal tent sum starting at this lane: acc = sum_kx w[kx] * g(lane + kx), kx ascending
+      float sh = g[k], acc = 0.0f;
+#pragma unroll
+      for (int kx = 0; kx < NT; ++kx) {
+        acc += w[kx] * sh;
+        if (kx + 1 < NT) sh = wave_shl1(sh);
+      }
+      cur += w[k + NR] * acc;               // output row ip - 1, taps NR .. 2NR-1
+      nxt += w[k] * acc;                    // output row ip, taps 0 .. NR-1
+    }
+    if (r > 0 && out_lane) {                // output row ip - 1 is complete
+      float* dst = o + static_cast<long>(ip - 1) * Ws;
+      if (rmw) *dst += cur; else *dst = cur;
+    }
+    cur = nxt; nxt = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) g[k] = gn[k];
+  }
+}
+
+__global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_bwd2(GeomDev D, GeomBwd G, int roll_mask) {
   const unsigned blk = blockIdx.x + D.blk_start[1];
   const int f = blockIdx.y / D.B, b = blockIdx.y - f * D.B;
   const int s = find_scale(D.blk_start, D.S, blk);
@@ -736,6 +745,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_bwd2(GeomDev D, G
   float* o = G.gdisp[f][s] + static_cast<long>(b) * Ns + static_cast<long>(i) * Ws + j;
   const int nr = H / Hs;
   if ((nr == 2 || nr == 4) && Hs * nr == H && Ws * nr == W && i >= 1 && i < Hs - 1 && j >= 1 && j < Ws - 1) {
+    if (roll_mask & (1 << s)) return;          // k_geom_disp_smooth_bwd2_roll owns the interior of this scale
     const float t = nr == 2 ? adj_pow2<2>(gu, W, 2 * i - 1, 2 * j - 1) : adj_pow2<4>(gu, W, 4 * i - 2, 4 * j - 2);
     if (f == 1 || G.rmw_all) *o += t; else *o = t;
     return;
@@ -873,8 +883,66 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_bwd2_coarse(GeomD
   }
 }
 
-__global__ void __launch_bounds__(64) k_geom_pose_finalize(GeomDev D, GeomBwd G, float* __restrict__ gpose) {
-  pose_finalize_wave(D, G, gpose, blockIdx.x);
+// ---------------------------------------------------------------------- pose finalize
+// (Measured and rejected in round 3: one wave per camera with a shuffle butterfly instead of the LDS pass -- 16.7 us against
+// 15.0; and running it as an extra block row of k_geom_disp_smooth_bwd1 -- its 21 double accumulators lift that kernel from
+// 58 to 145 VGPRs.)
+// One 256-thread block per (b, d).  Per scale, thread t accumulates rows k = t (mod 256) of the 21
+// columns (12 camera sums + 9 dF sums, the latter only at scale 0) in double; one thread per column
+// then adds the 256 per-thread sums in thread order (fixed order -> reproducible).
+__global__ void __launch_bounds__(256) k_geom_pose_finalize(GeomDev D, GeomBwd G, float* __restrict__ gpose) {
+  __shared__ double lds[256][PB_PER_DIR + 1];
+  __shared__ double sm[DFE_MAX_SCALES * 12 + 9];
+  const int cam = blockIdx.x, b = cam >> 1, d = cam & 1, S = D.S, t = threadIdx.x;
+  const unsigned nblk_total = D.blk_start[S];
+  for (int s = 0; s < S; ++s) {
+    double a[PB_PER_DIR];
+#pragma unroll
+    for (int i = 0; i < PB_PER_DIR; ++i) a[i] = 0.0;
+    for (int k = D.blk_start[s] + t; k < D.blk_start[s + 1]; k += 256) {
+      const float* r = G.bpart + (static_cast<long>(b) * nblk_total + k) * PB_COUNT + d * PB_PER_DIR;
+#pragma unroll
+      for (int i = 0; i < PB_PER_DIR; ++i) a[i] += r[i];
+    }
+#pragma unroll
+    for (int i = 0; i < PB_PER_DIR; ++i) lds[t][i] = a[i];
+    __syncthreads();
+    if (t < PB_PER_DIR) {
+      double v = 0.0;
+      for (int k = 0; k < 256; ++k) v += lds[k][t];
+      if (t < 12) sm[s * 12 + t] = v;
+      else if (s == 0) sm[S * 12 + (t - 12)] = v;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double g[6] = {0, 0, 0, 0, 0, 0}, gR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int s = 0; s < S; ++s) {
+    const double* acc = sm + s * 12;
+    const Camera& c = D.cams[cam * S + s];
+    for (int j = 0; j < 3; ++j) g[j] += c.K[j] * acc[0] + c.K[3 + j] * acc[1] + c.K[6 + j] * acc[2];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) gR[i * 3 + j] += c.K[i] * acc[3 + j] + c.K[3 + i] * acc[6 + j] + c.K[6 + i] * acc[9 + j];
+  }
+  const Camera& c0 = D.cams[cam * S];
+  if (D.mode == 0) {
+  // epipolar: F = Ki^T E Ki, E = S R
+  const Epi& e = D.epi[cam];
+  const double* gF = sm + S * 12;
+  double T[9], gE[9];
+  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) T[r * 3 + q] = e.Kinv[r * 3] * gF[q] + e.Kinv[r * 3 + 1] * gF[3 + q] + e.Kinv[r * 3 + 2] * gF[6 + q];
+  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) gE[r * 3 + q] = T[r * 3] * e.Kinv[q * 3] + T[r * 3 + 1] * e.Kinv[q * 3 + 1] + T[r * 3 + 2] * e.Kinv[q * 3 + 2];
+  double gS[9];
+  for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) {
+    double a = 0, bq = 0;
+    for (int k = 0; k < 3; ++k) { a += e.S[k * 3 + r] * gE[k * 3 + q]; bq += gE[r * 3 + k] * c0.R[q * 3 + k]; }
+    gR[r * 3 + q] += a; gS[r * 3 + q] = bq;
+  }
+  g[0] += gS[7] - gS[5]; g[1] += gS[2] - gS[6]; g[2] += gS[3] - gS[1];
+  }
+  for (int k = 0; k < 3; ++k) { double t = 0; for (int i = 0; i < 9; ++i) t += gR[i] * c0.dR[k * 9 + i]; g[3 + k] += t; }
+  for (int i = 0; i < 6; ++i) gpose[cam * 6 + i] = static_cast<float>(g[i]);
 }
 
 }  // namespace dfe
@@ -968,8 +1036,24 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   DFE_LAUNCH_CHECK();
   DFE_MARK();
   if (L.S > 1) {
-    k_geom_disp_smooth_bwd2<<<dim3(nblk_total - L.blk_start[1], 3 * L.B), GS_BLOCK, 0, st>>>(D, G);
+    // exact 1/2 and 1/4 levels: interior by the rolling kernel, the border ring (clamped taps) by the gather kernel
+    int roll_mask = 0;
+    if (getenv("DFE_DSM_BWD2_GATHER") == nullptr)
+      for (int s = 1; s < L.S; ++s) {
+        const int nr = L.H[0] / L.H[s];
+        if ((nr == 2 || nr == 4) && L.H[s] * nr == L.H[0] && L.W[s] * nr == L.W[0] && L.H[s] >= 3 && L.W[s] >= 3) roll_mask |= 1 << s;
+      }
+    k_geom_disp_smooth_bwd2<<<dim3(nblk_total - L.blk_start[1], 3 * L.B), GS_BLOCK, 0, st>>>(D, G, roll_mask);
     DFE_LAUNCH_CHECK();
+    for (int s = 1; s < L.S; ++s) {
+      if (!(roll_mask & (1 << s))) continue;
+      const int nr = L.H[0] / L.H[s], nj = 64 / nr - 1;
+      const int strips = (L.W[s] - 2 + nj - 1) / nj, rblocks = (L.H[s] - 2 + DSR_OUT_ROWS - 1) / DSR_OUT_ROWS;
+      const dim3 g(strips * rblocks, 3 * L.B);
+      if (nr == 2) k_geom_disp_smooth_bwd2_roll<2><<<g, 64, 0, st>>>(D, G, s, strips);
+      else k_geom_disp_smooth_bwd2_roll<4><<<g, 64, 0, st>>>(D, G, s, strips);
+      DFE_LAUNCH_CHECK();
+    }
     // scales coarser than 1/4 (H_s = int(H / 2^s), so the ratio is 2^s or slightly above): wave-per-pixel gather
     int s0 = 1;
     while (s0 < L.S && L.H[0] <= 4 * L.H[s0] && L.W[0] <= 4 * L.W[s0]) ++s0;
@@ -982,7 +1066,7 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   }
   DFE_MARK();
   if (a->grad_pose) {
-    k_geom_pose_finalize<<<L.B * 2, 64, 0, st>>>(D, G, a->grad_pose);
+    k_geom_pose_finalize<<<L.B * 2, 256, 0, st>>>(D, G, a->grad_pose);
     DFE_LAUNCH_CHECK();
   }
   DFE_MARK();

@@ -177,7 +177,7 @@ __device__ __forceinline__ void load2(const float* __restrict__ row, int x0, int
 __global__ void k_geom_pyramids(PyrJobs jobs) {
   const PyrJob jb = jobs.j[blockIdx.y];
   const long n = static_cast<long>(jobs.planes) * jb.outH * jb.outW;
-  const long i = static_cast<long>(xcd_swizzle(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;   // output rows share input rows: keep neighbours on one XCD
+  const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;     // (an XCD-swizzled block order was measured: 19.5 -> 30 us)
   if (i >= n) return;
   const int ox = static_cast<int>(i % jb.outW), oy = static_cast<int>((i / jb.outW) % jb.outH);
   const long pl = i / (static_cast<long>(jb.outW) * jb.outH);
@@ -515,6 +515,135 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, GeomT T,
   if (DT) block_sum<2>(dc, red, part2 + (static_cast<long>(b) * nblk_total + blk) * 2);
 }
 
+// Two horizontally adjacent pixels per thread (all W_s even): the 14 streamed loads and the 7 stores of a pixel become
+// 8-byte accesses shared by the pair (21 -> 10.5 vector-memory instructions per pixel; the 24 gathers stay), and the two
+// independent per-pixel chains interleave in one instruction stream.  A block is still one 256-pixel segment (128
+// threads), so the partial-sum layout and everything downstream is unchanged.  Selected at run time by
+// dfe_geom_loss_fwd when every scale has an even width; same arithmetic per pixel, block sums add the pair first.
+struct __attribute__((aligned(8))) F2a { float a, b; };
+__device__ __forceinline__ F2a ldb2(const float* __restrict__ base, unsigned byte_off) {
+  return *reinterpret_cast<const F2a*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void stb2(float* __restrict__ base, unsigned byte_off, float v0, float v1) {
+  *reinterpret_cast<F2a*>(reinterpret_cast<char*>(base) + byte_off) = F2a{v0, v1};
+}
+
+#ifndef DFE_PF2_WAVES
+#define DFE_PF2_WAVES 3      // minimum waves per SIMD asked of the register allocator (tuning switch)
+#endif
+template <bool DT>
+__global__ void __launch_bounds__(GS_BLOCK / 2, DFE_PF2_WAVES) k_geom_point_fwd2(GeomDev D, GeomT T, float* __restrict__ part, float* __restrict__ part2) {
+  constexpr int NW = GS_BLOCK / 128;          // waves per block
+  __shared__ float red[PT_COUNT * 4 * NW + 16];
+  const unsigned nblk_total = D.blk_start[D.S];
+  const unsigned blk = xcd_swizzle(blockIdx.x, nblk_total);
+  const int b = blockIdx.y;
+  const int s = find_scale(D.blk_start, D.S, blk);
+  const int H = D.H[s], W = D.W[s], N = D.N[s];
+  const unsigned p = (blk - D.blk_start[s]) * GS_BLOCK + 2u * threadIdx.x;
+  float acc[2][PT_COUNT];
+#pragma unroll
+  for (int i = 0; i < PT_COUNT; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
+  float dc[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+  if (p < static_cast<unsigned>(N)) {          // N even: the pair is either inside or outside
+    unsigned px, py;
+    split_pixel(p, W, T.rW[s], px, py);
+    const unsigned p4 = p * 4u, N4 = static_cast<unsigned>(N) * 4u;
+    PointCtx c;
+    c.b = b; c.s = s; c.H = H; c.W = W; c.ac = D.ac; c.N4 = N4; c.p4 = p4; c.alpha = D.alpha; c.beta = D.beta;
+    c.srcL = D.pyr[0][s] + static_cast<long>(b) * 3 * N; c.srcR = D.pyr[2][s] + static_cast<long>(b) * 3 * N;
+    c.areaL = D.area[0][s] + static_cast<long>(b) * 3 * N; c.areaR = D.area[1][s] + static_cast<long>(b) * 3 * N;
+    c.cam = D.cams + (b * 2) * D.S + s; c.cam_stride = D.S; c.epi = D.epi + b * 2;
+    c.dw = T.dw[s]; c.dh = T.dh[s];
+    c.dispL = D.disp[0][s] + static_cast<long>(b) * N; c.dispR = D.disp[2][s] + static_cast<long>(b) * N;
+    const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
+    const float* flb = D.flow[0][s] + static_cast<long>(b) * 2 * N;
+    const float* flf = D.flow[1][s] + static_cast<long>(b) * 2 * N;
+    const F2a i0 = ldb2(it, p4), i1 = ldb2(it, p4 + N4), i2 = ldb2(it, p4 + 2 * N4);
+    const F2a u0 = ldb2(flb, p4), v0 = ldb2(flb, p4 + N4), u1 = ldb2(flf, p4), v1 = ldb2(flf, p4 + N4);
+    const F2a ds = ldb2(D.disp[1][s] + static_cast<long>(b) * N, p4);
+    const F2a l0 = ldb2(c.srcL, p4), l1 = ldb2(c.srcL, p4 + N4), l2 = ldb2(c.srcL, p4 + 2 * N4);
+    const F2a r0 = ldb2(c.srcR, p4), r1 = ldb2(c.srcR, p4 + N4), r2 = ldb2(c.srcR, p4 + 2 * N4);
+    PixIn inA, inB;
+    inA.i0 = i0.a; inA.i1 = i1.a; inA.i2 = i2.a; inB.i0 = i0.b; inB.i1 = i1.b; inB.i2 = i2.b;
+    inA.fu[0] = u0.a; inA.fv[0] = v0.a; inA.fu[1] = u1.a; inA.fv[1] = v1.a;
+    inB.fu[0] = u0.b; inB.fv[0] = v0.b; inB.fu[1] = u1.b; inB.fv[1] = v1.b;
+    inA.dsp = ds.a; inB.dsp = ds.b;
+    inA.sl[0] = l0.a; inA.sl[1] = l1.a; inA.sl[2] = l2.a; inB.sl[0] = l0.b; inB.sl[1] = l1.b; inB.sl[2] = l2.b;
+    inA.sr[0] = r0.a; inA.sr[1] = r1.a; inA.sr[2] = r2.a; inB.sr[0] = r0.b; inB.sr[1] = r1.b; inB.sr[2] = r2.b;
+    float ywA[2][3], ywB[2][3], yrA[2][3], yrB[2][3];
+    unsigned bitsA, bitsB;
+    point_pixel<DT>(c, static_cast<int>(px), static_cast<int>(py), inA, ywA, bitsA, acc[0], yrA, dc[0]);
+    c.p4 = p4 + 4u;
+    point_pixel<DT>(c, static_cast<int>(px) + 1, static_cast<int>(py), inB, ywB, bitsB, acc[1], yrB, dc[1]);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      float* ywp = D.yw[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) stb2(ywp, p4 + ch * N4, ywA[d][ch], ywB[d][ch]);
+      if (DT && (D.dt & DFE_DEPTH_TERM_SSIM)) {
+        float* yrp = D.yr[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) stb2(yrp, p4 + ch * N4, yrA[d][ch], yrB[d][ch]);
+      }
+    }
+    *reinterpret_cast<unsigned short*>(D.mask[s] + static_cast<long>(b) * N + p) = static_cast<unsigned short>(bitsA | (bitsB << 8));
+  }
+  // block sums: float entries add the pair, then the DPP tree; {0,1} entries are two population counts
+  constexpr int NF = 11, NC = 9;
+  constexpr int FI[NF] = {PT_L1_DEPTH, PT_L1_RIG, PT_L1_DYN, PT_FDIFF, PT_EPI,
+                          PT_PER_DIR + PT_L1_DEPTH, PT_PER_DIR + PT_L1_RIG, PT_PER_DIR + PT_L1_DYN, PT_PER_DIR + PT_FDIFF,
+                          PT_PER_DIR + PT_EPI, PT_CONSIS};
+  constexpr int CI[NC] = {PT_M_TEX, PT_M_RIG, PT_M_DYN, PT_M_VO, PT_PER_DIR + PT_M_TEX, PT_PER_DIR + PT_M_RIG,
+                          PT_PER_DIR + PT_M_DYN, PT_PER_DIR + PT_M_VO, PT_INV};
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float f[NF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i) f[i] = acc[0][FI[i]] + acc[1][FI[i]];
+#pragma unroll
+  for (int i = 0; i < NF; ++i) f[i] = dpp_add<0xB1>(f[i]);
+#pragma unroll
+  for (int i = 0; i < NF; ++i) f[i] = dpp_add<0x4E>(f[i]);
+#pragma unroll
+  for (int i = 0; i < NF; ++i) f[i] = dpp_add<0x141>(f[i]);
+#pragma unroll
+  for (int i = 0; i < NF; ++i) f[i] = dpp_add<0x140>(f[i]);
+  if ((lane & 15) == 0) {
+    const int slot = wave * 4 + (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < NF; ++i) red[slot * NF + i] = f[i];
+  }
+  float* cnt = red + NF * 4 * NW;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const unsigned long long m0 = __ballot(acc[0][CI[i]] != 0.0f), m1 = __ballot(acc[1][CI[i]] != 0.0f);
+    if (lane == 0) cnt[wave * NC + i] = static_cast<float>(__popcll(m0) + __popcll(m1));
+  }
+  __syncthreads();
+  float* out = part + (static_cast<long>(b) * nblk_total + blk) * PT_COUNT;
+  if (threadIdx.x < NF) {
+    float sum = 0.0f;
+    for (int w = 0; w < 4 * NW; ++w) sum += red[w * NF + threadIdx.x];
+    int dst = 0;
+#pragma unroll
+    for (int i = 0; i < NF; ++i) dst = (static_cast<int>(threadIdx.x) == i) ? FI[i] : dst;
+    out[dst] = sum;
+  } else if (threadIdx.x < NF + NC) {
+    const int t = threadIdx.x - NF;
+    float sum = 0.0f;
+    for (int w = 0; w < NW; ++w) sum += cnt[w * NC + t];
+    int dst = 0;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) dst = (t == i) ? CI[i] : dst;
+    out[dst] = sum;
+  }
+  if (DT) {
+    __syncthreads();
+    float d2[2] = {dc[0][0] + dc[1][0], dc[0][1] + dc[1][1]};
+    block_sum<2>(d2, red, part2 + (static_cast<long>(b) * nblk_total + blk) * 2);
+  }
+}
+
 // ---------------------------------------------------------------------- depth-only pointwise forward
 // Model_depth loss stack (model_depth.py:296-323): rigid recon of both sources, mask = inverse_warp2
 // validity * texture mask, masked-L1 sums.  One pixel per thread over the 1-px block table.
@@ -815,23 +944,20 @@ __global__ void __launch_bounds__(64) k_geom_disp_smooth_fwd(GeomDev D, float* _
 }
 
 // ---------------------------------------------------------------------- finalize
-// k_geom_finalize_fwd: ONE 256-thread block per sample (round 2 ran a (scale, sample) reduction grid and a second
-// one-thread-per-sample assembly launch: 7 + 9.5 us and a launch gap for < 1 MB of partials).  Per scale, phase 1:
-// thread t accumulates the partial rows k = t (mod 256) of every column in double; phase 2: one thread per column adds
-// the 256 per-thread sums in thread order.  Both orders are fixed -> bitwise reproducible.  The sums stay in LDS and
-// thread 0 forms the loss values and the normalisers the backward needs (assemble_sample).
-__device__ void assemble_sample(const GeomDev& D, int b, const float* sums, const float* dsum, const float* __restrict__ sums2,
-                                float* __restrict__ coef, float* __restrict__ losses);
-
-__global__ void __launch_bounds__(256) k_geom_finalize_fwd(GeomDev D, const float* __restrict__ part,
+// (Measured and rejected in round 3: ONE block per sample that walks the scales and assembles in place -- 23 us against
+// 7 + 9 us for the two launches below: the per-scale passes are latency chains that the (scale, sample) grid runs side by side.)
+// k_geom_reduce_fwd: one 256-thread block per (scale, sample) plus one per sample for the disparity-smoothness
+// sums.  Phase 1: thread t accumulates the partial rows k = t (mod 256) of every column in double; phase 2: one
+// thread per column adds the 256 per-thread sums in thread order.  Both orders are fixed -> bitwise
+// reproducible.  k_geom_assemble_fwd (one thread per sample) then forms the eight loss values and the
+// normalisers the backward needs.
+__global__ void __launch_bounds__(256) k_geom_reduce_fwd(GeomDev D, const float* __restrict__ part,
                                     const float* __restrict__ spart, const float* __restrict__ fpart,
-                                    const float* __restrict__ dpart, int ndunit, const float* __restrict__ sums2,
-                                    float* __restrict__ sums_out, float* __restrict__ coef, float* __restrict__ losses) {
+                                    const float* __restrict__ dpart, int ndunit, float* __restrict__ sums,
+                                    float* __restrict__ dsum) {
   __shared__ double lds[256][SUM_COUNT + 1];
-  __shared__ float s_sums[DFE_MAX_SCALES * SUM_COUNT];
-  __shared__ float s_dsum[6];
-  const int b = blockIdx.x, S = D.S, B = D.B, t = threadIdx.x;
-  for (int s = 0; s < S; ++s) {
+  const int s = blockIdx.x, b = blockIdx.y, S = D.S, B = D.B, t = threadIdx.x;
+  if (s < S) {
     double a[SUM_COUNT];
 #pragma unroll
     for (int i = 0; i < SUM_COUNT; ++i) a[i] = 0.0;
@@ -859,12 +985,9 @@ __global__ void __launch_bounds__(256) k_geom_finalize_fwd(GeomDev D, const floa
     if (t < SUM_COUNT) {
       double v = 0.0;
       for (int k = 0; k < 256; ++k) v += lds[k][t];
-      s_sums[s * SUM_COUNT + t] = static_cast<float>(v);
-      sums_out[(static_cast<long>(b) * S + s) * SUM_COUNT + t] = static_cast<float>(v);
+      sums[(static_cast<long>(b) * S + s) * SUM_COUNT + t] = static_cast<float>(v);
     }
-    __syncthreads();
-  }
-  {
+  } else {
     double a[6] = {0, 0, 0, 0, 0, 0};
     if (D.mode != 2) for (int k = t; k < ndunit; k += 256)
 #pragma unroll
@@ -878,11 +1001,9 @@ __global__ void __launch_bounds__(256) k_geom_finalize_fwd(GeomDev D, const floa
     if (t < 6) {
       double v = 0.0;
       for (int k = 0; k < 256; ++k) v += lds[k][t];
-      s_dsum[t] = static_cast<float>(v);
+      dsum[((t >> 1) * B + b) * 2 + (t & 1)] = static_cast<float>(v);
     }
-    __syncthreads();
   }
-  if (t == 0) assemble_sample(D, b, s_sums, s_dsum, sums2, coef, losses);
 }
 
 // depth terms: fixed-order sums of the consistency block partials and the rigid-SSIM strip partials of one
@@ -912,15 +1033,15 @@ __global__ void __launch_bounds__(256) k_geom_reduce_dt(GeomDev D, const float* 
   }
 }
 
-// sums: [S][SUM_COUNT] of this sample; dsum: [3 frames][2] of this sample
-__device__ void assemble_sample(const GeomDev& D, int b, const float* sums, const float* dsum, const float* __restrict__ sums2,
-                                float* __restrict__ coef, float* __restrict__ losses) {
-  const int S = D.S, B = D.B;
+__global__ void k_geom_assemble_fwd(GeomDev D, const float* __restrict__ sums, const float* __restrict__ dsum,
+                                    const float* __restrict__ sums2, float* __restrict__ coef, float* __restrict__ losses) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x, S = D.S, B = D.B;
+  if (b >= B) return;
   const double eps = 1e-12;
   double l_dp = 0, l_fp = 0, l_fs = 0, l_sm = 0, l_fc = 0, l_dfc = 0, l_epi = 0, l_dss = 0, l_dcs = 0;
   for (int s = 0; s < S; ++s) {
     const double N = D.N[s], H = D.H[s], W = D.W[s];
-    const float* sm = sums + s * SUM_COUNT;
+    const float* sm = sums + (static_cast<long>(b) * S + s) * SUM_COUNT;
     float* cf = coef + (static_cast<long>(b) * S + s) * CF_COUNT;
     for (int d = 0; d < 2; ++d) {
       const float* a = sm + d * PT_PER_DIR;
@@ -953,7 +1074,7 @@ __device__ void assemble_sample(const GeomDev& D, int b, const float* sums, cons
   double l_ds = 0;
   {
     const double H = D.H[0], W = D.W[0];
-    for (int f = 0; f < 3; ++f) l_ds += dsum[f * 2] / (H * (W - 1.0)) + dsum[f * 2 + 1] / ((H - 1.0) * W);
+    for (int f = 0; f < 3; ++f) l_ds += dsum[(f * B + b) * 2] / (H * (W - 1.0)) + dsum[(f * B + b) * 2 + 1] / ((H - 1.0) * W);
   }
   losses[DFE_LOSS_DEPTH_PIXEL * B + b] = static_cast<float>(l_dp);
   losses[DFE_LOSS_DEPTH_SMOOTH * B + b] = static_cast<float>(l_ds);
@@ -1094,7 +1215,12 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     }
     DFE_MARK(); DFE_MARK();
   } else {
-    if (L.dt) k_geom_point_fwd<true><<<dim3(L.blk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, T, ws + L.o_part, ws + L.o_part2);
+    bool pairs = getenv("DFE_POINT_FWD_1PX") == nullptr;    // two pixels per thread when every scale has an even width
+    for (int s = 0; s < L.S; ++s) pairs = pairs && (L.W[s] % 2 == 0);
+    if (pairs) {
+      if (L.dt) k_geom_point_fwd2<true><<<dim3(L.blk_start[L.S], L.B), GS_BLOCK / 2, 0, st>>>(D, T, ws + L.o_part, ws + L.o_part2);
+      else k_geom_point_fwd2<false><<<dim3(L.blk_start[L.S], L.B), GS_BLOCK / 2, 0, st>>>(D, T, ws + L.o_part, nullptr);
+    } else if (L.dt) k_geom_point_fwd<true><<<dim3(L.blk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, T, ws + L.o_part, ws + L.o_part2);
     else k_geom_point_fwd<false><<<dim3(L.blk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, T, ws + L.o_part, nullptr);
     DFE_LAUNCH_CHECK();
     DFE_MARK();
@@ -1125,12 +1251,15 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   }
   DFE_LAUNCH_CHECK();
   DFE_MARK();
+  k_geom_reduce_fwd<<<dim3(L.S + 1, L.B), 256, 0, st>>>(D, ws + L.o_part, ws + L.o_spart, ws + L.o_fpart, ws + L.o_dpart,
+                                                     L.dsm_units, ws + L.o_sums, ws + L.o_dsum);
+  DFE_LAUNCH_CHECK();
   if (L.dt) {
     k_geom_reduce_dt<<<dim3(L.S, L.B), 256, 0, st>>>(D, ws + L.o_part2, ws + L.o_spart2, ws + L.o_sums2);
     DFE_LAUNCH_CHECK();
   }
-  k_geom_finalize_fwd<<<L.B, 256, 0, st>>>(D, ws + L.o_part, ws + L.o_spart, ws + L.o_fpart, ws + L.o_dpart, L.dsm_units,
-                                           L.dt ? ws + L.o_sums2 : nullptr, ws + L.o_sums, ws + L.o_coef, a->losses);
+  k_geom_assemble_fwd<<<(L.B + 63) / 64, 64, 0, st>>>(D, ws + L.o_sums, ws + L.o_dsum, L.dt ? ws + L.o_sums2 : nullptr,
+                                                      ws + L.o_coef, a->losses);
   DFE_LAUNCH_CHECK();
   DFE_MARK();
 #undef DFE_MARK

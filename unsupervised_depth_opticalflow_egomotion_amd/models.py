@@ -95,7 +95,7 @@ def _flow_branches(fpyramid, pwc_model, img_l, img, img_r):
 
 _PLACEHOLDERS = {}
 _SIDE_STREAMS = {}
-_DEFAULT_NET_STREAMS = int(__import__("os").environ.get("DFE_NET_STREAMS", "1"))
+_DEFAULT_NET_STREAMS = int(__import__("os").environ.get("DFE_NET_STREAMS", "3"))   # 1 = everything on the current stream
 
 
 def _side_streams(dev):
@@ -299,8 +299,21 @@ class Model_depth(LossTerms, nn.Module):
         images, K_ms, K_inv_ms = inputs
         K = K_ms[:, 0, :, :]
         img_l, img, img_r, batched = _contiguous_frames(images)
-        depth_l, depth_t, depth_r = _depth_frames(self.depth_net, img_l, img, img_r, batched)
-        pose = self.pose_net(torch.cat([img_l, img, img_r], 1))
+        if img.is_cuda and int(getattr(self, "net_streams", _DEFAULT_NET_STREAMS)) > 1:
+            # the pose net beside the depth net (see Model_geometry.run_networks)
+            main = torch.cuda.current_stream(img.device)
+            _, s_pose = _side_streams(img.device)
+            s_pose.wait_stream(main)
+            for t in (img_l, img, img_r):
+                t.record_stream(s_pose)
+            with torch.cuda.stream(s_pose):
+                pose = self.pose_net(torch.cat([img_l, img, img_r], 1))
+            depth_l, depth_t, depth_r = _depth_frames(self.depth_net, img_l, img, img_r, batched)
+            main.wait_stream(s_pose)
+            pose.record_stream(main)
+        else:
+            depth_l, depth_t, depth_r = _depth_frames(self.depth_net, img_l, img, img_r, batched)
+            pose = self.pose_net(torch.cat([img_l, img, img_r], 1))
         return self.loss_stack(img_l, img, img_r, depth_l, depth_t, depth_r, pose, K)
 
     def loss_stack(self, img_l, img, img_r, depth_l, depth_t, depth_r, pose, K):
