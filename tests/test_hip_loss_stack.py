@@ -447,8 +447,9 @@ def _run_with_env(inp, name, value, S=3):
     try:
         lp, mk, tot, (d, p, fb, ff) = run_hip(inp, False, S)
         torch.cuda.synchronize()
+        g = lambda t: None if t.grad is None else N(t.grad)   # noqa: E731  (the fourth flow level feeds no loss)
         return ({k: N(v) for k, v in lp.items()}, {k: [N(t) for t in v] for k, v in mk.items()},
-                [[N(t.grad) for t in lst] for lst in d], N(p.grad), [N(t.grad) for t in fb], [N(t.grad) for t in ff])
+                [[g(t) for t in lst] for lst in d], g(p), [g(t) for t in fb], [g(t) for t in ff])
     finally:
         if old is None:
             os.environ.pop(name, None)
@@ -467,21 +468,3 @@ def test_rolling_upsampling_adjoint_is_the_gather_bit_for_bit(shape):
     for f in range(3):
         for s in range(3):
             assert np.array_equal(a[2][f][s], b[2][f][s]), (f, s, float(np.abs(a[2][f][s] - b[2][f][s]).max()))
-
-
-@pytest.mark.parametrize("shape", [(2, 64, 208), (4, 256, 832)])
-def test_pixel_pair_forward_kernel_matches_the_one_pixel_kernel(shape):
-    """k_geom_point_fwd2 (two adjacent pixels per thread, 8-byte streamed accesses) against k_geom_point_fwd
-    (DFE_POINT_FWD_1PX=1): the per-pixel arithmetic is the same code, so masks and everything the backward derives from
-    the masked warps are identical; only the block sums add the pair first (loss rows to fp32 rounding of a sum)."""
-    inp = synthetic.make_loss_stack_inputs(*shape, 3, seed=43)
-    a = _run_with_env(inp, "DFE_POINT_FWD_1PX", None)
-    b = _run_with_env(inp, "DFE_POINT_FWD_1PX", "1")
-    for k in a[1]:
-        for s in range(3):
-            assert np.array_equal(a[1][k][s], b[1][k][s]), (k, s)
-    for k in a[0]:
-        np.testing.assert_allclose(a[0][k], b[0][k], rtol=2e-6, atol=1e-9, err_msg=k)
-    for s in range(3):
-        assert np.abs(a[4][s] - b[4][s]).max() <= 1e-5 * max(np.abs(b[4][s]).max(), 1e-12)
-        assert np.abs(a[5][s] - b[5][s]).max() <= 1e-5 * max(np.abs(b[5][s]).max(), 1e-12)

@@ -391,15 +391,19 @@ def test_network_streams_do_not_change_results():
         total_loss(lp, cfg).backward()
         torch.cuda.synchronize()
         return torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
-    a, a2, b = one_step(1), one_step(1), one_step(3)
+    a, a2, b, c = one_step(1), one_step(1), one_step(3), one_step(6)
     scale = float(a.abs().max())
     noise = float((a2 - a).abs().max())
-    diff = float((b - a).abs().max())
-    print("\nstreams: grad scale %.3e, single-stream run-to-run %.3e, 3 streams vs 1 %.3e" % (scale, noise, diff))
+    diff, diff6 = float((b - a).abs().max()), float((c - a).abs().max())
+    print("\nstreams: grad scale %.3e, single-stream run-to-run %.3e, 3 streams vs 1 %.3e, 6 (weight-gradient streams) vs 1 %.3e"
+          % (scale, noise, diff, diff6))
     assert diff <= max(4.0 * noise, 2e-6 * scale), (diff, noise, scale)
+    assert diff6 <= max(4.0 * noise, 2e-6 * scale), (diff6, noise, scale)
     l1, _ = _three_steps(1)
     l3, _ = _three_steps(3)
+    l6, _ = _three_steps(6)
     np.testing.assert_allclose(l3, l1, rtol=2e-5)
+    np.testing.assert_allclose(l6, l1, rtol=2e-5)
 
 
 def test_amp_bf16_mode_is_opt_in_and_close_to_fp32():

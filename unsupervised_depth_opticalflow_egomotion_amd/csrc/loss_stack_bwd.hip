@@ -683,23 +683,26 @@ __global__ void __launch_bounds__(64) k_geom_disp_smooth_bwd2_roll(GeomDev D, Ge
   float w[NT];
 #pragma unroll
   for (int k = 0; k < NT; ++k) w[k] = (k < NR) ? (2.0f * k + 1.0f) / (2.0f * NR) : (2.0f * (NT - 1 - k) + 1.0f) / (2.0f * NR);
-  // rows y = NR * i - NR/2 + ky; group r holds the NR rows NR * i' - NR/2 .. + NR - 1 with i' = I0 + r (r = 0 .. I1-I0)
-  auto load_group = [&](int ip, float (&v)[NR]) {
-    const int y0 = NR * ip - NR / 2;
-#pragma unroll
-    for (int k = 0; k < NR; ++k) v[k] = gu[static_cast<long>(y0 + k) * W];
-  };
-  float cur = 0.0f, nxt = 0.0f;
-  float g[NR], gn[NR];
-  load_group(I0, g);
+  // rows y = NR * i - NR/2 + ky; group r holds the NR rows NR * i' - NR/2 .. + NR - 1 with i' = I0 + r (r = 0 .. I1-I0).
+  // ALL groups are loaded before any arithmetic (NR * (DSR_OUT_ROWS + 1) independent loads per lane): the march is a
+  // dependency chain of memory latencies otherwise (measured: one group of prefetch -> 38 us against the gather's 24).
+  constexpr int NG = DSR_OUT_ROWS + 1;
+  float g[NG][NR];
   const int ngroups = I1 - I0 + 1;           // the last group only completes output I1 - 1
-  for (int r = 0; r < ngroups; ++r) {
+#pragma unroll
+  for (int r = 0; r < NG; ++r) {
+    const int y0 = NR * min(I0 + r, Hs - 1) - NR / 2;       // groups past the block's end repeat a valid row (unused)
+#pragma unroll
+    for (int k = 0; k < NR; ++k) g[r][k] = gu[static_cast<long>(y0 + k) * W];
+  }
+  float cur = 0.0f, nxt = 0.0f;
+#pragma unroll
+  for (int r = 0; r < NG; ++r) {
     const int ip = I0 + r;
-    if (r + 1 < ngroups) load_group(ip + 1, gn);
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
       // horizontal tent sum starting at this lane: acc = sum_kx w[kx] * g(lane + kx), kx ascending
-      float sh = g[k], acc = 0.0f;
+      float sh = g[r][k], acc = 0.0f;
 #pragma unroll
       for (int kx = 0; kx < NT; ++kx) {
         acc += w[kx] * sh;
@@ -708,13 +711,11 @@ __global__ void __launch_bounds__(64) k_geom_disp_smooth_bwd2_roll(GeomDev D, Ge
       cur += w[k + NR] * acc;               // output row ip - 1, taps NR .. 2NR-1
       nxt += w[k] * acc;                    // output row ip, taps 0 .. NR-1
     }
-    if (r > 0 && out_lane) {                // output row ip - 1 is complete
+    if (r > 0 && r < ngroups && out_lane) { // output row ip - 1 is complete
       float* dst = o + static_cast<long>(ip - 1) * Ws;
       if (rmw) *dst += cur; else *dst = cur;
     }
     cur = nxt; nxt = 0.0f;
-#pragma unroll
-    for (int k = 0; k < NR; ++k) g[k] = gn[k];
   }
 }
 

@@ -276,6 +276,11 @@ __global__ void __launch_bounds__(64) k_geom_area_coarse(PyrJobs jobs) {
 // RGBA-texel zero-bordered source planes with wave-persistent accumulation (fewer, wider gathers: the addresser cost
 // follows bytes, VGPRs double -> 54-60 us vs 48), 32x8 LDS-staged source tiles with a +-6 px halo around the
 // tile-centre flow (hit rate too low on rough flow fields: 59 us), LDS-transposed streamed loads / stores (53 us).
+// Round 3 (profiles/r03_point_fwd_ablation.md): what the 24 gathers cost is set by how many 128-byte lines a wave's
+// addresses touch (20 us of 50 with per-pixel random flows, 0.7 us with coherent ones), not by their count.  Two adjacent
+// pixels per thread with 8-byte streamed accesses (21 -> 10.5 streamed vector-memory instructions per pixel) was measured
+// and rejected: the two interleaved chains need 155 VGPRs (3 waves per SIMD): 59.9 vs 49.8 us in the loss_stack loop,
+// 40-41 vs 37.7 us inside the train step.
 // DFE_ABL: compile-time ablation switches of k_geom_point_fwd for the cost study of profiles/r03_point_fwd_ablation.md
 // (tools/ablate_point_fwd.sh builds one library per value; 0 = the shipped kernel, no code depends on it then).
 //   1 no block reductions   2 gathers at the pixel's own position (coherent)   4 no stores   8 rigid branch without gathers
@@ -513,135 +518,6 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_fwd(GeomDev D, GeomT T,
   }
   point_block_sums(acc, red, part + (static_cast<long>(b) * nblk_total + blk) * PT_COUNT);
   if (DT) block_sum<2>(dc, red, part2 + (static_cast<long>(b) * nblk_total + blk) * 2);
-}
-
-// Two horizontally adjacent pixels per thread (all W_s even): the 14 streamed loads and the 7 stores of a pixel become
-// 8-byte accesses shared by the pair (21 -> 10.5 vector-memory instructions per pixel; the 24 gathers stay), and the two
-// independent per-pixel chains interleave in one instruction stream.  A block is still one 256-pixel segment (128
-// threads), so the partial-sum layout and everything downstream is unchanged.  Selected at run time by
-// dfe_geom_loss_fwd when every scale has an even width; same arithmetic per pixel, block sums add the pair first.
-struct __attribute__((aligned(8))) F2a { float a, b; };
-__device__ __forceinline__ F2a ldb2(const float* __restrict__ base, unsigned byte_off) {
-  return *reinterpret_cast<const F2a*>(reinterpret_cast<const char*>(base) + byte_off);
-}
-__device__ __forceinline__ void stb2(float* __restrict__ base, unsigned byte_off, float v0, float v1) {
-  *reinterpret_cast<F2a*>(reinterpret_cast<char*>(base) + byte_off) = F2a{v0, v1};
-}
-
-#ifndef DFE_PF2_WAVES
-#define DFE_PF2_WAVES 3      // minimum waves per SIMD asked of the register allocator (tuning switch)
-#endif
-template <bool DT>
-__global__ void __launch_bounds__(GS_BLOCK / 2, DFE_PF2_WAVES) k_geom_point_fwd2(GeomDev D, GeomT T, float* __restrict__ part, float* __restrict__ part2) {
-  constexpr int NW = GS_BLOCK / 128;          // waves per block
-  __shared__ float red[PT_COUNT * 4 * NW + 16];
-  const unsigned nblk_total = D.blk_start[D.S];
-  const unsigned blk = xcd_swizzle(blockIdx.x, nblk_total);
-  const int b = blockIdx.y;
-  const int s = find_scale(D.blk_start, D.S, blk);
-  const int H = D.H[s], W = D.W[s], N = D.N[s];
-  const unsigned p = (blk - D.blk_start[s]) * GS_BLOCK + 2u * threadIdx.x;
-  float acc[2][PT_COUNT];
-#pragma unroll
-  for (int i = 0; i < PT_COUNT; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
-  float dc[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
-  if (p < static_cast<unsigned>(N)) {          // N even: the pair is either inside or outside
-    unsigned px, py;
-    split_pixel(p, W, T.rW[s], px, py);
-    const unsigned p4 = p * 4u, N4 = static_cast<unsigned>(N) * 4u;
-    PointCtx c;
-    c.b = b; c.s = s; c.H = H; c.W = W; c.ac = D.ac; c.N4 = N4; c.p4 = p4; c.alpha = D.alpha; c.beta = D.beta;
-    c.srcL = D.pyr[0][s] + static_cast<long>(b) * 3 * N; c.srcR = D.pyr[2][s] + static_cast<long>(b) * 3 * N;
-    c.areaL = D.area[0][s] + static_cast<long>(b) * 3 * N; c.areaR = D.area[1][s] + static_cast<long>(b) * 3 * N;
-    c.cam = D.cams + (b * 2) * D.S + s; c.cam_stride = D.S; c.epi = D.epi + b * 2;
-    c.dw = T.dw[s]; c.dh = T.dh[s];
-    c.dispL = D.disp[0][s] + static_cast<long>(b) * N; c.dispR = D.disp[2][s] + static_cast<long>(b) * N;
-    const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
-    const float* flb = D.flow[0][s] + static_cast<long>(b) * 2 * N;
-    const float* flf = D.flow[1][s] + static_cast<long>(b) * 2 * N;
-    const F2a i0 = ldb2(it, p4), i1 = ldb2(it, p4 + N4), i2 = ldb2(it, p4 + 2 * N4);
-    const F2a u0 = ldb2(flb, p4), v0 = ldb2(flb, p4 + N4), u1 = ldb2(flf, p4), v1 = ldb2(flf, p4 + N4);
-    const F2a ds = ldb2(D.disp[1][s] + static_cast<long>(b) * N, p4);
-    const F2a l0 = ldb2(c.srcL, p4), l1 = ldb2(c.srcL, p4 + N4), l2 = ldb2(c.srcL, p4 + 2 * N4);
-    const F2a r0 = ldb2(c.srcR, p4), r1 = ldb2(c.srcR, p4 + N4), r2 = ldb2(c.srcR, p4 + 2 * N4);
-    PixIn inA, inB;
-    inA.i0 = i0.a; inA.i1 = i1.a; inA.i2 = i2.a; inB.i0 = i0.b; inB.i1 = i1.b; inB.i2 = i2.b;
-    inA.fu[0] = u0.a; inA.fv[0] = v0.a; inA.fu[1] = u1.a; inA.fv[1] = v1.a;
-    inB.fu[0] = u0.b; inB.fv[0] = v0.b; inB.fu[1] = u1.b; inB.fv[1] = v1.b;
-    inA.dsp = ds.a; inB.dsp = ds.b;
-    inA.sl[0] = l0.a; inA.sl[1] = l1.a; inA.sl[2] = l2.a; inB.sl[0] = l0.b; inB.sl[1] = l1.b; inB.sl[2] = l2.b;
-    inA.sr[0] = r0.a; inA.sr[1] = r1.a; inA.sr[2] = r2.a; inB.sr[0] = r0.b; inB.sr[1] = r1.b; inB.sr[2] = r2.b;
-    float ywA[2][3], ywB[2][3], yrA[2][3], yrB[2][3];
-    unsigned bitsA, bitsB;
-    point_pixel<DT>(c, static_cast<int>(px), static_cast<int>(py), inA, ywA, bitsA, acc[0], yrA, dc[0]);
-    c.p4 = p4 + 4u;
-    point_pixel<DT>(c, static_cast<int>(px) + 1, static_cast<int>(py), inB, ywB, bitsB, acc[1], yrB, dc[1]);
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-      float* ywp = D.yw[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) stb2(ywp, p4 + ch * N4, ywA[d][ch], ywB[d][ch]);
-      if (DT && (D.dt & DFE_DEPTH_TERM_SSIM)) {
-        float* yrp = D.yr[s] + (static_cast<long>(d) * D.B + b) * 3 * N;
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) stb2(yrp, p4 + ch * N4, yrA[d][ch], yrB[d][ch]);
-      }
-    }
-    *reinterpret_cast<unsigned short*>(D.mask[s] + static_cast<long>(b) * N + p) = static_cast<unsigned short>(bitsA | (bitsB << 8));
-  }
-  // block sums: float entries add the pair, then the DPP tree; {0,1} entries are two population counts
-  constexpr int NF = 11, NC = 9;
-  constexpr int FI[NF] = {PT_L1_DEPTH, PT_L1_RIG, PT_L1_DYN, PT_FDIFF, PT_EPI,
-                          PT_PER_DIR + PT_L1_DEPTH, PT_PER_DIR + PT_L1_RIG, PT_PER_DIR + PT_L1_DYN, PT_PER_DIR + PT_FDIFF,
-                          PT_PER_DIR + PT_EPI, PT_CONSIS};
-  constexpr int CI[NC] = {PT_M_TEX, PT_M_RIG, PT_M_DYN, PT_M_VO, PT_PER_DIR + PT_M_TEX, PT_PER_DIR + PT_M_RIG,
-                          PT_PER_DIR + PT_M_DYN, PT_PER_DIR + PT_M_VO, PT_INV};
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float f[NF];
-#pragma unroll
-  for (int i = 0; i < NF; ++i) f[i] = acc[0][FI[i]] + acc[1][FI[i]];
-#pragma unroll
-  for (int i = 0; i < NF; ++i) f[i] = dpp_add<0xB1>(f[i]);
-#pragma unroll
-  for (int i = 0; i < NF; ++i) f[i] = dpp_add<0x4E>(f[i]);
-#pragma unroll
-  for (int i = 0; i < NF; ++i) f[i] = dpp_add<0x141>(f[i]);
-#pragma unroll
-  for (int i = 0; i < NF; ++i) f[i] = dpp_add<0x140>(f[i]);
-  if ((lane & 15) == 0) {
-    const int slot = wave * 4 + (lane >> 4);
-#pragma unroll
-    for (int i = 0; i < NF; ++i) red[slot * NF + i] = f[i];
-  }
-  float* cnt = red + NF * 4 * NW;
-#pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    const unsigned long long m0 = __ballot(acc[0][CI[i]] != 0.0f), m1 = __ballot(acc[1][CI[i]] != 0.0f);
-    if (lane == 0) cnt[wave * NC + i] = static_cast<float>(__popcll(m0) + __popcll(m1));
-  }
-  __syncthreads();
-  float* out = part + (static_cast<long>(b) * nblk_total + blk) * PT_COUNT;
-  if (threadIdx.x < NF) {
-    float sum = 0.0f;
-    for (int w = 0; w < 4 * NW; ++w) sum += red[w * NF + threadIdx.x];
-    int dst = 0;
-#pragma unroll
-    for (int i = 0; i < NF; ++i) dst = (static_cast<int>(threadIdx.x) == i) ? FI[i] : dst;
-    out[dst] = sum;
-  } else if (threadIdx.x < NF + NC) {
-    const int t = threadIdx.x - NF;
-    float sum = 0.0f;
-    for (int w = 0; w < NW; ++w) sum += cnt[w * NC + t];
-    int dst = 0;
-#pragma unroll
-    for (int i = 0; i < NC; ++i) dst = (t == i) ? CI[i] : dst;
-    out[dst] = sum;
-  }
-  if (DT) {
-    __syncthreads();
-    float d2[2] = {dc[0][0] + dc[1][0], dc[0][1] + dc[1][1]};
-    block_sum<2>(d2, red, part2 + (static_cast<long>(b) * nblk_total + blk) * 2);
-  }
 }
 
 // ---------------------------------------------------------------------- depth-only pointwise forward
@@ -1215,12 +1091,7 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     }
     DFE_MARK(); DFE_MARK();
   } else {
-    bool pairs = getenv("DFE_POINT_FWD_1PX") == nullptr;    // two pixels per thread when every scale has an even width
-    for (int s = 0; s < L.S; ++s) pairs = pairs && (L.W[s] % 2 == 0);
-    if (pairs) {
-      if (L.dt) k_geom_point_fwd2<true><<<dim3(L.blk_start[L.S], L.B), GS_BLOCK / 2, 0, st>>>(D, T, ws + L.o_part, ws + L.o_part2);
-      else k_geom_point_fwd2<false><<<dim3(L.blk_start[L.S], L.B), GS_BLOCK / 2, 0, st>>>(D, T, ws + L.o_part, nullptr);
-    } else if (L.dt) k_geom_point_fwd<true><<<dim3(L.blk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, T, ws + L.o_part, ws + L.o_part2);
+    if (L.dt) k_geom_point_fwd<true><<<dim3(L.blk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, T, ws + L.o_part, ws + L.o_part2);
     else k_geom_point_fwd<false><<<dim3(L.blk_start[L.S], L.B), GS_BLOCK, 0, st>>>(D, T, ws + L.o_part, nullptr);
     DFE_LAUNCH_CHECK();
     DFE_MARK();
