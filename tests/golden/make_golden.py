@@ -602,8 +602,56 @@ def gen_g10(ref, out):
     out["compute_errors"] = np.array(errs, np.float64)
 
 
-GENERATORS = dict(G1=gen_g1, G2=gen_g2, G3=gen_g3, G4=gen_g4, G5=gen_g5, G6=gen_g6, G7=gen_g7, G8=gen_g8, G9=gen_g9, G10=gen_g10)
-AC_INDEPENDENT = {"G3", "G4", "G10"}   # no grid_sample inside
+# ------------------------------------------------------------------------------------ G11
+def g11_inputs():
+    """Matches, cameras and depth maps for the triangulation family (model_geometry.py:427-470, 569-683)."""
+    r = rng(1111)
+    b, n, h, w = 2, 200, 48, 160
+    K = kmat(b, h, w)
+    pose = (0.05 * r.standard_normal((b, 6))).astype(np.float32)
+    pose[:, 3:] *= 0.3
+    pose[:, 0] += 0.4                                             # a baseline, so that the rays are not parallel
+    xy = np.stack([r.uniform(2, w - 3, (b, n)), r.uniform(2, h - 3, (b, n))], 1).astype(np.float32)
+    match = np.concatenate([xy, xy + r.normal(0, 3, (b, 2, n)).astype(np.float32)], 1)
+    depth1 = r.uniform(2, 30, (b, 1, h, w)).astype(np.float32)
+    depth2 = r.uniform(2, 30, (b, 1, h, w)).astype(np.float32)
+    flow = r.normal(0, 3, (b, 2, h, w)).astype(np.float32)
+    score = r.random((b, 1, h, w)).astype(np.float32)
+    return dict(K=K, pose=pose, match=match, depth1=depth1, depth2=depth2, flow=flow, score=score, hw=(h, w))
+
+
+def gen_g11(ref, out):
+    m = bare_geometry(ref)
+    m.ratio, m.num, m.dataset = 0.3, 50, "kitti_depth"
+    c = g11_inputs()
+    K, pose, match = T(c["K"]), T(c["pose"]), T(c["match"])
+    Ki = torch.inverse(K)
+    P1, P2 = ref["iw"].compute_projection_matrix(pose, K)
+    out["P2"] = N(P2)
+    pts = m.midpoint_triangulate(match, K, Ki, P1, P2)
+    out["points"] = N(pts)
+    c1, z1 = m.reproject(P1, pts)
+    c2, z2 = m.reproject(P2, pts)
+    out["coord1"], out["depth1"], out["coord2"], out["depth2"] = N(c1), N(z1), N(c2), N(z2)
+    d1 = T(c["depth1"])
+    r1, i1 = m.register_depth(d1, c1, z1)
+    out["reg_pred1"], out["reg_inter1"] = N(r1), N(i1)
+    a, bb = m.affine_adapt(i1, z1.abs() + 0.5, use_translation=True)
+    out["affine_a"], out["affine_b"], out["scale_a"] = N(a), N(bb), N(m.scale_adapt(i1, z1.abs() + 0.5))
+    out["trian_loss"] = N(m.compute_triangulate_loss(match, pose, K, Ki, [d1], [T(c["depth2"])]))
+    flow, score = T(c["flow"]), T(c["score"])
+    b, _, h, w = flow.shape
+    grid = m.meshgrid(b, h, w)
+    full = torch.cat([grid, grid + flow], 1).view(b, 4, -1)
+    tm, td, ts = m.top_ratio_sample(full, d1.view(b, 1, -1), score.view(b, 1, -1), 0.3)
+    out["top_match"], out["top_depth"], out["top_score"] = N(tm), N(td), N(ts)
+    torch.manual_seed(1111)
+    sm, sd = m.sample_match(flow, d1, score)
+    out["sample_match"], out["sample_depth"] = N(sm), N(sd)
+
+
+GENERATORS = dict(G1=gen_g1, G2=gen_g2, G3=gen_g3, G4=gen_g4, G5=gen_g5, G6=gen_g6, G7=gen_g7, G8=gen_g8, G9=gen_g9, G10=gen_g10, G11=gen_g11)
+AC_INDEPENDENT = {"G3", "G4", "G10"}   # no grid_sample inside (G11: register_depth samples with grid_sample)
 
 
 def main():

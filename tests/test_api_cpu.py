@@ -379,3 +379,88 @@ def test_kitti_png_codec_and_readers(tmp_path):
     gt = np.stack([np.eye(3, 4)] * 3); gt[1, 0, 3] = 1.0; gt[2, 0, 3] = 2.0
     ate, re = K.compute_pose_error(gt, gt * np.array([1, 1, 1, 0.5]))
     assert ate < 1e-12 and re < 1e-12          # the ATE is invariant to the prediction's scale
+
+
+@pytest.mark.parametrize("ac", [False, True])
+def test_triangulation_family_vs_reference_golden(golden_dir, ac):
+    """geometry_solvers: mid-point triangulation, reprojection, depth registration, affine / scale
+    fits, triangulation loss, top-ratio and random match sampling against golden G11 -- the reference's own methods
+    (model_geometry.py:427-470, 569-683) called unbound on a bare object.  Pure torch: runs on the host here."""
+    from tests.golden import make_golden as MG
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+    from unsupervised_depth_opticalflow_egomotion_amd.geometry_solvers import GeometrySolvers
+    from unsupervised_depth_opticalflow_egomotion_amd.loss_terms import LossTerms
+
+    class M(LossTerms, GeometrySolvers):
+        ratio, num = 0.3, 50
+    g = np.load(os.path.join(golden_dir, "G11_ac%d.npz" % ac))
+    c = MG.g11_inputs()
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()   # noqa: E731
+    m = M()
+    K, match = T(c["K"]), T(c["match"])
+    Ki = torch.inverse(K)
+    P1 = K.bmm(torch.cat([torch.eye(3), torch.zeros(3, 1)], -1).unsqueeze(0).repeat(K.shape[0], 1, 1))
+    P2 = T(g["P2"])
+    close = lambda a, b, tol=2e-5: np.testing.assert_allclose(a.detach().numpy(), b, rtol=tol, atol=tol * max(1.0, float(np.abs(b).max())))   # noqa: E731
+    old = ops.get_align_corners()
+    ops.set_align_corners(ac)
+    try:
+        pts = m.midpoint_triangulate(match, K, Ki, P1, P2)
+        close(pts, g["points"], 1e-4)
+        c1, z1 = m.reproject(P1, T(g["points"]))
+        c2, z2 = m.reproject(P2, T(g["points"]))
+        close(c1, g["coord1"], 1e-4); close(z1, g["depth1"]); close(c2, g["coord2"], 1e-4); close(z2, g["depth2"])
+        d1 = T(c["depth1"])
+        r1, i1 = m.register_depth(d1, T(g["coord1"]), T(g["depth1"]))
+        close(r1, g["reg_pred1"], 1e-4); close(i1, g["reg_inter1"], 1e-4)
+        a, b = m.affine_adapt(T(g["reg_inter1"]), T(g["depth1"]).abs() + 0.5, use_translation=True)
+        close(a, g["affine_a"], 1e-3); close(b, g["affine_b"], 1e-3)
+        close(m.scale_adapt(T(g["reg_inter1"]), T(g["depth1"]).abs() + 0.5), g["scale_a"], 1e-4)
+        loss = m.get_trian_loss(T(g["depth1"]), T(g["reg_inter1"]))
+        assert loss.shape == (2,)
+        flow, score = T(c["flow"]), T(c["score"])
+        bsz, _, h, w = flow.shape
+        grid = m.meshgrid(bsz, h, w)
+        full = torch.cat([grid, grid + flow], 1).view(bsz, 4, -1)
+        tm, td, ts = m.top_ratio_sample(full, d1.view(bsz, 1, -1), score.view(bsz, 1, -1), 0.3)
+        assert np.array_equal(tm.numpy(), g["top_match"]) and np.array_equal(td.numpy(), g["top_depth"]) and np.array_equal(ts.numpy(), g["top_score"])
+        torch.manual_seed(1111)
+        sm, sd = m.sample_match(flow, d1, score)
+        assert np.array_equal(sm.numpy(), g["sample_match"]) and np.array_equal(sd.numpy(), g["sample_depth"])
+    finally:
+        ops.set_align_corners(old)
+
+
+def test_eight_point_properties():
+    """compute_fundmental_mat (normalised eight-point, batched; stands in for cv2.findFundamentalMat, which is absent and
+    random): exact recovery of a known F from noise-free matches, rank 2, F[2,2] = 1, invariance to the order of the
+    matches, graceful least squares under noise."""
+    from unsupervised_depth_opticalflow_egomotion_amd.geometry_solvers import GeometrySolvers
+    r = np.random.default_rng(3)
+    b, n = 3, 64
+    K = np.array([[480.0, 0, 416], [0, 490, 128], [0, 0, 1]])
+    Fs, ms = [], []
+    for i in range(b):
+        ang = 0.05 * r.standard_normal(3)
+        cx, sx, cy, sy, cz, sz = np.cos(ang[0]), np.sin(ang[0]), np.cos(ang[1]), np.sin(ang[1]), np.cos(ang[2]), np.sin(ang[2])
+        R = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+        t = np.array([0.5, 0.05, 0.1]) + 0.05 * r.standard_normal(3)
+        X = np.stack([r.uniform(-4, 4, n), r.uniform(-1.5, 1.5, n), r.uniform(4, 30, n)])
+        x1 = K @ X
+        x2 = K @ (R @ X + t[:, None])
+        ms.append(np.concatenate([x1[:2] / x1[2], x2[:2] / x2[2]], 0))
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        Fm = np.linalg.inv(K).T @ tx @ R @ np.linalg.inv(K)
+        Fs.append(Fm / Fm[2, 2])
+    m = torch.from_numpy(np.stack(ms)).float()
+    est = GeometrySolvers().compute_fundmental_mat(m).double().numpy()
+    for i in range(b):
+        assert abs(est[i][2, 2] - 1.0) < 1e-6 and abs(np.linalg.det(est[i])) < 1e-9 * np.abs(est[i]).max() ** 3 + 1e-18
+        np.testing.assert_allclose(est[i], Fs[i], rtol=2e-3, atol=2e-3 * np.abs(Fs[i]).max())
+        x1 = np.concatenate([ms[i][:2], np.ones((1, n))]); x2 = np.concatenate([ms[i][2:], np.ones((1, n))])
+        res = np.abs(np.sum(x2 * (est[i] @ x1), 0)) / (np.linalg.norm((est[i] @ x1)[:2], axis=0) + 1e-12)
+        assert res.max() < 5e-2                                  # epipolar distance in pixels (float32 matches)
+    perm = torch.randperm(n)
+    np.testing.assert_allclose(GeometrySolvers().compute_fundmental_mat(m[:, :, perm]).numpy(), est, rtol=1e-3, atol=1e-5)
+    noisy = GeometrySolvers().compute_fundmental_mat(m + 0.2 * torch.randn_like(m)).numpy()
+    assert np.isfinite(noisy).all()

@@ -624,3 +624,39 @@ def test_device_side_evaluation_at_kitti_size(golden_dir):
     gtd = [np.where(r.random((H, W)) > 0.9, r.uniform(1, 90, (H, W)), 0).astype(np.float32) for _ in range(2)]
     prd = [r.uniform(0.5, 60, (H, W)).astype(np.float32) for _ in range(2)]
     np.testing.assert_allclose(eval_depth(gtd, [G(p) for p in prd]), EO.eval_depth(gtd, prd), rtol=3e-5)
+
+
+@pytest.mark.parametrize("ac", [False, True])
+def test_triangulation_and_eight_point_losses_on_the_device(golden_dir, ac):
+    """compute_triangulate_loss (golden G11: the reference's own value) and compute_eight_point_loss through the model's
+    method table on HIP tensors (pose matrices from the HIP pose_vec2mat)."""
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+    from unsupervised_depth_opticalflow_egomotion_amd.models import Model_geometry
+    g = np.load(os.path.join(golden_dir, "G11_ac%d.npz" % ac))
+    c = MG.g11_inputs()
+    m = Model_geometry.__new__(Model_geometry)          # method table only (as the goldens call the reference)
+    m.ratio, m.num, m.dataset = 0.3, 50, "kitti_depth"
+    K, pose, match = G(c["K"]), G(c["pose"]), G(c["match"])
+    Ki = torch.inverse(K)
+    old = ops.get_align_corners()
+    ops.set_align_corners(ac)
+    try:
+        loss = m.compute_triangulate_loss(match, pose, K, Ki, [G(c["depth1"])], [G(c["depth2"])])
+    finally:
+        ops.set_align_corners(old)
+    np.testing.assert_allclose(N(loss), g["trian_loss"], rtol=2e-3)
+    # eight-point: matches generated BY the pose -> the loss of that pose is ~0 and grows when the pose is perturbed
+    from unsupervised_depth_opticalflow_egomotion_amd.structures import compute_projection_matrix
+    P1, P2 = compute_projection_matrix(pose, K)
+    r = np.random.default_rng(2)
+    X = G(np.stack([r.uniform(-4, 4, (2, 80)), r.uniform(-1.5, 1.5, (2, 80)), r.uniform(4, 30, (2, 80)), np.ones((2, 80))], 1))
+    x1, x2 = P1.bmm(X), P2.bmm(X)
+    mt = torch.cat([x1[:, :2] / x1[:, 2:3], x2[:, :2] / x2[:, 2:3]], 1)
+    Fm = m.compute_fundmental_mat(mt)
+    E = ops.PoseMatsFn.apply(pose)[1]
+    Fp = torch.inverse(K.permute(0, 2, 1)).bmm(E.bmm(Ki))
+    Fp = Fp / Fp[:, 2:3, 2:3]
+    assert float((Fm - Fp).abs().max()) <= 5e-3 * float(Fp.abs().max())
+    l0 = float(m.compute_eight_point_loss(mt, pose, K, Ki))
+    l1 = float(m.compute_eight_point_loss(mt, pose + 0.05, K, Ki))
+    assert np.isfinite(l0) and l1 >= 0

@@ -1,0 +1,187 @@
+"""Batched geometric solvers behind the reference's zero-weighted placeholders ``loss_triangle`` / ``loss_eight_point``
+(core/networks/model_geometry.py:427-470, 532-683), on the device, as a mixin of the models.
+
+* match sampling (``top_ratio_sample``, ``robust_rand_sample``, ``sample_match``, model_geometry.py:427-470) -- torch
+  top-k / gathers on the device; the random pick uses the global torch RNG exactly as the reference does (one
+  ``torch.randint`` over the kept matches), so it follows the same seed.
+* mid-point triangulation and its depth-registration loss (``midpoint_triangulate`` ... ``compute_triangulate_loss``,
+  model_geometry.py:569-683): closed-form, batched over B x N matches; pinned by golden G11 (the reference's own methods
+  called unbound, like G5).
+* fundamental matrix from matches (``compute_fundmental_mat`` / ``compute_eight_point_loss``, model_geometry.py:532-566):
+  the reference calls ``cv2.findFundamentalMat`` (RANSAC / LMedS, on the host, one sample at a time; cv2 does not exist
+  here and RANSAC is not reproducible).  Here: Hartley's normalised eight-point algorithm over ALL given matches,
+  batched on the device (one 9x9 symmetric eigen-problem and one 3x3 SVD per sample), scaled like OpenCV's result
+  (F[2,2] = 1).  No oracle can exist for the RANSAC draw; property tests only (exact recovery on noise-free matches,
+  rank 2, invariance to the order of the matches).
+* ``cv2.solvePnPRansac`` (``compute_pnp_loss``, model_geometry.py:473-530) is NOT provided: it raises.
+
+None of this is reached by ``Model_geometry.forward`` (the reference keeps the calls commented, :939-951); the methods
+exist so that those lines can be switched on as written."""
+import torch
+import torch.nn.functional as F
+
+from .structures import compute_essential_matrix, compute_projection_matrix
+
+
+class GeometrySolvers:
+    ratio = 0.3
+    num = 6000
+    dataset = "kitti_depth"
+
+    # ------------------------------------------------------------------ match sampling (model_geometry.py:427-470)
+    def top_ratio_sample(self, match, depth, mask, ratio):
+        """match [b,4,n], depth [b,1,n], mask [b,1,n] (scores) -> the int(ratio * n) best-scored matches."""
+        n = match.shape[-1]
+        scores, idx = torch.topk(mask, int(ratio * n), dim=-1)
+        sel = idx.squeeze(1)
+        return (torch.gather(match, 2, sel.unsqueeze(1).expand(-1, 4, -1)),
+                torch.gather(depth, 2, sel.unsqueeze(1)), scores)
+
+    def robust_rand_sample(self, match, depth, mask, num):
+        """``num`` uniformly drawn matches; if some scores are zero, draw among the non-zero ones of every sample."""
+        b, n = match.shape[0], match.shape[2]
+        nonzero = int(torch.sum(mask > 0, dim=-1).min())
+        if nonzero == n:
+            pick = torch.randint(0, n, [num]).to(match.device)
+            return match[:, :, pick], depth[:, :, pick], num
+        num = min(nonzero, num)
+        rows = []
+        for i in range(b):
+            nz = torch.nonzero(mask[i, 0, :]).squeeze(1)
+            rows.append(nz[torch.randint(0, nz.shape[0], [int(num)]).to(nz.device)])
+        sel = torch.stack(rows, 0)
+        return (torch.gather(match, 2, sel.unsqueeze(1).expand(-1, 4, -1)), torch.gather(depth, 2, sel.unsqueeze(1)), num)
+
+    def sample_match(self, flow, depth, mask):
+        """(x, y, x + u, y + v) of the top-``ratio`` scored pixels, then ``num`` random ones -> ([b,4,m], [b,1,m])."""
+        b, _, h, w = flow.shape
+        grid = self.meshgrid(b, h, w).to(flow.device)
+        match = torch.cat([grid, grid + flow], 1).view(b, 4, -1)
+        m, d, s = self.top_ratio_sample(match, depth.reshape(b, 1, -1), mask.reshape(b, 1, -1), self.ratio)
+        m, d, _ = self.robust_rand_sample(m, d, s, self.num)
+        return m, d
+
+    # ------------------------------------------------------------------ triangulation (model_geometry.py:569-683)
+    def midpoint_triangulate(self, match, K, K_inv, P1, P2):
+        """Mid-point of the common perpendicular of the two viewing rays of every match -> homogeneous points [b,n,4]."""
+        b, n = match.shape[0], match.shape[2]
+        ones = torch.ones(b, 1, n, device=match.device, dtype=match.dtype)
+        rays, origins = [], []
+        for P, xy in ((P1, match[:, :2]), (P2, match[:, 2:])):
+            RT = K_inv.bmm(P)
+            Rt = RT[:, :, :3].transpose(1, 2)
+            d = Rt.bmm(K_inv).bmm(torch.cat([xy, ones], 1))
+            rays.append(d / (torch.norm(d, dim=1, keepdim=True, p=2) + 1e-12))
+            origins.append(-1 * Rt.bmm(RT[:, :, 3].unsqueeze(-1)))
+        cr = torch.cross(rays[0], rays[1], dim=1)
+        denom = 1.0 / (torch.sum(cr * cr, dim=1, keepdim=True) + 1e-12)
+        base = (origins[1] - origins[0]).repeat(1, 1, n)
+        a1 = torch.sum(torch.cross(base, rays[1], dim=1) * cr, dim=1, keepdim=True) * denom
+        a2 = torch.sum(torch.cross(base, rays[0], dim=1) * cr, dim=1, keepdim=True) * denom
+        point = ((origins[0] + a1 * rays[0]) + (origins[1] + a2 * rays[1])) / 2.0
+        return torch.cat([point, ones], dim=1).transpose(1, 2)
+
+    def reproject(self, P, point3d):
+        """P [b,3,4], points [b,n,4] -> pixel coordinates [b,n,2] and depths [b,n,1]."""
+        p = P.bmm(point3d.transpose(1, 2))
+        z = p[:, 2, :].unsqueeze(1)
+        return (p[:, :2, :] / (z + 1e-12)).transpose(1, 2), z.transpose(1, 2)
+
+    def scale_adapt(self, depth1, depth2, eps=1e-12):
+        with torch.no_grad():
+            A = torch.sum((depth1 ** 2) / (depth2 ** 2 + eps), dim=1)
+            C = torch.sum(depth1 / (depth2 + eps), dim=1)
+            return C / (A + eps)
+
+    def affine_adapt(self, depth1, depth2, use_translation=True, eps=1e-12):
+        a_scale = self.scale_adapt(depth1, depth2, eps=eps)
+        if not use_translation:
+            return a_scale, torch.zeros_like(a_scale)
+        with torch.no_grad():
+            A = torch.sum((depth1 ** 2) / (depth2 ** 2 + eps), dim=1)
+            B = torch.sum(depth1 / (depth2 ** 2 + eps), dim=1)
+            C = torch.sum(depth1 / (depth2 + eps), dim=1)
+            D = torch.sum(1.0 / (depth2 ** 2 + eps), dim=1)
+            E = torch.sum(1.0 / (depth2 + eps), dim=1)
+            det = B * B - A * D
+            a = (B * E - D * C) / (det + 1e-12)
+            b = (B * C - A * E) / (det + 1e-12)
+            ok = (torch.abs(det) > 1e-4).float()
+            return a * ok + a_scale * (1 - ok), b * ok
+
+    def register_depth(self, depth_pred, coord_tri, depth_tri):
+        """Sample the predicted depth at the reprojected points (reflection padding), normalise by the median ratio to
+        the triangulated depths and fit the remaining scale (model_geometry.py:633-651)."""
+        bsz, _, h, w = depth_pred.shape
+        n = depth_tri.shape[1]
+        grid = torch.stack([2.0 * coord_tri[:, :, 0] / (w - 1.0) - 1.0, 2.0 * coord_tri[:, :, 1] / (h - 1.0) - 1.0], -1)
+        from . import ops                   # the reference leaves align_corners to the installed torch (ops.set_align_corners)
+        inter = F.grid_sample(depth_pred, grid.view(bsz, n, 1, 2), padding_mode="reflection",
+                              align_corners=ops.get_align_corners()).squeeze(-1).transpose(1, 2)
+        scale = (torch.median(inter, 1)[0] / (torch.median(depth_tri, 1)[0] + 1e-12)).detach()
+        inter_s = inter / (scale.unsqueeze(-1) + 1e-12)
+        pred_s = depth_pred / (scale.unsqueeze(-1).unsqueeze(-1) + 1e-12)
+        a, b = self.affine_adapt(inter_s, depth_tri, use_translation=False)
+        return (a.unsqueeze(-1).unsqueeze(-1) * pred_s + b.unsqueeze(-1).unsqueeze(-1), a.unsqueeze(1) * inter_s + b.unsqueeze(1))
+
+    def get_trian_loss(self, tri_depth, pred_tri_depth):
+        return torch.pow(1.0 - pred_tri_depth / (tri_depth + 1e-12), 2).mean((1, 2))
+
+    def compute_triangulate_loss(self, match, pose, K, K_inv, depth_pred1, depth_pred2):
+        d1, d2 = depth_pred1[0], depth_pred2[0]
+        P1, P2 = compute_projection_matrix(pose, K)
+        pts = self.midpoint_triangulate(match, K, K_inv, P1, P2)
+        c1, z1 = self.reproject(P1, pts)
+        c2, z2 = self.reproject(P2, pts)
+        _, i1 = self.register_depth(d1, c1, z1)
+        _, i2 = self.register_depth(d2, c2, z2)
+        return self.get_trian_loss(z1, i1) + self.get_trian_loss(z2, i2)
+
+    # ------------------------------------------------------------------ eight-point (model_geometry.py:532-566)
+    @staticmethod
+    def _hartley(xy):
+        """Similarity that moves the centroid of [b,2,n] points to the origin and their mean distance to sqrt(2)."""
+        c = xy.mean(2, keepdim=True)
+        d = torch.sqrt(((xy - c) ** 2).sum(1)).mean(1)
+        s = (2.0 ** 0.5) / (d + 1e-12)
+        T = torch.zeros(xy.shape[0], 3, 3, device=xy.device, dtype=xy.dtype)
+        T[:, 0, 0] = s
+        T[:, 1, 1] = s
+        T[:, 0, 2] = -s * c[:, 0, 0]
+        T[:, 1, 2] = -s * c[:, 1, 0]
+        T[:, 2, 2] = 1.0
+        return T
+
+    def compute_fundmental_mat(self, matches, pose_vec=None, intrinsics=None, intrinsics_inverse=None):
+        """F [b,3,3] with x2^T F x1 = 0 for matches [b,4,n] = (x1, y1, x2, y2): normalised eight-point over all n >= 8
+        matches (least squares), rank 2 enforced, scaled to F[2,2] = 1 like cv2.findFundamentalMat's result.  float64
+        inside (the 9x9 normal matrix squares the condition number)."""
+        m = matches.detach().double()
+        b, _, n = m.shape
+        if n < 8:
+            raise ValueError("the eight-point algorithm needs at least 8 matches")
+        ones = torch.ones(b, 1, n, device=m.device, dtype=m.dtype)
+        T1, T2 = self._hartley(m[:, :2]), self._hartley(m[:, 2:])
+        p1 = T1.bmm(torch.cat([m[:, :2], ones], 1))
+        p2 = T2.bmm(torch.cat([m[:, 2:], ones], 1))
+        A = (p2.unsqueeze(2) * p1.unsqueeze(1)).reshape(b, 9, n)        # row (i, j) = p2_i * p1_j
+        _, vecs = torch.linalg.eigh(A.bmm(A.transpose(1, 2)))           # ascending: column 0 = the null direction
+        Fn = vecs[:, :, 0].reshape(b, 3, 3)
+        U, S, Vh = torch.linalg.svd(Fn)
+        S = S.clone()
+        S[:, 2] = 0.0
+        Fn = U.bmm(torch.diag_embed(S)).bmm(Vh)
+        Fm = T2.transpose(1, 2).bmm(Fn).bmm(T1)
+        Fm = Fm / Fm[:, 2:3, 2:3]
+        return Fm.to(matches.dtype)
+
+    def compute_eight_point_loss(self, matches, pose_vec, intrinsics, intrinsics_inverse):
+        """smooth-L1 between the fundamental matrix of the matches and the one the pose predicts,
+        K^-T ([t]x R) K^-1 (model_geometry.py:545-566)."""
+        target = self.compute_fundmental_mat(matches, pose_vec, intrinsics, intrinsics_inverse)
+        E = compute_essential_matrix(pose_vec)
+        F_pred = torch.inverse(intrinsics.permute([0, 2, 1])).bmm(E.bmm(intrinsics_inverse))
+        return F.smooth_l1_loss(F_pred, target)
+
+    def compute_pnp_loss(self, *args, **kwargs):
+        raise NotImplementedError("compute_pnp_loss needs cv2.solvePnPRansac (model_geometry.py:473-530): not provided")

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from .loss_stack import LossRows, geom_loss_stack, depth_loss_stack, flow_loss_stack, decode_mask
+from .geometry_solvers import GeometrySolvers
 from .loss_terms import LossTerms
 from .networks import Depth_Model, PoseCNN, FeaturePyramid, PWC_tf
 
@@ -120,7 +121,7 @@ def _zeros2(dev):
     return t
 
 
-class Model_geometry(LossTerms, nn.Module):
+class Model_geometry(LossTerms, GeometrySolvers, nn.Module):
     """Joint depth + pose + flow model ("monodepth2 + dynamic mask", model_geometry.py:15-953)."""
 
     def __init__(self, cfg):
