@@ -436,35 +436,3 @@ def test_full_size_properties():
         for k in m:
             u = torch.unique(m[k][s])
             assert set(u.tolist()) <= {0.0, 1.0}, k
-
-
-def _run_with_env(inp, name, value, S=3):
-    old = os.environ.get(name)
-    if value is None:
-        os.environ.pop(name, None)
-    else:
-        os.environ[name] = value
-    try:
-        lp, mk, tot, (d, p, fb, ff) = run_hip(inp, False, S)
-        torch.cuda.synchronize()
-        g = lambda t: None if t.grad is None else N(t.grad)   # noqa: E731  (the fourth flow level feeds no loss)
-        return ({k: N(v) for k, v in lp.items()}, {k: [N(t) for t in v] for k, v in mk.items()},
-                [[g(t) for t in lst] for lst in d], g(p), [g(t) for t in fb], [g(t) for t in ff])
-    finally:
-        if old is None:
-            os.environ.pop(name, None)
-        else:
-            os.environ[name] = old
-
-
-@pytest.mark.parametrize("shape", [(2, 64, 208), (4, 256, 832)])
-def test_rolling_upsampling_adjoint_is_the_gather_bit_for_bit(shape):
-    """k_geom_disp_smooth_bwd2_roll (interior of exact 1/2, 1/4 levels, one coalesced read of the up-sampled gradients)
-    against the thread-per-pixel gather it replaces (DFE_DSM_BWD2_GATHER=1): same taps, weights and summation order,
-    so every disparity gradient is bit-identical."""
-    inp = synthetic.make_loss_stack_inputs(*shape, 3, seed=41)
-    a = _run_with_env(inp, "DFE_DSM_BWD2_GATHER", None)
-    b = _run_with_env(inp, "DFE_DSM_BWD2_GATHER", "1")
-    for f in range(3):
-        for s in range(3):
-            assert np.array_equal(a[2][f][s], b[2][f][s]), (f, s, float(np.abs(a[2][f][s] - b[2][f][s]).max()))

@@ -391,19 +391,15 @@ def test_network_streams_do_not_change_results():
         total_loss(lp, cfg).backward()
         torch.cuda.synchronize()
         return torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
-    a, a2, b, c = one_step(1), one_step(1), one_step(3), one_step(6)
+    a, a2, b = one_step(1), one_step(1), one_step(3)
     scale = float(a.abs().max())
     noise = float((a2 - a).abs().max())
-    diff, diff6 = float((b - a).abs().max()), float((c - a).abs().max())
-    print("\nstreams: grad scale %.3e, single-stream run-to-run %.3e, 3 streams vs 1 %.3e, 6 (weight-gradient streams) vs 1 %.3e"
-          % (scale, noise, diff, diff6))
+    diff = float((b - a).abs().max())
+    print("\nstreams: grad scale %.3e, single-stream run-to-run %.3e, 3 streams vs 1 %.3e" % (scale, noise, diff))
     assert diff <= max(4.0 * noise, 2e-6 * scale), (diff, noise, scale)
-    assert diff6 <= max(4.0 * noise, 2e-6 * scale), (diff6, noise, scale)
     l1, _ = _three_steps(1)
     l3, _ = _three_steps(3)
-    l6, _ = _three_steps(6)
     np.testing.assert_allclose(l3, l1, rtol=2e-5)
-    np.testing.assert_allclose(l6, l1, rtol=2e-5)
 
 
 def test_amp_bf16_mode_is_opt_in_and_close_to_fp32():
@@ -481,7 +477,7 @@ def test_bench_gpus_flag_launches_the_ranks_itself():
     assert j["multi_gpu"]["rccl_ranks"] == 2 and j["multi_gpu"]["param_checksums_equal"] is True
     # under a profiler preload the GPU is already initialised in this process: it must not start ranks
     out = subprocess.run(base + ["--gpus", "2", "--backend", "gloo"], capture_output=True, text=True, cwd=repo,
-                         env=dict(clean, DFE_BENCH_ALL_ON_DEVICE0="1", ROCP_TOOL_LIBRARIES="/opt/rocm/lib/librocprofiler-sdk-tool.so"), timeout=300)
+                         env=dict(clean, DFE_BENCH_ALL_ON_DEVICE0="1", LD_PRELOAD="/nonexistent/librocprofiler-sdk-tool.so"), timeout=300)   # ld.so warns and carries on
     assert out.returncode == 4 and "profiler" in out.stderr
     if torch.cuda.device_count() < 2:
         out = subprocess.run(base + ["--gpus", "2"], capture_output=True, text=True, cwd=repo, env=clean, timeout=300)

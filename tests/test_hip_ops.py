@@ -808,31 +808,3 @@ def test_conv_bf16_compute_dtype():
     for a, c in zip((y1,) + g1, (y0,) + g0):
         assert float((a - c).abs().max()) <= 2e-2 * float(c.abs().max())
     assert float((y1 - y0).abs().max()) > 0      # it really ran in reduced precision
-
-
-def test_weight_gradient_streams_give_the_same_gradients():
-    """convs.weight_grad_streams: a convolution recorded as two autograd nodes (data gradient in line, weight gradient by
-    an identity node on the weight that lives on a side stream) returns the gradients of F.conv2d -- same MIOpen calls,
-    only enqueued elsewhere -- for a chain of layers, with and without bias, also under the bf16 compute dtype."""
-    from unsupervised_depth_opticalflow_egomotion_amd import convs
-    torch.manual_seed(5)
-    x = torch.randn(2, 16, 24, 40, device=dev(), requires_grad=True)
-    ws = [(0.1 * torch.randn(32, 16, 3, 3, device=dev())).requires_grad_(True), (0.1 * torch.randn(8, 32, 3, 3, device=dev())).requires_grad_(True)]
-    b = torch.randn(8, device=dev(), requires_grad=True)
-    r = torch.randn(2, 8, 24, 40, device=dev())
-
-    def net(split, dt=None):
-        with convs.weight_grad_streams(split), convs.compute_dtype(dt):
-            h = torch.relu(convs.conv2d(x, ws[0], None, 1, 1))
-            y = convs.conv2d(h, ws[1], b, 1, 2, 2)
-            g = torch.autograd.grad((y * r).sum(), [x] + ws + [b])
-        torch.cuda.synchronize()
-        return [y] + list(g)
-    ref = net(False)
-    got = net(True)
-    for a, c in zip(got, ref):
-        assert a.shape == c.shape and float((a - c).abs().max()) <= 1e-6 * max(float(c.abs().max()), 1.0)
-    assert not convs._WG["pending"]                     # every parked weight gradient was consumed
-    ref16, got16 = net(False, torch.bfloat16), net(True, torch.bfloat16)
-    for a, c in zip(got16, ref16):
-        assert float((a - c).abs().max()) <= 1e-6 * max(float(c.abs().max()), 1.0)

@@ -96,119 +96,12 @@ class _ConvFn(torch.autograd.Function):
         return gx, gw, None, None, None
 
 
-# ------------------------------------------------------------------------------------------------ weight-gradient streams
-# A convolution's weight gradient is needed by nobody until the optimiser step, yet autograd's ConvolutionBackward
-# computes it in line with the data gradient, in the middle of the backward pass's critical path.  With
-# ``weight_grad_streams(True)`` every convolution that goes through this module is recorded as TWO autograd nodes: the
-# convolution itself (its backward returns the data gradient and parks (gy, x)) and an identity on the weight that was
-# applied under a side stream -- autograd replays a node's backward on the stream its forward ran on, so that node's
-# backward, which computes the parked weight gradient, is enqueued on the side stream, ordered after the data-gradient
-# node by the engine's own events, and the gradient accumulation on the leaf waits for it.  No manual synchronisation.
-_WG = {"on": False, "streams": {}, "pending": {}, "seq": 0}
-
-
-@contextlib.contextmanager
-def weight_grad_streams(on=True):
-    old = _WG["on"]
-    _WG["on"] = bool(on)
-    try:
-        yield
-    finally:
-        _WG["on"] = old
-
-
-def _wg_stream(dev):
-    """The weight-gradient stream that belongs to the CURRENT compute stream (one per network chain)."""
-    cur = torch.cuda.current_stream(dev)
-    key = (dev.index, cur.cuda_stream)
-    st = _WG["streams"].get(key)
-    if st is None:
-        st = _WG["streams"][key] = torch.cuda.Stream(dev)
-    return st
-
-
-class _WeightOnStream(torch.autograd.Function):
-    """Identity on a weight tensor, applied under the weight-gradient stream; its backward computes the weight gradient
-    parked under ``key`` by the consumer's backward (``park_weight_grad``)."""
-
-    @staticmethod
-    def forward(ctx, w, key):
-        ctx.key = key
-        return w.view_as(w)
-
-    @staticmethod
-    def backward(ctx, _placeholder):
-        job = _WG["pending"].pop(ctx.key, None)
-        if job is None:               # the consumer produced no gradient for this weight
-            return None, None
-        fn, tensors = job
-        st = torch.cuda.current_stream()
-        for t in tensors:
-            t.record_stream(st)       # produced on the network's stream, read here
-        return fn(), None
-
-
-def weight_on_stream(w):
-    """(alias of w whose gradient is computed on the weight-gradient stream, key) -- or (w, None) when the mode is off."""
-    if not (_WG["on"] and w.is_cuda and w.requires_grad and torch.is_grad_enabled()):
-        return w, None
-    _WG["seq"] += 1
-    key = _WG["seq"]
-    with torch.cuda.stream(_wg_stream(w.device)):
-        w2 = _WeightOnStream.apply(w, key)
-    return w2, key
-
-
-def park_weight_grad(key, w, fn, tensors):
-    """Called from a consumer's backward: defer ``fn() -> gw`` (reading ``tensors``) to ``w``'s weight-gradient node and
-    return the placeholder the consumer hands to autograd as w's gradient (right shape, no memory)."""
-    _WG["pending"][key] = (fn, tensors)
-    return torch.zeros((), device=w.device, dtype=w.dtype).expand(w.shape)
-
-
-class _ConvSplitFn(torch.autograd.Function):
-    """conv2d without bias whose backward returns the data gradient and parks the weight gradient (see above)."""
-
-    @staticmethod
-    def forward(ctx, x, w2, key, stride, padding, dilation):
-        dt = _STATE["dtype"]
-        ctx.cfg = (key, stride, padding, dilation, dt)
-        xs = x if dt is None else x.to(dt)     # cast once: the forward, the data gradient and the weight gradient share it
-        y = raw_forward(xs, w2, stride, padding, dilation)
-        ctx.save_for_backward(xs, w2)
-        return y
-
-    @staticmethod
-    def backward(ctx, gy):
-        x, w2 = ctx.saved_tensors
-        key, stride, padding, dilation, dt = ctx.cfg
-        gy = gy.contiguous() if dt is None else gy.to(dt)
-        gx = None
-        with compute_dtype(dt):
-            if ctx.needs_input_grad[0]:
-                gx = raw_backward(gy, x, w2, stride, padding, dilation, True, False)[0]
-        gw = None
-        if ctx.needs_input_grad[1]:
-            def run():
-                with compute_dtype(dt):
-                    return raw_backward(gy, x, w2, stride, padding, dilation, False, True)[1]
-            gw = park_weight_grad(key, w2, run, (gy, x))
-        return gx, gw, None, None, None, None
-
-
 def conv2d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1):
-    """``F.conv2d``; in the reduced compute dtype when one is set, with the weight gradient on its own stream when
-    ``weight_grad_streams`` is on (HIP tensors, groups == 1)."""
+    """``F.conv2d``; in the reduced compute dtype when one is set (HIP tensors, groups == 1)."""
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
-    if not (x.is_cuda and groups == 1):
+    if not (x.is_cuda and groups == 1 and _STATE["dtype"] is not None):
         return F.conv2d(x, w, bias, stride, padding, dilation, groups)
-    w2, key = weight_on_stream(w)
-    if key is not None:
-        y = _ConvSplitFn.apply(x, w2, key, stride, padding, dilation)
-    elif _STATE["dtype"] is not None:
-        y = _ConvFn.apply(x, w, stride, padding, dilation)
-    else:
-        return F.conv2d(x, w, bias, stride, padding, dilation, groups)
+    y = _ConvFn.apply(x, w, stride, padding, dilation)
     return y if bias is None else y + bias.view(1, -1, 1, 1)
 
 

@@ -654,72 +654,12 @@ __device__ __forceinline__ float adj_pow2(const float* __restrict__ gu, int W, i
   return total;
 }
 
-// Rolling form of the same adjoint for the INTERIOR low-res pixels of an exact 1/NR pyramid level (NR = 2, 4): a wave
-// owns 64 full-resolution columns and marches down the rows, reading every up-sampled gradient ONCE with one coalesced
-// dword per lane (the thread-per-low-res-pixel gather above requests every value four times through strided loads:
-// 16 / 32 vector-memory instructions per output).  Horizontal tent sums by DPP wave shifts -- valid at every NR-th
-// lane --, vertical tent sums in two rolling accumulators (a full-res row feeds the lower half of one output row and the
-// upper half of the previous one).  Same taps, weights and summation order as adj_pow2: bit-identical results.
-// grid: x = strips x row blocks, y = f*B + b; block = one wave; one launch per eligible scale.
-constexpr int DSR_OUT_ROWS = 8;      // low-res output rows per wave
-
-template <int NR>
-__global__ void __launch_bounds__(64) k_geom_disp_smooth_bwd2_roll(GeomDev D, GeomBwd G, int s, int strips) {
-  constexpr int NT = 2 * NR, NJ = 64 / NR - 1;
-  const int f = blockIdx.y / D.B, b = blockIdx.y - f * D.B;
-  if (!G.gdisp[f][s]) return;
-  const unsigned unit = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int strip = unit % strips, rbk = unit / strips;
-  const int Hs = D.H[s], Ws = D.W[s], Ns = D.N[s], W = D.W[0], N = D.N[0];
-  const int lane = threadIdx.x;
-  const int J0 = 1 + strip * NJ, I0 = 1 + rbk * DSR_OUT_ROWS;
-  const int I1 = min(I0 + DSR_OUT_ROWS, Hs - 1);                 // interior rows [I0, I1)
-  const int x = min(NR * J0 - NR / 2 + lane, W - 1);              // clamped: lanes past the image feed no valid output
-  const int j = J0 + lane / NR;
-  const bool out_lane = (lane % NR == 0) && (lane / NR < NJ) && j <= Ws - 2;
-  const float* gu = G.gup + ((static_cast<long>(f) * (D.S - 1) + (s - 1)) * D.B + b) * N + x;
-  float* o = G.gdisp[f][s] + static_cast<long>(b) * Ns + j;
-  const bool rmw = f == 1 || G.rmw_all;
-  float w[NT];
-#pragma unroll
-  for (int k = 0; k < NT; ++k) w[k] = (k < NR) ? (2.0f * k + 1.0f) / (2.0f * NR) : (2.0f * (NT - 1 - k) + 1.0f) / (2.0f * NR);
-  // rows y = NR * i - NR/2 + ky; group r holds the NR rows NR * i' - NR/2 .. + NR - 1 with i' = I0 + r (r = 0 .. I1-I0).
-  // ALL groups are loaded before any arithmetic (NR * (DSR_OUT_ROWS + 1) independent loads per lane): the march is a
-  // dependency chain of memory latencies otherwise (measured: one group of prefetch -> 38 us against the gather's 24).
-  constexpr int NG = DSR_OUT_ROWS + 1;
-  float g[NG][NR];
-  const int ngroups = I1 - I0 + 1;           // the last group only completes output I1 - 1
-#pragma unroll
-  for (int r = 0; r < NG; ++r) {
-    const int y0 = NR * min(I0 + r, Hs - 1) - NR / 2;       // groups past the block's end repeat a valid row (unused)
-#pragma unroll
-    for (int k = 0; k < NR; ++k) g[r][k] = gu[static_cast<long>(y0 + k) * W];
-  }
-  float cur = 0.0f, nxt = 0.0f;
-#pragma unroll
-  for (int r = 0; r < NG; ++r) {
-    const int ip = I0 + r;
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      // horizontal tent sum starting at this lane: acc = sum_kx w[kx] * g(lane + kx), kx ascending
-      float sh = g[r][k], acc = 0.0f;
-#pragma unroll
-      for (int kx = 0; kx < NT; ++kx) {
-        acc += w[kx] * sh;
-        if (kx + 1 < NT) sh = wave_shl1(sh);
-      }
-      cur += w[k + NR] * acc;               // output row ip - 1, taps NR .. 2NR-1
-      nxt += w[k] * acc;                    // output row ip, taps 0 .. NR-1
-    }
-    if (r > 0 && r < ngroups && out_lane) { // output row ip - 1 is complete
-      float* dst = o + static_cast<long>(ip - 1) * Ws;
-      if (rmw) *dst += cur; else *dst = cur;
-    }
-    cur = nxt; nxt = 0.0f;
-  }
-}
-
-__global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_bwd2(GeomDev D, GeomBwd G, int roll_mask) {
+// Measured and rejected in round 3: a rolling form of this adjoint for the interior of exact 1/2 and 1/4 levels (a wave
+// marches down 64 full-resolution columns, every up-sampled gradient read once with a coalesced dword per lane, tent sums
+// by DPP shifts and two rolling accumulators; bit-identical results) plus this kernel for the border ring: 36-38 us
+// against 23.8 us here -- three launches instead of one, 18 / 36 dependent rows per wave and only every 2nd / 4th lane
+// producing an output, against 16-32 independent loads per thread below.
+__global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_bwd2(GeomDev D, GeomBwd G) {
   const unsigned blk = blockIdx.x + D.blk_start[1];
   const int f = blockIdx.y / D.B, b = blockIdx.y - f * D.B;
   const int s = find_scale(D.blk_start, D.S, blk);
@@ -746,7 +686,6 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_disp_smooth_bwd2(GeomDev D, G
   float* o = G.gdisp[f][s] + static_cast<long>(b) * Ns + static_cast<long>(i) * Ws + j;
   const int nr = H / Hs;
   if ((nr == 2 || nr == 4) && Hs * nr == H && Ws * nr == W && i >= 1 && i < Hs - 1 && j >= 1 && j < Ws - 1) {
-    if (roll_mask & (1 << s)) return;          // k_geom_disp_smooth_bwd2_roll owns the interior of this scale
     const float t = nr == 2 ? adj_pow2<2>(gu, W, 2 * i - 1, 2 * j - 1) : adj_pow2<4>(gu, W, 4 * i - 2, 4 * j - 2);
     if (f == 1 || G.rmw_all) *o += t; else *o = t;
     return;
@@ -1037,24 +976,8 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   DFE_LAUNCH_CHECK();
   DFE_MARK();
   if (L.S > 1) {
-    // exact 1/2 and 1/4 levels: interior by the rolling kernel, the border ring (clamped taps) by the gather kernel
-    int roll_mask = 0;
-    if (getenv("DFE_DSM_BWD2_GATHER") == nullptr)
-      for (int s = 1; s < L.S; ++s) {
-        const int nr = L.H[0] / L.H[s];
-        if ((nr == 2 || nr == 4) && L.H[s] * nr == L.H[0] && L.W[s] * nr == L.W[0] && L.H[s] >= 3 && L.W[s] >= 3) roll_mask |= 1 << s;
-      }
-    k_geom_disp_smooth_bwd2<<<dim3(nblk_total - L.blk_start[1], 3 * L.B), GS_BLOCK, 0, st>>>(D, G, roll_mask);
+    k_geom_disp_smooth_bwd2<<<dim3(nblk_total - L.blk_start[1], 3 * L.B), GS_BLOCK, 0, st>>>(D, G);
     DFE_LAUNCH_CHECK();
-    for (int s = 1; s < L.S; ++s) {
-      if (!(roll_mask & (1 << s))) continue;
-      const int nr = L.H[0] / L.H[s], nj = 64 / nr - 1;
-      const int strips = (L.W[s] - 2 + nj - 1) / nj, rblocks = (L.H[s] - 2 + DSR_OUT_ROWS - 1) / DSR_OUT_ROWS;
-      const dim3 g(strips * rblocks, 3 * L.B);
-      if (nr == 2) k_geom_disp_smooth_bwd2_roll<2><<<g, 64, 0, st>>>(D, G, s, strips);
-      else k_geom_disp_smooth_bwd2_roll<4><<<g, 64, 0, st>>>(D, G, s, strips);
-      DFE_LAUNCH_CHECK();
-    }
     // scales coarser than 1/4 (H_s = int(H / 2^s), so the ratio is 2^s or slightly above): wave-per-pixel gather
     int s0 = 1;
     while (s0 < L.S && L.H[0] <= 4 * L.H[s0] && L.W[0] <= 4 * L.W[s0]) ++s0;

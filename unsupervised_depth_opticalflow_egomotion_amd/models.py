@@ -102,7 +102,7 @@ _DEFAULT_NET_STREAMS = int(__import__("os").environ.get("DFE_NET_STREAMS", "3"))
 def _side_streams(dev):
     key = (dev.type, dev.index)
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        _SIDE_STREAMS[key] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
     return _SIDE_STREAMS[key]
 
 
@@ -162,7 +162,11 @@ class Model_geometry(LossTerms, GeometrySolvers, nn.Module):
         coarse pyramid levels launch grids far smaller than 256 CUs (512->512 at 8x26 x 12 images: 80 workgroups) and
         leave most of the chip idle when the nets run one after the other.  autograd replays every backward node on
         the stream of its forward op, so the backward passes overlap the same way.  Results are identical (same
-        kernels, same order within a net)."""
+        kernels, same order within a net).  Measured (MI355X, B=4): 32.4 -> 27.4 ms per step.  Measured and rejected in
+        round 3: also taking the depth net off the current stream and giving every convolution's weight gradient a node
+        and a stream of its own (two autograd nodes per convolution, so that no backward chain waits for a weight
+        gradient): 28.8-29.7 ms -- ~90 more nodes and stream switches per step on the host, and the split
+        data- / weight-gradient calls cost more than the joint ones."""
         n_streams = int(getattr(self, "net_streams", _DEFAULT_NET_STREAMS)) if img.is_cuda else 1
         if n_streams <= 1:
             disp_l, disp_t, disp_r = _depth_frames(self.depth_net, img_l, img, img_r, batched)
@@ -170,31 +174,20 @@ class Model_geometry(LossTerms, GeometrySolvers, nn.Module):
             flows_bwd, flows_fwd = _flow_branches(self.fpyramid, self.pwc_model, img_l, img, img_r)
             return disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd
         main = torch.cuda.current_stream(img.device)
-        s_flow, s_pose, s_depth = _side_streams(img.device)
-        # net_streams >= 4: the depth net leaves the current stream too and every convolution's weight gradient gets a
-        # stream of its own per network (convs.weight_grad_streams): the current stream then only carries the loss stack
-        # and the leaves' gradient accumulation, and no network's backward chain waits for a weight gradient.
-        split = n_streams >= 4 and self.training
-        s_depth = s_depth if split else main
-        from . import convs
-        for st in (s_flow, s_pose) + ((s_depth,) if split else ()):
-            st.wait_stream(main)
-            for t in (img_l, img, img_r) + ((batched,) if batched is not None else ()):
-                t.record_stream(st)
-        with convs.weight_grad_streams(split):
-            with torch.cuda.stream(s_flow):
-                flows_bwd, flows_fwd = _flow_branches(self.fpyramid, self.pwc_model, img_l, img, img_r)
-            with torch.cuda.stream(s_pose):
-                pose = self.pose_net(torch.cat([img_l, img, img_r], 1))
-            with torch.cuda.stream(s_depth):
-                disp_l, disp_t, disp_r = _depth_frames(self.depth_net, img_l, img, img_r, batched)
-        outs = list(flows_bwd) + list(flows_fwd) + [pose]
+        s_flow, s_pose = _side_streams(img.device)
+        s_flow.wait_stream(main)
+        s_pose.wait_stream(main)
+        for t in (img_l, img, img_r):
+            t.record_stream(s_flow)
+            t.record_stream(s_pose)
+        with torch.cuda.stream(s_flow):
+            flows_bwd, flows_fwd = _flow_branches(self.fpyramid, self.pwc_model, img_l, img, img_r)
+        with torch.cuda.stream(s_pose):
+            pose = self.pose_net(torch.cat([img_l, img, img_r], 1))
+        disp_l, disp_t, disp_r = _depth_frames(self.depth_net, img_l, img, img_r, batched)
         main.wait_stream(s_flow)
         main.wait_stream(s_pose)
-        if split:
-            main.wait_stream(s_depth)
-            outs += [t for lst in (disp_l, disp_t, disp_r) for t in lst]
-        for t in outs:
+        for t in list(flows_bwd) + list(flows_fwd) + [pose]:
             t.record_stream(main)       # produced on a side stream, consumed by the loss stack on this one
         return disp_l, disp_t, disp_r, pose, flows_bwd, flows_fwd
 
@@ -314,7 +307,7 @@ class Model_depth(LossTerms, nn.Module):
         if img.is_cuda and int(getattr(self, "net_streams", _DEFAULT_NET_STREAMS)) > 1:
             # the pose net beside the depth net (see Model_geometry.run_networks)
             main = torch.cuda.current_stream(img.device)
-            _, s_pose, _ = _side_streams(img.device)
+            _, s_pose = _side_streams(img.device)
             s_pose.wait_stream(main)
             for t in (img_l, img, img_r):
                 t.record_stream(s_pose)

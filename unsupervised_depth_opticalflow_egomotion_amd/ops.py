@@ -590,11 +590,10 @@ class DenseDecodeFn(torch.autograd.Function):
     place (``dfe_bias_act_bwd2``): no slice copies, no gradient-accumulation adds.  Same arithmetic as the composition."""
 
     @staticmethod
-    def forward(ctx, slope, x, keys, *wb):
+    def forward(ctx, slope, x, *wb):
         import torch.nn.functional as F
         lib = get_lib()
         x = f32c(x)
-        ctx.keys = keys                                    # weight-gradient stream keys (convs.weight_on_stream), or Nones
         w, b = list(wb[0:12:2]), list(wb[1:12:2])          # conv_0..conv_4, predict_flow
         B, _, H, W = x.shape
         HW = H * W
@@ -637,23 +636,11 @@ class DenseDecodeFn(torch.autograd.Function):
         HW = H * W
         dev = x.device
         st = stream_ptr()
-        need = ctx.needs_input_grad          # (slope, x, keys, w0, b0, ..., wp, bp)
-        nw = lambda k: bool(need[3 + 2 * k])
-        nb = lambda k: bool(need[4 + 2 * k])
-        keys = ctx.keys
-
-        def cb(g, inp, k, want_in, want_b=False):
-            """(d/d input, d/d weight, d/d bias) of layer k.  With weight-gradient streams on (convs.py) the weight
-            gradient is parked for the weight's own autograd node, which runs on the side stream."""
-            wt = w[k]
-            dt = convs.get_compute_dtype()
-            if dt is not None:               # cast once for the data- and the weight-gradient call
-                g, inp = g.to(dt), inp.to(dt)
-            if nw(k) and keys[k] is not None:
-                gin, _, gb = convs.raw_backward(g, inp, wt, 1, 1, 1, want_in, False, want_b) if (want_in or want_b) else (None, None, None)
-                gwk = convs.park_weight_grad(keys[k], wt, lambda: convs.raw_backward(g, inp, wt, 1, 1, 1, False, True)[1], (g, inp))
-                return gin, gwk, gb
-            return convs.raw_backward(g, inp, wt, 1, 1, 1, want_in, nw(k), want_b)
+        need = ctx.needs_input_grad          # (slope, x, w0, b0, ..., wp, bp)
+        nw = lambda k: bool(need[2 + 2 * k])
+        nb = lambda k: bool(need[3 + 2 * k])
+        def cb(g, inp, wt, want_in, want_w, bias_sizes=None, want_b=False):
+            return convs.raw_backward(g, inp, wt, 1, 1, 1, want_in, want_w, want_b)
 
         def epilogue_bwd(k, ysrc, y_off, g1, g1_off, g2, g2_off):
             c = co[k]
@@ -671,7 +658,7 @@ class DenseDecodeFn(torch.autograd.Function):
         gw, gbias = [None] * 6, [None] * 6
         if g_flow is not None:
             g_flow = f32c(g_flow)
-            g3, gw[5], gbias[5] = cb(g_flow, cat[3], 5, True, nb(5))       # d/d cat(x3, x4)
+            g3, gw[5], gbias[5] = cb(g_flow, cat[3], w[5], True, nw(5), [2], nb(5))       # d/d cat(x3, x4)
         else:
             g3 = torch.zeros_like(cat[3])
         if g_x4 is not None:     # usually a channel slice of the gradient of torch.cat([flow, x4]): read in place
@@ -679,29 +666,27 @@ class DenseDecodeFn(torch.autograd.Function):
                                                    and g_x4.stride(0) >= co[4] * HW):
                 g_x4 = f32c(g_x4)
         gz, gbias[4] = epilogue_bwd(4, cat[3], co[3], g3, co[3], g_x4, 0)                 # x4: cat3 slice + the returned copy
-        g2, gw[4], _ = cb(gz, cat[2], 4, True)                                  # d/d cat(x2, x3)
+        g2, gw[4], _ = cb(gz, cat[2], w[4], True, nw(4))                                  # d/d cat(x2, x3)
         gz, gbias[3] = epilogue_bwd(3, cat[3], 0, g3, 0, g2, co[2])                       # x3
-        g1, gw[3], _ = cb(gz, cat[1], 3, True)                                  # d/d cat(x1, x2)
+        g1, gw[3], _ = cb(gz, cat[1], w[3], True, nw(3))                                  # d/d cat(x1, x2)
         gz, gbias[2] = epilogue_bwd(2, cat[2], 0, g2, 0, g1, co[1])                       # x2
-        g0, gw[2], _ = cb(gz, cat[0], 2, True)                                  # d/d cat(x0, x1)
+        g0, gw[2], _ = cb(gz, cat[0], w[2], True, nw(2))                                  # d/d cat(x0, x1)
         gz, gbias[1] = epilogue_bwd(1, cat[1], 0, g1, 0, g0, co[0])                       # x1
-        gx0, gw[1], _ = cb(gz, x0, 1, True)                                     # d/d x0 through conv_1
+        gx0, gw[1], _ = cb(gz, x0, w[1], True, nw(1))                                     # d/d x0 through conv_1
         gz, gbias[0] = epilogue_bwd(0, cat[0], 0, g0, 0, gx0, 0)                          # x0
-        gx, gw[0], _ = cb(gz, x, 0, bool(need[1]))
-        out = [None, gx, None]
+        gx, gw[0], _ = cb(gz, x, w[0], bool(need[1]), nw(0))
+        out = [None, gx]
         for k in range(6):
             out += [gw[k], gbias[k]]
         return tuple(out)
 
 
-def dense_decode(x, convs_, predict_flow, slope=0.1):
+def dense_decode(x, convs, predict_flow, slope=0.1):
     """(flow, x4) of one PWC decoder level; ``convs``: the five Conv2d modules, ``predict_flow``: the 3x3 flow head."""
-    wb, keys = [], []
-    for c in list(convs_) + [predict_flow]:
-        w2, key = convs.weight_on_stream(c.weight)
-        wb += [w2, c.bias]
-        keys.append(key)
-    return DenseDecodeFn.apply(float(slope), x, tuple(keys), *wb)
+    wb = []
+    for c in list(convs) + [predict_flow]:
+        wb += [c.weight, c.bias]
+    return DenseDecodeFn.apply(float(slope), x, *wb)
 
 
 # --------------------------------------------------------------------------- grouped BatchNorm (+ residual + ReLU)
@@ -814,9 +799,8 @@ class ThinConv3x3Fn(torch.autograd.Function):
         return weight.shape[0] == 16 and weight.shape[1] == 16
 
     @staticmethod
-    def forward(ctx, p, weight, key=None):
+    def forward(ctx, p, weight):
         ctx.save_for_backward(p, weight)
-        ctx.key = key               # weight-gradient stream key (convs.weight_on_stream) or None
         if not ThinConv3x3Fn._mfma_passes(p, weight):
             return convs.raw_forward(p, weight)
         lib = get_lib()
@@ -842,13 +826,10 @@ class ThinConv3x3Fn(torch.autograd.Function):
             else:
                 gp = convs.raw_backward(gy, p, weight, 1, 0, 1, True, False)[0]
         if ctx.needs_input_grad[1]:
-            def wgrad():
-                g = torch.empty_like(weight)
-                part = torch.empty(lib.dfe_wgrad3x3_partials_floats(B, Ci, Co, H, W), device=p.device)
-                check(lib.dfe_wgrad3x3_fwd(ptr(p), ptr(gy), ptr(g), ptr(part), B, Ci, Co, H, W, stream_ptr()), "dfe_wgrad3x3_fwd")
-                return g
-            gw = convs.park_weight_grad(ctx.key, weight, wgrad, (p, gy)) if ctx.key is not None else wgrad()
-        return gp, gw, None
+            gw = torch.empty_like(weight)
+            part = torch.empty(lib.dfe_wgrad3x3_partials_floats(B, Ci, Co, H, W), device=p.device)
+            check(lib.dfe_wgrad3x3_fwd(ptr(p), ptr(gy), ptr(gw), ptr(part), B, Ci, Co, H, W, stream_ptr()), "dfe_wgrad3x3_fwd")
+        return gp, gw
 
 
 def thin_conv3x3_eligible(p, weight):
@@ -863,6 +844,5 @@ def thin_conv3x3_eligible(p, weight):
 def conv3x3_valid(p, weight):
     """3x3 convolution without padding or bias of a pre-padded activation (the decoder's ConvBlock convolutions)."""
     if thin_conv3x3_eligible(p, weight):
-        w2, key = convs.weight_on_stream(weight)
-        return ThinConv3x3Fn.apply(p, w2, key)
+        return ThinConv3x3Fn.apply(p, weight)
     return convs.conv2d(p, weight)
