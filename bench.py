@@ -277,7 +277,8 @@ class TrainStepWorkload:
 # from tools/byte_models.py, the same table tools/roofline_table.py prices the rocprof runs with
 from tools import byte_models  # noqa: E402
 
-POINT_LIMITER = {"geom": "vector-instruction issue (VALU + vector-memory instruction counts add up; working set is Infinity-Cache resident at B=4)"}
+POINT_LIMITER = {"geom": "VALU issue (870 instructions per pixel, ~5 cycles each) when the flows are smooth, the gathers' 128-byte line count when "
+                          "they are rough; Infinity-Cache resident at B=4 (profiles/r03_point_fwd_ablation.md)"}
 HBM_ACHIEVABLE_GBS = 6290.0    # measured float4 copy rate (MI355X_MICROARCH.md)
 KERNEL_SOURCES = ("loss_stack_fwd.hip", "loss_stack.h", "loss_stack_exact.h", "dfe_device.h")
 
