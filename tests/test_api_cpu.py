@@ -464,3 +464,36 @@ def test_eight_point_properties():
     np.testing.assert_allclose(GeometrySolvers().compute_fundmental_mat(m[:, :, perm]).numpy(), est, rtol=1e-3, atol=1e-5)
     noisy = GeometrySolvers().compute_fundmental_mat(m + 0.2 * torch.randn_like(m)).numpy()
     assert np.isfinite(noisy).all()
+
+
+def test_pnp_properties():
+    """pnp (batched Levenberg-Marquardt on SE(3); stands in for cv2.solvePnPRansac + solvePnP): exact recovery of a known
+    pose from noise-free 3-D / 2-D correspondences, from the identity and from a perturbed start, in the reference's
+    (T, axis-angle) output convention; small noise moves the answer by a comparable amount."""
+    from unsupervised_depth_opticalflow_egomotion_amd.geometry_solvers import GeometrySolvers as GS
+    r = np.random.default_rng(8)
+    b, n = 3, 120
+    K = torch.tensor([[480.0, 0, 416], [0, 490, 128], [0, 0, 1]])
+    w = torch.from_numpy(0.08 * r.standard_normal((b, 3))).float()
+    T = torch.from_numpy(np.array([[0.5, 0.05, 0.1]]) + 0.1 * r.standard_normal((b, 3))).float()
+    R = GS._so3_exp(w.double())
+    X = torch.from_numpy(np.stack([r.uniform(-4, 4, (b, n)), r.uniform(-1.5, 1.5, (b, n)), r.uniform(4, 30, (b, n))], 2))
+    Y = X.bmm(R.transpose(1, 2)) + T.double().unsqueeze(1)
+    x = torch.stack([480 * Y[:, :, 0] / Y[:, :, 2] + 416, 490 * Y[:, :, 1] / Y[:, :, 2] + 128], 2)
+    np.testing.assert_allclose(GS._so3_log(R).numpy(), w.double().numpy(), atol=1e-9)
+    est = GS().pnp(x.float(), X.float(), K)
+    np.testing.assert_allclose(est[:, :3].numpy(), T.numpy(), atol=2e-3)
+    np.testing.assert_allclose(est[:, 3:].numpy(), w.numpy(), atol=5e-4)
+    ini = torch.cat([w + 0.02, T + 0.1], 1)                      # the reference reads ini_pose as (axis-angle, T)
+    est2 = GS().pnp(x.float(), X.float(), K, ini_pose=ini)
+    np.testing.assert_allclose(est2.numpy(), est.numpy(), atol=2e-3)
+    noisy = GS().pnp((x + 0.3 * torch.randn_like(x)).float(), X.float(), K)
+    assert float((noisy - est).abs().max()) < 0.05
+    # compute_pnp_loss: zero when the pose vector equals the solved (T, axis-angle)
+    class M(GS):
+        beta = 1
+    Ki = torch.inverse(K).unsqueeze(0).repeat(b, 1, 1)
+    x1 = torch.stack([480 * X[:, :, 0] / X[:, :, 2] + 416, 490 * X[:, :, 1] / X[:, :, 2] + 128], 1).float()
+    matches = torch.cat([x1, x.float().transpose(1, 2)], 1)
+    loss = M().compute_pnp_loss(X[:, :, 2].float().unsqueeze(1), matches, est, K.unsqueeze(0).repeat(b, 1, 1), Ki)
+    assert loss.shape == (b, 3) and float(loss.max()) < 5e-3

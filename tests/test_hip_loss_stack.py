@@ -436,3 +436,28 @@ def test_full_size_properties():
         for k in m:
             u = torch.unique(m[k][s])
             assert set(u.tolist()) <= {0.0, 1.0}, k
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 208), (4, 256, 832)])
+def test_fused_two_level_pyramid_kernel_is_the_generic_one_bit_for_bit(shape):
+    """k_geom_pyramids12 (levels 1 and 2 of an exact power-of-two pyramid from one read of the frames) against the
+    per-(frame, scale) jobs of k_geom_pyramids (DFE_PYRAMIDS_GENERIC=1): every loss value, mask and gradient of the stack
+    that consumes the pyramids is bit-identical."""
+    inp = synthetic.make_loss_stack_inputs(*shape, 3, seed=47)
+
+    def run(flag):
+        old = os.environ.pop("DFE_PYRAMIDS_GENERIC", None)
+        if flag:
+            os.environ["DFE_PYRAMIDS_GENERIC"] = "1"
+        try:
+            lp, mk, tot, (d, p, fb, ff) = run_hip(inp, False, 3)
+            torch.cuda.synchronize()
+            return ([N(v) for v in lp.values()], [N(t) for v in mk.values() for t in v], [N(t.grad) for lst in d for t in lst],
+                    N(p.grad), [N(t.grad) for t in fb[:3]] + [N(t.grad) for t in ff[:3]])
+        finally:
+            os.environ.pop("DFE_PYRAMIDS_GENERIC", None)
+            if old is not None:
+                os.environ["DFE_PYRAMIDS_GENERIC"] = old
+    a, b = run(False), run(True)
+    for x, y in zip(a[0] + a[1] + a[2] + [a[3]] + a[4], b[0] + b[1] + b[2] + [b[3]] + b[4]):
+        assert np.array_equal(x, y)

@@ -639,13 +639,10 @@ __device__ __forceinline__ float adj_pow2(const float* __restrict__ gu, int W, i
   for (int ky = 0; ky < NT; ++ky) {
     const float* row = gu + static_cast<long>(y0 + ky) * W + x0;
     float v[NT];
-    if (NR == 4) {      // x0 = 4 j - 2: 8-byte aligned
+    // pairs of horizontally adjacent taps as one dword-aligned 8-byte load (x0 = 4 j - 2 is 8-byte aligned, x0 = 2 j - 1
+    // only dword aligned: the load is still one instruction; round 3: 16 -> 8 loads per pixel at the 1/2 level)
 #pragma unroll
-      for (int k = 0; k < NT; k += 2) { const PairF q = *reinterpret_cast<const PairF*>(row + k); v[k] = q.a; v[k + 1] = q.b; }
-    } else {
-#pragma unroll
-      for (int k = 0; k < NT; ++k) v[k] = row[k];
-    }
+    for (int k = 0; k < NT; k += 2) { const PairF q = *reinterpret_cast<const PairF*>(row + k); v[k] = q.a; v[k + 1] = q.b; }
     float acc = 0.0f;
 #pragma unroll
     for (int kx = 0; kx < NT; ++kx) acc += w[kx] * v[kx];

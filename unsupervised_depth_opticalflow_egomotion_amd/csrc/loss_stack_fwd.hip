@@ -208,6 +208,57 @@ __global__ void k_geom_pyramids(PyrJobs jobs) {
   }
 }
 
+// Levels 1 and 2 of an exact power-of-two pyramid (H, W multiples of 4: every KITTI training size) from ONE read of the
+// frame: a thread owns a 4x4 input block (four 16-byte loads per plane), and writes the 2x2 level-1 outputs and the level-2
+// output it covers, bilinear and (source frames) area.  The per-(frame, scale) jobs of k_geom_pyramids read the frame once
+// per scale and once more for the level-2 box mean (PMC: 1.5x the algorithmic bytes).  Same taps, weights and association
+// orders as the generic kernel (bilinear_src gives i0 = 2o, l = 0.5 at 1/2 and i0 = 4o + 1, l = 0.5 at 1/4; box means are
+// row-major sequential sums): bit-identical outputs.  grid: x = blocks over planes * (H/4) * (W/4), y = frame.
+struct Pyr12Job { const float* in[3]; float* b1[3]; float* b2[3]; float* a1[3]; float* a2[3]; int planes, H, W; };
+
+__global__ void __launch_bounds__(256) k_geom_pyramids12(Pyr12Job jb) {
+  const int f = blockIdx.y;
+  const int H2 = jb.H / 4, W2 = jb.W / 4, H1 = jb.H / 2, W1 = jb.W / 2;
+  const long n = static_cast<long>(jb.planes) * H2 * W2;
+  const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int ox = static_cast<int>(i % W2), oy = static_cast<int>((i / W2) % H2);
+  const long pl = i / (static_cast<long>(W2) * H2);
+  const float* src = jb.in[f] + pl * jb.H * jb.W + static_cast<long>(4 * oy) * jb.W + 4 * ox;
+  float v[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float4 q = *reinterpret_cast<const float4*>(src + static_cast<long>(r) * jb.W);
+    v[r][0] = q.x; v[r][1] = q.y; v[r][2] = q.z; v[r][3] = q.w;
+  }
+  const bool small1 = aten_small_resize(H1, W1), small2 = aten_small_resize(H2, W2);
+  float* o1 = jb.b1[f] + pl * H1 * W1 + static_cast<long>(2 * oy) * W1 + 2 * ox;
+  float* a1 = jb.a1[f] ? jb.a1[f] + pl * H1 * W1 + static_cast<long>(2 * oy) * W1 + 2 * ox : nullptr;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    float bl[2], ar[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float v00 = v[2 * r][2 * c], v01 = v[2 * r][2 * c + 1], v10 = v[2 * r + 1][2 * c], v11 = v[2 * r + 1][2 * c + 1];
+      bl[c] = lerp2_aten_sel(small1, v00, v01, v10, v11, 0.5f, 0.5f, 0.5f, 0.5f);
+      float sum = 0.0f;
+      sum += v00; sum += v01; sum += v10; sum += v11;
+      ar[c] = sum / 4.0f;
+    }
+    *reinterpret_cast<PairF*>(o1 + static_cast<long>(r) * W1) = PairF{bl[0], bl[1]};
+    if (a1) *reinterpret_cast<PairF*>(a1 + static_cast<long>(r) * W1) = PairF{ar[0], ar[1]};
+  }
+  jb.b2[f][pl * H2 * W2 + static_cast<long>(oy) * W2 + ox] = lerp2_aten_sel(small2, v[1][1], v[1][2], v[2][1], v[2][2], 0.5f, 0.5f, 0.5f, 0.5f);
+  if (jb.a2[f]) {
+    float sum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sum += v[r][c];
+    jb.a2[f][pl * H2 * W2 + static_cast<long>(oy) * W2 + ox] = sum / 16.0f;
+  }
+}
+
 // Box means with large windows (non-divisible sizes at coarse scales: up to (2^s + 1)^2 inputs per output).  A
 // thread-per-output loop pays one memory round trip per pair of inputs; here one wave stages the window in LDS
 // with row-coalesced loads and lane 0 adds it in ATen's row-major order (the mean stays bit-identical to
@@ -1027,11 +1078,29 @@ static int geom_fwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     DFE_LAUNCH_CHECK();
   }
   DFE_MARK();
-  if (L.S > 1) {
+  // levels 1 and 2 in one pass over the frames when the pyramid is an exact power-of-two one (geom / depth models)
+  int first_generic = 1;
+  if (L.S >= 3 && a->mode != 2 && a->H % 4 == 0 && a->W % 4 == 0 && getenv("DFE_PYRAMIDS_GENERIC") == nullptr &&
+      (reinterpret_cast<uintptr_t>(a->img[0]) & 15) == 0 && (reinterpret_cast<uintptr_t>(a->img[1]) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(a->img[2]) & 15) == 0) {
+    Pyr12Job jb;
+    jb.planes = L.B * 3; jb.H = a->H; jb.W = a->W;
+    for (int f = 0; f < 3; ++f) {
+      jb.in[f] = a->img[f];
+      jb.b1[f] = const_cast<float*>(D.pyr[f][1]); jb.b2[f] = const_cast<float*>(D.pyr[f][2]);
+      jb.a1[f] = f == 1 ? nullptr : const_cast<float*>(D.area[f == 0 ? 0 : 1][1]);
+      jb.a2[f] = f == 1 ? nullptr : const_cast<float*>(D.area[f == 0 ? 0 : 1][2]);
+    }
+    const long n = static_cast<long>(jb.planes) * (a->H / 4) * (a->W / 4);
+    k_geom_pyramids12<<<dim3(static_cast<unsigned>((n + 255) / 256), 3), 256, 0, st>>>(jb);
+    DFE_LAUNCH_CHECK();
+    first_generic = 3;
+  }
+  if (L.S > first_generic) {
     PyrJobs jobs;
     jobs.n = 0; jobs.planes = L.B * 3; jobs.inH = a->H; jobs.inW = a->W;
     int max_out = 0;
-    for (int s = 1; s < L.S; ++s) {
+    for (int s = first_generic; s < L.S; ++s) {
       for (int f = 0; f < 3; ++f) {
         if (a->mode == 2)   // Model_flow: box-mean (adaptive_avg_pool2d) pyramid of all three frames, model_flow.py:58-64
           jobs.j[jobs.n++] = PyrJob{a->img[f], nullptr, const_cast<float*>(D.pyr[f][s]), L.H[s], L.W[s]};

@@ -13,7 +13,9 @@
   batched on the device (one 9x9 symmetric eigen-problem and one 3x3 SVD per sample), scaled like OpenCV's result
   (F[2,2] = 1).  No oracle can exist for the RANSAC draw; property tests only (exact recovery on noise-free matches,
   rank 2, invariance to the order of the matches).
-* ``cv2.solvePnPRansac`` (``compute_pnp_loss``, model_geometry.py:473-530) is NOT provided: it raises.
+* perspective-n-point (``pnp`` / ``compute_pnp_loss``, model_geometry.py:473-530; the reference: ``cv2.solvePnPRansac`` +
+  ``cv2.solvePnP(ITERATIVE)`` per sample on the host): a batched Levenberg-Marquardt on SE(3) over all correspondences,
+  float64 inside, same (T, axis-angle) output convention; property tests only, for the same reason.
 
 None of this is reached by ``Model_geometry.forward`` (the reference keeps the calls commented, :939-951); the methods
 exist so that those lines can be switched on as written."""
@@ -183,5 +185,86 @@ class GeometrySolvers:
         F_pred = torch.inverse(intrinsics.permute([0, 2, 1])).bmm(E.bmm(intrinsics_inverse))
         return F.smooth_l1_loss(F_pred, target)
 
-    def compute_pnp_loss(self, *args, **kwargs):
-        raise NotImplementedError("compute_pnp_loss needs cv2.solvePnPRansac (model_geometry.py:473-530): not provided")
+    # ------------------------------------------------------------------ perspective-n-point (model_geometry.py:473-530)
+    @staticmethod
+    def _so3_exp(w):
+        """Rodrigues: axis-angle [b,3] -> rotation matrices [b,3,3] (series near zero)."""
+        th = torch.sqrt((w * w).sum(1, keepdim=True) + 1e-30).unsqueeze(-1)
+        z = torch.zeros_like(w[:, 0])
+        Kx = torch.stack([z, -w[:, 2], w[:, 1], w[:, 2], z, -w[:, 0], -w[:, 1], w[:, 0], z], 1).view(-1, 3, 3)
+        a = torch.where(th > 1e-6, torch.sin(th) / th, 1.0 - th * th / 6.0)
+        b = torch.where(th > 1e-6, (1.0 - torch.cos(th)) / (th * th), 0.5 - th * th / 24.0)
+        return torch.eye(3, dtype=w.dtype, device=w.device).unsqueeze(0) + a * Kx + b * Kx.bmm(Kx)
+
+    @staticmethod
+    def _so3_log(R):
+        """Rotation matrices [b,3,3] -> axis-angle [b,3] (angles below pi)."""
+        c = ((R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2] - 1.0) / 2.0).clamp(-1.0, 1.0)
+        th = torch.acos(c)
+        v = torch.stack([R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]], 1) / 2.0
+        k = torch.where(th > 1e-6, th / torch.sin(th).clamp_min(1e-30), 1.0 + th * th / 6.0)
+        return v * k.unsqueeze(1)
+
+    def pnp(self, pts2d, pts3d, K, ini_pose=None, iterations=20):
+        """Pose [b,6] = (T, axis-angle) minimising the reprojection error of pts3d [b,n,3] onto pts2d [b,n,2] under the
+        single camera matrix K [3,3] -- the output convention of the reference's ``pnp`` (model_geometry.py:473-495), which
+        runs cv2.solvePnPRansac + an iterative refinement per sample on the host.  Here: Levenberg-Marquardt on SE(3) over
+        ALL correspondences (no RANSAC: cv2 is absent and a random consensus cannot be pinned), batched on the device in
+        float64, started from ``ini_pose`` (axis-angle first, then T, as the reference reads it) or the identity."""
+        X = pts3d.detach().double()
+        x = pts2d.detach().double()
+        Kd = K.detach().double()
+        b, n = X.shape[0], X.shape[1]
+        fx, fy, cx, cy = Kd[0, 0], Kd[1, 1], Kd[0, 2], Kd[1, 2]
+        if ini_pose is None:
+            R = torch.eye(3, dtype=X.dtype, device=X.device).unsqueeze(0).repeat(b, 1, 1)
+            T = torch.zeros(b, 3, dtype=X.dtype, device=X.device)
+        else:
+            R, T = self._so3_exp(ini_pose[:, 0:3].detach().double()), ini_pose[:, 3:6].detach().double().clone()
+
+        def residual(R, T):
+            Y = X.bmm(R.transpose(1, 2)) + T.unsqueeze(1)
+            z = Y[:, :, 2].clamp_min(1e-9)
+            r = torch.stack([fx * Y[:, :, 0] / z + cx - x[:, :, 0], fy * Y[:, :, 1] / z + cy - x[:, :, 1]], 2)
+            return Y, z, r
+        lam = torch.full((b, 1, 1), 1e-3, dtype=X.dtype, device=X.device)
+        Y, z, r = residual(R, T)
+        cost = (r * r).sum((1, 2))
+        eye6 = torch.eye(6, dtype=X.dtype, device=X.device).unsqueeze(0)
+        for _ in range(iterations):
+            # d(u, v) / dY, dY / d(omega, T) with R <- exp([omega]x) R: dY/domega = -[Y - T]x, dY/dT = I
+            zi = 1.0 / z
+            du = torch.stack([fx * zi, torch.zeros_like(zi), -fx * Y[:, :, 0] * zi * zi], 2)
+            dv = torch.stack([torch.zeros_like(zi), fy * zi, -fy * Y[:, :, 1] * zi * zi], 2)
+            P = Y - T.unsqueeze(1)
+            zero = torch.zeros_like(zi)
+            Pc = torch.stack([zero, -P[:, :, 2], P[:, :, 1], P[:, :, 2], zero, -P[:, :, 0], -P[:, :, 1], P[:, :, 0], zero], 2).view(b, n, 3, 3)
+            Ju = torch.cat([-(du.unsqueeze(2) @ Pc).squeeze(2), du], 2)          # [b,n,6]
+            Jv = torch.cat([-(dv.unsqueeze(2) @ Pc).squeeze(2), dv], 2)
+            J = torch.cat([Ju, Jv], 1)                                           # [b,2n,6]
+            rr = torch.cat([r[:, :, 0], r[:, :, 1]], 1).unsqueeze(2)             # [b,2n,1]
+            H = J.transpose(1, 2).bmm(J)
+            g = J.transpose(1, 2).bmm(rr)
+            step = torch.linalg.solve(H + lam * (eye6 * torch.diagonal(H, dim1=1, dim2=2).unsqueeze(1).clamp_min(1e-12)), -g).squeeze(2)
+            Rn, Tn = self._so3_exp(step[:, :3]).bmm(R), T + step[:, 3:]
+            Yn, zn, rn = residual(Rn, Tn)
+            cn = (rn * rn).sum((1, 2))
+            ok = (cn < cost)
+            m3, m1 = ok.view(b, 1, 1), ok.view(b, 1)
+            R, T = torch.where(m3, Rn, R), torch.where(m1, Tn, T)
+            Y, z, r = torch.where(m3, Yn, Y), torch.where(m1, zn, z), torch.where(m3, rn, r)
+            cost = torch.where(ok, cn, cost)
+            lam = torch.where(m3, lam * 0.3, lam * 5.0).clamp(1e-9, 1e6)
+        return torch.cat([T, self._so3_log(R)], 1).to(pts2d.dtype)
+
+    def compute_pnp_loss(self, depth, matches, pose_vec, K, K_inv):
+        """model_geometry.py:498-530: back-project the first view's matched pixels with their depth, solve the pose that
+        reprojects them onto the second view's matched pixels, L1 between (T, axis-angle) and the pose vector's
+        (translation, Euler angles) -- the reference compares those two parameterisations as they stand."""
+        b, _, n = matches.shape
+        ones = torch.ones(b, 1, n, device=matches.device, dtype=matches.dtype)
+        pts3d = (K_inv.bmm(torch.cat([matches[:, :2], ones], 1)) * depth).transpose(1, 2)
+        pose_pred = self.pnp(matches[:, 2:].transpose(1, 2), pts3d, K[0])
+        beta = getattr(self, "beta", 1)
+        return F.l1_loss(pose_pred[:, :3], pose_vec[:, :3], reduction="none") + \
+            beta * F.l1_loss(pose_pred[:, 3:], pose_vec[:, 3:], reduction="none")
