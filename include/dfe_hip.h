@@ -199,7 +199,9 @@ int dfe_wgrad3x3_fwd(const float* p, const float* gy, float* gweight, float* par
 /* ---- forward / data-gradient pass of the decoder's thinnest 3x3 convolutions on the matrix cores (fp32 MFMA):
  * out [B,16,Ho,Wo][co][y][x] = sum_{ci,ky,kx} weight[co][ci][ky][kx] * in[b][ci][y+ky-P][x+kx-P] (zero outside in),
  * in [B,Ci,Hi,Wi], Ho = Hi + 2P - 2, Wo = Wi + 2P - 2.  P = 0: valid convolution of a pre-padded activation (forward);
- * P = 2: full correlation = the data gradient with transposed_weight = 1: ``weight`` is then the forward kernel
+ * P = 1: zero-padded "same" convolution (net_utils.conv(16, 16), feature_pyramid.py: forward, and its data gradient with
+ * transposed_weight = 1); P = 2: full correlation = the data gradient of the P = 0 form with transposed_weight = 1:
+ * ``weight`` is then the forward kernel
  * w [16,16,3,3] and is read as weight'[co'][ci'][ky][kx] = w[ci'][co'][2-ky][2-kx].  Output channels must be 16, Ci 16 or
  * 32 (16 when transposed) (DFE_ERR_UNSUPPORTED otherwise: the caller keeps MIOpen); out 16-byte aligned. */
 int dfe_thin_conv3x3(const float* in, const float* weight, float* out, int B, int Ci, int Co, int Hi, int Wi, int P,

@@ -808,3 +808,23 @@ def test_conv_bf16_compute_dtype():
     for a, c in zip((y1,) + g1, (y0,) + g0):
         assert float((a - c).abs().max()) <= 2e-2 * float(c.abs().max())
     assert float((y1 - y0).abs().max()) > 0      # it really ran in reduced precision
+
+
+def test_thin_conv_same_16_16_matches_miopen():
+    """ops.ThinConvSameFn (dfe_thin_conv3x3 with P = 1 + dfe_wgrad3x3 on a zero-padded copy): values and all gradients of
+    the zero-padded 16 -> 16 3x3 convolution of FeaturePyramid's conv2 against F.conv2d on the device (fp32 both:
+    summation order only)."""
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+    torch.manual_seed(6)
+    for B, H, W in ((2, 128, 416), (1, 130, 432)):
+        x = torch.randn(B, 16, H, W, device=dev(), requires_grad=True)
+        w = (0.1 * torch.randn(16, 16, 3, 3, device=dev())).requires_grad_(True)
+        r = torch.randn(B, 16, H, W, device=dev())
+        y0 = torch.nn.functional.conv2d(x, w, None, 1, 1)
+        g0 = torch.autograd.grad((y0 * r).sum(), (x, w))
+        y1 = ops.ThinConvSameFn.apply(x, w)
+        g1 = torch.autograd.grad((y1 * r).sum(), (x, w))
+        for a, c in zip((y1,) + g1, (y0,) + g0):
+            assert float((a - c).abs().max()) <= 2e-5 * max(float(c.abs().max()), 1.0)
+    conv = torch.nn.Conv2d(16, 16, 3, 1, 1)
+    assert ops.thin_conv_same_eligible(x, conv) and not ops.thin_conv_same_eligible(x[:, :, :64, :208], conv)

@@ -16,6 +16,8 @@ def models(B, H, W, S, mode="geom"):
     m = {
         "k_geom_pyramids": (3 * B * 3 * N0 * 4 + 3 * B * 3 * NL * 4 + 2 * B * 3 * NL * 4,
                             "read 3 frames 12 B/px + write bilinear levels>=1 of 3 frames + area levels>=1 of 2 frames"),
+        "k_geom_pyramids12": (3 * B * 3 * N0 * 4 + 3 * B * 3 * NL * 4 + 2 * B * 3 * NL * 4,
+                              "levels 1-2 from one read: read 3 frames 12 B/px + write bilinear levels 1-2 of 3 frames + area levels 1-2 of 2 frames"),
         "k_geom_point_fwd": (B * (81 * N0 + 105 * NL),
                              "per px: target 12 + 2 flows 16 + 2 bilinear sources 24 + 2 area sources 24 (level 0: the same tensor, counted once) + disp 4; mask 1 + masked warps 24 = 105 (81 at level 0)"),
         "k_depth_point_fwd": (B * (41 * N0 + 65 * NL), "per px: target 12 + 2 area sources 24 + 2 bilinear sources 24 (level 0: once) + disp 4; mask 1 = 65 (41 at level 0)"),

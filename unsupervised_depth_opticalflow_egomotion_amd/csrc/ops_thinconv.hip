@@ -126,7 +126,7 @@ using namespace dfe;
 extern "C" int dfe_thin_conv3x3(const float* in, const float* weight, float* out, int B, int Ci, int Co, int Hi, int Wi, int P,
                                 int transposed_weight, void* stream) {
   if (!in || !weight || !out) return DFE_ERR_NULL;
-  if (B <= 0 || Hi <= 0 || Wi <= 0 || (P != 0 && P != 2)) return DFE_ERR_DIMS;
+  if (B <= 0 || Hi <= 0 || Wi <= 0 || P < 0 || P > 2) return DFE_ERR_DIMS;
   if (Co != 16 || (Ci != 16 && Ci != 32)) return DFE_ERR_UNSUPPORTED;
   if (transposed_weight && Ci != 16) return DFE_ERR_UNSUPPORTED;      // weight [16 (= Ci here)][16 (= Co here)][3][3] read transposed
   const int Ho = Hi + 2 * P - 2, Wo = Wi + 2 * P - 2;

@@ -832,6 +832,47 @@ class ThinConv3x3Fn(torch.autograd.Function):
         return gp, gw
 
 
+class ThinConvSameFn(torch.autograd.Function):
+    """Zero-padded 3x3 "same" convolution 16 -> 16, bias-free (FeaturePyramid's conv2 at 128x416, feature_pyramid.py /
+    net_utils.conv): forward and data gradient on dfe_thin_conv3x3 with P = 1 (MIOpen: 88 / 82 us at 12 x 16 x 128 x 416,
+    25-36 TFLOP/s; here 54 us forward), weight gradient on dfe_wgrad3x3_fwd over a zero-padded copy of the input
+    (MIOpen: 119 us)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        lib = get_lib()
+        x, weight = f32c(x), f32c(weight)
+        B, _, H, W = x.shape
+        out = torch.empty(B, 16, H, W, device=x.device)
+        check(lib.dfe_thin_conv3x3(ptr(x), ptr(weight), ptr(out), B, 16, 16, H, W, 1, 0, stream_ptr()), "dfe_thin_conv3x3 (same)")
+        ctx.save_for_backward(x, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = get_lib()
+        x, weight = ctx.saved_tensors
+        gy = f32c(gy)
+        B, _, H, W = x.shape
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            check(lib.dfe_thin_conv3x3(ptr(gy), ptr(weight), ptr(gx), B, 16, 16, H, W, 1, 1, stream_ptr()), "dfe_thin_conv3x3 (same, data gradient)")
+        if ctx.needs_input_grad[1]:
+            p = torch.nn.functional.pad(x, (1, 1, 1, 1))
+            gw = torch.empty_like(weight)
+            part = torch.empty(lib.dfe_wgrad3x3_partials_floats(B, 16, 16, H, W), device=x.device)
+            check(lib.dfe_wgrad3x3_fwd(ptr(p), ptr(gy), ptr(gw), ptr(part), B, 16, 16, H, W, stream_ptr()), "dfe_wgrad3x3_fwd")
+        return gx, gw
+
+
+def thin_conv_same_eligible(x, conv):
+    """FeaturePyramid-style 16 -> 16 3x3 stride-1 pad-1 layers on planes of at least 128 x 416 (where it was measured)."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.in_channels == 16 and conv.out_channels == 16
+            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and x.shape[3] % 16 == 0 and x.shape[2] * x.shape[3] >= 128 * 416)
+
+
 def thin_conv3x3_eligible(p, weight):
     """Layers the MFMA weight gradient is measured to win on: <= 32 output channels at >= 64x208 pixels (the decoder's
     last stages), channel counts multiples of 16, width a multiple of 16."""

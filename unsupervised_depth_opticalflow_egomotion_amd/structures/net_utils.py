@@ -15,6 +15,8 @@ class ConvAct(nn.Sequential):
         if not x.is_cuda:
             return super().forward(x)
         c = self[0]
+        if ops.thin_conv_same_eligible(x, c):       # FeaturePyramid conv2: fp32 MFMA kernels (ops.ThinConvSameFn)
+            return ops.bias_act(ops.ThinConvSameFn.apply(x, c.weight), c.bias, self[1].negative_slope)
         z = convs.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
         return ops.bias_act(z, c.bias, self[1].negative_slope)
 
