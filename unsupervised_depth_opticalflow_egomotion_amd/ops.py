@@ -7,6 +7,7 @@ libdfe_hip.so.  There is no CPU fallback: CPU tensors raise ``DfeError``."""
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -868,6 +869,9 @@ class ThinConvSameFn(torch.autograd.Function):
 
 def thin_conv_same_eligible(x, conv):
     """FeaturePyramid-style 16 -> 16 3x3 stride-1 pad-1 layers on planes of at least 128 x 416 (where it was measured)."""
+    from . import convs
+    if os.environ.get("DFE_THIN_SAME", "1") == "0" or convs.get_compute_dtype() is not None:
+        return False
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.in_channels == 16 and conv.out_channels == 16
             and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
             and conv.groups == 1 and x.shape[3] % 16 == 0 and x.shape[2] * x.shape[3] >= 128 * 416)
