@@ -50,20 +50,29 @@ int dfe_prepare_cameras(const float* pose, const float* K, float* cams, int B, i
 int dfe_pose_vec2mat_fwd(const float* vec, float* T34, float* E, int n, void* stream);
 int dfe_pose_vec2mat_bwd(const float* vec, const float* gT34, const float* gE, float* gvec, int n, void* stream);
 
+/* ---- order-independent scatter-add workspace (csrc/dfe_scatter.h) -----------------------------
+ * Adjoint of a bilinear gather with respect to the sampled tensor: contributions are scaled by a power of two, rounded
+ * once to 64-bit integers, added with integer atomics (associative: no dependence on the order the atomics retire in)
+ * and converted back in one pass -- bitwise reproducible, no float atomics anywhere in the library.  A scatter into
+ * n floats needs a 16-byte aligned workspace of dfe_scatter_ws_bytes(n) bytes (64 + 8 n); the library zero-fills it. */
+long dfe_scatter_ws_bytes(long n);
+
 /* ---- warp_flow(x, flow, use_mask)  net_utils.py:16-54 --------------------------------------
  * x [B,C,H,W], flow [B,2,H,W] -> out [B,C,H,W].  Backward: gflow [B,2,H,W] (NULL to skip),
- * gx [B,C,H,W] scatter-added with float atomics, must be zero-initialised by the caller (NULL to skip);
- * gflow is written once per pixel from fixed-order partial sums (bitwise reproducible). */
+ * gx [B,C,H,W] (NULL to skip; every element written, no zero-fill needed) through the scatter workspace gx_ws
+ * (dfe_scatter_ws_bytes(B*C*H*W) bytes; may be NULL when gx is);
+ * gflow is written once per pixel from fixed-order partial sums.  Both are bitwise reproducible. */
 int dfe_warp_flow_fwd(const float* x, const float* flow, float* out, int B, int C, int H, int W, int use_mask,
                       int align_corners, void* stream);
-int dfe_warp_flow_bwd(const float* x, const float* flow, const float* gout, float* gflow, float* gx, int B, int C,
-                      int H, int W, int use_mask, int align_corners, void* stream);
+int dfe_warp_flow_bwd(const float* x, const float* flow, const float* gout, float* gflow, float* gx, void* gx_ws, int B,
+                      int C, int H, int W, int use_mask, int align_corners, void* stream);
 
 /* ---- inverse_warp2(img, depth, ref_depth, pose, intrinsics)  inverse_warp.py:263-303 -------
  * cams from dfe_prepare_cameras(pose[B,6], K, cams, B, 1, 1, {1}).  Outputs: projected image
  * [B,3,H,W], valid mask [B,1,H,W], projected depth [B,1,H,W], computed depth [B,1,H,W]
  * (the last three may be NULL).  Backward: g_depth [B,1,H,W], g_refdepth [B,1,H,W]
- * (zero-initialised by the caller, NULL to skip), g_pose [B,6]; partials: workspace of
+ * (NULL to skip; every element written, through the scatter workspace g_refdepth_ws of
+ * dfe_scatter_ws_bytes(B*H*W) bytes), g_pose [B,6]; partials: workspace of
  * dfe_pose_partials_floats(B,H,W) floats. */
 int dfe_pose_partials_floats(int B, int H, int W);
 int dfe_inverse_warp2_fwd(const float* img, const float* depth, const float* ref_depth, const float* cams,
@@ -71,8 +80,8 @@ int dfe_inverse_warp2_fwd(const float* img, const float* depth, const float* ref
                           int align_corners, void* stream);
 int dfe_inverse_warp2_bwd(const float* img, const float* depth, const float* ref_depth, const float* cams,
                           const float* g_img, const float* g_pdepth, const float* g_cdepth, float* g_depth,
-                          float* g_refdepth, float* g_pose, float* partials, int B, int H, int W, int align_corners,
-                          void* stream);
+                          float* g_refdepth, void* g_refdepth_ws, float* g_pose, float* partials, int B, int H, int W,
+                          int align_corners, void* stream);
 
 /* ---- calculate_rigid_flow(depth, pose, intrinsics)  inverse_warp.py:311-342 ---------------- */
 int dfe_rigid_flow_fwd(const float* depth, const float* cams, float* out, int B, int H, int W, void* stream);
@@ -103,8 +112,9 @@ int dfe_prepare_triplets(const unsigned char* in_u8, const unsigned char* flip, 
 
 /* ---- forward-splat occlusion map  core/networks/model_flow.py:33-39 (get_occlusion_mask_from_flow) -----------
  * The reference calls an undefined `transformerFwd`; this is its TrianFlow meaning: out [B,1,H,W] = bilinear forward
- * warp of a ones image by flow [B,2,H,W] (optionally clamped to [0,1]).  out is zeroed here; scatter with float atomics. */
-int dfe_forward_splat_ones(const float* flow, float* out, int B, int H, int W, int clamp01, void* stream);
+ * warp of a ones image by flow [B,2,H,W] (optionally clamped to [0,1]).  Order-independent scatter through ws
+ * (dfe_scatter_ws_bytes(B*H*W) bytes); every element of out is written; bitwise reproducible. */
+int dfe_forward_splat_ones(const float* flow, float* out, void* ws, int B, int H, int W, int clamp01, void* stream);
 
 /* ---- self-test of the short correctly rounded fp32 sequences (csrc/loss_stack_exact.h) ------------------------
  * The mask-deciding expressions of the reference use IEEE division and square root (torch CPU); the pointwise kernels
@@ -138,14 +148,15 @@ int dfe_maxpool3x3s2_bwd(const float* gy, const unsigned char* idx, float* gx, i
  * as ONE operator: the cost volume is written straight into planes [0,81) of x [B, 81+C+2, H, W] (caller-allocated),
  * c1 and the flow are copied behind it; `warped` [B,C,H,W] is kept for the backward pass.  The backward pass reads
  * the three channel slices of gx = dL/dx in place and returns complete gradients:
- *   g_c1 = dcorr/dc1 + gx[:,81:81+C];  g_flow = dwarp/dflow + gx[:,81+C:];  g_c2 (scatter; zero-filled here).
- * g_warped [B,C,H,W] is scratch.  g_c2 or g_flow may be NULL (not both). */
+ *   g_c1 = dcorr/dc1 + gx[:,81:81+C];  g_flow = dwarp/dflow + gx[:,81+C:];  g_c2 (order-independent scatter through
+ *   g_c2_ws, dfe_scatter_ws_bytes(B*C*H*W) bytes; every element of g_c2 is written).
+ * g_warped [B,C,H,W] is scratch.  g_c2 (with g_c2_ws) or g_flow may be NULL (not both). */
 int dfe_pwc_level_channels(int C);   /* 81 + C + 2 */
 int dfe_pwc_level_fwd(const float* c1, const float* c2, const float* flow, float* warped, float* x, int B, int C, int H,
                       int W, int align_corners, void* stream);
 int dfe_pwc_level_bwd(const float* c1, const float* c2, const float* flow, const float* warped, const float* gx,
-                      float* g_warped, float* g_c1, float* g_c2, float* g_flow, int B, int C, int H, int W,
-                      int align_corners, void* stream);
+                      float* g_warped, float* g_c1, float* g_c2, void* g_c2_ws, float* g_flow, int B, int C, int H,
+                      int W, int align_corners, void* stream);
 
 /* ---- pyramids: mode 0 = F.interpolate(bilinear, align_corners=False) (model_geometry.py:65-72),
  * mode 1 = F.interpolate(area) == adaptive_avg_pool2d (model_geometry.py:91, model_flow.py:58-64). */

@@ -274,15 +274,22 @@ def test_fused_stack_vs_golden(golden_dir, ac, case):
     assert fb[3].grad is None or float(fb[3].grad.abs().sum()) == 0.0   # the 1/8 flow is dropped
 
 
-def test_fused_stack_is_deterministic():
+@pytest.mark.parametrize("depth_terms", [False, True])
+def test_fused_stack_is_deterministic(depth_terms):
+    """Bitwise equal from run to run, every loss and every gradient -- with the optional depth terms too, whose
+    projected-depth scatter into the source frames' disparity gradients adds 64-bit fixed-point integers
+    (csrc/dfe_scatter.h) instead of floats."""
     inp = synthetic.make_loss_stack_inputs(2, 64, 208, 3, seed=5)
-    a = run_hip(inp, False, 3)
-    b = run_hip(inp, False, 3)
+    a = run_hip(inp, False, 3, depth_terms=depth_terms)
+    b = run_hip(inp, False, 3, depth_terms=depth_terms)
     for k in a[0]:
         assert torch.equal(a[0][k], b[0][k])
     assert torch.equal(a[3][1].grad, b[3][1].grad)
     for x, y in zip(a[3][2][:3], b[3][2][:3]):
         assert torch.equal(x.grad, y.grad)
+    for f in range(3):
+        for x, y in zip(a[3][0][f], b[3][0][f]):
+            assert torch.equal(x.grad, y.grad), f
 
 
 @pytest.mark.parametrize("shape,S", [((3, 70, 100), 2), ((1, 64, 208), 1), ((2, 40, 72), 3)])

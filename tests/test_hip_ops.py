@@ -162,21 +162,68 @@ def test_exact_math_sequences_exhaustive():
     assert counts.tolist() == [0, 0, 0, 0], counts.tolist()
 
 
-def test_warp_flow_backward_flow_gradient_is_deterministic():
-    """grad wrt flow sums over all channels in a fixed order (per-group register sums met in LDS): bitwise equal from
-    run to run at the PWC feature-warp shapes.  (grad wrt x scatters with float atomics and is not.)"""
+def test_warp_flow_backward_is_deterministic():
+    """Both gradients are bitwise equal from run to run at the PWC feature-warp shapes: grad wrt flow sums over all
+    channels in a fixed order (per-group register sums met in LDS); grad wrt x is a scatter-add done in 64-bit fixed
+    point with integer atomics (csrc/dfe_scatter.h: integer addition is associative, the order the atomics retire in
+    cannot matter).  The last case sends every pixel to the same spot (H*W-fold collisions)."""
     from unsupervised_depth_opticalflow_egomotion_amd.structures import warp_flow
     r = MG.rng(99)
-    for shape in [(2, 128, 8, 26), (2, 64, 32, 104), (1, 196, 4, 13)]:
+    for shape, pile in [((2, 128, 8, 26), False), ((2, 64, 32, 104), False), ((1, 196, 4, 13), False), ((2, 32, 64, 208), False),
+                        ((1, 4, 64, 208), True)]:
         b, c, h, w = shape
         x, fl = r.standard_normal(shape).astype(np.float32), (2.0 * r.standard_normal((b, 2, h, w))).astype(np.float32)
+        if pile:
+            yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+            fl[:, 0], fl[:, 1] = 100.3 - xx, 30.6 - yy
         wgt = r.standard_normal(shape).astype(np.float32)
         grads = []
         for _ in range(3):
             xt, ft = G(x, True), G(fl, True)
             (warp_flow(xt, ft) * G(wgt)).sum().backward()
-            grads.append(ft.grad.clone())
-        assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2]), shape
+            grads.append((ft.grad.clone(), xt.grad.clone()))
+        for k in (0, 1):
+            assert torch.equal(grads[0][k], grads[1][k]) and torch.equal(grads[0][k], grads[2][k]), (shape, k)
+
+
+def test_warp_flow_backward_scatter_accuracy_and_edge_cases():
+    """The fixed-point scatter against a float64 scatter of the same contributions: closer than an fp32 accumulation
+    could promise (quantum 2^-36 of the largest gradient's binade; one fp32 rounding at the end), including gradients
+    spanning 30 binades, a heavy pile-up, an all-zero gradient (exact zeros) and a non-finite one (NaN everywhere: fails
+    loudly instead of wrapping an integer)."""
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+    r = MG.rng(5)
+    # align_corners=True with W-1, H-1 powers of two and dyadic flows: the sampling coordinates and the tap weights are
+    # exact in fp32, so the float64 oracle scatters exactly the kernel's contributions and only the accumulation differs
+    B, C, H, W = 2, 8, 33, 129
+    x = r.standard_normal((B, C, H, W)).astype(np.float32)
+    fl = (r.integers(-6, 7, (B, 2, H, W)) + r.integers(0, 4, (B, 2, H, W)) / 4.0).astype(np.float32)
+    fl[1, 0] = 50.25 - np.arange(W)[None, :]; fl[1, 1] = 10.5 - np.arange(H)[:, None]       # sample 1: everything to one spot
+    g = (r.standard_normal((B, C, H, W)) * np.exp2(r.integers(-30, 1, (B, C, H, W)))).astype(np.float32)
+
+    def run(gout):
+        xt = G(x, True)
+        y = ops.warp_flow(xt, G(fl), align_corners=True)
+        y.backward(G(gout))
+        return N(xt.grad)
+
+    xo = torch.from_numpy(x).double().requires_grad_(True)
+    yo = O.warp_flow(xo, torch.from_numpy(fl).double(), use_mask=False, align_corners=True)
+    yo.backward(torch.from_numpy(g).double())
+    want = xo.grad.numpy()
+    xo.grad = None
+    O.warp_flow(xo, torch.from_numpy(fl).double(), use_mask=False, align_corners=True).backward(torch.from_numpy(np.abs(g)).double())
+    mass = xo.grad.numpy()                                 # sum of |contribution| per element
+    got = run(g)
+    quantum = 2.0 ** -36 * 2.0 * np.abs(g).max()           # of the largest gradient's binade
+    for b in range(B):
+        err = np.abs(got[b] - want[b])
+        # each contribution g * w is one fp32 product (2^-24 relative), then a half-quantum per term, then one fp32 rounding
+        bound = 2.0 ** -24 * mass[b] + 0.5 * quantum * 4 * H * W + 2.0 ** -24 * np.abs(want[b])
+        assert (err <= bound).all(), (b, float((err - bound).max()))
+    assert np.array_equal(run(np.zeros_like(g)), np.zeros_like(g))
+    gbad = g.copy(); gbad[0, 0, 0, 0] = np.inf
+    assert np.isnan(run(gbad)).all()
 
 
 @pytest.mark.parametrize("ac", [False, True])
@@ -208,6 +255,27 @@ def test_rigid_golden(golden_dir, ac):
         assert np.array_equal(N(rf), g[key + "_rflow"]), key
         gclose(dt3.grad, g[key + "_rflow_gdepth"], rel=2e-4, atol=1e-4)
         gclose(pt3.grad, g[key + "_rflow_gpose"], rel=2e-4, atol=1e-3)
+
+
+def test_scatters_of_the_per_operator_api_are_reproducible():
+    """inverse_warp2's reference-depth gradient and the forward splat are scatter-adds too: both go through the
+    fixed-point accumulators of csrc/dfe_scatter.h and come out bitwise equal from run to run."""
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+    from unsupervised_depth_opticalflow_egomotion_amd.structures import inverse_warp2
+    img, depth, ref_depth, pose, k, wi, wd, wf = MG.g2_inputs(128, 416, 31, "rand")
+    outs = []
+    for _ in range(3):
+        rdt = G(ref_depth, True)
+        pi, valid, pd, cd = inverse_warp2(G(img), G(depth), rdt, G(pose), G(k), align_corners=False)
+        (pd * G(wd)).sum().backward()
+        outs.append(rdt.grad.clone())
+    assert float(outs[0].abs().max()) > 0 and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    r = MG.rng(77)
+    fl = G((3.0 * r.standard_normal((2, 2, 128, 416))).astype(np.float32))
+    sp = [ops.forward_splat_ones(fl, clamp=False) for _ in range(3)]
+    assert torch.equal(sp[0], sp[1]) and torch.equal(sp[0], sp[2])
+    # mass: every deposited weight lands somewhere or falls off the border -- at most one per source pixel
+    assert float(sp[0].double().sum()) <= 2 * 128 * 416 * (1 + 1e-6)
 
 
 @pytest.mark.parametrize("ac", [False, True])

@@ -31,10 +31,11 @@ _SIGNATURES = {
     "dfe_pose_vec2mat_fwd": [_P, _P, _P, _I, _P],
     "dfe_pose_vec2mat_bwd": [_P, _P, _P, _P, _I, _P],
     "dfe_warp_flow_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "dfe_warp_flow_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "dfe_scatter_ws_bytes": [ctypes.c_long],
+    "dfe_warp_flow_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dfe_pose_partials_floats": [_I, _I, _I],
     "dfe_inverse_warp2_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "dfe_inverse_warp2_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "dfe_inverse_warp2_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_thin_conv3x3": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dfe_wgrad3x3_partials_floats": [_I, _I, _I, _I, _I],
     "dfe_wgrad3x3_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -61,7 +62,7 @@ _SIGNATURES = {
     "dfe_dynamic_mask": [_P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _I, _I, _I, _P],
     "dfe_exact_math_selftest": [_P, ctypes.c_ulonglong, _P],
     "dfe_prepare_triplets": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "dfe_forward_splat_ones": [_P, _P, _I, _I, _I, _I, _P],
+    "dfe_forward_splat_ones": [_P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_ssim_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_ssim_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_corr_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -71,7 +72,7 @@ _SIGNATURES = {
     "dfe_maxpool3x3s2_bwd": [_P, _P, _P, _I, _I, _I, _P],
     "dfe_pwc_level_channels": [_I],
     "dfe_pwc_level_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "dfe_pwc_level_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dfe_pwc_level_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_resize": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dfe_resize_bilinear_fwd": [_P, _P, _I, _I, _I, _I, _I, ctypes.c_float, _I, _P],
     "dfe_resize_bilinear_bwd": [_P, _P, _I, _I, _I, _I, _I, ctypes.c_float, _I, _P],
@@ -89,7 +90,7 @@ _RESTYPES = {"dfe_error_string": ctypes.c_char_p, "dfe_geom_workspace_floats": c
              "dfe_bias_act_partials_floats": ctypes.c_long, "dfe_glue_partials_floats": ctypes.c_long,
              "dfe_bn_partials_floats": ctypes.c_long, "dfe_disp_head_partials_floats": ctypes.c_long,
              "dfe_wgrad3x3_partials_floats": ctypes.c_long,
-             "dfe_geom_maskpack_offset_bytes": ctypes.c_long}
+             "dfe_geom_maskpack_offset_bytes": ctypes.c_long, "dfe_scatter_ws_bytes": ctypes.c_long}
 
 
 class DfeError(RuntimeError):

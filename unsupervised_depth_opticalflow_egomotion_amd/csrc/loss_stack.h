@@ -49,6 +49,8 @@ struct GeomLayout {
   // offset (the mask pack's in particular) does not depend on the flag
   int dt;
   long o_yr, o_gyr, o_part2, o_spart2, o_sums2;   // masked rigid warps, their SSIM gradient, block / strip partials, sums
+  long o_scq;       // depth-consistency term: fixed-point accumulators of the projected-depth scatter (dfe_scatter.h),
+                    // 64-byte header + int64 [2 source frames][scale][B][N_s]
 };
 
 // Kernel-argument tables (passed by value).

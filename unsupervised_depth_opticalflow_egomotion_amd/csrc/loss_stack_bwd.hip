@@ -10,8 +10,10 @@
 //   k_geom_disp_smooth_bwd2 adjoint of the bilinear up-sampling as a gather per low-res pixel (register path for
 //                           ratios >= 1/4, k_geom_disp_smooth_bwd2_coarse = one wave per pixel below that)
 //   k_geom_pose_finalize    fixed-order reduction + closed-form 3x3 chains -> grad_pose
-// No float atomics anywhere: gradients are bitwise reproducible run to run.
+// No float atomics anywhere (the one scatter, of the optional depth-consistency term, adds 64-bit fixed-point
+// integers): gradients are bitwise reproducible run to run.
 #include "loss_stack_exact.h"
+#include "dfe_scatter.h"
 #include <cstdlib>
 
 namespace dfe {
@@ -27,7 +29,26 @@ struct GeomBwd {
   float* gyr[DFE_MAX_SCALES];    // depth-SSIM term: dL/d(masked rigid reconstruction) [2][B][3][N_s]
   int rmw_all;          // depth-consistency term: grad_disp of the SOURCE frames already holds the projected-depth
                         // scatter when the smoothness kernels run -> they add instead of store
+  const unsigned* scq_header;                  // ... and that scatter's fixed-point accumulators (dfe_scatter.h)
+  long long* gdq[2][DFE_MAX_SCALES];           // [source frame 0 / 2][scale] -> [B][N_s]
 };
+
+// Bound of every value the depth-consistency term scatters: d q / d pd = gq (-a - b q), |.| <= gq (1 + q) / |cd + pd|
+// <= gq * 2 / 2e-3 (q <= 1 inside the clamp; both depths are clamped at 1e-3).  gq is uniform per (sample, scale,
+// direction).  <<<1, 64>>>; writes the workspace header.
+__global__ void __launch_bounds__(64) k_geom_scatter_bound(GeomDev D, GeomBwd G, unsigned* __restrict__ header) {
+  unsigned m = 0u;
+  for (int i = threadIdx.x; i < D.B * D.S * 2; i += 64) {
+    const int d = i & 1, s = (i >> 1) % D.S, b = (i >> 1) / D.S;
+    const float gl = G.gl[DFE_LOSS_DEPTH_CONSIS * D.B + b];
+    const float gq = D.mode == 1 ? gl / static_cast<float>(D.N[s])
+                                 : gl * 3.0f * G.coef[(static_cast<long>(b) * D.S + s) * CF_COUNT + d * CF_PER_DIR + CF_DEPTH];
+    m = max(m, static_cast<unsigned>(__float_as_int(gq * 1000.0f)) & 0x7fffffffu);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, static_cast<unsigned>(__shfl_xor(static_cast<int>(m), o)));
+  if (threadIdx.x == 0) *header = m;
+}
 
 __device__ __forceinline__ float sgn(float v) { return static_cast<float>(v > 0.0f) - static_cast<float>(v < 0.0f); }
 
@@ -144,7 +165,8 @@ __global__ void __launch_bounds__(64) k_geom_ssim_bwd_roll(GeomDev D, GeomBwd G,
 // ---------------------------------------------------------------------- pointwise backward
 // DT: + the two optional depth terms (dfe_geom_args.depth_terms): dL/d(rigid reconstruction) of the SSIM launch over
 // the rigid warps (G.gyr), and the depth-consistency term's gradient wrt the computed depth (the projection's Z), the
-// rigid coordinate (through the sampled source disparity) and the source disparity itself (bilinear scatter, atomics).
+// rigid coordinate (through the sampled source disparity) and the source disparity itself (bilinear scatter in 64-bit
+// fixed point, dfe_scatter.h: order-independent).
 template <bool DT>
 __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomT T, GeomBwd G) {
   __shared__ float red[PB_COUNT * 4 * (GS_BLOCK / 64)];
@@ -242,11 +264,12 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomT T,
             interp_grad(qd, t, dx, dy);
             gix += gp * dx; giy += gp * dy;
             if (G.gdisp[fs][s] && gp != 0.0f) {
-              float* base = G.gdisp[fs][s] + static_cast<long>(b) * N + static_cast<long>(t.y0) * W + t.x0;
-              if (t.in_nw) atomicAdd(base, gp * t.nw);
-              if (t.in_ne) atomicAdd(base + 1, gp * t.ne);
-              if (t.in_sw) atomicAdd(base + W, gp * t.sw);
-              if (t.in_se) atomicAdd(base + W + 1, gp * t.se);
+              long long* base = G.gdq[fs >> 1][s] + static_cast<long>(b) * N + static_cast<long>(t.y0) * W + t.x0;
+              const float gs = gp * scatter_scale(*G.scq_header).to_fixed;
+              if (t.in_nw) fixed_add(base, to_fixed(gs, t.nw));
+              if (t.in_ne) fixed_add(base + 1, to_fixed(gs, t.ne));
+              if (t.in_sw) fixed_add(base + W, to_fixed(gs, t.sw));
+              if (t.in_se) fixed_add(base + W + 1, to_fixed(gs, t.se));
             }
           }
         }
@@ -427,11 +450,12 @@ __global__ void __launch_bounds__(GS_BLOCK) k_depth_point_bwd(GeomDev D, GeomBwd
             interp_grad(qd, t, dx, dy);
             gix += gp * dx; giy += gp * dy;
             if (G.gdisp[fs][s] && gp != 0.0f) {
-              float* base = G.gdisp[fs][s] + static_cast<long>(b) * N + static_cast<long>(t.y0) * W + t.x0;
-              if (t.in_nw) atomicAdd(base, gp * t.nw);
-              if (t.in_ne) atomicAdd(base + 1, gp * t.ne);
-              if (t.in_sw) atomicAdd(base + W, gp * t.sw);
-              if (t.in_se) atomicAdd(base + W + 1, gp * t.se);
+              long long* base = G.gdq[fs >> 1][s] + static_cast<long>(b) * N + static_cast<long>(t.y0) * W + t.x0;
+              const float gs = gp * scatter_scale(*G.scq_header).to_fixed;
+              if (t.in_nw) fixed_add(base, to_fixed(gs, t.nw));
+              if (t.in_ne) fixed_add(base + 1, to_fixed(gs, t.ne));
+              if (t.in_sw) fixed_add(base + W, to_fixed(gs, t.sw));
+              if (t.in_se) fixed_add(base + W + 1, to_fixed(gs, t.se));
             }
           }
         }
@@ -911,14 +935,31 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
   }
   for (int s = 0; s < DFE_MAX_SCALES; ++s) G.gyr[s] = (s < L.S) ? ws + L.o_gyr + 6L * L.B * L.off_px[s] : nullptr;
   G.rmw_all = (L.dt & DFE_DEPTH_TERM_CONSIS) ? 1 : 0;
+  G.scq_header = reinterpret_cast<const unsigned*>(ws + L.o_scq);
+  for (int fi = 0; fi < 2; ++fi)
+    for (int s = 0; s < DFE_MAX_SCALES; ++s)
+      G.gdq[fi][s] = (G.rmw_all && s < L.S) ? scatter_acc(ws + L.o_scq) + (static_cast<long>(fi) * L.off_px[L.S] + L.off_px[s]) * L.B : nullptr;
   const unsigned nblk_total = L.blk_start[L.S];
   int seg = 0;
 #define DFE_MARK() do { if (ev) (void)hipEventRecord(ev[++seg], st); } while (0)
   if (ev) (void)hipEventRecord(ev[0], st);
-  if (G.rmw_all)   // the projected-depth scatter accumulates into the source frames' disparity gradients
-    for (int f = 0; f < 3; f += 2)
+  if (G.rmw_all) {   // the projected-depth scatter: zero accumulators + the analytic bound of what is added to them
+    const int rc = scatter_begin_bound(ws + L.o_scq, 2L * L.B * L.off_px[L.S], st);
+    if (rc != DFE_OK) return rc;
+    k_geom_scatter_bound<<<1, 64, 0, st>>>(D, G, reinterpret_cast<unsigned*>(ws + L.o_scq));
+    DFE_LAUNCH_CHECK();
+  }
+  // ... and its sums become the source frames' disparity gradients before the smoothness kernels add to them
+  auto finish_scatter = [&]() -> int {
+    if (!G.rmw_all) return DFE_OK;
+    for (int fi = 0; fi < 2; ++fi)
       for (int s = 0; s < L.S; ++s)
-        if (a->grad_disp[f][s] && hipMemsetAsync(a->grad_disp[f][s], 0, sizeof(float) * L.B * L.N[s], st) != hipSuccess) return DFE_ERR_LAUNCH;
+        if (a->grad_disp[2 * fi][s]) {
+          const int rc = scatter_finish_at(G.scq_header, G.gdq[fi][s], a->grad_disp[2 * fi][s], static_cast<long>(L.B) * L.N[s], st);
+          if (rc != DFE_OK) return rc;
+        }
+    return DFE_OK;
+  };
   if (a->mode == 2) {
     k_geom_ssim_bwd_roll<<<dim3(L.rollb_start[L.S], L.B * 2), 64, 0, st>>>(D, G, 0);
     DFE_LAUNCH_CHECK();
@@ -940,6 +981,7 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     if (L.dt) k_depth_point_bwd<true><<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, G);
     else k_depth_point_bwd<false><<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, G);
     DFE_LAUNCH_CHECK();
+    { const int rc = finish_scatter(); if (rc != DFE_OK) return rc; }
     DFE_MARK(); DFE_MARK();
   } else {
     k_geom_ssim_bwd_roll<<<dim3(L.rollb_start[L.S], L.B * 2), 64, 0, st>>>(D, G, 0);
@@ -952,6 +994,7 @@ static int geom_bwd_impl(const dfe_geom_args* a, void* stream, hipEvent_t* ev) {
     if (L.dt) k_geom_point_bwd<true><<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, T, G);
     else k_geom_point_bwd<false><<<dim3(nblk_total, L.B), GS_BLOCK, 0, st>>>(D, T, G);
     DFE_LAUNCH_CHECK();
+    { const int rc = finish_scatter(); if (rc != DFE_OK) return rc; }
     DFE_MARK();
     k_geom_flow_smooth_bwd<<<dim3(L.rollb_start[L.S], L.B), 64, 0, st>>>(D, G);
     DFE_LAUNCH_CHECK();

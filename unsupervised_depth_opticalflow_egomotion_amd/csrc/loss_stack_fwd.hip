@@ -79,6 +79,7 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
   L->o_part2 = o; o = align4(o + (L->dt ? B * nblk_total * 2 : 0));
   L->o_spart2 = o; o = align4(o + ((L->dt & DFE_DEPTH_TERM_SSIM) ? B * 2 * static_cast<long>(L->roll_start[S]) : 0));
   L->o_sums2 = o; o = align4(o + (L->dt ? B * S * 4 : 0));
+  L->o_scq = o; o = align4(o + ((L->dt & DFE_DEPTH_TERM_CONSIS) ? 16 + 4 * B * sumN : 0));
   L->total = o;
   return DFE_OK;
 }

@@ -10,6 +10,7 @@
 // All kernels are HBM/L2-bound stencil or gather work: no MFMA, coalesced row-major
 // accesses, LDS only where a tile is re-read (SSIM window, correlation window).
 #include "dfe_camera.h"
+#include "dfe_scatter.h"
 #include <cstdint>
 
 namespace dfe {
@@ -134,18 +135,22 @@ __global__ void __launch_bounds__(64) k_warp_flow_fwd(const float* __restrict__ 
     if (c < nch) out[(static_cast<long>(b) * C + c0 + c) * HW + p] = interp(q[c], t) * keep;
 }
 
-// grad wrt flow (a sum over all channels) and optionally wrt x (scatter-add; gx pre-zeroed by the caller).
+// grad wrt flow (a sum over all channels) and optionally wrt x (scatter-add into the 64-bit fixed-point accumulators
+// of gx_ws, dfe_scatter.h: order-independent, so gx is bitwise reproducible too).
 // Block = 64 pixels x WF_GROUPS channel groups: group g walks the channel chunks g, g + WF_GROUPS, ... and keeps its
 // partial (d/dix, d/diy) sums in registers; the groups' partials meet in LDS and are added in group order, so gflow
-// is written once per pixel and is bitwise reproducible (no float atomics, no zero-fill).  Only the scatter into gx
-// (PWC feature warps) uses atomics.  grid: x = pixel blocks of 64, y = 1, z = sample.
+// is written once per pixel and is bitwise reproducible (no float atomics, no zero-fill).
+// grid: x = pixel blocks of 64, y = 1, z = sample.
 constexpr int WF_GROUPS = 4;
 
 __global__ void __launch_bounds__(64 * WF_GROUPS) k_warp_flow_bwd(const float* __restrict__ x, const float* __restrict__ flow,
                                                       const float* __restrict__ gout, float* __restrict__ gflow,
-                                                      float* __restrict__ gx, const float* __restrict__ gflow_add, long gfa_bs,
+                                                      void* __restrict__ gx_ws, const float* __restrict__ gflow_add, long gfa_bs,
                                                       int C, int H, int W, int use_mask, int ac) {
   __shared__ float red[WF_GROUPS][2][64];
+  ScatterScale sc{};
+  long long* gxq = nullptr;
+  if (gx_ws) { sc = scatter_scale(*static_cast<const unsigned*>(gx_ws)); gxq = scatter_acc(gx_ws); }
   const int b = blockIdx.z, HW = H * W;
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int p = blockIdx.x * 64 + lane;
@@ -175,15 +180,16 @@ __global__ void __launch_bounds__(64 * WF_GROUPS) k_warp_flow_bwd(const float* _
         gix += g[c] * dx; giy += g[c] * dy;
       }
     }
-    if (gx) {
+    if (gxq) {
 #pragma unroll
       for (int c = 0; c < WF_CK; ++c) {
         if (c < nch && g[c] != 0.0f) {
-          float* base = gx + (static_cast<long>(b) * C + c0 + c) * HW + static_cast<long>(t.y0) * W + t.x0;
-          if (t.in_nw) atomicAdd(base, g[c] * t.nw);
-          if (t.in_ne) atomicAdd(base + 1, g[c] * t.ne);
-          if (t.in_sw) atomicAdd(base + W, g[c] * t.sw);
-          if (t.in_se) atomicAdd(base + W + 1, g[c] * t.se);
+          long long* base = gxq + (static_cast<long>(b) * C + c0 + c) * HW + static_cast<long>(t.y0) * W + t.x0;
+          const float gs = g[c] * sc.to_fixed;
+          if (t.in_nw) fixed_add(base, to_fixed(gs, t.nw));
+          if (t.in_ne) fixed_add(base + 1, to_fixed(gs, t.ne));
+          if (t.in_sw) fixed_add(base + W, to_fixed(gs, t.sw));
+          if (t.in_se) fixed_add(base + W + 1, to_fixed(gs, t.se));
         }
       }
     }
@@ -233,15 +239,18 @@ __global__ void k_inverse_warp2_fwd(const float* __restrict__ img, const float* 
   if (out_cdepth) out_cdepth[static_cast<long>(b) * HW + p] = pr.Z;
 }
 
-// Backward of inverse_warp2: grads wrt depth, ref_depth (scatter) and the 12 camera sums.
+// Backward of inverse_warp2: grads wrt depth, ref_depth (order-independent scatter, dfe_scatter.h) and the 12 camera sums.
 // partials [B][1][gridDim.x][12].
 __global__ void k_inverse_warp2_bwd(const float* __restrict__ img, const float* __restrict__ depth,
                                     const float* __restrict__ ref_depth, const Camera* __restrict__ cams,
                                     const float* __restrict__ g_img, const float* __restrict__ g_pdepth,
                                     const float* __restrict__ g_cdepth, float* __restrict__ g_depth,
-                                    float* __restrict__ g_refdepth, float* __restrict__ partials,
+                                    void* __restrict__ g_refdepth_ws, float* __restrict__ partials,
                                     int H, int W, int ac) {
   __shared__ float red[12 * 16];
+  ScatterScale sc{};
+  long long* g_refq = nullptr;
+  if (g_refdepth_ws) { sc = scatter_scale(*static_cast<const unsigned*>(g_refdepth_ws)); g_refq = scatter_acc(g_refdepth_ws); }
   const int b = blockIdx.y, HW = H * W;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   float acc[12];
@@ -272,12 +281,13 @@ __global__ void k_inverse_warp2_bwd(const float* __restrict__ img, const float* 
       float dx, dy;
       interp_grad(q, t, dx, dy);
       gix += g * dx; giy += g * dy;
-      if (g_refdepth && g != 0.0f) {
-        float* base = g_refdepth + static_cast<long>(b) * HW + static_cast<long>(t.y0) * W + t.x0;
-        if (t.in_nw) atomicAdd(base, g * t.nw);
-        if (t.in_ne) atomicAdd(base + 1, g * t.ne);
-        if (t.in_sw) atomicAdd(base + W, g * t.sw);
-        if (t.in_se) atomicAdd(base + W + 1, g * t.se);
+      if (g_refq && g != 0.0f) {
+        long long* base = g_refq + static_cast<long>(b) * HW + static_cast<long>(t.y0) * W + t.x0;
+        const float gs = g * sc.to_fixed;
+        if (t.in_nw) fixed_add(base, to_fixed(gs, t.nw));
+        if (t.in_ne) fixed_add(base + 1, to_fixed(gs, t.ne));
+        if (t.in_sw) fixed_add(base + W, to_fixed(gs, t.sw));
+        if (t.in_se) fixed_add(base + W + 1, to_fixed(gs, t.se));
       }
     }
     const float sx = ac ? static_cast<float>(W - 1) / 2.0f : static_cast<float>(W) / 2.0f;
@@ -742,15 +752,19 @@ int dfe_warp_flow_fwd(const float* x, const float* flow, float* out, int B, int 
   return DFE_OK;
 }
 
-int dfe_warp_flow_bwd(const float* x, const float* flow, const float* gout, float* gflow, float* gx, int B, int C,
-                      int H, int W, int use_mask, int align_corners, void* stream) {
+int dfe_warp_flow_bwd(const float* x, const float* flow, const float* gout, float* gflow, float* gx, void* gx_ws, int B,
+                      int C, int H, int W, int use_mask, int align_corners, void* stream) {
   DFE_REQUIRE(x && flow && gout && (gflow || gx), DFE_ERR_NULL);
+  DFE_REQUIRE(!gx || gx_ws, DFE_ERR_NULL);
   DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
   DFE_REQUIRE(B <= 65535 && (C + WF_CK - 1) / WF_CK <= 65535, DFE_ERR_DIMS);
   dim3 g(static_cast<unsigned>((static_cast<long>(H) * W + 63) / 64), 1, B);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  k_warp_flow_bwd<<<g, 64 * WF_GROUPS, 0, st>>>(x, flow, gout, gflow, gx, nullptr, 0, C, H, W, use_mask, align_corners);
+  const long n = static_cast<long>(B) * C * H * W;
+  if (gx) { const int rc = scatter_begin(gx_ws, n, gout, n, st); if (rc != DFE_OK) return rc; }
+  k_warp_flow_bwd<<<g, 64 * WF_GROUPS, 0, st>>>(x, flow, gout, gflow, gx ? gx_ws : nullptr, nullptr, 0, C, H, W, use_mask, align_corners);
   DFE_LAUNCH_CHECK();
+  if (gx) return scatter_finish(gx_ws, gx, n, st);
   return DFE_OK;
 }
 
@@ -772,16 +786,20 @@ int dfe_inverse_warp2_fwd(const float* img, const float* depth, const float* ref
 
 int dfe_inverse_warp2_bwd(const float* img, const float* depth, const float* ref_depth, const float* cams,
                           const float* g_img, const float* g_pdepth, const float* g_cdepth, float* g_depth,
-                          float* g_refdepth, float* g_pose, float* partials, int B, int H, int W, int align_corners,
-                          void* stream) {
+                          float* g_refdepth, void* g_refdepth_ws, float* g_pose, float* partials, int B, int H, int W,
+                          int align_corners, void* stream) {
   DFE_REQUIRE(img && depth && cams && g_depth && g_pose && partials, DFE_ERR_NULL);
   DFE_REQUIRE(!g_pdepth || ref_depth, DFE_ERR_NULL);
+  DFE_REQUIRE(!g_refdepth || (g_refdepth_ws && g_pdepth), DFE_ERR_NULL);
   DFE_REQUIRE(B > 0 && H > 1 && W > 1, DFE_ERR_DIMS);
   const int nblk = static_cast<int>((static_cast<long>(H) * W + 255) / 256);
   dim3 g(nblk, B);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  k_inverse_warp2_bwd<<<g, 256, 0, st>>>(img, depth, ref_depth, reinterpret_cast<const Camera*>(cams), g_img, g_pdepth, g_cdepth, g_depth, g_refdepth, partials, H, W, align_corners);
+  const long n = static_cast<long>(B) * H * W;
+  if (g_refdepth) { const int rc = scatter_begin(g_refdepth_ws, n, g_pdepth, n, st); if (rc != DFE_OK) return rc; }
+  k_inverse_warp2_bwd<<<g, 256, 0, st>>>(img, depth, ref_depth, reinterpret_cast<const Camera*>(cams), g_img, g_pdepth, g_cdepth, g_depth, g_refdepth ? g_refdepth_ws : nullptr, partials, H, W, align_corners);
   DFE_LAUNCH_CHECK();
+  if (g_refdepth) { const int rc = scatter_finish(g_refdepth_ws, g_refdepth, n, st); if (rc != DFE_OK) return rc; }
   IntList nb; nb.v[0] = nblk;
   k_pose_finalize<<<grid1d(B, 64), 64, 0, st>>>(partials, reinterpret_cast<const Camera*>(cams), g_pose, B, 1, nblk, nb, 0);
   DFE_LAUNCH_CHECK();
@@ -908,10 +926,11 @@ int dfe_pwc_level_fwd(const float* c1, const float* c2, const float* flow, float
 }
 
 int dfe_pwc_level_bwd(const float* c1, const float* c2, const float* flow, const float* warped, const float* gx,
-                      float* g_warped, float* g_c1, float* g_c2, float* g_flow, int B, int C, int H, int W,
+                      float* g_warped, float* g_c1, float* g_c2, void* g_c2_ws, float* g_flow, int B, int C, int H, int W,
                       int align_corners, void* stream) {
   DFE_REQUIRE(c1 && c2 && flow && warped && gx && g_warped && g_c1, DFE_ERR_NULL);
   DFE_REQUIRE(g_c2 || g_flow, DFE_ERR_NULL);
+  DFE_REQUIRE(!g_c2 || g_c2_ws, DFE_ERR_NULL);
   DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
   DFE_REQUIRE(B <= 65535, DFE_ERR_DIMS);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -921,10 +940,12 @@ int dfe_pwc_level_bwd(const float* c1, const float* c2, const float* flow, const
   // dL/dc1 = correlation gradient + the concatenated copy's slice; dL/dwarped
   launch_corr_bwd(c1, warped, gx, xbs, gx_c1, xbs, g_c1, g_warped, B, C, H, W, st);
   DFE_LAUNCH_CHECK();
-  if (g_c2 && hipMemsetAsync(g_c2, 0, sizeof(float) * B * C * HW, st) != hipSuccess) return DFE_ERR_LAUNCH;
+  const long n = static_cast<long>(B) * C * HW;
+  if (g_c2) { const int rc = scatter_begin(g_c2_ws, n, g_warped, n, st); if (rc != DFE_OK) return rc; }
   dim3 g(static_cast<unsigned>((HW + 63) / 64), 1, B);
-  k_warp_flow_bwd<<<g, 64 * WF_GROUPS, 0, st>>>(c2, flow, g_warped, g_flow, g_c2, g_flow ? gx_flow : nullptr, xbs, C, H, W, 0, align_corners);
+  k_warp_flow_bwd<<<g, 64 * WF_GROUPS, 0, st>>>(c2, flow, g_warped, g_flow, g_c2 ? g_c2_ws : nullptr, g_flow ? gx_flow : nullptr, xbs, C, H, W, 0, align_corners);
   DFE_LAUNCH_CHECK();
+  if (g_c2) return scatter_finish(g_c2_ws, g_c2, n, st);
   return DFE_OK;
 }
 

@@ -32,6 +32,11 @@ def _ac(flag):
     return int(_ALIGN_CORNERS if flag is None else bool(flag))
 
 
+def scatter_ws(n, device):
+    """Workspace of the order-independent scatter-add into ``n`` floats (csrc/dfe_scatter.h; zero-filled by the library)."""
+    return torch.empty(get_lib().dfe_scatter_ws_bytes(int(n)), device=device, dtype=torch.uint8)
+
+
 # --------------------------------------------------------------------------- cameras
 def prepare_cameras(pose, K, downscales):
     """pose [B,ndir,6] or [B,6], K [B,3,3] -> opaque camera buffer [B*ndir*len(downscales), 66]."""
@@ -70,11 +75,12 @@ class WarpFlowFn(torch.autograd.Function):
         use_mask, ac = ctx.cfg
         B, C, H, W = x.shape
         gout = f32c(gout)
-        gflow = torch.empty_like(flow) if ctx.needs_input_grad[1] else None   # zero-filled by the library when C > 8
-        gx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
+        gflow = torch.empty_like(flow) if ctx.needs_input_grad[1] else None
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None         # every element written by the library
         if gflow is None and gx is None:
             return None, None, None, None
-        check(lib.dfe_warp_flow_bwd(ptr(x), ptr(flow), ptr(gout), ptr(gflow), ptr(gx), B, C, H, W, use_mask, ac,
+        ws = scatter_ws(x.numel(), x.device) if gx is not None else None
+        check(lib.dfe_warp_flow_bwd(ptr(x), ptr(flow), ptr(gout), ptr(gflow), ptr(gx), ptr(ws), B, C, H, W, use_mask, ac,
                                     stream_ptr()), "dfe_warp_flow_bwd")
         return gx, gflow, None, None
 
@@ -149,12 +155,13 @@ class InverseWarp2Fn(torch.autograd.Function):
         g_pd = f32c(g_pd) if g_pd is not None else None
         g_cd = f32c(g_cd) if g_cd is not None else None
         g_depth = torch.empty(B, 1, H, W, device=dev)
-        g_ref = torch.zeros(B, 1, H, W, device=dev) if (ctx.needs_input_grad[2] and g_pd is not None) else None
+        g_ref = torch.empty(B, 1, H, W, device=dev) if (ctx.needs_input_grad[2] and g_pd is not None) else None
+        g_ref_ws = scatter_ws(B * H * W, dev) if g_ref is not None else None
         g_pose = torch.empty(B, 6, device=dev)
         ws = torch.empty(lib.dfe_pose_partials_floats(B, H, W), device=dev)
         check(lib.dfe_inverse_warp2_bwd(ptr(img), ptr(depth), ptr(ref_depth), ptr(cams), ptr(g_img), ptr(g_pd),
-                                        ptr(g_cd), ptr(g_depth), ptr(g_ref), ptr(g_pose), ptr(ws), B, H, W, ctx.ac,
-                                        stream_ptr()), "dfe_inverse_warp2_bwd")
+                                        ptr(g_cd), ptr(g_depth), ptr(g_ref), ptr(g_ref_ws), ptr(g_pose), ptr(ws), B, H, W,
+                                        ctx.ac, stream_ptr()), "dfe_inverse_warp2_bwd")
         return None, g_depth, g_ref, g_pose, None, None
 
 
@@ -303,11 +310,12 @@ class PwcLevelInputFn(torch.autograd.Function):
         B, C, H, W = c1.shape
         gx = f32c(gx)
         g_c1 = torch.empty_like(c1)
-        g_c2 = torch.empty_like(c2) if ctx.needs_input_grad[1] else None    # zero-filled by the library
+        g_c2 = torch.empty_like(c2) if ctx.needs_input_grad[1] else None    # every element written by the library
         g_flow = torch.empty_like(flow) if (ctx.needs_input_grad[2] or g_c2 is None) else None
         g_warped = torch.empty_like(c2)
+        ws = scatter_ws(c2.numel(), c2.device) if g_c2 is not None else None
         check(lib.dfe_pwc_level_bwd(ptr(c1), ptr(c2), ptr(flow), ptr(warped), ptr(gx), ptr(g_warped), ptr(g_c1),
-                                    ptr(g_c2), ptr(g_flow), B, C, H, W, ctx.ac, stream_ptr()), "dfe_pwc_level_bwd")
+                                    ptr(g_c2), ptr(ws), ptr(g_flow), B, C, H, W, ctx.ac, stream_ptr()), "dfe_pwc_level_bwd")
         return g_c1, g_c2, (g_flow if ctx.needs_input_grad[2] else None), None
 
 
@@ -407,7 +415,9 @@ def forward_splat_ones(flow, clamp=True):
     if C != 2:
         raise ValueError("flow must be [B,2,H,W]")
     out = torch.empty(B, 1, H, W, device=fl.device)
-    check(lib.dfe_forward_splat_ones(ptr(fl), ptr(out), B, H, W, int(bool(clamp)), stream_ptr()), "dfe_forward_splat_ones")
+    ws = scatter_ws(B * H * W, fl.device)
+    check(lib.dfe_forward_splat_ones(ptr(fl), ptr(out), ptr(ws), B, H, W, int(bool(clamp)), stream_ptr()),
+          "dfe_forward_splat_ones")
     return out
 
 
