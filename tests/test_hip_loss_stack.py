@@ -351,7 +351,7 @@ def test_flow_mode_vs_oracle(shape, S, ac):
 
 
 @pytest.mark.parametrize("ac", [False, True])
-@pytest.mark.parametrize("shape,S", [((2, 128, 448), 3), ((3, 70, 100), 2), ((1, 256, 832), 4)])
+@pytest.mark.parametrize("shape,S", [((2, 128, 448), 3), ((3, 70, 100), 2), ((1, 256, 832), 4), ((4, 256, 832), 3)])
 @pytest.mark.parametrize("depth_terms", [False, True])
 def test_depth_mode_vs_oracle(shape, S, ac, depth_terms):
     """mode 1 (Model_depth stack, model_depth.py:272-337): the inverse_warp2 validity and texture masks are exact IEEE
@@ -359,7 +359,9 @@ def test_depth_mode_vs_oracle(shape, S, ac, depth_terms):
     feeds a decision); losses 5e-6, gradients 1e-4 of their scale element-wise, pose gradient 2e-5."""
     from unsupervised_depth_opticalflow_egomotion_amd.loss_stack import depth_loss_stack
     b, h, w = shape
-    inp = synthetic.make_loss_stack_inputs(b, h, w, S, seed=1700 + h)
+    if b == 4 and (ac or depth_terms):
+        pytest.skip("BASELINE configs[1] (B=4, 256x832, S=3) is compared once, in the default convention")
+    inp = synthetic.make_loss_stack_inputs(b, h, w, S, seed=1700 + h + (b if b == 4 else 0))
     wts = dict(loss_depth_pixel=1.0, loss_depth_smooth=0.1)
     if depth_terms:   # the terms the reference keeps commented (model_depth.py:326-327,332-333), config weights
         wts.update(loss_depth_ssim=0.85, loss_depth_consis=0.1)
