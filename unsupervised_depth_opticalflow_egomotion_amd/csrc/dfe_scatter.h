@@ -50,6 +50,15 @@ __device__ __forceinline__ void fixed_add(long long* acc, long long q) {
   if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(acc), static_cast<unsigned long long>(q));
 }
 
+// lane l receives lane l-1's value (0 in lane 0): two DPP wave_shr:1 moves.  All lanes of the wave must be active.
+__device__ __forceinline__ long long fixed_from_left_lane(long long q) {
+  const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(q), 0x138, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(q >> 32), 0x138, 0xF, 0xF, true);
+  return (static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo);
+}
+__device__ __forceinline__ int int_from_left_lane(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true); }
+__device__ __forceinline__ int int_from_right_lane(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xF, 0xF, true); }
+
 __device__ __forceinline__ float from_fixed(long long q, const ScatterScale& s) {
   if (s.to_fixed != s.to_fixed) return s.to_fixed;
   return static_cast<float>(static_cast<double>(q) * s.to_float);

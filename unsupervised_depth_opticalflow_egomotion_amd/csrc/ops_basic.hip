@@ -152,7 +152,8 @@ __global__ void __launch_bounds__(64 * WF_GROUPS) k_warp_flow_bwd(const float* _
   long long* gxq = nullptr;
   if (gx_ws) { sc = scatter_scale(*static_cast<const unsigned*>(gx_ws)); gxq = scatter_acc(gx_ws); }
   const int b = blockIdx.z, HW = H * W;
-  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: the channel loop is scalar control flow
   const int p = blockIdx.x * 64 + lane;
   const bool live = p < HW;
   const int pc = live ? p : HW - 1;
@@ -164,6 +165,15 @@ __global__ void __launch_bounds__(64 * WF_GROUPS) k_warp_flow_bwd(const float* _
   float keep = live ? 1.0f : 0.0f;
   if (use_mask && tap_cover(t) < 0.9999f) keep = 0.0f;
   float gix = 0.0f, giy = 0.0f;
+  // Neighbouring lanes are neighbouring pixels: where the flow is smooth, lane l's north-east / south-east taps are lane
+  // l+1's north-west / south-west taps.  Integer sums may be regrouped freely, so such pairs are added in registers
+  // (one DPP move) and scattered with ONE atomic: about half the atomics on the flows a trained (or freshly
+  // initialised) PWC net produces.  The channel loop is wave-uniform, so every lane takes part in the moves.
+  // (the moves first, unconditionally: a DPP move reads 0 from a lane that a short-circuited condition has switched off)
+  const int y0_r = int_from_right_lane(t.y0), x0_r = int_from_right_lane(t.x0);
+  const int y0_l = int_from_left_lane(t.y0), x0_l = int_from_left_lane(t.x0);
+  const bool gives_right = (lane < 63) & (y0_r == t.y0) & (x0_r == t.x0 + 1);
+  const bool takes_left = (lane > 0) & (y0_l == t.y0) & (x0_l + 1 == t.x0);
   for (int c0 = grp * WF_CK; c0 < C; c0 += WF_GROUPS * WF_CK) {
     const int nch = min(WF_CK, C - c0);
     float g[WF_CK];
@@ -183,13 +193,18 @@ __global__ void __launch_bounds__(64 * WF_GROUPS) k_warp_flow_bwd(const float* _
     if (gxq) {
 #pragma unroll
       for (int c = 0; c < WF_CK; ++c) {
-        if (c < nch && g[c] != 0.0f) {
-          long long* base = gxq + (static_cast<long>(b) * C + c0 + c) * HW + static_cast<long>(t.y0) * W + t.x0;
+        if (c < nch) {     // wave-uniform
           const float gs = g[c] * sc.to_fixed;
-          if (t.in_nw) fixed_add(base, to_fixed(gs, t.nw));
-          if (t.in_ne) fixed_add(base + 1, to_fixed(gs, t.ne));
-          if (t.in_sw) fixed_add(base + W, to_fixed(gs, t.sw));
-          if (t.in_se) fixed_add(base + W + 1, to_fixed(gs, t.se));
+          long long q_nw = t.in_nw ? to_fixed(gs, t.nw) : 0, q_ne = t.in_ne ? to_fixed(gs, t.ne) : 0;
+          long long q_sw = t.in_sw ? to_fixed(gs, t.sw) : 0, q_se = t.in_se ? to_fixed(gs, t.se) : 0;
+          const long long l_ne = fixed_from_left_lane(q_ne), l_se = fixed_from_left_lane(q_se);
+          q_nw += takes_left ? l_ne : 0; q_sw += takes_left ? l_se : 0;
+          q_ne = gives_right ? 0 : q_ne; q_se = gives_right ? 0 : q_se;
+          long long* base = gxq + (static_cast<long>(b) * C + c0 + c) * HW + static_cast<long>(t.y0) * W + t.x0;
+          fixed_add(base, q_nw);           // a zero is not added (and an out-of-range corner is zero)
+          fixed_add(base + 1, q_ne);
+          fixed_add(base + W, q_sw);
+          fixed_add(base + W + 1, q_se);
         }
       }
     }

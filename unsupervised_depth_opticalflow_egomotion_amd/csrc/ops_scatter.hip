@@ -20,7 +20,14 @@ __global__ void __launch_bounds__(256) k_scatter_amax(const float* __restrict__ 
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, static_cast<unsigned>(__shfl_xor(static_cast<int>(m), o)));
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(header, m);
+  __shared__ unsigned wmax[4];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    // one atomic per block, and none when the word already holds at least this much (a stale read can only be smaller)
+    if (m > __hip_atomic_load(header, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(header, m);
+  }
 }
 
 __global__ void __launch_bounds__(256) k_scatter_to_float(const unsigned* __restrict__ header, const long long* __restrict__ acc,
@@ -49,8 +56,8 @@ int scatter_begin(void* ws, long n, const float* amax_of, long amax_n, hipStream
   const int rc = scatter_begin_bound(ws, n, st);
   if (rc != DFE_OK) return rc;
   if (!amax_of || amax_n <= 0) return DFE_ERR_NULL;
-  const long blocks = (amax_n + 256 * 4 * 4 - 1) / (256 * 4 * 4);      // ~4 float4 per thread
-  k_scatter_amax<<<static_cast<unsigned>(blocks > 4096 ? 4096 : blocks), 256, 0, st>>>(amax_of, amax_n, static_cast<unsigned*>(ws));
+  const long blocks = (amax_n + 256 * 4 * 4 - 1) / (256 * 4 * 4);      // >= 4 float4 per thread
+  k_scatter_amax<<<static_cast<unsigned>(blocks > 1024 ? 1024 : blocks), 256, 0, st>>>(amax_of, amax_n, static_cast<unsigned*>(ws));
   return hipGetLastError() == hipSuccess ? DFE_OK : DFE_ERR_LAUNCH;
 }
 
