@@ -14,6 +14,7 @@
 #include "dfe_internal.h"
 #include "dfe_device.h"
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 namespace dfe {
 
@@ -128,6 +129,55 @@ __global__ void __launch_bounds__(256) k_elu_pad_bwd_pair(const float* __restric
     acc[0] = g0 + g1;
   }
   if (part) block_sum<1>(acc, red, part + static_cast<long>(plane_id()) * gridDim.x + blockIdx.x);
+}
+
+// ---- four elements per thread (W % 4 == 0): 16-byte loads / stores of x and gx, and ONE dword-aligned 16-byte load
+// of the padded gradient (it sits one element to the right: offset +1); the quads that contain column 1 or W-2 and
+// the rows 1 and H-2 collect the mirrored padding entries element by element.  Round 3: the pair kernels above move
+// 8 bytes per lane and instruction and stop at 3 TB/s on the decoder's large planes.
+struct __attribute__((packed, aligned(4))) QuadU { float a, b, c, d; };     // dword-aligned 16 bytes
+
+__device__ __forceinline__ float4 pad_adjoint_quad(const float* __restrict__ g, int iy, int ix, int H, int W) {
+  if (iy != 1 && iy != H - 2 && ix != 0 && ix != W - 4) {
+    const QuadU q = *reinterpret_cast<const QuadU*>(g + static_cast<long>(iy + 1) * (W + 2) + ix + 1);
+    return make_float4(q.a, q.b, q.c, q.d);
+  }
+  return make_float4(pad_adjoint(g, iy, ix, H, W), pad_adjoint(g, iy, ix + 1, H, W), pad_adjoint(g, iy, ix + 2, H, W),
+                     pad_adjoint(g, iy, ix + 3, H, W));
+}
+
+__global__ void __launch_bounds__(256) k_elu_pad_bwd_quad(const float* __restrict__ x, const float* __restrict__ bias,
+                                                          const float* __restrict__ gp, float* __restrict__ gx,
+                                                          float* __restrict__ part, int C, int H, int W, int elu) {
+  __shared__ float red[4 * 4];
+  const int Wq = W / 4;
+  const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+  float acc[1] = {0.0f};
+  if (e < static_cast<unsigned>(H * Wq)) {
+    const int iy = e / static_cast<unsigned>(Wq), ix = 4 * (e - iy * Wq);
+    const long pl = plane_id();
+    float4 g = pad_adjoint_quad(gp + pl * (H + 2) * (W + 2), iy, ix, H, W);
+    const long o = (pl * H + iy) * W + ix;
+    if (elu) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + o);
+      const float bv = bias ? bias[plane_id() % C] : 0.0f;
+      g.x *= elu1_grad(xv.x + bv); g.y *= elu1_grad(xv.y + bv); g.z *= elu1_grad(xv.z + bv); g.w *= elu1_grad(xv.w + bv);
+    }
+    *reinterpret_cast<float4*>(gx + o) = g;
+    acc[0] = (g.x + g.y) + (g.z + g.w);
+  }
+  if (part) block_sum<1>(acc, red, part + static_cast<long>(plane_id()) * gridDim.x + blockIdx.x);
+}
+
+__global__ void __launch_bounds__(256) k_cat_pad_bwd_skip_quad(const float* __restrict__ gp, float* __restrict__ gskip,
+                                                               int C1, int C2, int H, int W) {
+  const int Wq = W / 4;
+  const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= static_cast<unsigned>(H * Wq)) return;
+  const int iy = e / static_cast<unsigned>(Wq), ix = 4 * (e - iy * Wq);
+  const int b = plane_id() / C2, c = plane_id() - b * C2;
+  const float* g = gp + (static_cast<long>(b) * (C1 + C2) + C1 + c) * (H + 2) * (W + 2);
+  *reinterpret_cast<float4*>(gskip + (static_cast<long>(plane_id()) * H + iy) * W + ix) = pad_adjoint_quad(g, iy, ix, H, W);
 }
 
 __global__ void __launch_bounds__(256) k_cat_pad_bwd_skip_pair(const float* __restrict__ gp, float* __restrict__ gskip,
@@ -279,100 +329,123 @@ __global__ void __launch_bounds__(256) k_elu_up2_cat_pad_bwd_x(const float* __re
   if (part) block_sum<1>(acc, red, part + static_cast<long>(plane_id()) * gridDim.x + blockIdx.x);
 }
 
-// The same gradient as a rolling-window wave kernel (the thread-per-element kernel above reads every padded gradient
-// four times through L1 with ten vector-memory instructions per output: 0.8 TB/s).  A wave owns 64 low-res columns
-// and marches down UB_ROWS low-res rows: low-res row i needs the padded rows 2i..2i+3, two of which the next row
-// re-uses, so each step loads two padded rows -- one 8-byte load per lane (columns 2j, 2j+1), columns 2j+2, 2j+3 come
-// from the right-hand lane by DPP wave shifts -- folds them with the horizontal tent (1/4, 3/4, 3/4, 1/4) and keeps two
-// folded rows in registers: every padded gradient is loaded once, 4 vector-memory instructions per output row.
-// Border elements (two rows / columns on each side: clamped taps and the reflection-pad adjoint) take the general
-// path of the kernel above.  Same arithmetic and summation order per element -> identical gx.
-// grid: x = strips * row blocks, y = c, z = b; block = one wave.
-constexpr int UB_ROWS = 8;
+// The same gradient through an LDS tile (round 3): a block owns UT_H x TW low-res outputs of one plane, stages the
+// (2 UT_H + 2) x (2 TW + 2) padded gradients they touch with coalesced 8-byte loads that are all in flight at once
+// (the element kernel above issues ten tiny loads per output: 0.6-1.1 TB/s; round 2's rolling-window wave kernel, two
+// loads per row with one row of prefetch, reached 1.9 TB/s on the widest plane and is gone), and every lane then folds
+// its four columns and four rows out of LDS.  Depth decoder, 12 images: 393 -> 185 us over the five stages, 3.6 TB/s
+// on the widest.  Tiles
+// that touch the plane's ring apply the reflection-pad adjoint while staging (zero outside the plane) and use the
+// clamped tap weights; same products and the same summation order per element as the two kernels above -> identical gx.
+// grid: x = tiles_x * tiles_y, y = c, z = b; 256 threads = (256 / TW) row groups x TW columns.
+constexpr int UT_H = 16;
 
-__global__ void __launch_bounds__(64) k_elu_up2_cat_pad_bwd_x_roll(const float* __restrict__ x, const float* __restrict__ bias,
-                                                                   const float* __restrict__ gp, float* __restrict__ gx,
-                                                                   float* __restrict__ part, int C1, int C2, int h, int w,
-                                                                   int strips) {
-  __shared__ float red[4];
+__device__ __forceinline__ void up2_adjoint_weights(int i, int n_lo, float (&wgt)[4]) {
+  const int n_hi = 2 * n_lo;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int a0, a1; float l0, l1;
+    const int y = 2 * i - 1 + k;
+    up2_tap(min(max(y, 0), n_hi - 1), n_lo, a0, a1, l0, l1);
+    wgt[k] = (y >= 0 && y < n_hi) ? ((a0 == i ? l0 : 0.0f) + (a1 == i ? l1 : 0.0f)) : 0.0f;
+  }
+}
+
+template <int TW>
+__global__ void __launch_bounds__(256) k_elu_up2_cat_pad_bwd_x_tile(const float* __restrict__ x, const float* __restrict__ bias,
+                                                                    const float* __restrict__ gp, float* __restrict__ gx,
+                                                                    float* __restrict__ part, int C1, int C2, int h, int w,
+                                                                    int tiles_x) {
+  constexpr int GROUPS = 256 / TW, R = UT_H / GROUPS, LW = 2 * TW + 2, LH = 2 * UT_H + 2, LW2 = LW / 2;
+  __shared__ __attribute__((aligned(16))) float tile[LH * LW];
+  __shared__ float red[4 * 4];
   const int H = 2 * h, W = 2 * w, Wp = W + 2;
-  const int strip = blockIdx.x % strips, rb = blockIdx.x / strips;
-  const int lane = threadIdx.x;
-  const int j = strip * 64 + lane, jc = min(j, w - 1);
-  const int i0 = rb * UB_ROWS, i1 = min(i0 + UB_ROWS, h);
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int i0 = ty * UT_H, j0 = tx * TW;
   const int b = plane_id() / C1, c = plane_id() - b * C1;
   const float* g = gp + (static_cast<long>(b) * (C1 + C2) + c) * (H + 2) * Wp;
-  const float bv = bias ? bias[c] : 0.0f;
-  const bool col_fast = j >= 2 && j < w - 2;
-  const bool own_d = lane == 63 && 2 * jc + 3 < Wp;
-  // raw loads of padded row r (columns 2j, 2j+1; the last lane also fetches 2j+2, 2j+3 itself) are issued one step
-  // ahead of their use; the fold is the horizontal tent over columns 2j..2j+3 (every lane executes the shifts)
-  struct Raw { PairF a, d; };
-  auto load_row = [&](int r) {
-    Raw o;
-    const float* q = g + static_cast<long>(min(r, H + 1)) * Wp + 2 * jc;
-    o.a = *reinterpret_cast<const PairF*>(q);
-    o.d = o.a;
-    if (own_d) o.d = *reinterpret_cast<const PairF*>(q + 2);
-    return o;
-  };
-#define DFE_UB_FOLD(dst, raw)                                                   \
-  {                                                                             \
-    float da_ = wave_shl1(raw.a.a), db_ = wave_shl1(raw.a.b);                   \
-    if (own_d) { da_ = raw.d.a; db_ = raw.d.b; }                                \
-    dst = ((0.25f * raw.a.a + 0.75f * raw.a.b) + 0.75f * da_) + 0.25f * db_;    \
-  }
-  const long obase = (static_cast<long>(b) * C1 + c) * h * w + jc;
-  float hA, hB;
+  const int t = threadIdx.x, jl = t % TW, grp = t / TW;
+  const int j = j0 + jl;
+  const long obase = (static_cast<long>(b) * C1 + c) * h * w;
+  // this thread's outputs: rows i0 + grp * R + q, column j; their x values are fetched while the tile is staged
+  float xv[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) xv[q] = x[obase + static_cast<long>(min(i0 + grp * R + q, h - 1)) * w + min(j, w - 1)];
+  const bool inner = i0 >= 2 && i0 + UT_H <= h - 2 && j0 >= 2 && j0 + TW <= w - 2;   // wave-uniform
+  // entry (r, cc) = unpadded gradient at (y, xq) = (2 i0 - 1 + r, 2 j0 - 1 + cc); away from the plane's ring that is
+  // the padded entry (2 i0 + r, 2 j0 + cc): a plain copy, 8 bytes per load (addresses clamped into the padded plane)
   {
-    const Raw r0 = load_row(2 * i0), r1 = load_row(2 * i0 + 1);
-    DFE_UB_FOLD(hA, r0);
-    DFE_UB_FOLD(hB, r1);
-  }
-  Raw nC = load_row(2 * i0 + 2), nD = load_row(2 * i0 + 3);
-  float nx = x[obase + static_cast<long>(i0) * w];
-  float acc[1] = {0.0f};
-  for (int i = i0; i < i1; ++i) {
-    const Raw cC = nC, cD = nD;
-    const float xv = nx;
-    nC = load_row(2 * i + 4); nD = load_row(2 * i + 5);          // rows of step i+1 (clamped at the plane's end)
-    nx = x[obase + static_cast<long>(min(i + 1, h - 1)) * w];
-    float hC, hD;
-    DFE_UB_FOLD(hC, cC);
-    DFE_UB_FOLD(hD, cD);
-    if (j < w) {
-      float total = 0.0f;
-      if (col_fast && i >= 2 && i < h - 2) {
-        total += 0.25f * hA; total += 0.75f * hB; total += 0.75f * hC; total += 0.25f * hD;
-      } else {
-        float wy[4], wx[4];
+    const float* src = g + static_cast<long>(2 * i0) * Wp + 2 * j0;
+    const int rmax = H + 1 - 2 * i0, kmax = (W - 2 * j0) / 2;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          int a0, a1; float l0, l1;
-          const int y = 2 * i - 1 + k;
-          up2_tap(min(max(y, 0), H - 1), h, a0, a1, l0, l1);
-          wy[k] = (y >= 0 && y < H) ? ((a0 == i ? l0 : 0.0f) + (a1 == i ? l1 : 0.0f)) : 0.0f;
-          const int xq = 2 * j - 1 + k;
-          up2_tap(min(max(xq, 0), W - 1), w, a0, a1, l0, l1);
-          wx[k] = (xq >= 0 && xq < W) ? ((a0 == j ? l0 : 0.0f) + (a1 == j ? l1 : 0.0f)) : 0.0f;
-        }
-#pragma unroll
-        for (int ky = 0; ky < 4; ++ky) {
-          if (wy[ky] == 0.0f) continue;
-          float a = 0.0f;
-#pragma unroll
-          for (int kx = 0; kx < 4; ++kx)
-            if (wx[kx] != 0.0f) a += wx[kx] * pad_adjoint(g, 2 * i - 1 + ky, 2 * j - 1 + kx, H, W);
-          total += wy[ky] * a;
-        }
+    for (int it = 0; it < (LH * LW2 + 255) / 256; ++it) {
+      const int idx = it * 256 + t;
+      if (idx < LH * LW2) {
+        const int r = idx / LW2, k = idx - r * LW2;
+        const AF2 v = *reinterpret_cast<const AF2*>(src + static_cast<long>(inner ? r : min(r, rmax)) * Wp + 2 * (inner ? k : min(k, kmax)));
+        *reinterpret_cast<AF2*>(tile + r * LW + 2 * k) = v;
       }
-      const float v = total * elu1_grad(xv + bv);
-      gx[obase + static_cast<long>(i) * w] = v;
+    }
+  }
+  if (!inner) {
+    // ring tiles: rows / columns 1 and H-2 / W-2 of the plane also collect the mirrored padding entries (reflection-pad
+    // adjoint): at most two rows and two columns of the tile.  Entries outside the plane keep whatever the clamped copy
+    // brought in: their tap weights are zero and zero weights are skipped below.
+    __syncthreads();
+    const int rs[2] = {2 - 2 * i0, H - 1 - 2 * i0}, ys[2] = {1, H - 2};
+    const int cs[2] = {2 - 2 * j0, W - 1 - 2 * j0}, xs[2] = {1, W - 2};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (rs[k] >= 0 && rs[k] < LH && t < LW) {
+        const int xq = 2 * j0 - 1 + t;
+        if (xq >= 0 && xq < W) tile[rs[k] * LW + t] = pad_adjoint(g, ys[k], xq, H, W);
+      }
+      if (cs[k] >= 0 && cs[k] < LW && t < LH) {
+        const int y = 2 * i0 - 1 + t;
+        if (y >= 0 && y < H) tile[t * LW + cs[k]] = pad_adjoint(g, y, xs[k], H, W);
+      }
+    }
+  }
+  __syncthreads();
+  float wx[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+  if (!inner) up2_adjoint_weights(min(j, w - 1), w, wx);
+  // horizontal fold of the 2R + 2 staged rows this thread's outputs touch
+  float f[2 * R + 2];
+  const float* trow = tile + (2 * grp * R) * LW + 2 * jl;
+#pragma unroll
+  for (int rr = 0; rr < 2 * R + 2; ++rr) {
+    const AF2 a = *reinterpret_cast<const AF2*>(trow + rr * LW), d = *reinterpret_cast<const AF2*>(trow + rr * LW + 2);
+    if (inner) f[rr] = ((0.25f * a.a + 0.75f * a.b) + 0.75f * d.a) + 0.25f * d.b;
+    else {
+      float s = 0.0f;
+      if (wx[0] != 0.0f) s += wx[0] * a.a;
+      if (wx[1] != 0.0f) s += wx[1] * a.b;
+      if (wx[2] != 0.0f) s += wx[2] * d.a;
+      if (wx[3] != 0.0f) s += wx[3] * d.b;
+      f[rr] = s;
+    }
+  }
+  const float bv = bias ? bias[c] : 0.0f;
+  float acc[1] = {0.0f};
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const int i = i0 + grp * R + q;
+    float total = 0.0f;
+    if (inner) {
+      total += 0.25f * f[2 * q]; total += 0.75f * f[2 * q + 1]; total += 0.75f * f[2 * q + 2]; total += 0.25f * f[2 * q + 3];
+    } else {
+      float wy[4];
+      up2_adjoint_weights(min(i, h - 1), h, wy);
+#pragma unroll
+      for (int ky = 0; ky < 4; ++ky)
+        if (wy[ky] != 0.0f) total += wy[ky] * f[2 * q + ky];
+    }
+    if (i < h && j < w) {
+      const float v = total * elu1_grad(xv[q] + bv);
+      gx[obase + static_cast<long>(i) * w + j] = v;
       acc[0] += v;
     }
-    hA = hC; hB = hD;
   }
-#undef DFE_UB_FOLD
   if (part) block_sum<1>(acc, red, part + static_cast<long>(plane_id()) * gridDim.x + blockIdx.x);
 }
 
@@ -412,13 +485,12 @@ using namespace dfe;
 
 static inline bool grid_ok(long plane_elems, long batch, long channels) { return plane_elems < (1L << 31) && batch <= 65535 && channels <= 65535; }
 static inline bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline unsigned nblk(long n) { return static_cast<unsigned>((n + 255) / 256); }
 
 extern "C" long dfe_glue_partials_floats(int B, int C, int H, int W) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
-  const long roll = W >= 256 ? static_cast<long>((W + 63) / 64) * ((H + UB_ROWS - 1) / UB_ROWS) : 0;   // units of the rolling kernel (wide planes only)
-  const long blocks = nblk(static_cast<long>(H) * W);
-  return static_cast<long>(B) * C * (roll > blocks ? roll : blocks);
+  return static_cast<long>(B) * C * nblk(static_cast<long>(H) * W);     // one partial per block of the widest grid used
 }
 
 extern "C" int dfe_elu_pad_fwd(const float* x, const float* bias, float* out, int B, int C, int H, int W, int apply_elu,
@@ -438,8 +510,10 @@ extern "C" int dfe_elu_pad_bwd(const float* x, const float* bias, const float* g
   if (B <= 0 || C <= 0 || H < 2 || W < 2 || !grid_ok((H + 2L) * (W + 2L), B, C)) return DFE_ERR_DIMS;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool pair = W % 2 == 0 && W >= 4 && al8(gx) && (!apply_elu || al8(x));
-  const unsigned nb = nblk(pair ? static_cast<long>(H) * (W / 2) : static_cast<long>(H) * W);   // <= the scratch size
-  if (pair) k_elu_pad_bwd_pair<<<dim3(nb, C, B), 256, 0, st>>>(x, bias, gout, gx, gbias ? partials : nullptr, C, H, W, apply_elu);
+  const bool quad = W % 4 == 0 && W >= 8 && al16(gx) && (!apply_elu || al16(x));
+  const unsigned nb = nblk(quad ? static_cast<long>(H) * (W / 4) : pair ? static_cast<long>(H) * (W / 2) : static_cast<long>(H) * W);   // <= the scratch size
+  if (quad) k_elu_pad_bwd_quad<<<dim3(nb, C, B), 256, 0, st>>>(x, bias, gout, gx, gbias ? partials : nullptr, C, H, W, apply_elu);
+  else if (pair) k_elu_pad_bwd_pair<<<dim3(nb, C, B), 256, 0, st>>>(x, bias, gout, gx, gbias ? partials : nullptr, C, H, W, apply_elu);
   else k_elu_pad_bwd<<<dim3(nb, C, B), 256, 0, st>>>(x, bias, gout, gx, gbias ? partials : nullptr, C, H, W, apply_elu);
   DFE_LAUNCH_CHECK();
   if (gbias) {
@@ -467,10 +541,12 @@ extern "C" int dfe_elu_up2_cat_pad_bwd(const float* x, const float* bias, const 
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (gx) {
     unsigned nb = nblk(static_cast<long>(h) * w);
-    if (w >= 256 && al8(gout)) {   // measured (12 images): 16 ch @128x416 178 -> 136 us; at 64x208 and below the element kernel wins (116 vs 152 us)
-      const int strips = (w + 63) / 64;
-      nb = static_cast<unsigned>(strips * ((h + UB_ROWS - 1) / UB_ROWS));
-      k_elu_up2_cat_pad_bwd_x_roll<<<dim3(nb, C1, B), 64, 0, st>>>(x, bias, gout, gx, gbias ? partials : nullptr, C1, C2, h, w, strips);
+    const int tw = w <= 32 ? 32 : 64;
+    const int tiles_x = (w + tw - 1) / tw, tiles_y = (h + UT_H - 1) / UT_H;
+    if (al8(gout) && static_cast<unsigned>(tiles_x * tiles_y) <= nb) {     // (the partial-sum scratch holds nb per plane)
+      nb = static_cast<unsigned>(tiles_x * tiles_y);
+      if (tw == 32) k_elu_up2_cat_pad_bwd_x_tile<32><<<dim3(nb, C1, B), 256, 0, st>>>(x, bias, gout, gx, gbias ? partials : nullptr, C1, C2, h, w, tiles_x);
+      else k_elu_up2_cat_pad_bwd_x_tile<64><<<dim3(nb, C1, B), 256, 0, st>>>(x, bias, gout, gx, gbias ? partials : nullptr, C1, C2, h, w, tiles_x);
     } else {
       k_elu_up2_cat_pad_bwd_x<<<dim3(nb, C1, B), 256, 0, st>>>(x, bias, gout, gx, gbias ? partials : nullptr, C1, C2, h, w);
     }
@@ -481,7 +557,8 @@ extern "C" int dfe_elu_up2_cat_pad_bwd(const float* x, const float* bias, const 
     }
   }
   if (gskip && C2 > 0) {
-    if (w >= 2 && al8(gskip)) k_cat_pad_bwd_skip_pair<<<dim3(nblk(2L * h * w), C2, B), 256, 0, st>>>(gout, gskip, C1, C2, 2 * h, 2 * w);
+    if (w % 2 == 0 && w >= 4 && al16(gskip)) k_cat_pad_bwd_skip_quad<<<dim3(nblk(1L * h * w), C2, B), 256, 0, st>>>(gout, gskip, C1, C2, 2 * h, 2 * w);
+    else if (w >= 2 && al8(gskip)) k_cat_pad_bwd_skip_pair<<<dim3(nblk(2L * h * w), C2, B), 256, 0, st>>>(gout, gskip, C1, C2, 2 * h, 2 * w);
     else k_cat_pad_bwd_skip<<<dim3(nblk(4L * h * w), C2, B), 256, 0, st>>>(gout, gskip, C1, C2, 2 * h, 2 * w);
     DFE_LAUNCH_CHECK();
   }
