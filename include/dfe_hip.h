@@ -199,6 +199,18 @@ int dfe_disp_head_fwd(const float* p, const float* weight, const float* bias, fl
 int dfe_disp_head_bwd(const float* p, const float* weight, const float* out, const float* gout, float* gp, float* gweight,
                       float* gbias, float* partials, int B, int C, int H, int W, void* stream);
 
+/* ---- flow head  pwc_tf.py:39-40  predict_flow = Conv2d(C, 2, kernel_size=3, stride=1, padding=1, bias=True) ----------
+ * The same rolling-window kernels with two output channels on the unpadded activation x [B,C,H,W] (zero padding is
+ * virtual): out [B,2,H,W] = conv3x3(x, weight [2,C,3,3]) + bias [2].  MIOpen has no matrix to feed with two output
+ * channels (4-5 TFLOP/s: 69 / 26 / 99 us forward / data / weight gradient at C = 96, 64x208, 8 images).
+ * Backward: gx [B,C,H,W] (every element written), gweight [2*C*9] / gbias [2] (may both be NULL), fixed-order sums;
+ * partials: dfe_flow_head_partials_floats floats of scratch.  C must be a multiple of 8 (DFE_ERR_UNSUPPORTED otherwise). */
+long dfe_flow_head_partials_floats(int B, int C, int H, int W);
+int dfe_flow_head_fwd(const float* x, const float* weight, const float* bias, float* out, int B, int C, int H, int W,
+                      void* stream);
+int dfe_flow_head_bwd(const float* x, const float* weight, const float* gout, float* gx, float* gweight, float* gbias,
+                      float* partials, int B, int C, int H, int W, void* stream);
+
 /* ---- weight gradient of the thin, wide 3x3 convolutions of the depth decoder on pre-padded inputs (fp32 MFMA):
  * gweight [Co,Ci,3,3] = sum_{b,y,x} gy[b,co,y,x] * p[b,ci,y+ky,x+kx],  p [B,Ci,H+2,W+2], gy [B,Co,H,W].
  * Requires Ci % 16 == 0, Co % 16 == 0, W % 16 == 0, p 8-byte and gy 16-byte aligned (DFE_ERR_UNSUPPORTED otherwise: the

@@ -547,6 +547,65 @@ def test_elu_up2_cat_pad(shape, c2):
         gclose(bh.grad, bo.grad, rel=2e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("shape", [(8, 96, 64, 208), (2, 32, 64, 208), (2, 96, 4, 13), (3, 8, 7, 70), (1, 16, 1, 5)])
+def test_flow_head_matches_miopen(shape):
+    """PWC's predict_flow = Conv2d(C, 2, 3, 1, 1) (pwc_tf.py:39-40) on the rolling-window head kernels against ATen's
+    convolution: forward 1e-5 of the output scale, the three gradients 1e-4 of theirs (fp32 sums of C*9 / H*W*B terms in a
+    different order); ragged sizes, one row, strips that end mid-wave."""
+    import torch.nn.functional as F
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+    b, c, h, w = shape
+    r = MG.rng(500 + c + h)
+    x = r.standard_normal(shape).astype(np.float32)
+    wt = (r.standard_normal((2, c, 3, 3)) / np.sqrt(9 * c)).astype(np.float32)
+    bs = r.standard_normal(2).astype(np.float32)
+    gy = r.standard_normal((b, 2, h, w)).astype(np.float32)
+    xt, wtt, bt = G(x, True), G(wt, True), G(bs, True)
+    assert ops.flow_head_eligible(xt, wtt, bt)
+    y = ops.FlowHeadFn.apply(xt, wtt, bt)
+    y.backward(G(gy))
+    xr, wr, br = G(x, True), G(wt, True), G(bs, True)
+    yr = F.conv2d(xr, wr, br, 1, 1)
+    yr.backward(G(gy))
+    gclose(y, yr, rel=1e-5)
+    gclose(xt.grad, xr.grad, rel=1e-4)
+    gclose(wtt.grad, wr.grad, rel=1e-4)
+    gclose(bt.grad, br.grad, rel=1e-4)
+    # reproducible: fixed-order partial sums
+    x2, w2, b2 = G(x, True), G(wt, True), G(bs, True)
+    ops.FlowHeadFn.apply(x2, w2, b2).backward(G(gy))
+    assert torch.equal(w2.grad, wtt.grad) and torch.equal(b2.grad, bt.grad) and torch.equal(x2.grad, xt.grad)
+
+
+@pytest.mark.parametrize("cfg", [(2, 16, 24, 64, 64, 8), (1, 8, 12, 32, 48, 16), (2, 8, 8, 16, 32, 2)])
+def test_dilated_conv_on_phase_images_matches_the_dilated_call(cfg):
+    """convs.conv2d sends a dilated 3x3 'same' convolution (PWC's context network, pwc_tf.py:31-36) to MIOpen as a dense
+    3x3 convolution on the d*d phase images: the same products and sums, another kernel -- values and gradients agree
+    with the dilated call to fp32 rounding."""
+    import torch.nn.functional as F
+    from unsupervised_depth_opticalflow_egomotion_amd import convs
+    b, ci, co, h, w, d = cfg
+    r = MG.rng(900 + d)
+    x = r.standard_normal((b, ci, h, w)).astype(np.float32)
+    wt = (r.standard_normal((co, ci, 3, 3)) / np.sqrt(9 * ci)).astype(np.float32)
+    gy = r.standard_normal((b, co, h, w)).astype(np.float32)
+    old = convs.PHASE_MIN_DILATION
+    convs.PHASE_MIN_DILATION = 2
+    try:
+        xt, wtt = G(x, True), G(wt, True)
+        assert convs._phase_eligible(xt, wtt, (1, 1), (d, d), (d, d), 1)
+        y = convs.conv2d(xt, wtt, None, 1, d, d)
+        y.backward(G(gy))
+    finally:
+        convs.PHASE_MIN_DILATION = old
+    xr, wr = G(x, True), G(wt, True)
+    yr = F.conv2d(xr, wr, None, 1, d, d)
+    yr.backward(G(gy))
+    gclose(y, yr, rel=2e-5)
+    gclose(xt.grad, xr.grad, rel=1e-4)
+    gclose(wtt.grad, wr.grad, rel=1e-4)
+
+
 def test_decoder_glue_argument_errors():
     from unsupervised_depth_opticalflow_egomotion_amd import ops
     from unsupervised_depth_opticalflow_egomotion_amd._lib import DfeError

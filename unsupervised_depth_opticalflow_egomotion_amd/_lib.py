@@ -42,6 +42,9 @@ _SIGNATURES = {
     "dfe_disp_head_partials_floats": [_I, _I, _I, _I],
     "dfe_disp_head_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_disp_head_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "dfe_flow_head_partials_floats": [_I, _I, _I, _I],
+    "dfe_flow_head_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "dfe_flow_head_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_bn_partials_floats": [_I, _I, _I, _I, _I],
     "dfe_bn_fwd": [_P] * 10 + [_I] * 5 + [ctypes.c_float, ctypes.c_float, _I, _P],
     "dfe_bn_bwd": [_P] * 12 + [_I] * 6 + [_P],
@@ -89,6 +92,7 @@ _SIGNATURES = {
 _RESTYPES = {"dfe_error_string": ctypes.c_char_p, "dfe_geom_workspace_floats": ctypes.c_long,
              "dfe_bias_act_partials_floats": ctypes.c_long, "dfe_glue_partials_floats": ctypes.c_long,
              "dfe_bn_partials_floats": ctypes.c_long, "dfe_disp_head_partials_floats": ctypes.c_long,
+             "dfe_flow_head_partials_floats": ctypes.c_long,
              "dfe_wgrad3x3_partials_floats": ctypes.c_long,
              "dfe_geom_maskpack_offset_bytes": ctypes.c_long, "dfe_scatter_ws_bytes": ctypes.c_long}
 

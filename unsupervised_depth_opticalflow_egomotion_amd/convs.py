@@ -17,6 +17,7 @@ transposed problem lands on the same kernels: 458 -> 432 us at best, within nois
 from __future__ import annotations
 
 import contextlib
+import os
 
 import torch
 import torch.nn as nn
@@ -96,9 +97,39 @@ class _ConvFn(torch.autograd.Function):
         return gx, gw, None, None, None
 
 
+# Dilated 3x3 "same" convolutions (PWC's context network, pwc_tf.py:31-36: dilation 2, 4, 8, 16 at 64x208) as a dense 3x3
+# convolution on the d*d phase images: pixel (y, x) of a dilation-d convolution only ever meets pixels (y + i d, x + j d),
+# i.e. the d*d sub-images x[:, :, p::d, q::d] are convolved independently with the same 3x3 weights, padding 1 (= d
+# full-resolution pixels).  Same products, same sums; what changes is the kernel MIOpen can use: the dilated problem
+# goes to its implicit-GEMM kernels (51-94 TFLOP/s, dilation 8 forward 458 us), the phase images to Winograd (204 us).
+# Measured per layer (B = 8, scratch/dil_bench.py): forward 379 / 345 / 458 / 153 -> 290 / 285 / 204 / 127 us, data
+# gradient 365 / 342 / 277 / 252 -> 308 / 297 / 220 / 137 us, weight gradient unchanged; the two re-layout copies each
+# way cost 21-52 us.  In the step (profiles/r03_dilated_phase_conv.txt): 26.81 ms without, 26.60 with every dilated layer on
+# the phase path, 26.62 with dilation >= 8 only -- the default: the two layers that gain most, half the copies.
+PHASE_MIN_DILATION = int(os.environ.get("DFE_PHASE_CONV", "8"))      # smallest dilation that takes the phase path; 0 = off
+
+
+def _phase_eligible(x, w, stride, padding, dilation, groups):
+    d = dilation[0]
+    return (PHASE_MIN_DILATION > 0 and x.is_cuda and groups == 1 and d >= PHASE_MIN_DILATION and dilation == (d, d)
+            and stride == (1, 1) and padding == (d, d) and tuple(w.shape[2:]) == (3, 3) and x.dim() == 4
+            and x.shape[2] % d == 0 and x.shape[3] % d == 0)
+
+
+def _phase_conv(x, w, d):
+    B, C, H, W = x.shape
+    xs = x.view(B, C, H // d, d, W // d, d).permute(0, 3, 5, 1, 2, 4).reshape(B * d * d, C, H // d, W // d)
+    ys = conv2d(xs, w, None, 1, 1, 1)
+    return ys.view(B, d, d, w.shape[0], H // d, W // d).permute(0, 3, 4, 1, 5, 2).reshape(B, w.shape[0], H, W)
+
+
 def conv2d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1):
-    """``F.conv2d``; in the reduced compute dtype when one is set (HIP tensors, groups == 1)."""
+    """``F.conv2d``; in the reduced compute dtype when one is set (HIP tensors, groups == 1); dilated 3x3 "same"
+    convolutions on the phase images (above)."""
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
+    if dilation[0] > 1 and _phase_eligible(x, w, stride, padding, dilation, groups):
+        y = _phase_conv(x, w, dilation[0])
+        return y if bias is None else y + bias.view(1, -1, 1, 1)
     if not (x.is_cuda and groups == 1 and _STATE["dtype"] is not None):
         return F.conv2d(x, w, bias, stride, padding, dilation, groups)
     y = _ConvFn.apply(x, w, stride, padding, dilation)
@@ -111,4 +142,9 @@ class Conv2d(nn.Conv2d):
     def forward(self, x):
         if self.padding_mode != "zeros" or isinstance(self.padding, str):
             return super().forward(x)
+        if (self.out_channels == 2 and x.is_cuda and self.kernel_size == (3, 3) and self.stride == (1, 1)
+                and self.padding == (1, 1) and self.dilation == (1, 1) and self.groups == 1):
+            from . import ops                      # PWC's flow heads (pwc_tf.py:39-40): rolling-window HIP kernels
+            if ops.flow_head_eligible(x, self.weight, self.bias):
+                return ops.FlowHeadFn.apply(x, self.weight, self.bias)
         return conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)

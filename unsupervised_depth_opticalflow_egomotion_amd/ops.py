@@ -630,8 +630,11 @@ class DenseDecodeFn(torch.autograd.Function):
         epilogue(z, 3, cat[2], co[2], cat[3], 0)                            # x3
         x4 = convs.raw_forward(cat[2], w[4], 1, 1)
         epilogue(x4, 4, x4, 0, cat[3], co[3])                               # x4: in place (returned) + cat3[:, 64:]
-        flow = F.conv2d(cat[3], w[5], b[5], 1, 1) if convs.get_compute_dtype() is None else \
-            convs.raw_forward(cat[3], w[5], 1, 1) + b[5].view(1, -1, 1, 1)
+        if flow_head_eligible(cat[3], w[5], b[5]):
+            flow = flow_head_fwd_raw(cat[3], f32c(w[5]), f32c(b[5]))
+        else:
+            flow = F.conv2d(cat[3], w[5], b[5], 1, 1) if convs.get_compute_dtype() is None else \
+                convs.raw_forward(cat[3], w[5], 1, 1) + b[5].view(1, -1, 1, 1)
         ctx.save_for_backward(x, z0, *cat, *w)
         ctx.slope, ctx.co = slope, co
         ctx.set_materialize_grads(False)
@@ -669,7 +672,10 @@ class DenseDecodeFn(torch.autograd.Function):
         gw, gbias = [None] * 6, [None] * 6
         if g_flow is not None:
             g_flow = f32c(g_flow)
-            g3, gw[5], gbias[5] = cb(g_flow, cat[3], w[5], True, nw(5), [2], nb(5))       # d/d cat(x3, x4)
+            if flow_head_eligible(cat[3], w[5], True):
+                g3, gw[5], gbias[5] = flow_head_bwd_raw(cat[3], f32c(w[5]), g_flow, nw(5), nb(5))
+            else:
+                g3, gw[5], gbias[5] = cb(g_flow, cat[3], w[5], True, nw(5), [2], nb(5))       # d/d cat(x3, x4)
         else:
             g3 = torch.zeros_like(cat[3])
         if g_x4 is not None:     # usually a channel slice of the gradient of torch.cat([flow, x4]): read in place
@@ -799,6 +805,52 @@ def disp_head(p, weight, bias):
 
 
 # --------------------------------------------------------------------------- thin 3x3 convolution (MFMA weight gradient)
+def flow_head_fwd_raw(x, weight, bias):
+    """Conv2d(C, 2, 3, 1, 1) forward on a contiguous fp32 HIP tensor (no autograd of its own)."""
+    lib = get_lib()
+    B, C, H, W = x.shape
+    out = torch.empty(B, 2, H, W, device=x.device, dtype=torch.float32)
+    check(lib.dfe_flow_head_fwd(ptr(x), ptr(weight), ptr(bias), ptr(out), B, C, H, W, stream_ptr()), "dfe_flow_head_fwd")
+    return out
+
+
+def flow_head_bwd_raw(x, weight, gout, want_w=True, want_b=True):
+    """(gx, gweight, gbias) of the flow head."""
+    lib = get_lib()
+    B, C, H, W = x.shape
+    gx = torch.empty_like(x)
+    gw = torch.empty_like(weight) if want_w else None
+    gb = torch.empty(2, device=x.device, dtype=torch.float32) if want_b else None
+    part = torch.empty(lib.dfe_flow_head_partials_floats(B, C, H, W), device=x.device, dtype=torch.float32)
+    check(lib.dfe_flow_head_bwd(ptr(x), ptr(weight), ptr(gout), ptr(gx), ptr(gw), ptr(gb), ptr(part), B, C, H, W,
+                                stream_ptr()), "dfe_flow_head_bwd")
+    return gx, gw, gb
+
+
+def flow_head_eligible(x, weight, bias=None):
+    """PWC's predict_flow layers (pwc_tf.py:39-40): fp32, two output channels, 3x3, channel count a multiple of 8."""
+    return (os.environ.get("DFE_FLOW_HEAD", "1") != "0" and convs.get_compute_dtype() is None and x.is_cuda
+            and x.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and weight.shape[0] == 2
+            and weight.shape[1] == x.shape[1] and x.shape[1] % 8 == 0 and bias is not None)
+
+
+class FlowHeadFn(torch.autograd.Function):
+    """``F.conv2d(x, weight, bias, 1, 1)`` with two output channels on the rolling-window head kernels
+    (csrc/ops_disphead.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x, weight, bias = f32c(x), f32c(weight), f32c(bias)
+        ctx.save_for_backward(x, weight)
+        return flow_head_fwd_raw(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, weight = ctx.saved_tensors
+        gx, gw, gb = flow_head_bwd_raw(x, weight, f32c(gout), ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        return (gx if ctx.needs_input_grad[0] else None), gw, gb
+
+
 class ThinConv3x3Fn(torch.autograd.Function):
     """Valid 3x3 convolution of a pre-padded activation, bias-free, for the decoder's thin full-resolution layers.
     The weight gradient -- a (Co x 9 Ci) contraction over B*H*W pixels -- always runs the fp32-MFMA kernel
