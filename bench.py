@@ -182,6 +182,13 @@ class LossStackWorkload:
 
 
 # ------------------------------------------------------------------------------------------------ train step
+def miopen_db_status():
+    """'tuned' = the auto-tuned MIOpen user databases shipped with the package (miopen_tuning.py), 'env' = a path the
+    caller set, 'default' = MIOpen's own."""
+    from unsupervised_depth_opticalflow_egomotion_amd import miopen_tuning
+    return miopen_tuning.status()
+
+
 class TrainStepWorkload:
     """bench.py workload: mode=geom on synthetic KITTI-shaped triplets (configs[2] / configs[3])."""
     name = "train_step"
@@ -431,7 +438,7 @@ def main():
             "+Adam" if wl.name == "train_step" else "") + ("" if args.amp == "off" else
             " [OPT-IN mixed precision, not the headline: convolutions in %s with fp32 accumulation; glue, loss stack, optimiser fp32]" % args.amp),
             "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-            "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE")},
+            "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE"), "miopen_user_db": miopen_db_status()},
     }
     if evidence is not None:
         out["multi_gpu"] = evidence

@@ -23,6 +23,10 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import miopen_tuning
+
+miopen_tuning.activate()      # before the first convolution: MIOpen reads MIOPEN_USER_DB_PATH when it first opens its databases
+
 _STATE = {"dtype": None}
 
 
