@@ -497,3 +497,27 @@ def test_pnp_properties():
     matches = torch.cat([x1, x.float().transpose(1, 2)], 1)
     loss = M().compute_pnp_loss(X[:, :, 2].float().unsqueeze(1), matches, est, K.unsqueeze(0).repeat(b, 1, 1), Ki)
     assert loss.shape == (b, 3) and float(loss.max()) < 5e-3
+
+
+def test_miopen_tuned_databases_are_activated_before_the_first_convolution(tmp_path):
+    """miopen_tuning.activate(): the shipped user databases (text files keyed by architecture / CU count / MIOpen build) are
+    copied to a per-user directory and MIOPEN_USER_DB_PATH points there -- unless the caller chose a path or switched it
+    off.  Run in fresh interpreters: the decision is taken once per process, at the import of convs."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os; from unsupervised_depth_opticalflow_egomotion_amd import convs, miopen_tuning as m; "
+            "p = os.environ.get('MIOPEN_USER_DB_PATH'); print(m.status(), p, sorted(os.listdir(p)) if p and os.path.isdir(p) else None)")
+
+    def run(extra):
+        env = {k: v for k, v in os.environ.items() if k not in ("MIOPEN_USER_DB_PATH", "DFE_MIOPEN_DB")}
+        env.update(extra, PYTHONPATH=root, TMPDIR=str(tmp_path))
+        return subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=root, timeout=300).stdout.strip()
+
+    shipped = sorted(f for f in os.listdir(os.path.join(root, "unsupervised_depth_opticalflow_egomotion_amd", "miopen_db")) if f.endswith(".txt"))
+    assert len(shipped) == 2 and all(f.startswith("gfx950") for f in shipped)
+    out = run({})
+    assert out.startswith("tuned " + str(tmp_path)) and all(f in out for f in shipped), out
+    assert run({"DFE_MIOPEN_DB": "0"}).startswith("default None")
+    mine = tmp_path / "mine"; mine.mkdir()
+    assert run({"MIOPEN_USER_DB_PATH": str(mine)}).startswith("env " + str(mine))
