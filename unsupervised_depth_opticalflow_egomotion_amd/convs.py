@@ -106,7 +106,7 @@ class _ConvFn(torch.autograd.Function):
 # i.e. the d*d sub-images x[:, :, p::d, q::d] are convolved independently with the same 3x3 weights, padding 1 (= d
 # full-resolution pixels).  Same products, same sums; what changes is the kernel MIOpen can use: the dilated problem
 # goes to its implicit-GEMM kernels (51-94 TFLOP/s, dilation 8 forward 458 us), the phase images to Winograd (204 us).
-# Measured per layer (B = 8, scratch/dil_bench.py): forward 379 / 345 / 458 / 153 -> 290 / 285 / 204 / 127 us, data
+# Measured per layer (B = 8, tools/dilated_conv_bench.py): forward 379 / 345 / 458 / 153 -> 290 / 285 / 204 / 127 us, data
 # gradient 365 / 342 / 277 / 252 -> 308 / 297 / 220 / 137 us, weight gradient unchanged; the two re-layout copies each
 # way cost 21-52 us.  In the step (profiles/r03_dilated_phase_conv.txt): 26.81 ms without, 26.60 with every dilated layer on
 # the phase path, 26.62 with dilation >= 8 only -- the default: the two layers that gain most, half the copies.
