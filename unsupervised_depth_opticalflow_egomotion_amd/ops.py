@@ -828,8 +828,9 @@ def flow_head_bwd_raw(x, weight, gout, want_w=True, want_b=True):
 
 
 def flow_head_eligible(x, weight, bias=None):
-    """PWC's predict_flow layers (pwc_tf.py:39-40): fp32, two output channels, 3x3, channel count a multiple of 8."""
-    return (os.environ.get("DFE_FLOW_HEAD", "1") != "0" and convs.get_compute_dtype() is None and x.is_cuda
+    """PWC's predict_flow layers (pwc_tf.py:39-40): two output channels, 3x3, channel count a multiple of 8.  The head
+    kernels compute in fp32 whatever ``convs.compute_dtype`` says (activations are fp32 between the convolutions' doors)."""
+    return (os.environ.get("DFE_FLOW_HEAD", "1") != "0" and x.is_cuda
             and x.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and weight.shape[0] == 2
             and weight.shape[1] == x.shape[1] and x.shape[1] % 8 == 0 and bias is not None)
 
