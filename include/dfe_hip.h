@@ -50,6 +50,14 @@ int dfe_prepare_cameras(const float* pose, const float* K, float* cams, int B, i
 int dfe_pose_vec2mat_fwd(const float* vec, float* T34, float* E, int n, void* stream);
 int dfe_pose_vec2mat_bwd(const float* vec, const float* gT34, const float* gE, float* gvec, int n, void* stream);
 
+/* ---- Adam update of many tensors in one launch  train.py:85-87 (torch.optim.Adam, default betas / eps) ---------------
+ * table: device array of ntensors records {float* p, const float* g, float* m, float* v, int64 n} (5 x 8 bytes);
+ * blockmap: device int32 pairs (tensor, chunk), one per block of dfe_adam_chunk() elements; bias_correction1 / 2 =
+ * 1 - beta^t of the step count t.  m = m + (1-b1)(g-m); v = b2 v + (1-b2) g g; p -= (lr/c1) m / (sqrt(v)/sqrt(c2) + eps). */
+int dfe_adam_chunk(void);
+int dfe_adam_step(const void* table, const int* blockmap, int nblocks, double lr, double beta1, double beta2, double eps,
+                  double bias_correction1, double bias_correction2, void* stream);
+
 /* ---- order-independent scatter-add workspace (csrc/dfe_scatter.h) -----------------------------
  * Adjoint of a bilinear gather with respect to the sampled tensor: contributions are scaled by a power of two, rounded
  * once to 64-bit integers, added with integer atomics (associative: no dependence on the order the atomics retire in)

@@ -658,3 +658,45 @@ def test_triangulation_and_eight_point_losses_on_the_device(golden_dir, ac):
     l0 = float(m.compute_eight_point_loss(mt, pose, K, Ki))
     l1 = float(m.compute_eight_point_loss(mt, pose + 0.05, K, Ki))
     assert np.isfinite(l0) and l1 >= 0
+
+
+def test_fused_adam_matches_torch_adam_and_exchanges_checkpoints():
+    """optim.FusedAdam (one launch for all parameters, csrc/ops_adam.hip) against torch.optim.Adam on the same
+    gradients: parameters and both moments after five steps to fp32 rounding (1e-6 of their scale: the same
+    arithmetic as ATen's fused kernel up to the order of two multiplications), odd sizes and a parameter without a
+    gradient included; the state dicts are interchangeable in both directions (train.py:90-94 resumes from them)."""
+    from unsupervised_depth_opticalflow_egomotion_amd.optim import FusedAdam
+    torch.manual_seed(3)
+    shapes = [(64, 3, 7, 7), (5,), (1,), (4097,), (128, 64, 3, 3), (3, 1023), (2, 2)]
+    pa = [torch.randn(s, device=dev(), requires_grad=True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa, ob = FusedAdam(pa, lr=1e-3), torch.optim.Adam(pb, lr=1e-3)
+    for it in range(5):
+        for k, (a, b) in enumerate(zip(pa, pb)):
+            if k == len(pa) - 1:
+                continue                       # the last parameter never gets a gradient
+            g = torch.randn_like(a) * (10.0 ** (it - 2))
+            a.grad, b.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 1e-6 * scale + 1e-7
+    for a, b in zip(pa[:-1], pb[:-1]):
+        for key in ("exp_avg", "exp_avg_sq"):
+            x, y = oa.state[a][key], ob.state[b][key]
+            assert float((x - y).abs().max()) <= 1e-6 * float(y.abs().max()) + 1e-12
+        assert float(oa.state[a]["step"]) == float(ob.state[b]["step"]) == 5.0
+    assert len(oa.state[pa[-1]]) == 0 and torch.equal(pa[-1], pb[-1])
+    # a checkpoint carries one step count per parameter (inside, the group shares one tensor)
+    steps = [v["step"] for v in oa.state_dict()["state"].values() if "step" in v]
+    assert len(steps) == len(pa) - 1 and len({id(t) for t in steps}) == len(steps) and all(float(t) == 5.0 for t in steps)
+    # checkpoints: torch -> fused and fused -> torch, then one more identical step
+    oa2, ob2 = FusedAdam(pa, lr=1e-3), torch.optim.Adam(pb, lr=1e-3)
+    oa2.load_state_dict(ob.state_dict()); ob2.load_state_dict(oa.state_dict())
+    for a, b in zip(pa[:-1], pb[:-1]):
+        g = torch.randn_like(a)
+        a.grad, b.grad = g.clone(), g.clone()
+    oa2.step(); ob2.step()
+    for a, b in zip(pa, pb):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-7
+    assert float(oa2.state[pa[0]]["step"]) == 6.0

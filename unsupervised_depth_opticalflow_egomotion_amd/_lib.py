@@ -32,6 +32,8 @@ _SIGNATURES = {
     "dfe_pose_vec2mat_bwd": [_P, _P, _P, _P, _I, _P],
     "dfe_warp_flow_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dfe_scatter_ws_bytes": [ctypes.c_long],
+    "dfe_adam_chunk": [],
+    "dfe_adam_step": [_P, _P, _I, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _P],
     "dfe_warp_flow_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dfe_pose_partials_floats": [_I, _I, _I],
     "dfe_inverse_warp2_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

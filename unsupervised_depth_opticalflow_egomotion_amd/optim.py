@@ -1,0 +1,130 @@
+"""The optimiser of the reference's training loop -- ``torch.optim.Adam(model.parameters(), lr)`` (train.py:85-87) -- as
+one HIP launch per step (csrc/ops_adam.hip).
+
+``FusedAdam`` keeps ``torch.optim.Adam``'s hyper-parameters, update rule and state layout (``step``, ``exp_avg``,
+``exp_avg_sq`` per parameter; the same ``param_groups`` keys), so a checkpoint written by one loads into the other
+(train.py:90-94 resumes from ``optimizer.state_dict()``).  What changes is how the update reaches the GPU: ATen's fused
+multi-tensor kernel takes its pointer tables as kernel arguments -- six launches of ~48 us for this model's ~250 tensors,
+on the serial tail of the step -- here the tables are device tensors (the gradient pointers are refreshed each step, the
+rest is built once) and one launch updates everything.
+
+fp32 parameters on one HIP device, dense gradients, no weight decay / amsgrad / maximize (the reference uses none);
+anything else raises."""
+import ctypes
+
+import torch
+
+from ._lib import check, get_lib, stream_ptr
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
+            raise ValueError("invalid Adam hyper-parameters")
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
+                        capturable=False, differentiable=False, fused=None)
+        super().__init__(params, defaults)
+        self._plans = {}
+
+    def state_dict(self):
+        """As torch.optim.Adam's.  Inside this optimiser the parameters of a group share ONE step-count tensor (one
+        increment per step instead of ~250); a checkpoint must not carry that sharing -- torch.optim.Adam increments
+        every parameter's count, i.e. a shared one once per parameter -- so every entry gets its own copy here."""
+        sd = super().state_dict()
+        sd["state"] = {k: ({**v, "step": v["step"].clone()} if "step" in v else v) for k, v in sd["state"].items()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._plans = {}                       # the moment tensors were replaced
+
+    def _fingerprint(self, params):
+        """Cheap check that the cached parameter / moment pointers are still the live ones."""
+        a, b = params[0], params[-1]
+        return (a.data_ptr(), b.data_ptr(), self.state[a]["exp_avg"].data_ptr(), self.state[b]["exp_avg_sq"].data_ptr())
+
+    # ------------------------------------------------------------------ tables
+    def _plan(self, gi, params):
+        """Static part of the launch for one param group and one set of parameters that have gradients."""
+        key = (gi, tuple(id(p) for p in params))
+        plan = self._plans.get(key)
+        if plan is not None and plan["fingerprint"] == self._fingerprint(params):
+            return plan
+        lib = get_lib()
+        chunk = lib.dfe_adam_chunk()
+        dev = params[0].device
+        rows, blocks = [], []
+        for t, p in enumerate(params):
+            st = self.state[p]
+            rows.append([p.data_ptr(), 0, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()])
+            blocks += [[t, c] for c in range((p.numel() + chunk - 1) // chunk)]
+        # the pointer table reaches the device through a small ring of pinned buffers (an un-pinned source would make the
+        # copy synchronise the stream, i.e. stall the host once per step); a buffer is reused only after its copy ran
+        plan = {"host": torch.tensor(rows, dtype=torch.int64),
+                "pinned": [torch.empty(len(rows), 5, dtype=torch.int64).pin_memory() for _ in range(4)],
+                "events": [None] * 4, "turn": 0,
+                "table": torch.empty(len(rows), 5, dtype=torch.int64, device=dev),
+                "blockmap": torch.tensor(blocks, dtype=torch.int32).to(dev), "nblocks": len(blocks),
+                "fingerprint": self._fingerprint(params)}
+        self._plans = {k: v for k, v in self._plans.items() if k[0] != gi}      # one live plan per group
+        self._plans[key] = plan
+        return plan
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = get_lib()
+        for gi, group in enumerate(self.param_groups):
+            if group.get("weight_decay", 0) or group.get("amsgrad") or group.get("maximize"):
+                raise NotImplementedError("FusedAdam implements the reference's plain Adam (no weight decay / amsgrad / maximize)")
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            dev = params[0].device
+            grads = []
+            for p in params:
+                g = p.grad
+                if (g.is_sparse or g.dtype != torch.float32 or p.dtype != torch.float32 or not p.is_cuda or p.device != dev
+                        or not p.is_contiguous()):
+                    raise NotImplementedError("FusedAdam needs dense fp32 parameters and gradients on one HIP device")
+                grads.append(g if g.is_contiguous() else g.contiguous())
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            # parameters of a group that stepped together share their count: one launch per distinct count
+            by_step = {}
+            for p, g in zip(params, grads):
+                by_step.setdefault(float(self.state[p]["step"]), []).append((p, g))
+            for t0, pg in by_step.items():
+                ps = [p for p, _ in pg]
+                plan = self._plan(gi, ps) if len(by_step) == 1 else self._plan((gi, t0), ps)
+                host = plan["host"]
+                host[:, 1] = torch.tensor([g.data_ptr() for _, g in pg], dtype=torch.int64)
+                k = plan["turn"]
+                plan["turn"] = (k + 1) % len(plan["pinned"])
+                if plan["events"][k] is not None:
+                    plan["events"][k].synchronize()
+                plan["pinned"][k].copy_(host)
+                plan["table"].copy_(plan["pinned"][k], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                plan["events"][k] = ev
+                t = t0 + 1.0
+                b1, b2 = group["betas"]
+                check(lib.dfe_adam_step(ctypes.c_void_p(plan["table"].data_ptr()), ctypes.c_void_p(plan["blockmap"].data_ptr()),
+                                        plan["nblocks"], float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                        1.0 - b1 ** t, 1.0 - b2 ** t, stream_ptr()), "dfe_adam_step")
+                first = self.state[ps[0]]["step"]
+                shared = all(self.state[p]["step"] is first for p in (ps[-1], ps[len(ps) // 2]))
+                if shared:
+                    first += 1.0                    # one CPU tensor shared by the group's parameters
+                else:
+                    new = torch.tensor(t, dtype=torch.float32)
+                    for p in ps:
+                        self.state[p]["step"] = new
+        return loss

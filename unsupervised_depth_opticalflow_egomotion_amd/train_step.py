@@ -26,12 +26,16 @@ def make_cfg(**over):
 
 def make_optimizer(model, lr):
     """The reference's ``torch.optim.Adam(model.parameters(), lr)`` (train.py:85-87), same hyper-parameters, state
-    layout and update rule.  On a HIP device the single-pass fused implementation is selected (one read of p / g / m / v
-    and one write of p / m / v per step instead of the multi-kernel foreach chain: 0.5 -> 0.2 ms at 21.6 M parameters)."""
+    layout and update rule.  On a HIP device: ``optim.FusedAdam``, one launch for all parameters (ATen's fused
+    multi-tensor Adam needs six for this model; ``DFE_FUSED_ADAM=0`` selects it)."""
+    import os
     import torch
     params = [p for p in model.parameters() if p.requires_grad]
-    fused = bool(params) and all(p.is_cuda for p in params)
-    return torch.optim.Adam(params, lr=lr, fused=True) if fused else torch.optim.Adam(params, lr=lr)
+    on_gpu = bool(params) and all(p.is_cuda and p.dtype == torch.float32 for p in params)
+    if on_gpu and os.environ.get("DFE_FUSED_ADAM", "1") != "0":
+        from .optim import FusedAdam
+        return FusedAdam(params, lr=lr)
+    return torch.optim.Adam(params, lr=lr, fused=True) if on_gpu else torch.optim.Adam(params, lr=lr)
 
 
 _WEIGHT_ROWS = {}
