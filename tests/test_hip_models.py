@@ -700,3 +700,39 @@ def test_fused_adam_matches_torch_adam_and_exchanges_checkpoints():
     for a, b in zip(pa, pb):
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-7
     assert float(oa2.state[pa[0]]["step"]) == 6.0
+
+
+def test_fused_adam_staggered_gradients_keep_per_parameter_counts_and_bounded_plans():
+    """Parameters whose first gradient arrives late, or that sit a step out, keep torch.optim.Adam's per-parameter step
+    counts (the shared count tensor is split, never incremented for an absent parameter), and the launch plans stay
+    bounded: they are keyed by the parameter set, not by the step count (one leaked plan per step)."""
+    from unsupervised_depth_opticalflow_egomotion_amd.optim import FusedAdam
+    torch.manual_seed(5)
+    shapes = [(33, 7), (4097,), (16, 3, 3, 3), (5,)]
+    pa = [torch.randn(s, device=dev(), requires_grad=True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa, ob = FusedAdam(pa, lr=1e-3), torch.optim.Adam(pb, lr=1e-3)
+    # which parameters have a gradient at which step: [1] joins at step 2, [2] skips step 3, [3] joins at step 4
+    present = [(0, 2), (0, 1, 2), (0, 1, 2), (0, 1), (0, 1, 2, 3), (0, 1, 2, 3), (0, 1, 2, 3), (0, 1, 2, 3)]
+    for it, who in enumerate(present):
+        for k, (a, b) in enumerate(zip(pa, pb)):
+            if k in who:
+                g = torch.randn_like(a)
+                a.grad, b.grad = g.clone(), g.clone()
+            else:
+                a.grad = b.grad = None
+        oa.step(); ob.step()
+        assert len(oa._plans) <= FusedAdam.MAX_PLANS
+    for a, b in zip(pa, pb):
+        assert float(oa.state[a]["step"]) == float(ob.state[b]["step"])
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-7
+        for key in ("exp_avg", "exp_avg_sq"):
+            x, y = oa.state[a][key], ob.state[b][key]
+            assert float((x - y).abs().max()) <= 2e-6 * float(y.abs().max()) + 1e-12
+    assert [float(oa.state[a]["step"]) for a in pa] == [8.0, 7.0, 7.0, 4.0]
+    # steady state: the same sub-groups every step re-use their plans (no new pinned buffers)
+    before = {k: id(v) for k, v in oa._plans.items()}
+    for a, b in zip(pa, pb):
+        a.grad = torch.randn_like(a)
+    oa.step()
+    assert {k: id(v) for k, v in oa._plans.items()} == before

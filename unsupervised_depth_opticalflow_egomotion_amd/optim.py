@@ -26,6 +26,8 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._plans = {}
 
+    MAX_PLANS = 8
+
     def state_dict(self):
         """As torch.optim.Adam's.  Inside this optimiser the parameters of a group share ONE step-count tensor (one
         increment per step instead of ~250); a checkpoint must not carry that sharing -- torch.optim.Adam increments
@@ -66,7 +68,12 @@ class FusedAdam(torch.optim.Optimizer):
                 "table": torch.empty(len(rows), 5, dtype=torch.int64, device=dev),
                 "blockmap": torch.tensor(blocks, dtype=torch.int32).to(dev), "nblocks": len(blocks),
                 "fingerprint": self._fingerprint(params)}
-        self._plans = {k: v for k, v in self._plans.items() if k[0] != gi}      # one live plan per group
+        # a group normally has ONE live plan; parameters that got their first gradient at different steps need one per
+        # distinct count.  Plans are keyed by (group, parameter ids) only -- never by the count, which changes every
+        # step -- and a group keeps at most MAX_PLANS of them (oldest dropped: pinned buffers, table, block map).
+        mine = [k for k in self._plans if k[0] == gi]
+        for k in mine[:max(0, len(mine) - (self.MAX_PLANS - 1))]:
+            del self._plans[k]
         self._plans[key] = plan
         return plan
 
@@ -102,7 +109,7 @@ class FusedAdam(torch.optim.Optimizer):
                 by_step.setdefault(float(self.state[p]["step"]), []).append((p, g))
             for t0, pg in by_step.items():
                 ps = [p for p, _ in pg]
-                plan = self._plan(gi, ps) if len(by_step) == 1 else self._plan((gi, t0), ps)
+                plan = self._plan(gi, ps)
                 host = plan["host"]
                 host[:, 1] = torch.tensor([g.data_ptr() for _, g in pg], dtype=torch.int64)
                 k = plan["turn"]
@@ -120,9 +127,17 @@ class FusedAdam(torch.optim.Optimizer):
                                         plan["nblocks"], float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                         1.0 - b1 ** t, 1.0 - b2 ** t, stream_ptr()), "dfe_adam_step")
                 first = self.state[ps[0]]["step"]
-                shared = all(self.state[p]["step"] is first for p in (ps[-1], ps[len(ps) // 2]))
+                shared = all(self.state[p]["step"] is first for p in ps)
                 if shared:
-                    first += 1.0                    # one CPU tensor shared by the group's parameters
+                    # torch.optim.Adam counts per parameter: one that holds the shared tensor but sits this launch out
+                    # (no gradient this step) keeps its count on a copy of its own
+                    if len(ps) != len(group["params"]):
+                        inside = {id(p) for p in ps}
+                        for q in group["params"]:
+                            sq = self.state.get(q)
+                            if sq and sq.get("step") is first and id(q) not in inside:
+                                sq["step"] = first.clone()
+                    first += 1.0                    # one CPU tensor shared by the launch's parameters
                 else:
                     new = torch.tensor(t, dtype=torch.float32)
                     for p in ps:
