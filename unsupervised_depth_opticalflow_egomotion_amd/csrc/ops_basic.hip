@@ -427,201 +427,8 @@ __global__ void k_ssim_bwd(const float* __restrict__ x, const float* __restrict_
   if (gy_out) gy_out[plane + static_cast<long>(gy) * W + gx] = (s[1] + 2.0f * yv * s[3] + xv * s[4]) / 9.0f;
 }
 
-// ====================================================================== correlation (d = 4, 81 taps)
-// out[b, i*9+j, y, x] = 1/C sum_c f1[b,c,y,x] * f2[b,c,y+i-4,x+j-4]   (zero outside; pwc_tf.py:97-106)
-// Bandwidth-bound (AI ~ 9 FLOP/B): no MFMA.  Parallelism comes from the displacement rows: one thread
-// owns (b, dy, y, 4 consecutive x) -> 36 outputs, and per channel reads one float4 of f1 and a 12-float
-// window of the f2 row (3 aligned float4): 36 FMAs per 4 vector loads, fully coalesced, no LDS and no
-// barriers (the coarsest PWC level is 4x13 px -- a tile/LDS formulation leaves 252 of 256 CUs idle).
-// W % 4 != 0 (levels 8x26, 4x13) takes the scalar instantiation V = 1.
+// ====================================================================== correlation (d = 4, 81 taps): ops_corr.hip
 constexpr int CR_D = 4, CR_K = 2 * CR_D + 1;
-
-template <int V>
-__device__ __forceinline__ void load_window(const float* __restrict__ row, int x0, int W, bool row_ok, float (&w)[V + 2 * CR_D]) {
-  // w[m] = row[x0 - 4 + m], zero outside [0, W)
-  if (V == 4) {
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const int xs = x0 - 4 + 4 * q;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row_ok && xs >= 0 && xs < W) v = *reinterpret_cast<const float4*>(row + xs);
-      w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
-    }
-  } else {
-#pragma unroll
-    for (int m = 0; m < V + 2 * CR_D; ++m) {
-      const int xs = x0 - CR_D + m;
-      w[m] = (row_ok && xs >= 0 && xs < W) ? row[xs] : 0.0f;
-    }
-  }
-}
-
-template <int V>
-__global__ void __launch_bounds__(256) k_corr_fwd(const float* __restrict__ f1, const float* __restrict__ f2,
-                                                  float* __restrict__ out, long obs, int B, int C, int H, int W) {
-  const int WQ = (W + V - 1) / V;
-  const long total = static_cast<long>(B) * CR_K * H * WQ;
-  const long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (t >= total) return;
-  const int xq = static_cast<int>(t % WQ), y = static_cast<int>((t / WQ) % H);
-  const int i = static_cast<int>((t / (static_cast<long>(WQ) * H)) % CR_K), b = static_cast<int>(t / (static_cast<long>(WQ) * H * CR_K));
-  const int x0 = xq * V, r = y + i - CR_D;
-  const bool row_ok = r >= 0 && r < H;
-  const long HW = static_cast<long>(H) * W;
-  const float* p1 = f1 + static_cast<long>(b) * C * HW + static_cast<long>(y) * W + x0;
-  const float* p2 = f2 + static_cast<long>(b) * C * HW + static_cast<long>(row_ok ? r : 0) * W;
-  float acc[V][CR_K];
-#pragma unroll
-  for (int u = 0; u < V; ++u)
-#pragma unroll
-    for (int j = 0; j < CR_K; ++j) acc[u][j] = 0.0f;
-  if (row_ok) {
-#pragma unroll 4
-    for (int c = 0; c < C; ++c) {   // 4 channels of loads in flight: the mid levels run ~1 wave per SIMD
-      float a[V], w[V + 2 * CR_D];
-      if (V == 4) { float4 v = *reinterpret_cast<const float4*>(p1 + c * HW); a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
-      else a[0] = p1[c * HW];
-      load_window<V>(p2 + c * HW, x0, W, true, w);
-#pragma unroll
-      for (int u = 0; u < V; ++u)
-#pragma unroll
-        for (int j = 0; j < CR_K; ++j) acc[u][j] += a[u] * w[u + j];
-    }
-  }
-  const float fc = static_cast<float>(C);
-  float* o = out + static_cast<long>(b) * obs + static_cast<long>(i * CR_K) * HW + static_cast<long>(y) * W + x0;   // obs: batch stride of out (the 81 planes may be a slice of a wider tensor)
-#pragma unroll
-  for (int j = 0; j < CR_K; ++j) {
-    if (V == 4) *reinterpret_cast<float4*>(o + j * HW) = make_float4(acc[0][j] / fc, acc[1][j] / fc, acc[2][j] / fc, acc[3][j] / fc);
-    else o[j * HW] = acc[0][j] / fc;
-  }
-}
-
-// W % 4 != 0 (the 8x26 and 4x13 PWC levels): one thread per OUTPUT element.  These levels are tiny (<= 208 px)
-// with the most channels (128/196); a thread per (b, k, y, x) gives 81x the threads of a per-pixel mapping and
-// two independent, coalesced loads per channel (4-way unrolled), instead of 52 px * 9 threads looping 196 channels.
-__global__ void __launch_bounds__(256) k_corr_fwd_naive(const float* __restrict__ f1, const float* __restrict__ f2,
-                                                        float* __restrict__ out, long obs, int B, int C, int H, int W) {
-  const long HW = static_cast<long>(H) * W, total = static_cast<long>(B) * CR_K * CR_K * HW;
-  const long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (t >= total) return;
-  const int x = static_cast<int>(t % W), y = static_cast<int>((t / W) % H);
-  const int k = static_cast<int>((t / HW) % (CR_K * CR_K)), b = static_cast<int>(t / (HW * CR_K * CR_K));
-  const int r = y + k / CR_K - CR_D, q = x + k % CR_K - CR_D;
-  float acc = 0.0f;
-  if (r >= 0 && r < H && q >= 0 && q < W) {
-    const float* p1 = f1 + static_cast<long>(b) * C * HW + static_cast<long>(y) * W + x;
-    const float* p2 = f2 + static_cast<long>(b) * C * HW + static_cast<long>(r) * W + q;
-#pragma unroll 4
-    for (int c = 0; c < C; ++c) acc += p1[c * HW] * p2[c * HW];
-  }
-  out[static_cast<long>(b) * obs + static_cast<long>(k) * HW + static_cast<long>(y) * W + x] = acc / static_cast<float>(C);
-}
-
-// one thread per (b, c, y, x); MODE as in k_corr_bwd below
-template <int MODE>
-__global__ void __launch_bounds__(256) k_corr_bwd_naive(const float* __restrict__ other, const float* __restrict__ gout, long gbs,
-                                                        const float* __restrict__ addend, long abs_,
-                                                        float* __restrict__ gin, int B, int C, int H, int W) {
-  const long HW = static_cast<long>(H) * W, total = static_cast<long>(B) * C * HW;
-  const long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (t >= total) return;
-  const int x = static_cast<int>(t % W), y = static_cast<int>((t / W) % H);
-  const int c = static_cast<int>((t / HW) % C), b = static_cast<int>(t / (HW * C));
-  const float* ob = other + (static_cast<long>(b) * C + c) * HW;
-  const float* gb = gout + static_cast<long>(b) * gbs;
-  float acc = 0.0f;
-#pragma unroll 3
-  for (int i = 0; i < CR_K; ++i) {
-    const int r = (MODE == 0) ? y + i - CR_D : y - (i - CR_D);
-    if (r < 0 || r >= H) continue;
-#pragma unroll
-    for (int j = 0; j < CR_K; ++j) {
-      const int q = (MODE == 0) ? x + j - CR_D : x - (j - CR_D);
-      if (q < 0 || q >= W) continue;
-      const float g = (MODE == 0) ? gb[(i * CR_K + j) * HW + static_cast<long>(y) * W + x]
-                                  : gb[(i * CR_K + j) * HW + static_cast<long>(r) * W + q];
-      acc += g * ob[static_cast<long>(r) * W + q];
-    }
-  }
-  float v = acc / static_cast<float>(C);
-  if (addend) v += addend[static_cast<long>(b) * abs_ + static_cast<long>(c) * HW + static_cast<long>(y) * W + x];
-  gin[t] = v;
-}
-
-// g1[c,p] = 1/C sum_{i,j} g[i*9+j, p] * f2[c, p + (i-4, j-4)]          (MODE 0, other = f2)
-// g2[c,p] = 1/C sum_{i,j} g[i*9+j, p - (i-4,j-4)] * f1[c, p - (i-4,j-4)]  (MODE 1, other = f1)
-// One thread owns (b, chunk of CK channels, y, V consecutive x).  Per displacement row it holds the 9 (MODE 0)
-// gradient vectors or streams the 9 gradient windows (MODE 1) and re-uses them across the CK channels.
-constexpr int CR_CK = 8;
-
-template <int V, int MODE>
-__global__ void __launch_bounds__(256) k_corr_bwd(const float* __restrict__ other, const float* __restrict__ gout, long gbs,
-                                                  const float* __restrict__ addend, long abs_,
-                                                  float* __restrict__ gin, int B, int C, int H, int W) {
-  const int WQ = (W + V - 1) / V, NCH = (C + CR_CK - 1) / CR_CK;
-  const long total = static_cast<long>(B) * NCH * H * WQ;
-  const long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (t >= total) return;
-  const int xq = static_cast<int>(t % WQ), y = static_cast<int>((t / WQ) % H);
-  const int ch = static_cast<int>((t / (static_cast<long>(WQ) * H)) % NCH), b = static_cast<int>(t / (static_cast<long>(WQ) * H * NCH));
-  const int x0 = xq * V, c0 = ch * CR_CK, nch = min(CR_CK, C - c0);
-  const long HW = static_cast<long>(H) * W;
-  const float* ob = other + (static_cast<long>(b) * C + c0) * HW;
-  const float* gb = gout + static_cast<long>(b) * gbs;
-  float acc[CR_CK][V];
-#pragma unroll
-  for (int c = 0; c < CR_CK; ++c)
-#pragma unroll
-    for (int u = 0; u < V; ++u) acc[c][u] = 0.0f;
-#pragma unroll 1
-  for (int i = 0; i < CR_K; ++i) {
-    const int r = (MODE == 0) ? y + i - CR_D : y - (i - CR_D);
-    if (r < 0 || r >= H) continue;
-    if (MODE == 0) {
-      float g[CR_K][V];
-#pragma unroll
-      for (int j = 0; j < CR_K; ++j) {
-        const float* gp = gb + (i * CR_K + j) * HW + static_cast<long>(y) * W + x0;
-        if (V == 4) { float4 v = *reinterpret_cast<const float4*>(gp); g[j][0] = v.x; g[j][1] = v.y; g[j][2] = v.z; g[j][3] = v.w; }
-        else g[j][0] = gp[0];
-      }
-#pragma unroll
-      for (int c = 0; c < CR_CK; ++c) {   // fully unrolled: all CR_CK windows in flight
-        float w[V + 2 * CR_D];
-        load_window<V>(ob + (c < nch ? c : 0) * HW + static_cast<long>(r) * W, x0, W, c < nch, w);
-#pragma unroll
-        for (int u = 0; u < V; ++u)
-#pragma unroll
-          for (int j = 0; j < CR_K; ++j) acc[c][u] += g[j][u] * w[u + j];
-      }
-    } else {
-      float w[CR_CK][V + 2 * CR_D];
-#pragma unroll
-      for (int c = 0; c < CR_CK; ++c) load_window<V>(ob + (c < nch ? c : 0) * HW + static_cast<long>(r) * W, x0, W, c < nch, w[c]);
-#pragma unroll
-      for (int j = 0; j < CR_K; ++j) {
-        float gw[V + 2 * CR_D];
-        load_window<V>(gb + (i * CR_K + j) * HW + static_cast<long>(r) * W, x0, W, true, gw);
-        // source column q = x - (j-4)  ->  window index m = u - j + 8
-#pragma unroll
-        for (int c = 0; c < CR_CK; ++c)
-#pragma unroll
-          for (int u = 0; u < V; ++u) acc[c][u] += gw[u - j + 2 * CR_D] * w[c][u - j + 2 * CR_D];
-      }
-    }
-  }
-  const float fc = static_cast<float>(C);
-  for (int c = 0; c < nch; ++c) {
-    float* o = gin + (static_cast<long>(b) * C + c0 + c) * HW + static_cast<long>(y) * W + x0;
-    const float* ad = addend ? addend + static_cast<long>(b) * abs_ + static_cast<long>(c0 + c) * HW + static_cast<long>(y) * W + x0 : nullptr;
-    if (V == 4) {
-      float4 v = make_float4(acc[c][0] / fc, acc[c][1] / fc, acc[c][2] / fc, acc[c][3] / fc);
-      if (ad) { const float4 a4 = *reinterpret_cast<const float4*>(ad); v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w; }
-      *reinterpret_cast<float4*>(o) = v;
-    } else { float v = acc[c][0] / fc; if (ad) v += ad[0]; o[0] = v; }
-  }
-}
 
 // ====================================================================== resize (pyramids)
 // mode 0: bilinear align_corners=False (F.interpolate); mode 1: area (adaptive average pool)
@@ -864,42 +671,12 @@ int dfe_ssim_bwd(const float* x, const float* y, const float* gout, float* gx, f
   return DFE_OK;
 }
 
-static inline bool corr_vec_ok(const void* a, const void* b, const void* c, int W) {
-  auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  return (W % 4 == 0) && al(a) && al(b) && al(c);
-}
-
-static void launch_corr_fwd(const float* f1, const float* f2, float* out, long obs, int B, int C, int H, int W, hipStream_t st) {
-  if (corr_vec_ok(f1, f2, out, W) && obs % 4 == 0) {
-    long n = static_cast<long>(B) * CR_K * H * (W / 4);
-    k_corr_fwd<4><<<grid1d(n, 256), 256, 0, st>>>(f1, f2, out, obs, B, C, H, W);
-  } else {
-    long n = static_cast<long>(B) * CR_K * CR_K * H * W;
-    k_corr_fwd_naive<<<grid1d(n, 256), 256, 0, st>>>(f1, f2, out, obs, B, C, H, W);
-  }
-}
-
-// gout: 81 planes per sample with batch stride gbs; add1 (batch stride abs1) is added to g1 when given
-static void launch_corr_bwd(const float* f1, const float* f2, const float* gout, long gbs, const float* add1, long abs1,
-                            float* g1, float* g2, int B, int C, int H, int W, hipStream_t st) {
-  const int nchunk = (C + CR_CK - 1) / CR_CK;
-  const bool vec = corr_vec_ok(f1, f2, gout, W) && corr_vec_ok(g1, g2, add1, W) && gbs % 4 == 0 && abs1 % 4 == 0;
-  const long n = static_cast<long>(B) * nchunk * H * (W / 4), nn = static_cast<long>(B) * C * H * W;
-  if (g1) {
-    if (vec) k_corr_bwd<4, 0><<<grid1d(n, 256), 256, 0, st>>>(f2, gout, gbs, add1, abs1, g1, B, C, H, W);
-    else k_corr_bwd_naive<0><<<grid1d(nn, 256), 256, 0, st>>>(f2, gout, gbs, add1, abs1, g1, B, C, H, W);
-  }
-  if (g2) {
-    if (vec) k_corr_bwd<4, 1><<<grid1d(n, 256), 256, 0, st>>>(f1, gout, gbs, nullptr, 0, g2, B, C, H, W);
-    else k_corr_bwd_naive<1><<<grid1d(nn, 256), 256, 0, st>>>(f1, gout, gbs, nullptr, 0, g2, B, C, H, W);
-  }
-}
-
 int dfe_corr_fwd(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int d, void* stream) {
   DFE_REQUIRE(f1 && f2 && out, DFE_ERR_NULL);
   DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
   DFE_REQUIRE(d == CR_D, DFE_ERR_UNSUPPORTED);
-  launch_corr_fwd(f1, f2, out, static_cast<long>(CR_K) * CR_K * H * W, B, C, H, W, static_cast<hipStream_t>(stream));
+  const int rc = launch_corr_fwd(f1, f2, out, static_cast<long>(CR_K) * CR_K * H * W, B, C, H, W, static_cast<hipStream_t>(stream));
+  if (rc != DFE_OK) return rc;
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
@@ -909,7 +686,8 @@ int dfe_corr_bwd(const float* f1, const float* f2, const float* gout, float* g1,
   DFE_REQUIRE(f1 && f2 && gout && (g1 || g2), DFE_ERR_NULL);
   DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
   DFE_REQUIRE(d == CR_D, DFE_ERR_UNSUPPORTED);
-  launch_corr_bwd(f1, f2, gout, static_cast<long>(CR_K) * CR_K * H * W, nullptr, 0, g1, g2, B, C, H, W, static_cast<hipStream_t>(stream));
+  const int rc = launch_corr_bwd(f1, f2, gout, static_cast<long>(CR_K) * CR_K * H * W, nullptr, 0, g1, g2, B, C, H, W, static_cast<hipStream_t>(stream));
+  if (rc != DFE_OK) return rc;
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
@@ -929,7 +707,7 @@ int dfe_pwc_level_fwd(const float* c1, const float* c2, const float* flow, float
   dim3 gw(static_cast<unsigned>((HW + 63) / 64), (C + WF_CK - 1) / WF_CK, B);
   k_warp_flow_fwd<<<gw, 64, 0, st>>>(c2, flow, warped, C, H, W, 0, align_corners);
   DFE_LAUNCH_CHECK();
-  launch_corr_fwd(c1, warped, x, xbs, B, C, H, W, st);
+  { const int rc = launch_corr_fwd(c1, warped, x, xbs, B, C, H, W, st); if (rc != DFE_OK) return rc; }
   DFE_LAUNCH_CHECK();
   auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const int vec = (HW % 4 == 0) && al(c1) && al(flow) && al(x);
@@ -953,7 +731,7 @@ int dfe_pwc_level_bwd(const float* c1, const float* c2, const float* flow, const
   const float* gx_c1 = gx + static_cast<long>(CR_K) * CR_K * HW;
   const float* gx_flow = gx_c1 + static_cast<long>(C) * HW;
   // dL/dc1 = correlation gradient + the concatenated copy's slice; dL/dwarped
-  launch_corr_bwd(c1, warped, gx, xbs, gx_c1, xbs, g_c1, g_warped, B, C, H, W, st);
+  { const int rc = launch_corr_bwd(c1, warped, gx, xbs, gx_c1, xbs, g_c1, g_warped, B, C, H, W, st); if (rc != DFE_OK) return rc; }
   DFE_LAUNCH_CHECK();
   const long n = static_cast<long>(B) * C * HW;
   if (g_c2) { const int rc = scatter_begin(g_c2_ws, n, g_warped, n, st); if (rc != DFE_OK) return rc; }
