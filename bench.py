@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--workload", default="auto", choices=["auto", "train_step", "loss_stack"])
     ap.add_argument("--mode", default="geom", choices=["geom", "depth", "flow"], help="train_step model: geom = configs[2] (default, the metric's configuration), depth = configs[1], flow = configs[0]")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for single-GPU functional tests)")
+    ap.add_argument("--force-ddp", action="store_true", help="with --gpus 1: still create the process group (RCCL communicator at world size 1) and wrap the "
+                    "model in DistributedDataParallel, and print the multi_gpu evidence block -- the only way the RCCL path can run on a 1-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--miopen-benchmark", type=int, default=0, help="torch.backends.cudnn.benchmark (MIOpen exhaustive find)")
@@ -107,19 +109,26 @@ def init_dist(args):
     if os.environ.get("DFE_BENCH_ALL_ON_DEVICE0") == "1":   # functional test of the N>1 path on a 1-GPU box
         local = 0
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or args.force_ddp:
         import torch.distributed as dist
+        from unsupervised_depth_opticalflow_egomotion_amd import ddp
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            with socket.socket() as sock:      # a free port: several single-rank runs may share a box
+                sock.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            kw = {"pg_options": ddp.rccl_options()} if ddp.rccl_options() is not None else {}
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), **kw)
         else:
             dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
     return world, rank, local
 
 
 def barrier(world):
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if world > 1 or dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
 
@@ -208,7 +217,7 @@ class TrainStepWorkload:
         self.inputs = [torch.from_numpy(a).to(dev) for a in (im, k, ki)]   # resident in HBM before timing
         if world > 1:
             self.find_warmup(world)
-        self.model = ddp.wrap(self.model, dev)
+        self.model = ddp.wrap(self.model, dev, force=bool(getattr(args, "force_ddp", False)))
         self.opt = make_optimizer(self.model, self.cfg.lr)
 
     def find_warmup(self, world):
@@ -284,7 +293,7 @@ class TrainStepWorkload:
 # from tools/byte_models.py, the same table tools/roofline_table.py prices the rocprof runs with
 from tools import byte_models  # noqa: E402
 
-POINT_LIMITER = {"geom": "VALU issue (870 instructions per pixel, ~5 cycles each) when the flows are smooth, the gathers' 128-byte line count when "
+POINT_LIMITER = {"geom": "VALU issue (871 instructions per pixel at a measured ~3 SIMD-cycles each: roofline.valu_frac) when the flows are smooth, the gathers' 128-byte line count when "
                           "they are rough; Infinity-Cache resident at B=4 (profiles/r03_point_fwd_ablation.md)"}
 HBM_ACHIEVABLE_GBS = 6290.0    # measured float4 copy rate (MI355X_MICROARCH.md)
 KERNEL_SOURCES = ("loss_stack_fwd.hip", "loss_stack.h", "loss_stack_exact.h", "dfe_device.h")
@@ -308,6 +317,7 @@ def point_fwd_roofline(args, mode, fwd_ms, bwd_ms):
     bytes_per_launch, byte_model = byte_models.models(args.batch, args.height, args.width, S)[kernel]
     t_ms = float(fwd_ms[:, 2].mean())
     achieved = bytes_per_launch / (t_ms * 1e-3) / 1e9
+    valu_per_wave, valu_src = None, "static (tools/byte_models.VALU_PER_WAVE)"
     traffic = None   # PMC-derived HBM bytes per launch: cannot be collected from inside this process; taken from
     try:             # the committed rocprofv3 --pmc pass ONLY when it was made on exactly this kernel source and workload
         with open(os.path.join(ROOT, "profiles", "pmc_point_fwd_traffic.json")) as fh:
@@ -316,12 +326,23 @@ def point_fwd_roofline(args, mode, fwd_ms, bwd_ms):
         same_kernel = pm.get("kernel_source_sha256") == kernel_source_hash()
         if mode == "geom" and same_kernel and (w["batch"], w["height"], w["width"], w["scales"]) == (args.batch, args.height, args.width, S):
             traffic = pm["hbm_bytes_per_launch"]
+            if pm.get("valu_per_wave"):
+                valu_per_wave, valu_src = float(pm["valu_per_wave"]), "pmc (profiles/pmc_point_fwd_traffic.json, same kernel source)"
     except Exception:
         traffic = None
-    # "bound": the roofline the contract prices this kernel against is HBM; what the PMC passes say
-    # actually limits it is reported next to it ("limiter")
-    roof = {"bound": "hbm", "limiter": POINT_LIMITER.get(mode), "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4),
+    # The second roof: vector-ALU issue.  One thread per pixel of every (sample, scale) image; executed VALU instructions per
+    # wave x the measured issue cost of this kernel's instruction mix, on all 1024 SIMDs (tools/byte_models.valu_time_s).
+    threads = args.batch * sum(byte_models.scale_pixels(args.height, args.width, S))
+    t_valu = byte_models.valu_time_s(kernel, threads, valu_per_wave)
+    valu_frac = None if t_valu is None else round(t_valu / (t_ms * 1e-3), 4)
+    hbm_frac = round(achieved / HBM_PEAK_GBS, 4)
+    roof = {"bound": "valu" if (valu_frac is not None and valu_frac > hbm_frac) else "hbm",
+            "bound_note": "the larger of frac (algorithmic bytes / time / HBM peak) and valu_frac (VALU instructions x measured issue cycles / time); "
+                          "achieved / peak / frac stay the HBM roofline SURVEY 8(d) prices this kernel against",
+            "valu_frac": valu_frac, "valu_insts_per_wave": valu_per_wave if valu_per_wave is not None else byte_models.VALU_PER_WAVE.get(kernel),
+            "valu_cycles_per_inst": round(byte_models.VALU_CYCLES_PER_INST, 2), "valu_source": valu_src,
+            "limiter": POINT_LIMITER.get(mode), "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": hbm_frac, "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4),
             "traffic": traffic,
             "bytes_per_launch": bytes_per_launch, "byte_model": byte_model, "avg_kernel_ms": round(t_ms, 5), "launches_timed": int(fwd_ms.shape[0])}
     segs = {"fwd_ms": [round(float(x), 5) for x in fwd_ms.mean(0)],
@@ -384,7 +405,8 @@ def multi_gpu_evidence(wl, world, rank, dev, dt_local, args):
     times = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(times, torch.tensor([1e3 * dt_local / args.steps], device=dev, dtype=torch.float64))
     times = [float(t.item()) for t in times]
-    ev = {"backend": dist.get_backend(), "collective_library": "RCCL" if dist.get_backend() == "nccl" else dist.get_backend(),
+    ddp_model = type(model).__name__ == "DistributedDataParallel" if model is not None else False
+    ev = {"ddp_wrapped": ddp_model, "backend": dist.get_backend(), "collective_library": "RCCL" if dist.get_backend() == "nccl" else dist.get_backend(),
           "rccl_ranks": int(ids[1].item()), "rank_id_allreduce_ok": bool(ids_ok),
           "ms_per_step_min": round(min(times), 4), "ms_per_step_max": round(max(times), 4),
           "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE")}
@@ -426,7 +448,7 @@ def main():
     dt_local = time.perf_counter() - t0
     dt = max_over_ranks(dt_local, world, dev)
     fwd_ms, bwd_ms = LS.timing_collect()
-    evidence = multi_gpu_evidence(wl, world, rank, dev, dt_local, args) if world > 1 else None
+    evidence = multi_gpu_evidence(wl, world, rank, dev, dt_local, args) if (world > 1 or args.force_ddp) else None
     pairs_per_step = 2 * args.batch * world
     value = pairs_per_step * args.steps / dt
     out = {
@@ -449,7 +471,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args, 2 * args.batch)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_ddp:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -36,3 +36,22 @@ def models(B, H, W, S, mode="geom"):
 
 
 POINT_KERNEL = {"geom": "k_geom_point_fwd", "depth": "k_depth_point_fwd", "flow": "k_flow_point_fwd"}
+
+
+# ---- VALU-issue roof of the pointwise kernels (bench.py roofline.valu_frac)
+# Executed vector-ALU instructions per wave (rocprofv3 SQ_INSTS_VALU / SQ_WAVES, profiles/r03_pmc_loss_stack.json; the
+# static mix is profiles/r03_point_fwd_isa_mix.md) and what one of them costs a SIMD when >= 2 waves share it, measured
+# with tools/ubench/valu.hip (profiles/r02_issue_cost_model.md section 1, at an assumed 2.4 GHz): 2.64 cycles for
+# mul / add / fma, 3.9 for compare + select pairs (22 % of this kernel's mix), ~8 for the few transcendentals.
+VALU_PER_WAVE = {"k_geom_point_fwd": 871.1}
+VALU_CYCLES_PER_INST = 0.76 * 2.64 + 0.22 * 3.9 + 0.02 * 8.2      # = 3.03
+GPU_SIMDS, GPU_CLOCK_HZ = 256 * 4, 2.4e9
+
+
+def valu_time_s(kernel, pixels_threads, valu_per_wave=None):
+    """Time the launch's vector-ALU instructions alone need on the whole chip (every SIMD issuing back to back)."""
+    v = valu_per_wave if valu_per_wave is not None else VALU_PER_WAVE.get(kernel)
+    if v is None:
+        return None
+    waves = (pixels_threads + 63) // 64
+    return waves * v * VALU_CYCLES_PER_INST / GPU_SIMDS / GPU_CLOCK_HZ

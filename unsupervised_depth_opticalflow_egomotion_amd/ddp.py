@@ -16,9 +16,25 @@ def env_world():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init_process_group(backend=None):
+def rccl_options():
+    """Process-group options for backend "nccl" (= RCCL): the communicator's stream is a HIGH-priority HIP stream.
+    models.run_networks puts the flow and pose branches on high-priority streams (the flow branch is the step's long
+    pole); DDP's reducer enqueues every bucket's all-reduce on the process group's own stream while
+    backward is still running, and a default-priority stream gets its kernels scheduled only when no high-priority
+    queue has a wave ready -- the buckets would drain after backward instead of under it."""
+    try:
+        opts = dist.ProcessGroupNCCL.Options()
+        opts.is_high_priority_stream = True
+        return opts
+    except AttributeError:          # a torch build without the NCCL/RCCL process group
+        return None
+
+
+def init_process_group(backend=None, force=False):
+    """One process per GPU: reads RANK / LOCAL_RANK / WORLD_SIZE.  ``force`` initialises the group at world size 1 too
+    (the RCCL communicator, DDP's reducer and its bucket views then run on a single GPU: tests, bench.py --force-ddp)."""
     world, rank, local = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -27,6 +43,8 @@ def init_process_group(backend=None):
         if backend == "nccl":
             torch.cuda.set_device(local)
             kw["device_id"] = torch.device("cuda", local)
+            if rccl_options() is not None:
+                kw["pg_options"] = rccl_options()
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return world, rank, local
 
@@ -40,12 +58,13 @@ def unused_parameter_names(model):
             if ".encoder.encoder.fc." in n or n.startswith("encoder.encoder.fc.")]
 
 
-def wrap(model, device=None, bucket_cap_mb=25):
-    """DistributedDataParallel when WORLD_SIZE > 1, the bare module otherwise.  The never-used ``fc`` parameters are
+def wrap(model, device=None, bucket_cap_mb=25, force=False):
+    """DistributedDataParallel when WORLD_SIZE > 1 (or ``force``: DDP over a world-size-1 group, which still builds the
+    reducer, the bucket views and the communicator), the bare module otherwise.  The never-used ``fc`` parameters are
     excluded from the reducer (it would wait for their gradients forever) instead of being frozen: 21.06 M of the
     model's 21.57 M parameters are all-reduced (84 MB fp32 per step)."""
     world, _, local = env_world()
-    if world == 1:
+    if world == 1 and not force:
         return model
     from torch.nn.parallel import DistributedDataParallel as DDP
     DDP._set_params_and_buffers_to_ignore_for_model(model, unused_parameter_names(model))
