@@ -276,6 +276,11 @@ int dfe_bias_act_fwd2(const float* z, const float* bias, float* dst1, long dst1_
 int dfe_bias_act_bwd2(const float* y, long y_batch_stride, const float* g1, long g1_batch_stride, const float* g2,
                       long g2_batch_stride, float* gz, float* gbias, float* partials, int B, int C, int H, int W,
                       float slope, void* stream);
+/* With gbias == NULL and partials != NULL dfe_bias_act_bwd / dfe_bias_act_bwd2 only write the per-block partial sums; the
+ * bias gradients of up to 8 such layers of one plane size (a PWC decoder level: pwc_tf.py:113-117) are then finished by
+ * ONE launch: host arrays of n device pointers / channel counts; same summation order as the single-layer finish. */
+int dfe_bias_grad_final_multi(const float* const* partials, float* const* gbias, const int* C, int n, int B, int H, int W,
+                              void* stream);
 
 /* ---- fused loss stack: everything from model_geometry.py:797 to :951 given the nets' outputs ---
  * One call computes the active loss_pack vectors of Model_geometry.forward (mode 0) for a batch:

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "dfe_bias_act_bwd": [_P, _P, ctypes.c_long, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, _P],
     "dfe_bias_act_fwd2": [_P, _P, _P, ctypes.c_long, _P, ctypes.c_long, _I, _I, _I, _I, ctypes.c_float, _P],
     "dfe_bias_act_bwd2": [_P, ctypes.c_long, _P, ctypes.c_long, _P, ctypes.c_long, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, _P],
+    "dfe_bias_grad_final_multi": [_P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_glue_partials_floats": [_I, _I, _I, _I],
     "dfe_elu_pad_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_elu_pad_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

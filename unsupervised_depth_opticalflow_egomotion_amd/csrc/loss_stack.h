@@ -51,7 +51,13 @@ struct GeomLayout {
   long o_yr, o_gyr, o_part2, o_spart2, o_sums2;   // masked rigid warps, their SSIM gradient, block / strip partials, sums
   long o_scq;       // depth-consistency term: fixed-point accumulators of the projected-depth scatter (dfe_scatter.h),
                     // 64-byte header + int64 [2 source frames][scale][B][N_s]
+  // separable adjoint of the bilinear up-sampling at the coarse levels (ratio below 1/4, s >= adj_s0; none: adj_s0 = S):
+  // column sums of the up-sampled gradients per segment of adj_L[s] rows, [3][S - adj_s0][B][adj_nseg][ADJ_SLOTS][W_0]
+  int adj_mode, adj_s0, adj_nseg, adj_L[DFE_MAX_SCALES];
+  long o_adjp;
 };
+constexpr int ADJ_SLOTS = 8;      // low-res rows a segment can touch: ceil(L * ratio) + 2 with L * ratio <= 6
+constexpr int ADJ_LMAX = 32;      // rows per segment (all of a lane's loads in flight at once)
 
 // Kernel-argument tables (passed by value).
 struct GeomDev {

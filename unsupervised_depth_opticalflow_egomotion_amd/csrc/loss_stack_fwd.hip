@@ -80,6 +80,31 @@ int geom_layout(const dfe_geom_args* a, GeomLayout* L) {
   L->o_spart2 = o; o = align4(o + ((L->dt & DFE_DEPTH_TERM_SSIM) ? B * 2 * static_cast<long>(L->roll_start[S]) : 0));
   L->o_sums2 = o; o = align4(o + (L->dt ? B * S * 4 : 0));
   L->o_scq = o; o = align4(o + ((L->dt & DFE_DEPTH_TERM_CONSIS) ? 16 + 4 * B * sumN : 0));
+  // adjoint of the bilinear up-sampling in the disparity-smoothness backward (loss_stack_bwd.hip: k_geom_adj_rows /
+  // k_geom_adj_cols).  Modes: 0 "separable" = every level >= 1 in two passes (rows, then columns); 1 "mixed" = round 3's
+  // register gather for ratios >= 1/4 and the two passes below that; 2 "gather" = round 3's two gather kernels.
+  // Default: mixed where levels 1-2 are exact 1/2 and 1/4 (the dense tent fast path of the register gather: 23.8 us
+  // against 26.5 at B = 4, 256 x 832), separable for every other size (48.9 against 72.0 us at B = 2, 375 x 1242, S = 6;
+  // 235 against 335 at B = 16; round 3's gathers: 126 / 785).  DFE_ADJ_MODE=separable|mixed|gather overrides.
+  {
+    bool exact = true;
+    for (int s = 1; s < L->S && s <= 2; ++s) exact = exact && (L->H[s] << s) == L->H[0] && (L->W[s] << s) == L->W[0];
+    L->adj_mode = exact ? 1 : 0;
+    const char* m = getenv("DFE_ADJ_MODE");
+    if (m) L->adj_mode = m[0] == 'g' ? 2 : (m[0] == 'm' ? 1 : 0);
+  }
+  L->adj_s0 = 1;
+  if (L->adj_mode != 0) while (L->adj_s0 < L->S && L->H[0] <= 4 * L->H[L->adj_s0] && L->W[0] <= 4 * L->W[L->adj_s0]) ++L->adj_s0;
+  L->adj_nseg = 0;
+  for (int s = 0; s < DFE_MAX_SCALES; ++s) L->adj_L[s] = 1;
+  for (int s = L->adj_s0; s < L->S; ++s) {
+    int len = static_cast<int>(6.0 * L->H[0] / L->H[s]);           // L * (H_s / H_0) <= 6  ->  at most 8 low-res rows touched
+    len = len > ADJ_LMAX ? ADJ_LMAX : (len < 1 ? 1 : len);
+    L->adj_L[s] = len;
+    const int nseg = (L->H[0] + len - 1) / len;
+    if (nseg > L->adj_nseg) L->adj_nseg = nseg;
+  }
+  L->o_adjp = o; o = align4(o + 3 * (S - L->adj_s0) * B * static_cast<long>(L->adj_nseg) * ADJ_SLOTS * L->W[0]);
   L->total = o;
   return DFE_OK;
 }

@@ -210,6 +210,14 @@ __global__ void __launch_bounds__(64) k_head_bwd(const float* __restrict__ p, co
     G[co][3] = dh_grad<SIG>(go, oo, r0 - 1, xx, H, W); G[co][6] = dh_grad<SIG>(go, oo, r0 - 2, xx, H, W);
     G[co][4] = wave_shr1(G[co][3]); G[co][5] = wave_shr1(G[co][4]); G[co][7] = wave_shr1(G[co][6]); G[co][8] = wave_shr1(G[co][7]);
   }
+  // the input rows are loaded two rows ahead of their use (a wave is alone on its SIMD most of the time -- 190 VGPRs --
+  // and a row's 288 FMAs are shorter than a round trip to memory: without the prefetch every row paid one)
+  float pn1[CI], pn2[CI];
+#pragma unroll
+  for (int k = 0; k < CI; ++k) {
+    pn1[k] = head_load<VPAD>(pb + k * plane, r0, xx, H, W, own);
+    pn2[k] = head_load<VPAD>(pb + k * plane, r0 + 1 < rend ? r0 + 1 : r0, xx, H, W, own);
+  }
   for (int r = r0; r < rend; ++r) {
 #pragma unroll
     for (int co = 0; co < CO; ++co) {
@@ -219,8 +227,9 @@ __global__ void __launch_bounds__(64) k_head_bwd(const float* __restrict__ p, co
       G[co][1] = wave_shr1(G[co][0]); G[co][2] = wave_shr1(G[co][1]);
     }
     float pv[CI];
+    const int rn = r + 2 < rend ? r + 2 : r0;
 #pragma unroll
-    for (int k = 0; k < CI; ++k) pv[k] = head_load<VPAD>(pb + k * plane, r, xx, H, W, own);
+    for (int k = 0; k < CI; ++k) { pv[k] = pn1[k]; pn1[k] = pn2[k]; pn2[k] = head_load<VPAD>(pb + k * plane, rn, xx, H, W, own); }
     const bool wr = VPAD ? (own && r >= 1 && r <= H && xx >= 1 && xx <= W) : own;
 #pragma unroll
     for (int k = 0; k < CI; ++k) {

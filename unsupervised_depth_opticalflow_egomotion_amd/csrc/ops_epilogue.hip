@@ -97,6 +97,29 @@ __global__ void __launch_bounds__(64) k_bias_grad_final(const float* __restrict_
   if (lane == 0) gbias[c] = (r0 + r1) + (r2 + r3);
 }
 
+// The same for up to EP_MAXL layers in ONE launch (a PWC decoder level's five epilogues used to finish their bias
+// gradients with five one-wave-per-channel launches of ~4.5 us each, serialised in the flow stream's backward chain).
+// grid.x = sum of the layers' channel counts; block = one wave; same summation order as k_bias_grad_final.
+constexpr int EP_MAXL = 8;
+struct BiasFinalJobs { const float* part[EP_MAXL]; float* gbias[EP_MAXL]; int C[EP_MAXL]; int nchunk[EP_MAXL]; int first[EP_MAXL + 1]; int n; };
+
+__global__ void __launch_bounds__(64) k_bias_grad_final_multi(BiasFinalJobs j, int B) {
+  int l = 0;
+  while (l + 1 < j.n && static_cast<int>(blockIdx.x) >= j.first[l + 1]) ++l;
+  const int c = blockIdx.x - j.first[l], lane = threadIdx.x, C = j.C[l], nchunk = j.nchunk[l];
+  float s = 0.0f;
+  for (int b = 0; b < B; ++b) {
+    const float* p = j.part[l] + (static_cast<long>(b) * C + c) * nchunk;
+    for (int k = lane; k < nchunk; k += 64) s += p[k];
+  }
+  s = dpp_add<0xB1>(s); s = dpp_add<0x4E>(s); s = dpp_add<0x141>(s); s = dpp_add<0x140>(s);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 48));
+  if (lane == 0) j.gbias[l][c] = (r0 + r1) + (r2 + r3);
+}
+
 // ---- the same epilogue for a DenseNet-style block (PWC_tf's decoder, pwc_tf.py:113-117: every layer output is
 // consumed through torch.cat by the next two layers).  Forward: read the bias-free convolution output z once and write
 // act(z + bias) straight into the channel slices of the (up to two) concatenated buffers that consume it -- dst1 may
@@ -213,7 +236,7 @@ extern "C" int dfe_bias_act_bwd(const float* y, const float* gy, long gy_batch_s
   const int nchunk = static_cast<int>((hw + EP_CHUNK - 1) / EP_CHUNK);
   const dim3 g(nchunk, C, B);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  float* part = gbias ? partials : nullptr;
+  float* part = partials;      // written whenever given: gbias == NULL leaves the finish to dfe_bias_grad_final_multi
   const bool vec = hw % 4 == 0 && aligned16(y) && aligned16(gy) && aligned16(gz) && gy_batch_stride % 4 == 0;
   if (vec) k_bias_act_bwd<true><<<g, EP_BLOCK, 0, st>>>(y, gy, gz, part, static_cast<int>(hw), hw, gy_batch_stride, C, slope);
   else k_bias_act_bwd<false><<<g, EP_BLOCK, 0, st>>>(y, gy, gz, part, static_cast<int>(hw), hw, gy_batch_stride, C, slope);
@@ -251,7 +274,7 @@ extern "C" int dfe_bias_act_bwd2(const float* y, long y_batch_stride, const floa
   const int nchunk = static_cast<int>((hw + EP_CHUNK - 1) / EP_CHUNK);
   const dim3 g(nchunk, C, B);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  float* part = gbias ? partials : nullptr;
+  float* part = partials;      // written whenever given: gbias == NULL leaves the finish to dfe_bias_grad_final_multi
   const bool vec = hw % 4 == 0 && aligned16(y) && aligned16(g1) && aligned16(gz) && y_batch_stride % 4 == 0 &&
                    g1_batch_stride % 4 == 0 && (!g2 || (aligned16(g2) && g2_batch_stride % 4 == 0));
   if (vec) k_bias_act_bwd2<true><<<g, EP_BLOCK, 0, st>>>(y, y_batch_stride, g1, g1_batch_stride, g2, g2_batch_stride, gz, part, C, static_cast<int>(hw), slope);
@@ -261,5 +284,24 @@ extern "C" int dfe_bias_act_bwd2(const float* y, long y_batch_stride, const floa
     k_bias_grad_final<<<C, 64, 0, st>>>(partials, gbias, B, C, nchunk);
     DFE_LAUNCH_CHECK();
   }
+  return DFE_OK;
+}
+
+extern "C" int dfe_bias_grad_final_multi(const float* const* partials, float* const* gbias, const int* C, int n, int B, int H, int W,
+                                         void* stream) {
+  if (!partials || !gbias || !C) return DFE_ERR_NULL;
+  const long hw = static_cast<long>(H) * W;
+  if (n <= 0 || n > EP_MAXL || B <= 0 || H <= 0 || W <= 0 || hw >= (1L << 31)) return DFE_ERR_DIMS;
+  BiasFinalJobs j;
+  j.n = n; j.first[0] = 0;
+  for (int l = 0; l < n; ++l) {
+    if (!partials[l] || !gbias[l]) return DFE_ERR_NULL;
+    if (C[l] <= 0 || C[l] > 65535) return DFE_ERR_DIMS;
+    j.part[l] = partials[l]; j.gbias[l] = gbias[l]; j.C[l] = C[l];
+    j.nchunk[l] = static_cast<int>((hw + EP_CHUNK - 1) / EP_CHUNK);
+    j.first[l + 1] = j.first[l] + C[l];
+  }
+  k_bias_grad_final_multi<<<j.first[n], 64, 0, static_cast<hipStream_t>(stream)>>>(j, B);
+  DFE_LAUNCH_CHECK();
   return DFE_OK;
 }

@@ -660,14 +660,17 @@ class DenseDecodeFn(torch.autograd.Function):
             c = co[k]
             gz = torch.empty(B, c, H, W, device=dev, dtype=torch.float32)
             gb = part = None
-            if nb(k):
+            if nb(k):       # only the per-block partial sums now; the level's bias gradients are finished by ONE launch below
                 gb = torch.empty(c, device=dev, dtype=torch.float32)
                 part = torch.empty(lib.dfe_bias_act_partials_floats(B, c, H, W), device=dev, dtype=torch.float32)
+                pending.append((part, gb, c))
             sl = lambda t, off: ctypes.c_void_p(t.data_ptr() + 4 * off * HW)
             check(lib.dfe_bias_act_bwd2(sl(ysrc, y_off), ysrc.stride(0), sl(g1, g1_off), g1.stride(0),
                                         sl(g2, g2_off) if g2 is not None else None, g2.stride(0) if g2 is not None else 0,
-                                        ptr(gz), ptr(gb), ptr(part), B, c, H, W, slope, st), "dfe_bias_act_bwd2")
+                                        ptr(gz), None, ptr(part), B, c, H, W, slope, st), "dfe_bias_act_bwd2")
             return gz, gb
+
+        pending = []
 
         gw, gbias = [None] * 6, [None] * 6
         if g_flow is not None:
@@ -691,6 +694,12 @@ class DenseDecodeFn(torch.autograd.Function):
         gz, gbias[1] = epilogue_bwd(1, cat[1], 0, g1, 0, g0, co[0])                       # x1
         gx0, gw[1], _ = cb(gz, x0, w[1], True, nw(1))                                     # d/d x0 through conv_1
         gz, gbias[0] = epilogue_bwd(0, cat[0], 0, g0, 0, gx0, 0)                          # x0
+        if pending:
+            n = len(pending)
+            parts = (ctypes.c_void_p * n)(*[t[0].data_ptr() for t in pending])
+            outs = (ctypes.c_void_p * n)(*[t[1].data_ptr() for t in pending])
+            chans = (ctypes.c_int * n)(*[t[2] for t in pending])
+            check(lib.dfe_bias_grad_final_multi(parts, outs, chans, n, B, H, W, st), "dfe_bias_grad_final_multi")
         gx, gw[0], _ = cb(gz, x, w[0], bool(need[1]), nw(0))
         out = [None, gx]
         for k in range(6):
