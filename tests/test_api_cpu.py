@@ -466,6 +466,41 @@ def test_eight_point_properties():
     assert np.isfinite(noisy).all()
 
 
+def test_ransac_solvers_reject_gross_outliers():
+    """The robust half of SURVEY 8(f) rank 4 (model_geometry.py:473-566: cv2.findFundamentalMat(FM_RANSAC, 0.1, 0.99) /
+    FM_LMEDS, cv2.solvePnPRansac(reprojectionError=1)): with 30 % gross outliers among the matches the batched RANSAC
+    recovers F and the pose within 1e-2; the all-match least squares of round 3 does not."""
+    from unsupervised_depth_opticalflow_egomotion_amd.geometry_solvers import GeometrySolvers as GS
+    r = np.random.default_rng(5)
+    b, n = 2, 400
+    K = torch.tensor([[480.0, 0, 416], [0, 490, 128], [0, 0, 1]], dtype=torch.float64)
+    w = torch.from_numpy(0.06 * r.standard_normal((b, 3)))
+    T = torch.from_numpy(np.array([[0.5, 0.05, 0.1]]) + 0.1 * r.standard_normal((b, 3)))
+    R = GS._so3_exp(w)
+    X = torch.from_numpy(np.stack([r.uniform(-4, 4, (b, n)), r.uniform(-1.5, 1.5, (b, n)), r.uniform(4, 30, (b, n))], 2))
+    Y = X.bmm(R.transpose(1, 2)) + T.unsqueeze(1)
+    proj = lambda P: torch.stack([480 * P[:, :, 0] / P[:, :, 2] + 416, 490 * P[:, :, 1] / P[:, :, 2] + 128], 2)   # noqa: E731
+    x1, x2 = proj(X), proj(Y) + torch.from_numpy(0.02 * r.standard_normal((b, n, 2)))
+    no = int(0.3 * n)
+    x2[:, :no] += torch.from_numpy(r.uniform(-60, 60, (b, no, 2)))
+    matches = torch.cat([x1.transpose(1, 2), x2.transpose(1, 2)], 1).float()
+    tx = torch.zeros(b, 3, 3, dtype=torch.float64)
+    tx[:, 0, 1], tx[:, 0, 2], tx[:, 1, 0], tx[:, 1, 2], tx[:, 2, 0], tx[:, 2, 1] = -T[:, 2], T[:, 1], T[:, 2], -T[:, 0], -T[:, 1], T[:, 0]
+    Ft = torch.inverse(K).t().unsqueeze(0).matmul(tx.bmm(R)).matmul(torch.inverse(K).unsqueeze(0))
+    Ft = Ft / Ft[:, 2:3, 2:3]
+    rel = lambda A: float(((A.double() - Ft).abs().amax((1, 2)) / Ft.abs().amax((1, 2))).max())   # noqa: E731
+    m = GS()
+    assert rel(m.compute_fundmental_mat(matches)) <= 1e-2
+    assert rel(m.compute_fundmental_mat(matches, robust=False)) > 2e-2
+    m.dataset = "nyuv2"                    # cv2.FM_LMEDS
+    assert rel(m.compute_fundmental_mat(matches)) <= 1e-2
+    est = GS().pnp(x2.float(), X.float(), K.float())
+    assert float((est[:, :3].double() - T).abs().max()) <= 1e-2 and float((est[:, 3:].double() - w).abs().max()) <= 1e-2
+    lsq = GS().pnp(x2.float(), X.float(), K.float(), robust=False)
+    assert max(float((lsq[:, :3].double() - T).abs().max()), float((lsq[:, 3:].double() - w).abs().max())) > 2e-2
+    assert torch.equal(est, GS().pnp(x2.float(), X.float(), K.float()))      # seeded draw: reproducible
+
+
 def test_pnp_properties():
     """pnp (batched Levenberg-Marquardt on SE(3); stands in for cv2.solvePnPRansac + solvePnP): exact recovery of a known
     pose from noise-free 3-D / 2-D correspondences, from the identity and from a perturbed start, in the reference's

@@ -8,14 +8,19 @@
   model_geometry.py:569-683): closed-form, batched over B x N matches; pinned by golden G11 (the reference's own methods
   called unbound, like G5).
 * fundamental matrix from matches (``compute_fundmental_mat`` / ``compute_eight_point_loss``, model_geometry.py:532-566):
-  the reference calls ``cv2.findFundamentalMat`` (RANSAC / LMedS, on the host, one sample at a time; cv2 does not exist
-  here and RANSAC is not reproducible).  Here: Hartley's normalised eight-point algorithm over ALL given matches,
-  batched on the device (one 9x9 symmetric eigen-problem and one 3x3 SVD per sample), scaled like OpenCV's result
-  (F[2,2] = 1).  No oracle can exist for the RANSAC draw; property tests only (exact recovery on noise-free matches,
-  rank 2, invariance to the order of the matches).
-* perspective-n-point (``pnp`` / ``compute_pnp_loss``, model_geometry.py:473-530; the reference: ``cv2.solvePnPRansac`` +
-  ``cv2.solvePnP(ITERATIVE)`` per sample on the host): a batched Levenberg-Marquardt on SE(3) over all correspondences,
-  float64 inside, same (T, axis-angle) output convention; property tests only, for the same reason.
+  the reference calls ``cv2.findFundamentalMat(FM_RANSAC, 0.1, 0.99)`` (``FM_LMEDS, 0.99`` for nyuv2) on the host, one
+  sample at a time.  Here (round 4) the same robust estimate as ONE batched computation on the device: ``ransac_iters``
+  minimal sets of 8 matches per sample drawn from a seeded generator, one normalised eight-point solve per set (batched
+  SVDs), OpenCV's residual -- the larger of the two squared point-to-epipolar-line distances -- for all matches x all
+  hypotheses at once, consensus by inlier count at the reference's threshold (RANSAC) or by the median residual with
+  OpenCV's robust sigma (LMedS), then Hartley's normalised eight-point refit on the consensus set, rank 2 enforced,
+  scaled like OpenCV's result (F[2,2] = 1).  cv2 does not exist here and its RANSAC draw cannot be pinned: property
+  tests (exact recovery from noise-free matches, recovery within 1e-2 with 30 % gross outliers, rank 2).
+* perspective-n-point (``pnp`` / ``compute_pnp_loss``, model_geometry.py:473-530; the reference:
+  ``cv2.solvePnPRansac(confidence=0.9999, reprojectionError=1)`` + ``cv2.solvePnP(ITERATIVE, useExtrinsicGuess)`` per
+  sample on the host): batched RANSAC -- six-point DLT hypotheses, reprojection residuals of all correspondences, the
+  1-pixel consensus set -- then a Levenberg-Marquardt refinement on SE(3) over that set (float64 inside), same
+  (T, axis-angle) output convention; property tests (30 % gross outliers, pose within 1e-2).
 
 None of this is reached by ``Model_geometry.forward`` (the reference keeps the calls commented, :939-951); the methods
 exist so that those lines can be switched on as written."""
@@ -29,6 +34,8 @@ class GeometrySolvers:
     ratio = 0.3
     num = 6000
     dataset = "kitti_depth"
+    ransac_iters = 256          # hypotheses per sample (cv2's adaptive count is at most ~300 at its defaults for >= 50 % inliers)
+    ransac_seed = 0             # the draw is a function of (seed, batch shape): reproducible, unlike cv2's
 
     # ------------------------------------------------------------------ match sampling (model_geometry.py:427-470)
     def top_ratio_sample(self, match, depth, mask, ratio):
@@ -154,26 +161,100 @@ class GeometrySolvers:
         T[:, 2, 2] = 1.0
         return T
 
-    def compute_fundmental_mat(self, matches, pose_vec=None, intrinsics=None, intrinsics_inverse=None):
-        """F [b,3,3] with x2^T F x1 = 0 for matches [b,4,n] = (x1, y1, x2, y2): normalised eight-point over all n >= 8
-        matches (least squares), rank 2 enforced, scaled to F[2,2] = 1 like cv2.findFundamentalMat's result.  float64
-        inside (the 9x9 normal matrix squares the condition number)."""
-        m = matches.detach().double()
+    @staticmethod
+    def _weighted_hartley(xy, w):
+        """_hartley over the matches with weight 1 (w [b,n] in {0,1}; at least one per sample)."""
+        cnt = w.sum(1).clamp_min(1.0)
+        c = (xy * w.unsqueeze(1)).sum(2, keepdim=True) / cnt.view(-1, 1, 1)
+        d = (torch.sqrt(((xy - c) ** 2).sum(1)) * w).sum(1) / cnt
+        s = (2.0 ** 0.5) / (d + 1e-12)
+        T = torch.zeros(xy.shape[0], 3, 3, device=xy.device, dtype=xy.dtype)
+        T[:, 0, 0] = s
+        T[:, 1, 1] = s
+        T[:, 0, 2] = -s * c[:, 0, 0]
+        T[:, 1, 2] = -s * c[:, 1, 0]
+        T[:, 2, 2] = 1.0
+        return T
+
+    @classmethod
+    def _eight_point(cls, m, w=None):
+        """Normalised eight-point over the matches m [b,4,n] (float64) with 0/1 weights w [b,n]: least squares, rank 2
+        enforced, un-normalised; not yet scaled."""
         b, _, n = m.shape
-        if n < 8:
-            raise ValueError("the eight-point algorithm needs at least 8 matches")
+        if w is None:
+            w = torch.ones(b, n, device=m.device, dtype=m.dtype)
         ones = torch.ones(b, 1, n, device=m.device, dtype=m.dtype)
-        T1, T2 = self._hartley(m[:, :2]), self._hartley(m[:, 2:])
+        T1, T2 = cls._weighted_hartley(m[:, :2], w), cls._weighted_hartley(m[:, 2:], w)
         p1 = T1.bmm(torch.cat([m[:, :2], ones], 1))
         p2 = T2.bmm(torch.cat([m[:, 2:], ones], 1))
         A = (p2.unsqueeze(2) * p1.unsqueeze(1)).reshape(b, 9, n)        # row (i, j) = p2_i * p1_j
-        _, vecs = torch.linalg.eigh(A.bmm(A.transpose(1, 2)))           # ascending: column 0 = the null direction
+        _, vecs = torch.linalg.eigh((A * w.unsqueeze(1)).bmm(A.transpose(1, 2)))   # ascending: column 0 = the null direction
         Fn = vecs[:, :, 0].reshape(b, 3, 3)
         U, S, Vh = torch.linalg.svd(Fn)
         S = S.clone()
         S[:, 2] = 0.0
         Fn = U.bmm(torch.diag_embed(S)).bmm(Vh)
-        Fm = T2.transpose(1, 2).bmm(Fn).bmm(T1)
+        return T2.transpose(1, 2).bmm(Fn).bmm(T1)
+
+    @staticmethod
+    def _epipolar_residual(Fm, m):
+        """OpenCV's residual of findFundamentalMat (modules/calib3d/src/fundam.cpp computeError): the larger of the squared
+        distances of x2 to the line F x1 and of x1 to the line F^T x2.  Fm [b,h,3,3], m [b,4,n] -> [b,h,n]."""
+        b, _, n = m.shape
+        ones = torch.ones(b, 1, n, device=m.device, dtype=m.dtype)
+        x1 = torch.cat([m[:, :2], ones], 1).unsqueeze(1)                # [b,1,3,n]
+        x2 = torch.cat([m[:, 2:], ones], 1).unsqueeze(1)
+        l2 = Fm.matmul(x1)                                              # lines in image 2  [b,h,3,n]
+        l1 = Fm.transpose(2, 3).matmul(x2)                              # lines in image 1
+        num = (x2 * l2).sum(2)                                          # x2^T F x1        [b,h,n]
+        d2 = num * num / (l2[:, :, 0] ** 2 + l2[:, :, 1] ** 2 + 1e-300)
+        d1 = num * num / (l1[:, :, 0] ** 2 + l1[:, :, 1] ** 2 + 1e-300)
+        return torch.maximum(d1, d2)
+
+    def _minimal_sets(self, b, n, k, device):
+        """ransac_iters index sets of k matches per sample [b,h,k] from a generator seeded with ransac_seed (a set may
+        repeat an index: such a hypothesis is degenerate and simply loses the vote)."""
+        g = torch.Generator(device="cpu")
+        g.manual_seed(int(self.ransac_seed) + 1000003 * n + 7919 * k)
+        return torch.randint(0, n, (b, int(self.ransac_iters), k), generator=g).to(device)
+
+    def compute_fundmental_mat(self, matches, pose_vec=None, intrinsics=None, intrinsics_inverse=None, robust=True):
+        """F [b,3,3] with x2^T F x1 = 0 for matches [b,4,n] = (x1, y1, x2, y2), as cv2.findFundamentalMat returns it
+        (F[2,2] = 1): RANSAC at 0.1 px (LMedS for dataset 'nyuv2'), then the normalised eight-point refit on the
+        consensus set (model_geometry.py:532-543).  ``robust=False``: plain least squares over all matches.  float64
+        inside (the 9x9 normal matrix squares the condition number)."""
+        m = matches.detach().double()
+        b, _, n = m.shape
+        if n < 8:
+            raise ValueError("the eight-point algorithm needs at least 8 matches")
+        w = None
+        if robust and n > 8:
+            idx = self._minimal_sets(b, n, 8, m.device)                              # [b,h,8]
+            h = idx.shape[1]
+            sets = torch.gather(m.unsqueeze(1).expand(b, h, 4, n), 3, idx.unsqueeze(2).expand(b, h, 4, 8))
+            Fh = self._eight_point(sets.reshape(b * h, 4, 8)).reshape(b, h, 3, 3)
+            err = self._epipolar_residual(Fh, m)                                     # [b,h,n]
+            err = torch.where(torch.isfinite(err), err, torch.full_like(err, float("inf")))
+            if self.dataset == "nyuv2":            # cv2.FM_LMEDS: least median of the residuals, then OpenCV's robust sigma
+                med = err.median(dim=2)[0]                                           # [b,h]
+                best = med.argmin(1)
+                e = torch.gather(err, 1, best.view(b, 1, 1).expand(b, 1, n)).squeeze(1)
+                sigma = 2.5 * 1.4826 * (1.0 + 5.0 / max(n - 8, 1)) * torch.sqrt(torch.gather(med, 1, best.view(b, 1)).clamp_min(0.0))
+                w = (e <= (sigma * sigma).clamp_min(1e-12)).double()
+            else:                                  # cv2.FM_RANSAC, ransacReprojThreshold = 0.1
+                inl = err <= 0.1 * 0.1
+                best = inl.sum(2).argmax(1)
+                w = torch.gather(inl, 1, best.view(b, 1, 1).expand(b, 1, n)).squeeze(1).double()
+            few = w.sum(1) < 8                                                       # no consensus: fall back to all matches
+            w = torch.where(few.unsqueeze(1), torch.ones_like(w), w)
+        Fm = self._eight_point(m, w)
+        if w is not None:      # one more pass: the consensus set of the refit (cv2 refits on its inliers once; this is that set)
+            e = self._epipolar_residual(Fm.unsqueeze(1), m).squeeze(1)
+            thr = 0.1 * 0.1 if self.dataset != "nyuv2" else None
+            if thr is not None:
+                w2 = (e <= thr).double()
+                w2 = torch.where((w2.sum(1) < 8).unsqueeze(1), w, w2)
+                Fm = self._eight_point(m, w2)
         Fm = Fm / Fm[:, 2:3, 2:3]
         return Fm.to(matches.dtype)
 
@@ -205,27 +286,82 @@ class GeometrySolvers:
         k = torch.where(th > 1e-6, th / torch.sin(th).clamp_min(1e-30), 1.0 + th * th / 6.0)
         return v * k.unsqueeze(1)
 
-    def pnp(self, pts2d, pts3d, K, ini_pose=None, iterations=20):
+    def _pnp_hypotheses(self, x, X, Kd):
+        """Six-point DLT poses for ransac_iters minimal sets per sample: x [b,n,2] pixels, X [b,n,3] points, float64 ->
+        R [b,h,3,3], T [b,h,3] (R projected onto SO(3), the scale taken from its singular values, the sign from det)."""
+        b, n = X.shape[0], X.shape[1]
+        idx = self._minimal_sets(b, n, 6, X.device)                                   # [b,h,6]
+        h = idx.shape[1]
+        Xs = torch.gather(X.unsqueeze(1).expand(b, h, n, 3), 2, idx.unsqueeze(3).expand(b, h, 6, 3))
+        xs = torch.gather(x.unsqueeze(1).expand(b, h, n, 2), 2, idx.unsqueeze(3).expand(b, h, 6, 2))
+        Kinv = torch.inverse(Kd)
+        ones = torch.ones(b, h, 6, 1, dtype=X.dtype, device=X.device)
+        xn = torch.cat([xs, ones], 3).matmul(Kinv.t())                                # normalised image coordinates
+        Xh = torch.cat([Xs, ones], 3)                                                 # [b,h,6,4]
+        zero = torch.zeros_like(Xh)
+        A = torch.cat([torch.cat([Xh, zero, -xn[..., 0:1] * Xh], 3), torch.cat([zero, Xh, -xn[..., 1:2] * Xh], 3)], 2)   # [b,h,12,12]
+        _, _, Vh = torch.linalg.svd(A)
+        P = Vh[..., -1, :].reshape(b, h, 3, 4)
+        U, S, Wh = torch.linalg.svd(P[..., :3])
+        det = torch.det(U.matmul(Wh))
+        sign = torch.where(det < 0, -torch.ones_like(det), torch.ones_like(det))
+        R = U.matmul(Wh) * sign.view(b, h, 1, 1)
+        T = P[..., 3] * (sign / S.mean(-1).clamp_min(1e-300)).unsqueeze(-1)
+        return R, T
+
+    def pnp(self, pts2d, pts3d, K, ini_pose=None, iterations=20, robust=True):
         """Pose [b,6] = (T, axis-angle) minimising the reprojection error of pts3d [b,n,3] onto pts2d [b,n,2] under the
         single camera matrix K [3,3] -- the output convention of the reference's ``pnp`` (model_geometry.py:473-495), which
-        runs cv2.solvePnPRansac + an iterative refinement per sample on the host.  Here: Levenberg-Marquardt on SE(3) over
-        ALL correspondences (no RANSAC: cv2 is absent and a random consensus cannot be pinned), batched on the device in
-        float64, started from ``ini_pose`` (axis-angle first, then T, as the reference reads it) or the identity."""
+        runs cv2.solvePnPRansac(confidence=0.9999, reprojectionError=1) + an iterative refinement per sample on the host.
+        Here, batched on the device in float64: RANSAC (six-point DLT hypotheses, 1-pixel consensus) unless ``ini_pose``
+        is given (axis-angle first, then T, as the reference reads it) or ``robust=False``, then Levenberg-Marquardt on
+        SE(3) over the consensus set (the reference refines over all points from the RANSAC pose; with gross outliers
+        that undoes the RANSAC, so the refinement here is weighted by the consensus and re-scored once)."""
         X = pts3d.detach().double()
         x = pts2d.detach().double()
         Kd = K.detach().double()
         b, n = X.shape[0], X.shape[1]
         fx, fy, cx, cy = Kd[0, 0], Kd[1, 1], Kd[0, 2], Kd[1, 2]
-        if ini_pose is None:
+        wgt = torch.ones(b, n, dtype=X.dtype, device=X.device)
+        use_ransac = robust and ini_pose is None and n > 6
+        if use_ransac:
+            Rh, Th = self._pnp_hypotheses(x, X, Kd)                                   # [b,h,3,3], [b,h,3]
+            Yh = X.unsqueeze(1).matmul(Rh.transpose(2, 3)) + Th.unsqueeze(2)          # [b,h,n,3]
+            zh = Yh[..., 2]
+            eu = fx * Yh[..., 0] / zh.clamp_min(1e-9) + cx - x[:, :, 0].unsqueeze(1)
+            ev = fy * Yh[..., 1] / zh.clamp_min(1e-9) + cy - x[:, :, 1].unsqueeze(1)
+            inl = ((eu * eu + ev * ev) <= 1.0) & (zh > 0)                            # reprojectionError = 1 pixel
+            best = inl.sum(2).argmax(1)
+            R = torch.gather(Rh, 1, best.view(b, 1, 1, 1).expand(b, 1, 3, 3)).squeeze(1)
+            T = torch.gather(Th, 1, best.view(b, 1, 1).expand(b, 1, 3)).squeeze(1)
+            wgt = torch.gather(inl, 1, best.view(b, 1, 1).expand(b, 1, n)).squeeze(1).double()
+            wgt = torch.where((wgt.sum(1) < 6).unsqueeze(1), torch.ones_like(wgt), wgt)
+        elif ini_pose is None:
             R = torch.eye(3, dtype=X.dtype, device=X.device).unsqueeze(0).repeat(b, 1, 1)
             T = torch.zeros(b, 3, dtype=X.dtype, device=X.device)
         else:
             R, T = self._so3_exp(ini_pose[:, 0:3].detach().double()), ini_pose[:, 3:6].detach().double().clone()
+        R, T = self._pnp_refine(X, x, (fx, fy, cx, cy), R, T, wgt, iterations)
+        if use_ransac:       # the consensus set of the refined pose, and one more refinement on it
+            Y = X.bmm(R.transpose(1, 2)) + T.unsqueeze(1)
+            z = Y[:, :, 2]
+            eu = fx * Y[:, :, 0] / z.clamp_min(1e-9) + cx - x[:, :, 0]
+            ev = fy * Y[:, :, 1] / z.clamp_min(1e-9) + cy - x[:, :, 1]
+            w2 = (((eu * eu + ev * ev) <= 1.0) & (z > 0)).double()
+            w2 = torch.where((w2.sum(1) < 6).unsqueeze(1), wgt, w2)
+            R, T = self._pnp_refine(X, x, (fx, fy, cx, cy), R, T, w2, max(iterations // 2, 1))
+        return torch.cat([T, self._so3_log(R)], 1).to(pts2d.dtype)
+
+    def _pnp_refine(self, X, x, cam, R, T, wgt, iterations):
+        """Levenberg-Marquardt on SE(3) over the correspondences with weight 1 (wgt [b,n])."""
+        fx, fy, cx, cy = cam
+        b, n = X.shape[0], X.shape[1]
+        sw = wgt.unsqueeze(2)
 
         def residual(R, T):
             Y = X.bmm(R.transpose(1, 2)) + T.unsqueeze(1)
             z = Y[:, :, 2].clamp_min(1e-9)
-            r = torch.stack([fx * Y[:, :, 0] / z + cx - x[:, :, 0], fy * Y[:, :, 1] / z + cy - x[:, :, 1]], 2)
+            r = torch.stack([fx * Y[:, :, 0] / z + cx - x[:, :, 0], fy * Y[:, :, 1] / z + cy - x[:, :, 1]], 2) * sw
             return Y, z, r
         lam = torch.full((b, 1, 1), 1e-3, dtype=X.dtype, device=X.device)
         Y, z, r = residual(R, T)
@@ -239,8 +375,8 @@ class GeometrySolvers:
             P = Y - T.unsqueeze(1)
             zero = torch.zeros_like(zi)
             Pc = torch.stack([zero, -P[:, :, 2], P[:, :, 1], P[:, :, 2], zero, -P[:, :, 0], -P[:, :, 1], P[:, :, 0], zero], 2).view(b, n, 3, 3)
-            Ju = torch.cat([-(du.unsqueeze(2) @ Pc).squeeze(2), du], 2)          # [b,n,6]
-            Jv = torch.cat([-(dv.unsqueeze(2) @ Pc).squeeze(2), dv], 2)
+            Ju = torch.cat([-(du.unsqueeze(2) @ Pc).squeeze(2), du], 2) * sw     # [b,n,6]
+            Jv = torch.cat([-(dv.unsqueeze(2) @ Pc).squeeze(2), dv], 2) * sw
             J = torch.cat([Ju, Jv], 1)                                           # [b,2n,6]
             rr = torch.cat([r[:, :, 0], r[:, :, 1]], 1).unsqueeze(2)             # [b,2n,1]
             H = J.transpose(1, 2).bmm(J)
@@ -255,7 +391,7 @@ class GeometrySolvers:
             Y, z, r = torch.where(m3, Yn, Y), torch.where(m1, zn, z), torch.where(m3, rn, r)
             cost = torch.where(ok, cn, cost)
             lam = torch.where(m3, lam * 0.3, lam * 5.0).clamp(1e-9, 1e6)
-        return torch.cat([T, self._so3_log(R)], 1).to(pts2d.dtype)
+        return R, T
 
     def compute_pnp_loss(self, depth, matches, pose_vec, K, K_inv):
         """model_geometry.py:498-530: back-project the first view's matched pixels with their depth, solve the pose that
