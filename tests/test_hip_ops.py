@@ -365,6 +365,34 @@ def test_corr_oracle(shape):
     gclose(b.grad, bo.grad)
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (2, 3, 2, 3), (1, 5, 3, 70), (1, 8, 5, 67), (3, 17, 9, 33), (2, 7, 12, 260), (1, 40, 6, 4)])
+def test_corr_ragged_shapes(shape):
+    """The LDS-staged correlation kernels (csrc/ops_corr.hip) on shapes no PWC level has: single pixels, widths below one
+    quad, widths that are not multiples of 4 (the dword staging path), more than one tile across (W > 64), channel counts
+    below the channel split and not multiples of the backward's 8-channel groups -- forward and both gradients against the
+    oracle's corr_naive on the host, each gradient also requested alone (one-sided launches)."""
+    from unsupervised_depth_opticalflow_egomotion_amd.ops import corr81
+    r = MG.rng(77)
+    f1 = r.standard_normal(shape).astype(np.float32)
+    f2 = r.standard_normal(shape).astype(np.float32)
+    wgt = r.standard_normal((shape[0], 81, shape[2], shape[3])).astype(np.float32)
+    ao, bo = T(f1, True), T(f2, True)
+    co = O.corr_naive(ao, bo)
+    (co * T(wgt)).sum().backward()
+    a, b = G(f1, True), G(f2, True)
+    cv = corr81(a, b)
+    (cv * G(wgt)).sum().backward()
+    close(cv, co, atol=1e-5)
+    gclose(a.grad, ao.grad)
+    gclose(b.grad, bo.grad)
+    a1 = G(f1, True)
+    (corr81(a1, G(f2)) * G(wgt)).sum().backward()
+    gclose(a1.grad, ao.grad)          # (the one-sided launch may pick another tiling: same sums, another order)
+    b1 = G(f2, True)
+    (corr81(G(f1), b1) * G(wgt)).sum().backward()
+    gclose(b1.grad, bo.grad)
+
+
 @pytest.mark.parametrize("shape", [(3, 64, 128, 416), (2, 5, 37, 131), (1, 3, 8, 9), (2, 2, 1, 1), (1, 4, 2, 130)])
 def test_stem_maxpool_is_aten_bit_for_bit(shape):
     """ops.maxpool3x3s2 (ResNet stem, depth_model.py:60-95) against F.max_pool2d(x, 3, 2, 1) on the host: values and
