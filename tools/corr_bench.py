@@ -105,7 +105,11 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--only-corr", action="store_true")
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--lib", default="", help="another build of libdfe_hip.so (tools/corr_ablate.sh) instead of the in-tree one")
     a = ap.parse_args()
+    if a.lib:
+        from unsupervised_depth_opticalflow_egomotion_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(a.lib)
     B = a.batch
     if a.sweep:
         lib = get_lib()

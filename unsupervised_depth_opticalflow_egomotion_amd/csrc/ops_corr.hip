@@ -31,6 +31,11 @@
 #include <cstdio>
 #include <cstdlib>
 
+// DFE_CORR_ABL (debug builds of tools/corr_ablate.sh only): 1 = no output stores, 2 = no FMAs, 4 = no staging loads
+#ifndef DFE_CORR_ABL
+#define DFE_CORR_ABL 0
+#endif
+
 namespace dfe {
 
 namespace {
@@ -157,6 +162,7 @@ k_corr_fwd_lds(const float* __restrict__ f1, const float* __restrict__ f2, float
     const bool ok = off >= 0 && cl < C - c0;
     const float* p = base + (ok ? static_cast<long>(c0) * HW + off : 0);
     float4 v;
+    if (DFE_CORR_ABL & 4) return make_float4(1.f, 2.f, 3.f, static_cast<float>(off));
     if (VEC) v = *reinterpret_cast<const float4*>(p);           // W % 4 == 0: a quad is inside or outside as a whole
     else v = load_quad_right(p, ok ? gx : 0, W);
     return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -211,6 +217,7 @@ k_corr_fwd_lds(const float* __restrict__ f1, const float* __restrict__ f2, float
         w0 = *reinterpret_cast<const float4*>(s2 + mn * st2);
         w1 = *reinterpret_cast<const float4*>(s2 + mn * st2 + 4);
         w2 = *reinterpret_cast<const float4*>(s2 + mn * st2 + 8);
+        if (DFE_CORR_ABL & 2) { acc[0][0] += a[0] + a[1] + a[2] + a[3] + w[0] + w[4] + w[8] + w[11]; continue; }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -225,6 +232,7 @@ k_corr_fwd_lds(const float* __restrict__ f1, const float* __restrict__ f2, float
   float* o = out + static_cast<long>(b) * obs + static_cast<long>(dy * CR_K) * HW + static_cast<long>(y) * W + x0;   // obs: batch stride of out (the 81 planes may be a slice of a wider tensor)
   const bool live = worker && y < H && x0 < W;
   if (g.KS == 1) {
+    if ((DFE_CORR_ABL & 1) && acc[0][0] != 12345.678f) return;
     if (live) {
 #pragma unroll
       for (int j = 0; j < CR_K; ++j) {
