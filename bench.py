@@ -368,16 +368,21 @@ def cpu_baseline(wl, args, unit_pairs):
     torch.set_num_threads(threads)
     run = wl.cpu_step_fn(threads)
     run()                       # warm-up (allocator, thread pool)
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        run(); n += 1
-        if time.perf_counter() - t0 > 15.0 or n >= 3:
+    # median of up to 5 timed steps (the mean of 3 moved +-20 % between samples), bounded at ~30 s of CPU work
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 5:
+        t0 = time.perf_counter()
+        run()
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > 30.0 and len(times) >= 3:
             break
-    dt = (time.perf_counter() - t0) / n
+    times.sort()
+    n = len(times)
+    dt = times[n // 2] if n % 2 else 0.5 * (times[n // 2 - 1] + times[n // 2])
     return {"value": round(unit_pairs / dt, 4), "unit": "frame-pairs/s", "cores": threads, "cpu_model": cpu_model(),
             "host_cores": os.cpu_count(), "kind": "port",
-            "sample": "%d timed step(s) of the same workload (%s, B=%d, %dx%d, S=%d, fwd+bwd%s) on the host CPU, %.2f s/step"
+            "sample": "median of %d timed step(s) of the same workload (%s, B=%d, %dx%d, S=%d, fwd+bwd%s) on the host CPU, %.2f s/step"
                       % (n, wl.name, args.batch, args.height, args.width, args.scales,
                          "+Adam" if wl.name == "train_step" else "", dt)}
 

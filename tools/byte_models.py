@@ -32,6 +32,25 @@ def models(B, H, W, S, mode="geom"):
                                     "3 frames per full-res px: image 12 + disp 4 + up-sampled rows ~2; write grad_disp0 4 + up-sampled grads 4(S-1)"),
         "k_geom_disp_smooth_bwd2": (3 * B * (4 * (S - 1) * N0 + 4 * NL), "read the up-sampled grads once, write grad_disp of levels >= 1"),
     }
+    # adjoint of the bilinear up-sampling in two passes (round 4, loss_stack_bwd.hip k_geom_adj_rows / k_geom_adj_cols): every
+    # level >= 1 for generic sizes, the levels coarser than 1/4 where levels 1-2 are exact (the register gather keeps those)
+    Hs, Ws = [int(H / 2 ** s) for s in range(S)], [int(W / 2 ** s) for s in range(S)]
+    exact = all((Hs[s] << s) == H and (Ws[s] << s) == W for s in range(1, min(S, 3)))
+    s0 = 1
+    if exact:
+        while s0 < S and H <= 4 * Hs[s0] and W <= 4 * Ws[s0]:
+            s0 += 1
+    if s0 < S:
+        seg = 0
+        for s in range(s0, S):
+            L = max(1, min(32, int(6.0 * H / Hs[s])))
+            seg += ((H + L - 1) // L) * 8 * W          # partial-sum floats per (frame, sample) of this level
+        m["k_geom_adj_rows"] = (3 * B * 4 * ((S - s0) * N0 + seg), "read the up-sampled gradients of the levels >= %d once (4 B per full-res px and level), write the per-segment column sums" % s0)
+        m["k_geom_adj_cols"] = (3 * B * 4 * (seg + sum(N[s0:])), "read the segment sums once, write grad_disp of the levels >= %d" % s0)
+        if s0 == 1:
+            m.pop("k_geom_disp_smooth_bwd2", None)
+        else:
+            m["k_geom_disp_smooth_bwd2"] = (3 * B * (4 * (s0 - 1) * N0 + 4 * sum(N[1:s0])), "read the up-sampled grads of levels 1..%d once, write their grad_disp" % (s0 - 1))
     return m
 
 

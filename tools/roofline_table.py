@@ -101,6 +101,7 @@ if "pmc_bytes" in e:
                "kernel": "k_geom_point_fwd", "kernel_source_sha256": h.hexdigest(),
                "workload": {"batch": B, "height": H, "width": W, "scales": S},
                "FETCH_SIZE_KB": e["FETCH_SIZE_KB"], "WRITE_SIZE_KB": e["WRITE_SIZE_KB"], "hbm_bytes_per_launch": e["pmc_bytes"],
+               "waves": e.get("waves"), "valu_per_wave": e.get("valu_per_wave"),
                "algorithmic_bytes_per_launch": e.get("algorithmic_bytes"), "source": TAG + "_pmc_loss_stack.json"},
               open(os.path.join(OUT, TAG + "_pmc_point_fwd_traffic.json"), "w"), indent=1)
 print(open(os.path.join(OUT, TAG + "_roofline_table.md")).read())
