@@ -466,6 +466,27 @@ def test_eight_point_properties():
     assert np.isfinite(noisy).all()
 
 
+def test_kitti_pose_snippets_are_rgb_like_the_reference_loader(tmp_path):
+    """The reference's odometry loader reads frames with imageio (RGB, core/dataset/kitti_pose.py:6,18) while its flow and
+    depth loaders use cv2 (BGR): KITTIPoseSnippets must hand infer_pose RGB frames."""
+    from PIL import Image
+    from unsupervised_depth_opticalflow_egomotion_amd import kitti_io
+    root = tmp_path / "odom"
+    (root / "sequences" / "09" / "image_2").mkdir(parents=True)
+    (root / "poses").mkdir()
+    rgb = np.zeros((4, 6, 3), np.uint8)
+    rgb[..., 0], rgb[..., 1], rgb[..., 2] = 200, 100, 50
+    for i in range(3):
+        Image.fromarray(rgb).save(str(root / "sequences" / "09" / "image_2" / ("%06d.png" % i)))
+    eye = np.hstack([np.eye(3), np.zeros((3, 1))]).reshape(-1)
+    np.savetxt(str(root / "poses" / "09.txt"), np.stack([eye, eye, eye]))
+    ds = kitti_io.KITTIPoseSnippets(str(root), ["09"], 3)
+    assert len(ds) == 1
+    img = ds[0]["imgs"][0]
+    assert img.dtype == np.uint8 and tuple(img[0, 0]) == (200, 100, 50)                       # R, G, B
+    assert tuple(kitti_io.read_image_bgr(str(root / "sequences" / "09" / "image_2" / "000000.png"))[0, 0]) == (50, 100, 200)
+
+
 def test_ransac_solvers_reject_gross_outliers():
     """The robust half of SURVEY 8(f) rank 4 (model_geometry.py:473-566: cv2.findFundamentalMat(FM_RANSAC, 0.1, 0.99) /
     FM_LMEDS, cv2.solvePnPRansac(reprojectionError=1)): with 30 % gross outliers among the matches the batched RANSAC

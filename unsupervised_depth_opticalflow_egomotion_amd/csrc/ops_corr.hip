@@ -12,9 +12,11 @@
 // image, double-buffered: the next chunk's loads are in flight while this one is multiplied), then every thread
 // (displacement row dy, tile row, quad of 4 pixels) reads one f1 quad + its 12-wide f2 window (4 ds_read_b128) per
 // channel and issues 36 FMAs.  Each input byte crosses the fabric ~once per tile (halo re-reads stay inside the XCD's
-// L2: tiles are dealt in XCD order), 9 FMAs per LDS read keep the LDS array < 50 % busy.  Bound (level 2, C = 32):
-// 4.3 M wave-FMAs = 7.0 us of VALU issue against 7.7 us of HBM time -- no MFMA: the fp32 matrix pipe has 2x the
-// VALU's FMA rate but a banded 16x16 Gram tile uses 28 % of it (9 of 32 diagonals), and exact fp32 sums are kept.
+// L2: tiles are dealt in XCD order), 9 FMAs per LDS read keep the LDS array ~25 % busy.  No MFMA: a banded 16x16 Gram tile
+// uses 28 % of the matrix pipe (9 of 32 diagonals) while a wave-wide fp32 FMA issues every ~2.5 cycles, and exact fp32
+// sums in channel order are kept.  Measured (level 2, C = 32, B = 8: 61.8 MB in 21.0 us = 0.37 of the HBM peak, PMC /
+// algorithmic 1.00; tools/corr_ablate.sh): the FMAs are free (20.5 us without them); the launch is one round of 512
+// blocks in lockstep -- read burst, LDS pipeline, 34.5 MB write burst back to back.
 // Coarse levels (16x52 ... 4x13: fewer pixels than the chip has lanes): the channel sum is split over KS threads per
 // output and the partials meet in LDS in fixed order (deterministic).
 //

@@ -68,10 +68,21 @@ def wrap(model, device=None, bucket_cap_mb=25, force=False):
         return model
     from torch.nn.parallel import DistributedDataParallel as DDP
     DDP._set_params_and_buffers_to_ignore_for_model(model, unused_parameter_names(model))
+    # static_graph: the set of parameters that receive a gradient never changes (the ignored fc pair aside), so the
+    #   reducer can skip its per-iteration bookkeeping.  broadcast_buffers=False: the only buffers are BatchNorm's running
+    #   statistics; train-mode forwards do not read them, rank 0's are what checkpoints hold either way (the reference's
+    #   DataParallel keeps device 0's and discards the replicas', train.py:59-60), so the per-forward broadcast buys
+    #   nothing.  Measured at world size 1 on MI355X (bench.py --force-ddp, plain step 25.3 ms): DDP defaults 28.4 ms,
+    #   static_graph 26.9, both 26.5 (profiles/r04_ddp_overhead.txt).
+    # DFE_DDP_OPTS: experiment switches, e.g. "broadcast_buffers=1,static_graph=0,bucket_cap_mb=100"
+    kw = dict(bucket_cap_mb=bucket_cap_mb, static_graph=True, broadcast_buffers=False)
+    for item in filter(None, os.environ.get("DFE_DDP_OPTS", "").split(",")):
+        k, v = item.split("=")
+        kw[k] = float(v) if k == "bucket_cap_mb" else bool(int(v))
     if device is not None and device.type == "cuda":
-        return DDP(model, device_ids=[device.index], output_device=device.index, bucket_cap_mb=bucket_cap_mb,
-                   gradient_as_bucket_view=True)
-    return DDP(model, bucket_cap_mb=bucket_cap_mb)
+        kw.setdefault("gradient_as_bucket_view", True)
+        return DDP(model, device_ids=[device.index], output_device=device.index, **kw)
+    return DDP(model, **kw)
 
 
 def shard_indices(n, world, rank):

@@ -173,6 +173,14 @@ def read_image_bgr(path: str) -> np.ndarray:
     return np.ascontiguousarray(rgb[:, :, ::-1])
 
 
+def read_image_rgb(path: str) -> np.ndarray:
+    """imageio.imread(path): uint8 [H,W,3] in R, G, B order -- what the reference's odometry loader feeds infer_pose
+    (core/dataset/kitti_pose.py:6,18), unlike its cv2-based flow / depth loaders."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.ascontiguousarray(np.asarray(im.convert("RGB")))
+
+
 def resize_bilinear_u8(img: np.ndarray, out_hw) -> np.ndarray:
     """cv2.resize(img, (W, H), INTER_LINEAR) for uint8 / float [h,w,C]: half-pixel centres, edge replication, no
     antialiasing; float32 result (not rounded back to uint8)."""
@@ -257,7 +265,8 @@ def read_odometry_poses(path: str) -> np.ndarray:
 
 class KITTIPoseSnippets:
     """core/dataset (KITTI_pose, test.py:137-139): 3-frame snippets of the odometry sequences with their ground-truth
-    poses expressed relative to the first frame of the snippet.  ``ds[j] -> {'imgs': [3 x uint8 HxWx3 BGR], 'poses': [3,3,4]}``."""
+    poses expressed relative to the first frame of the snippet.  ``ds[j] -> {'imgs': [3 x uint8 HxWx3 RGB], 'poses': [3,3,4]}``
+    -- RGB: the reference reads these frames with imageio (kitti_pose.py:18), not with cv2."""
 
     def __init__(self, root: str, sequences, seq_length: int = 3):
         self.samples = []
@@ -279,7 +288,7 @@ class KITTIPoseSnippets:
         first = np.vstack([poses[0], [0, 0, 0, 1]])
         inv = np.linalg.inv(first)
         rel = np.stack([(inv @ np.vstack([p, [0, 0, 0, 1]]))[:3] for p in poses])
-        return {"imgs": [read_image_bgr(p) for p in paths], "poses": rel}
+        return {"imgs": [read_image_rgb(p) for p in paths], "poses": rel}
 
 
 def compute_pose_error(gt: np.ndarray, pred: np.ndarray):
