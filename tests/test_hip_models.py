@@ -404,6 +404,51 @@ def test_network_streams_do_not_change_results():
     np.testing.assert_allclose(l3, l1, rtol=1e-4)
 
 
+def test_network_streams_stress_many_forward_backward_passes_with_a_churning_allocator():
+    """Stress form of the stream test (a missing wait_stream that bites one run in twenty passes a
+    three-step comparison).  ONE model, fixed weights, 24 forward + backward passes on three streams; between passes the
+    caching allocator is churned (random-sized scratch tensors allocated and freed on the main stream, so the blocks the
+    side streams get differ from pass to pass) and every fourth pass the streams are given unrelated work to run ahead
+    of.  Every pass must reproduce the single-stream gradient of the same weights within the yardstick of the test
+    above -- 4x the single-stream run-to-run noise or 1e-3 of the gradient scale; a stale or half-written tensor shows up
+    at O(1) -- and every loss to 1e-5."""
+    from unsupervised_depth_opticalflow_egomotion_amd.train_step import make_cfg, total_loss
+    from unsupervised_depth_opticalflow_egomotion_amd.models import get_model
+    cfg = make_cfg()
+    torch.manual_seed(0)
+    model = get_model("geom")(cfg).to(dev()).train()
+    inputs = [torch.from_numpy(a).to(dev()) for a in synthetic.make_triplet_batch(2, 256, 832, 3, seed=1)]
+    bn_state = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k or "num_batches" in k}
+
+    def one_pass(streams):
+        model.load_state_dict(bn_state, strict=False)          # the running statistics are the only state a pass changes
+        model.net_streams = streams
+        for p in model.parameters():
+            p.grad = None
+        lp, _ = model(inputs)
+        loss = total_loss(lp, cfg)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
+    l_ref, g_ref = one_pass(1)
+    _, g_ref2 = one_pass(1)
+    scale, noise = float(g_ref.abs().max()), float((g_ref2 - g_ref).abs().max())
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    worst = 0.0
+    for it in range(24):
+        junk = [torch.empty(int(torch.randint(1 << 10, 1 << 24, (1,), generator=gen)), device=dev()) for _ in range(int(torch.randint(1, 6, (1,), generator=gen)))]
+        if it % 4 == 3:                  # unrelated work queued on the main stream: the side streams must still wait for their inputs
+            big = torch.randn(4096, 4096, device=dev())
+            for _ in range(3):
+                big = big @ big * 1e-4
+        del junk
+        loss, g = one_pass(3)
+        assert abs(loss - l_ref) <= 1e-5 * abs(l_ref), (it, loss, l_ref)
+        worst = max(worst, float((g - g_ref).abs().max()))
+    print("\nstream stress: grad scale %.3e, single-stream noise %.3e, worst of 24 three-stream passes %.3e" % (scale, noise, worst))
+    assert worst <= max(4.0 * noise, 1e-3 * scale), (worst, noise, scale)
+
+
 def test_amp_bf16_mode_is_opt_in_and_close_to_fp32():
     """convs.compute_dtype(torch.bfloat16) (train.py / bench.py --amp bf16): the convolutions run in bf16, everything else
     in fp32.  Off by default; the first step's loss stays within 2 % of fp32's (bf16 has 8 significant bits, the loss is
