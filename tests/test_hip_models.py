@@ -376,7 +376,7 @@ def _three_steps(net_streams=1, amp=None, B=2):
 def test_network_streams_do_not_change_results():
     """Model_geometry.run_networks with the flow / pose nets on side streams (net_streams = 3) runs the same kernels in the
     same order inside every net.  The step is not bitwise reproducible even on one stream: MIOpen's split-K weight gradients
-    and warp_flow's feature-gradient scatter use float atomics (1e-7 .. 1e-5 of the gradient scale), and MIOpen falls back to
+    use float atomics (1e-7 .. 1e-5 of the gradient scale; this build's own scatters are 64-bit fixed-point and reproducible), and MIOpen falls back to
     another solver for a layer when the workspace the allocator happens to hand it is too small ("IsEnoughWorkspace"
     warnings; 1e-4 .. 1e-3: two single-stream runs of one process have differed by 2.7e-4).  The yardstick is therefore
     the larger of the single-stream run-to-run difference and 1e-3 of the gradient scale -- a missing synchronisation

@@ -418,7 +418,7 @@ def test_stem_maxpool_is_aten_bit_for_bit(shape):
 @pytest.mark.parametrize("shape", [(2, 128, 8, 26), (2, 96, 16, 52), (3, 32, 64, 208), (1, 20, 7, 10)])
 def test_pwc_level_input(shape):
     """One PWC decoder level's input (pwc_tf.py:119-121) as one operator: equal to the composition of the per-op HIP
-    operators (forward bit for bit; g_c1 / g_flow bit for bit -- two-term sums; g_c2 is an atomic scatter) and to the
+    operators (forward bit for bit; g_c1 / g_flow bit for bit -- two-term sums; g_c2 is a 64-bit fixed-point integer scatter: reproducible, held to the gradient tolerance here) and to the
     oracle's warp_flow + corr_naive + cat on the host."""
     from unsupervised_depth_opticalflow_egomotion_amd.ops import corr81, pwc_level_input, warp_flow
     B, C, H, W = shape
