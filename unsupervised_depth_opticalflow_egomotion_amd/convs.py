@@ -29,10 +29,32 @@ miopen_tuning.activate()      # before the first convolution: MIOpen reads MIOPE
 
 _STATE = {"dtype": None}
 
+# Reduced-precision mode, measured in round 4 and NOT adopted (DFE_AMP_NHWC=1 switches it on): the operands go to MIOpen
+# as CHANNELS-LAST tensors (one ATen cast + permute kernel each way instead of a cast followed by MIOpen's own NCHW -> NHWC
+# transposes: its bf16 kernels are all NHWC implicit GEMMs) with PYTORCH_MIOPEN_SUGGEST_NHWC=1.  The convolutions themselves
+# run ~25 % faster that way (tools/nhwc_probe.py), but ATen's strided cast + permute kernels cost more than the pair they
+# replace: 24.2 / 24.5 ms per step against 21.6 / 25.2 with NCHW casts (same box, bench.py --amp bf16).  The mode pays only
+# when activations stay bf16 channels-last between the convolutions.
+_AMP_NHWC = os.environ.get("DFE_AMP_NHWC", "0") == "1"
+
+
+def _low(t, dt):
+    """fp32 NCHW -> compute dtype (channels-last when _AMP_NHWC and 4-d)."""
+    if _AMP_NHWC and t.dim() == 4:
+        return t.to(dt, memory_format=torch.channels_last)
+    return t.to(dt)
+
+
+def _high(t):
+    """compute dtype (any layout) -> fp32 NCHW contiguous: what every glue kernel of this build takes."""
+    return None if t is None else t.to(torch.float32, memory_format=torch.contiguous_format)
+
 
 def set_compute_dtype(dtype):
     if dtype not in (None, torch.bfloat16, torch.float16):
         raise ValueError("compute dtype must be None (fp32), torch.bfloat16 or torch.float16")
+    if dtype is not None and _AMP_NHWC:
+        os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")      # read by ATen's MIOpen wrapper; fp32 calls pass NCHW tensors and are not affected
     _STATE["dtype"] = dtype
 
 
@@ -62,7 +84,7 @@ def raw_forward(x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1)):
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
     dt = _STATE["dtype"]
     if dt is not None:
-        return F.conv2d(x.to(dt), w.to(dt), None, stride, padding, dilation).float()
+        return _high(F.conv2d(_low(x, dt), _low(w, dt), None, stride, padding, dilation))
     return F.conv2d(x, w, None, stride, padding, dilation)
 
 
@@ -72,10 +94,9 @@ def raw_backward(gy, x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1), want_
     dt = _STATE["dtype"]
     bias_sizes = [int(w.shape[0])] if want_b else None
     if dt is not None:
-        gx, gw, gb = _cb(gy.to(dt), x.to(dt), w.to(dt), bias_sizes, list(stride), list(padding), list(dilation), False, [0, 0], 1,
+        gx, gw, gb = _cb(_low(gy, dt), _low(x, dt), _low(w, dt), bias_sizes, list(stride), list(padding), list(dilation), False, [0, 0], 1,
                          [want_x, want_w, want_b])
-        return (gx.float() if gx is not None else None, gw.float() if gw is not None else None,
-                gb.float() if gb is not None else None)
+        return _high(gx), _high(gw), (gb.float() if gb is not None else None)
     return _cb(gy, x, w, bias_sizes, list(stride), list(padding), list(dilation), False, [0, 0], 1, [want_x, want_w, want_b])
 
 
@@ -86,10 +107,10 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x, w, stride, padding, dilation):
         dt = _STATE["dtype"]
         ctx.cfg = (stride, padding, dilation, dt)
-        xs = x if dt is None else x.to(dt)     # the activation is kept in the compute dtype (half the footprint in bf16)
+        xs = x if dt is None else _low(x, dt)     # the activation is kept in the compute dtype (half the footprint in bf16)
         ctx.save_for_backward(xs, w)
         if dt is not None:
-            return F.conv2d(xs, w.to(dt), None, stride, padding, dilation).float()
+            return _high(F.conv2d(xs, _low(w, dt), None, stride, padding, dilation))
         return raw_forward(x, w, stride, padding, dilation)
 
     @staticmethod
