@@ -119,18 +119,21 @@ def main():
             go = torch.randn(B, 81, H, W, device=dev); out = torch.empty(B, 81, H, W, device=dev)
             g1 = torch.empty_like(f1); g2 = torch.empty_like(f1)
             best = []
-            for th in (1, 2, 4):
-                for ks in (0, 1, 2, 4, 8):
-                    for m in (0, 8, 12, 16, 24, 32, 48, 64):
-                        os.environ["DFE_CORR_FWD"] = "%d,%d,%d" % (th, ks, m)
-                        try:
-                            t = timeit(lambda: check(lib.dfe_corr_fwd(ptr(f1), ptr(f2), ptr(out), B, C, H, W, 4, s), "fwd"), n=20, warm=2)
-                        except Exception:
-                            continue
-                        best.append((t, th, ks, m))
+            for dyg in (9, 5, 3):
+                os.environ["DFE_CORR_DYG"] = str(dyg)
+                for th in (1, 2, 4, 8):
+                    for ks in (0, 1, 2, 4):
+                        for m in (0, 8, 16, 32):
+                            os.environ["DFE_CORR_FWD"] = "%d,%d,%d" % (th, ks, m)
+                            try:
+                                t = timeit(lambda: check(lib.dfe_corr_fwd(ptr(f1), ptr(f2), ptr(out), B, C, H, W, 4, s), "fwd"), n=20, warm=2)
+                            except Exception:
+                                continue
+                            best.append((t, th, ks, m, dyg))
+            os.environ.pop("DFE_CORR_DYG", None)
             os.environ.pop("DFE_CORR_FWD", None)
             best.sort()
-            print("level %d fwd  best (us, TH, KS, CC):" % lvl, ["%.1f %d %d %d" % b for b in best[:6]], flush=True)
+            print("level %d fwd  best (us, TH, KS, CC, DYG):" % lvl, ["%.1f %d %d %d %d" % b for b in best[:8]], flush=True)
             best = []
             for th in (1, 2, 4, 8):
                 for ncg in (1, 2, 3, 4, 6):

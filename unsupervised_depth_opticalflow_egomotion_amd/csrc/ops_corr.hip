@@ -75,7 +75,8 @@ __device__ __forceinline__ void stage_next(StagePos& s, StageStep st, int rows, 
 
 struct CorrFwdCfg {
   int TH, TXQ, KS, CC;             // tile rows, tile width in quads, channel split, channels per chunk
-  int ntx, nty, NI;                // tiles across / down, work items per channel slot (TH * TXQ * 9)
+  int DYG, ndyg;                   // displacement rows per block (9 = all of them), groups of them (ceil(9 / DYG))
+  int ntx, nty, NI;                // tiles across / down, work items per channel slot (TH * TXQ * DYG)
   int R2, Q2, P2, P1;              // f2 tile rows / quads per row, quads per channel of the f2 / f1 tile
   int n2, n1;                      // CC * P2, CC * P1
   MagicDiv mP2, mQ2, mP1, mTXQ;
@@ -130,8 +131,9 @@ k_corr_fwd_lds(const float* __restrict__ f1, const float* __restrict__ f2, float
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, NT = blockDim.x;
   const unsigned bid = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int tx = bid % g.ntx, ty = (bid / g.ntx) % g.nty, b = bid / (g.ntx * g.nty);
-  const int tx0 = tx * 4 * g.TXQ, ty0 = ty * g.TH;
+  const int dyg = bid % g.ndyg, tile = bid / g.ndyg;
+  const int tx = tile % g.ntx, ty = (tile / g.ntx) % g.nty, b = tile / (g.ntx * g.nty);
+  const int tx0 = tx * 4 * g.TXQ, ty0 = ty * g.TH, dy0 = dyg * g.DYG;
   const long HW = static_cast<long>(H) * W;
   const float* f1b = f1 + static_cast<long>(b) * C * HW;
   const float* f2b = f2 + static_cast<long>(b) * C * HW;
@@ -142,7 +144,7 @@ k_corr_fwd_lds(const float* __restrict__ f1, const float* __restrict__ f2, float
     StagePos s = stage_first(tid, g.mP2, g.mQ2, g.P2, g.Q2);
 #pragma unroll
     for (int q = 0; q < PF2; ++q) {
-      const int gy = ty0 - CR_D + s.r, gx = tx0 - CR_D + 4 * s.q;
+      const int gy = ty0 - CR_D + dy0 + s.r, gx = tx0 - CR_D + 4 * s.q;
       const bool ok = (tid + q * NT < g.n2) && gy >= 0 && gy < H && gx >= 0 && gx < W;
       off2[q] = ok ? static_cast<int>(s.cl * HW + static_cast<long>(gy) * W + gx) : -1;
       cl2[q] = s.cl; gx2[q] = gx;
@@ -183,11 +185,11 @@ k_corr_fwd_lds(const float* __restrict__ f1, const float* __restrict__ f2, float
   };
 
   // ---- this thread's outputs: displacement row dy, tile row yl, quad xq, channel slot ks
-  const bool worker = tid < g.NI * g.KS;
   const int ks = tid / g.NI, item = tid - ks * g.NI;
-  const int xq = item % g.TXQ, t2 = item / g.TXQ, yl = t2 % g.TH, dy = t2 / g.TH;
+  const int xq = item % g.TXQ, t2 = item / g.TXQ, yl = t2 % g.TH, dyl = t2 / g.TH, dy = dy0 + dyl;    // dyl: row inside the block's group
+  const bool worker = tid < g.NI * g.KS && dy < CR_K;
   const int S2 = 4 * g.Q2, S1 = 4 * g.TXQ;
-  const int o2 = (ks * g.R2 + yl + dy) * S2 + 4 * xq, o1 = 4 * g.n2 + (ks * g.TH + yl) * S1 + 4 * xq;
+  const int o2 = (ks * g.R2 + yl + dyl) * S2 + 4 * xq, o1 = 4 * g.n2 + (ks * g.TH + yl) * S1 + 4 * xq;
   const int st2 = g.KS * g.R2 * S2, st1 = g.KS * g.TH * S1, nm = g.CC / g.KS;
   const int buf_floats = 4 * (g.n2 + g.n1);
 
@@ -459,18 +461,22 @@ bool corr_fwd_config(int B, int C, int H, int W, CorrFwdCfg& g, int& NT, size_t&
   // tools/corr_bench.py --sweep, profiles/r04_corr_sweep.txt)
   int TH = 4;
   while (TH > 1 && (TH > H || static_cast<long>(B) * ((H + TH - 1) / TH) * ntx < 256)) TH >>= 1;
-  int KS = 0, CC = 0;
+  // displacement rows per block: all 9 where the tiles alone fill the chip; 3 on the coarse levels (three times the
+  // blocks, a 3-row instead of a 9-row f2 tile each: 13.8 / 19.7 / 17.2 -> 11.4 / 11.0 / 12.1 us at levels 4 / 5 / 6)
+  int KS = 0, CC = 0, DYG = static_cast<long>(B) * ((H + TH - 1) / TH) * ntx >= 256 ? CR_K : 3;
   env_triple("DFE_CORR_FWD", TH, KS, CC);
-  int NI = TH * TXQ * CR_K;
-  while (NI > 512 && TH > 1) { TH >>= 1; NI = TH * TXQ * CR_K; }
+  if (const char* e = std::getenv("DFE_CORR_DYG")) { const int v = std::atoi(e); if (v >= 1 && v <= CR_K) DYG = v; }
+  const int ndyg = (CR_K + DYG - 1) / DYG;
+  int NI = TH * TXQ * DYG;
+  while (NI > 512 && TH > 1) { TH >>= 1; NI = TH * TXQ * DYG; }
   if (NI > 512) return false;
   if (KS <= 0) KS = static_cast<long>(B) * ((H + TH - 1) / TH) * ntx >= 256 ? 1 : 512 / NI;   // the channel sum is split only where the grid cannot fill the chip
   if (KS > C) KS = C;
   if (KS < 1) KS = 1;
   while (NI * KS > 512) --KS;
   NT = ((NI * KS + 63) / 64) * 64;
-  const int R2 = TH + 2 * CR_D, Q2 = TXQ + 2, P2 = R2 * Q2, P1 = TH * TXQ;
-  const long blocks = static_cast<long>(B) * ((H + TH - 1) / TH) * ntx;
+  const int R2 = TH + DYG - 1, Q2 = TXQ + 2, P2 = R2 * Q2, P1 = TH * TXQ;      // rows y + dy - 4 for the block's dy group
+  const long blocks = static_cast<long>(B) * ((H + TH - 1) / TH) * ntx * ndyg;
   // fine levels (every CU has two 512-thread blocks): chunks of ~8 channels, 4 staged quads per thread (<= 128 VGPRs),
   // 2 x 36 KB of LDS; coarse levels: as few chunks as 10 staged quads per thread and 2 x 72 KB of LDS allow -- every
   // chunk is a global-memory round trip that the little arithmetic of a small level cannot hide
@@ -482,7 +488,7 @@ bool corr_fwd_config(int B, int C, int H, int W, CorrFwdCfg& g, int& NT, size_t&
   const int Cr = ((C + KS - 1) / KS) * KS;
   if (CC <= 0) {
     CC = KS;
-    if (coarse) while (CC + KS <= Cr && fits(CC + KS, 10, 72 * 1024)) CC += KS;
+    if (coarse) while (CC + KS <= Cr && fits(CC + KS, 10, 72 * 1024) && 3 * (CC + KS) <= Cr + 3 * KS - 1) CC += KS;   // about three chunks
     else while (CC + KS <= Cr && fits(CC + KS, 4, 36 * 1024) && (KS > 1 || CC < 8)) CC += KS;
     const int nch = (C + CC - 1) / CC;      // the same number of chunks with the smallest chunk size
     while (CC - KS >= KS && (C + (CC - KS) - 1) / (CC - KS) == nch) CC -= KS;
@@ -492,7 +498,7 @@ bool corr_fwd_config(int B, int C, int H, int W, CorrFwdCfg& g, int& NT, size_t&
   while (CC > KS && !fits(CC, 10, 72 * 1024)) CC -= KS;
   if (!fits(CC, 10, 72 * 1024)) return false;
   pf2 = fits(CC, 4, 36 * 1024) ? 4 : 10;
-  g.TH = TH; g.TXQ = TXQ; g.KS = KS; g.CC = CC; g.ntx = ntx; g.nty = (H + TH - 1) / TH; g.NI = NI;
+  g.TH = TH; g.TXQ = TXQ; g.KS = KS; g.CC = CC; g.DYG = DYG; g.ndyg = ndyg; g.ntx = ntx; g.nty = (H + TH - 1) / TH; g.NI = NI;
   g.R2 = R2; g.Q2 = Q2; g.P2 = P2; g.P1 = P1; g.n2 = CC * P2; g.n1 = CC * P1;
   g.mP2 = make_magic(P2); g.mQ2 = make_magic(Q2); g.mP1 = make_magic(P1); g.mTXQ = make_magic(TXQ);
   g.s2 = make_step(NT, R2, Q2); g.s1 = make_step(NT, TH, TXQ);
@@ -558,7 +564,7 @@ inline int run_corr_fwd(const float* f1, const float* f2, float* out, long obs, 
                         size_t lds, hipStream_t st) {
   if (!allow_lds(k_corr_fwd_lds<VEC, PF2, WPE>, lds)) return DFE_ERR_LAUNCH;
   const float fC = static_cast<float>(C), rC = 1.0f / fC;
-  k_corr_fwd_lds<VEC, PF2, WPE><<<static_cast<unsigned>(B) * g.nty * g.ntx, NT, lds, st>>>(f1, f2, out, obs, C, H, W, fC, rC, g);
+  k_corr_fwd_lds<VEC, PF2, WPE><<<static_cast<unsigned>(B) * g.nty * g.ntx * g.ndyg, NT, lds, st>>>(f1, f2, out, obs, C, H, W, fC, rC, g);
   return DFE_OK;
 }
 
