@@ -410,8 +410,7 @@ def multi_gpu_evidence(wl, world, rank, dev, dt_local, args):
     times = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(times, torch.tensor([1e3 * dt_local / args.steps], device=dev, dtype=torch.float64))
     times = [float(t.item()) for t in times]
-    ddp_model = type(model).__name__ == "DistributedDataParallel" if model is not None else False
-    ev = {"ddp_wrapped": ddp_model, "backend": dist.get_backend(), "collective_library": "RCCL" if dist.get_backend() == "nccl" else dist.get_backend(),
+    ev = {"data_parallel": type(model).__name__ if model is not None else None, "backend": dist.get_backend(), "collective_library": "RCCL" if dist.get_backend() == "nccl" else dist.get_backend(),
           "rccl_ranks": int(ids[1].item()), "rank_id_allreduce_ok": bool(ids_ok),
           "ms_per_step_min": round(min(times), 4), "ms_per_step_max": round(max(times), 4),
           "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE")}

@@ -163,16 +163,21 @@ def _ddp_worker(rank, world, port, out):
     idx = ddp.shard_indices(4, world, rank)
     shard = [t[idx] for t in full]
     _ddp_loss(model, shard).backward()
+    if hasattr(model, "reduce_gradients"):       # strategy "flat": one all-reduce after backward ("torch": DDP reduced during it)
+        model.reduce_gradients()
     grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
     if rank == 0:
         torch.save(grads, out)
     torch.distributed.destroy_process_group()
 
 
-def test_two_process_gloo_matches_single_process(tmp_path):
+@pytest.mark.parametrize("strategy", ["flat", "torch"])
+def test_two_process_gloo_matches_single_process(tmp_path, strategy, monkeypatch):
+    """ddp.wrap's two strategies (the flat all-reduce after backward, round 4's default; torch's DistributedDataParallel)."""
     import torch.multiprocessing as mp
+    monkeypatch.setenv("DFE_DP_STRATEGY", strategy)      # inherited by the spawned ranks
     out = str(tmp_path / "g.pt")
-    port = 29500 + (os.getpid() % 2000)
+    port = 29500 + (os.getpid() % 2000) + (7 if strategy == "torch" else 0)
     mp.spawn(_ddp_worker, args=(2, port, out), nprocs=2, join=True)
     g2 = torch.load(out)
     torch.manual_seed(0)
@@ -224,10 +229,14 @@ def _real_worker(rank, world, port, out):
     net = _RealDepthNets()
     net.eval()                        # BatchNorm on running statistics: sharding-invariant, so gradients can be compared
     model = ddp.wrap(net)
-    assert type(model).__name__ == "DistributedDataParallel"
+    flat = os.environ.get("DFE_DP_STRATEGY", "flat") == "flat"
+    assert type(model).__name__ == ("FlatAllReduce" if flat else "DistributedDataParallel")
     full = _real_batch(2)
     idx = ddp.shard_indices(2, world, rank)
     _real_loss(model, [t[idx] for t in full]).backward()
+    if flat:
+        model.reduce_gradients()
+        assert model.ignored == ["depth_net.encoder.encoder.fc.bias", "depth_net.encoder.encoder.fc.weight"]
     named = dict(net.named_parameters())
     fc = [n for n in named if ".fc." in n]
     assert len(fc) == 2 and all(named[n].grad is None and named[n].requires_grad for n in fc)   # ignored, not frozen
@@ -236,20 +245,26 @@ def _real_worker(rank, world, port, out):
     net.train()
     net.zero_grad()
     _real_loss(model, [t[idx] for t in full]).backward()
+    if flat:
+        model.reduce_gradients()
+        assert all(p.grad.data_ptr() >= model._flat.data_ptr() and p.grad.data_ptr() < model._flat.data_ptr() + 4 * model._flat.numel()
+                   for n, p in named.items() if n not in fc)          # the reduced gradients are views of the flat buffer
     assert all(torch.isfinite(p.grad).all() for n, p in named.items() if n not in fc)
     if rank == 0:
         torch.save(grads, out)
     torch.distributed.destroy_process_group()
 
 
-def test_two_process_gloo_real_depth_nets(tmp_path):
-    """world_size 2 over gloo with the PRODUCT's networks (not a stand-in): DDP reproduces the single-process gradient,
-    and the never-used ``encoder.fc`` parameters are excluded from the reducer while staying in the optimizer's
-    parameter list (reference optimizer-state compatibility, train.py:85-87)."""
+@pytest.mark.parametrize("strategy", ["flat", "torch"])
+def test_two_process_gloo_real_depth_nets(tmp_path, strategy, monkeypatch):
+    """world_size 2 over gloo with the PRODUCT's networks (not a stand-in): both data-parallel strategies reproduce the
+    single-process gradient, and the never-used ``encoder.fc`` parameters are excluded from the reduction while staying in
+    the optimizer's parameter list (reference optimizer-state compatibility, train.py:85-87)."""
     import torch.multiprocessing as mp
     from unsupervised_depth_opticalflow_egomotion_amd import ddp
+    monkeypatch.setenv("DFE_DP_STRATEGY", strategy)
     out = str(tmp_path / "g.pt")
-    port = 31500 + (os.getpid() % 2000)
+    port = 31500 + (os.getpid() % 2000) + (7 if strategy == "torch" else 0)
     mp.spawn(_real_worker, args=(2, port, out), nprocs=2, join=True)
     g2 = torch.load(out)
     torch.manual_seed(0)

@@ -529,18 +529,22 @@ def run(wrapped):
     model.train()
     info = {}
     if wrapped:
-        model = ddp.wrap(model, dev, force=True)
-        info["is_ddp"] = type(model).__name__ == "DistributedDataParallel"
-        info["ignored"] = sorted(model.parameters_to_ignore)
-        info["bucket_view"] = bool(model.gradient_as_bucket_view)
+        model = ddp.wrap(model, dev, force=True, strategy=wrapped)
+        info["type"] = type(model).__name__
+        info["ignored"] = sorted(model.parameters_to_ignore) if wrapped == "torch" else model.ignored
+        info["bucket_view"] = bool(model.gradient_as_bucket_view) if wrapped == "torch" else True
     opt = make_optimizer(model, cfg.lr)
     losses = [float(train_step(model, opt, inputs, cfg)[0]) for _ in range(2)]
     torch.cuda.synchronize()
-    if wrapped:      # after backward every reduced gradient is a view into one of the reducer's buckets
+    if wrapped:      # after the step every reduced gradient is a view into the reducer's buffer(s)
         m = ddp.unwrap(model)
         grads = [p.grad for n, p in m.named_parameters() if p.grad is not None]
         info["n_grads"] = len(grads)
         info["fc_has_no_grad"] = all(p.grad is None for n, p in m.named_parameters() if ".encoder.encoder.fc." in n)
+        if wrapped == "flat":
+            lo, hi = model._flat.data_ptr(), model._flat.data_ptr() + 4 * model._flat.numel()
+            info["grads_in_flat_buffer"] = all(lo <= g.data_ptr() < hi for g in grads)
+            info["flat_numel"] = int(model._flat.numel())
     return [p.detach().clone() for p in ddp.unwrap(model).parameters()], losses, info
 
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
@@ -550,21 +554,26 @@ a1, la1, _ = run(False)
 ddp.init_process_group("nccl", force=True)
 assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
 t = torch.tensor([3.0], device=dev); dist.all_reduce(t); torch.cuda.synchronize()
-b, lb, info = run(True)
+b, lb, info = run("flat")
+c, lc, info_t = run("torch")
 dist.barrier(); dist.destroy_process_group()
 noise = max(float((x - y).abs().max()) for x, y in zip(a0, a1))
 diff = max(float((x - y).abs().max()) for x, y in zip(a0, b))
+diff_t = max(float((x - y).abs().max()) for x, y in zip(a0, c))
 scale = max(float(x.abs().max()) for x in a0)
-print("RESULT " + json.dumps({"noise": noise, "diff": diff, "scale": scale, "allreduce": float(t), "losses": [la0, lb], "info": info}))
+print("RESULT " + json.dumps({"noise": noise, "diff": diff, "diff_torch": diff_t, "scale": scale, "allreduce": float(t), "losses": [la0, lb, lc],
+                              "info": info, "info_torch": info_t}))
 """
 
 
 def test_rccl_world1_ddp_on_the_real_joint_model():
     """backend "nccl" (= RCCL) executed on the one GPU of this box (VERDICT r03 missing #1): a world-size-1 process group
-    with the high-priority communicator stream of ddp.rccl_options(), an all-reduce through it, DistributedDataParallel
-    forced around the real joint model (ddp.wrap(force=True): reducer, 25 MB buckets, gradients as bucket views, the
-    never-used fc pair ignored) with the three network streams, two training steps -- parameters equal to the un-wrapped
-    run within the run-to-run noise of MIOpen's split-K atomics (and 1e-6 of the parameter scale when that is larger).
+    with the high-priority communicator stream of ddp.rccl_options(), an all-reduce through it, and BOTH data-parallel
+    strategies of ddp.wrap(force=True) around the real joint model with the three network streams -- "flat" (round 4's
+    default: one 84 MB all-reduce after backward, gradients handed to FusedAdam as views of the flat buffer, the reduction
+    hooked in front of optimizer.step()) and "torch" (DistributedDataParallel: 25 MB buckets, gradients as bucket views) --
+    two training steps each: parameters equal to the un-wrapped run within the run-to-run noise of MIOpen's split-K atomics
+    (and 1e-6 of the parameter scale when that is larger); the never-used fc pair ignored by both.
     A fresh child process: the process group, the MIOpen handles and the stream pool are per process."""
     import json, subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -575,11 +584,16 @@ def test_rccl_world1_ddp_on_the_real_joint_model():
     r = json.loads(line[-1][7:])
     print(r)
     assert r["allreduce"] == 3.0
-    info = r["info"]
-    assert info["is_ddp"] and info["bucket_view"] and info["fc_has_no_grad"] and info["n_grads"] > 200
-    assert info["ignored"] == ["depth_net.encoder.encoder.fc.bias", "depth_net.encoder.encoder.fc.weight"]
+    info, info_t = r["info"], r["info_torch"]
+    assert info["type"] == "FlatAllReduce" and info["grads_in_flat_buffer"] and info["fc_has_no_grad"] and info["n_grads"] > 200
+    assert 21_000_000 < info["flat_numel"] < 21_100_000                      # 21.06 M of the 21.57 M parameters
+    assert info_t["type"] == "DistributedDataParallel" and info_t["bucket_view"] and info_t["fc_has_no_grad"]
+    for i in (info, info_t):
+        assert i["ignored"] == ["depth_net.encoder.encoder.fc.bias", "depth_net.encoder.encoder.fc.weight"]
     assert r["diff"] <= max(4.0 * r["noise"], 1e-6 * r["scale"]), r
-    assert abs(r["losses"][0][0] - r["losses"][1][0]) <= 1e-4 * abs(r["losses"][0][0])
+    assert r["diff_torch"] <= max(4.0 * r["noise"], 1e-6 * r["scale"]), r
+    for k in (1, 2):
+        assert abs(r["losses"][0][0] - r["losses"][k][0]) <= 1e-4 * abs(r["losses"][0][0])
 
 
 def test_bench_force_ddp_prints_the_multi_gpu_block_on_one_gpu():
@@ -590,7 +604,7 @@ def test_bench_force_ddp_prints_the_multi_gpu_block_on_one_gpu():
     j = _bench_json(subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--force-ddp", "--steps", "2", "--warmup", "1",
                                     "--batch", "2", "--no-cpu-baseline"], capture_output=True, text=True, cwd=repo, env=clean, timeout=900))
     mg = j["multi_gpu"]
-    assert j["n_gpus"] == 1 and mg["ddp_wrapped"] is True and mg["backend"] == "nccl" and mg["collective_library"] == "RCCL"
+    assert j["n_gpus"] == 1 and mg["data_parallel"] == "FlatAllReduce" and mg["backend"] == "nccl" and mg["collective_library"] == "RCCL"
     assert mg["rccl_ranks"] == 1 and mg["rank_id_allreduce_ok"] is True and mg["param_checksums_equal"] is True
 
 

@@ -2,10 +2,11 @@
 
 Replaces the reference's single-process ``nn.DataParallel`` (train.py:59-60,277-283).  Every loss term is a
 per-sample (B,) vector with per-sample normalisers, so equal shards + gradient averaging reproduce the
-single-process gradient.  One collective per step: the bucketed all-reduce of 21.06 M fp32
-gradients (84 MB: the model's 21.57 M parameters minus the never-used 513 k of ``depth_net.encoder.encoder.fc``),
-overlapped with backward by DistributedDataParallel.  The loss-stack
-kernels themselves are single-GPU; nothing on the data path is exchanged."""
+single-process gradient.  One collective per step: the all-reduce of 21.06 M fp32 gradients (84 MB:
+the model's 21.57 M parameters minus the never-used 513 k of ``depth_net.encoder.encoder.fc``) -- as ONE flat message
+after backward (``FlatAllReduce``, the default since round 4) or bucketed and overlapped with backward by torch's
+DistributedDataParallel (``strategy="torch"``).  The loss-stack kernels themselves are single-GPU; nothing on the data
+path is exchanged."""
 import os
 
 import torch
@@ -58,24 +59,100 @@ def unused_parameter_names(model):
             if ".encoder.encoder.fc." in n or n.startswith("encoder.encoder.fc.")]
 
 
-def wrap(model, device=None, bucket_cap_mb=25, force=False):
-    """DistributedDataParallel when WORLD_SIZE > 1 (or ``force``: DDP over a world-size-1 group, which still builds the
-    reducer, the bucket views and the communicator), the bare module otherwise.  The never-used ``fc`` parameters are
-    excluded from the reducer (it would wait for their gradients forever) instead of being frozen: 21.06 M of the
-    model's 21.57 M parameters are all-reduced (84 MB fp32 per step)."""
+class FlatAllReduce(torch.nn.Module):
+    """The model's replica in a data-parallel job, round 4's default (``wrap(strategy="flat")``).
+
+    One collective per step, issued AFTER backward: the gradients are copied into ONE persistent flat fp32 buffer (a
+    single multi-tensor copy kernel), all-reduced in place as one 84 MB message -- the size RCCL's ring over xGMI is most
+    efficient at -- and handed to the optimiser as views of that buffer (no copy back: ``optim.FusedAdam`` refreshes its
+    gradient pointers every step).  ``make_optimizer`` hooks ``reduce_gradients`` in front of ``optimizer.step()``, so the
+    reference's loop (``loss.backward(); optimizer.step()``, train.py:215-216) needs no extra call.
+
+    Why not torch's DistributedDataParallel (``strategy="torch"`` keeps it): measured on MI355X at world size 1 around the
+    real joint model (profiles/r04_ddp_overhead.txt; plain step 25.3 ms) its reducer costs 2.5-3.1 ms per step in
+    per-parameter autograd hooks and bookkeeping (250 parameters) before any byte is communicated -- a weak-scaling
+    ceiling of 0.89-0.91 -- and its ``static_graph`` mode, which would halve that, silently stops reducing this model's
+    gradients on the device (cross-rank parameter checksums diverge: bench.py's multi_gpu evidence caught it).  This
+    class costs 0.1 ms per step at world size 1; what it gives up is the overlap of the all-reduce with backward
+    (~1 ms of ring time at 8 GPUs, exposed: expected efficiency ~0.96).
+
+    The never-used ``fc`` parameters are left out (no gradient ever exists for them).  Parameters and buffers start from
+    rank 0's values (one coalesced broadcast at construction); BatchNorm's running statistics are NOT re-broadcast every
+    forward: train-mode forwards do not read them and rank 0's are what checkpoints hold either way (the reference's
+    DataParallel keeps device 0's and discards the replicas', train.py:59-60)."""
+
+    def __init__(self, module, ignore=()):
+        super().__init__()
+        self.module = module
+        self.world = dist.get_world_size()
+        self.backend = dist.get_backend()
+        self.ignored = sorted(ignore)
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad and n not in set(ignore)]
+        self._params = [p for _, p in named]
+        self._numel = sum(p.numel() for p in self._params)
+        self._flat = None
+        self._views = None
+        tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+        if tensors and self.world > 1:
+            dist._broadcast_coalesced(dist.group.WORLD, tensors, 250 * 1024 * 1024, 0)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def _buffers_for(self, ref):
+        if self._flat is None or self._flat.device != ref.device:
+            self._flat = torch.zeros(self._numel, device=ref.device, dtype=torch.float32)
+            self._views, off = [], 0
+            for p in self._params:
+                self._views.append(self._flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        return self._flat, self._views
+
+    @torch.no_grad()
+    def reduce_gradients(self):
+        """Average the gradients over the ranks (call once after backward; ``make_optimizer`` does it before every step)."""
+        grads = [p.grad for p in self._params]
+        if all(g is not None for g in grads):        # the steady state: every reducible parameter has a gradient
+            flat, views = self._buffers_for(grads[0])
+            torch._foreach_copy_(views, grads)
+            have = None
+        else:
+            have = [i for i, g in enumerate(grads) if g is not None]
+            if not have:
+                return
+            flat, views = self._buffers_for(grads[have[0]])
+            present = set(have)
+            for i, v in enumerate(views):            # a parameter without a gradient this step contributes zeros
+                if i not in present:
+                    v.zero_()
+            torch._foreach_copy_([views[i] for i in have], [grads[i] for i in have])
+        if self.backend == "nccl":
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(flat)
+            flat.div_(self.world)
+        for i in (range(len(views)) if have is None else have):
+            self._params[i].grad = views[i]
+
+
+def wrap(model, device=None, bucket_cap_mb=25, force=False, strategy=None):
+    """The data-parallel replica of ``model`` when WORLD_SIZE > 1 (or ``force``: the same machinery over a world-size-1
+    group), the bare module otherwise.  ``strategy``: "flat" (default, FlatAllReduce above) or "torch" (torch's
+    DistributedDataParallel with 25 MB buckets overlapped with backward, gradients as bucket views); DFE_DP_STRATEGY
+    overrides.  Either way the never-used ``fc`` parameters are excluded from the reduction instead of being frozen:
+    21.06 M of the model's 21.57 M parameters are all-reduced (84 MB fp32 per step)."""
     world, _, local = env_world()
     if world == 1 and not force:
         return model
+    strategy = os.environ.get("DFE_DP_STRATEGY", strategy or "flat")
+    if strategy == "flat":
+        return FlatAllReduce(model, unused_parameter_names(model))
     from torch.nn.parallel import DistributedDataParallel as DDP
     DDP._set_params_and_buffers_to_ignore_for_model(model, unused_parameter_names(model))
-    # static_graph: the set of parameters that receive a gradient never changes (the ignored fc pair aside), so the
-    #   reducer can skip its per-iteration bookkeeping.  broadcast_buffers=False: the only buffers are BatchNorm's running
-    #   statistics; train-mode forwards do not read them, rank 0's are what checkpoints hold either way (the reference's
-    #   DataParallel keeps device 0's and discards the replicas', train.py:59-60), so the per-forward broadcast buys
-    #   nothing.  Measured at world size 1 on MI355X (bench.py --force-ddp, plain step 25.3 ms): DDP defaults 28.4 ms,
-    #   static_graph 26.9, both 26.5 (profiles/r04_ddp_overhead.txt).
-    # DFE_DDP_OPTS: experiment switches, e.g. "broadcast_buffers=1,static_graph=0,bucket_cap_mb=100"
-    kw = dict(bucket_cap_mb=bucket_cap_mb, static_graph=True, broadcast_buffers=False)
+    # broadcast_buffers=False: the only buffers are BatchNorm's running statistics (see FlatAllReduce).  static_graph stays
+    #   False: with it this model's gradients are no longer reduced on the device (see FlatAllReduce).
+    # DFE_DDP_OPTS: experiment switches, e.g. "broadcast_buffers=1,static_graph=1,bucket_cap_mb=100"
+    kw = dict(bucket_cap_mb=bucket_cap_mb, static_graph=False, broadcast_buffers=False)
     for item in filter(None, os.environ.get("DFE_DDP_OPTS", "").split(",")):
         k, v = item.split("=")
         kw[k] = float(v) if k == "bucket_cap_mb" else bool(int(v))

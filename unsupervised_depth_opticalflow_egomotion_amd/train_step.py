@@ -34,8 +34,12 @@ def make_optimizer(model, lr):
     on_gpu = bool(params) and all(p.is_cuda and p.dtype == torch.float32 for p in params)
     if on_gpu and os.environ.get("DFE_FUSED_ADAM", "1") != "0":
         from .optim import FusedAdam
-        return FusedAdam(params, lr=lr)
-    return torch.optim.Adam(params, lr=lr, fused=True) if on_gpu else torch.optim.Adam(params, lr=lr)
+        opt = FusedAdam(params, lr=lr)
+    else:
+        opt = torch.optim.Adam(params, lr=lr, fused=True) if on_gpu else torch.optim.Adam(params, lr=lr)
+    if hasattr(model, "reduce_gradients"):      # ddp.FlatAllReduce: the gradient all-reduce runs in front of every step
+        opt.register_step_pre_hook(lambda _opt, _args, _kwargs: model.reduce_gradients())
+    return opt
 
 
 _WEIGHT_ROWS = {}
