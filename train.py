@@ -5,7 +5,7 @@
   torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py -c config/kitti_geom.yaml --mode geom
 
 Differences from the reference, all forced by what it cannot do: data parallelism is one process per GPU
-with DDP over RCCL instead of nn.DataParallel (``--multi_gpu`` is accepted and ignored; launch with
+with one process per GPU over RCCL (ddp.wrap: one flat gradient all-reduce per step) instead of nn.DataParallel (``--multi_gpu`` is accepted and ignored; launch with
 torchrun); the data source is the synthetic KITTI-shaped triplet generator (no KITTI on this machine);
 periodic KITTI evaluation (train.py:136-164) needs the datasets and is skipped (``--no_test`` semantics).
 Checkpoints keep the reference format: {iteration, model_state_dict, optimizer_state_dict} in
