@@ -500,30 +500,6 @@ __global__ void __launch_bounds__(256) k_resize_bilinear_bwd(const float* __rest
 }  // namespace dfe
 
 // ====================================================================== C ABI
-// tail of one PWC level's concatenated input (dfe_pwc_level_fwd below): planes 81.. <- c1, then the flow
-namespace dfe {
-__global__ void __launch_bounds__(256) k_pwc_cat_tail(const float* __restrict__ c1, const float* __restrict__ flow,
-                                                      float* __restrict__ x, int C, long HW, long xbs, int vec) {
-  // planes 81 .. 81+C-1 <- c1, 81+C .. 81+C+1 <- flow; grid.y = sample
-  const int b = blockIdx.y;
-  const long n = static_cast<long>(C + 2) * HW;
-  float* dst = x + static_cast<long>(b) * xbs + static_cast<long>(CR_K) * CR_K * HW;
-  const float* s1 = c1 + static_cast<long>(b) * C * HW;
-  const float* s2 = flow + static_cast<long>(b) * 2 * HW;
-  const long split = static_cast<long>(C) * HW;
-  if (vec) {
-    const long i = (static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x) * 4;
-    if (i >= n) return;
-    const float4 v = (i < split) ? *reinterpret_cast<const float4*>(s1 + i) : *reinterpret_cast<const float4*>(s2 + (i - split));
-    *reinterpret_cast<float4*>(dst + i) = v;
-  } else {
-    const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    dst[i] = (i < split) ? s1[i] : s2[i - split];
-  }
-}
-}  // namespace dfe
-
 using namespace dfe;
 
 #define DFE_REQUIRE(cond, code) do { if (!(cond)) return (code); } while (0)
@@ -675,7 +651,7 @@ int dfe_corr_fwd(const float* f1, const float* f2, float* out, int B, int C, int
   DFE_REQUIRE(f1 && f2 && out, DFE_ERR_NULL);
   DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
   DFE_REQUIRE(d == CR_D, DFE_ERR_UNSUPPORTED);
-  const int rc = launch_corr_fwd(f1, f2, out, static_cast<long>(CR_K) * CR_K * H * W, B, C, H, W, static_cast<hipStream_t>(stream));
+  const int rc = launch_corr_fwd(f1, f2, out, static_cast<long>(CR_K) * CR_K * H * W, nullptr, nullptr, B, C, H, W, static_cast<hipStream_t>(stream));
   if (rc != DFE_OK) return rc;
   DFE_LAUNCH_CHECK();
   return DFE_OK;
@@ -686,7 +662,7 @@ int dfe_corr_bwd(const float* f1, const float* f2, const float* gout, float* g1,
   DFE_REQUIRE(f1 && f2 && gout && (g1 || g2), DFE_ERR_NULL);
   DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
   DFE_REQUIRE(d == CR_D, DFE_ERR_UNSUPPORTED);
-  const int rc = launch_corr_bwd(f1, f2, gout, static_cast<long>(CR_K) * CR_K * H * W, nullptr, 0, g1, g2, B, C, H, W, static_cast<hipStream_t>(stream));
+  const int rc = launch_corr_bwd(f1, f2, gout, static_cast<long>(CR_K) * CR_K * H * W, nullptr, 0, g1, g2, nullptr, B, C, H, W, static_cast<hipStream_t>(stream));
   if (rc != DFE_OK) return rc;
   DFE_LAUNCH_CHECK();
   return DFE_OK;
@@ -707,13 +683,8 @@ int dfe_pwc_level_fwd(const float* c1, const float* c2, const float* flow, float
   dim3 gw(static_cast<unsigned>((HW + 63) / 64), (C + WF_CK - 1) / WF_CK, B);
   k_warp_flow_fwd<<<gw, 64, 0, st>>>(c2, flow, warped, C, H, W, 0, align_corners);
   DFE_LAUNCH_CHECK();
-  { const int rc = launch_corr_fwd(c1, warped, x, xbs, B, C, H, W, st); if (rc != DFE_OK) return rc; }
-  DFE_LAUNCH_CHECK();
-  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  const int vec = (HW % 4 == 0) && al(c1) && al(flow) && al(x);
-  const long n = static_cast<long>(C + 2) * HW;
-  dim3 gt(static_cast<unsigned>(((vec ? (n + 3) / 4 : n) + 255) / 256), B);
-  k_pwc_cat_tail<<<gt, 256, 0, st>>>(c1, flow, x, C, HW, xbs, vec);
+  // the correlation kernel also writes the c1 and flow planes behind the cost volume (the c1 tiles it stages anyway)
+  { const int rc = launch_corr_fwd(c1, warped, x, xbs, x + static_cast<long>(CR_K) * CR_K * HW, flow, B, C, H, W, st); if (rc != DFE_OK) return rc; }
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
@@ -730,11 +701,13 @@ int dfe_pwc_level_bwd(const float* c1, const float* c2, const float* flow, const
   const long HW = static_cast<long>(H) * W, xbs = static_cast<long>(dfe_pwc_level_channels(C)) * HW;
   const float* gx_c1 = gx + static_cast<long>(CR_K) * CR_K * HW;
   const float* gx_flow = gx_c1 + static_cast<long>(C) * HW;
-  // dL/dc1 = correlation gradient + the concatenated copy's slice; dL/dwarped
-  { const int rc = launch_corr_bwd(c1, warped, gx, xbs, gx_c1, xbs, g_c1, g_warped, B, C, H, W, st); if (rc != DFE_OK) return rc; }
-  DFE_LAUNCH_CHECK();
+  // the feature-warp scatter's accumulators are zeroed first: the correlation backward writes their bound (max |dL/dwarped|,
+  // the gradient about to be scattered) from its epilogue -- round 3 spent a launch of its own on that max
   const long n = static_cast<long>(B) * C * HW;
-  if (g_c2) { const int rc = scatter_begin(g_c2_ws, n, g_warped, n, st); if (rc != DFE_OK) return rc; }
+  if (g_c2) { const int rc = scatter_begin_bound(g_c2_ws, n, st); if (rc != DFE_OK) return rc; }
+  // dL/dc1 = correlation gradient + the concatenated copy's slice; dL/dwarped
+  { const int rc = launch_corr_bwd(c1, warped, gx, xbs, gx_c1, xbs, g_c1, g_warped, g_c2 ? static_cast<unsigned*>(g_c2_ws) : nullptr, B, C, H, W, st); if (rc != DFE_OK) return rc; }
+  DFE_LAUNCH_CHECK();
   dim3 g(static_cast<unsigned>((HW + 63) / 64), 1, B);
   k_warp_flow_bwd<<<g, 64 * WF_GROUPS, 0, st>>>(c2, flow, g_warped, g_flow, g_c2 ? g_c2_ws : nullptr, g_flow ? gx_flow : nullptr, xbs, C, H, W, 0, align_corners);
   DFE_LAUNCH_CHECK();

@@ -93,7 +93,7 @@ struct CorrBwdCfg {
 };
 
 // one gradient of the backward launch: MODE 0 (g1: other = f2, addend optional) or MODE 1 (g2: other = f1)
-struct CorrBwdSide { const float* other; float* gin; const float* addend; long abs_; };
+struct CorrBwdSide { const float* other; float* gin; const float* addend; long abs_; unsigned* amax; };   // amax: word that receives max |gin| as a bit pattern (dfe_scatter.h header), or NULL
 
 __device__ __forceinline__ float4 load_quad_checked(const float* __restrict__ p, int gx, int W) {
   // p points at column gx of a valid row; elements outside [0, W) read as zero
@@ -120,14 +120,23 @@ __device__ __forceinline__ float4 load_quad_right(const float* __restrict__ p, i
   return v;
 }
 
+// max over the wave of a non-negative bit pattern, then one atomicMax per wave (none when the word already holds as much):
+// max is associative and commutative, so the word does not depend on the order (dfe_scatter.h; a NaN's pattern wins)
+__device__ __forceinline__ void wave_amax_to(unsigned* word, unsigned m) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, static_cast<unsigned>(__shfl_xor(static_cast<int>(m), o)));
+  if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(word, m);
+}
+__device__ __forceinline__ unsigned abs_bits(float v) { return static_cast<unsigned>(__float_as_int(v)) & 0x7fffffffu; }
+
 // ------------------------------------------------------------------------------------------------ forward
 // PF2: staged f2 quads per thread and chunk (4: the fine levels, <= 128 VGPRs = two 512-thread blocks per CU;
 // 10: the coarse levels, where few large chunks beat many small ones -- every chunk is a global-memory round trip
 // that the little arithmetic of a small level cannot hide).
 template <bool VEC, int PF2, int WPE>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
-k_corr_fwd_lds(const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ out, long obs, int C, int H, int W,
-               float fC, float rC, CorrFwdCfg g) {
+k_corr_fwd_lds(const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ out, long obs, float* __restrict__ tail,
+               const float* __restrict__ flow, int C, int H, int W, float fC, float rC, CorrFwdCfg g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, NT = blockDim.x;
   const unsigned bid = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -177,12 +186,41 @@ k_corr_fwd_lds(const float* __restrict__ f1, const float* __restrict__ f2, float
 #pragma unroll
     for (int q = 0; q < CF_PF1; ++q) pf1[q] = fetch(f1b, off1[q], cl1[q], gx1[q], c0);
   };
-  auto commit = [&](float* buf) {
+  // One PWC level's input is x = cat(cost volume, c1, flow) (pwc_tf.py:119-121): when `tail` is given (planes 81 ... of x, same
+  // batch stride as the cost volume) the f1 quads this block stages anyway are also stored there, and the flow planes copied
+  // below -- round 3 ran a copy kernel of its own for that.  Only the block of the first displacement-row group writes.
+  float* tail_b = (tail && dyg == 0) ? tail + static_cast<long>(b) * obs : nullptr;
+  auto commit = [&](float* buf, int c0) {
 #pragma unroll
     for (int q = 0; q < PF2; ++q) { const int e = tid + q * NT; if (e < g.n2) *reinterpret_cast<float4*>(buf + 4 * e) = pf2[q]; }
 #pragma unroll
-    for (int q = 0; q < CF_PF1; ++q) { const int e = tid + q * NT; if (e < g.n1) *reinterpret_cast<float4*>(buf + 4 * (g.n2 + e)) = pf1[q]; }
+    for (int q = 0; q < CF_PF1; ++q) {
+      const int e = tid + q * NT;
+      if (e < g.n1) *reinterpret_cast<float4*>(buf + 4 * (g.n2 + e)) = pf1[q];
+      if (tail_b && off1[q] >= 0 && cl1[q] < C - c0) {
+        float* t = tail_b + static_cast<long>(c0) * HW + off1[q];
+        if (VEC) *reinterpret_cast<float4*>(t) = pf1[q];
+        else {
+          t[0] = pf1[q].x;
+          if (gx1[q] + 1 < W) t[1] = pf1[q].y;
+          if (gx1[q] + 2 < W) t[2] = pf1[q].z;
+          if (gx1[q] + 3 < W) t[3] = pf1[q].w;
+        }
+      }
+    }
   };
+  if (tail_b) {       // the two flow planes of this tile
+    const float* fb = flow + static_cast<long>(b) * 2 * HW;
+    float* tb = tail_b + static_cast<long>(C) * HW;
+    for (int e = tid; e < 2 * g.P1; e += NT) {
+      const int pl = e / g.P1, rem = e - pl * g.P1, r = rem / g.TXQ, y = ty0 + r, x = tx0 + 4 * (rem - r * g.TXQ);
+      if (y < H && x < W) {
+        const long o = static_cast<long>(pl) * HW + static_cast<long>(y) * W + x;
+        if (VEC) *reinterpret_cast<float4*>(tb + o) = *reinterpret_cast<const float4*>(fb + o);
+        else for (int u = 0; u < 4 && x + u < W; ++u) tb[o + u] = fb[o + u];
+      }
+    }
+  }
 
   // ---- this thread's outputs: displacement row dy, tile row yl, quad xq, channel slot ks
   const int ks = tid / g.NI, item = tid - ks * g.NI;
@@ -201,7 +239,7 @@ k_corr_fwd_lds(const float* __restrict__ f1, const float* __restrict__ f2, float
 
   const int nchunk = (C + g.CC - 1) / g.CC;
   prefetch(0);
-  commit(smem);
+  commit(smem, 0);
   __syncthreads();
   for (int k = 0; k < nchunk; ++k) {
     const float* buf = smem + (k & 1) * buf_floats;
@@ -228,7 +266,7 @@ k_corr_fwd_lds(const float* __restrict__ f1, const float* __restrict__ f2, float
           for (int j = 0; j < CR_K; ++j) acc[u][j] = __fmaf_rn(a[u], w[u + j], acc[u][j]);
       }
     }
-    if (k + 1 < nchunk) commit(smem + ((k + 1) & 1) * buf_floats);
+    if (k + 1 < nchunk) commit(smem + ((k + 1) & 1) * buf_floats, (k + 1) * g.CC);
     __syncthreads();
   }
 
@@ -384,21 +422,25 @@ __device__ __forceinline__ void corr_bwd_body(float* smem, const CorrBwdSide sd,
   float* gi = sd.gin + static_cast<long>(b) * C * HW + static_cast<long>(c0) * HW + static_cast<long>(y) * W + x0;
   const float* ad = sd.addend ? sd.addend + static_cast<long>(b) * sd.abs_ + static_cast<long>(c0) * HW + static_cast<long>(y) * W + x0 : nullptr;
   if (g.IS == 1) {
-    if (!live) return;
+    unsigned am = 0u;
+    if (live) {
 #pragma unroll
-    for (int c = 0; c < CB_CK; ++c) {
-      if (c0 + c >= C) break;
-      float v0 = div_cr(acc[c][0], fC, rC), v1 = div_cr(acc[c][1], fC, rC), v2 = div_cr(acc[c][2], fC, rC), v3 = div_cr(acc[c][3], fC, rC);
-      if (VEC) {
-        if (ad) { const float4 a4 = *reinterpret_cast<const float4*>(ad + c * HW); v0 += a4.x; v1 += a4.y; v2 += a4.z; v3 += a4.w; }
-        *reinterpret_cast<float4*>(gi + c * HW) = make_float4(v0, v1, v2, v3);
-      } else {
-        const float vv[4] = {v0, v1, v2, v3};
+      for (int c = 0; c < CB_CK; ++c) {
+        if (c0 + c >= C) break;
+        float v0 = div_cr(acc[c][0], fC, rC), v1 = div_cr(acc[c][1], fC, rC), v2 = div_cr(acc[c][2], fC, rC), v3 = div_cr(acc[c][3], fC, rC);
+        if (VEC) {
+          if (ad) { const float4 a4 = *reinterpret_cast<const float4*>(ad + c * HW); v0 += a4.x; v1 += a4.y; v2 += a4.z; v3 += a4.w; }
+          *reinterpret_cast<float4*>(gi + c * HW) = make_float4(v0, v1, v2, v3);
+          am = max(max(am, abs_bits(v0)), max(abs_bits(v1), max(abs_bits(v2), abs_bits(v3))));
+        } else {
+          const float vv[4] = {v0, v1, v2, v3};
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (x0 + u < W) gi[c * HW + u] = ad ? vv[u] + ad[c * HW + u] : vv[u];
+          for (int u = 0; u < 4; ++u)
+            if (x0 + u < W) { const float r = ad ? vv[u] + ad[c * HW + u] : vv[u]; gi[c * HW + u] = r; am = max(am, abs_bits(r)); }
+        }
       }
     }
+    if (sd.amax) wave_amax_to(sd.amax, am);        // every lane of every wave arrives here
     return;
   }
   // displacement-row partials meet in LDS in row-slot order: red[(is * 32 + a) * NI + item], a = c * 4 + u; row slot `is`
@@ -412,6 +454,7 @@ __device__ __forceinline__ void corr_bwd_body(float* smem, const CorrBwdSide sd,
       for (int u = 0; u < 4; ++u) red[(is * 32 + c * 4 + u) * g.NI + item] = acc[c][u];
   }
   __syncthreads();
+  unsigned am = 0u;
   if (live) {
     const int nout = 32 * g.NI;
     for (int a = is; a < 32; a += g.IS) {
@@ -422,9 +465,11 @@ __device__ __forceinline__ void corr_bwd_body(float* smem, const CorrBwdSide sd,
         float v = div_cr(s, fC, rC);
         if (ad) v += ad[c * HW + u];
         gi[c * HW + u] = v;
+        am = max(am, abs_bits(v));
       }
     }
   }
+  if (sd.amax) wave_amax_to(sd.amax, am);
 }
 
 // both gradients in one launch: blockIdx.y picks the side (mode0: the first side's MODE)
@@ -560,39 +605,42 @@ inline bool allow_lds(K kernel, size_t lds) {
 }
 
 template <bool VEC, int PF2, int WPE>
-inline int run_corr_fwd(const float* f1, const float* f2, float* out, long obs, int B, int C, int H, int W, const CorrFwdCfg& g, int NT,
-                        size_t lds, hipStream_t st) {
+inline int run_corr_fwd(const float* f1, const float* f2, float* out, long obs, float* tail, const float* flow, int B, int C, int H, int W,
+                        const CorrFwdCfg& g, int NT, size_t lds, hipStream_t st) {
   if (!allow_lds(k_corr_fwd_lds<VEC, PF2, WPE>, lds)) return DFE_ERR_LAUNCH;
   const float fC = static_cast<float>(C), rC = 1.0f / fC;
-  k_corr_fwd_lds<VEC, PF2, WPE><<<static_cast<unsigned>(B) * g.nty * g.ntx * g.ndyg, NT, lds, st>>>(f1, f2, out, obs, C, H, W, fC, rC, g);
+  k_corr_fwd_lds<VEC, PF2, WPE><<<static_cast<unsigned>(B) * g.nty * g.ntx * g.ndyg, NT, lds, st>>>(f1, f2, out, obs, tail, flow, C, H, W, fC, rC, g);
   return DFE_OK;
 }
 
 }  // namespace
 
-int launch_corr_fwd(const float* f1, const float* f2, float* out, long obs, int B, int C, int H, int W, hipStream_t st) {
+int launch_corr_fwd(const float* f1, const float* f2, float* out, long obs, float* tail, const float* flow, int B, int C, int H, int W,
+                    hipStream_t st) {
   CorrFwdCfg g;
   int NT, pf2;
   size_t lds;
   if (!corr_fwd_config(B, C, H, W, g, NT, lds, pf2)) return DFE_ERR_UNSUPPORTED;
-  const bool vec = (W % 4 == 0) && al16(f1) && al16(f2) && al16(out) && obs % 4 == 0;
-  if (pf2 == 4) return vec ? run_corr_fwd<true, 4, 4>(f1, f2, out, obs, B, C, H, W, g, NT, lds, st)
-                           : run_corr_fwd<false, 4, 3>(f1, f2, out, obs, B, C, H, W, g, NT, lds, st);
-  return vec ? run_corr_fwd<true, 10, 2>(f1, f2, out, obs, B, C, H, W, g, NT, lds, st)
-             : run_corr_fwd<false, 10, 2>(f1, f2, out, obs, B, C, H, W, g, NT, lds, st);
+  const bool vec = (W % 4 == 0) && al16(f1) && al16(f2) && al16(out) && obs % 4 == 0 && al16(tail) && al16(flow);
+  if (tail && !flow) return DFE_ERR_NULL;
+  if (pf2 == 4) return vec ? run_corr_fwd<true, 4, 4>(f1, f2, out, obs, tail, flow, B, C, H, W, g, NT, lds, st)
+                           : run_corr_fwd<false, 4, 3>(f1, f2, out, obs, tail, flow, B, C, H, W, g, NT, lds, st);
+  return vec ? run_corr_fwd<true, 10, 2>(f1, f2, out, obs, tail, flow, B, C, H, W, g, NT, lds, st)
+             : run_corr_fwd<false, 10, 2>(f1, f2, out, obs, tail, flow, B, C, H, W, g, NT, lds, st);
 }
 
 // gout: 81 planes per sample with batch stride gbs; add1 (batch stride abs1) is added to g1 when given.  Both gradients
-// go out in ONE launch (grid.y = 2).
+// go out in ONE launch (grid.y = 2).  amax2 (optional): a zeroed word that receives max |g2| as a bit pattern -- the bound
+// of the feature-warp scatter that follows in a PWC level (dfe_scatter.h), saving that pass its own max-reduction launch.
 int launch_corr_bwd(const float* f1, const float* f2, const float* gout, long gbs, const float* add1, long abs1,
-                    float* g1, float* g2, int B, int C, int H, int W, hipStream_t st) {
+                    float* g1, float* g2, unsigned* amax2, int B, int C, int H, int W, hipStream_t st) {
   CorrBwdCfg g;
   int NT;
   size_t lds;
   if (!corr_bwd_config(B, C, H, W, (g1 && g2) ? 2 : 1, g, NT, lds)) return DFE_ERR_UNSUPPORTED;
   const bool vec = (W % 4 == 0) && al16(f1) && al16(f2) && al16(gout) && al16(g1) && al16(g2) && al16(add1) && gbs % 4 == 0 && abs1 % 4 == 0;
   const float fC = static_cast<float>(C), rC = 1.0f / fC;
-  const CorrBwdSide side1{f2, g1, add1, abs1}, side2{f1, g2, nullptr, 0};
+  const CorrBwdSide side1{f2, g1, add1, abs1, nullptr}, side2{f1, g2, nullptr, 0, g2 ? amax2 : nullptr};
   const CorrBwdSide s0 = g1 ? side1 : side2, s1 = side2;
   const int mode0 = g1 ? 0 : 1;
   const dim3 grid(static_cast<unsigned>(B) * g.nty * g.ntx * g.ncr, (g1 && g2) ? 2 : 1);
