@@ -72,29 +72,28 @@ def run_level(B, C, H, W, do_check, only_corr=False, iters=50):
         (ref * go.double()).sum().backward()
         fwd(); bw1(); bw2()
         torch.cuda.synchronize()
-        err = (float((out.double() - ref).abs().max()), float((g1.double() - a.grad.double()).abs().max()),
+        err = (float((out.double() - ref.detach()).abs().max()), float((g1.double() - a.grad.double()).abs().max()),
                float((g2.double() - b.grad.double()).abs().max()))
     if only_corr:
         return res, err
-    # feature warp (pwc_tf.py:119 et al.)
-    wf = lambda: ops.warp_flow(f2, flow, use_mask=False)
-    res["warp_flow_fwd"] = (timeit(wf), (2 * C + 2) * H * W * 4 * B)
-    x2 = f2.clone().requires_grad_(True)
-    fl = flow.clone().requires_grad_(True)
-    y = ops.warp_flow(x2, fl, use_mask=False)
-    gy = torch.randn_like(y)
-    wb = lambda: torch.autograd.grad(y, (x2, fl), gy, retain_graph=True)
-    res["warp_flow_bwd (+scatter passes)"] = (timeit(wb), (3 * C + 4 + C) * H * W * 4 * B)
-    # the fused level input and its backward
-    c1 = f1.clone().requires_grad_(True)
-    c2 = f2.clone().requires_grad_(True)
-    fl2 = flow.clone().requires_grad_(True)
-    lv = lambda: ops.pwc_level_input(c1, c2, fl2)
-    res["pwc_level_fwd (warp+corr+cat)"] = (timeit(lv), ((2 * C + 2) + (2 * C + 81) + 2 * (C + 2)) * H * W * 4 * B)
-    x = lv()
-    gx = torch.randn_like(x)
-    lb = lambda: torch.autograd.grad(x, (c1, c2, fl2), gx, retain_graph=True)
-    res["pwc_level_bwd"] = (timeit(lb), (2 * (2 * C + 81) + (C + 2) + (4 * C + 4)) * H * W * 4 * B)
+    # feature warp (pwc_tf.py:119 et al.) and the fused level input: straight through the C ABI with caller-owned buffers (the
+    # autograd wrappers add allocations and Python time that the training step hides behind its GPU work)
+    HW, n = H * W, B * C * H * W
+    warped, gflow, gx2 = torch.empty_like(f2), torch.empty_like(flow), torch.empty_like(f2)
+    ws = torch.empty(lib.dfe_scatter_ws_bytes(n) // 4 + 4, device=dev, dtype=torch.float32)
+    gy = torch.randn(B, C, H, W, generator=g).to(dev)
+    wf = lambda: check(lib.dfe_warp_flow_fwd(ptr(f2), ptr(flow), ptr(warped), B, C, H, W, 0, 0, s), "wf")
+    wb = lambda: check(lib.dfe_warp_flow_bwd(ptr(f2), ptr(flow), ptr(gy), ptr(gflow), ptr(gx2), ptr(ws), B, C, H, W, 0, 0, s), "wb")
+    res["warp_flow_fwd"] = (timeit(wf, iters), (2 * C + 2) * HW * 4 * B)
+    res["warp_flow_bwd (zero-fill + max + scatter + convert: 4 launches)"] = (timeit(wb, iters), (4 * C + 4) * HW * 4 * B)
+    x = torch.empty(B, lib.dfe_pwc_level_channels(C), H, W, device=dev)
+    gxl = torch.randn_like(x)
+    g_w, g_c1, g_c2, g_fl = torch.empty_like(f1), torch.empty_like(f1), torch.empty_like(f1), torch.empty_like(flow)
+    lv = lambda: check(lib.dfe_pwc_level_fwd(ptr(f1), ptr(f2), ptr(flow), ptr(warped), ptr(x), B, C, H, W, 0, s), "lvl")
+    lb = lambda: check(lib.dfe_pwc_level_bwd(ptr(f1), ptr(f2), ptr(flow), ptr(warped), ptr(gxl), ptr(g_w), ptr(g_c1), ptr(g_c2), ptr(ws),
+                                             ptr(g_fl), B, C, H, W, 0, s), "lvlb")
+    res["pwc_level_fwd (warp + corr + c1 / flow planes: 2 launches)"] = (timeit(lv, iters), ((2 * C + 2) + (2 * C + 81) + 2 * (C + 2)) * HW * 4 * B)
+    res["pwc_level_bwd (zero-fill + corr both gradients + warp scatter + convert: 4 launches)"] = (timeit(lb, iters), (2 * (2 * C + 81) + (C + 2) + (4 * C + 4)) * HW * 4 * B)
     return res, err
 
 
@@ -149,6 +148,11 @@ def main():
             best.sort()
             print("level %d bwd  best (g1+g2 us, g1, g2, TH, NCG, IS):" % lvl, ["%.1f %.1f %.1f %d %d %d" % b for b in best[:6]], flush=True)
         return
+    print("# PWC-side hot-path kernels against ALGORITHMIC bytes (tools/corr_bench.py%s, MI355X)\n" % (" --check" if a.check else ""))
+    print("HIP-event time per launch (50 launches back to back, so a launch's floor of ~5 us is in every figure) against the bytes the")
+    print("operator cannot avoid: correlation forward (2C + 81) H W 4 B, both gradients (4C + 81) H W 4; feature warp forward (2C + 2) H W 4,")
+    print("backward (4C + 4) H W 4; the fused level input = warp + correlation + the c1 / flow planes.  The five PWC levels of a 256x832")
+    print("frame, B = %d (target, source) pairs = BASELINE configs[2]; flows are smooth (low-resolution noise up-sampled, ~2 px).\n" % B)
     print("| level (C, H x W), B = %d | kernel / operator | algorithmic MB | us | alg GB/s | frac of 8 TB/s |" % B)
     print("|---|---|---|---|---|---|")
     tot = {}
@@ -164,6 +168,9 @@ def main():
         return
     print("correlation per training step (one PWC pass over the 2B pairs): fwd %.1f + bwd %.1f us"
           % (tot["corr_fwd"], tot["corr_bwd (g1 + g2, one launch)"]))
+    lv = [k for k in tot if k.startswith("pwc_level")]
+    print("level inputs per training step (levels 5..2 run the fused operator; level 6 the plain correlation): fwd %.1f + bwd %.1f us"
+          % (tot[lv[0]], tot[lv[1]]))
 
 
 if __name__ == "__main__":

@@ -73,6 +73,8 @@ long scatter_ws_bytes(long n);
 // zero-fills the n accumulators and sets the bound to max |amax_of[0 .. amax_n)| (the gradient about to be scattered:
 // the taps' weights are <= 1, so it bounds every contribution)
 int scatter_begin(void* ws, long n, const float* amax_of, long amax_n, hipStream_t st);
+// max |amax_of[0 .. amax_n)| as a bit pattern into a zeroed header word (what scatter_begin does after its zero-fill)
+int scatter_amax_into(unsigned* header, const float* amax_of, long amax_n, hipStream_t st);
 // zero-fill only: a kernel of the caller writes the bound (an analytic one) into word 0 before the scatter
 int scatter_begin_bound(void* ws, long n, hipStream_t st);
 // zero-fill and a constant bound (e.g. 1 for a scatter of bilinear weights)

@@ -12,6 +12,7 @@
 #include "dfe_camera.h"
 #include "dfe_scatter.h"
 #include <cstdint>
+#include <cstdlib>
 
 namespace dfe {
 
@@ -141,8 +142,9 @@ __global__ void __launch_bounds__(64) k_warp_flow_fwd(const float* __restrict__ 
 // partial (d/dix, d/diy) sums in registers; the groups' partials meet in LDS and are added in group order, so gflow
 // is written once per pixel and is bitwise reproducible (no float atomics, no zero-fill).
 // grid: x = pixel blocks of 64, y = 1, z = sample.
-constexpr int WF_GROUPS = 4;
-
+// WF_GROUPS: 4 on the large planes; 16 on the small ones (a PWC level of 16x52 is 104 blocks: every block walks all the
+// channels, so the groups are what parallelism there is -- one round of loads per group instead of three)
+template <int WF_GROUPS>
 __global__ void __launch_bounds__(64 * WF_GROUPS) k_warp_flow_bwd(const float* __restrict__ x, const float* __restrict__ flow,
                                                       const float* __restrict__ gout, float* __restrict__ gflow,
                                                       void* __restrict__ gx_ws, const float* __restrict__ gflow_add, long gfa_bs,
@@ -225,6 +227,120 @@ __global__ void __launch_bounds__(64 * WF_GROUPS) k_warp_flow_bwd(const float* _
       gf[p] = vx; gf[HW + p] = vy;
     }
   }
+}
+
+// ---------------------------------------------------------------------- gx of warp_flow as a GATHER (round 4)
+// The scatter above issues one 64-bit atomic per (channel, pixel, tap with a non-zero weight): with the zero flows of a
+// freshly initialised PWC net that is one atomic per element (61 us at 32 x 64 x 208 x 8), with real flows four (224 us:
+// profiles/r04_pwc_roofline_table.md).  The taps depend on the flow only, not on the channel, so for the large levels the
+// inverse map is built once per call -- per target pixel the list of (source pixel, weight) pairs that hit it: count
+// (int atomics on H*W counters), exclusive scan, fill -- and ONE thread per (channel chunk, target pixel) then sums its
+// list in registers.  Every contribution is rounded exactly as the scatter rounds it (to_fixed(g * scale, w)) and the
+// 64-bit integer sums do not depend on the order of the list, so the result is bit-identical to the scatter's, and
+// reproducible, with no atomic on the gradient and no 8-byte accumulator per element.
+// The lists live in the caller's scatter workspace (64 + 8 B*C*H*W bytes): header | cnt[B*HW] | off[B*(HW+1)] | ent[B*4*HW].
+constexpr int WFG_MIN_C = 8, WFG_MIN_HW = 512;     // (measured at the PWC levels: 16x52 gains, 8x26 and below are launch-bound either way)
+static inline bool wfg_eligible(int C, long HW) { return C >= WFG_MIN_C && HW >= WFG_MIN_HW && HW < (1l << 28); }
+static inline size_t wfg_head_bytes(int B, long HW) { return static_cast<size_t>(SCATTER_HEADER_BYTES) + 4ul * B * HW; }    // header + counters: what must be zero
+struct WfgWs { unsigned* header; int* cnt; int* off; int2* ent; };
+static inline WfgWs wfg_layout(void* ws, int B, long HW) {
+  char* base = static_cast<char*>(ws);
+  WfgWs w;
+  w.header = reinterpret_cast<unsigned*>(base);
+  w.cnt = reinterpret_cast<int*>(base + SCATTER_HEADER_BYTES);
+  w.off = w.cnt + static_cast<long>(B) * HW;
+  size_t o = SCATTER_HEADER_BYTES + 4ul * B * HW + 4ul * B * (HW + 1);
+  o = (o + 15) & ~static_cast<size_t>(15);
+  w.ent = reinterpret_cast<int2*>(base + o);
+  return w;
+}
+
+// the (at most four) in-bounds taps with a non-zero weight of source pixel p: target index and weight
+__device__ __forceinline__ int wfg_taps(const float* __restrict__ f, int p, int H, int W, int use_mask, int ac, int (&q)[4], float (&w)[4]) {
+  const int HW = H * W, py = p / W, px = p - py * W;
+  float ix, iy;
+  flow_coords(px, py, f[p], f[HW + p], H, W, ac, ix, iy);
+  const Tap t = make_tap(ix, iy, H, W);
+  if (use_mask && tap_cover(t) < 0.9999f) return 0;
+  int n = 0;
+  const int base = t.y0 * W + t.x0;
+  if (t.in_nw && t.nw != 0.0f) { q[n] = base; w[n++] = t.nw; }
+  if (t.in_ne && t.ne != 0.0f) { q[n] = base + 1; w[n++] = t.ne; }
+  if (t.in_sw && t.sw != 0.0f) { q[n] = base + W; w[n++] = t.sw; }
+  if (t.in_se && t.se != 0.0f) { q[n] = base + W + 1; w[n++] = t.se; }
+  return n;
+}
+
+// grid: (ceil(HW / 256), B)
+__global__ void __launch_bounds__(256) k_wfg_count(const float* __restrict__ flow, int* __restrict__ cnt, int H, int W, int use_mask, int ac) {
+  const int b = blockIdx.y, HW = H * W, p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  int q[4]; float w[4];
+  const int n = wfg_taps(flow + static_cast<long>(b) * 2 * HW, p, H, W, use_mask, ac, q, w);
+  for (int k = 0; k < n; ++k) atomicAdd(cnt + static_cast<long>(b) * HW + q[k], 1);
+}
+
+// exclusive scan of one sample's counters; grid: B, block: 1024 (thread t owns a contiguous run of the counters)
+__global__ void __launch_bounds__(1024) k_wfg_scan(const int* __restrict__ cnt, int* __restrict__ off, int HW) {
+  __shared__ int part[1024];
+  const int b = blockIdx.x, t = threadIdx.x, per = (HW + 1023) / 1024, lo = min(t * per, HW), hi = min(lo + per, HW);
+  const int* c = cnt + static_cast<long>(b) * HW;
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += c[i];
+  part[t] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {          // Hillis-Steele inclusive scan of the 1024 run sums
+    const int v = (t >= d) ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;
+  int* o = off + static_cast<long>(b) * (HW + 1);
+  for (int i = lo; i < hi; ++i) { o[i] = run; run += c[i]; }
+  if (t == 1023) o[HW] = part[1023];
+}
+
+// grid: (ceil(HW / 256), B); the counters are counted back down to zero (slot = the value before the decrement, minus 1)
+__global__ void __launch_bounds__(256) k_wfg_fill(const float* __restrict__ flow, int* __restrict__ cnt, const int* __restrict__ off,
+                                                  int2* __restrict__ ent, int H, int W, int use_mask, int ac) {
+  const int b = blockIdx.y, HW = H * W, p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  int q[4]; float w[4];
+  const int n = wfg_taps(flow + static_cast<long>(b) * 2 * HW, p, H, W, use_mask, ac, q, w);
+  for (int k = 0; k < n; ++k) {
+    const int slot = atomicSub(cnt + static_cast<long>(b) * HW + q[k], 1) - 1;
+    ent[static_cast<long>(b) * 4 * HW + off[static_cast<long>(b) * (HW + 1) + q[k]] + slot] = make_int2(p, __float_as_int(w[k]));
+  }
+}
+
+// grid: (ceil(HW / 64), ceil(C / 8), B); block: one wave, lane = target pixel
+__global__ void __launch_bounds__(64) k_wfg_gather(const float* __restrict__ gout, const int* __restrict__ off, const int2* __restrict__ ent,
+                                                   const unsigned* __restrict__ header, float* __restrict__ gx, int C, int HW) {
+  const int b = blockIdx.z, c0 = blockIdx.y * WF_CK, q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= HW) return;
+  const ScatterScale sc = scatter_scale(*header);
+  const int nch = min(WF_CK, C - c0);
+  const int* o = off + static_cast<long>(b) * (HW + 1);
+  const int e0 = o[q], e1 = o[q + 1];
+  const int2* e = ent + static_cast<long>(b) * 4 * HW;
+  const float* g = gout + (static_cast<long>(b) * C + c0) * HW;
+  long long acc[WF_CK];
+#pragma unroll
+  for (int c = 0; c < WF_CK; ++c) acc[c] = 0;
+  for (int k = e0; k < e1; ++k) {
+    const int2 pw = e[k];
+    const float w = __int_as_float(pw.y);
+    float v[WF_CK];
+#pragma unroll
+    for (int c = 0; c < WF_CK; ++c) v[c] = g[static_cast<long>(c < nch ? c : 0) * HW + pw.x];
+#pragma unroll
+    for (int c = 0; c < WF_CK; ++c) acc[c] += to_fixed(v[c] * sc.to_fixed, w);       // the scatter's own rounding of each contribution
+  }
+  float* out = gx + (static_cast<long>(b) * C + c0) * HW + q;
+#pragma unroll
+  for (int c = 0; c < WF_CK; ++c)
+    if (c < nch) out[static_cast<long>(c) * HW] = from_fixed(acc[c], sc);
 }
 
 // ====================================================================== inverse_warp2 / rigid flow
@@ -507,6 +623,32 @@ using namespace dfe;
 
 static inline dim3 grid1d(long n, int bs) { return dim3(static_cast<unsigned>((n + bs - 1) / bs)); }
 
+// warp_flow's backward kernel with 4 channel groups per block, or 16 where the plane is small
+static void launch_warp_flow_bwd(dim3 g, hipStream_t st, const float* x, const float* flow, const float* gout, float* gflow, void* gx_ws,
+                                 const float* gflow_add, long gfa_bs, int C, int H, int W, int use_mask, int ac) {
+  if (static_cast<long>(H) * W < 2048 && C > 4 * WF_CK)
+    k_warp_flow_bwd<16><<<g, 64 * 16, 0, st>>>(x, flow, gout, gflow, gx_ws, gflow_add, gfa_bs, C, H, W, use_mask, ac);
+  else
+    k_warp_flow_bwd<4><<<g, 64 * 4, 0, st>>>(x, flow, gout, gflow, gx_ws, gflow_add, gfa_bs, C, H, W, use_mask, ac);
+}
+
+// gx of warp_flow by the gather path: the workspace's header holds the bound and its counters are zero (wfg_head_bytes)
+static int warp_gx_gather(const float* flow, const float* gout, float* gx, void* ws, int B, int C, int H, int W, int use_mask, int ac,
+                          hipStream_t st) {
+  const long HW = static_cast<long>(H) * W;
+  const WfgWs w = wfg_layout(ws, B, HW);
+  const dim3 gp(static_cast<unsigned>((HW + 255) / 256), B);
+  k_wfg_count<<<gp, 256, 0, st>>>(flow, w.cnt, H, W, use_mask, ac);
+  DFE_LAUNCH_CHECK();
+  k_wfg_scan<<<B, 1024, 0, st>>>(w.cnt, w.off, static_cast<int>(HW));
+  DFE_LAUNCH_CHECK();
+  k_wfg_fill<<<gp, 256, 0, st>>>(flow, w.cnt, w.off, w.ent, H, W, use_mask, ac);
+  DFE_LAUNCH_CHECK();
+  k_wfg_gather<<<dim3(static_cast<unsigned>((HW + 63) / 64), (C + WF_CK - 1) / WF_CK, B), 64, 0, st>>>(gout, w.off, w.ent, w.header, gx, C, static_cast<int>(HW));
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
 extern "C" {
 
 int dfe_camera_floats(void) { return static_cast<int>(sizeof(Camera) / sizeof(float)); }
@@ -558,9 +700,20 @@ int dfe_warp_flow_bwd(const float* x, const float* flow, const float* gout, floa
   DFE_REQUIRE(B <= 65535 && (C + WF_CK - 1) / WF_CK <= 65535, DFE_ERR_DIMS);
   dim3 g(static_cast<unsigned>((static_cast<long>(H) * W + 63) / 64), 1, B);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const long n = static_cast<long>(B) * C * H * W;
+  const long HW = static_cast<long>(H) * W, n = static_cast<long>(B) * C * HW;
+  if (gx && wfg_eligible(C, HW) && getenv("DFE_WARP_SCATTER") == nullptr) {
+    // large planes: gx as a gather over the inverse map of the flow (above); the bound of the contributions first
+    if (reinterpret_cast<uintptr_t>(gx_ws) & 15) return DFE_ERR_DIMS;
+    if (hipMemsetAsync(gx_ws, 0, wfg_head_bytes(B, HW), st) != hipSuccess) return DFE_ERR_LAUNCH;
+    { const int rc = scatter_amax_into(static_cast<unsigned*>(gx_ws), gout, n, st); if (rc != DFE_OK) return rc; }
+    if (gflow) {
+      launch_warp_flow_bwd(g, st, x, flow, gout, gflow, nullptr, nullptr, 0, C, H, W, use_mask, align_corners);
+      DFE_LAUNCH_CHECK();
+    }
+    return warp_gx_gather(flow, gout, gx, gx_ws, B, C, H, W, use_mask, align_corners, st);
+  }
   if (gx) { const int rc = scatter_begin(gx_ws, n, gout, n, st); if (rc != DFE_OK) return rc; }
-  k_warp_flow_bwd<<<g, 64 * WF_GROUPS, 0, st>>>(x, flow, gout, gflow, gx ? gx_ws : nullptr, nullptr, 0, C, H, W, use_mask, align_corners);
+  launch_warp_flow_bwd(g, st, x, flow, gout, gflow, gx ? gx_ws : nullptr, nullptr, 0, C, H, W, use_mask, align_corners);
   DFE_LAUNCH_CHECK();
   if (gx) return scatter_finish(gx_ws, gx, n, st);
   return DFE_OK;
@@ -701,16 +854,23 @@ int dfe_pwc_level_bwd(const float* c1, const float* c2, const float* flow, const
   const long HW = static_cast<long>(H) * W, xbs = static_cast<long>(dfe_pwc_level_channels(C)) * HW;
   const float* gx_c1 = gx + static_cast<long>(CR_K) * CR_K * HW;
   const float* gx_flow = gx_c1 + static_cast<long>(C) * HW;
-  // the feature-warp scatter's accumulators are zeroed first: the correlation backward writes their bound (max |dL/dwarped|,
-  // the gradient about to be scattered) from its epilogue -- round 3 spent a launch of its own on that max
+  // the feature-warp gradient's workspace is zeroed first: the correlation backward writes the bound of its contributions
+  // (max |dL/dwarped|, the gradient about to be scattered) from its epilogue -- round 3 spent a launch of its own on that max
   const long n = static_cast<long>(B) * C * HW;
-  if (g_c2) { const int rc = scatter_begin_bound(g_c2_ws, n, st); if (rc != DFE_OK) return rc; }
+  const bool gather = g_c2 && wfg_eligible(C, HW) && getenv("DFE_WARP_SCATTER") == nullptr;
+  if (gather) {
+    if (reinterpret_cast<uintptr_t>(g_c2_ws) & 15) return DFE_ERR_DIMS;
+    if (hipMemsetAsync(g_c2_ws, 0, wfg_head_bytes(B, HW), st) != hipSuccess) return DFE_ERR_LAUNCH;
+  } else if (g_c2) { const int rc = scatter_begin_bound(g_c2_ws, n, st); if (rc != DFE_OK) return rc; }
   // dL/dc1 = correlation gradient + the concatenated copy's slice; dL/dwarped
   { const int rc = launch_corr_bwd(c1, warped, gx, xbs, gx_c1, xbs, g_c1, g_warped, g_c2 ? static_cast<unsigned*>(g_c2_ws) : nullptr, B, C, H, W, st); if (rc != DFE_OK) return rc; }
   DFE_LAUNCH_CHECK();
   dim3 g(static_cast<unsigned>((HW + 63) / 64), 1, B);
-  k_warp_flow_bwd<<<g, 64 * WF_GROUPS, 0, st>>>(c2, flow, g_warped, g_flow, g_c2 ? g_c2_ws : nullptr, g_flow ? gx_flow : nullptr, xbs, C, H, W, 0, align_corners);
-  DFE_LAUNCH_CHECK();
+  if (!gather || g_flow) {
+    launch_warp_flow_bwd(g, st, c2, flow, g_warped, g_flow, (g_c2 && !gather) ? g_c2_ws : nullptr, g_flow ? gx_flow : nullptr, xbs, C, H, W, 0, align_corners);
+    DFE_LAUNCH_CHECK();
+  }
+  if (gather) return warp_gx_gather(flow, g_warped, g_c2, g_c2_ws, B, C, H, W, 0, align_corners, st);
   if (g_c2) return scatter_finish(g_c2_ws, g_c2, n, st);
   return DFE_OK;
 }

@@ -52,13 +52,17 @@ int scatter_begin_bound(void* ws, long n, hipStream_t st) {
   return DFE_OK;
 }
 
+int scatter_amax_into(unsigned* header, const float* amax_of, long amax_n, hipStream_t st) {
+  if (!header || !amax_of || amax_n <= 0) return DFE_ERR_NULL;
+  const long blocks = (amax_n + 256 * 4 * 4 - 1) / (256 * 4 * 4);      // >= 4 float4 per thread
+  k_scatter_amax<<<static_cast<unsigned>(blocks > 1024 ? 1024 : blocks), 256, 0, st>>>(amax_of, amax_n, header);
+  return hipGetLastError() == hipSuccess ? DFE_OK : DFE_ERR_LAUNCH;
+}
+
 int scatter_begin(void* ws, long n, const float* amax_of, long amax_n, hipStream_t st) {
   const int rc = scatter_begin_bound(ws, n, st);
   if (rc != DFE_OK) return rc;
-  if (!amax_of || amax_n <= 0) return DFE_ERR_NULL;
-  const long blocks = (amax_n + 256 * 4 * 4 - 1) / (256 * 4 * 4);      // >= 4 float4 per thread
-  k_scatter_amax<<<static_cast<unsigned>(blocks > 1024 ? 1024 : blocks), 256, 0, st>>>(amax_of, amax_n, static_cast<unsigned*>(ws));
-  return hipGetLastError() == hipSuccess ? DFE_OK : DFE_ERR_LAUNCH;
+  return scatter_amax_into(static_cast<unsigned*>(ws), amax_of, amax_n, st);
 }
 
 __global__ void k_scatter_set_bound(unsigned* header, float bound) { *header = static_cast<unsigned>(__float_as_int(bound)); }
