@@ -238,6 +238,26 @@ int dfe_wgrad3x3_fwd(const float* p, const float* gy, float* gweight, float* par
 int dfe_thin_conv3x3(const float* in, const float* weight, float* out, int B, int Ci, int Co, int Hi, int Wi, int P,
                      int transposed_weight, void* stream);
 
+/* ---- 3x3 / stride 1 / pad 1 convolutions on small planes (H*W <= 4096 per sample) on the fp32 matrix cores: PWC's decoder
+ * levels 6 and 5 (pwc_tf.py:28-47 conv6_0 .. conv5_4 = Conv2d(3x3, pad 1, bias) + LeakyReLU(0.1), called at
+ * pwc_tf.py:113-135), where MIOpen's kernels are launch- and layout-bound (10-45 us forward, 26-126 us per weight gradient
+ * for 0.1-0.4 GFLOP).  x [B,Ci,H,W], weight [Co,Ci,3,3], all fp32 NCHW contiguous.
+ * dfe_planeconv_fwd:   y = act(conv(x, weight) + bias[co]) (bias may be NULL; act(v) = v > 0 ? v : slope * v, slope 1 = none)
+ *                      written to dst1 and (optional) dst2: element (b,co,i) at dst + b * batch_stride + co*H*W + i, so the
+ *                      output lands in the channel slices of the concatenated buffers that consume it.
+ * dfe_planeconv_dgrad: gx [B,Ci,H,W] = the data gradient of conv(x, weight) for the output gradient gy [B,Co,H,W].
+ * dfe_planeconv_wgrad: gweight [Co,Ci,3,3] = the weight gradient.
+ * ws: dfe_planeconv_ws_floats floats of scratch (partial sums of the split reductions; every sum is added in a fixed order:
+ * results are reproducible).  DFE_ERR_UNSUPPORTED (dfe_planeconv_supported == 0) for larger planes: the caller keeps MIOpen. */
+int dfe_planeconv_supported(int B, int Ci, int Co, int H, int W);
+long dfe_planeconv_ws_floats(int B, int Ci, int Co, int H, int W);
+int dfe_planeconv_fwd(const float* x, const float* weight, const float* bias, float slope, float* dst1, long dst1_batch_stride,
+                      float* dst2, long dst2_batch_stride, float* ws, int B, int Ci, int Co, int H, int W, void* stream);
+int dfe_planeconv_dgrad(const float* gy, const float* weight, float* gx, float* ws, int B, int Ci, int Co, int H, int W,
+                        void* stream);
+int dfe_planeconv_wgrad(const float* gy, const float* x, float* gweight, float* ws, int B, int Ci, int Co, int H, int W,
+                        void* stream);
+
 /* ---- grouped training-mode BatchNorm2d (+ residual + ReLU) of the depth encoder (SURVEY.md 8(f) rank 1;
  * depth_model.py:60-95 = torchvision BasicBlock conv-bn-relu-conv-bn-(+identity)-relu; model_geometry.py:786-788 calls the
  * depth net once per frame).  x [G*Bg,C,H,W] is G groups of Bg consecutive samples: statistics are per (group, channel)

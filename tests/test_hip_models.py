@@ -58,12 +58,13 @@ def test_g7_full_model_vs_reference(golden_dir):
     np.testing.assert_allclose(float(f.mean()), g["eval_flow_stats"][0], rtol=1e-3)
 
 
-@pytest.mark.parametrize("lvl,hw,B", [(6, (4, 13), 8), (4, (16, 52), 3), (2, (64, 208), 2)])
+@pytest.mark.parametrize("lvl,hw,B", [(6, (4, 13), 8), (5, (8, 26), 8), (4, (16, 52), 3), (2, (64, 208), 2)])
 def test_pwc_dense_block_matches_composition(lvl, hw, B):
     """PWC_tf._decode as one operator (ops.dense_decode: epilogues writing into the concatenated buffers, manual
     convolution backward) against the plain module composition of the same level on the same device: outputs and
     every gradient (input, five conv weights / biases, flow head) to 1e-6 of their scale (same MIOpen calls; only the
-    order of the two-term gradient sums can differ)."""
+    order of the two-term gradient sums can differ).  Levels 6 and 5 run this build's small-plane convolutions
+    (ops_planeconv.hip) instead of MIOpen's: fp32 sums in another order, held to 2e-5."""
     from unsupervised_depth_opticalflow_egomotion_amd.networks.pwc_tf import PWC_tf
     torch.manual_seed(5 + lvl)
     pw = PWC_tf().to(dev())
@@ -88,9 +89,10 @@ def test_pwc_dense_block_matches_composition(lvl, hw, B):
         return [flow.detach(), x4.detach(), xi.grad] + [params[n].grad.clone() for n in names]
 
     a, b = run(True), run(False)
+    tol = 2e-5 if hw[0] * hw[1] <= 208 else 1e-6
     for i, (u, v) in enumerate(zip(a, b)):
         scale = float(v.abs().max())
-        assert float((u - v).abs().max()) <= 1e-6 * scale + 1e-9, (i, float((u - v).abs().max()), scale)
+        assert float((u - v).abs().max()) <= tol * scale + 1e-9, (i, float((u - v).abs().max()), scale)
 
 
 def test_pwc_hip_vs_oracle_ops():

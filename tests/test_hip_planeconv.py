@@ -1,0 +1,73 @@
+"""GPU: the small-plane 3x3 convolutions (csrc/ops_planeconv.hip: forward + bias + LeakyReLU into two concatenated buffers,
+data gradient, weight gradient; reference pwc_tf.py:28-47 / 113-135) through the C ABI against float64
+``aten::convolution`` / ``convolution_backward`` of the same tensors.  Tolerance: 1e-5 of the result's scale (fp32 fma
+chains in a different order than MIOpen's; the float64 reference is the arbiter), results reproducible bit for bit."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from unsupervised_depth_opticalflow_egomotion_amd import ops
+from unsupervised_depth_opticalflow_egomotion_amd._lib import get_lib
+
+pytestmark = pytest.mark.gpu
+
+# (B, Ci, Co, H, W): every layer of PWC levels 6 and 5 at 256x832 (B = 8 pairs), ragged / tiny / one-row / wide cases
+SHAPES = [(8, 81, 128, 4, 13), (8, 128, 128, 4, 13), (8, 256, 96, 4, 13), (8, 224, 64, 4, 13), (8, 160, 32, 4, 13),
+          (8, 211, 128, 8, 26), (8, 128, 128, 8, 26), (8, 256, 96, 8, 26), (8, 224, 64, 8, 26), (8, 160, 32, 8, 26),
+          (1, 1, 1, 1, 1), (2, 3, 5, 3, 5), (3, 17, 33, 1, 70), (2, 20, 70, 9, 7), (1, 36, 48, 16, 52), (2, 5, 16, 64, 2)]
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def close(a, ref, what):
+    scale = float(ref.abs().max())
+    err = float((a.double() - ref).abs().max())
+    assert err <= 1e-5 * scale + 1e-12, (what, err, scale)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_planeconv_matches_float64(shape):
+    B, Ci, Co, H, W = shape
+    assert get_lib().dfe_planeconv_supported(B, Ci, Co, H, W) == 1
+    torch.manual_seed(sum(shape))
+    x = torch.randn(B, Ci, H, W, device=dev())
+    w = torch.randn(Co, Ci, 3, 3, device=dev()) / (3.0 * Ci ** 0.5)
+    bias = torch.randn(Co, device=dev())
+    gy = torch.randn(B, Co, H, W, device=dev())
+    # forward + bias + LeakyReLU(0.1) into channel slices of two wider buffers
+    d1 = torch.full((B, Co + 3, H, W), 7.0, device=dev())
+    d2 = torch.full((B, Co + 5, H, W), 9.0, device=dev())
+    ops.planeconv_fwd_into(x, w, bias, 0.1, d1, 3, d2, 0)
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), bias.double(), 1, 1), 0.1)
+    close(d1[:, 3:], ref, "fwd d1")
+    assert torch.equal(d1[:, 3:], d2[:, :Co]) and bool((d1[:, :3] == 7.0).all()) and bool((d2[:, Co:] == 9.0).all())
+    y = ops.planeconv_forward(x, w)                       # no bias, no activation
+    close(y, F.conv2d(x.double(), w.double(), None, 1, 1), "fwd raw")
+    assert torch.equal(y, ops.planeconv_forward(x, w))    # fixed-order sums
+    gx, gw = ops.planeconv_backward(gy, x, w)
+    rgx, rgw, _ = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), None, [1, 1], [1, 1], [1, 1], False,
+                                                      [0, 0], 1, [True, True, False])
+    close(gx, rgx, "dgrad")
+    close(gw, rgw, "wgrad")
+    gx2, gw2 = ops.planeconv_backward(gy, x, w)
+    assert torch.equal(gx, gx2) and torch.equal(gw, gw2)
+
+
+def test_planeconv_rejects_large_planes_and_null():
+    lib = get_lib()
+    assert lib.dfe_planeconv_supported(8, 64, 64, 64, 208) == 0 and lib.dfe_planeconv_ws_floats(8, 64, 64, 64, 208) == 0
+    x = torch.zeros(1, 4, 64, 208, device=dev())
+    w = torch.zeros(4, 4, 3, 3, device=dev())
+    assert not ops.planeconv_eligible(x, w)
+    assert lib.dfe_planeconv_fwd(None, None, None, 1.0, None, 0, None, 0, None, 1, 1, 1, 1, 1, None) != 0
+
+
+def test_planeconv_nonfinite_inputs_propagate():
+    x = torch.randn(1, 8, 4, 13, device=dev())
+    w = torch.randn(16, 8, 3, 3, device=dev())
+    x[0, 3, 2, 5] = float("nan")
+    y = ops.planeconv_forward(x, w)
+    ref = F.conv2d(x, w, None, 1, 1)
+    assert torch.equal(torch.isnan(y), torch.isnan(ref))

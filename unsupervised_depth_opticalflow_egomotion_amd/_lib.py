@@ -41,6 +41,11 @@ _SIGNATURES = {
     "dfe_thin_conv3x3": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dfe_wgrad3x3_partials_floats": [_I, _I, _I, _I, _I],
     "dfe_wgrad3x3_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dfe_planeconv_supported": [_I, _I, _I, _I, _I],
+    "dfe_planeconv_ws_floats": [_I, _I, _I, _I, _I],
+    "dfe_planeconv_fwd": [_P, _P, _P, ctypes.c_float, _P, ctypes.c_long, _P, ctypes.c_long, _P, _I, _I, _I, _I, _I, _P],
+    "dfe_planeconv_dgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dfe_planeconv_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_disp_head_partials_floats": [_I, _I, _I, _I],
     "dfe_disp_head_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_disp_head_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -96,7 +101,7 @@ _RESTYPES = {"dfe_error_string": ctypes.c_char_p, "dfe_geom_workspace_floats": c
              "dfe_bias_act_partials_floats": ctypes.c_long, "dfe_glue_partials_floats": ctypes.c_long,
              "dfe_bn_partials_floats": ctypes.c_long, "dfe_disp_head_partials_floats": ctypes.c_long,
              "dfe_flow_head_partials_floats": ctypes.c_long,
-             "dfe_wgrad3x3_partials_floats": ctypes.c_long,
+             "dfe_wgrad3x3_partials_floats": ctypes.c_long, "dfe_planeconv_ws_floats": ctypes.c_long,
              "dfe_geom_maskpack_offset_bytes": ctypes.c_long, "dfe_scatter_ws_bytes": ctypes.c_long}
 
 

@@ -588,6 +588,60 @@ def bias_act(z, bias, slope):
     return BiasActFn.apply(z, bias, float(slope))
 
 
+# --------------------------------------------------------------------------- small-plane 3x3 convolutions (fp32 MFMA)
+# Planes of at most this many pixels per sample take the dfe_planeconv_* kernels inside DenseDecodeFn (PWC levels 6 and 5 of
+# a 256x832 frame: 52 and 208 pixels); 0 = every layer stays on MIOpen.
+PLANECONV_MAX_HW = int(os.environ.get("DFE_PLANECONV_MAX_HW", "208"))
+
+
+def planeconv_eligible(x, w):
+    if PLANECONV_MAX_HW <= 0 or not x.is_cuda or convs.get_compute_dtype() is not None or x.dim() != 4:
+        return False
+    B, Ci, H, W = x.shape
+    return (x.dtype == torch.float32 and w.dtype == torch.float32 and tuple(w.shape[1:]) == (Ci, 3, 3)
+            and H * W <= PLANECONV_MAX_HW and get_lib().dfe_planeconv_supported(B, Ci, int(w.shape[0]), H, W) == 1)
+
+
+def _planeconv_ws(B, Ci, Co, H, W, dev):
+    return torch.empty(get_lib().dfe_planeconv_ws_floats(B, Ci, Co, H, W), device=dev, dtype=torch.float32)
+
+
+def planeconv_fwd_into(x, w, bias, slope, d1, d1_off=0, d2=None, d2_off=0):
+    """act(conv3x3(x, w) + bias) into channels d1_off.. of d1 and (optionally) d2_off.. of d2 (contiguous NCHW buffers)."""
+    B, Ci, H, W = x.shape
+    Co, HW = int(w.shape[0]), H * W
+    p1 = ctypes.c_void_p(d1.data_ptr() + 4 * d1_off * HW)
+    p2 = ctypes.c_void_p(d2.data_ptr() + 4 * d2_off * HW) if d2 is not None else None
+    ws = _planeconv_ws(B, Ci, Co, H, W, x.device)
+    check(get_lib().dfe_planeconv_fwd(ptr(x), ptr(w), ptr(bias), float(slope), p1, d1.stride(0), p2,
+                                      d2.stride(0) if d2 is not None else 0, ptr(ws), B, Ci, Co, H, W, stream_ptr()),
+          "dfe_planeconv_fwd")
+
+
+def planeconv_forward(x, w, bias=None, slope=1.0):
+    x, w = f32c(x), f32c(w)
+    y = torch.empty(x.shape[0], w.shape[0], x.shape[2], x.shape[3], device=x.device, dtype=torch.float32)
+    planeconv_fwd_into(x, w, None if bias is None else f32c(bias), slope, y)
+    return y
+
+
+def planeconv_backward(gy, x, w, want_x=True, want_w=True):
+    """(gx, gw) of conv3x3(x, w), pad 1."""
+    gy, x, w = f32c(gy), f32c(x), f32c(w)
+    B, Ci, H, W = x.shape
+    Co = int(w.shape[0])
+    lib = get_lib()
+    ws = _planeconv_ws(B, Ci, Co, H, W, x.device)
+    gx = gw = None
+    if want_x:
+        gx = torch.empty_like(x)
+        check(lib.dfe_planeconv_dgrad(ptr(gy), ptr(w), ptr(gx), ptr(ws), B, Ci, Co, H, W, stream_ptr()), "dfe_planeconv_dgrad")
+    if want_w:
+        gw = torch.empty_like(w)
+        check(lib.dfe_planeconv_wgrad(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, Co, H, W, stream_ptr()), "dfe_planeconv_wgrad")
+    return gx, gw
+
+
 class DenseDecodeFn(torch.autograd.Function):
     """One PWC decoder level's DenseNet-style block (pwc_tf.py:113-118 and the same six lines per level)::
 
@@ -620,23 +674,33 @@ class DenseDecodeFn(torch.autograd.Function):
             check(lib.dfe_bias_act_fwd2(ptr(z), ptr(b[k]), p1, d1.stride(0), p2, d2.stride(0) if d2 is not None else 0,
                                         B, c, H, W, slope, st), "dfe_bias_act_fwd2")
 
-        z0 = convs.raw_forward(x, w[0], 1, 1)
-        epilogue(z0, 0, z0, 0, cat[0], 0)                                   # x0: in place (conv_1's input) + cat0[:, :128]
-        z = convs.raw_forward(z0, w[1], 1, 1)
-        epilogue(z, 1, cat[0], co[0], cat[1], 0)                            # x1
-        z = convs.raw_forward(cat[0], w[2], 1, 1)
-        epilogue(z, 2, cat[1], co[1], cat[2], 0)                            # x2
-        z = convs.raw_forward(cat[1], w[3], 1, 1)
-        epilogue(z, 3, cat[2], co[2], cat[3], 0)                            # x3
-        x4 = convs.raw_forward(cat[2], w[4], 1, 1)
-        epilogue(x4, 4, x4, 0, cat[3], co[3])                               # x4: in place (returned) + cat3[:, 64:]
+        plane = planeconv_eligible(x, w[0])      # levels 6 / 5: the convolution and its epilogue are this build's kernels
+        if plane:
+            z0 = torch.empty(B, co[0], H, W, device=dev, dtype=torch.float32)
+            x4 = torch.empty(B, co[4], H, W, device=dev, dtype=torch.float32)
+            planeconv_fwd_into(x, w[0], b[0], slope, z0, 0, cat[0], 0)          # x0
+            planeconv_fwd_into(z0, w[1], b[1], slope, cat[0], co[0], cat[1], 0)  # x1
+            planeconv_fwd_into(cat[0], w[2], b[2], slope, cat[1], co[1], cat[2], 0)
+            planeconv_fwd_into(cat[1], w[3], b[3], slope, cat[2], co[2], cat[3], 0)
+            planeconv_fwd_into(cat[2], w[4], b[4], slope, x4, 0, cat[3], co[3])
+        else:
+            z0 = convs.raw_forward(x, w[0], 1, 1)
+            epilogue(z0, 0, z0, 0, cat[0], 0)                                   # x0: in place (conv_1's input) + cat0[:, :128]
+            z = convs.raw_forward(z0, w[1], 1, 1)
+            epilogue(z, 1, cat[0], co[0], cat[1], 0)                            # x1
+            z = convs.raw_forward(cat[0], w[2], 1, 1)
+            epilogue(z, 2, cat[1], co[1], cat[2], 0)                            # x2
+            z = convs.raw_forward(cat[1], w[3], 1, 1)
+            epilogue(z, 3, cat[2], co[2], cat[3], 0)                            # x3
+            x4 = convs.raw_forward(cat[2], w[4], 1, 1)
+            epilogue(x4, 4, x4, 0, cat[3], co[3])                               # x4: in place (returned) + cat3[:, 64:]
         if flow_head_eligible(cat[3], w[5], b[5]):
             flow = flow_head_fwd_raw(cat[3], f32c(w[5]), f32c(b[5]))
         else:
             flow = F.conv2d(cat[3], w[5], b[5], 1, 1) if convs.get_compute_dtype() is None else \
                 convs.raw_forward(cat[3], w[5], 1, 1) + b[5].view(1, -1, 1, 1)
         ctx.save_for_backward(x, z0, *cat, *w)
-        ctx.slope, ctx.co = slope, co
+        ctx.slope, ctx.co, ctx.plane = slope, co, plane
         ctx.set_materialize_grads(False)
         return flow, x4
 
@@ -654,6 +718,8 @@ class DenseDecodeFn(torch.autograd.Function):
         nw = lambda k: bool(need[2 + 2 * k])
         nb = lambda k: bool(need[3 + 2 * k])
         def cb(g, inp, wt, want_in, want_w, bias_sizes=None, want_b=False):
+            if ctx.plane and not want_b:
+                return planeconv_backward(g, inp, wt, want_in, want_w) + (None,)
             return convs.raw_backward(g, inp, wt, 1, 1, 1, want_in, want_w, want_b)
 
         def epilogue_bwd(k, ysrc, y_off, g1, g1_off, g2, g2_off):
