@@ -14,7 +14,4 @@ int launch_corr_fwd(const float* f1, const float* f2, float* out, long obs, floa
                     hipStream_t st);
 int launch_corr_bwd(const float* f1, const float* f2, const float* gout, long gbs, const float* add1, long abs1, float* g1,
                     float* g2, unsigned* amax2, int B, int C, int H, int W, hipStream_t st);
-
-// ops_wgrad.hip: gw[co][ci][tap] = sum over units of part[u][tap][co][ci] in a fixed order (n = Co * Ci * 9, coci = Co * Ci)
-int launch_wgrad_final(const float* part, float* gw, int n, int nunits, int coci, hipStream_t st);
 }  // namespace dfe

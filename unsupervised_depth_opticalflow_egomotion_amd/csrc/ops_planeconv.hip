@@ -15,11 +15,12 @@
 //   weight gradient (k_planeconv_wgrad):  M = 16 output channels, N = 16 input channels, K = 4 pixels, 9 accumulator tiles
 //     (one per tap) per wave.  Both operands sit in LDS in a row-padded layout (gy with zero pad columns, x with a zero
 //     border), so a tap is a constant address offset and no lane ever tests a border.  One block per (sample, row band,
-//     32 x 32 channel tile); k_wgrad_final (ops_wgrad.hip) adds the per-block partial planes in a fixed order.
+//     32 x 32 channel tile); k_planeconv_finish adds the per-block partial planes in unit order.
 // Bound: launch latency and the LDS round trip of one chunk (the whole of level 6 is 0.5 GFLOP and 2.5 MB of weights).
 #include "dfe_internal.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 
 namespace dfe {
 
@@ -28,6 +29,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int PC_CC = 16;        // channels per staged chunk (4 K-steps per tap)
 constexpr int PC_MT = 64;        // pixels per block: 4 waves x one 16-pixel M tile
 constexpr int PC_KW = PC_CC * 9; // weights per output channel and chunk
+constexpr int PC_XT_MAX = 18;    // activation staging loads per thread and chunk: bounds the plane width
+constexpr int PW_U = 8;          // the same in the weight-gradient kernel
 
 // idx / d for 0 <= idx < 2^20 (d > 0, inv = 1 / d): the quotient's distance to the next integer is >= 0.5 / d, the float
 // error of the product is < idx / d * 2^-22
@@ -37,12 +40,12 @@ __device__ __forceinline__ int fdiv(int idx, float inv) { return static_cast<int
 // DGRAD = false: w [N][Ck][3][3],  out[n][p] = sum_{c,t} x[c][p + d(t)] * w[n][c][t]
 // DGRAD = true : w [Ck][N][3][3],  out[n][p] = sum_{c,t} x[c][p + d(t)] * w[c][n][8 - t]      (x = the output gradient)
 // LDS: xs [PC_CC][XP] (rows r0-1 .. r0+RB-2 of the plane with a zero border, pitch W+2), wl [16*NSUB][KP] ([n][c*9 + t])
-template <int NSUB, bool DGRAD>
+template <int NSUB, bool DGRAD, int XT>
 __global__ void __launch_bounds__(256) k_planeconv(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ part,
                                                    int B, int Ck, int N, int H, int W, int KS, int cps, int RB, int XP, int KP,
                                                    float inv_rbwp, float inv_wp) {
   extern __shared__ float lds[];
-  constexpr int NT = 16 * NSUB;
+  constexpr int NT = 16 * NSUB, WT = NT * PC_KW / 256;
   float* xs = lds;
   float* wl = lds + PC_CC * XP;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = lane & 15, kq = lane >> 4;
@@ -58,37 +61,69 @@ __global__ void __launch_bounds__(256) k_planeconv(const float* __restrict__ x, 
   f32x4 acc[NSUB][2];
 #pragma unroll
   for (int s = 0; s < NSUB; ++s) { acc[s][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc[s][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-  const int E = PC_CC * RB * Wp, rbwp = RB * Wp;
-  const float* xb = x + static_cast<long>(b) * Ck * HW;
-  for (int c0 = cbeg; c0 < cend; c0 += PC_CC) {
+  const int rbwp = RB * Wp;
+  // Staging.  Every load is unconditional from a clamped 32-bit offset and masked when it is written to LDS, so a chunk's
+  // loads (XT + WT per thread) are all in flight at once -- and they are issued for chunk i+1 before chunk i is multiplied.
+  // Activations: 16 threads per channel copy the positions rem = l16 + 16 i of its zero-bordered band (the offsets inside
+  // a plane do not depend on the chunk: computed once).  Weights: 16 threads per row of the slab, 16 i + l16 along it.
+  const int sc = tid >> 4, l16 = tid & 15;
+  int xoff[XT];
+#pragma unroll
+  for (int i = 0; i < XT; ++i) {
+    const int rem = l16 + 16 * i;
+    const int r = fdiv(rem, inv_wp), col = rem - r * Wp;
+    const int gy = r0 - 1 + r, gx = col - 1;
+    xoff[i] = (rem < rbwp && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+  }
+  const unsigned xbase = static_cast<unsigned>(b) * Ck * HW;
+  float xv[XT], wr[WT];
+  auto fetch = [&](int c0) {
     const int nc = min(PC_CC, cend - c0);
-    for (int idx = tid; idx < E; idx += 256) {
-      const int c = fdiv(idx, inv_rbwp), rem = idx - c * rbwp;
-      const int r = fdiv(rem, inv_wp), col = rem - r * Wp;
-      const int gy = r0 - 1 + r, gx = col - 1;
-      float v = 0.0f;
-      if (c < nc && gy >= 0 && gy < H && gx >= 0 && gx < W) v = xb[static_cast<long>(c0 + c) * HW + gy * W + gx];
-      xs[c * XP + rem] = v;
-    }
+    const unsigned cb = xbase + static_cast<unsigned>(c0 + min(sc, nc - 1)) * HW;
+#pragma unroll
+    for (int i = 0; i < XT; ++i) xv[i] = x[cb + static_cast<unsigned>(max(xoff[i], 0))];
     if (!DGRAD) {
-#pragma unroll 6
-      for (int idx = tid; idx < NT * PC_KW; idx += 256) {
-        const int n = idx / PC_KW, j = idx - n * PC_KW;
-        float v = 0.0f;
-        if (n0 + n < N && j < nc * 9) v = w[(static_cast<long>(n0 + n) * Ck + c0) * 9 + j];
-        wl[n * KP + j] = v;
+      const int jmax = nc * 9 - 1;
+#pragma unroll
+      for (int q = 0; q < NSUB; ++q) {
+        const unsigned rb = (static_cast<unsigned>(min(n0 + sc + 16 * q, N - 1)) * Ck + c0) * 9;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) wr[q * 9 + i] = w[rb + static_cast<unsigned>(min(l16 + 16 * i, jmax))];
       }
     } else {
-#pragma unroll 6
-      for (int idx = tid; idx < NT * PC_KW; idx += 256) {
-        const int cl = idx / (NT * 9), r = idx - cl * (NT * 9);
-        const int n = r / 9, t = r - n * 9;
-        float v = 0.0f;
-        if (cl < nc && n0 + n < N) v = w[(static_cast<long>(c0 + cl) * N + n0 + n) * 9 + t];
-        wl[n * KP + cl * 9 + 8 - t] = v;
+      const unsigned rb = (static_cast<unsigned>(c0 + min(sc, nc - 1)) * N + n0) * 9;
+      const int rmax = (N - n0) * 9 - 1;
+#pragma unroll
+      for (int i = 0; i < WT; ++i) wr[i] = w[rb + static_cast<unsigned>(min(l16 + 16 * i, rmax))];
+    }
+  };
+  auto stage = [&](int c0) {
+    const int nc = min(PC_CC, cend - c0);
+#pragma unroll
+    for (int i = 0; i < XT; ++i)
+      if (l16 + 16 * i < rbwp) xs[sc * XP + l16 + 16 * i] = (xoff[i] >= 0 && sc < nc) ? xv[i] : 0.0f;
+    if (!DGRAD) {
+#pragma unroll
+      for (int q = 0; q < NSUB; ++q) {
+        const bool okn = n0 + sc + 16 * q < N;
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+          wl[(sc + 16 * q) * KP + l16 + 16 * i] = (okn && l16 + 16 * i < nc * 9) ? wr[q * 9 + i] : 0.0f;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < WT; ++i) {
+        const int r = l16 + 16 * i, n = r / 9, t = r - n * 9;
+        wl[n * KP + sc * 9 + 8 - t] = (sc < nc && n0 + n < N) ? wr[i] : 0.0f;
       }
     }
+  };
+  if (cbeg < cend) fetch(cbeg);
+  for (int c0 = cbeg; c0 < cend; c0 += PC_CC) {
+    const int nc = min(PC_CC, cend - c0);
+    stage(c0);
     __syncthreads();
+    if (c0 + PC_CC < cend) fetch(c0 + PC_CC);
 #pragma unroll
     for (int cq = 0; cq < PC_CC / 4; ++cq) {
       if (cq * 4 < nc) {
@@ -128,6 +163,7 @@ __global__ void __launch_bounds__(256) k_planeconv_finish(const float* __restric
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   float s = part[idx];
+#pragma unroll 4
   for (int k = 1; k < KS; ++k) s += part[static_cast<long>(k) * total + idx];
   int b = fdiv(idx, inv_nhw);
   int r = idx - b * NHW;
@@ -153,20 +189,53 @@ __global__ void __launch_bounds__(256) k_planeconv_wgrad(const float* __restrict
   const int y0 = band * RS, y1 = min(H, y0 + RS), Q = (y1 - y0) * Wp;
   const float* gb = gy + static_cast<long>(b) * Co * HW;
   const float* xb = x + static_cast<long>(b) * Ci * HW;
-  for (int idx = tid; idx < 32 * Q4; idx += 256) {
+  auto gsite = [&](int idx, long& src, int& dst) -> bool {
     const int c = fdiv(idx, inv_q4), q = idx - c * Q4;
     const int yy = fdiv(q, inv_wp), xx = q - yy * Wp;
-    float v = 0.0f;
-    if (co0 + c < Co && q < Q && xx < W) v = gb[static_cast<long>(co0 + c) * HW + (y0 + yy) * W + xx];
-    gs[c * GP + q] = v;
-  }
-  for (int idx = tid; idx < 32 * XE; idx += 256) {
+    const bool ok = co0 + c < Co && q < Q && xx < W;
+    src = ok ? static_cast<long>(co0 + c) * HW + (y0 + yy) * W + xx : 0L;
+    dst = c * GP + q;
+    return ok;
+  };
+  auto xsite = [&](int idx, long& src, int& dst) -> bool {
     const int c = fdiv(idx, inv_xe), e = idx - c * XE;
     const int r = fdiv(e, inv_wp), col = e - r * Wp;
     const int yy = y0 - 1 + r, xx = col - 1;
-    float v = 0.0f;
-    if (ci0 + c < Ci && yy >= 0 && yy < H && xx >= 0 && xx < W) v = xb[static_cast<long>(ci0 + c) * HW + yy * W + xx];
-    xs[c * XP + e] = v;
+    const bool ok = ci0 + c < Ci && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    src = ok ? static_cast<long>(ci0 + c) * HW + yy * W + xx : 0L;
+    dst = c * XP + e;
+    return ok;
+  };
+  const int EG = 32 * Q4, EX = 32 * XE;
+  for (int base = tid; base < EG; base += 256 * PW_U) {
+    float v[PW_U];
+#pragma unroll
+    for (int u = 0; u < PW_U; ++u) {
+      long src; int dst;
+      gsite(min(base + u * 256, EG - 1), src, dst);
+      v[u] = gb[src];
+    }
+#pragma unroll
+    for (int u = 0; u < PW_U; ++u) {
+      long src; int dst;
+      const bool ok = gsite(min(base + u * 256, EG - 1), src, dst);
+      if (base + u * 256 < EG) gs[dst] = ok ? v[u] : 0.0f;
+    }
+  }
+  for (int base = tid; base < EX; base += 256 * PW_U) {
+    float v[PW_U];
+#pragma unroll
+    for (int u = 0; u < PW_U; ++u) {
+      long src; int dst;
+      xsite(min(base + u * 256, EX - 1), src, dst);
+      v[u] = xb[src];
+    }
+#pragma unroll
+    for (int u = 0; u < PW_U; ++u) {
+      long src; int dst;
+      const bool ok = xsite(min(base + u * 256, EX - 1), src, dst);
+      if (base + u * 256 < EX) xs[dst] = ok ? v[u] : 0.0f;
+    }
   }
   __syncthreads();
   const int wco = wv & 1, wci = wv >> 1;
@@ -181,17 +250,20 @@ __global__ void __launch_bounds__(256) k_planeconv_wgrad(const float* __restrict
     for (int t = 0; t < 9; ++t)
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xa[q0 + (t / 3) * Wp + (t % 3)], acc[t], 0, 0, 0);
   }
-  // D[i][j]: rows i = 4 kq + r = output channel, column j = m = input channel; partial planes are [tap][co][ci]
+  // D[i][j]: rows i = 4 kq + r = output channel, column j = m = input channel; partial planes are [co][ci][tap] like the
+  // weight itself (a lane writes the 9 taps of its four (co, ci) pairs: 36 contiguous bytes each)
   float* po = part + static_cast<long>(blockIdx.x) * Co * Ci * 9;
   const int ci = ci0 + 16 * wci + m;
   if (ci < Ci) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + 16 * wco + 4 * kq + r;
+      if (co < Co) {
+        float* q = po + (static_cast<long>(co) * Ci + ci) * 9;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = co0 + 16 * wco + 4 * kq + r;
-        if (co < Co) po[(static_cast<long>(t) * Co + co) * Ci + ci] = acc[t][r];
+        for (int t = 0; t < 9; ++t) q[t] = acc[t][r];
       }
+    }
   }
 }
 
@@ -203,7 +275,12 @@ using namespace dfe;
 namespace {
 constexpr long PC_MAX_PIXELS = 4096;      // per sample: "small plane"; larger images are MIOpen's
 
-struct PcCfg { int nsub, KS, cps, RB, XP, KP, ntm, ntn; size_t lds; };
+struct PcCfg { int nsub, KS, cps, RB, XP, KP, ntm, ntn, xt; size_t lds; };
+
+int pc_target_blocks() {
+  static const int v = [] { const char* e = getenv("DFE_PLANECONV_BLOCKS"); const int t = e ? atoi(e) : 0; return t > 0 ? t : 512; }();
+  return v;
+}
 
 // forward / data gradient: Ck reduction channels, N output channels
 PcCfg pc_cfg(int B, int Ck, int N, int H, int W) {
@@ -219,7 +296,8 @@ PcCfg pc_cfg(int B, int Ck, int N, int H, int W) {
   g.nsub = (N > 32 && base32 * ((Ck + 31) / 32) >= 1024) ? 4 : 2;
   g.ntn = (N + 16 * g.nsub - 1) / (16 * g.nsub);
   const long base = static_cast<long>(B) * g.ntm * g.ntn;
-  int ks = static_cast<int>((512 + base - 1) / base);
+  g.xt = (g.RB * Wp + 15) / 16;                     // activation loads per thread and chunk
+  int ks = static_cast<int>((pc_target_blocks() + base - 1) / base);
   ks = std::max(1, std::min(ks, (Ck + PC_CC - 1) / PC_CC));
   g.cps = ((Ck + ks - 1) / ks + 3) / 4 * 4;
   g.KS = (Ck + g.cps - 1) / g.cps;
@@ -250,25 +328,33 @@ PwCfg pw_cfg(int B, int H, int W) {
 int pc_dims(int B, int Ci, int Co, int H, int W) {
   if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return DFE_ERR_DIMS;
   if (static_cast<long>(H) * W > PC_MAX_PIXELS || B > 8192 || Ci > 8192 || Co > 8192) return DFE_ERR_UNSUPPORTED;
+  if (((std::min(H, (PC_MT - 1) / W + 2) + 2) * (W + 2) + 15) / 16 > PC_XT_MAX) return DFE_ERR_UNSUPPORTED;   // very wide rows
+  return DFE_OK;
+}
+
+template <int NSUB, bool DGRAD, int XT>
+int pc_launch(const float* x, const float* w, float* part, int B, int Ck, int N, int H, int W, const PcCfg& g, hipStream_t st) {
+  const dim3 grid(g.ntm, g.ntn, B * g.KS);
+  const int Wp = W + 2;
+  k_planeconv<NSUB, DGRAD, XT><<<grid, 256, g.lds, st>>>(x, w, part, B, Ck, N, H, W, g.KS, g.cps, g.RB, g.XP, g.KP,
+                                                         1.0f / static_cast<float>(g.RB * Wp), 1.0f / static_cast<float>(Wp));
+  DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
 
 template <int NSUB, bool DGRAD>
-int pc_launch(const float* x, const float* w, float* part, int B, int Ck, int N, int H, int W, const PcCfg& g, hipStream_t st) {
-  const dim3 grid(g.ntm, g.ntn, B * g.KS);
-  const int Wp = W + 2;
-  k_planeconv<NSUB, DGRAD><<<grid, 256, g.lds, st>>>(x, w, part, B, Ck, N, H, W, g.KS, g.cps, g.RB, g.XP, g.KP,
-                                                     1.0f / static_cast<float>(g.RB * Wp), 1.0f / static_cast<float>(Wp));
-  DFE_LAUNCH_CHECK();
-  return DFE_OK;
+int pc_launch_xt(const float* x, const float* w, float* part, int B, int Ck, int N, int H, int W, const PcCfg& g, hipStream_t st) {
+  if (g.xt <= 6) return pc_launch<NSUB, DGRAD, 6>(x, w, part, B, Ck, N, H, W, g, st);
+  if (g.xt <= 12) return pc_launch<NSUB, DGRAD, 12>(x, w, part, B, Ck, N, H, W, g, st);
+  return pc_launch<NSUB, DGRAD, PC_XT_MAX>(x, w, part, B, Ck, N, H, W, g, st);
 }
 
 int pc_run(bool dgrad, const float* x, const float* w, const float* bias, float slope, float* d1, long bs1, float* d2, long bs2,
            float* ws, int B, int Ck, int N, int H, int W, hipStream_t st) {
   const PcCfg g = pc_cfg(B, Ck, N, H, W);
   int rc;
-  if (g.nsub == 4) rc = dgrad ? pc_launch<4, true>(x, w, ws, B, Ck, N, H, W, g, st) : pc_launch<4, false>(x, w, ws, B, Ck, N, H, W, g, st);
-  else rc = dgrad ? pc_launch<2, true>(x, w, ws, B, Ck, N, H, W, g, st) : pc_launch<2, false>(x, w, ws, B, Ck, N, H, W, g, st);
+  if (g.nsub == 4) rc = dgrad ? pc_launch_xt<4, true>(x, w, ws, B, Ck, N, H, W, g, st) : pc_launch_xt<4, false>(x, w, ws, B, Ck, N, H, W, g, st);
+  else rc = dgrad ? pc_launch_xt<2, true>(x, w, ws, B, Ck, N, H, W, g, st) : pc_launch_xt<2, false>(x, w, ws, B, Ck, N, H, W, g, st);
   if (rc != DFE_OK) return rc;
   const long HW = static_cast<long>(H) * W, total = B * N * HW;
   k_planeconv_finish<<<static_cast<unsigned>((total + 255) / 256), 256, 0, st>>>(
@@ -281,7 +367,8 @@ int pc_run(bool dgrad, const float* x, const float* w, const float* bias, float 
 
 extern "C" int dfe_planeconv_supported(int B, int Ci, int Co, int H, int W) {
   if (pc_dims(B, Ci, Co, H, W) != DFE_OK) return 0;
-  return static_cast<long>(B) * Co * H * W < (1L << 20) && static_cast<long>(B) * Ci * H * W < (1L << 20);   // fdiv's range
+  return static_cast<long>(B) * Co * H * W < (1L << 20) && static_cast<long>(B) * Ci * H * W < (1L << 20) &&
+         static_cast<long>(Co) * Ci * 9 < (1L << 20);   // fdiv's range
 }
 
 extern "C" long dfe_planeconv_ws_floats(int B, int Ci, int Co, int H, int W) {
@@ -329,5 +416,10 @@ extern "C" int dfe_planeconv_wgrad(const float* gy, const float* x, float* gweig
                                               1.0f / static_cast<float>(g.Q4), 1.0f / static_cast<float>(g.XE),
                                               1.0f / static_cast<float>(W + 2));
   DFE_LAUNCH_CHECK();
-  return launch_wgrad_final(ws, gweight, Co * Ci * 9, static_cast<int>(g.units), Co * Ci, st);
+  const int total = Co * Ci * 9;      // the units' partial planes are added in unit order
+  k_planeconv_finish<<<(total + 255) / 256, 256, 0, st>>>(ws, nullptr, gweight, 0, nullptr, 0, total, total, total,
+                                                          static_cast<int>(g.units), 1.0f, 1.0f / static_cast<float>(total),
+                                                          1.0f / static_cast<float>(total));
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
 }

@@ -142,11 +142,6 @@ __global__ void __launch_bounds__(16 * WF_LANES) k_wgrad_final(const float* __re
   }
 }
 
-int launch_wgrad_final(const float* part, float* gw, int n, int nunits, int coci, hipStream_t st) {
-  k_wgrad_final<<<(n + 15) / 16, 16 * WF_LANES, 0, st>>>(part, gw, n, nunits, coci);
-  return hipGetLastError() == hipSuccess ? DFE_OK : DFE_ERR_LAUNCH;
-}
-
 }  // namespace dfe
 
 #define DFE_LAUNCH_CHECK() do { if (hipGetLastError() != hipSuccess) return DFE_ERR_LAUNCH; } while (0)
