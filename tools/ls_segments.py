@@ -9,13 +9,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=4); ap.add_argument("--height", type=int, default=256)
 ap.add_argument("--width", type=int, default=832); ap.add_argument("--scales", type=int, default=3)
 ap.add_argument("--iters", type=int, default=200); ap.add_argument("--tag", default="")
+ap.add_argument("--flow-noise", type=float, default=0.3, help="white noise (px at scale 0) added to the synthetic flows; 0 = smooth rigid flows")
 ap.add_argument("--lib", default="", help="another build of libdfe_hip.so (tools/ablate_point_fwd.sh) instead of the in-tree one")
 a = ap.parse_args()
 if a.lib:
     from unsupervised_depth_opticalflow_egomotion_amd import _lib
     _lib.LIB_PATH = os.path.abspath(a.lib)
 dev = torch.device("cuda:0")
-inp = synthetic.make_loss_stack_inputs(a.batch, a.height, a.width, a.scales, seed=1234, num_flow_scales=max(a.scales, 4) if a.scales > 3 else None)
+inp = synthetic.make_loss_stack_inputs(a.batch, a.height, a.width, a.scales, seed=1234, num_flow_scales=max(a.scales, 4) if a.scales > 3 else None, flow_noise=a.flow_noise)
 g = lambda x, grad=False: torch.from_numpy(np.ascontiguousarray(x)).to(dev).requires_grad_(grad)
 imgs = [g(x) for x in inp.imgs]; disps = [[g(x, True) for x in l] for l in inp.disps]; pose = g(inp.pose, True)
 fb = [g(x, True) for x in inp.flows_bwd]; ff = [g(x, True) for x in inp.flows_fwd]; K, Ki = g(inp.K), g(inp.K_inv)

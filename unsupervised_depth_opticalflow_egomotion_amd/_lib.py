@@ -13,7 +13,9 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdfe_hip.so")
+# DFE_HIP_LIB: another build of the same sources (the ablation / experiment variants tools/*_experiment.sh and tools/*ablate*.sh
+# put under scratch/abl/), for measurements only
+LIB_PATH = os.environ.get("DFE_HIP_LIB") or os.path.join(_HERE, "libdfe_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dfe_hip.h")
 
 _lib = None

@@ -16,6 +16,11 @@
 #include "dfe_scatter.h"
 #include <cstdlib>
 
+// wave footprint of the pointwise kernels: DFE_PB_TILE x (64 / DFE_PB_TILE) pixels (tile_pixel, loss_stack_exact.h); 0 = a row segment
+#ifndef DFE_PB_TILE
+#define DFE_PB_TILE 16
+#endif
+
 namespace dfe {
 
 struct GeomBwd {
@@ -177,14 +182,14 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomT T,
   const int b = blockIdx.y, B = D.B;
   const int s = find_scale(D.blk_start, D.S, blk);
   const int H = D.H[s], W = D.W[s], N = D.N[s];
-  const int p = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
+  const int pl = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
   float acc[PB_COUNT];
 #pragma unroll
   for (int i = 0; i < PB_COUNT; ++i) acc[i] = 0.0f;
-  if (p < N) {
+  if (pl < N) {
     unsigned upx, upy;
-    split_pixel(static_cast<unsigned>(p), W, T.rW[s], upx, upy);
-    const int px = static_cast<int>(upx), py = static_cast<int>(upy);
+    tile_pixel<DFE_PB_TILE>(static_cast<unsigned>(pl), W, H, T.rW[s], upx, upy);     // wave footprint: loss_stack_exact.h
+    const int px = static_cast<int>(upx), py = static_cast<int>(upy), p = py * W + px;
     const Divisor dw = T.dw[s], dh = T.dh[s];
     const long o3 = static_cast<long>(b) * 3 * N + p, o2 = static_cast<long>(b) * 2 * N + p, o1 = static_cast<long>(b) * N + p;
     const float* it = D.pyr[1][s];
@@ -337,9 +342,11 @@ __global__ void __launch_bounds__(GS_BLOCK) k_flow_point_bwd(GeomDev D, GeomBwd 
   const int b = blockIdx.y, B = D.B;
   const int s = find_scale(D.blk_start, D.S, blk);
   const int H = D.H[s], W = D.W[s], N = D.N[s];
-  const int p = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
-  if (p >= N) return;
-  const int py = p / W, px = p - py * W;
+  const int pl = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
+  if (pl >= N) return;
+  unsigned upx, upy;
+  tile_pixel<DFE_PB_TILE>(static_cast<unsigned>(pl), W, H, upx, upy);      // wave footprint: loss_stack_exact.h
+  const int px = static_cast<int>(upx), py = static_cast<int>(upy), p = py * W + px;
   const long o3 = static_cast<long>(b) * 3 * N + p, o2 = static_cast<long>(b) * 2 * N + p;
   const float* it = D.pyr[1][s];
   const float im[3] = {it[o3], it[o3 + N], it[o3 + 2 * N]};
@@ -398,12 +405,14 @@ __global__ void __launch_bounds__(GS_BLOCK) k_depth_point_bwd(GeomDev D, GeomBwd
   const int b = blockIdx.y, B = D.B;
   const int s = find_scale(D.blk_start, D.S, blk);
   const int H = D.H[s], W = D.W[s], N = D.N[s];
-  const int p = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
+  const int pl = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
   float acc[PB_COUNT];
 #pragma unroll
   for (int i = 0; i < PB_COUNT; ++i) acc[i] = 0.0f;
-  if (p < N) {
-    const int py = p / W, px = p - py * W;
+  if (pl < N) {
+    unsigned upx, upy;
+    tile_pixel<DFE_PB_TILE>(static_cast<unsigned>(pl), W, H, upx, upy);    // wave footprint: loss_stack_exact.h
+    const int px = static_cast<int>(upx), py = static_cast<int>(upy), p = py * W + px;
     const long o3 = static_cast<long>(b) * 3 * N + p, o1 = static_cast<long>(b) * N + p;
     const float* it = D.pyr[1][s];
     const float im[3] = {it[o3], it[o3 + N], it[o3 + 2 * N]};

@@ -46,6 +46,48 @@ __device__ __forceinline__ void split_pixel(unsigned p, int W, float rW, unsigne
   px = p - py * static_cast<unsigned>(W);
 }
 
+// Pixel order of the pointwise kernels.  TW = 0: thread p of a scale computes pixel p (a wave = 64 consecutive pixels of a
+// row).  TW = 8 / 16 / 32: a wave covers a TW x (64 / TW) tile -- the bilinear taps of both warps then fall into a few
+// cache lines of 5 rows instead of 2 x 64-pixel row segments shifted by the flow, which is what the texture path is busy
+// with (round 4: k_geom_point_fwd 48.9 -> 43.3 us at B = 4, 616 -> 508 us at 375x1242 B = 16; results unchanged, the
+// per-block partial sums cover other pixels but add up to the same totals).  The linear index is re-read as (group of TR
+// rows, TW-column chunk, row in group, column in chunk); columns past the last full chunk and rows past the last full group
+// keep the row-major order, so the map is a bijection of [0, H*W) for every size.  rW = 1 / W as split_pixel wants it.
+template <int TW>
+__device__ __forceinline__ void tile_pixel(unsigned p, int W, int H, float rW, unsigned& px, unsigned& py) {
+  if (TW == 0) { split_pixel(p, W, rW, px, py); return; }
+  constexpr unsigned TWu = TW > 0 ? TW : 1, TR = 64u / TWu, LG = TWu == 8 ? 3u : TWu == 16 ? 4u : 5u;
+  static_assert(TW == 0 || TW == 8 || TW == 16 || TW == 32, "tile width");
+  const unsigned Wu = static_cast<unsigned>(W);
+  const unsigned g = static_cast<unsigned>((static_cast<float>(p) + 0.5f) * (rW * (1.0f / static_cast<float>(TR))));   // p / (TR * W)
+  if (g < static_cast<unsigned>(H) / TR) {
+    const unsigned q = p - g * TR * Wu, WT = Wu & ~(TWu - 1u);
+    if (q < TR * WT) { px = TWu * (q >> 6) + (q & (TWu - 1u)); py = TR * g + ((q & 63u) >> LG); }
+    else {
+      const unsigned e = q - TR * WT, wr = Wu - WT;
+      const unsigned r = static_cast<unsigned>((static_cast<float>(e) + 0.5f) / static_cast<float>(wr));
+      px = WT + e - r * wr; py = TR * g + r;
+    }
+  } else split_pixel(p, W, rW, px, py);
+}
+
+// the same map with integer divisions (kernels that carry no reciprocal table)
+template <int TW>
+__device__ __forceinline__ void tile_pixel(unsigned p, int W, int H, unsigned& px, unsigned& py) {
+  const unsigned Wu = static_cast<unsigned>(W);
+  if (TW == 0) { py = p / Wu; px = p - py * Wu; return; }
+  constexpr unsigned TWu = TW > 0 ? TW : 1, TR = 64u / TWu, LG = TWu == 8 ? 3u : TWu == 16 ? 4u : 5u;
+  const unsigned g = p / (TR * Wu);
+  if (g < static_cast<unsigned>(H) / TR) {
+    const unsigned q = p - g * TR * Wu, WT = Wu & ~(TWu - 1u);
+    if (q < TR * WT) { px = TWu * (q >> 6) + (q & (TWu - 1u)); py = TR * g + ((q & 63u) >> LG); }
+    else {
+      const unsigned e = q - TR * WT, wr = Wu - WT, r = e / wr;
+      px = WT + e - r * wr; py = TR * g + r;
+    }
+  } else { py = p / Wu; px = p - py * Wu; }
+}
+
 // projection with the correctly rounded short sequences: X / Z and Y / Z share RN(1 / Z) (same bits as project())
 __device__ __forceinline__ Proj project_fast(const Camera& c, int x, int y, float depth) {
   Proj p;

@@ -17,6 +17,11 @@
 #include <cstdint>
 #include <cstdlib>
 
+// wave footprint of the pointwise kernels: DFE_PT_TILE x (64 / DFE_PT_TILE) pixels (tile_pixel, loss_stack_exact.h); 0 = a row segment
+#ifndef DFE_PT_TILE
+#define DFE_PT_TILE 16
+#endif
+
 namespace dfe {
 
 static inline long align4(long v) { return (v + 3) & ~3L; }
@@ -553,8 +558,9 @@ __global__ void __launch_bounds__(GS_BLOCK) DFE_PT_ATTR k_geom_point_fwd(GeomDev
   float dc[2] = {0.0f, 0.0f};
   if (p < static_cast<unsigned>(N)) {
     unsigned px, py;
-    split_pixel(p, W, T.rW[s], px, py);
-    const unsigned p4 = p * 4u, N4 = static_cast<unsigned>(N) * 4u;
+    tile_pixel<DFE_PT_TILE>(p, W, H, T.rW[s], px, py);      // a wave covers a 16 x 4 pixel tile (loss_stack_exact.h)
+    const unsigned pm = py * static_cast<unsigned>(W) + px;   // the pixel this thread computes (index in memory)
+    const unsigned p4 = pm * 4u, N4 = static_cast<unsigned>(N) * 4u;
     PointCtx c;
     c.b = b; c.s = s; c.H = H; c.W = W; c.ac = D.ac; c.N4 = N4; c.p4 = p4; c.alpha = D.alpha; c.beta = D.beta;
     c.srcL = D.pyr[0][s] + static_cast<long>(b) * 3 * N; c.srcR = D.pyr[2][s] + static_cast<long>(b) * 3 * N;
@@ -590,7 +596,7 @@ __global__ void __launch_bounds__(GS_BLOCK) DFE_PT_ATTR k_geom_point_fwd(GeomDev
         for (int ch = 0; ch < 3; ++ch) stb(yrp, p4 + ch * N4, yr[d][ch]);
       }
     }
-    if (!(DFE_ABL & 4)) (D.mask[s] + static_cast<long>(b) * N)[p] = static_cast<unsigned char>(bits);
+    if (!(DFE_ABL & 4)) (D.mask[s] + static_cast<long>(b) * N)[pm] = static_cast<unsigned char>(bits);
     else if (bits == 0x12345u) D.mask[s][1] = 1;
   }
   if (DFE_ABL & 1) {
@@ -617,13 +623,15 @@ __global__ void __launch_bounds__(GS_BLOCK) k_depth_point_fwd(GeomDev D, float* 
   const int b = blockIdx.y;
   const int s = find_scale(D.blk_start, D.S, blk);
   const int H = D.H[s], W = D.W[s], N = D.N[s];
-  const unsigned p = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
+  const unsigned pl = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
   float acc[PT_COUNT];
 #pragma unroll
   for (int i = 0; i < PT_COUNT; ++i) acc[i] = 0.0f;
   float dc[2] = {0.0f, 0.0f};
-  if (p < static_cast<unsigned>(N)) {
-    const unsigned py = p / static_cast<unsigned>(W), px = p - py * W;
+  if (pl < static_cast<unsigned>(N)) {
+    unsigned px, py;
+    tile_pixel<DFE_PT_TILE>(pl, W, H, px, py);               // wave footprint: loss_stack_exact.h
+    const unsigned p = py * static_cast<unsigned>(W) + px;
     const unsigned p4 = p * 4u, N4 = static_cast<unsigned>(N) * 4u;
     const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
     const float i0 = ldb(it, p4), i1 = ldb(it, p4 + N4), i2 = ldb(it, p4 + 2 * N4);
@@ -676,12 +684,14 @@ __global__ void __launch_bounds__(GS_BLOCK) k_flow_point_fwd(GeomDev D, float* _
   const int b = blockIdx.y;
   const int s = find_scale(D.blk_start, D.S, blk);
   const int H = D.H[s], W = D.W[s], N = D.N[s];
-  const unsigned p = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
+  const unsigned pl = (blk - D.blk_start[s]) * GS_BLOCK + threadIdx.x;
   float acc[PT_COUNT];
 #pragma unroll
   for (int i = 0; i < PT_COUNT; ++i) acc[i] = 0.0f;
-  if (p < static_cast<unsigned>(N)) {
-    const unsigned py = p / static_cast<unsigned>(W), px = p - py * W;
+  if (pl < static_cast<unsigned>(N)) {
+    unsigned px, py;
+    tile_pixel<DFE_PT_TILE>(pl, W, H, px, py);               // wave footprint: loss_stack_exact.h
+    const unsigned p = py * static_cast<unsigned>(W) + px;
     const unsigned p4 = p * 4u, N4 = static_cast<unsigned>(N) * 4u;
     const float* it = D.pyr[1][s] + static_cast<long>(b) * 3 * N;
     const float i0 = ldb(it, p4), i1 = ldb(it, p4 + N4), i2 = ldb(it, p4 + 2 * N4);
@@ -842,7 +852,7 @@ __global__ void __launch_bounds__(64) k_geom_flow_smooth_fwd(GeomDev D, float* _
 // First-order edge-aware disparity smoothness at full resolution, all scales fused
 // (model_geometry.py:225-252).  Rolling wave kernel: a wave owns 62 full-res columns (lanes 0..61 produce
 // output; x+1 comes from a DPP wave shift) and marches down DSM_ROWS rows; the up-sampled disparity of every
-// coarser scale is evaluated row by row from a cache of horizontally interpolated low-res rows (loss_stack.h),
+// coarser scale is evaluated row by row from a cache of horizontally interpolated low-res rows (loss_stack_exact.h),
 // so a row costs 4 streamed loads plus ~1 pair of low-res loads per scale instead of ~36 gathers.
 // grid: x = units (strip x row block), y = f*B + b over the 3 frames; block = one wave.  NS = number of scales.
 template <int NS>
