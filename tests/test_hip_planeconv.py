@@ -71,3 +71,21 @@ def test_planeconv_nonfinite_inputs_propagate():
     y = ops.planeconv_forward(x, w)
     ref = F.conv2d(x, w, None, 1, 1)
     assert torch.equal(torch.isnan(y), torch.isnan(ref))
+
+
+def test_planeconv_act_autograd_matches_aten():
+    """ops.planeconv_act (PoseCNN's Conv2d(12, 12, 3, 1, 1) + ReLU on 2x7 planes) against the ATen composition: output and the
+    three gradients."""
+    torch.manual_seed(4)
+    x = torch.randn(4, 12, 2, 7, device=dev())
+    w = torch.randn(12, 12, 3, 3, device=dev()) * 0.2
+    b = torch.randn(12, device=dev()) * 0.1
+    gy = torch.randn(4, 12, 2, 7, device=dev())
+    outs = []
+    for fused in (True, False):
+        xi, wi, bi = [t.clone().requires_grad_(True) for t in (x, w, b)]
+        y = ops.planeconv_act(xi, wi, bi, 0.0) if fused else F.relu(F.conv2d(xi, wi, bi, 1, 1))
+        (y * gy).sum().backward()
+        outs.append([y.detach(), xi.grad, wi.grad, bi.grad])
+    for u, v in zip(*outs):
+        assert float((u - v).abs().max()) <= 1e-5 * float(v.abs().max()) + 1e-9

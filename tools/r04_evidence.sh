@@ -21,6 +21,10 @@ python tools/stream_kernels.py $t 4 45 15 > $out/r04_stream_kernels.txt; python 
 # PWC-side kernels: algorithmic-byte table + PMC traffic
 python tools/corr_bench.py --check > $out/r04_pwc_roofline_table.md 2>&1
 bash tools/pmc_corr.sh r04
+# small-plane convolutions: HIP-event time per call against MIOpen + kernel durations by grid
+python tools/planeconv_bench.py --levels 6,5 > $out/r04_planeconv_bench.md 2>&1
+rm -rf /tmp/pcv; rocprofv3 --kernel-trace --output-format csv -d /tmp/pcv -o t -- python3 tools/planeconv_bench.py --levels 6,5 --iters 10 --reps 1 > /dev/null 2>&1
+python tools/trace_by_grid.py $(find /tmp/pcv -name '*kernel_trace.csv' | head -1) "planeconv|miopenSp3|igemm|batched_transpose|SubTensor" > $out/r04_planeconv_kernels.txt 2>&1
 # fused loss stack: per-kernel roofline tables at the headline shape and at configs[4] (B = 2, B = 16)
 bash tools/pmc_loss_stack.sh r04 > /dev/null 2>&1
 bash tools/pmc_loss_stack.sh r04_config5_b2 2 375 1242 6 > /dev/null 2>&1

@@ -33,6 +33,9 @@ class PoseCNN(nn.Module):
         """``self.relu(conv(x))`` (pose_cnn.py:68-69, 84-85).  On the GPU the convolution runs without its bias and the bias +
         ReLU epilogue is one in-place HIP pass whose backward also yields the bias gradient (ops.bias_act, slope 0)."""
         if x.is_cuda:
+            if (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+                    and conv.groups == 1 and ops.planeconv_eligible(x, conv.weight)):
+                return ops.planeconv_act(x, conv.weight, conv.bias, 0.0)     # the 2x7 refinement planes: this build's MFMA kernels
             return ops.bias_act(convs.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups),
                                 conv.bias, 0.0)
         return self.relu(conv(x))

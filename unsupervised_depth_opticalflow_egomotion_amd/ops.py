@@ -642,6 +642,41 @@ def planeconv_backward(gy, x, w, want_x=True, want_w=True):
     return gx, gw
 
 
+class PlaneConvActFn(torch.autograd.Function):
+    """act(conv3x3(x, w, pad 1) + bias) on a small plane as one operator (PoseCNN's refinement convolutions,
+    pose_cnn.py:43-46, 66-69: Conv2d(12, 12, 3, 1, 1) + ReLU on 2x7 planes): dfe_planeconv_fwd with the epilogue inside;
+    backward = dfe_bias_act_bwd (activation mask from the output, bias gradient) + dfe_planeconv_dgrad / _wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, slope):
+        x, w = f32c(x), f32c(w)
+        y = torch.empty(x.shape[0], w.shape[0], x.shape[2], x.shape[3], device=x.device, dtype=torch.float32)
+        planeconv_fwd_into(x, w, None if bias is None else f32c(bias), slope, y)
+        ctx.save_for_backward(x, w, y)
+        ctx.slope, ctx.has_bias = float(slope), bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = get_lib()
+        x, w, y = ctx.saved_tensors
+        B, C, H, W = y.shape
+        gy = f32c(gy)
+        gz = torch.empty_like(y)
+        gb = part = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = torch.empty(C, device=y.device, dtype=torch.float32)
+            part = torch.empty(lib.dfe_bias_act_partials_floats(B, C, H, W), device=y.device, dtype=torch.float32)
+        check(lib.dfe_bias_act_bwd(ptr(y), ptr(gy), gy.stride(0), ptr(gz), ptr(gb), ptr(part), B, C, H, W, ctx.slope,
+                                   stream_ptr()), "dfe_bias_act_bwd")
+        gx, gw = planeconv_backward(gz, x, w, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return gx, gw, gb, None
+
+
+def planeconv_act(x, w, bias, slope):
+    return PlaneConvActFn.apply(x, w, bias, float(slope))
+
+
 class DenseDecodeFn(torch.autograd.Function):
     """One PWC decoder level's DenseNet-style block (pwc_tf.py:113-118 and the same six lines per level)::
 
