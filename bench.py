@@ -293,8 +293,9 @@ class TrainStepWorkload:
 # from tools/byte_models.py, the same table tools/roofline_table.py prices the rocprof runs with
 from tools import byte_models  # noqa: E402
 
-POINT_LIMITER = {"geom": "VALU issue (871 instructions per pixel at a measured ~3 SIMD-cycles each: roofline.valu_frac) when the flows are smooth, the gathers' 128-byte line count when "
-                          "they are rough; Infinity-Cache resident at B=4 (profiles/r03_point_fwd_ablation.md)"}
+POINT_LIMITER = {"geom": "VALU issue (~880 instructions per pixel at a measured ~3 SIMD-cycles each: roofline.valu_frac) and the line count of the 48 bilinear taps per pixel; "
+                          "a wave covers a 16x4 pixel tile (round 4): 9-16 % faster than a 64-pixel row segment on displaced flows, 3 % slower on the ZERO flows the "
+                          "random-initialised nets of this train step produce (profiles/r04_point_tile_experiment.md); Infinity-Cache resident at B=4"}
 HBM_ACHIEVABLE_GBS = 6290.0    # measured float4 copy rate (MI355X_MICROARCH.md)
 KERNEL_SOURCES = ("loss_stack_fwd.hip", "loss_stack.h", "loss_stack_exact.h", "dfe_device.h")
 
