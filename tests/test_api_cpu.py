@@ -56,6 +56,19 @@ def test_error_strings_and_argument_checks_without_gpu():
     assert lib.dfe_bn_fwd(P, None, P, P, None, None, None, P, P, P, 1, 2, 4, 8, 8, 1e-5, 0.1, 0, None) == -1
     assert lib.dfe_bn_bwd(P, None, P, P, P, P, P, None, None, None, P, P, 1, 2, 4, 8, 8, 1, None) == -1       # ReLU mask needs y
     assert lib.dfe_geom_timed_collect(None, None) == -1
+    # small-plane convolutions (ops_planeconv.hip): the host-side shape logic runs without a GPU
+    assert lib.dfe_planeconv_supported(8, 81, 128, 4, 13) == 1 and lib.dfe_planeconv_supported(8, 211, 128, 8, 26) == 1
+    assert lib.dfe_planeconv_supported(8, 64, 64, 64, 208) == 0          # > 4096 pixels per sample: MIOpen's
+    assert lib.dfe_planeconv_supported(1, 4, 4, 1, 4000) == 0            # one very wide row does not fit the staging budget
+    assert lib.dfe_planeconv_supported(0, 4, 4, 4, 4) == 0
+    for (B, Ci, Co, H, W) in [(8, 81, 128, 4, 13), (8, 256, 96, 8, 26), (4, 12, 12, 2, 7), (1, 1, 1, 1, 1)]:
+        ws = lib.dfe_planeconv_ws_floats(B, Ci, Co, H, W)
+        assert ws >= max(B * Co * H * W, B * Ci * H * W, Co * Ci * 9), (B, Ci, Co, H, W, ws)   # one partial plane of each pass at least
+    assert lib.dfe_planeconv_ws_floats(8, 64, 64, 64, 208) == 0
+    assert lib.dfe_planeconv_fwd(None, P, None, 0.1, P, 0, None, 0, P, 1, 4, 4, 4, 4, None) == -1
+    assert lib.dfe_planeconv_fwd(P, P, None, 0.1, P, 10, None, 0, P, 1, 4, 4, 4, 4, None) == -2      # batch stride < Co*H*W
+    assert lib.dfe_planeconv_dgrad(P, P, P, P, 8, 64, 64, 64, 208, None) == -4                        # unsupported: larger plane
+    assert lib.dfe_planeconv_wgrad(P, P, None, P, 1, 4, 4, 4, 4, None) == -1
 
 
 def test_no_cpu_fallback():
