@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 # (B, Ci, Co, H, W): every layer of PWC levels 6 and 5 at 256x832 (B = 8 pairs), ragged / tiny / one-row / wide cases
 SHAPES = [(8, 81, 128, 4, 13), (8, 128, 128, 4, 13), (8, 256, 96, 4, 13), (8, 224, 64, 4, 13), (8, 160, 32, 4, 13),
           (8, 211, 128, 8, 26), (8, 128, 128, 8, 26), (8, 256, 96, 8, 26), (8, 224, 64, 8, 26), (8, 160, 32, 8, 26),
-          (1, 1, 1, 1, 1), (2, 3, 5, 3, 5), (3, 17, 33, 1, 70), (2, 20, 70, 9, 7), (1, 36, 48, 16, 52), (2, 5, 16, 64, 2)]
+          (1, 1, 1, 1, 1), (2, 3, 5, 3, 5), (3, 17, 33, 1, 70), (2, 20, 70, 9, 7), (1, 36, 48, 16, 52), (2, 5, 16, 64, 2),
+          (8, 128, 128, 16, 52)]      # the last one takes the 64-channel block tile (NSUB = 4) in both directions
 
 
 def dev():
