@@ -62,7 +62,7 @@ POINT_KERNEL = {"geom": "k_geom_point_fwd", "depth": "k_depth_point_fwd", "flow"
 # static mix is profiles/r03_point_fwd_isa_mix.md) and what one of them costs a SIMD when >= 2 waves share it, measured
 # with tools/ubench/valu.hip (profiles/r02_issue_cost_model.md section 1, at an assumed 2.4 GHz): 2.64 cycles for
 # mul / add / fma, 3.9 for compare + select pairs (22 % of this kernel's mix), ~8 for the few transcendentals.
-VALU_PER_WAVE = {"k_geom_point_fwd": 871.1}
+VALU_PER_WAVE = {"k_geom_point_fwd": 887.1}
 VALU_CYCLES_PER_INST = 0.76 * 2.64 + 0.22 * 3.9 + 0.02 * 8.2      # = 3.03
 GPU_SIMDS, GPU_CLOCK_HZ = 256 * 4, 2.4e9
 
