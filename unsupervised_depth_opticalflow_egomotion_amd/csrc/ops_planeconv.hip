@@ -30,7 +30,7 @@ constexpr int PC_CC = 16;        // channels per staged chunk (4 K-steps per tap
 constexpr int PC_MT = 64;        // pixels per block: 4 waves x one 16-pixel M tile
 constexpr int PC_KW = PC_CC * 9; // weights per output channel and chunk
 constexpr int PC_XT_MAX = 18;    // activation staging loads per thread and chunk: bounds the plane width
-constexpr int PW_U = 8;          // the same in the weight-gradient kernel
+constexpr int PW_U = 8;          // staging loads in flight per thread and batch in the weight-gradient kernel
 
 // idx / d for 0 <= idx < 2^20 (d > 0, inv = 1 / d): the quotient's distance to the next integer is >= 0.5 / d, the float
 // error of the product is < idx / d * 2^-22
@@ -43,7 +43,7 @@ __device__ __forceinline__ int fdiv(int idx, float inv) { return static_cast<int
 template <int NSUB, bool DGRAD, int XT>
 __global__ void __launch_bounds__(256) k_planeconv(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ part,
                                                    int B, int Ck, int N, int H, int W, int KS, int cps, int RB, int XP, int KP,
-                                                   float inv_rbwp, float inv_wp) {
+                                                   float inv_wp) {
   extern __shared__ float lds[];
   constexpr int NT = 16 * NSUB, WT = NT * PC_KW / 256;
   float* xs = lds;
@@ -337,7 +337,7 @@ int pc_launch(const float* x, const float* w, float* part, int B, int Ck, int N,
   const dim3 grid(g.ntm, g.ntn, B * g.KS);
   const int Wp = W + 2;
   k_planeconv<NSUB, DGRAD, XT><<<grid, 256, g.lds, st>>>(x, w, part, B, Ck, N, H, W, g.KS, g.cps, g.RB, g.XP, g.KP,
-                                                         1.0f / static_cast<float>(g.RB * Wp), 1.0f / static_cast<float>(Wp));
+                                                         1.0f / static_cast<float>(Wp));
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
