@@ -258,6 +258,14 @@ int dfe_planeconv_dgrad(const float* gy, const float* weight, float* gx, float* 
 int dfe_planeconv_wgrad(const float* gy, const float* x, float* gweight, float* ws, int B, int Ci, int Co, int H, int W,
                         void* stream);
 
+/* ---- layout-changing casts at the door of MIOpen's bf16 convolutions (opt-in mixed-precision mode, SURVEY.md 8(f) rank 1:
+ * the nets of depth_model.py:60-211 / pwc_tf.py:108-179 in bf16; never the headline).  MIOpen's bf16 kernels are NHWC:
+ * dfe_cast_f32_nchw_to_bf16_nhwc: y[b][p][c] = bf16(x[b][c][p]), round to nearest even like torch's .to(torch.bfloat16);
+ * dfe_cast_bf16_nhwc_to_f32_nchw: y[b][c][p] = float(x[b][p][c]).  x / y contiguous, HW = H * W; y of the first is what
+ * torch calls a channels_last bf16 tensor.  One pass instead of a cast plus MIOpen's own transpose. */
+int dfe_cast_f32_nchw_to_bf16_nhwc(const float* x, void* y, int B, int C, long HW, void* stream);
+int dfe_cast_bf16_nhwc_to_f32_nchw(const void* x, float* y, int B, int C, long HW, void* stream);
+
 /* ---- grouped training-mode BatchNorm2d (+ residual + ReLU) of the depth encoder (SURVEY.md 8(f) rank 1;
  * depth_model.py:60-95 = torchvision BasicBlock conv-bn-relu-conv-bn-(+identity)-relu; model_geometry.py:786-788 calls the
  * depth net once per frame).  x [G*Bg,C,H,W] is G groups of Bg consecutive samples: statistics are per (group, channel)

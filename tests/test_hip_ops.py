@@ -983,3 +983,23 @@ def test_thin_conv_same_16_16_matches_miopen():
             assert float((a - c).abs().max()) <= 2e-5 * max(float(c.abs().max()), 1.0)
     conv = torch.nn.Conv2d(16, 16, 3, 1, 1)
     assert ops.thin_conv_same_eligible(x, conv) and not ops.thin_conv_same_eligible(x[:, :, :64, :208], conv)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 8, 26), (3, 81, 4, 13), (1, 3, 7, 5), (2, 128, 64, 208), (128, 115, 3, 3), (1, 1, 1, 1)])
+def test_layout_changing_bf16_casts_match_torch(shape):
+    """dfe_cast_f32_nchw_to_bf16_nhwc / dfe_cast_bf16_nhwc_to_f32_nchw (the opt-in bf16 mode's door to MIOpen) against
+    torch's .to(bfloat16, channels_last) / .float(): bit-identical, NaN and infinities included."""
+    from unsupervised_depth_opticalflow_egomotion_amd import convs
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    x = torch.randn(*shape, device=dev) * 3.0
+    flat = x.view(-1)
+    if flat.numel() > 8:
+        flat[1], flat[3], flat[5] = float("nan"), float("inf"), float("-inf")
+        flat[7] = 1.00390625        # a tie: rounds to even
+    y = convs._f32_nchw_to_bf16_nhwc(x)
+    ref = x.to(torch.bfloat16, memory_format=torch.channels_last)
+    assert y.dtype == torch.bfloat16 and (y.stride() == ref.stride() or shape[1] == 1 or shape[2] * shape[3] == 1)
+    assert torch.equal(y.view(torch.int16), ref.view(torch.int16))
+    z = convs._bf16_nhwc_to_f32_nchw(ref) if not ref.is_contiguous() else ref.float()
+    assert z.is_contiguous() and torch.equal(z.view(torch.int32), ref.float().contiguous().view(torch.int32))

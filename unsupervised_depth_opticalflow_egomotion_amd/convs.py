@@ -30,24 +30,55 @@ miopen_tuning.activate()      # before the first convolution: MIOpen reads MIOPE
 _STATE = {"dtype": None}
 
 # Reduced-precision mode, measured in round 4 and NOT adopted (DFE_AMP_NHWC=1 switches it on): the operands go to MIOpen
-# as CHANNELS-LAST tensors (one ATen cast + permute kernel each way instead of a cast followed by MIOpen's own NCHW -> NHWC
-# transposes: its bf16 kernels are all NHWC implicit GEMMs) with PYTORCH_MIOPEN_SUGGEST_NHWC=1.  The convolutions themselves
-# run ~25 % faster that way (tools/nhwc_probe.py), but ATen's strided cast + permute kernels cost more than the pair they
-# replace: 24.2 / 24.5 ms per step against 21.6 / 25.2 with NCHW casts (same box, bench.py --amp bf16).  The mode pays only
-# when activations stay bf16 channels-last between the convolutions.
+# as CHANNELS-LAST bf16 tensors with PYTORCH_MIOPEN_SUGGEST_NHWC=1, so that its NHWC implicit GEMMs need no transposes of
+# their own.  The convolutions themselves run ~25 % faster that way (tools/nhwc_probe.py).  First with ATen's strided cast +
+# permute kernels at the door: 24.2 / 24.5 ms per step against 21.6 / 25.2 with NCHW casts.  Then with this build's one-pass
+# transposing casts (csrc/ops_cast.hip, bit-identical to torch's): 25.3 / 26.3 against 24.4 / 24.8 on the same box -- the
+# layout change at EVERY convolution's door costs what MIOpen's transposes cost.  The mode pays only when activations stay
+# bf16 channels-last between the convolutions.
 _AMP_NHWC = os.environ.get("DFE_AMP_NHWC", "0") == "1"
 
 
 def _low(t, dt):
-    """fp32 NCHW -> compute dtype (channels-last when _AMP_NHWC and 4-d)."""
+    """fp32 NCHW -> compute dtype (channels-last when _AMP_NHWC and 4-d: one transposing cast of this build for bf16)."""
     if _AMP_NHWC and t.dim() == 4:
+        if dt is torch.bfloat16 and t.is_cuda and t.dtype == torch.float32:
+            return _f32_nchw_to_bf16_nhwc(t)
         return t.to(dt, memory_format=torch.channels_last)
     return t.to(dt)
 
 
 def _high(t):
     """compute dtype (any layout) -> fp32 NCHW contiguous: what every glue kernel of this build takes."""
-    return None if t is None else t.to(torch.float32, memory_format=torch.contiguous_format)
+    if t is None:
+        return None
+    if (_AMP_NHWC and t.dtype == torch.bfloat16 and t.dim() == 4 and t.is_cuda and not t.is_contiguous()
+            and t.is_contiguous(memory_format=torch.channels_last)):
+        return _bf16_nhwc_to_f32_nchw(t)
+    return t.to(torch.float32, memory_format=torch.contiguous_format)
+
+
+def _f32_nchw_to_bf16_nhwc(t):
+    import ctypes
+    from ._lib import check, get_lib, ptr, stream_ptr
+    t = t.contiguous()
+    B, C, H, W = t.shape
+    y = torch.empty((B, C, H, W), dtype=torch.bfloat16, device=t.device, memory_format=torch.channels_last)
+    if y.numel():
+        check(get_lib().dfe_cast_f32_nchw_to_bf16_nhwc(ptr(t), ctypes.c_void_p(y.data_ptr()), B, C, H * W, stream_ptr()),
+              "dfe_cast_f32_nchw_to_bf16_nhwc")
+    return y
+
+
+def _bf16_nhwc_to_f32_nchw(t):
+    import ctypes
+    from ._lib import check, get_lib, ptr, stream_ptr
+    B, C, H, W = t.shape
+    y = torch.empty((B, C, H, W), dtype=torch.float32, device=t.device)
+    if y.numel():
+        check(get_lib().dfe_cast_bf16_nhwc_to_f32_nchw(ctypes.c_void_p(t.data_ptr()), ptr(y), B, C, H * W, stream_ptr()),
+              "dfe_cast_bf16_nhwc_to_f32_nchw")
+    return y
 
 
 def set_compute_dtype(dtype):
