@@ -258,6 +258,17 @@ int dfe_planeconv_dgrad(const float* gy, const float* weight, float* gx, float* 
 int dfe_planeconv_wgrad(const float* gy, const float* x, float* gweight, float* ws, int B, int Ci, int Co, int H, int W,
                         void* stream);
 
+/* ---- 1x1 convolutions on tiny planes (H*W <= 256, B*H*W <= 4096): PoseCNN's pose_conv and refinement head
+ * (pose_cnn.py:32,43,48: Conv2d(256 | 24 | 12, 12, 1) on 2x7 planes).  x [B,Ci,H,W], weight [Co,Ci] (= [Co,Ci,1,1]).
+ * dfe_conv1x1_small_fwd: y = act(conv1x1(x, weight) + bias[co]) (bias may be NULL; act as in dfe_planeconv_fwd).
+ * dfe_conv1x1_small_bwd: gx [B,Ci,H,W] and / or gweight [Co,Ci] (either may be NULL) for the output gradient gy [B,Co,H,W]
+ * (of the pre-activation: apply dfe_bias_act_bwd first).  One thread per output, serial sums: reproducible. */
+int dfe_conv1x1_small_supported(int B, int Ci, int Co, int H, int W);
+int dfe_conv1x1_small_fwd(const float* x, const float* weight, const float* bias, float slope, float* y, int B, int Ci, int Co,
+                          int H, int W, void* stream);
+int dfe_conv1x1_small_bwd(const float* gy, const float* x, const float* weight, float* gx, float* gweight, int B, int Ci, int Co,
+                          int H, int W, void* stream);
+
 /* ---- layout-changing casts at the door of MIOpen's bf16 convolutions (opt-in mixed-precision mode, SURVEY.md 8(f) rank 1:
  * the nets of depth_model.py:60-211 / pwc_tf.py:108-179 in bf16; never the headline).  MIOpen's bf16 kernels are NHWC:
  * dfe_cast_f32_nchw_to_bf16_nhwc: y[b][p][c] = bf16(x[b][c][p]), round to nearest even like torch's .to(torch.bfloat16);

@@ -90,3 +90,26 @@ def test_planeconv_act_autograd_matches_aten():
         outs.append([y.detach(), xi.grad, wi.grad, bi.grad])
     for u, v in zip(*outs):
         assert float((u - v).abs().max()) <= 1e-5 * float(v.abs().max()) + 1e-9
+
+
+@pytest.mark.parametrize("shape,slope", [((4, 256, 12, 2, 7), 1.0), ((4, 24, 12, 2, 7), 0.0), ((4, 12, 12, 2, 7), 0.0), ((3, 5, 7, 4, 13), 0.1)])
+def test_conv1x1_small_autograd_matches_aten(shape, slope):
+    """ops.Conv1x1SmallFn (PoseCNN's 1x1 convolutions on 2x7 planes) against the ATen composition: output and the gradients."""
+    import torch.nn as nn
+    B, Ci, Co, H, W = shape
+    torch.manual_seed(B + Ci)
+    conv = nn.Conv2d(Ci, Co, 1).to(dev())
+    x = torch.randn(B, Ci, H, W, device=dev())
+    gy = torch.randn(B, Co, H, W, device=dev())
+    assert ops.conv1x1_small_eligible(x, conv)
+    outs = []
+    for fused in (True, False):
+        conv.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        y = ops.conv1x1_small(xi, conv, slope) if fused else F.leaky_relu(conv(xi), slope)
+        (y * gy).sum().backward()
+        outs.append([y.detach(), xi.grad, conv.weight.grad.clone(), conv.bias.grad.clone()])
+    for u, v in zip(*outs):
+        assert float((u - v).abs().max()) <= 1e-5 * float(v.abs().max()) + 1e-9
+    big = torch.zeros(1, 4, 64, 208, device=dev())
+    assert not ops.conv1x1_small_eligible(big, nn.Conv2d(4, 4, 1).to(dev()))

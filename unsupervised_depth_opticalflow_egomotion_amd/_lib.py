@@ -45,6 +45,9 @@ _SIGNATURES = {
     "dfe_wgrad3x3_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_cast_f32_nchw_to_bf16_nhwc": [_P, _P, _I, _I, ctypes.c_long, _P],
     "dfe_cast_bf16_nhwc_to_f32_nchw": [_P, _P, _I, _I, ctypes.c_long, _P],
+    "dfe_conv1x1_small_supported": [_I, _I, _I, _I, _I],
+    "dfe_conv1x1_small_fwd": [_P, _P, _P, ctypes.c_float, _P, _I, _I, _I, _I, _I, _P],
+    "dfe_conv1x1_small_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_planeconv_supported": [_I, _I, _I, _I, _I],
     "dfe_planeconv_ws_floats": [_I, _I, _I, _I, _I],
     "dfe_planeconv_fwd": [_P, _P, _P, ctypes.c_float, _P, ctypes.c_long, _P, ctypes.c_long, _P, _I, _I, _I, _I, _I, _P],

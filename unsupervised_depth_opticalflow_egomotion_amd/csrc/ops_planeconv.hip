@@ -267,6 +267,43 @@ __global__ void __launch_bounds__(256) k_planeconv_wgrad(const float* __restrict
   }
 }
 
+// ---- 1x1 convolutions on tiny planes (PoseCNN's pose_conv / refinement head, pose_cnn.py:32,43,48: Conv2d(256|24|12, 12, 1)
+// on 2x7 planes, B = 4: 672 outputs of <= 256 products each -- MIOpen spends ~45 us per pass on them).  One thread per output,
+// serial sums in channel (or sample-pixel) order: reproducible.
+// TRANSPOSED = false: y[b][n][p] = act(sum_k x[b][k][p] * w[n][k] + bias[n])      w [N][K]
+// TRANSPOSED = true : y[b][n][p] =     sum_k x[b][k][p] * w[k][n]                 w [K][N]   (data gradient)
+template <bool TRANSPOSED>
+__global__ void __launch_bounds__(256) k_conv1x1_small(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int K, int N, int HW,
+                                                       int total, float slope) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int p = idx % HW, bn = idx / HW, n = bn % N, b = bn / N;
+  const float* xp = x + static_cast<long>(b) * K * HW + p;
+  float s = 0.0f;
+  for (int k = 0; k < K; ++k) s = __fmaf_rn(xp[static_cast<long>(k) * HW], TRANSPOSED ? w[static_cast<long>(k) * N + n] : w[static_cast<long>(n) * K + k], s);
+  if (!TRANSPOSED) {
+    if (bias) s += bias[n];
+    s = s > 0.0f ? s : s * slope;
+  }
+  y[idx] = s;
+}
+
+// gw[n][k] = sum_{b,p} gy[b][n][p] * x[b][k][p]
+__global__ void __launch_bounds__(256) k_conv1x1_small_wgrad(const float* __restrict__ gy, const float* __restrict__ x,
+                                                             float* __restrict__ gw, int B, int K, int N, int HW) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * K) return;
+  const int k = idx % K, n = idx / K;
+  float s = 0.0f;
+  for (int b = 0; b < B; ++b) {
+    const float* g = gy + (static_cast<long>(b) * N + n) * HW;
+    const float* xv = x + (static_cast<long>(b) * K + k) * HW;
+    for (int p = 0; p < HW; ++p) s = __fmaf_rn(g[p], xv[p], s);
+  }
+  gw[idx] = s;
+}
+
 }  // namespace dfe
 
 #define DFE_LAUNCH_CHECK() do { if (hipGetLastError() != hipSuccess) return DFE_ERR_LAUNCH; } while (0)
@@ -421,5 +458,43 @@ extern "C" int dfe_planeconv_wgrad(const float* gy, const float* x, float* gweig
                                                           static_cast<int>(g.units), 1.0f, 1.0f / static_cast<float>(total),
                                                           1.0f / static_cast<float>(total));
   DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+// ---- 1x1 convolutions on tiny planes
+static int c1_dims(int B, int Ci, int Co, int H, int W) {
+  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return DFE_ERR_DIMS;
+  if (static_cast<long>(H) * W > 256 || static_cast<long>(B) * H * W > 4096 || Ci > 4096 || Co > 4096) return DFE_ERR_UNSUPPORTED;
+  return DFE_OK;
+}
+
+extern "C" int dfe_conv1x1_small_supported(int B, int Ci, int Co, int H, int W) { return c1_dims(B, Ci, Co, H, W) == DFE_OK; }
+
+extern "C" int dfe_conv1x1_small_fwd(const float* x, const float* weight, const float* bias, float slope, float* y, int B, int Ci,
+                                     int Co, int H, int W, void* stream) {
+  if (!x || !weight || !y) return DFE_ERR_NULL;
+  const int rc = c1_dims(B, Ci, Co, H, W);
+  if (rc != DFE_OK) return rc;
+  const int total = B * Co * H * W;
+  k_conv1x1_small<false><<<(total + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(x, weight, bias, y, Ci, Co, H * W, total, slope);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+extern "C" int dfe_conv1x1_small_bwd(const float* gy, const float* x, const float* weight, float* gx, float* gweight, int B, int Ci,
+                                     int Co, int H, int W, void* stream) {
+  if (!gy || !x || !weight) return DFE_ERR_NULL;
+  const int rc = c1_dims(B, Ci, Co, H, W);
+  if (rc != DFE_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (gx) {
+    const int total = B * Ci * H * W;
+    k_conv1x1_small<true><<<(total + 255) / 256, 256, 0, st>>>(gy, weight, nullptr, gx, Co, Ci, H * W, total, 1.0f);
+    DFE_LAUNCH_CHECK();
+  }
+  if (gweight) {
+    k_conv1x1_small_wgrad<<<(Co * Ci + 255) / 256, 256, 0, st>>>(gy, x, gweight, B, Ci, Co, H * W);
+    DFE_LAUNCH_CHECK();
+  }
   return DFE_OK;
 }

@@ -36,9 +36,18 @@ class PoseCNN(nn.Module):
             if (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
                     and conv.groups == 1 and ops.planeconv_eligible(x, conv.weight)):
                 return ops.planeconv_act(x, conv.weight, conv.bias, 0.0)     # the 2x7 refinement planes: this build's MFMA kernels
+            if ops.conv1x1_small_eligible(x, conv):
+                return ops.conv1x1_small(x, conv, 0.0)
             return ops.bias_act(convs.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups),
                                 conv.bias, 0.0)
         return self.relu(conv(x))
+
+    @staticmethod
+    def _conv1x1(conv, x):
+        """A 1x1 convolution without activation (pose_conv, refine_pose_conv: pose_cnn.py:32,48,88,72) on the tiny-plane kernel."""
+        if x.is_cuda and ops.conv1x1_small_eligible(x, conv):
+            return ops.conv1x1_small(x, conv, 1.0)
+        return conv(x)
 
     def atten_refine(self, x):
         B, C, H, W = x.size()
@@ -48,13 +57,13 @@ class PoseCNN(nn.Module):
         out = torch.cat([flat, torch.bmm(attn, v)], 1).view(B, 2 * C, H, W)
         for conv in self.refine_net:
             out = self.conv_relu(conv, out)
-        out = self.refine_pose_conv(out).mean(3).mean(2)
+        out = self._conv1x1(self.refine_pose_conv, out).mean(3).mean(2)
         return 0.01 * out.view(-1, self.num_input_frames - 1, 6)
 
     def forward(self, x):
         for conv in self.net:
             x = self.conv_relu(conv, x)
-        x = self.pose_conv(x)
+        x = self._conv1x1(self.pose_conv, x)
         delta = self.atten_refine(x)
         x = x.mean(3).mean(2)
         return 0.01 * x.view(-1, self.num_input_frames - 1, 6) + delta

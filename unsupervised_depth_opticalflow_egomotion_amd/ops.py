@@ -677,6 +677,54 @@ def planeconv_act(x, w, bias, slope):
     return PlaneConvActFn.apply(x, w, bias, float(slope))
 
 
+class Conv1x1SmallFn(torch.autograd.Function):
+    """act(conv1x1(x, w) + bias) on a tiny plane (PoseCNN's pose_conv / refinement 1x1 convolutions on 2x7 planes,
+    pose_cnn.py:32,43,48) as one operator: dfe_conv1x1_small_fwd; backward = dfe_bias_act_bwd + dfe_conv1x1_small_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, slope):
+        x, w = f32c(x), f32c(w)
+        B, Ci, H, W = x.shape
+        Co = int(w.shape[0])
+        y = torch.empty(B, Co, H, W, device=x.device, dtype=torch.float32)
+        check(get_lib().dfe_conv1x1_small_fwd(ptr(x), ptr(w), ptr(None if bias is None else f32c(bias)), float(slope), ptr(y),
+                                              B, Ci, Co, H, W, stream_ptr()), "dfe_conv1x1_small_fwd")
+        ctx.save_for_backward(x, w, y)
+        ctx.slope, ctx.has_bias = float(slope), bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = get_lib()
+        x, w, y = ctx.saved_tensors
+        B, Co, H, W = y.shape
+        Ci = int(x.shape[1])
+        gy = f32c(gy)
+        gz = torch.empty_like(y)
+        gb = part = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = torch.empty(Co, device=y.device, dtype=torch.float32)
+            part = torch.empty(lib.dfe_bias_act_partials_floats(B, Co, H, W), device=y.device, dtype=torch.float32)
+        check(lib.dfe_bias_act_bwd(ptr(y), ptr(gy), gy.stride(0), ptr(gz), ptr(gb), ptr(part), B, Co, H, W, ctx.slope,
+                                   stream_ptr()), "dfe_bias_act_bwd")
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        check(lib.dfe_conv1x1_small_bwd(ptr(gz), ptr(x), ptr(w), ptr(gx), ptr(gw), B, Ci, Co, H, W, stream_ptr()),
+              "dfe_conv1x1_small_bwd")
+        return gx, gw, gb, None
+
+
+def conv1x1_small_eligible(x, conv):
+    return (PLANECONV_MAX_HW > 0 and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and convs.get_compute_dtype() is None
+            and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+            and get_lib().dfe_conv1x1_small_supported(x.shape[0], x.shape[1], conv.out_channels, x.shape[2], x.shape[3]) == 1)
+
+
+def conv1x1_small(x, conv, slope):
+    """``act(conv(x))`` for an nn.Conv2d with a 1x1 kernel on a tiny plane; slope 1 = no activation."""
+    return Conv1x1SmallFn.apply(x, conv.weight, conv.bias, float(slope))
+
+
 class DenseDecodeFn(torch.autograd.Function):
     """One PWC decoder level's DenseNet-style block (pwc_tf.py:113-118 and the same six lines per level)::
 
