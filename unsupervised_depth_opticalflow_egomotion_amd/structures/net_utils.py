@@ -17,6 +17,9 @@ class ConvAct(nn.Sequential):
         c = self[0]
         if ops.thin_conv_same_eligible(x, c):       # FeaturePyramid conv2: fp32 MFMA kernels (ops.ThinConvSameFn)
             return ops.bias_act(ops.ThinConvSameFn.apply(x, c.weight), c.bias, self[1].negative_slope)
+        if (c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1) and c.groups == 1
+                and ops.planeconv_eligible(x, c.weight)):   # FeaturePyramid's top levels (8x26, 4x13): small-plane MFMA kernels
+            return ops.planeconv_act(x, c.weight, c.bias, self[1].negative_slope)
         z = convs.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
         return ops.bias_act(z, c.bias, self[1].negative_slope)
 
