@@ -957,10 +957,11 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_adj_cols(GeomDev D, GeomBwd G
 // 15.0; and running it as an extra block row of k_geom_disp_smooth_bwd1 -- its 21 double accumulators lift that kernel from
 // 58 to 145 VGPRs.)
 // One 256-thread block per (b, d).  Per scale, thread t accumulates rows k = t (mod 256) of the 21
-// columns (12 camera sums + 9 dF sums, the latter only at scale 0) in double; one thread per column
-// then adds the 256 per-thread sums in thread order (fixed order -> reproducible).
+// columns (12 camera sums + 9 dF sums, the latter only at scale 0) in double; the 256 per-thread sums of a column
+// are then added in two fixed-order stages (32 at a time, then the 8 parts: reproducible).
 __global__ void __launch_bounds__(256) k_geom_pose_finalize(GeomDev D, GeomBwd G, float* __restrict__ gpose) {
   __shared__ double lds[256][PB_PER_DIR + 1];
+  __shared__ double parts[8][PB_PER_DIR + 1];
   __shared__ double sm[DFE_MAX_SCALES * 12 + 9];
   const int cam = blockIdx.x, b = cam >> 1, d = cam & 1, S = D.S, t = threadIdx.x;
   const unsigned nblk_total = D.blk_start[S];
@@ -968,17 +969,41 @@ __global__ void __launch_bounds__(256) k_geom_pose_finalize(GeomDev D, GeomBwd G
     double a[PB_PER_DIR];
 #pragma unroll
     for (int i = 0; i < PB_PER_DIR; ++i) a[i] = 0.0;
-    for (int k = D.blk_start[s] + t; k < D.blk_start[s + 1]; k += 256) {
-      const float* r = G.bpart + (static_cast<long>(b) * nblk_total + k) * PB_COUNT + d * PB_PER_DIR;
+    // four rows' loads in flight at once, added in row order (the same sums as one row at a time)
+    const float* base = G.bpart + static_cast<long>(b) * nblk_total * PB_COUNT + d * PB_PER_DIR;
+    const int kend = D.blk_start[s + 1];
+    int k = D.blk_start[s] + t;
+    for (; k + 3 * 256 < kend; k += 4 * 256) {
+      float v[4][PB_PER_DIR];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < PB_PER_DIR; ++i) v[u][i] = base[static_cast<long>(k + u * 256) * PB_COUNT + i];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < PB_PER_DIR; ++i) a[i] += v[u][i];
+    }
+    for (; k < kend; k += 256) {
+      const float* r = base + static_cast<long>(k) * PB_COUNT;
 #pragma unroll
       for (int i = 0; i < PB_PER_DIR; ++i) a[i] += r[i];
     }
 #pragma unroll
     for (int i = 0; i < PB_PER_DIR; ++i) lds[t][i] = a[i];
     __syncthreads();
+    // column sums in two fixed-order stages: 8 x 21 threads add 32 per-thread sums each, then 21 threads add the 8 parts
+    if (t < 8 * PB_PER_DIR) {
+      const int c = t % PB_PER_DIR, part = t / PB_PER_DIR;
+      double v = 0.0;
+      for (int k = part * 32; k < part * 32 + 32; ++k) v += lds[k][c];
+      parts[part][c] = v;
+    }
+    __syncthreads();
     if (t < PB_PER_DIR) {
       double v = 0.0;
-      for (int k = 0; k < 256; ++k) v += lds[k][t];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v += parts[k][t];
       if (t < 12) sm[s * 12 + t] = v;
       else if (s == 0) sm[S * 12 + (t - 12)] = v;
     }
