@@ -1,0 +1,53 @@
+"""GPU: the fused Winograd F(2x2, 3x3) convolution on the fp32 matrix cores (csrc/ops_wino.hip) through the C ABI against
+float64 ``aten::convolution`` / ``convolution_backward``: forward (padding 1 and valid) and the data-gradient form, on the
+networks' layer shapes and on ragged ones (odd sizes, channel counts that are no multiple of 2 / 16 / 32).  Tolerance 2e-5 of
+the result's scale (fp32 Winograd: the filter and data transforms add a few roundings to the direct sums), reproducible."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from unsupervised_depth_opticalflow_egomotion_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+# (B, Ci, Co, H, W, P)
+SHAPES = [(2, 64, 64, 64, 208, 1), (2, 128, 128, 32, 104, 1), (1, 115, 128, 64, 208, 1), (2, 96, 32, 34, 50, 0),
+          (1, 256, 96, 16, 52, 1), (3, 17, 33, 7, 9, 1), (1, 1, 1, 3, 3, 1), (2, 5, 70, 11, 6, 0), (1, 18, 40, 2, 2, 1),
+          (1, 34, 32, 5, 64, 1)]
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_wino_conv_matches_float64(shape):
+    B, Ci, Co, H, W, P = shape
+    torch.manual_seed(sum(shape))
+    x = torch.randn(B, Ci, H, W, device=dev())
+    w = torch.randn(Co, Ci, 3, 3, device=dev()) / (3.0 * Ci ** 0.5)
+    y = ops.wino_conv3x3(x, w, P)
+    ref = F.conv2d(x.double(), w.double(), None, 1, P)
+    assert y.shape == ref.shape
+    err, scale = float((y.double() - ref).abs().max()), float(ref.abs().max())
+    assert err <= 2e-5 * scale + 1e-12, (err, scale)
+    assert torch.equal(y, ops.wino_conv3x3(x, w, P))
+    if P == 1:      # data gradient of the same convolution: gy [B,Co,H,W] -> gx [B,Ci,H,W]
+        gy = torch.randn(B, Co, H, W, device=dev())
+        gx = ops.wino_conv3x3(gy, w, 1, transposed=True)
+        rgx = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                  [True, False, False])[0]
+        err, scale = float((gx.double() - rgx).abs().max()), float(rgx.abs().max())
+        assert err <= 2e-5 * scale + 1e-12, (err, scale)
+
+
+def test_wino_conv_nonfinite_and_errors():
+    from unsupervised_depth_opticalflow_egomotion_amd._lib import get_lib
+    x = torch.randn(1, 4, 6, 8, device=dev())
+    w = torch.randn(8, 4, 3, 3, device=dev())
+    x[0, 1, 2, 3] = float("nan")
+    y = ops.wino_conv3x3(x, w, 1)
+    ref = F.conv2d(x, w, None, 1, 1)
+    assert bool(torch.isnan(y[0, :, 1:4, 2:5]).all()) and bool(torch.isnan(ref[0, :, 1:4, 2:5]).all())
+    assert get_lib().dfe_wino_conv3x3(None, None, None, 0, None, 1, 1, 1, 4, 4, 1, 0, None) == -1
+    assert get_lib().dfe_wino_weight_floats(5, 33) == 64 * 5 * 16

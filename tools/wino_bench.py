@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""The fused Winograd-on-MFMA convolution (csrc/ops_wino.hip) against MIOpen on the networks' large 3x3 stride-1 layers:
+HIP-event time per call of the forward pass and of the data gradient (the same kernel on the transposed filter).
+
+    python tools/wino_bench.py [--iters 30]
+"""
+import argparse, os, sys
+import torch
+import torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from unsupervised_depth_opticalflow_egomotion_amd import ops          # noqa: E402
+
+SHAPES = [(12, 64, 64, 64, 208), (12, 128, 128, 32, 104), (12, 256, 256, 16, 52), (12, 512, 512, 8, 26), (8, 128, 128, 64, 208),
+          (8, 115, 128, 64, 208), (8, 256, 96, 64, 208), (8, 224, 64, 64, 208), (8, 160, 32, 64, 208), (8, 128, 128, 32, 104),
+          (12, 32, 32, 64, 208), (8, 179, 128, 16, 52)]
+
+
+def ev(fn, n):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / n
+
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=30); a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    print("| B x Ci -> Co @ H x W | GFLOP (direct) | MIOpen fwd us (TF/s) | wino fwd us (TF/s) | MIOpen dgrad us | wino dgrad us | max rel err |")
+    print("|---|---|---|---|---|---|---|")
+    for (B, ci, co, H, W) in SHAPES:
+        x = torch.randn(B, ci, H, W, device=dev); w = torch.randn(co, ci, 3, 3, device=dev) * 0.05; gy = torch.randn(B, co, H, W, device=dev)
+        fl = 2.0 * B * co * ci * 9 * H * W
+        t_m = ev(lambda: F.conv2d(x, w, None, 1, 1), a.iters)
+        t_w = ev(lambda: ops.wino_conv3x3(x, w, 1), a.iters)
+        t_md = ev(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False]), a.iters)
+        t_wd = ev(lambda: ops.wino_conv3x3(gy, w, 1, transposed=True), a.iters)
+        ref = F.conv2d(x, w, None, 1, 1)
+        err = float((ops.wino_conv3x3(x, w, 1) - ref).abs().max() / ref.abs().max())
+        print("| %d x %d -> %d @ %dx%d | %.1f | %.1f (%.0f) | %.1f (%.0f) | %.1f | %.1f | %.1e |" % (
+            B, ci, co, H, W, fl / 1e9, t_m, fl / t_m / 1e6, t_w, fl / t_w / 1e6, t_md, t_wd, err))
+
+
+if __name__ == "__main__":
+    main()

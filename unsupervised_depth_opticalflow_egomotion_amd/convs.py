@@ -109,6 +109,27 @@ def _pair(v):
 
 _cb = torch.ops.aten.convolution_backward
 
+# Large 3x3 stride-1 layers in fp32: this build's fused Winograd F(2x2, 3x3) kernel on the matrix cores (csrc/ops_wino.hip,
+# ops.wino_conv3x3) for the forward pass and the data gradient -- MIOpen runs the same algorithm on the vector ALU and is
+# 1.15-1.3x slower where there are enough 2x2 output tiles to fill the chip (tools/wino_bench.py); the weight gradient stays
+# MIOpen's.  DFE_WINO_MIN_TILES: smallest B * ceil(Ho/2) * ceil(Wo/2) that takes the kernel (0 = never).
+WINO_MIN_TILES = int(os.environ.get("DFE_WINO_MIN_TILES", "5000"))
+WINO_MIN_CHANNELS = int(os.environ.get("DFE_WINO_MIN_CHANNELS", "48"))
+
+
+def _wino_eligible(x, w_shape, cin, stride, padding, dilation, groups=1):
+    """x [B,cin,H,W] convolved 3x3 / stride 1 with ``padding`` in {0, 1}: enough tiles and reduction channels?"""
+    if (WINO_MIN_TILES <= 0 or _STATE["dtype"] is not None or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4
+            or groups != 1 or tuple(w_shape[2:]) != (3, 3) or stride != (1, 1) or dilation != (1, 1)
+            or padding not in ((0, 0), (1, 1))):
+        return False
+    B, C, H, W = x.shape
+    P = padding[0]
+    Ho, Wo = H + 2 * P - 2, W + 2 * P - 2
+    if C != cin or Ho < 1 or Wo < 1:
+        return False
+    return (B * ((Ho + 1) // 2) * ((Wo + 1) // 2) >= WINO_MIN_TILES and C >= WINO_MIN_CHANNELS and B * C * H * W < (1 << 30))
+
 
 def raw_forward(x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1)):
     """y = conv(x, w) without bias, fp32 in / fp32 out, no autograd of its own."""
@@ -116,6 +137,9 @@ def raw_forward(x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1)):
     dt = _STATE["dtype"]
     if dt is not None:
         return _high(F.conv2d(_low(x, dt), _low(w, dt), None, stride, padding, dilation))
+    if _wino_eligible(x, w.shape, w.shape[1], stride, padding, dilation):
+        from . import ops
+        return ops.wino_conv3x3(x, w, padding[0])
     return F.conv2d(x, w, None, stride, padding, dilation)
 
 
@@ -128,6 +152,13 @@ def raw_backward(gy, x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1), want_
         gx, gw, gb = _cb(_low(gy, dt), _low(x, dt), _low(w, dt), bias_sizes, list(stride), list(padding), list(dilation), False, [0, 0], 1,
                          [want_x, want_w, want_b])
         return _high(gx), _high(gw), (gb.float() if gb is not None else None)
+    if want_x and padding == (1, 1) and _wino_eligible(gy, w.shape, w.shape[0], stride, padding, dilation):
+        from . import ops
+        gx = ops.wino_conv3x3(gy, w, 1, transposed=True)       # the data gradient = the same kernel on the transposed filter
+        if not (want_w or want_b):
+            return gx, None, None
+        _, gw, gb = _cb(gy, x, w, bias_sizes, list(stride), list(padding), list(dilation), False, [0, 0], 1, [False, want_w, want_b])
+        return gx, gw, gb
     return _cb(gy, x, w, bias_sizes, list(stride), list(padding), list(dilation), False, [0, 0], 1, [want_x, want_w, want_b])
 
 
@@ -179,12 +210,32 @@ def _phase_conv(x, w, d):
     return ys.view(B, d, d, w.shape[0], H // d, W // d).permute(0, 3, 4, 1, 5, 2).reshape(B, w.shape[0], H, W)
 
 
+class _RawConvFn(torch.autograd.Function):
+    """conv2d without bias through raw_forward / raw_backward (fp32 layers that take this build's Winograd kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, padding, dilation):
+        ctx.cfg = (stride, padding, dilation)
+        ctx.save_for_backward(x, w)
+        return raw_forward(x, w, stride, padding, dilation)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, padding, dilation = ctx.cfg
+        gx, gw, _ = raw_backward(gy.contiguous(), x, w, stride, padding, dilation, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return gx, gw, None, None, None
+
+
 def conv2d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1):
     """``F.conv2d``; in the reduced compute dtype when one is set (HIP tensors, groups == 1); dilated 3x3 "same"
     convolutions on the phase images (above)."""
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
     if dilation[0] > 1 and _phase_eligible(x, w, stride, padding, dilation, groups):
         y = _phase_conv(x, w, dilation[0])
+        return y if bias is None else y + bias.view(1, -1, 1, 1)
+    if groups == 1 and _wino_eligible(x, w.shape, w.shape[1], stride, padding, dilation):
+        y = _RawConvFn.apply(x, w, stride, padding, dilation)
         return y if bias is None else y + bias.view(1, -1, 1, 1)
     if not (x.is_cuda and groups == 1 and _STATE["dtype"] is not None):
         return F.conv2d(x, w, bias, stride, padding, dilation, groups)

@@ -642,6 +642,22 @@ def planeconv_backward(gy, x, w, want_x=True, want_w=True):
     return gx, gw
 
 
+# --------------------------------------------------------------------------- Winograd F(2x2, 3x3) on the fp32 matrix cores
+def wino_conv3x3(x, w, padding=1, transposed=False):
+    """3x3 stride-1 convolution of x [B,Ci,H,W] (no bias) on dfe_wino_conv3x3.  ``transposed``: w is the forward filter
+    [Ci,Co,3,3] of a convolution whose output gradient is x; the result is its data gradient."""
+    x, w = f32c(x), f32c(w)
+    B, Ci, H, W = x.shape
+    Co = int(w.shape[1] if transposed else w.shape[0])
+    P = int(padding)
+    lib = get_lib()
+    y = torch.empty(B, Co, H + 2 * P - 2, W + 2 * P - 2, device=x.device, dtype=torch.float32)
+    wbuf = torch.empty(lib.dfe_wino_weight_floats(Ci, Co), device=x.device, dtype=torch.float32)
+    check(lib.dfe_wino_conv3x3(ptr(x), ptr(w), ptr(y), y.stride(0), ptr(wbuf), B, Ci, Co, H, W, P, int(bool(transposed)),
+                               stream_ptr()), "dfe_wino_conv3x3")
+    return y
+
+
 class PlaneConvActFn(torch.autograd.Function):
     """act(conv3x3(x, w, pad 1) + bias) on a small plane as one operator (PoseCNN's refinement convolutions,
     pose_cnn.py:43-46, 66-69: Conv2d(12, 12, 3, 1, 1) + ReLU on 2x7 planes): dfe_planeconv_fwd with the epilogue inside;
