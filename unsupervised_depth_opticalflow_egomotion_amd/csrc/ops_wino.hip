@@ -241,12 +241,16 @@ __global__ void __launch_bounds__(256) k_wino_fwd(const float* __restrict__ x, c
 // and the hardware hides one wave's loads and LDS reads under the other's MFMAs: v_mfma_f32_16x16x4_f32, a lane owns
 // (tile = lane & 15, channel 4 g + (lane >> 4)) of step g; block = 4 waves = 64 tiles x 32 output channels.
 __global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__ x, const float* __restrict__ U, float* __restrict__ y,
-                                                       long ybs, int B, int C, int K, int H, int W, int P, int TH, int TW, int ntiles) {
+                                                       long ybs, int B, int C, int K, int H, int W, int P, int TH, int TW, int ntiles,
+                                                       unsigned nkt) {
   extern __shared__ float lds[];      // [WN_CC][32][WN_XP]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
-  const int kt = blockIdx.y;
+  // logical block id = tile block * nkt + kt, dealt so that the nkt blocks of one tile range (they load the same patches)
+  // run on the same XCD at about the same time and share its L2
+  const unsigned lid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int kt = static_cast<int>(lid % nkt), tb = static_cast<int>(lid / nkt);
   const int Ho = H + 2 * P - 2, Wo = W + 2 * P - 2, HW = H * W;
-  const int tile = min(blockIdx.x * 64 + wv * 16 + n, ntiles - 1);
+  const int tile = min(tb * 64 + wv * 16 + n, ntiles - 1);
   const int b = tile / (TH * TW), tr = tile - b * TH * TW, ty = tr / TW, tx = tr - ty * TW;
   const int iy0 = 2 * ty - P, ix0 = 2 * tx - P;
   unsigned off[16], inb = 0;          // BYTE offsets of the 4x4 patch in channel 0 of this lane's sample (0 when outside)
@@ -275,13 +279,34 @@ __global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__
     for (int q = 0; q < 16; ++q) dn[q] = *reinterpret_cast<const float*>(xc + (off[q] + cb));
   };
   issue(kq);
-  for (int c0 = 0; c0 < C; c0 += WN_CC) {
-    const int nc = min(WN_CC, C - c0);
-    for (int e = tid; e < nc * 128; e += 256) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(Ut + static_cast<long>(c0) * 512 + e * 4);
-      *reinterpret_cast<f32x4*>(lds + (e >> 2) * WN_XP + (e & 3) * 4) = v;
+  // weight slabs of 8 input channels, double-buffered: slab i + 1 travels global -> registers under the two steps of slab i
+  // and is written to the other LDS buffer before the chunk's single barrier
+  constexpr int SC = 8, SLAB = SC * 32 * WN_XP;
+  f32x4 wreg[SC * 128 / 256];
+  auto wfetch = [&](int c0) {
+    const int nc = min(SC, C - c0);
+#pragma unroll
+    for (int i = 0; i < SC * 128 / 256; ++i) {
+      const int e = tid + i * 256;
+      wreg[i] = *reinterpret_cast<const f32x4*>(Ut + static_cast<long>(c0) * 512 + (e < nc * 128 ? e : 0) * 4);
     }
-    __syncthreads();
+  };
+  auto wstore = [&](float* buf) {
+#pragma unroll
+    for (int i = 0; i < SC * 128 / 256; ++i) {
+      const int e = tid + i * 256;
+      *reinterpret_cast<f32x4*>(buf + (e >> 2) * WN_XP + (e & 3) * 4) = wreg[i];
+    }
+  };
+  wfetch(0);
+  wstore(lds);
+  __syncthreads();
+  int cur = 0;
+  for (int c0 = 0; c0 < C; c0 += SC) {
+    const int nc = min(SC, C - c0);
+    const bool more = c0 + SC < C;
+    if (more) wfetch(c0 + SC);
+    const float* slab = lds + cur * SLAB;
     for (int cs = 0; cs < nc; cs += 4) {
       float d[16], t[16], v[16];
 #pragma unroll
@@ -301,7 +326,7 @@ __global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__
         v[i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1];
         v[i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
       }
-      const float* up = lds + (min(cs + kq, nc - 1) * 32 + n) * WN_XP;     // a lane past the last channel holds a zero patch
+      const float* up = slab + (min(cs + kq, nc - 1) * 32 + n) * WN_XP;    // a lane past the last channel holds a zero patch
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         float u[16];
@@ -314,10 +339,14 @@ __global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__
         for (int s = 0; s < 16; ++s) acc[h][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[s], v[s], acc[h][s], 0, 0, 0);
       }
     }
-    __syncthreads();
+    if (more) {
+      wstore(lds + (cur ^ 1) * SLAB);               // nobody reads that buffer: its last readers passed the previous barrier
+      __syncthreads();
+      cur ^= 1;
+    }
   }
   // D[i][j]: lane holds tile j = n and the output channels i = 4 kq + r of each 16-channel half
-  if (blockIdx.x * 64 + wv * 16 + n >= ntiles) return;
+  if (tb * 64 + wv * 16 + n >= ntiles) return;
   const int oy = 2 * ty, ox = 2 * tx;
   float* yb = y + b * ybs;
 #pragma unroll
@@ -381,8 +410,11 @@ extern "C" int dfe_wino_conv3x3(const float* x, const float* weight, float* y, l
   const size_t lds_bytes = sizeof(float) * WN_CC * 32 * WN_XP;
   static const int variant = [] { const char* e = getenv("DFE_WINO_VARIANT"); return e ? atoi(e) : 16; }();
   if (variant == 16) {
-    const dim3 grid(static_cast<unsigned>((ntiles + 63) / 64), Kpad / 32);
-    k_wino_fwd16<<<grid, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, static_cast<int>(ntiles));
+    const unsigned nkt = Kpad / 32;
+    const long nblk = (ntiles + 63) / 64 * nkt;
+    if (nblk >= (1L << 31)) return DFE_ERR_DIMS;
+    k_wino_fwd16<<<static_cast<unsigned>(nblk), 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW,
+                                                                   static_cast<int>(ntiles), nkt);
   } else {
     const dim3 grid(static_cast<unsigned>((ntiles + 127) / 128), Kpad / 32);
     if (variant == 2 && P == 1 && W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0)
