@@ -240,6 +240,7 @@ __global__ void __launch_bounds__(256) k_wino_fwd(const float* __restrict__ x, c
 // Variant with HALF the accumulators per wave (16 tiles x 32 output channels: 128 registers) so that two blocks share a CU
 // and the hardware hides one wave's loads and LDS reads under the other's MFMAs: v_mfma_f32_16x16x4_f32, a lane owns
 // (tile = lane & 15, channel 4 g + (lane >> 4)) of step g; block = 4 waves = 64 tiles x 32 output channels.
+template <bool PAIR>
 __global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__ x, const float* __restrict__ U, float* __restrict__ y,
                                                        long ybs, int B, int C, int K, int H, int W, int P, int TH, int TW, int ntiles,
                                                        unsigned nkt) {
@@ -253,16 +254,37 @@ __global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__
   const int tile = min(tb * 64 + wv * 16 + n, ntiles - 1);
   const int b = tile / (TH * TW), tr = tile - b * TH * TW, ty = tr / TW, tx = tr - ty * TW;
   const int iy0 = 2 * ty - P, ix0 = 2 * tx - P;
-  unsigned off[16], inb = 0;          // BYTE offsets of the 4x4 patch in channel 0 of this lane's sample (0 when outside)
+  // PAIR (P = 1, W even): a patch row = [left tile's odd column | this tile's aligned pair | right tile's even column]; a
+  // lane loads its pair with one 8-byte load per row and takes the outer columns from the neighbouring lanes of its 16-lane
+  // row (consecutive lanes = consecutive tiles) by DPP row shifts.  Columns -1 and W are the zero border (this also covers
+  // every row wrap); lanes 0 and 15 of a row have no neighbour and load their outer column themselves (4 lanes per load).
+  unsigned off[16], inb = 0;          // BYTE offsets in channel 0 of this lane's sample (0 when outside); PAIR: off[i] = pair of row i,
+                                      // off[4 + i] / off[8 + i] = the outer columns; inb bits 0-3 rows, 4 = column -1 exists, 5 = column W
+  const bool edge_l = PAIR && n == 0 && tx > 0, edge_r = PAIR && n == 15 && tx < TW - 1;
+  if (PAIR) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int yy = iy0 + i, xx = ix0 + j;
-      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-      off[i * 4 + j] = 4u * (static_cast<unsigned>(b) * C * HW + (ok ? yy * W + xx : 0));
-      inb |= ok ? (1u << (i * 4 + j)) : 0u;
+    for (int i = 0; i < 4; ++i) {
+      const int yy = iy0 + i;
+      const bool ok = yy >= 0 && yy < H;
+      const unsigned rowb = 4u * (static_cast<unsigned>(b) * C * HW + (ok ? yy * W : 0));
+      off[i] = rowb + 8u * static_cast<unsigned>(tx);
+      off[4 + i] = rowb + 4u * static_cast<unsigned>(max(2 * tx - 1, 0));
+      off[8 + i] = rowb + 4u * static_cast<unsigned>(min(2 * tx + 2, W - 1));
+      off[12 + i] = 0;
+      inb |= ok ? (1u << i) : 0u;
     }
+    inb |= (tx > 0 ? 16u : 0u) | (tx < TW - 1 ? 32u : 0u);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int yy = iy0 + i, xx = ix0 + j;
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        off[i * 4 + j] = 4u * (static_cast<unsigned>(b) * C * HW + (ok ? yy * W + xx : 0));
+        inb |= ok ? (1u << (i * 4 + j)) : 0u;
+      }
+  }
   f32x4 acc[2][16];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
@@ -270,13 +292,48 @@ __global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__
     for (int s = 0; s < 16; ++s) acc[h][s] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   const float* Ut = U + static_cast<long>(kt) * C * 512;
   const char* xc = reinterpret_cast<const char*>(x);
-  float dn[16];
+  float dn[16];                       // PAIR: dn[2 i], dn[2 i + 1] = the pair of row i; dn[8 + i] / dn[12 + i] = outer columns (edge lanes)
   unsigned mn;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   auto issue = [&](int c) {
     mn = c < C ? inb : 0u;
     const unsigned cb = 4u * static_cast<unsigned>(c < C ? c : 0) * HW;
+    if (PAIR) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) dn[q] = *reinterpret_cast<const float*>(xc + (off[q] + cb));
+      for (int i = 0; i < 4; ++i) {
+        const f32x2 p = *reinterpret_cast<const f32x2*>(xc + (off[i] + cb));
+        dn[2 * i] = p[0]; dn[2 * i + 1] = p[1];
+      }
+      if (edge_l) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dn[8 + i] = *reinterpret_cast<const float*>(xc + (off[4 + i] + cb));
+      }
+      if (edge_r) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dn[12 + i] = *reinterpret_cast<const float*>(xc + (off[8 + i] + cb));
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) dn[q] = *reinterpret_cast<const float*>(xc + (off[q] + cb));
+    }
+  };
+  auto gather = [&](float (&d)[16]) {                // the masked 4x4 patch of the step whose loads were issued last
+    if (PAIR) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool rok = (mn >> i) & 1u;
+        const float p1 = rok ? dn[2 * i] : 0.0f, p2 = rok ? dn[2 * i + 1] : 0.0f;
+        const float fromL = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p2), 0x111, 0xF, 0xF, true));   // row_shr:1
+        const float fromR = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p1), 0x101, 0xF, 0xF, true));   // row_shl:1
+        const float l = edge_l ? (rok ? dn[8 + i] : 0.0f) : fromL, r = edge_r ? (rok ? dn[12 + i] : 0.0f) : fromR;
+        d[4 * i] = (mn & 16u) ? l : 0.0f;
+        d[4 * i + 1] = p1; d[4 * i + 2] = p2;
+        d[4 * i + 3] = (mn & 32u) ? r : 0.0f;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) d[q] = ((mn >> q) & 1u) ? dn[q] : 0.0f;
+    }
   };
   issue(kq);
   // weight slabs of 8 input channels, double-buffered: slab i + 1 travels global -> registers under the two steps of slab i
@@ -309,8 +366,7 @@ __global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__
     const float* slab = lds + cur * SLAB;
     for (int cs = 0; cs < nc; cs += 4) {
       float d[16], t[16], v[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) d[q] = ((mn >> q) & 1u) ? dn[q] : 0.0f;
+      gather(d);
       issue(c0 + cs + 4 + kq);                      // the next step's patch
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -413,8 +469,13 @@ extern "C" int dfe_wino_conv3x3(const float* x, const float* weight, float* y, l
     const unsigned nkt = Kpad / 32;
     const long nblk = (ntiles + 63) / 64 * nkt;
     if (nblk >= (1L << 31)) return DFE_ERR_DIMS;
-    k_wino_fwd16<<<static_cast<unsigned>(nblk), 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW,
-                                                                   static_cast<int>(ntiles), nkt);
+    static const bool pair_ok = [] { const char* e = getenv("DFE_WINO_PAIR"); return !e || atoi(e) != 0; }();
+    if (pair_ok && P == 1 && W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0)
+      k_wino_fwd16<true><<<static_cast<unsigned>(nblk), 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW,
+                                                                           static_cast<int>(ntiles), nkt);
+    else
+      k_wino_fwd16<false><<<static_cast<unsigned>(nblk), 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW,
+                                                                            static_cast<int>(ntiles), nkt);
   } else {
     const dim3 grid(static_cast<unsigned>((ntiles + 127) / 128), Kpad / 32);
     if (variant == 2 && P == 1 && W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0)
