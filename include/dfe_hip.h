@@ -261,11 +261,12 @@ int dfe_planeconv_wgrad(const float* gy, const float* x, float* gweight, float* 
 /* ---- 3x3 / stride 1 convolutions of the networks' large layers as Winograd F(2x2, 3x3) on the fp32 matrix cores, one fused
  * kernel (depth_model.py:60-211 ResNet encoder / decoder, pwc_tf.py:28-95 decoder and context network, feature_pyramid.py:7-36;
  * MIOpen runs the same algorithm on the vector ALU).  x [B,Ci,H,W]; y [B,Co,Ho,Wo], Ho = H + 2P - 2, Wo = W + 2P - 2, P = 1
- * (zero padding) or 0 (valid); element (b,co,i) of y at y + b * y_batch_stride + co * Ho*Wo + i.
+ * (zero padding), 0 (valid) or 2 (full: the data gradient of a valid convolution); element (b,co,i) of y at
+ * y + b * y_batch_stride + co * Ho*Wo + i.
  * transposed_weight = 0: weight [Co,Ci,3,3], y = conv(x, weight) (no bias).
  * transposed_weight = 1: weight [Ci,Co,3,3] is the FORWARD filter of a convolution whose output gradient is x: y is its data
- *                        gradient, i.e. conv(x, w') with w'[co][ci][ky][kx] = weight[ci][co][2-ky][2-kx] (use P = 1 for a
- *                        forward P = 1, P = 2 is not offered).
+ *                        gradient, i.e. conv(x, w') with w'[co][ci][ky][kx] = weight[ci][co][2-ky][2-kx] (P = 1 for a forward
+ *                        P = 1, P = 2 for a forward P = 0).
  * wbuf: dfe_wino_weight_floats(Ci, Co) floats of scratch for the transformed filters (16-byte aligned).
  * DFE_ERR_DIMS when B*Ci*H*W >= 2^30 (32-bit offsets). */
 long dfe_wino_weight_floats(int Ci, int Co);

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 # (B, Ci, Co, H, W, P)
 SHAPES = [(2, 64, 64, 64, 208, 1), (2, 128, 128, 32, 104, 1), (1, 115, 128, 64, 208, 1), (2, 96, 32, 34, 50, 0),
           (1, 256, 96, 16, 52, 1), (3, 17, 33, 7, 9, 1), (1, 1, 1, 3, 3, 1), (2, 5, 70, 11, 6, 0), (1, 18, 40, 2, 2, 1),
-          (1, 34, 32, 5, 64, 1)]
+          (1, 34, 32, 5, 64, 1), (2, 40, 48, 18, 54, 0), (1, 33, 20, 6, 10, 2), (2, 32, 32, 7, 9, 2), (1, 8, 8, 4, 34, 0)]
 
 
 def dev():
@@ -32,11 +32,12 @@ def test_wino_conv_matches_float64(shape):
     err, scale = float((y.double() - ref).abs().max()), float(ref.abs().max())
     assert err <= 2e-5 * scale + 1e-12, (err, scale)
     assert torch.equal(y, ops.wino_conv3x3(x, w, P))
-    if P == 1:      # data gradient of the same convolution: gy [B,Co,H,W] -> gx [B,Ci,H,W]
-        gy = torch.randn(B, Co, H, W, device=dev())
-        gx = ops.wino_conv3x3(gy, w, 1, transposed=True)
-        rgx = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+    if P in (0, 1):      # data gradient of the same convolution: gy [B,Co,Ho,Wo] -> gx [B,Ci,H,W] (full correlation when P = 0)
+        gy = torch.randn(*ref.shape, device=dev())
+        gx = ops.wino_conv3x3(gy, w, 1 if P == 1 else 2, transposed=True)
+        rgx = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), None, [1, 1], [P, P], [1, 1], False, [0, 0], 1,
                                                   [True, False, False])[0]
+        assert gx.shape == x.shape
         err, scale = float((gx.double() - rgx).abs().max()), float(rgx.abs().max())
         assert err <= 2e-5 * scale + 1e-12, (err, scale)
 

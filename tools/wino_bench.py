@@ -27,6 +27,9 @@ def ev(fn, n):
     return a.elapsed_time(b) * 1e3 / n
 
 
+VALID = [(12, 96, 32, 130, 418), (12, 128, 64, 66, 210), (12, 256, 128, 34, 106), (12, 512, 256, 18, 54), (12, 64, 32, 130, 418)]
+
+
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=30); a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -45,5 +48,20 @@ def main():
             B, ci, co, H, W, fl / 1e9, t_m, fl / t_m / 1e6, t_w, fl / t_w / 1e6, t_md, t_wd, err))
 
 
+def valid():
+    dev = torch.device("cuda:0")
+    print()
+    print("| valid (pre-padded input) B x Ci -> Co @ Hp x Wp | MIOpen fwd us | wino fwd us | MIOpen dgrad us | wino dgrad (full) us |")
+    print("|---|---|---|---|---|")
+    for (B, ci, co, H, W) in VALID:
+        x = torch.randn(B, ci, H, W, device=dev); w = torch.randn(co, ci, 3, 3, device=dev) * 0.05; gy = torch.randn(B, co, H - 2, W - 2, device=dev)
+        t_m = ev(lambda: F.conv2d(x, w), 20)
+        t_w = ev(lambda: ops.wino_conv3x3(x, w, 0), 20)
+        t_md = ev(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False]), 20)
+        t_wd = ev(lambda: ops.wino_conv3x3(gy, w, 2, transposed=True), 20)
+        print("| %d x %d -> %d @ %dx%d | %.1f | %.1f | %.1f | %.1f |" % (B, ci, co, H, W, t_m, t_w, t_md, t_wd))
+
+
 if __name__ == "__main__":
     main()
+    valid()

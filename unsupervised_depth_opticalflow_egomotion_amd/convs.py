@@ -111,10 +111,10 @@ _cb = torch.ops.aten.convolution_backward
 
 # Large 3x3 stride-1 layers in fp32: this build's fused Winograd F(2x2, 3x3) kernel on the matrix cores (csrc/ops_wino.hip,
 # ops.wino_conv3x3) for the forward pass and the data gradient -- MIOpen runs the same algorithm on the vector ALU and is
-# 1.15-1.3x slower where there are enough 2x2 output tiles to fill the chip (tools/wino_bench.py); the weight gradient stays
+# 1.2-1.7x slower where there are enough 2x2 output tiles to fill the chip (tools/wino_bench.py); the weight gradient stays
 # MIOpen's.  DFE_WINO_MIN_TILES: smallest B * ceil(Ho/2) * ceil(Wo/2) that takes the kernel (0 = never).
-WINO_MIN_TILES = int(os.environ.get("DFE_WINO_MIN_TILES", "5000"))
-WINO_MIN_CHANNELS = int(os.environ.get("DFE_WINO_MIN_CHANNELS", "48"))
+WINO_MIN_TILES = int(os.environ.get("DFE_WINO_MIN_TILES", "500"))
+WINO_MIN_CHANNELS = int(os.environ.get("DFE_WINO_MIN_CHANNELS", "32"))
 
 
 def _wino_eligible(x, w_shape, cin, stride, padding, dilation, groups=1):
@@ -152,9 +152,10 @@ def raw_backward(gy, x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1), want_
         gx, gw, gb = _cb(_low(gy, dt), _low(x, dt), _low(w, dt), bias_sizes, list(stride), list(padding), list(dilation), False, [0, 0], 1,
                          [want_x, want_w, want_b])
         return _high(gx), _high(gw), (gb.float() if gb is not None else None)
-    if want_x and padding == (1, 1) and _wino_eligible(gy, w.shape, w.shape[0], stride, padding, dilation):
+    if want_x and padding in ((1, 1), (0, 0)) and _wino_eligible(gy, w.shape, w.shape[0], stride, (1, 1), dilation):
         from . import ops
-        gx = ops.wino_conv3x3(gy, w, 1, transposed=True)       # the data gradient = the same kernel on the transposed filter
+        # the data gradient = the same kernel on the transposed filter (full correlation, padding 2, for a valid convolution)
+        gx = ops.wino_conv3x3(gy, w, 1 if padding == (1, 1) else 2, transposed=True)
         if not (want_w or want_b):
             return gx, None, None
         _, gw, gb = _cb(gy, x, w, bias_sizes, list(stride), list(padding), list(dilation), False, [0, 0], 1, [False, want_w, want_b])

@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(256) k_wino_fwd(const float* __restrict__ x, c
 // Variant with HALF the accumulators per wave (16 tiles x 32 output channels: 128 registers) so that two blocks share a CU
 // and the hardware hides one wave's loads and LDS reads under the other's MFMAs: v_mfma_f32_16x16x4_f32, a lane owns
 // (tile = lane & 15, channel 4 g + (lane >> 4)) of step g; block = 4 waves = 64 tiles x 32 output channels.
-template <bool PAIR>
+template <int PP>      // PP = 0 / 1 / 2: the padding, pair loads (W even); -1: any padding and width, 16 single loads per patch
 __global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__ x, const float* __restrict__ U, float* __restrict__ y,
                                                        long ybs, int B, int C, int K, int H, int W, int P, int TH, int TW, int ntiles,
                                                        unsigned nkt) {
@@ -254,26 +254,32 @@ __global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__
   const int tile = min(tb * 64 + wv * 16 + n, ntiles - 1);
   const int b = tile / (TH * TW), tr = tile - b * TH * TW, ty = tr / TW, tx = tr - ty * TW;
   const int iy0 = 2 * ty - P, ix0 = 2 * tx - P;
-  // PAIR (P = 1, W even): a patch row = [left tile's odd column | this tile's aligned pair | right tile's even column]; a
-  // lane loads its pair with one 8-byte load per row and takes the outer columns from the neighbouring lanes of its 16-lane
-  // row (consecutive lanes = consecutive tiles) by DPP row shifts.  Columns -1 and W are the zero border (this also covers
-  // every row wrap); lanes 0 and 15 of a row have no neighbour and load their outer column themselves (4 lanes per load).
-  unsigned off[16], inb = 0;          // BYTE offsets in channel 0 of this lane's sample (0 when outside); PAIR: off[i] = pair of row i,
-                                      // off[4 + i] / off[8 + i] = the outer columns; inb bits 0-3 rows, 4 = column -1 exists, 5 = column W
-  const bool edge_l = PAIR && n == 0 && tx > 0, edge_r = PAIR && n == 15 && tx < TW - 1;
+  // Pair loads (PP >= 0, W even).  With L / own / R the aligned column pairs (2tx-2, 2tx-1) / (2tx, 2tx+1) / (2tx+2, 2tx+3):
+  //   P = 1: a patch row = [L.b, own.a, own.b, R.a]     P = 0: [own.a, own.b, R.a, R.b]     P = 2: [L.a, L.b, own.a, own.b]
+  // A lane loads only its own pair (one 8-byte load per row); L and R are the own pairs of the neighbouring lanes of its
+  // 16-lane row (consecutive lanes = consecutive tiles) and arrive by DPP row shifts.  Pairs outside the image are the
+  // zero border, which also covers the row wraps; the lanes without a usable neighbour (lane 0 / 15 of a row; the last tile
+  // of an image row when P = 0) load that pair themselves -- a handful of lanes per load instruction.
+  constexpr bool PAIR = PP >= 0;
+  constexpr bool USE_L = PP == 1 || PP == 2, USE_R = PP == 1 || PP == 0;
+  unsigned off[16], inb = 0;          // BYTE offsets in channel 0 of this lane's sample (0 when outside).  PAIR: off[i] = own pair of
+                                      // row i, off[4 + i] = the pair an edge lane loads; inb bits 0-3 rows, 4 = L, 5 = R, 6 = own inside
+  bool edge_l = false, edge_r = false;
   if (PAIR) {
+    const bool okL = tx >= 1, okR = 2 * tx + 3 < W, okO = 2 * tx + 1 < W;
+    edge_l = USE_L && okL && n == 0;
+    edge_r = USE_R && okR && (n == 15 || tx == TW - 1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int yy = iy0 + i;
       const bool ok = yy >= 0 && yy < H;
       const unsigned rowb = 4u * (static_cast<unsigned>(b) * C * HW + (ok ? yy * W : 0));
-      off[i] = rowb + 8u * static_cast<unsigned>(tx);
-      off[4 + i] = rowb + 4u * static_cast<unsigned>(max(2 * tx - 1, 0));
-      off[8 + i] = rowb + 4u * static_cast<unsigned>(min(2 * tx + 2, W - 1));
-      off[12 + i] = 0;
+      off[i] = rowb + (okO ? 8u * static_cast<unsigned>(tx) : 0u);
+      off[4 + i] = rowb + (edge_l ? 8u * static_cast<unsigned>(tx - 1) : edge_r ? 8u * static_cast<unsigned>(tx + 1) : 0u);
+      off[8 + i] = 0; off[12 + i] = 0;
       inb |= ok ? (1u << i) : 0u;
     }
-    inb |= (tx > 0 ? 16u : 0u) | (tx < TW - 1 ? 32u : 0u);
+    inb |= (okL ? 16u : 0u) | (okR ? 32u : 0u) | (okO ? 64u : 0u);
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -292,7 +298,7 @@ __global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__
     for (int s = 0; s < 16; ++s) acc[h][s] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   const float* Ut = U + static_cast<long>(kt) * C * 512;
   const char* xc = reinterpret_cast<const char*>(x);
-  float dn[16];                       // PAIR: dn[2 i], dn[2 i + 1] = the pair of row i; dn[8 + i] / dn[12 + i] = outer columns (edge lanes)
+  float dn[16];                       // PAIR: dn[2 i], dn[2 i + 1] = the own pair of row i; dn[8 + 2 i], dn[9 + 2 i] = an edge lane's L / R pair
   unsigned mn;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   auto issue = [&](int c) {
@@ -304,31 +310,44 @@ __global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__
         const f32x2 p = *reinterpret_cast<const f32x2*>(xc + (off[i] + cb));
         dn[2 * i] = p[0]; dn[2 * i + 1] = p[1];
       }
-      if (edge_l) {
+      if (edge_l || edge_r) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dn[8 + i] = *reinterpret_cast<const float*>(xc + (off[4 + i] + cb));
-      }
-      if (edge_r) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dn[12 + i] = *reinterpret_cast<const float*>(xc + (off[8 + i] + cb));
+        for (int i = 0; i < 4; ++i) {
+          const f32x2 p = *reinterpret_cast<const f32x2*>(xc + (off[4 + i] + cb));
+          dn[8 + 2 * i] = p[0]; dn[9 + 2 * i] = p[1];
+        }
       }
     } else {
 #pragma unroll
       for (int q = 0; q < 16; ++q) dn[q] = *reinterpret_cast<const float*>(xc + (off[q] + cb));
     }
   };
+  auto shr1 = [](float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true)); };   // row_shr:1
+  auto shl1 = [](float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xF, 0xF, true)); };   // row_shl:1
   auto gather = [&](float (&d)[16]) {                // the masked 4x4 patch of the step whose loads were issued last
     if (PAIR) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bool rok = (mn >> i) & 1u;
-        const float p1 = rok ? dn[2 * i] : 0.0f, p2 = rok ? dn[2 * i + 1] : 0.0f;
-        const float fromL = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p2), 0x111, 0xF, 0xF, true));   // row_shr:1
-        const float fromR = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p1), 0x101, 0xF, 0xF, true));   // row_shl:1
-        const float l = edge_l ? (rok ? dn[8 + i] : 0.0f) : fromL, r = edge_r ? (rok ? dn[12 + i] : 0.0f) : fromR;
-        d[4 * i] = (mn & 16u) ? l : 0.0f;
-        d[4 * i + 1] = p1; d[4 * i + 2] = p2;
-        d[4 * i + 3] = (mn & 32u) ? r : 0.0f;
+        const bool oko = rok && (mn & 64u);
+        const float o1 = oko ? dn[2 * i] : 0.0f, o2 = oko ? dn[2 * i + 1] : 0.0f;
+        const float e1 = rok ? dn[8 + 2 * i] : 0.0f, e2 = rok ? dn[9 + 2 * i] : 0.0f;
+        float l1 = 0.0f, l2 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+        if (USE_L) {
+          if (PP == 2) l1 = shr1(o1);
+          l2 = shr1(o2);
+          if (PP == 2) l1 = (mn & 16u) ? (edge_l ? e1 : l1) : 0.0f;
+          l2 = (mn & 16u) ? (edge_l ? e2 : l2) : 0.0f;
+        }
+        if (USE_R) {
+          r1 = shl1(o1);
+          if (PP == 0) r2 = shl1(o2);
+          r1 = (mn & 32u) ? (edge_r ? e1 : r1) : 0.0f;
+          if (PP == 0) r2 = (mn & 32u) ? (edge_r ? e2 : r2) : 0.0f;
+        }
+        if (PP == 1) { d[4 * i] = l2; d[4 * i + 1] = o1; d[4 * i + 2] = o2; d[4 * i + 3] = r1; }
+        else if (PP == 0) { d[4 * i] = o1; d[4 * i + 1] = o2; d[4 * i + 2] = r1; d[4 * i + 3] = r2; }
+        else { d[4 * i] = l1; d[4 * i + 1] = l2; d[4 * i + 2] = o1; d[4 * i + 3] = o2; }
       }
     } else {
 #pragma unroll
@@ -437,7 +456,7 @@ using namespace dfe;
 
 static int wn_dims(int B, int Ci, int Co, int H, int W, int P) {
   if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return DFE_ERR_DIMS;
-  if (P != 0 && P != 1) return DFE_ERR_UNSUPPORTED;
+  if (P < 0 || P > 2) return DFE_ERR_UNSUPPORTED;
   if (H + 2 * P < 3 || W + 2 * P < 3) return DFE_ERR_DIMS;
   if (static_cast<long>(B) * Ci * H * W >= (1L << 30) || static_cast<long>(Co) * H * W >= (1L << 31) || Co > 65535 * 32) return DFE_ERR_DIMS;   // 32-bit offsets
   return DFE_OK;
@@ -470,12 +489,13 @@ extern "C" int dfe_wino_conv3x3(const float* x, const float* weight, float* y, l
     const long nblk = (ntiles + 63) / 64 * nkt;
     if (nblk >= (1L << 31)) return DFE_ERR_DIMS;
     static const bool pair_ok = [] { const char* e = getenv("DFE_WINO_PAIR"); return !e || atoi(e) != 0; }();
-    if (pair_ok && P == 1 && W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0)
-      k_wino_fwd16<true><<<static_cast<unsigned>(nblk), 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW,
-                                                                           static_cast<int>(ntiles), nkt);
-    else
-      k_wino_fwd16<false><<<static_cast<unsigned>(nblk), 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW,
-                                                                            static_cast<int>(ntiles), nkt);
+    const bool pair = pair_ok && W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0;
+    const unsigned g = static_cast<unsigned>(nblk);
+    const int nt = static_cast<int>(ntiles);
+    if (pair && P == 1) k_wino_fwd16<1><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt);
+    else if (pair && P == 0) k_wino_fwd16<0><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt);
+    else if (pair && P == 2) k_wino_fwd16<2><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt);
+    else k_wino_fwd16<-1><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt);
   } else {
     const dim3 grid(static_cast<unsigned>((ntiles + 127) / 128), Kpad / 32);
     if (variant == 2 && P == 1 && W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0)
