@@ -270,6 +270,10 @@ int dfe_planeconv_wgrad(const float* gy, const float* x, float* gweight, float* 
  * wbuf: dfe_wino_weight_floats(Ci, Co) floats of scratch for the transformed filters (16-byte aligned).
  * DFE_ERR_DIMS when B*Ci*H*W >= 2^30 (32-bit offsets). */
 long dfe_wino_weight_floats(int Ci, int Co);
+/* the same for a DILATED 3x3 convolution with padding = dilation (pwc_tf.py:31-36 context network: dilation 2, 4, 8, 16): the
+ * Winograd tiles live on the dilation x dilation phase images; H and W must be multiples of the dilation.  y has x's size. */
+int dfe_wino_conv3x3_dilated(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, int B, int Ci, int Co,
+                             int H, int W, int dilation, int transposed_weight, void* stream);
 int dfe_wino_conv3x3(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, int B, int Ci, int Co, int H,
                      int W, int P, int transposed_weight, void* stream);
 

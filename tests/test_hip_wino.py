@@ -52,3 +52,20 @@ def test_wino_conv_nonfinite_and_errors():
     assert bool(torch.isnan(y[0, :, 1:4, 2:5]).all()) and bool(torch.isnan(ref[0, :, 1:4, 2:5]).all())
     assert get_lib().dfe_wino_conv3x3(None, None, None, 0, None, 1, 1, 1, 4, 4, 1, 0, None) == -1
     assert get_lib().dfe_wino_weight_floats(5, 33) == 64 * 5 * 16
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, 16, 32, 2), (1, 40, 36, 32, 64, 4), (1, 16, 24, 32, 48, 8), (2, 33, 17, 8, 12, 2), (1, 8, 8, 64, 64, 16)])
+def test_wino_dilated_conv_matches_float64(shape):
+    """dilated 3x3 convolutions (padding = dilation; PWC's context network): forward and data gradient on the phase images."""
+    B, Ci, Co, H, W, d = shape
+    torch.manual_seed(sum(shape))
+    x = torch.randn(B, Ci, H, W, device=dev())
+    w = torch.randn(Co, Ci, 3, 3, device=dev()) / (3.0 * Ci ** 0.5)
+    gy = torch.randn(B, Co, H, W, device=dev())
+    y = ops.wino_conv3x3(x, w, dilation=d)
+    ref = F.conv2d(x.double(), w.double(), None, 1, d, d)
+    assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    gx = ops.wino_conv3x3(gy, w, transposed=True, dilation=d)
+    rgx = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), None, [1, 1], [d, d], [d, d], False, [0, 0], 1,
+                                              [True, False, False])[0]
+    assert float((gx.double() - rgx).abs().max()) <= 2e-5 * float(rgx.abs().max())

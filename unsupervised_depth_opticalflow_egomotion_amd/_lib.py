@@ -47,6 +47,7 @@ _SIGNATURES = {
     "dfe_cast_bf16_nhwc_to_f32_nchw": [_P, _P, _I, _I, ctypes.c_long, _P],
     "dfe_wino_weight_floats": [_I, _I],
     "dfe_wino_conv3x3": [_P, _P, _P, ctypes.c_long, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dfe_wino_conv3x3_dilated": [_P, _P, _P, ctypes.c_long, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dfe_conv1x1_small_supported": [_I, _I, _I, _I, _I],
     "dfe_conv1x1_small_fwd": [_P, _P, _P, ctypes.c_float, _P, _I, _I, _I, _I, _I, _P],
     "dfe_conv1x1_small_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -115,20 +115,30 @@ _cb = torch.ops.aten.convolution_backward
 # MIOpen's.  DFE_WINO_MIN_TILES: smallest B * ceil(Ho/2) * ceil(Wo/2) that takes the kernel (0 = never).
 WINO_MIN_TILES = int(os.environ.get("DFE_WINO_MIN_TILES", "500"))
 WINO_MIN_CHANNELS = int(os.environ.get("DFE_WINO_MIN_CHANNELS", "32"))
+WINO_DILATED = os.environ.get("DFE_WINO_DILATED", "1") == "1"     # dilated layers too (instead of MIOpen / the phase-image path)
 
 
 def _wino_eligible(x, w_shape, cin, stride, padding, dilation, groups=1):
-    """x [B,cin,H,W] convolved 3x3 / stride 1 with ``padding`` in {0, 1}: enough tiles and reduction channels?"""
+    """x [B,cin,H,W] convolved 3x3 / stride 1 with ``padding`` in {0, 1} (or dilated with padding = dilation dividing H and
+    W): enough tiles and reduction channels?"""
     if (WINO_MIN_TILES <= 0 or _STATE["dtype"] is not None or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4
-            or groups != 1 or tuple(w_shape[2:]) != (3, 3) or stride != (1, 1) or dilation != (1, 1)
-            or padding not in ((0, 0), (1, 1))):
+            or groups != 1 or tuple(w_shape[2:]) != (3, 3) or stride != (1, 1) or dilation[0] != dilation[1]):
         return False
     B, C, H, W = x.shape
-    P = padding[0]
-    Ho, Wo = H + 2 * P - 2, W + 2 * P - 2
+    d = dilation[0]
+    if d > 1:
+        if padding != (d, d) or H % d or W % d or H // d < 2 or W // d < 2 or not WINO_DILATED:
+            return False
+        Ho, Wo = H // d, W // d
+        B = B * d * d
+    else:
+        if padding not in ((0, 0), (1, 1)):
+            return False
+        P = padding[0]
+        Ho, Wo = H + 2 * P - 2, W + 2 * P - 2
     if C != cin or Ho < 1 or Wo < 1:
         return False
-    return (B * ((Ho + 1) // 2) * ((Wo + 1) // 2) >= WINO_MIN_TILES and C >= WINO_MIN_CHANNELS and B * C * H * W < (1 << 30))
+    return (B * ((Ho + 1) // 2) * ((Wo + 1) // 2) >= WINO_MIN_TILES and C >= WINO_MIN_CHANNELS and x.numel() < (1 << 30))
 
 
 def raw_forward(x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1)):
@@ -139,7 +149,7 @@ def raw_forward(x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1)):
         return _high(F.conv2d(_low(x, dt), _low(w, dt), None, stride, padding, dilation))
     if _wino_eligible(x, w.shape, w.shape[1], stride, padding, dilation):
         from . import ops
-        return ops.wino_conv3x3(x, w, padding[0])
+        return ops.wino_conv3x3(x, w, padding[0], dilation=dilation[0])
     return F.conv2d(x, w, None, stride, padding, dilation)
 
 
@@ -152,10 +162,12 @@ def raw_backward(gy, x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1), want_
         gx, gw, gb = _cb(_low(gy, dt), _low(x, dt), _low(w, dt), bias_sizes, list(stride), list(padding), list(dilation), False, [0, 0], 1,
                          [want_x, want_w, want_b])
         return _high(gx), _high(gw), (gb.float() if gb is not None else None)
-    if want_x and padding in ((1, 1), (0, 0)) and _wino_eligible(gy, w.shape, w.shape[0], stride, (1, 1), dilation):
+    d = dilation[0]
+    if want_x and (padding in ((1, 1), (0, 0)) or (d > 1 and padding == (d, d))) and \
+            _wino_eligible(gy, w.shape, w.shape[0], stride, (d, d) if d > 1 else (1, 1), dilation):
         from . import ops
         # the data gradient = the same kernel on the transposed filter (full correlation, padding 2, for a valid convolution)
-        gx = ops.wino_conv3x3(gy, w, 1 if padding == (1, 1) else 2, transposed=True)
+        gx = ops.wino_conv3x3(gy, w, 1 if padding != (0, 0) else 2, transposed=True, dilation=d)
         if not (want_w or want_b):
             return gx, None, None
         _, gw, gb = _cb(gy, x, w, bias_sizes, list(stride), list(padding), list(dilation), False, [0, 0], 1, [False, want_w, want_b])
@@ -232,6 +244,9 @@ def conv2d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1):
     """``F.conv2d``; in the reduced compute dtype when one is set (HIP tensors, groups == 1); dilated 3x3 "same"
     convolutions on the phase images (above)."""
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
+    if groups == 1 and dilation[0] > 1 and _wino_eligible(x, w.shape, w.shape[1], stride, padding, dilation):
+        y = _RawConvFn.apply(x, w, stride, padding, dilation)
+        return y if bias is None else y + bias.view(1, -1, 1, 1)
     if dilation[0] > 1 and _phase_eligible(x, w, stride, padding, dilation, groups):
         y = _phase_conv(x, w, dilation[0])
         return y if bias is None else y + bias.view(1, -1, 1, 1)

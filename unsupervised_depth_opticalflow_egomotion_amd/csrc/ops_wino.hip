@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256) k_wino_fwd(const float* __restrict__ x, c
 template <int PP>      // PP = 0 / 1 / 2: the padding, pair loads (W even); -1: any padding and width, 16 single loads per patch
 __global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__ x, const float* __restrict__ U, float* __restrict__ y,
                                                        long ybs, int B, int C, int K, int H, int W, int P, int TH, int TW, int ntiles,
-                                                       unsigned nkt) {
+                                                       unsigned nkt, int dil) {
   extern __shared__ float lds[];      // [WN_CC][32][WN_XP]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
   // logical block id = tile block * nkt + kt, dealt so that the nkt blocks of one tile range (they load the same patches)
@@ -252,7 +252,21 @@ __global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__
   const int kt = static_cast<int>(lid % nkt), tb = static_cast<int>(lid / nkt);
   const int Ho = H + 2 * P - 2, Wo = W + 2 * P - 2, HW = H * W;
   const int tile = min(tb * 64 + wv * 16 + n, ntiles - 1);
-  const int b = tile / (TH * TW), tr = tile - b * TH * TW, ty = tr / TW, tx = tr - ty * TW;
+  // dil > 1 (PP = -1 only): the convolution acts on the dil x dil phase images (pixels y = py + dil qy, x = px + dil qx) with
+  // padding 1 in phase coordinates; tiles are numbered (b, py, ty, tx, px) so that consecutive lanes read consecutive pixels
+  int b, ty, tx, py = 0, px = 0;
+  if (PP >= 0 || dil == 1) {
+    b = tile / (TH * TW);
+    const int tr = tile - b * TH * TW;
+    ty = tr / TW; tx = tr - ty * TW;
+  } else {
+    const int per_row = TW * dil, per_phase = TH * per_row, per_img = per_phase * dil;
+    b = tile / per_img;
+    int tr = tile - b * per_img;
+    py = tr / per_phase; tr -= py * per_phase;
+    ty = tr / per_row; tr -= ty * per_row;
+    tx = tr / dil; px = tr - tx * dil;
+  }
   const int iy0 = 2 * ty - P, ix0 = 2 * tx - P;
   // Pair loads (PP >= 0, W even).  With L / own / R the aligned column pairs (2tx-2, 2tx-1) / (2tx, 2tx+1) / (2tx+2, 2tx+3):
   //   P = 1: a patch row = [L.b, own.a, own.b, R.a]     P = 0: [own.a, own.b, R.a, R.b]     P = 2: [L.a, L.b, own.a, own.b]
@@ -281,13 +295,14 @@ __global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__
     }
     inb |= (okL ? 16u : 0u) | (okR ? 32u : 0u) | (okO ? 64u : 0u);
   } else {
+    const int Hq = H / dil, Wq = W / dil;           // phase-image size (H, W themselves when dil = 1)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int yy = iy0 + i, xx = ix0 + j;
-        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-        off[i * 4 + j] = 4u * (static_cast<unsigned>(b) * C * HW + (ok ? yy * W + xx : 0));
+        const bool ok = yy >= 0 && yy < Hq && xx >= 0 && xx < Wq;
+        off[i * 4 + j] = 4u * (static_cast<unsigned>(b) * C * HW + (ok ? (py + dil * yy) * W + px + dil * xx : 0));
         inb |= ok ? (1u << (i * 4 + j)) : 0u;
       }
   }
@@ -422,8 +437,10 @@ __global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__
   }
   // D[i][j]: lane holds tile j = n and the output channels i = 4 kq + r of each 16-channel half
   if (tb * 64 + wv * 16 + n >= ntiles) return;
+  const int Hoq = (PP >= 0 || dil == 1) ? Ho : H / dil, Woq = (PP >= 0 || dil == 1) ? Wo : W / dil;   // outputs per phase image
   const int oy = 2 * ty, ox = 2 * tx;
-  float* yb = y + b * ybs;
+  const int sy = dil * Wo, sx = dil;                // strides of the 2x2 outputs in y
+  float* yb = y + b * ybs + static_cast<long>(py + dil * oy) * Wo + px + dil * ox;
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -438,13 +455,14 @@ __global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__
       }
       const float y00 = (t0[0] + t0[1]) + t0[2], y01 = (t0[1] - t0[2]) - t0[3];
       const float y10 = (t1[0] + t1[1]) + t1[2], y11 = (t1[1] - t1[2]) - t1[3];
-      float* o = yb + static_cast<long>(k) * Ho * Wo + oy * Wo + ox;
-      if (ox + 1 < Wo) {
-        if (oy < Ho) { o[0] = y00; o[1] = y01; }
-        if (oy + 1 < Ho) { o[Wo] = y10; o[Wo + 1] = y11; }
-      } else if (ox < Wo) {
-        if (oy < Ho) o[0] = y00;
-        if (oy + 1 < Ho) o[Wo] = y10;
+      float* o = yb + static_cast<long>(k) * Ho * Wo;
+      if (oy < Hoq) {
+        if (ox < Woq) o[0] = y00;
+        if (ox + 1 < Woq) o[sx] = y01;
+      }
+      if (oy + 1 < Hoq) {
+        if (ox < Woq) o[sy] = y10;
+        if (ox + 1 < Woq) o[sy + sx] = y11;
       }
     }
 }
@@ -465,12 +483,14 @@ static int wn_dims(int B, int Ci, int Co, int H, int W, int P) {
 extern "C" long dfe_wino_weight_floats(int Ci, int Co) { return (Ci <= 0 || Co <= 0) ? 0 : static_cast<long>((Co + 31) / 32) * 32 * Ci * 16; }
 
 // transposed_weight: see include/dfe_hip.h
-extern "C" int dfe_wino_conv3x3(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, int B, int Ci,
-                                int Co, int H, int W, int P, int transposed_weight, void* stream) {
+static int wino_run(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, int B, int Ci, int Co, int H, int W,
+                    int P, int dil, int transposed_weight, void* stream) {
   if (!x || !weight || !y || !wbuf) return DFE_ERR_NULL;
   const int rc = wn_dims(B, Ci, Co, H, W, P);
   if (rc != DFE_OK) return rc;
-  const int Ho = H + 2 * P - 2, Wo = W + 2 * P - 2;
+  if (dil < 1 || (dil > 1 && (P != 1 || H % dil != 0 || W % dil != 0 || H / dil < 2 || W / dil < 2))) return DFE_ERR_UNSUPPORTED;
+  // dil > 1: padding = dil in pixels = 1 in phase coordinates: the output has the input's size
+  const int Ho = dil > 1 ? H : H + 2 * P - 2, Wo = dil > 1 ? W : W + 2 * P - 2;
   if (y_batch_stride < static_cast<long>(Co) * Ho * Wo) return DFE_ERR_DIMS;
   if ((reinterpret_cast<uintptr_t>(wbuf) & 15) != 0) return DFE_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -479,23 +499,23 @@ extern "C" int dfe_wino_conv3x3(const float* x, const float* weight, float* y, l
   if (transposed_weight) k_wino_weights<true><<<(nw + 255) / 256, 256, 0, st>>>(weight, wbuf, Co, Ci, Kpad);
   else k_wino_weights<false><<<(nw + 255) / 256, 256, 0, st>>>(weight, wbuf, Co, Ci, Kpad);
   DFE_LAUNCH_CHECK();
-  const int TH = (Ho + 1) / 2, TW = (Wo + 1) / 2;
-  const long ntiles = static_cast<long>(B) * TH * TW;
+  const int TH = (Ho / dil + 1) / 2, TW = (Wo / dil + 1) / 2;
+  const long ntiles = static_cast<long>(B) * TH * TW * dil * dil;
   if (ntiles >= (1L << 31)) return DFE_ERR_DIMS;
   const size_t lds_bytes = sizeof(float) * WN_CC * 32 * WN_XP;
   static const int variant = [] { const char* e = getenv("DFE_WINO_VARIANT"); return e ? atoi(e) : 16; }();
-  if (variant == 16) {
+  if (variant == 16 || dil > 1) {
     const unsigned nkt = Kpad / 32;
     const long nblk = (ntiles + 63) / 64 * nkt;
     if (nblk >= (1L << 31)) return DFE_ERR_DIMS;
     static const bool pair_ok = [] { const char* e = getenv("DFE_WINO_PAIR"); return !e || atoi(e) != 0; }();
-    const bool pair = pair_ok && W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0;
+    const bool pair = pair_ok && dil == 1 && W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0;
     const unsigned g = static_cast<unsigned>(nblk);
     const int nt = static_cast<int>(ntiles);
-    if (pair && P == 1) k_wino_fwd16<1><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt);
-    else if (pair && P == 0) k_wino_fwd16<0><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt);
-    else if (pair && P == 2) k_wino_fwd16<2><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt);
-    else k_wino_fwd16<-1><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt);
+    if (pair && P == 1) k_wino_fwd16<1><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt, dil);
+    else if (pair && P == 0) k_wino_fwd16<0><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt, dil);
+    else if (pair && P == 2) k_wino_fwd16<2><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt, dil);
+    else k_wino_fwd16<-1><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt, dil);
   } else {
     const dim3 grid(static_cast<unsigned>((ntiles + 127) / 128), Kpad / 32);
     if (variant == 2 && P == 1 && W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0)
@@ -505,4 +525,14 @@ extern "C" int dfe_wino_conv3x3(const float* x, const float* weight, float* y, l
   }
   DFE_LAUNCH_CHECK();
   return DFE_OK;
+}
+
+extern "C" int dfe_wino_conv3x3(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, int B, int Ci,
+                                int Co, int H, int W, int P, int transposed_weight, void* stream) {
+  return wino_run(x, weight, y, y_batch_stride, wbuf, B, Ci, Co, H, W, P, 1, transposed_weight, stream);
+}
+
+extern "C" int dfe_wino_conv3x3_dilated(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, int B,
+                                        int Ci, int Co, int H, int W, int dilation, int transposed_weight, void* stream) {
+  return wino_run(x, weight, y, y_batch_stride, wbuf, B, Ci, Co, H, W, 1, dilation, transposed_weight, stream);
 }

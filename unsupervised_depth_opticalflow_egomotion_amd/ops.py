@@ -643,16 +643,22 @@ def planeconv_backward(gy, x, w, want_x=True, want_w=True):
 
 
 # --------------------------------------------------------------------------- Winograd F(2x2, 3x3) on the fp32 matrix cores
-def wino_conv3x3(x, w, padding=1, transposed=False):
+def wino_conv3x3(x, w, padding=1, transposed=False, dilation=1):
     """3x3 stride-1 convolution of x [B,Ci,H,W] (no bias) on dfe_wino_conv3x3.  ``transposed``: w is the forward filter
-    [Ci,Co,3,3] of a convolution whose output gradient is x; the result is its data gradient."""
+    [Ci,Co,3,3] of a convolution whose output gradient is x; the result is its data gradient.  ``dilation`` > 1: a dilated
+    convolution with padding = dilation (``padding`` is ignored)."""
     x, w = f32c(x), f32c(w)
     B, Ci, H, W = x.shape
     Co = int(w.shape[1] if transposed else w.shape[0])
-    P = int(padding)
+    P, d = int(padding), int(dilation)
     lib = get_lib()
-    y = torch.empty(B, Co, H + 2 * P - 2, W + 2 * P - 2, device=x.device, dtype=torch.float32)
     wbuf = torch.empty(lib.dfe_wino_weight_floats(Ci, Co), device=x.device, dtype=torch.float32)
+    if d > 1:
+        y = torch.empty(B, Co, H, W, device=x.device, dtype=torch.float32)
+        check(lib.dfe_wino_conv3x3_dilated(ptr(x), ptr(w), ptr(y), y.stride(0), ptr(wbuf), B, Ci, Co, H, W, d, int(bool(transposed)),
+                                           stream_ptr()), "dfe_wino_conv3x3_dilated")
+        return y
+    y = torch.empty(B, Co, H + 2 * P - 2, W + 2 * P - 2, device=x.device, dtype=torch.float32)
     check(lib.dfe_wino_conv3x3(ptr(x), ptr(w), ptr(y), y.stride(0), ptr(wbuf), B, Ci, Co, H, W, P, int(bool(transposed)),
                                stream_ptr()), "dfe_wino_conv3x3")
     return y
