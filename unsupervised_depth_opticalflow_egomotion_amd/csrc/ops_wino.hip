@@ -240,8 +240,9 @@ __global__ void __launch_bounds__(256) k_wino_fwd(const float* __restrict__ x, c
 // Variant with HALF the accumulators per wave (16 tiles x 32 output channels: 128 registers) so that two blocks share a CU
 // and the hardware hides one wave's loads and LDS reads under the other's MFMAs: v_mfma_f32_16x16x4_f32, a lane owns
 // (tile = lane & 15, channel 4 g + (lane >> 4)) of step g; block = 4 waves = 64 tiles x 32 output channels.
-template <int PP>      // PP = 0 / 1 / 2: the padding, pair loads (W even); -1: any padding and width, 16 single loads per patch
-__global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__ x, const float* __restrict__ U, float* __restrict__ y,
+template <int PP, int NW>      // PP = 0 / 1 / 2: the padding, pair loads (W even); -1: any padding and width, 16 single loads per
+                               // patch.  NW = waves per block (4, or 1 where 64-tile blocks would not fill the chip)
+__global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restrict__ x, const float* __restrict__ U, float* __restrict__ y,
                                                        long ybs, int B, int C, int K, int H, int W, int P, int TH, int TW, int ntiles,
                                                        unsigned nkt, int dil) {
   extern __shared__ float lds[];      // [WN_CC][32][WN_XP]
@@ -251,7 +252,7 @@ __global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__
   const unsigned lid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int kt = static_cast<int>(lid % nkt), tb = static_cast<int>(lid / nkt);
   const int Ho = H + 2 * P - 2, Wo = W + 2 * P - 2, HW = H * W;
-  const int tile = min(tb * 64 + wv * 16 + n, ntiles - 1);
+  const int tile = min(tb * (16 * NW) + wv * 16 + n, ntiles - 1);
   // dil > 1 (PP = -1 only): the convolution acts on the dil x dil phase images (pixels y = py + dil qy, x = px + dil qx) with
   // padding 1 in phase coordinates; tiles are numbered (b, py, ty, tx, px) so that consecutive lanes read consecutive pixels
   int b, ty, tx, py = 0, px = 0;
@@ -373,30 +374,42 @@ __global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__
   // weight slabs of 8 input channels, double-buffered: slab i + 1 travels global -> registers under the two steps of slab i
   // and is written to the other LDS buffer before the chunk's single barrier
   constexpr int SC = 8, SLAB = SC * 32 * WN_XP;
-  f32x4 wreg[SC * 128 / 256];
+  constexpr int NTH = 64 * NW;
+  f32x4 wreg[NW == 1 ? 1 : SC * 128 / NTH];
   auto wfetch = [&](int c0) {
     const int nc = min(SC, C - c0);
 #pragma unroll
-    for (int i = 0; i < SC * 128 / 256; ++i) {
-      const int e = tid + i * 256;
+    for (int i = 0; i < (NW == 1 ? 1 : SC * 128 / NTH); ++i) {
+      const int e = tid + i * NTH;
       wreg[i] = *reinterpret_cast<const f32x4*>(Ut + static_cast<long>(c0) * 512 + (e < nc * 128 ? e : 0) * 4);
     }
   };
   auto wstore = [&](float* buf) {
 #pragma unroll
-    for (int i = 0; i < SC * 128 / 256; ++i) {
-      const int e = tid + i * 256;
+    for (int i = 0; i < (NW == 1 ? 1 : SC * 128 / NTH); ++i) {
+      const int e = tid + i * NTH;
       *reinterpret_cast<f32x4*>(buf + (e >> 2) * WN_XP + (e & 3) * 4) = wreg[i];
     }
   };
-  wfetch(0);
-  wstore(lds);
+  // a one-wave block stages each slab where it needs it (4 loads in flight): the CU's other blocks cover the wait, and the
+  // 16 prefetch registers per thread would not fit
+  auto wdirect = [&](int c0, float* buf) {
+    const int nc = min(SC, C - c0);
+#pragma unroll 4
+    for (int i = 0; i < SC * 128 / NTH; ++i) {
+      const int e = tid + i * NTH;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(Ut + static_cast<long>(c0) * 512 + (e < nc * 128 ? e : 0) * 4);
+      *reinterpret_cast<f32x4*>(buf + (e >> 2) * WN_XP + (e & 3) * 4) = v;
+    }
+  };
+  if (NW == 1) wdirect(0, lds);
+  else { wfetch(0); wstore(lds); }
   __syncthreads();
   int cur = 0;
   for (int c0 = 0; c0 < C; c0 += SC) {
     const int nc = min(SC, C - c0);
     const bool more = c0 + SC < C;
-    if (more) wfetch(c0 + SC);
+    if (more && NW != 1) wfetch(c0 + SC);
     const float* slab = lds + cur * SLAB;
     for (int cs = 0; cs < nc; cs += 4) {
       float d[16], t[16], v[16];
@@ -430,13 +443,14 @@ __global__ void __launch_bounds__(256, 2) k_wino_fwd16(const float* __restrict__
       }
     }
     if (more) {
-      wstore(lds + (cur ^ 1) * SLAB);               // nobody reads that buffer: its last readers passed the previous barrier
+      if (NW == 1) wdirect(c0 + SC, lds + (cur ^ 1) * SLAB);
+      else wstore(lds + (cur ^ 1) * SLAB);          // nobody reads that buffer: its last readers passed the previous barrier
       __syncthreads();
       cur ^= 1;
     }
   }
   // D[i][j]: lane holds tile j = n and the output channels i = 4 kq + r of each 16-channel half
-  if (tb * 64 + wv * 16 + n >= ntiles) return;
+  if (tb * (16 * NW) + wv * 16 + n >= ntiles) return;
   const int Hoq = (PP >= 0 || dil == 1) ? Ho : H / dil, Woq = (PP >= 0 || dil == 1) ? Wo : W / dil;   // outputs per phase image
   const int oy = 2 * ty, ox = 2 * tx;
   const int sy = dil * Wo, sx = dil;                // strides of the 2x2 outputs in y
@@ -506,16 +520,23 @@ static int wino_run(const float* x, const float* weight, float* y, long y_batch_
   static const int variant = [] { const char* e = getenv("DFE_WINO_VARIANT"); return e ? atoi(e) : 16; }();
   if (variant == 16 || dil > 1) {
     const unsigned nkt = Kpad / 32;
-    const long nblk = (ntiles + 63) / 64 * nkt;
+    // one-wave blocks (16 tiles) where 64-tile blocks would leave the chip's 512 block slots half empty
+    const bool small = (ntiles + 63) / 64 * nkt < 512;
+    const int tpb = small ? 16 : 64;
+    const long nblk = (ntiles + tpb - 1) / tpb * nkt;
     if (nblk >= (1L << 31)) return DFE_ERR_DIMS;
     static const bool pair_ok = [] { const char* e = getenv("DFE_WINO_PAIR"); return !e || atoi(e) != 0; }();
     const bool pair = pair_ok && dil == 1 && W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0;
     const unsigned g = static_cast<unsigned>(nblk);
     const int nt = static_cast<int>(ntiles);
-    if (pair && P == 1) k_wino_fwd16<1><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt, dil);
-    else if (pair && P == 0) k_wino_fwd16<0><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt, dil);
-    else if (pair && P == 2) k_wino_fwd16<2><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt, dil);
-    else k_wino_fwd16<-1><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt, dil);
+    const int pp = pair ? P : -1;
+#define WN_LAUNCH(PPV, NWV) k_wino_fwd16<PPV, NWV><<<g, 64 * NWV, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt, dil)
+    if (small) {
+      if (pp == 1) WN_LAUNCH(1, 1); else if (pp == 0) WN_LAUNCH(0, 1); else if (pp == 2) WN_LAUNCH(2, 1); else WN_LAUNCH(-1, 1);
+    } else {
+      if (pp == 1) WN_LAUNCH(1, 4); else if (pp == 0) WN_LAUNCH(0, 4); else if (pp == 2) WN_LAUNCH(2, 4); else WN_LAUNCH(-1, 4);
+    }
+#undef WN_LAUNCH
   } else {
     const dim3 grid(static_cast<unsigned>((ntiles + 127) / 128), Kpad / 32);
     if (variant == 2 && P == 1 && W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0)
