@@ -520,9 +520,9 @@ static int wino_run(const float* x, const float* weight, float* y, long y_batch_
   static const int variant = [] { const char* e = getenv("DFE_WINO_VARIANT"); return e ? atoi(e) : 16; }();
   if (variant == 16 || dil > 1) {
     const unsigned nkt = Kpad / 32;
-    // one-wave blocks (16 tiles) where 64-tile blocks would leave the chip's 512 block slots half empty
-    const bool small = (ntiles + 63) / 64 * nkt < 512;
-    const int tpb = small ? 16 : 64;
+    // (one-wave blocks of 16 tiles for the planes that cannot fill the chip with 64-tile blocks were measured and lose: every
+    // wave then stages the weight slabs for itself -- 12 x 256 -> 256 @ 16x52: 222 us against 112)
+    const int tpb = 64;
     const long nblk = (ntiles + tpb - 1) / tpb * nkt;
     if (nblk >= (1L << 31)) return DFE_ERR_DIMS;
     static const bool pair_ok = [] { const char* e = getenv("DFE_WINO_PAIR"); return !e || atoi(e) != 0; }();
@@ -531,11 +531,7 @@ static int wino_run(const float* x, const float* weight, float* y, long y_batch_
     const int nt = static_cast<int>(ntiles);
     const int pp = pair ? P : -1;
 #define WN_LAUNCH(PPV, NWV) k_wino_fwd16<PPV, NWV><<<g, 64 * NWV, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt, dil)
-    if (small) {
-      if (pp == 1) WN_LAUNCH(1, 1); else if (pp == 0) WN_LAUNCH(0, 1); else if (pp == 2) WN_LAUNCH(2, 1); else WN_LAUNCH(-1, 1);
-    } else {
-      if (pp == 1) WN_LAUNCH(1, 4); else if (pp == 0) WN_LAUNCH(0, 4); else if (pp == 2) WN_LAUNCH(2, 4); else WN_LAUNCH(-1, 4);
-    }
+    if (pp == 1) WN_LAUNCH(1, 4); else if (pp == 0) WN_LAUNCH(0, 4); else if (pp == 2) WN_LAUNCH(2, 4); else WN_LAUNCH(-1, 4);
 #undef WN_LAUNCH
   } else {
     const dim3 grid(static_cast<unsigned>((ntiles + 127) / 128), Kpad / 32);
