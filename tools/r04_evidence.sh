@@ -21,6 +21,8 @@ python tools/stream_kernels.py $t 4 45 15 > $out/r04_stream_kernels.txt; python 
 # PWC-side kernels: algorithmic-byte table + PMC traffic
 python tools/corr_bench.py --check > $out/r04_pwc_roofline_table.md 2>&1
 bash tools/pmc_corr.sh r04
+# fused Winograd-on-MFMA convolution against MIOpen on the nets' large layers
+python tools/wino_bench.py > $out/r04_wino_bench.md 2>&1
 # small-plane convolutions: HIP-event time per call against MIOpen + kernel durations by grid
 python tools/planeconv_bench.py --levels 6,5 > $out/r04_planeconv_bench.md 2>&1
 rm -rf /tmp/pcv; rocprofv3 --kernel-trace --output-format csv -d /tmp/pcv -o t -- python3 tools/planeconv_bench.py --levels 6,5 --iters 10 --reps 1 > /dev/null 2>&1
