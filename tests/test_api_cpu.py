@@ -69,6 +69,18 @@ def test_error_strings_and_argument_checks_without_gpu():
     assert lib.dfe_planeconv_fwd(P, P, None, 0.1, P, 10, None, 0, P, 1, 4, 4, 4, 4, None) == -2      # batch stride < Co*H*W
     assert lib.dfe_planeconv_dgrad(P, P, P, P, 8, 64, 64, 64, 208, None) == -4                        # unsupported: larger plane
     assert lib.dfe_planeconv_wgrad(P, P, None, P, 1, 4, 4, 4, 4, None) == -1
+    # fused Winograd convolution (ops_wino.hip) and the tiny 1x1 convolutions: argument checks and scratch sizes
+    assert lib.dfe_wino_weight_floats(64, 64) == 64 * 64 * 16 and lib.dfe_wino_weight_floats(5, 33) == 64 * 5 * 16
+    assert lib.dfe_wino_weight_floats(0, 4) == 0
+    assert lib.dfe_wino_conv3x3(None, P, P, 0, P, 1, 4, 4, 8, 8, 1, 0, None) == -1
+    assert lib.dfe_wino_conv3x3(P, P, P, 4 * 8 * 8, P, 1, 4, 4, 8, 8, 3, 0, None) == -4          # padding 0, 1 or 2
+    assert lib.dfe_wino_conv3x3(P, P, P, 10, P, 1, 4, 4, 8, 8, 1, 0, None) == -2                 # batch stride < Co*Ho*Wo
+    assert lib.dfe_wino_conv3x3(P, P, P, 4 * 8 * 8, ctypes.c_void_p(20), 1, 4, 4, 8, 8, 1, 0, None) == -4   # scratch not 16-byte aligned
+    assert lib.dfe_wino_conv3x3_dilated(P, P, P, 4 * 8 * 9, P, 1, 4, 4, 8, 9, 2, 0, None) == -4  # W not a multiple of the dilation
+    assert lib.dfe_wino_conv3x3(P, P, P, 1 << 40, P, 64, 256, 4, 512, 512, 1, 0, None) == -2     # 32-bit offsets: B*Ci*H*W < 2^30
+    assert lib.dfe_conv1x1_small_supported(4, 256, 12, 2, 7) == 1 and lib.dfe_conv1x1_small_supported(4, 16, 16, 64, 208) == 0
+    assert lib.dfe_conv1x1_small_fwd(P, None, None, 1.0, P, 4, 12, 12, 2, 7, None) == -1
+    assert lib.dfe_cast_f32_nchw_to_bf16_nhwc(None, P, 1, 4, 16, None) == -1 and lib.dfe_cast_bf16_nhwc_to_f32_nchw(P, P, 0, 4, 16, None) == -2
 
 
 def test_no_cpu_fallback():
