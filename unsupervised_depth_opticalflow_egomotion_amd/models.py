@@ -101,14 +101,15 @@ _DEFAULT_NET_STREAMS = int(__import__("os").environ.get("DFE_NET_STREAMS", "3"))
 
 def _side_streams(dev):
     """(flow stream, pose stream) of a device, with their HIP priorities (DFE_STREAM_PRIORITIES = "flow,pose"; the depth net
-    stays on the caller's stream at priority 0).  Round 3, when the flow branch was the step's long pole: flow and pose both
-    high (-1,-1) 25.73 ms against 26.09 for 0,0.  Round 4, after this build's Winograd kernel took 2.5 ms out of both long
-    branches and left the DEPTH branch the longer one (14.4 against 12.7 ms of kernels): 0,-1 21.71-21.87 and 0,0 21.65-21.83
-    against 21.92-21.99 for -1,-1 (three alternating runs each) -- the flow branch no longer goes first; the short pose
-    chain still does."""
+    stays on the caller's stream at priority 0).  Both HIGH (-1,-1).  Round 3, when the flow branch was the step's long pole:
+    25.73 ms against 26.09 for 0,0.  Round 4, after this build's Winograd kernel left the DEPTH branch the longer one (14.4
+    against 12.7 ms of kernels), 0,-1 / 0,0 measure 0.18 ms better in a plain process (21.77 against 21.95) -- but a
+    normal-priority side stream is only concurrent while it gets a hardware queue of its own: with a process group alive
+    (RCCL's or gloo's streams present) the flow branch at priority 0 ran SERIALISED behind the depth branch, 27.0 ms =
+    the one-stream time, against 22.2 with both side streams high.  High-priority streams have their own queues: kept."""
     key = (dev.type, dev.index)
     if key not in _SIDE_STREAMS:
-        pf, pp = (int(v) for v in __import__("os").environ.get("DFE_STREAM_PRIORITIES", "0,-1").split(","))
+        pf, pp = (int(v) for v in __import__("os").environ.get("DFE_STREAM_PRIORITIES", "-1,-1").split(","))
         _SIDE_STREAMS[key] = (torch.cuda.Stream(dev, priority=pf), torch.cuda.Stream(dev, priority=pp))
     return _SIDE_STREAMS[key]
 
