@@ -637,3 +637,39 @@ def test_miopen_db_status_reports_tuned_only_for_a_matching_key(monkeypatch, tmp
     assert m.status() == "tuned-unverified"
     monkeypatch.setitem(m._state, "path", str(tmp_path / "mine"))
     assert m.status() == "env"
+
+
+def test_winograd_dispatch_rule_is_shape_logic_only(monkeypatch):
+    """convs._wino_eligible (which 3x3 layers take dfe_wino_conv3x3) is pure shape logic: CPU tensors never qualify, and on a
+    fake device tensor the thresholds, the paddings and the dilation rule decide."""
+    from unsupervised_depth_opticalflow_egomotion_amd import convs
+
+    class FakeCuda:
+        is_cuda, dtype = True, torch.float32
+
+        def __init__(self, *shape):
+            self.shape = shape
+
+        def dim(self):
+            return len(self.shape)
+
+        def numel(self):
+            n = 1
+            for s in self.shape:
+                n *= s
+            return n
+    el = convs._wino_eligible
+    assert not el(torch.zeros(8, 64, 64, 208), (64, 64, 3, 3), 64, (1, 1), (1, 1), (1, 1))          # CPU tensor
+    x = FakeCuda(8, 128, 64, 208)
+    assert el(x, (128, 128, 3, 3), 128, (1, 1), (1, 1), (1, 1)) and el(x, (96, 128, 3, 3), 128, (1, 1), (0, 0), (1, 1))
+    assert not el(x, (128, 128, 3, 3), 128, (2, 2), (1, 1), (1, 1))                                   # stride 2
+    assert not el(x, (128, 128, 5, 5), 128, (1, 1), (2, 2), (1, 1))                                   # 5x5
+    assert not el(x, (128, 128, 3, 3), 128, (1, 1), (2, 2), (1, 1))                                   # padding 2 without dilation
+    assert el(x, (128, 128, 3, 3), 128, (1, 1), (4, 4), (4, 4)) and el(x, (128, 128, 3, 3), 128, (1, 1), (16, 16), (16, 16))
+    assert not el(x, (128, 128, 3, 3), 128, (1, 1), (3, 3), (3, 3))                                   # 64 is no multiple of 3
+    assert not el(x, (128, 128, 3, 3), 128, (1, 1), (1, 1), (1, 1), groups=2)
+    assert not el(FakeCuda(8, 16, 64, 208), (16, 16, 3, 3), 16, (1, 1), (1, 1), (1, 1))               # too few reduction channels
+    assert not el(FakeCuda(8, 128, 4, 13), (128, 128, 3, 3), 128, (1, 1), (1, 1), (1, 1))             # 8 * 2 * 7 tiles: the small-plane kernels' job
+    assert not el(FakeCuda(64, 512, 128, 416), (64, 512, 3, 3), 512, (1, 1), (1, 1), (1, 1))          # > 2^30 elements: 32-bit offsets
+    monkeypatch.setattr(convs, "WINO_MIN_TILES", 0)
+    assert not el(x, (128, 128, 3, 3), 128, (1, 1), (1, 1), (1, 1))                                   # switched off
