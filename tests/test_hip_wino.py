@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 # (B, Ci, Co, H, W, P)
 SHAPES = [(2, 64, 64, 64, 208, 1), (2, 128, 128, 32, 104, 1), (1, 115, 128, 64, 208, 1), (2, 96, 32, 34, 50, 0),
           (1, 256, 96, 16, 52, 1), (3, 17, 33, 7, 9, 1), (1, 1, 1, 3, 3, 1), (2, 5, 70, 11, 6, 0), (1, 18, 40, 2, 2, 1),
-          (1, 34, 32, 5, 64, 1), (2, 40, 48, 18, 54, 0), (1, 33, 20, 6, 10, 2), (2, 32, 32, 7, 9, 2), (1, 8, 8, 4, 34, 0)]
+          (1, 34, 32, 5, 64, 1), (2, 40, 48, 18, 54, 0), (1, 33, 20, 6, 10, 2), (2, 32, 32, 7, 9, 2), (1, 8, 8, 4, 34, 0),
+          (2, 24, 16, 12, 20, 1), (1, 16, 8, 6, 10, 0), (1, 33, 16, 8, 8, 2), (1, 20, 3, 9, 11, 1)]      # Co <= 16: the half-tile kernel
 
 
 def dev():

@@ -114,7 +114,7 @@ _cb = torch.ops.aten.convolution_backward
 # 1.2-1.7x slower where there are enough 2x2 output tiles to fill the chip (tools/wino_bench.py); the weight gradient stays
 # MIOpen's.  DFE_WINO_MIN_TILES: smallest B * ceil(Ho/2) * ceil(Wo/2) that takes the kernel (0 = never).
 WINO_MIN_TILES = int(os.environ.get("DFE_WINO_MIN_TILES", "500"))
-WINO_MIN_CHANNELS = int(os.environ.get("DFE_WINO_MIN_CHANNELS", "32"))
+WINO_MIN_CHANNELS = int(os.environ.get("DFE_WINO_MIN_CHANNELS", "16"))
 WINO_DILATED = os.environ.get("DFE_WINO_DILATED", "1") == "1"     # dilated layers too (instead of MIOpen / the phase-image path)
 
 

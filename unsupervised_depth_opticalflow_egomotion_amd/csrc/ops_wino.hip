@@ -240,8 +240,9 @@ __global__ void __launch_bounds__(256) k_wino_fwd(const float* __restrict__ x, c
 // Variant with HALF the accumulators per wave (16 tiles x 32 output channels: 128 registers) so that two blocks share a CU
 // and the hardware hides one wave's loads and LDS reads under the other's MFMAs: v_mfma_f32_16x16x4_f32, a lane owns
 // (tile = lane & 15, channel 4 g + (lane >> 4)) of step g; block = 4 waves = 64 tiles x 32 output channels.
-template <int PP, int NW>      // PP = 0 / 1 / 2: the padding, pair loads (W even); -1: any padding and width, 16 single loads per
-                               // patch.  NW = waves per block (4, or 1 where 64-tile blocks would not fill the chip)
+template <int PP, int NW, int NH>   // PP = 0 / 1 / 2: the padding, pair loads (W even); -1: any padding and width, 16 single loads
+                                    // per patch.  NW = waves per block.  NH = 16-channel halves of the 32-channel output tile that
+                                    // exist (1 when Co <= 16: half the MFMAs, half the accumulators)
 __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restrict__ x, const float* __restrict__ U, float* __restrict__ y,
                                                        long ybs, int B, int C, int K, int H, int W, int P, int TH, int TW, int ntiles,
                                                        unsigned nkt, int dil) {
@@ -307,9 +308,9 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
         inb |= ok ? (1u << (i * 4 + j)) : 0u;
       }
   }
-  f32x4 acc[2][16];
+  f32x4 acc[NH][16];
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < NH; ++h)
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc[h][s] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   const float* Ut = U + static_cast<long>(kt) * C * 512;
@@ -431,7 +432,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
       }
       const float* up = slab + (min(cs + kq, nc - 1) * 32 + n) * WN_XP;    // a lane past the last channel holds a zero patch
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < NH; ++h) {
         float u[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -456,7 +457,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
   const int sy = dil * Wo, sx = dil;                // strides of the 2x2 outputs in y
   float* yb = y + b * ybs + static_cast<long>(py + dil * oy) * Wo + px + dil * ox;
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < NH; ++h)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int k = kt * 32 + 16 * h + 4 * kq + r;
@@ -530,8 +531,12 @@ static int wino_run(const float* x, const float* weight, float* y, long y_batch_
     const unsigned g = static_cast<unsigned>(nblk);
     const int nt = static_cast<int>(ntiles);
     const int pp = pair ? P : -1;
-#define WN_LAUNCH(PPV, NWV) k_wino_fwd16<PPV, NWV><<<g, 64 * NWV, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt, dil)
-    if (pp == 1) WN_LAUNCH(1, 4); else if (pp == 0) WN_LAUNCH(0, 4); else if (pp == 2) WN_LAUNCH(2, 4); else WN_LAUNCH(-1, 4);
+#define WN_LAUNCH(PPV, NHV) k_wino_fwd16<PPV, 4, NHV><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt, dil)
+    if (Co <= 16) {
+      if (pp == 1) WN_LAUNCH(1, 1); else if (pp == 0) WN_LAUNCH(0, 1); else if (pp == 2) WN_LAUNCH(2, 1); else WN_LAUNCH(-1, 1);
+    } else {
+      if (pp == 1) WN_LAUNCH(1, 2); else if (pp == 0) WN_LAUNCH(0, 2); else if (pp == 2) WN_LAUNCH(2, 2); else WN_LAUNCH(-1, 2);
+    }
 #undef WN_LAUNCH
   } else {
     const dim3 grid(static_cast<unsigned>((ntiles + 127) / 128), Kpad / 32);

@@ -1040,7 +1040,10 @@ class ThinConv3x3Fn(torch.autograd.Function):
 
     @staticmethod
     def _mfma_passes(p, weight):
-        return weight.shape[0] == 16 and weight.shape[1] == 16
+        """16 -> 16 on dfe_thin_conv3x3 -- unless the fused Winograd kernel takes the layer (round 4: 154 / 157 us against
+        165 / 186 for the forward pass / data gradient at 258x834 x 12): then raw_forward / raw_backward route it there."""
+        return (weight.shape[0] == 16 and weight.shape[1] == 16 and
+                not convs._wino_eligible(p, weight.shape, weight.shape[1], (1, 1), (0, 0), (1, 1)))
 
     @staticmethod
     def forward(ctx, p, weight):
@@ -1115,6 +1118,8 @@ def thin_conv_same_eligible(x, conv):
     from . import convs
     if os.environ.get("DFE_THIN_SAME", "1") == "0" or convs.get_compute_dtype() is not None:
         return False
+    if convs._wino_eligible(x, conv.weight.shape, conv.in_channels, conv.stride, conv.padding, conv.dilation, conv.groups):
+        return False        # the fused Winograd kernel takes the layer (37 against ~57 us at 128x416 x 12)
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.in_channels == 16 and conv.out_channels == 16
             and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
             and conv.groups == 1 and x.shape[3] % 16 == 0 and x.shape[2] * x.shape[3] >= 128 * 416)
