@@ -270,6 +270,13 @@ int dfe_planeconv_wgrad(const float* gy, const float* x, float* gweight, float* 
  * wbuf: dfe_wino_weight_floats(Ci, Co) floats of scratch for the transformed filters (16-byte aligned).
  * DFE_ERR_DIMS when B*Ci*H*W >= 2^30 (32-bit offsets). */
 long dfe_wino_weight_floats(int Ci, int Co);
+/* weight gradient of the same convolutions in the Winograd domain: gweight [Co,Ci,3,3] = d/dw of conv(x [B,Ci,H,W], w, padding P
+ * in {0, 1}) for the output gradient gy (element (b,co,i) at gy + b * gy_batch_stride + co * Ho*Wo + i).  Straight from NCHW:
+ * no layout transposes, no zero fill, no atomics (fixed-order partial sums in ws: dfe_wino_wgrad_floats floats, 16-byte
+ * aligned).  W and Wo must be even, x / gy 8-byte aligned, gy_batch_stride even (DFE_ERR_UNSUPPORTED otherwise). */
+long dfe_wino_wgrad_floats(int B, int Ci, int Co, int H, int W, int P);
+int dfe_wino_wgrad3x3(const float* x, const float* gy, long gy_batch_stride, float* gweight, float* ws, int B, int Ci, int Co, int H,
+                      int W, int P, void* stream);
 /* the same for a DILATED 3x3 convolution with padding = dilation (pwc_tf.py:31-36 context network: dilation 2, 4, 8, 16): the
  * Winograd tiles live on the dilation x dilation phase images; H and W must be multiples of the dilation.  y has x's size. */
 int dfe_wino_conv3x3_dilated(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, int B, int Ci, int Co,

@@ -70,3 +70,20 @@ def test_wino_dilated_conv_matches_float64(shape):
     rgx = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), None, [1, 1], [d, d], [d, d], False, [0, 0], 1,
                                               [True, False, False])[0]
     assert float((gx.double() - rgx).abs().max()) <= 2e-5 * float(rgx.abs().max())
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 16, 24, 1), (3, 40, 70, 10, 12, 1), (2, 33, 17, 8, 6, 0), (1, 3, 5, 4, 4, 1), (2, 96, 32, 34, 50, 0),
+                                   (4, 128, 128, 32, 104, 1), (1, 16, 16, 64, 208, 1)])
+def test_wino_wgrad_matches_float64(shape):
+    """the Winograd-domain weight gradient against float64 aten (padding 1 and valid; channel counts off the 64 / 32 tiles)."""
+    B, Ci, Co, H, W, P = shape
+    torch.manual_seed(sum(shape))
+    x = torch.randn(B, Ci, H, W, device=dev())
+    w = torch.randn(Co, Ci, 3, 3, device=dev())
+    gy = torch.randn(B, Co, H + 2 * P - 2, W + 2 * P - 2, device=dev())
+    gw = ops.wino_wgrad3x3(x, gy, P)
+    ref = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), None, [1, 1], [P, P], [1, 1], False, [0, 0], 1,
+                                              [False, True, False])[1]
+    err, scale = float((gw.double() - ref).abs().max()), float(ref.abs().max())
+    assert err <= 3e-5 * scale, (err, scale)
+    assert torch.equal(gw, ops.wino_wgrad3x3(x, gy, P))

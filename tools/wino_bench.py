@@ -62,6 +62,23 @@ def valid():
         print("| %d x %d -> %d @ %dx%d | %.1f | %.1f | %.1f | %.1f |" % (B, ci, co, H, W, t_m, t_w, t_md, t_wd))
 
 
+def wgrad():
+    dev = torch.device("cuda:0")
+    print()
+    print("| weight gradient B x Ci -> Co @ H x W (P) | MIOpen us (incl. its transposes / fill) | wino wgrad us | max rel err |")
+    print("|---|---|---|---|")
+    for (B, ci, co, H, W, P) in [(12, 64, 64, 64, 208, 1), (12, 128, 128, 32, 104, 1), (12, 256, 256, 16, 52, 1), (8, 128, 128, 64, 208, 1), (8, 115, 128, 64, 208, 1),
+                                 (8, 256, 96, 64, 208, 1), (8, 224, 64, 64, 208, 1), (8, 160, 32, 64, 208, 1), (12, 96, 32, 130, 418, 0), (12, 128, 64, 66, 210, 0),
+                                 (12, 256, 128, 34, 106, 0), (12, 32, 32, 64, 208, 1)]:
+        x = torch.randn(B, ci, H, W, device=dev); w = torch.randn(co, ci, 3, 3, device=dev); gy = torch.randn(B, co, H + 2 * P - 2, W + 2 * P - 2, device=dev)
+        t_m = ev(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [P, P], [1, 1], False, [0, 0], 1, [False, True, False]), 20)
+        t_w = ev(lambda: ops.wino_wgrad3x3(x, gy, P), 20)
+        ref = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [P, P], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        err = float((ops.wino_wgrad3x3(x, gy, P) - ref).abs().max() / ref.abs().max())
+        print("| %d x %d -> %d @ %dx%d (%d) | %.1f | %.1f | %.1e |" % (B, ci, co, H, W, P, t_m, t_w, err))
+
+
 if __name__ == "__main__":
     main()
     valid()
+    wgrad()

@@ -141,6 +141,19 @@ def _wino_eligible(x, w_shape, cin, stride, padding, dilation, groups=1):
     return (B * ((Ho + 1) // 2) * ((Wo + 1) // 2) >= WINO_MIN_TILES and C >= WINO_MIN_CHANNELS and x.numel() < (1 << 30))
 
 
+# Weight gradient in the Winograd domain (dfe_wino_wgrad3x3), OPT-IN (DFE_WINO_WGRAD_MIN_CHANNELS=96 routes the layers with at
+# least that many input and output channels there; 0 = never, the default): correct and reproducible, 1.05-1.2x MIOpen's
+# implicit GEMM + transposes on the wide layers in isolation (tools/wino_bench.py) but 0.15 ms SLOWER per step when it runs
+# beside the other stream's kernels (21.69 against 21.54 ms): its LDS-staged transposes and MIOpen's are both hidden, its
+# MFMA time is not shorter yet.
+WINO_WGRAD_MIN_CHANNELS = int(os.environ.get("DFE_WINO_WGRAD_MIN_CHANNELS", "0"))
+
+
+def _wino_wgrad_eligible(x, gy, w_shape, padding, d):
+    return (WINO_WGRAD_MIN_CHANNELS > 0 and d == 1 and padding in ((0, 0), (1, 1)) and w_shape[0] >= WINO_WGRAD_MIN_CHANNELS
+            and w_shape[1] >= WINO_WGRAD_MIN_CHANNELS and x.shape[3] % 2 == 0 and gy.shape[3] % 2 == 0 and gy.is_contiguous())
+
+
 def raw_forward(x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1)):
     """y = conv(x, w) without bias, fp32 in / fp32 out, no autograd of its own."""
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
@@ -170,6 +183,8 @@ def raw_backward(gy, x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1), want_
         gx = ops.wino_conv3x3(gy, w, 1 if padding != (0, 0) else 2, transposed=True, dilation=d)
         if not (want_w or want_b):
             return gx, None, None
+        if want_w and not want_b and _wino_wgrad_eligible(x, gy, w.shape, padding, d):
+            return gx, ops.wino_wgrad3x3(x, gy, padding[0]), None
         _, gw, gb = _cb(gy, x, w, bias_sizes, list(stride), list(padding), list(dilation), False, [0, 0], 1, [False, want_w, want_b])
         return gx, gw, gb
     return _cb(gy, x, w, bias_sizes, list(stride), list(padding), list(dilation), False, [0, 0], 1, [want_x, want_w, want_b])

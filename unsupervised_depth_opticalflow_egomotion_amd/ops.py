@@ -664,6 +664,19 @@ def wino_conv3x3(x, w, padding=1, transposed=False, dilation=1):
     return y
 
 
+def wino_wgrad3x3(x, gy, padding=1):
+    """Weight gradient [Co,Ci,3,3] of a 3x3 stride-1 convolution of x [B,Ci,H,W] with ``padding`` in {0, 1} for the output
+    gradient gy [B,Co,Ho,Wo], on dfe_wino_wgrad3x3 (Winograd domain, fp32 MFMA)."""
+    x, gy = f32c(x), f32c(gy)
+    B, Ci, H, W = x.shape
+    Co, P = int(gy.shape[1]), int(padding)
+    lib = get_lib()
+    gw = torch.empty(Co, Ci, 3, 3, device=x.device, dtype=torch.float32)
+    ws = torch.empty(lib.dfe_wino_wgrad_floats(B, Ci, Co, H, W, P), device=x.device, dtype=torch.float32)
+    check(lib.dfe_wino_wgrad3x3(ptr(x), ptr(gy), gy.stride(0), ptr(gw), ptr(ws), B, Ci, Co, H, W, P, stream_ptr()), "dfe_wino_wgrad3x3")
+    return gw
+
+
 class PlaneConvActFn(torch.autograd.Function):
     """act(conv3x3(x, w, pad 1) + bias) on a small plane as one operator (PoseCNN's refinement convolutions,
     pose_cnn.py:43-46, 66-69: Conv2d(12, 12, 3, 1, 1) + ReLU on 2x7 planes): dfe_planeconv_fwd with the epilogue inside;
