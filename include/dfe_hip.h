@@ -267,9 +267,14 @@ int dfe_planeconv_wgrad(const float* gy, const float* x, float* gweight, float* 
  * transposed_weight = 1: weight [Ci,Co,3,3] is the FORWARD filter of a convolution whose output gradient is x: y is its data
  *                        gradient, i.e. conv(x, w') with w'[co][ci][ky][kx] = weight[ci][co][2-ky][2-kx] (P = 1 for a forward
  *                        P = 1, P = 2 for a forward P = 0).
- * wbuf: dfe_wino_weight_floats(Ci, Co) floats of scratch for the transformed filters (16-byte aligned).
+ * wbuf: scratch, 16-byte aligned, wbuf_floats floats: at least dfe_wino_weight_floats(Ci, Co) (the transformed filters);
+ * with dfe_wino_scratch_floats(B, Ci, Co, H, W, P) the planes that cannot fill the chip (few tiles, many channels) split their
+ * input channels over several blocks whose partial outputs are added in a fixed order.
  * DFE_ERR_DIMS when B*Ci*H*W >= 2^30 (32-bit offsets). */
 long dfe_wino_weight_floats(int Ci, int Co);
+long dfe_wino_scratch_floats(int B, int Ci, int Co, int H, int W, int P);
+int dfe_wino_conv3x3(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, long wbuf_floats, int B, int Ci,
+                     int Co, int H, int W, int P, int transposed_weight, void* stream);
 /* weight gradient of the same convolutions in the Winograd domain: gweight [Co,Ci,3,3] = d/dw of conv(x [B,Ci,H,W], w, padding P
  * in {0, 1}) for the output gradient gy (element (b,co,i) at gy + b * gy_batch_stride + co * Ho*Wo + i).  Straight from NCHW:
  * no layout transposes, no zero fill, no atomics (fixed-order partial sums in ws: dfe_wino_wgrad_floats floats, 16-byte
@@ -281,8 +286,6 @@ int dfe_wino_wgrad3x3(const float* x, const float* gy, long gy_batch_stride, flo
  * Winograd tiles live on the dilation x dilation phase images; H and W must be multiples of the dilation.  y has x's size. */
 int dfe_wino_conv3x3_dilated(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, int B, int Ci, int Co,
                              int H, int W, int dilation, int transposed_weight, void* stream);
-int dfe_wino_conv3x3(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, int B, int Ci, int Co, int H,
-                     int W, int P, int transposed_weight, void* stream);
 
 /* ---- 1x1 convolutions on tiny planes (H*W <= 256, B*H*W <= 4096): PoseCNN's pose_conv and refinement head
  * (pose_cnn.py:32,43,48: Conv2d(256 | 24 | 12, 12, 1) on 2x7 planes).  x [B,Ci,H,W], weight [Co,Ci] (= [Co,Ci,1,1]).

@@ -72,12 +72,15 @@ def test_error_strings_and_argument_checks_without_gpu():
     # fused Winograd convolution (ops_wino.hip) and the tiny 1x1 convolutions: argument checks and scratch sizes
     assert lib.dfe_wino_weight_floats(64, 64) == 64 * 64 * 16 and lib.dfe_wino_weight_floats(5, 33) == 64 * 5 * 16
     assert lib.dfe_wino_weight_floats(0, 4) == 0
-    assert lib.dfe_wino_conv3x3(None, P, P, 0, P, 1, 4, 4, 8, 8, 1, 0, None) == -1
-    assert lib.dfe_wino_conv3x3(P, P, P, 4 * 8 * 8, P, 1, 4, 4, 8, 8, 3, 0, None) == -4          # padding 0, 1 or 2
-    assert lib.dfe_wino_conv3x3(P, P, P, 10, P, 1, 4, 4, 8, 8, 1, 0, None) == -2                 # batch stride < Co*Ho*Wo
-    assert lib.dfe_wino_conv3x3(P, P, P, 4 * 8 * 8, ctypes.c_void_p(20), 1, 4, 4, 8, 8, 1, 0, None) == -4   # scratch not 16-byte aligned
+    assert lib.dfe_wino_conv3x3(None, P, P, 0, P, 1 << 20, 1, 4, 4, 8, 8, 1, 0, None) == -1
+    assert lib.dfe_wino_conv3x3(P, P, P, 4 * 8 * 8, P, 1 << 20, 1, 4, 4, 8, 8, 3, 0, None) == -4  # padding 0, 1 or 2
+    assert lib.dfe_wino_conv3x3(P, P, P, 10, P, 1 << 20, 1, 4, 4, 8, 8, 1, 0, None) == -2        # batch stride < Co*Ho*Wo
+    assert lib.dfe_wino_conv3x3(P, P, P, 4 * 8 * 8, ctypes.c_void_p(20), 1 << 20, 1, 4, 4, 8, 8, 1, 0, None) == -4   # scratch not 16-byte aligned
+    assert lib.dfe_wino_conv3x3(P, P, P, 4 * 8 * 8, P, 10, 1, 4, 4, 8, 8, 1, 0, None) == -5     # scratch smaller than the transformed filters
+    assert lib.dfe_wino_scratch_floats(12, 512, 512, 8, 26, 1) > lib.dfe_wino_weight_floats(512, 512)      # small plane: channel splits
+    assert lib.dfe_wino_scratch_floats(8, 128, 128, 64, 208, 1) == lib.dfe_wino_weight_floats(128, 128)   # large plane: none
     assert lib.dfe_wino_conv3x3_dilated(P, P, P, 4 * 8 * 9, P, 1, 4, 4, 8, 9, 2, 0, None) == -4  # W not a multiple of the dilation
-    assert lib.dfe_wino_conv3x3(P, P, P, 1 << 40, P, 64, 256, 4, 512, 512, 1, 0, None) == -2     # 32-bit offsets: B*Ci*H*W < 2^30
+    assert lib.dfe_wino_conv3x3(P, P, P, 1 << 40, P, 1 << 30, 64, 256, 4, 512, 512, 1, 0, None) == -2   # 32-bit offsets: B*Ci*H*W < 2^30
     assert lib.dfe_wino_wgrad_floats(8, 128, 128, 64, 208, 1) > 0 and lib.dfe_wino_wgrad_floats(8, 128, 128, 64, 208, 2) == 0
     assert lib.dfe_wino_wgrad3x3(P, P, 128 * 64 * 208, P, P, 8, 128, 128, 64, 207, 1, None) == -4      # odd width: pair loads
     assert lib.dfe_wino_wgrad3x3(P, None, 0, P, P, 1, 4, 4, 8, 8, 1, None) == -1

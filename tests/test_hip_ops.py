@@ -981,8 +981,17 @@ def test_thin_conv_same_16_16_matches_miopen():
         g1 = torch.autograd.grad((y1 * r).sum(), (x, w))
         for a, c in zip((y1,) + g1, (y0,) + g0):
             assert float((a - c).abs().max()) <= 2e-5 * max(float(c.abs().max()), 1.0)
+    # since round 4 the fused Winograd kernel takes the layer wherever it is eligible; the thin kernels keep it only when that
+    # kernel is switched off
+    from unsupervised_depth_opticalflow_egomotion_amd import convs
     conv = torch.nn.Conv2d(16, 16, 3, 1, 1)
-    assert ops.thin_conv_same_eligible(x, conv) and not ops.thin_conv_same_eligible(x[:, :, :64, :208], conv)
+    assert not ops.thin_conv_same_eligible(x, conv) and convs._wino_eligible(x, conv.weight.shape, 16, (1, 1), (1, 1), (1, 1))
+    old = convs.WINO_MIN_TILES
+    convs.WINO_MIN_TILES = 0
+    try:
+        assert ops.thin_conv_same_eligible(x, conv) and not ops.thin_conv_same_eligible(x[:, :, :64, :208], conv)
+    finally:
+        convs.WINO_MIN_TILES = old
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 8, 26), (3, 81, 4, 13), (1, 3, 7, 5), (2, 128, 64, 208), (128, 115, 3, 3), (1, 1, 1, 1)])

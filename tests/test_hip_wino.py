@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 SHAPES = [(2, 64, 64, 64, 208, 1), (2, 128, 128, 32, 104, 1), (1, 115, 128, 64, 208, 1), (2, 96, 32, 34, 50, 0),
           (1, 256, 96, 16, 52, 1), (3, 17, 33, 7, 9, 1), (1, 1, 1, 3, 3, 1), (2, 5, 70, 11, 6, 0), (1, 18, 40, 2, 2, 1),
           (1, 34, 32, 5, 64, 1), (2, 40, 48, 18, 54, 0), (1, 33, 20, 6, 10, 2), (2, 32, 32, 7, 9, 2), (1, 8, 8, 4, 34, 0),
-          (2, 24, 16, 12, 20, 1), (1, 16, 8, 6, 10, 0), (1, 33, 16, 8, 8, 2), (1, 20, 3, 9, 11, 1)]      # Co <= 16: the half-tile kernel
+          (2, 24, 16, 12, 20, 1), (1, 16, 8, 6, 10, 0), (1, 33, 16, 8, 8, 2), (1, 20, 3, 9, 11, 1),      # Co <= 16: the half-tile kernel
+          (12, 512, 512, 8, 26, 1), (3, 200, 96, 6, 10, 1), (2, 130, 40, 8, 8, 0), (4, 256, 64, 4, 14, 2)]   # few tiles, many channels: channel splits
 
 
 def dev():
@@ -51,7 +52,7 @@ def test_wino_conv_nonfinite_and_errors():
     y = ops.wino_conv3x3(x, w, 1)
     ref = F.conv2d(x, w, None, 1, 1)
     assert bool(torch.isnan(y[0, :, 1:4, 2:5]).all()) and bool(torch.isnan(ref[0, :, 1:4, 2:5]).all())
-    assert get_lib().dfe_wino_conv3x3(None, None, None, 0, None, 1, 1, 1, 4, 4, 1, 0, None) == -1
+    assert get_lib().dfe_wino_conv3x3(None, None, None, 0, None, 0, 1, 1, 1, 4, 4, 1, 0, None) == -1
     assert get_lib().dfe_wino_weight_floats(5, 33) == 64 * 5 * 16
 
 

@@ -58,6 +58,16 @@ __global__ void __launch_bounds__(256) k_wino_weights(const float* __restrict__ 
   }
 }
 
+// y[b][k][i] = sum over the channel splits of part[sp][b][k][i], in split order
+__global__ void __launch_bounds__(256) k_wino_sum(const float* __restrict__ part, float* __restrict__ y, long ybs, int nsp, int B, long KHW) {
+  const long idx = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= B * KHW) return;
+  float s = part[idx];
+  for (int k = 1; k < nsp; ++k) s += part[static_cast<long>(k) * B * KHW + idx];
+  const long b = idx / KHW;
+  y[b * ybs + (idx - b * KHW)] = s;
+}
+
 // x [B,C,H,W]; y [B,K,Ho,Wo], Ho = H + 2P - 2, Wo = W + 2P - 2 (P = 1: zero padding, P = 0: valid); element (b,k,i) of y at
 // y + b * ybs + k * Ho*Wo + i.  Tiles are numbered (b, ty, tx) row-major; grid (ceil(tiles / 128), Kpad / 32), 256 threads.
 template <bool PAIR>
@@ -245,13 +255,16 @@ template <int PP, int NW, int NH>   // PP = 0 / 1 / 2: the padding, pair loads (
                                     // exist (1 when Co <= 16: half the MFMAs, half the accumulators)
 __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restrict__ x, const float* __restrict__ U, float* __restrict__ y,
                                                        long ybs, int B, int C, int K, int H, int W, int P, int TH, int TW, int ntiles,
-                                                       unsigned nkt, int dil) {
+                                                       unsigned nkt, int dil, unsigned nsp, int cps, float* __restrict__ part) {
   extern __shared__ float lds[];      // [WN_CC][32][WN_XP]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
   // logical block id = tile block * nkt + kt, dealt so that the nkt blocks of one tile range (they load the same patches)
   // run on the same XCD at about the same time and share its L2
   const unsigned lid = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int kt = static_cast<int>(lid % nkt), tb = static_cast<int>(lid / nkt);
+  // nsp > 1: the input channels are split over nsp blocks (planes too small to fill the chip otherwise); each writes its partial
+  // output to part[sp] (the output transform is linear) and k_wino_sum adds them in split order
+  const int kt = static_cast<int>(lid % nkt), sp = static_cast<int>((lid / nkt) % nsp), tb = static_cast<int>(lid / (nkt * nsp));
+  const int cbeg = sp * cps, Cend = min(C, cbeg + cps);
   const int Ho = H + 2 * P - 2, Wo = W + 2 * P - 2, HW = H * W;
   const int tile = min(tb * (16 * NW) + wv * 16 + n, ntiles - 1);
   // dil > 1 (PP = -1 only): the convolution acts on the dil x dil phase images (pixels y = py + dil qy, x = px + dil qx) with
@@ -319,8 +332,8 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
   unsigned mn;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   auto issue = [&](int c) {
-    mn = c < C ? inb : 0u;
-    const unsigned cb = 4u * static_cast<unsigned>(c < C ? c : 0) * HW;
+    mn = c < Cend ? inb : 0u;
+    const unsigned cb = 4u * static_cast<unsigned>(c < Cend ? c : 0) * HW;
     if (PAIR) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -371,14 +384,14 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
       for (int q = 0; q < 16; ++q) d[q] = ((mn >> q) & 1u) ? dn[q] : 0.0f;
     }
   };
-  issue(kq);
+  issue(cbeg + kq);
   // weight slabs of 8 input channels, double-buffered: slab i + 1 travels global -> registers under the two steps of slab i
   // and is written to the other LDS buffer before the chunk's single barrier
   constexpr int SC = 8, SLAB = SC * 32 * WN_XP;
   constexpr int NTH = 64 * NW;
   f32x4 wreg[NW == 1 ? 1 : SC * 128 / NTH];
   auto wfetch = [&](int c0) {
-    const int nc = min(SC, C - c0);
+    const int nc = min(SC, Cend - c0);
 #pragma unroll
     for (int i = 0; i < (NW == 1 ? 1 : SC * 128 / NTH); ++i) {
       const int e = tid + i * NTH;
@@ -395,7 +408,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
   // a one-wave block stages each slab where it needs it (4 loads in flight): the CU's other blocks cover the wait, and the
   // 16 prefetch registers per thread would not fit
   auto wdirect = [&](int c0, float* buf) {
-    const int nc = min(SC, C - c0);
+    const int nc = min(SC, Cend - c0);
 #pragma unroll 4
     for (int i = 0; i < SC * 128 / NTH; ++i) {
       const int e = tid + i * NTH;
@@ -403,13 +416,13 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
       *reinterpret_cast<f32x4*>(buf + (e >> 2) * WN_XP + (e & 3) * 4) = v;
     }
   };
-  if (NW == 1) wdirect(0, lds);
-  else { wfetch(0); wstore(lds); }
+  if (NW == 1) wdirect(cbeg, lds);
+  else { wfetch(cbeg); wstore(lds); }
   __syncthreads();
   int cur = 0;
-  for (int c0 = 0; c0 < C; c0 += SC) {
-    const int nc = min(SC, C - c0);
-    const bool more = c0 + SC < C;
+  for (int c0 = cbeg; c0 < Cend; c0 += SC) {
+    const int nc = min(SC, Cend - c0);
+    const bool more = c0 + SC < Cend;
     if (more && NW != 1) wfetch(c0 + SC);
     const float* slab = lds + cur * SLAB;
     for (int cs = 0; cs < nc; cs += 4) {
@@ -455,7 +468,8 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
   const int Hoq = (PP >= 0 || dil == 1) ? Ho : H / dil, Woq = (PP >= 0 || dil == 1) ? Wo : W / dil;   // outputs per phase image
   const int oy = 2 * ty, ox = 2 * tx;
   const int sy = dil * Wo, sx = dil;                // strides of the 2x2 outputs in y
-  float* yb = y + b * ybs + static_cast<long>(py + dil * oy) * Wo + px + dil * ox;
+  const long kplane = static_cast<long>(Ho) * Wo;
+  float* yb = (nsp > 1 ? part + (static_cast<long>(sp) * B + b) * K * kplane : y + b * ybs) + static_cast<long>(py + dil * oy) * Wo + px + dil * ox;
 #pragma unroll
   for (int h = 0; h < NH; ++h)
 #pragma unroll
@@ -705,8 +719,27 @@ static int wn_dims(int B, int Ci, int Co, int H, int W, int P) {
 extern "C" long dfe_wino_weight_floats(int Ci, int Co) { return (Ci <= 0 || Co <= 0) ? 0 : static_cast<long>((Co + 31) / 32) * 32 * Ci * 16; }
 
 // transposed_weight: see include/dfe_hip.h
-static int wino_run(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, int B, int Ci, int Co, int H, int W,
-                    int P, int dil, int transposed_weight, void* stream) {
+extern "C" long dfe_wino_weight_floats(int Ci, int Co);
+
+struct WinoSplit { int nsp, cps; long part_floats; };
+
+// channel splits for the planes that cannot fill the chip: ntb tile blocks x nkt k-tiles < 384 blocks
+static WinoSplit wino_split(long ntiles, int Kpad, int Ci, int B, int Co, int Ho, int Wo) {
+  WinoSplit w{1, Ci, 0};
+  const long nblk = (ntiles + 63) / 64 * (Kpad / 32);
+  if (nblk >= 384 || Ci < 64) return w;
+  int nsp = static_cast<int>((512 + nblk - 1) / nblk);
+  nsp = std::min(nsp, std::min(Ci / 32, 8));
+  if (nsp < 2) return w;
+  w.cps = ((Ci + nsp - 1) / nsp + 7) / 8 * 8;
+  w.nsp = (Ci + w.cps - 1) / w.cps;
+  if (w.nsp < 2) { w.nsp = 1; w.cps = Ci; return w; }
+  w.part_floats = static_cast<long>(w.nsp) * B * Co * Ho * Wo;
+  return w;
+}
+
+static int wino_run(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, long wbuf_floats, int B, int Ci, int Co,
+                    int H, int W, int P, int dil, int transposed_weight, void* stream) {
   if (!x || !weight || !y || !wbuf) return DFE_ERR_NULL;
   const int rc = wn_dims(B, Ci, Co, H, W, P);
   if (rc != DFE_OK) return rc;
@@ -715,6 +748,7 @@ static int wino_run(const float* x, const float* weight, float* y, long y_batch_
   const int Ho = dil > 1 ? H : H + 2 * P - 2, Wo = dil > 1 ? W : W + 2 * P - 2;
   if (y_batch_stride < static_cast<long>(Co) * Ho * Wo) return DFE_ERR_DIMS;
   if ((reinterpret_cast<uintptr_t>(wbuf) & 15) != 0) return DFE_ERR_UNSUPPORTED;
+  if (wbuf_floats < dfe_wino_weight_floats(Ci, Co)) return DFE_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int Kpad = (Co + 31) / 32 * 32;
   const int nw = Kpad * Ci;
@@ -728,23 +762,32 @@ static int wino_run(const float* x, const float* weight, float* y, long y_batch_
   static const int variant = [] { const char* e = getenv("DFE_WINO_VARIANT"); return e ? atoi(e) : 16; }();
   if (variant == 16 || dil > 1) {
     const unsigned nkt = Kpad / 32;
+    const long ufl = static_cast<long>(Kpad) * Ci * 16;
+    WinoSplit sp = wino_split(ntiles, Kpad, Ci, B, Co, Ho, Wo);
+    if (dil > 1 || wbuf_floats < ufl + sp.part_floats) sp = WinoSplit{1, Ci, 0};      // no room for the partial outputs: one block per tile range
+    float* part = wbuf + ufl;
     // (one-wave blocks of 16 tiles for the planes that cannot fill the chip with 64-tile blocks were measured and lose: every
     // wave then stages the weight slabs for itself -- 12 x 256 -> 256 @ 16x52: 222 us against 112)
     const int tpb = 64;
-    const long nblk = (ntiles + tpb - 1) / tpb * nkt;
+    const long nblk = (ntiles + tpb - 1) / tpb * nkt * sp.nsp;
     if (nblk >= (1L << 31)) return DFE_ERR_DIMS;
     static const bool pair_ok = [] { const char* e = getenv("DFE_WINO_PAIR"); return !e || atoi(e) != 0; }();
     const bool pair = pair_ok && dil == 1 && W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0;
     const unsigned g = static_cast<unsigned>(nblk);
     const int nt = static_cast<int>(ntiles);
     const int pp = pair ? P : -1;
-#define WN_LAUNCH(PPV, NHV) k_wino_fwd16<PPV, 4, NHV><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt, dil)
+#define WN_LAUNCH(PPV, NHV) k_wino_fwd16<PPV, 4, NHV><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt, dil, static_cast<unsigned>(sp.nsp), sp.cps, part)
     if (Co <= 16) {
       if (pp == 1) WN_LAUNCH(1, 1); else if (pp == 0) WN_LAUNCH(0, 1); else if (pp == 2) WN_LAUNCH(2, 1); else WN_LAUNCH(-1, 1);
     } else {
       if (pp == 1) WN_LAUNCH(1, 2); else if (pp == 0) WN_LAUNCH(0, 2); else if (pp == 2) WN_LAUNCH(2, 2); else WN_LAUNCH(-1, 2);
     }
 #undef WN_LAUNCH
+    DFE_LAUNCH_CHECK();
+    if (sp.nsp > 1) {
+      const long khw = static_cast<long>(Co) * Ho * Wo, n = B * khw;
+      k_wino_sum<<<static_cast<unsigned>((n + 255) / 256), 256, 0, st>>>(part, y, y_batch_stride, sp.nsp, B, khw);
+    }
   } else {
     const dim3 grid(static_cast<unsigned>((ntiles + 127) / 128), Kpad / 32);
     if (variant == 2 && P == 1 && W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0)
@@ -756,14 +799,23 @@ static int wino_run(const float* x, const float* weight, float* y, long y_batch_
   return DFE_OK;
 }
 
-extern "C" int dfe_wino_conv3x3(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, int B, int Ci,
-                                int Co, int H, int W, int P, int transposed_weight, void* stream) {
-  return wino_run(x, weight, y, y_batch_stride, wbuf, B, Ci, Co, H, W, P, 1, transposed_weight, stream);
+extern "C" long dfe_wino_scratch_floats(int B, int Ci, int Co, int H, int W, int P) {
+  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || P < 0 || P > 2) return 0;
+  const int Ho = H + 2 * P - 2, Wo = W + 2 * P - 2;
+  if (Ho < 1 || Wo < 1) return 0;
+  const int Kpad = (Co + 31) / 32 * 32;
+  const long ntiles = static_cast<long>(B) * ((Ho + 1) / 2) * ((Wo + 1) / 2);
+  return static_cast<long>(Kpad) * Ci * 16 + wino_split(ntiles, Kpad, Ci, B, Co, Ho, Wo).part_floats;
+}
+
+extern "C" int dfe_wino_conv3x3(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, long wbuf_floats, int B,
+                                int Ci, int Co, int H, int W, int P, int transposed_weight, void* stream) {
+  return wino_run(x, weight, y, y_batch_stride, wbuf, wbuf_floats, B, Ci, Co, H, W, P, 1, transposed_weight, stream);
 }
 
 extern "C" int dfe_wino_conv3x3_dilated(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, int B,
                                         int Ci, int Co, int H, int W, int dilation, int transposed_weight, void* stream) {
-  return wino_run(x, weight, y, y_batch_stride, wbuf, B, Ci, Co, H, W, 1, dilation, transposed_weight, stream);
+  return wino_run(x, weight, y, y_batch_stride, wbuf, dfe_wino_weight_floats(Ci, Co), B, Ci, Co, H, W, 1, dilation, transposed_weight, stream);
 }
 
 // ---- weight gradient

@@ -652,14 +652,15 @@ def wino_conv3x3(x, w, padding=1, transposed=False, dilation=1):
     Co = int(w.shape[1] if transposed else w.shape[0])
     P, d = int(padding), int(dilation)
     lib = get_lib()
-    wbuf = torch.empty(lib.dfe_wino_weight_floats(Ci, Co), device=x.device, dtype=torch.float32)
+    nws = lib.dfe_wino_weight_floats(Ci, Co) if d > 1 else lib.dfe_wino_scratch_floats(B, Ci, Co, H, W, P)
+    wbuf = torch.empty(nws, device=x.device, dtype=torch.float32)
     if d > 1:
         y = torch.empty(B, Co, H, W, device=x.device, dtype=torch.float32)
         check(lib.dfe_wino_conv3x3_dilated(ptr(x), ptr(w), ptr(y), y.stride(0), ptr(wbuf), B, Ci, Co, H, W, d, int(bool(transposed)),
                                            stream_ptr()), "dfe_wino_conv3x3_dilated")
         return y
     y = torch.empty(B, Co, H + 2 * P - 2, W + 2 * P - 2, device=x.device, dtype=torch.float32)
-    check(lib.dfe_wino_conv3x3(ptr(x), ptr(w), ptr(y), y.stride(0), ptr(wbuf), B, Ci, Co, H, W, P, int(bool(transposed)),
+    check(lib.dfe_wino_conv3x3(ptr(x), ptr(w), ptr(y), y.stride(0), ptr(wbuf), nws, B, Ci, Co, H, W, P, int(bool(transposed)),
                                stream_ptr()), "dfe_wino_conv3x3")
     return y
 
