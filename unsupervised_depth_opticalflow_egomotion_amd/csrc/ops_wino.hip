@@ -726,8 +726,9 @@ struct WinoSplit { int nsp, cps; long part_floats; };
 // channel splits for the planes that cannot fill the chip: ntb tile blocks x nkt k-tiles < 384 blocks
 static WinoSplit wino_split(long ntiles, int Kpad, int Ci, int B, int Co, int Ho, int Wo) {
   WinoSplit w{1, Ci, 0};
+  static const bool enabled = [] { const char* e = getenv("DFE_WINO_SPLIT"); return !e || atoi(e) != 0; }();
   const long nblk = (ntiles + 63) / 64 * (Kpad / 32);
-  if (nblk >= 384 || Ci < 64) return w;
+  if (!enabled || nblk >= 384 || Ci < 64) return w;
   int nsp = static_cast<int>((512 + nblk - 1) / nblk);
   nsp = std::min(nsp, std::min(Ci / 32, 8));
   if (nsp < 2) return w;
