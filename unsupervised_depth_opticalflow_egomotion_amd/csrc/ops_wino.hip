@@ -4,14 +4,17 @@
 // these layers with the same algorithm on the vector ALU (miopenSp3AsmConv_*_f2x3: ~105 TFLOP/s effective); here
 //     Y = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A
 // keeps the per-position sums over the input channels as 16 independent GEMMs  M[xi] = U[xi] (k x c) * V[xi] (c x tiles)
-// on v_mfma_f32_32x32x2_f32.  A wave owns 32 output channels x 32 tiles and all 16 positions: 256 accumulator registers
-// per lane; per step of 2 input channels a lane loads the 4x4 input patch of ITS (tile, channel) -- the MFMA's B operand
+// on v_mfma_f32_16x16x4_f32.  A wave owns 32 output channels x 16 tiles and all 16 positions (128 accumulator registers: two
+// blocks per CU); per step of 4 input channels a lane loads the 4x4 input patch of ITS (tile, channel) -- the MFMA's B operand
 // layout is exactly "one (channel, tile) per lane", so the transformed patch never leaves the registers -- and reads its
-// 16 transformed weights from LDS (a 16-channel slab staged per chunk, shared by the block's four waves).  After the
-// channel loop a lane holds, for its tile, the 16 positions of 16 output channels: the output transform is register
-// arithmetic and the 2x2 outputs leave as 8-byte stores that are contiguous across the wave.
+// transformed weights from LDS (8-channel slabs, double-buffered, shared by the block's four waves).  The patch arrives as
+// one aligned 8-byte load per row plus the neighbouring lanes' pairs by DPP row shifts.  After the channel loop a lane holds,
+// for its tile, the 16 positions of 8 output channels: the output transform is register arithmetic and the 2x2 outputs leave
+// as stores that are contiguous across the wave.  The data gradient is the same kernel on the transposed, tap-reversed
+// filter; dilated layers run on the phase images; planes too small to fill the chip split their input channels over blocks
+// (fixed-order partial outputs).  k_wino_wgrad is the weight gradient in the same domain (opt-in).
 // Same numerics class as the MIOpen kernels it replaces (fp32 Winograd F(2,3)); sums in a fixed order: reproducible.
-// Bound: MFMA (2.25 x 157 TFLOP/s effective at 100 % of the fp32 matrix pipe).
+// Bound: MFMA (2.25 x 157 TFLOP/s effective at 100 % of the fp32 matrix pipe; measured 51 %).
 #include "dfe_internal.h"
 #include "dfe_device.h"
 #include <hip/hip_runtime.h>
@@ -68,188 +71,12 @@ __global__ void __launch_bounds__(256) k_wino_sum(const float* __restrict__ part
   y[b * ybs + (idx - b * KHW)] = s;
 }
 
-// x [B,C,H,W]; y [B,K,Ho,Wo], Ho = H + 2P - 2, Wo = W + 2P - 2 (P = 1: zero padding, P = 0: valid); element (b,k,i) of y at
-// y + b * ybs + k * Ho*Wo + i.  Tiles are numbered (b, ty, tx) row-major; grid (ceil(tiles / 128), Kpad / 32), 256 threads.
-template <bool PAIR>
-__global__ void __launch_bounds__(256) k_wino_fwd(const float* __restrict__ x, const float* __restrict__ U, float* __restrict__ y,
-                                                  long ybs, int B, int C, int K, int H, int W, int P, int TH, int TW, int ntiles) {
-  extern __shared__ float lds[];      // [WN_CC][32][WN_XP]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, kk = lane >> 5;
-  const int kt = blockIdx.y;
-  const int Ho = H + 2 * P - 2, Wo = W + 2 * P - 2, HW = H * W;
-  const int tile = min(blockIdx.x * 128 + wv * 32 + n, ntiles - 1);
-  const int b = tile / (TH * TW), tr = tile - b * TH * TW, ty = tr / TW, tx = tr - ty * TW;
-  const int iy0 = 2 * ty - P, ix0 = 2 * tx - P;
-  // PAIR (P = 1, W even): a patch row is columns 2tx-1 .. 2tx+2 = [left tile's odd column | this tile's aligned pair | right
-  // tile's even column].  A lane loads only its pair (one 8-byte load per row); the outer columns come from the
-  // neighbouring lanes (consecutive lanes are consecutive tiles) by DPP wave shifts.  Column -1 and column W are the zero
-  // border, which covers every row wrap; only the first and the last lane of a 32-lane half have no neighbour and load
-  // their outer column themselves (eoff / lanes_edge).  Otherwise: 16 single loads per patch.
-  unsigned off[16];                   // BYTE offsets in channel 0 of this lane's sample (0 when outside); PAIR: off[i] = row i's pair
-  unsigned inb = 0;                   // PAIR: bit i = row i inside, bit 4 = column -1 exists (tx > 0), bit 5 = column W exists
-  unsigned eoff[8];                   // PAIR: byte offsets of the outer columns (left 0..3, right 4..7) for the edge lanes
-  const bool edge_l = PAIR && n == 0 && tx > 0, edge_r = PAIR && n == 31 && tx < TW - 1;
-  if (PAIR) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int yy = iy0 + i;
-      const bool ok = yy >= 0 && yy < H;
-      const unsigned rowb = 4u * (static_cast<unsigned>(b) * C * HW + (ok ? yy * W : 0));
-      off[i] = rowb + 4u * static_cast<unsigned>(2 * tx);
-      eoff[i] = rowb + 4u * static_cast<unsigned>(max(2 * tx - 1, 0));
-      eoff[4 + i] = rowb + 4u * static_cast<unsigned>(min(2 * tx + 2, W - 1));
-      inb |= ok ? (1u << i) : 0u;
-    }
-    inb |= (tx > 0 ? 16u : 0u) | (tx < TW - 1 ? 32u : 0u);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int yy = iy0 + i, xx = ix0 + j;
-        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-        off[i * 4 + j] = 4u * (static_cast<unsigned>(b) * C * HW + (ok ? yy * W + xx : 0));
-        inb |= ok ? (1u << (i * 4 + j)) : 0u;
-      }
-  }
-  f32x16 acc[16];
-#pragma unroll
-  for (int s = 0; s < 16; ++s)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[s][i] = 0.0f;
-  const float* Ut = U + static_cast<long>(kt) * C * 512;
-  // Software pipeline over the steps of 2 input channels (this lane's channel of step g is 2 g + kk):
-  //   the patch of step g + 1 (loaded during step g - 1; unconditional loads from clamped offsets, masked when consumed) is
-  //   transformed at the top of step g, then the loads of step g + 2 are issued and stay in flight under the 16 MFMAs.
-  float dA[16], dB[16], vcur[16];
-  unsigned mA, mB;
-  struct F2 { float a, b; };
-  auto issue = [&](int c, float (&dst)[16], unsigned& m) {
-    m = c < C ? inb : 0u;
-    const unsigned cb = 4u * static_cast<unsigned>(c < C ? c : 0) * HW;
-    const char* xc = reinterpret_cast<const char*>(x);
-    if (PAIR) {
-      // dst[4 i + 1], dst[4 i + 2] = the pair of row i; dst[4 i] / dst[4 i + 3] = the outer columns of the edge lanes
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const F2 p = *reinterpret_cast<const F2*>(xc + (off[i] + cb));
-        dst[4 * i + 1] = p.a; dst[4 * i + 2] = p.b;
-      }
-      if (edge_l) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dst[4 * i] = *reinterpret_cast<const float*>(xc + (eoff[i] + cb));
-      }
-      if (edge_r) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dst[4 * i + 3] = *reinterpret_cast<const float*>(xc + (eoff[4 + i] + cb));
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) dst[q] = *reinterpret_cast<const float*>(xc + (off[q] + cb));
-    }
-  };
-  auto transform = [&](const float (&src)[16], unsigned m, float (&v)[16]) {      // B^T d B of this lane's (tile, channel)
-    float d[16], t[16];
-    if (PAIR) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool rok = (m >> i) & 1u;
-        const float p1 = rok ? src[4 * i + 1] : 0.0f, p2 = rok ? src[4 * i + 2] : 0.0f;
-        // outer columns: the neighbour lanes' pair halves (every lane executes the shifts), or this lane's own load
-        const float fromL = wave_shr1(p2), fromR = wave_shl1(p1);
-        const float l = edge_l ? (rok ? src[4 * i] : 0.0f) : fromL, r = edge_r ? (rok ? src[4 * i + 3] : 0.0f) : fromR;
-        d[4 * i] = (m & 16u) ? l : 0.0f;
-        d[4 * i + 1] = p1; d[4 * i + 2] = p2;
-        d[4 * i + 3] = (m & 32u) ? r : 0.0f;
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) d[q] = ((m >> q) & 1u) ? src[q] : 0.0f;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      t[j] = d[j] - d[8 + j];
-      t[4 + j] = d[4 + j] + d[8 + j];
-      t[8 + j] = d[8 + j] - d[4 + j];
-      t[12 + j] = d[4 + j] - d[12 + j];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v[i * 4 + 0] = t[i * 4] - t[i * 4 + 2];
-      v[i * 4 + 1] = t[i * 4 + 1] + t[i * 4 + 2];
-      v[i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1];
-      v[i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
-    }
-  };
-  // two raw-patch slots in rotation (slot g % 2 receives step g + 2 while step g runs): no register is copied after a load,
-  // so nothing waits for the loads in flight
-  auto step = [&](int g, float (&dnew)[16], unsigned& mnew, const float (&dnext)[16], unsigned mnext) {
-    const int cs = (g & 7) * 2, c0 = (g >> 3) * WN_CC, nc = min(WN_CC, C - c0);
-    // this lane's channel inside the slab; a lane past the last channel multiplies its zero patch with a staged row
-    float u[16];
-    const float* up = lds + (max(min(cs + kk, nc - 1), 0) * 32 + n) * WN_XP;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 w4 = *reinterpret_cast<const f32x4*>(up + 4 * q);
-      u[4 * q] = w4[0]; u[4 * q + 1] = w4[1]; u[4 * q + 2] = w4[2]; u[4 * q + 3] = w4[3];
-    }
-    float vnext[16];
-    transform(dnext, mnext, vnext);                 // step g + 1's patch, issued one step ago
-    issue(2 * (g + 2) + kk, dnew, mnew);            // slot of step g (already transformed) <- step g + 2
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < 16; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[s], vcur[s], acc[s], 0, 0, 0);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) vcur[q] = vnext[q];
-  };
-  issue(kk, dA, mA);
-  issue(2 + kk, dB, mB);
-  transform(dA, mA, vcur);
-  const int nsteps = (C + 3) / 4 * 2;              // an even number of steps; a step past the last channel multiplies zero patches
-  for (int g = 0; g < nsteps; g += 2) {
-    if ((g & 7) == 0) {
-      if (g) __syncthreads();
-      const int c0 = (g >> 3) * WN_CC, nc = min(WN_CC, C - c0);
-      // the slab's nc * 32 * 16 floats are contiguous in U: straight copy, re-pitched to WN_XP
-      for (int e = tid; e < nc * 128; e += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(Ut + static_cast<long>(c0) * 512 + e * 4);
-        *reinterpret_cast<f32x4*>(lds + (e >> 2) * WN_XP + (e & 3) * 4) = v;
-      }
-      __syncthreads();
-    }
-    step(g, dA, mA, dB, mB);
-    step(g + 1, dB, mB, dA, mA);
-  }
-  // D[m][n]: lane holds tile n and the output channels m = 8 (i / 4) + 4 kk + i % 4, i = 0 .. 15, for each position
-  if (blockIdx.x * 128 + wv * 32 + n >= ntiles) return;
-  const int oy = 2 * ty, ox = 2 * tx;
-  float* yb = y + b * ybs;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int k = kt * 32 + 8 * (i >> 2) + 4 * kk + (i & 3);
-    if (k >= K) continue;
-    float t0[4], t1[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      t0[s] = (acc[s][i] + acc[4 + s][i]) + acc[8 + s][i];
-      t1[s] = (acc[4 + s][i] - acc[8 + s][i]) - acc[12 + s][i];
-    }
-    const float y00 = (t0[0] + t0[1]) + t0[2], y01 = (t0[1] - t0[2]) - t0[3];
-    const float y10 = (t1[0] + t1[1]) + t1[2], y11 = (t1[1] - t1[2]) - t1[3];
-    float* o = yb + static_cast<long>(k) * Ho * Wo + oy * Wo + ox;
-    if (ox + 1 < Wo) {
-      if (oy < Ho) { o[0] = y00; o[1] = y01; }
-      if (oy + 1 < Ho) { o[Wo] = y10; o[Wo + 1] = y11; }
-    } else if (ox < Wo) {
-      if (oy < Ho) o[0] = y00;
-      if (oy + 1 < Ho) o[Wo] = y10;
-    }
-  }
-}
-
-// Variant with HALF the accumulators per wave (16 tiles x 32 output channels: 128 registers) so that two blocks share a CU
-// and the hardware hides one wave's loads and LDS reads under the other's MFMAs: v_mfma_f32_16x16x4_f32, a lane owns
-// (tile = lane & 15, channel 4 g + (lane >> 4)) of step g; block = 4 waves = 64 tiles x 32 output channels.
+// x [B,C,H,W]; y [B,K,Ho,Wo], Ho = H + 2P - 2, Wo = W + 2P - 2 (P = 1: zero padding, 0: valid, 2: full); element (b,k,i) of y at
+// y + b * ybs + k * Ho*Wo + i.  Tiles are numbered (b, ty, tx) row-major.  A wave owns 16 tiles x 32 output channels (128
+// accumulator registers), so that two blocks share a CU and the hardware hides one wave's loads and LDS reads under the
+// other's MFMAs: v_mfma_f32_16x16x4_f32, a lane owns (tile = lane & 15, channel 4 g + (lane >> 4)) of step g; block = 4 waves
+// = 64 tiles x 32 output channels.  (The first version -- 32 tiles x 32 channels per wave on v_mfma_f32_32x32x2_f32, 256
+// accumulators, one wave per SIMD with software-pipelined loads -- only tied MIOpen and was removed.)
 template <int PP, int NW, int NH>   // PP = 0 / 1 / 2: the padding, pair loads (W even); -1: any padding and width, 16 single loads
                                     // per patch.  NW = waves per block.  NH = 16-channel halves of the 32-channel output tile that
                                     // exist (1 when Co <= 16: half the MFMAs, half the accumulators)
@@ -389,41 +216,30 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
   // and is written to the other LDS buffer before the chunk's single barrier
   constexpr int SC = 8, SLAB = SC * 32 * WN_XP;
   constexpr int NTH = 64 * NW;
-  f32x4 wreg[NW == 1 ? 1 : SC * 128 / NTH];
+  f32x4 wreg[SC * 128 / NTH];
   auto wfetch = [&](int c0) {
     const int nc = min(SC, Cend - c0);
 #pragma unroll
-    for (int i = 0; i < (NW == 1 ? 1 : SC * 128 / NTH); ++i) {
+    for (int i = 0; i < SC * 128 / NTH; ++i) {
       const int e = tid + i * NTH;
       wreg[i] = *reinterpret_cast<const f32x4*>(Ut + static_cast<long>(c0) * 512 + (e < nc * 128 ? e : 0) * 4);
     }
   };
   auto wstore = [&](float* buf) {
 #pragma unroll
-    for (int i = 0; i < (NW == 1 ? 1 : SC * 128 / NTH); ++i) {
+    for (int i = 0; i < SC * 128 / NTH; ++i) {
       const int e = tid + i * NTH;
       *reinterpret_cast<f32x4*>(buf + (e >> 2) * WN_XP + (e & 3) * 4) = wreg[i];
     }
   };
-  // a one-wave block stages each slab where it needs it (4 loads in flight): the CU's other blocks cover the wait, and the
-  // 16 prefetch registers per thread would not fit
-  auto wdirect = [&](int c0, float* buf) {
-    const int nc = min(SC, Cend - c0);
-#pragma unroll 4
-    for (int i = 0; i < SC * 128 / NTH; ++i) {
-      const int e = tid + i * NTH;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(Ut + static_cast<long>(c0) * 512 + (e < nc * 128 ? e : 0) * 4);
-      *reinterpret_cast<f32x4*>(buf + (e >> 2) * WN_XP + (e & 3) * 4) = v;
-    }
-  };
-  if (NW == 1) wdirect(cbeg, lds);
-  else { wfetch(cbeg); wstore(lds); }
+  wfetch(cbeg);
+  wstore(lds);
   __syncthreads();
   int cur = 0;
   for (int c0 = cbeg; c0 < Cend; c0 += SC) {
     const int nc = min(SC, Cend - c0);
     const bool more = c0 + SC < Cend;
-    if (more && NW != 1) wfetch(c0 + SC);
+    if (more) wfetch(c0 + SC);
     const float* slab = lds + cur * SLAB;
     for (int cs = 0; cs < nc; cs += 4) {
       float d[16], t[16], v[16];
@@ -457,8 +273,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
       }
     }
     if (more) {
-      if (NW == 1) wdirect(c0 + SC, lds + (cur ^ 1) * SLAB);
-      else wstore(lds + (cur ^ 1) * SLAB);          // nobody reads that buffer: its last readers passed the previous barrier
+      wstore(lds + (cur ^ 1) * SLAB);               // nobody reads that buffer: its last readers passed the previous barrier
       __syncthreads();
       cur ^= 1;
     }
@@ -760,8 +575,7 @@ static int wino_run(const float* x, const float* weight, float* y, long y_batch_
   const long ntiles = static_cast<long>(B) * TH * TW * dil * dil;
   if (ntiles >= (1L << 31)) return DFE_ERR_DIMS;
   const size_t lds_bytes = sizeof(float) * WN_CC * 32 * WN_XP;
-  static const int variant = [] { const char* e = getenv("DFE_WINO_VARIANT"); return e ? atoi(e) : 16; }();
-  if (variant == 16 || dil > 1) {
+  {
     const unsigned nkt = Kpad / 32;
     const long ufl = static_cast<long>(Kpad) * Ci * 16;
     WinoSplit sp = wino_split(ntiles, Kpad, Ci, B, Co, Ho, Wo);
@@ -789,12 +603,6 @@ static int wino_run(const float* x, const float* weight, float* y, long y_batch_
       const long khw = static_cast<long>(Co) * Ho * Wo, n = B * khw;
       k_wino_sum<<<static_cast<unsigned>((n + 255) / 256), 256, 0, st>>>(part, y, y_batch_stride, sp.nsp, B, khw);
     }
-  } else {
-    const dim3 grid(static_cast<unsigned>((ntiles + 127) / 128), Kpad / 32);
-    if (variant == 2 && P == 1 && W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0)
-      k_wino_fwd<true><<<grid, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, static_cast<int>(ntiles));
-    else
-      k_wino_fwd<false><<<grid, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, static_cast<int>(ntiles));
   }
   DFE_LAUNCH_CHECK();
   return DFE_OK;
