@@ -674,7 +674,8 @@ def test_winograd_dispatch_rule_is_shape_logic_only(monkeypatch):
     assert el(x, (128, 128, 3, 3), 128, (1, 1), (4, 4), (4, 4)) and el(x, (128, 128, 3, 3), 128, (1, 1), (16, 16), (16, 16))
     assert not el(x, (128, 128, 3, 3), 128, (1, 1), (3, 3), (3, 3))                                   # 64 is no multiple of 3
     assert not el(x, (128, 128, 3, 3), 128, (1, 1), (1, 1), (1, 1), groups=2)
-    assert not el(FakeCuda(8, 16, 64, 208), (16, 16, 3, 3), 16, (1, 1), (1, 1), (1, 1))               # too few reduction channels
+    assert not el(FakeCuda(8, 8, 64, 208), (16, 8, 3, 3), 8, (1, 1), (1, 1), (1, 1))                  # too few reduction channels
+    assert el(FakeCuda(12, 16, 256, 832), (16, 16, 3, 3), 16, (1, 1), (1, 1), (1, 1))                 # the decoder's 16 -> 16 layers qualify
     assert not el(FakeCuda(8, 128, 4, 13), (128, 128, 3, 3), 128, (1, 1), (1, 1), (1, 1))             # 8 * 2 * 7 tiles: the small-plane kernels' job
     assert not el(FakeCuda(64, 512, 128, 416), (64, 512, 3, 3), 512, (1, 1), (1, 1), (1, 1))          # > 2^30 elements: 32-bit offsets
     monkeypatch.setattr(convs, "WINO_MIN_TILES", 0)
