@@ -167,6 +167,8 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
         const f32x2 p = *reinterpret_cast<const f32x2*>(xc + (off[i] + cb));
         dn[2 * i] = p[0]; dn[2 * i + 1] = p[1];
       }
+#pragma unroll
+      for (int i = 8; i < 16; ++i) dn[i] = 0.0f;      // defined on every lane (the selects below must not see an undefined value)
       if (edge_l || edge_r) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -181,8 +183,28 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
   };
   auto shr1 = [](float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true)); };   // row_shr:1
   auto shl1 = [](float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xF, 0xF, true)); };   // row_shl:1
+  // a wave whose 64 patches lie inside the image (most waves) skips the border selects: 121 -> ~80 vector instructions per step
+  constexpr unsigned NEED = 0xFu | (USE_L ? 16u : 0u) | (USE_R ? 32u : 0u) | 64u;
+  const bool plain_wave = PAIR && __all(static_cast<int>((inb & NEED) == NEED)) != 0;
   auto gather = [&](float (&d)[16]) {                // the masked 4x4 patch of the step whose loads were issued last
-    if (PAIR) {
+    if (PAIR && plain_wave && __all(static_cast<int>(mn != 0u)) != 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float o1 = dn[2 * i], o2 = dn[2 * i + 1], e1 = dn[8 + 2 * i], e2 = dn[9 + 2 * i];
+        float l1 = 0.0f, l2 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+        if (USE_L) {
+          if (PP == 2) { l1 = shr1(o1); l1 = edge_l ? e1 : l1; }
+          l2 = shr1(o2); l2 = edge_l ? e2 : l2;
+        }
+        if (USE_R) {
+          r1 = shl1(o1); r1 = edge_r ? e1 : r1;
+          if (PP == 0) { r2 = shl1(o2); r2 = edge_r ? e2 : r2; }
+        }
+        if (PP == 1) { d[4 * i] = l2; d[4 * i + 1] = o1; d[4 * i + 2] = o2; d[4 * i + 3] = r1; }
+        else if (PP == 0) { d[4 * i] = o1; d[4 * i + 1] = o2; d[4 * i + 2] = r1; d[4 * i + 3] = r2; }
+        else { d[4 * i] = l1; d[4 * i + 1] = l2; d[4 * i + 2] = o1; d[4 * i + 3] = o2; }
+      }
+    } else if (PAIR) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bool rok = (mn >> i) & 1u;
