@@ -286,6 +286,19 @@ int dfe_wino_wgrad3x3(const float* x, const float* gy, long gy_batch_stride, flo
  * Winograd tiles live on the dilation x dilation phase images; H and W must be multiples of the dilation.  y has x's size. */
 int dfe_wino_conv3x3_dilated(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, int B, int Ci, int Co,
                              int H, int W, int dilation, int transposed_weight, void* stream);
+/* Transformed filters kept across calls (a training step transforms every filter twice -- forward and data gradient -- although
+ * it only changes once, in the optimiser step; nn.Conv2d has no such state, depth_model.py:60-211 / pwc_tf.py:28-95):
+ * dfe_wino_transform_weights_multi transforms n filters in ONE launch, bit-identically to what dfe_wino_conv3x3 computes for
+ * itself.  table (device): 6 longs per filter = {weight pointer, U pointer (dfe_wino_weight_floats(Ci, Co) floats, 16-byte
+ * aligned), K, C, transposed_weight, first block}, where (K, C) = (Co, Ci) of the convolution the U is FOR (transposed_weight = 1:
+ * weight is [C,K,3,3]); a filter takes dfe_wino_transform_blocks(Ci = C, Co = K) consecutive blocks; blockmap (device): the
+ * filter index of each of the n_blocks blocks.
+ * dfe_wino_conv3x3_u is dfe_wino_conv3x3 / _dilated (dilation > 1: P is ignored) on such a U; part: part_floats floats of
+ * scratch for the channel splits (dfe_wino_scratch_floats - dfe_wino_weight_floats; may be null / 0: no splits). */
+long dfe_wino_transform_blocks(int Ci, int Co);
+int dfe_wino_transform_weights_multi(const long* table, const int* blockmap, int n_blocks, void* stream);
+int dfe_wino_conv3x3_u(const float* x, const float* U, float* y, long y_batch_stride, float* part, long part_floats, int B, int Ci,
+                       int Co, int H, int W, int P, int dilation, void* stream);
 
 /* ---- 1x1 convolutions on tiny planes (H*W <= 256, B*H*W <= 4096): PoseCNN's pose_conv and refinement head
  * (pose_cnn.py:32,43,48: Conv2d(256 | 24 | 12, 12, 1) on 2x7 planes).  x [B,Ci,H,W], weight [Co,Ci] (= [Co,Ci,1,1]).

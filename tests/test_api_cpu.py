@@ -84,6 +84,13 @@ def test_error_strings_and_argument_checks_without_gpu():
     assert lib.dfe_wino_wgrad_floats(8, 128, 128, 64, 208, 1) > 0 and lib.dfe_wino_wgrad_floats(8, 128, 128, 64, 208, 2) == 0
     assert lib.dfe_wino_wgrad3x3(P, P, 128 * 64 * 208, P, P, 8, 128, 128, 64, 207, 1, None) == -4      # odd width: pair loads
     assert lib.dfe_wino_wgrad3x3(P, None, 0, P, P, 1, 4, 4, 8, 8, 1, None) == -1
+    # transformed filters kept across calls: blocks per filter, argument checks
+    assert lib.dfe_wino_transform_blocks(64, 64) == 16 and lib.dfe_wino_transform_blocks(5, 33) == 2 and lib.dfe_wino_transform_blocks(0, 3) == 0
+    assert lib.dfe_wino_transform_weights_multi(None, P, 4, None) == -1 and lib.dfe_wino_transform_weights_multi(P, P, 0, None) == -2
+    assert lib.dfe_wino_conv3x3_u(P, None, P, 4 * 8 * 8, None, 0, 1, 4, 4, 8, 8, 1, 1, None) == -1
+    assert lib.dfe_wino_conv3x3_u(P, P, P, 4 * 8 * 8, ctypes.c_void_p(20), 64, 1, 4, 4, 8, 8, 1, 1, None) == -4    # partial sums not 16-byte aligned
+    assert lib.dfe_wino_conv3x3_u(P, P, P, 4 * 8 * 9, None, 0, 1, 4, 4, 8, 9, 1, 2, None) == -4    # W not a multiple of the dilation
+    assert lib.dfe_wino_conv3x3(P, None, P, 4 * 8 * 8, P, 1 << 20, 1, 4, 4, 8, 8, 1, 0, None) == -1
     assert lib.dfe_conv1x1_small_supported(4, 256, 12, 2, 7) == 1 and lib.dfe_conv1x1_small_supported(4, 16, 16, 64, 208) == 0
     assert lib.dfe_conv1x1_small_fwd(P, None, None, 1.0, P, 4, 12, 12, 2, 7, None) == -1
     assert lib.dfe_cast_f32_nchw_to_bf16_nhwc(None, P, 1, 4, 16, None) == -1 and lib.dfe_cast_bf16_nhwc_to_f32_nchw(P, P, 0, 4, 16, None) == -2

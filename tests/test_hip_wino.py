@@ -88,3 +88,111 @@ def test_wino_wgrad_matches_float64(shape):
     err, scale = float((gw.double() - ref).abs().max()), float(ref.abs().max())
     assert err <= 3e-5 * scale, (err, scale)
     assert torch.equal(gw, ops.wino_wgrad3x3(x, gy, P))
+
+
+# ---- transformed filters kept across steps (ops.WinoWeightCache, dfe_wino_transform_weights_multi / dfe_wino_conv3x3_u)
+CACHE_SHAPES = [(2, 64, 64, 64, 208, 1, 1), (1, 115, 128, 32, 104, 1, 1), (2, 96, 32, 34, 50, 0, 1), (3, 17, 33, 7, 9, 1, 1),
+                (2, 24, 16, 12, 20, 1, 1), (12, 512, 512, 8, 26, 1, 1), (2, 130, 40, 8, 8, 0, 1), (2, 32, 32, 16, 32, 1, 4),
+                (1, 40, 20, 16, 48, 1, 8)]
+
+
+def _both(x, gy, w, P, d):
+    y = ops.wino_conv3x3(x, w, P, dilation=d)
+    gx = ops.wino_conv3x3(gy, w, 1 if P == 1 else 2, transposed=True, dilation=d)
+    return y, gx
+
+
+def test_cached_filters_are_bit_identical_to_the_per_call_transform():
+    """Every parameter the kernel has seen is transformed by ONE launch at refresh(); calls then read the cached U: outputs
+    (forward and data gradient; plain, half-tile, channel-split, valid and dilated forms) equal the per-call path bit for bit."""
+    cache = ops.WinoWeightCache()
+    old, ops.wino_weights = ops.wino_weights, cache
+    try:
+        assert cache.enabled
+        cases = []
+        for shape in CACHE_SHAPES:
+            B, Ci, Co, H, W, P, d = shape
+            torch.manual_seed(sum(shape))
+            x = torch.randn(B, Ci, H, W, device=dev())
+            w = torch.nn.Parameter(torch.randn(Co, Ci, 3, 3, device=dev()) / (3.0 * Ci ** 0.5))
+            Ho, Wo = (H, W) if d > 1 else (H + 2 * P - 2, W + 2 * P - 2)
+            gy = torch.randn(B, Co, Ho, Wo, device=dev())
+            with torch.no_grad():
+                cases.append((x, gy, w, P, d, _both(x, gy, w, P, d)))       # misses: registered, transformed per call
+        assert cache.hits == 0 and cache.misses == 2 * len(cases) and len(cache.entries) == len(cases)
+        cache.refresh()
+        assert cache.blockmap.numel() == sum(int(ops.get_lib().dfe_wino_transform_blocks(c[2].shape[1], c[2].shape[0])) +
+                                             int(ops.get_lib().dfe_wino_transform_blocks(c[2].shape[0], c[2].shape[1])) for c in cases)
+        for x, gy, w, P, d, (y0, gx0) in cases:
+            with torch.no_grad():
+                y1, gx1 = _both(x, gy, w, P, d)
+            assert torch.equal(y0, y1) and torch.equal(gx0, gx1), (tuple(w.shape), P, d)
+        assert cache.hits == 2 * len(cases)
+    finally:
+        ops.wino_weights = old
+
+
+def test_cached_filters_miss_when_the_parameter_changes():
+    """In-place torch updates bump the version counter: the stale entry is not used (the call transforms for itself) until
+    the next refresh; a parameter that died or moved to other storage is dropped; plain tensors are never registered."""
+    cache = ops.WinoWeightCache()
+    old, ops.wino_weights = ops.wino_weights, cache
+    try:
+        torch.manual_seed(5)
+        x = torch.randn(2, 48, 20, 36, device=dev())
+        w = torch.nn.Parameter(torch.randn(40, 48, 3, 3, device=dev()) * 0.05)
+        with torch.no_grad():
+            ops.wino_conv3x3(x, w, 1)
+            cache.refresh()
+            y_old = ops.wino_conv3x3(x, w, 1)
+            assert cache.hits == 1
+            w.mul_(-2.0)                                    # version bump
+            y_new = ops.wino_conv3x3(x, w, 1)
+            assert cache.hits == 1 and torch.equal(y_new, ops.wino_conv3x3(x, w.detach().clone(), 1))
+            assert float((y_new + 2.0 * y_old).abs().max()) <= 1e-4 * float(y_old.abs().max())
+            cache.refresh()
+            assert torch.equal(ops.wino_conv3x3(x, w, 1), y_new) and cache.hits == 2
+            cache.invalidate()
+            assert torch.equal(ops.wino_conv3x3(x, w, 1), y_new) and cache.hits == 2
+            n = len(cache.entries)
+            ops.wino_conv3x3(x, w.detach().clone(), 1)      # not a Parameter: not registered
+            assert len(cache.entries) == n
+            w.data = w.data.clone()                          # other storage: the old entry goes at the next refresh
+            ops.wino_conv3x3(x, w, 1)
+            cache.refresh()
+            assert len(cache.entries) == 1 and torch.equal(ops.wino_conv3x3(x, w, 1), y_new) and cache.hits == 3
+            del w
+            cache.refresh()
+            assert len(cache.entries) == 0
+    finally:
+        ops.wino_weights = old
+
+
+def test_fused_adam_refreshes_the_cached_filters():
+    """optim.FusedAdam writes parameters through raw pointers (no version bump) and therefore rebuilds the cache itself: in a
+    convolution layer trained for three steps, every step's output and input gradient (cached filters from step 2 on) equal
+    the per-call transform of the weights of that moment, bit for bit."""
+    from unsupervised_depth_opticalflow_egomotion_amd import convs, optim
+
+    cache = ops.WinoWeightCache()
+    old, ops.wino_weights = ops.wino_weights, cache
+    try:
+        torch.manual_seed(11)
+        conv = torch.nn.Conv2d(64, 64, 3, 1, 1).to(dev())
+        x = torch.randn(4, 64, 64, 104, device=dev())
+        opt = optim.FusedAdam(conv.parameters(), lr=1e-2)
+        w_before = conv.weight.detach().clone()
+        for step in range(3):
+            opt.zero_grad()
+            xi = x.clone().requires_grad_(True)
+            y = convs.conv2d(xi, conv.weight, None, 1, 1)
+            gy = torch.randn_like(y)
+            y.backward(gy)
+            w_now = conv.weight.detach().clone()               # a plain tensor: never cached
+            assert torch.equal(y.detach(), ops.wino_conv3x3(x, w_now, 1))
+            assert torch.equal(xi.grad, ops.wino_conv3x3(gy, w_now, 1, transposed=True))
+            assert (cache.hits, cache.misses) == (2 * step, 2 + 2 * (step + 1))     # step 0 transforms per call, then the cache
+            opt.step()
+        assert not torch.equal(conv.weight.detach(), w_before)
+    finally:
+        ops.wino_weights = old

@@ -51,6 +51,9 @@ _SIGNATURES = {
     "dfe_wino_wgrad_floats": [_I, _I, _I, _I, _I, _I],
     "dfe_wino_wgrad3x3": [_P, _P, ctypes.c_long, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dfe_wino_conv3x3_dilated": [_P, _P, _P, ctypes.c_long, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dfe_wino_transform_blocks": [_I, _I],
+    "dfe_wino_transform_weights_multi": [_P, _P, _I, _P],
+    "dfe_wino_conv3x3_u": [_P, _P, _P, ctypes.c_long, _P, ctypes.c_long, _I, _I, _I, _I, _I, _I, _I, _P],
     "dfe_conv1x1_small_supported": [_I, _I, _I, _I, _I],
     "dfe_conv1x1_small_fwd": [_P, _P, _P, ctypes.c_float, _P, _I, _I, _I, _I, _I, _P],
     "dfe_conv1x1_small_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -114,7 +117,7 @@ _RESTYPES = {"dfe_error_string": ctypes.c_char_p, "dfe_geom_workspace_floats": c
              "dfe_bias_act_partials_floats": ctypes.c_long, "dfe_glue_partials_floats": ctypes.c_long,
              "dfe_bn_partials_floats": ctypes.c_long, "dfe_disp_head_partials_floats": ctypes.c_long,
              "dfe_flow_head_partials_floats": ctypes.c_long,
-             "dfe_wgrad3x3_partials_floats": ctypes.c_long, "dfe_planeconv_ws_floats": ctypes.c_long, "dfe_wino_weight_floats": ctypes.c_long, "dfe_wino_scratch_floats": ctypes.c_long, "dfe_wino_wgrad_floats": ctypes.c_long,
+             "dfe_wgrad3x3_partials_floats": ctypes.c_long, "dfe_planeconv_ws_floats": ctypes.c_long, "dfe_wino_weight_floats": ctypes.c_long, "dfe_wino_scratch_floats": ctypes.c_long, "dfe_wino_wgrad_floats": ctypes.c_long, "dfe_wino_transform_blocks": ctypes.c_long,
              "dfe_geom_maskpack_offset_bytes": ctypes.c_long, "dfe_scatter_ws_bytes": ctypes.c_long}
 
 

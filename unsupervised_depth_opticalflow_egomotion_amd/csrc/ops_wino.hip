@@ -32,9 +32,7 @@ constexpr int WN_XP = 20;        // LDS floats per (channel, k): 16 positions + 
 // U[ktile][c][k32][16] = G g G^T of the 3x3 filter from input channel c to output channel ktile*32 + k32 (zero past K).
 // TRANSPOSED (data gradient): the filter is w[c][k][8 - t] (w is [Co][Ci][3][3], "k" runs over Ci, "c" over Co).
 template <bool TRANSPOSED>
-__global__ void __launch_bounds__(256) k_wino_weights(const float* __restrict__ w, float* __restrict__ U, int K, int C, int Kpad) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= Kpad * C) return;
+__device__ __forceinline__ void wino_weight_one(const float* __restrict__ w, float* __restrict__ U, int K, int C, int Kpad, int idx) {
   const int k = idx % Kpad, c = idx / Kpad;
   float g[9];
 #pragma unroll
@@ -59,6 +57,26 @@ __global__ void __launch_bounds__(256) k_wino_weights(const float* __restrict__ 
     o[i * 4 + 2] = 0.5f * ((r[i][0] - r[i][1]) + r[i][2]);
     o[i * 4 + 3] = r[i][2];
   }
+}
+
+template <bool TRANSPOSED>
+__global__ void __launch_bounds__(256) k_wino_weights(const float* __restrict__ w, float* __restrict__ U, int K, int C, int Kpad) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Kpad * C) return;
+  wino_weight_one<TRANSPOSED>(w, U, K, C, Kpad, idx);
+}
+
+// The filters of a whole model in one launch (after the optimiser step): table[e] = {weight, U, K, C, transposed, first block},
+// blockmap[block] = e.  Same arithmetic as k_wino_weights: the cached U is bit-identical to the one a call computes for itself.
+__global__ void __launch_bounds__(256) k_wino_weights_multi(const long* __restrict__ table, const int* __restrict__ blockmap) {
+  const long* e = table + 6L * blockmap[blockIdx.x];
+  const float* w = reinterpret_cast<const float*>(e[0]);
+  float* U = reinterpret_cast<float*>(e[1]);
+  const int K = static_cast<int>(e[2]), C = static_cast<int>(e[3]), Kpad = (K + 31) / 32 * 32;
+  const int idx = (static_cast<int>(blockIdx.x) - static_cast<int>(e[5])) * 256 + threadIdx.x;
+  if (idx >= Kpad * C) return;
+  if (e[4]) wino_weight_one<true>(w, U, K, C, Kpad, idx);
+  else wino_weight_one<false>(w, U, K, C, Kpad, idx);
 }
 
 // y[b][k][i] = sum over the channel splits of part[sp][b][k][i], in split order
@@ -576,9 +594,11 @@ static WinoSplit wino_split(long ntiles, int Kpad, int Ci, int B, int Co, int Ho
   return w;
 }
 
-static int wino_run(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, long wbuf_floats, int B, int Ci, int Co,
-                    int H, int W, int P, int dil, int transposed_weight, void* stream) {
-  if (!x || !weight || !y || !wbuf) return DFE_ERR_NULL;
+// weight == nullptr: wbuf already holds the transformed filters (dfe_wino_conv3x3_u) and is only read; part / part_floats: room
+// for the channel splits' partial outputs (may be null / 0)
+static int wino_run(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, float* part, long part_floats, int B,
+                    int Ci, int Co, int H, int W, int P, int dil, int transposed_weight, void* stream) {
+  if (!x || !y || !wbuf) return DFE_ERR_NULL;
   const int rc = wn_dims(B, Ci, Co, H, W, P);
   if (rc != DFE_OK) return rc;
   if (dil < 1 || (dil > 1 && (P != 1 || H % dil != 0 || W % dil != 0 || H / dil < 2 || W / dil < 2))) return DFE_ERR_UNSUPPORTED;
@@ -586,23 +606,23 @@ static int wino_run(const float* x, const float* weight, float* y, long y_batch_
   const int Ho = dil > 1 ? H : H + 2 * P - 2, Wo = dil > 1 ? W : W + 2 * P - 2;
   if (y_batch_stride < static_cast<long>(Co) * Ho * Wo) return DFE_ERR_DIMS;
   if ((reinterpret_cast<uintptr_t>(wbuf) & 15) != 0) return DFE_ERR_UNSUPPORTED;
-  if (wbuf_floats < dfe_wino_weight_floats(Ci, Co)) return DFE_ERR_WORKSPACE;
+  if (part && (reinterpret_cast<uintptr_t>(part) & 15) != 0) return DFE_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int Kpad = (Co + 31) / 32 * 32;
   const int nw = Kpad * Ci;
-  if (transposed_weight) k_wino_weights<true><<<(nw + 255) / 256, 256, 0, st>>>(weight, wbuf, Co, Ci, Kpad);
-  else k_wino_weights<false><<<(nw + 255) / 256, 256, 0, st>>>(weight, wbuf, Co, Ci, Kpad);
-  DFE_LAUNCH_CHECK();
+  if (weight) {
+    if (transposed_weight) k_wino_weights<true><<<(nw + 255) / 256, 256, 0, st>>>(weight, wbuf, Co, Ci, Kpad);
+    else k_wino_weights<false><<<(nw + 255) / 256, 256, 0, st>>>(weight, wbuf, Co, Ci, Kpad);
+    DFE_LAUNCH_CHECK();
+  }
   const int TH = (Ho / dil + 1) / 2, TW = (Wo / dil + 1) / 2;
   const long ntiles = static_cast<long>(B) * TH * TW * dil * dil;
   if (ntiles >= (1L << 31)) return DFE_ERR_DIMS;
   const size_t lds_bytes = sizeof(float) * WN_CC * 32 * WN_XP;
   {
     const unsigned nkt = Kpad / 32;
-    const long ufl = static_cast<long>(Kpad) * Ci * 16;
     WinoSplit sp = wino_split(ntiles, Kpad, Ci, B, Co, Ho, Wo);
-    if (dil > 1 || wbuf_floats < ufl + sp.part_floats) sp = WinoSplit{1, Ci, 0};      // no room for the partial outputs: one block per tile range
-    float* part = wbuf + ufl;
+    if (dil > 1 || !part || part_floats < sp.part_floats) sp = WinoSplit{1, Ci, 0};      // no room for the partial outputs: one block per tile range
     // (one-wave blocks of 16 tiles for the planes that cannot fill the chip with 64-tile blocks were measured and lose: every
     // wave then stages the weight slabs for itself -- 12 x 256 -> 256 @ 16x52: 222 us against 112)
     const int tpb = 64;
@@ -641,12 +661,35 @@ extern "C" long dfe_wino_scratch_floats(int B, int Ci, int Co, int H, int W, int
 
 extern "C" int dfe_wino_conv3x3(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, long wbuf_floats, int B,
                                 int Ci, int Co, int H, int W, int P, int transposed_weight, void* stream) {
-  return wino_run(x, weight, y, y_batch_stride, wbuf, wbuf_floats, B, Ci, Co, H, W, P, 1, transposed_weight, stream);
+  if (!weight) return DFE_ERR_NULL;
+  const long ufl = dfe_wino_weight_floats(Ci, Co);
+  if (wbuf_floats < ufl) return DFE_ERR_WORKSPACE;
+  return wino_run(x, weight, y, y_batch_stride, wbuf, wbuf ? wbuf + ufl : nullptr, wbuf_floats - ufl, B, Ci, Co, H, W, P, 1, transposed_weight, stream);
 }
 
 extern "C" int dfe_wino_conv3x3_dilated(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, int B,
                                         int Ci, int Co, int H, int W, int dilation, int transposed_weight, void* stream) {
-  return wino_run(x, weight, y, y_batch_stride, wbuf, dfe_wino_weight_floats(Ci, Co), B, Ci, Co, H, W, 1, dilation, transposed_weight, stream);
+  if (!weight) return DFE_ERR_NULL;
+  return wino_run(x, weight, y, y_batch_stride, wbuf, nullptr, 0, B, Ci, Co, H, W, 1, dilation, transposed_weight, stream);
+}
+
+extern "C" int dfe_wino_conv3x3_u(const float* x, const float* U, float* y, long y_batch_stride, float* part, long part_floats, int B, int Ci,
+                                  int Co, int H, int W, int P, int dilation, void* stream) {
+  return wino_run(x, nullptr, y, y_batch_stride, const_cast<float*>(U), part, part_floats, B, Ci, Co, H, W, dilation > 1 ? 1 : P, dilation, 0,
+                  stream);
+}
+
+extern "C" long dfe_wino_transform_blocks(int Ci, int Co) {
+  if (Ci <= 0 || Co <= 0) return 0;
+  return (static_cast<long>((Co + 31) / 32 * 32) * Ci + 255) / 256;
+}
+
+extern "C" int dfe_wino_transform_weights_multi(const long* table, const int* blockmap, int n_blocks, void* stream) {
+  if (!table || !blockmap) return DFE_ERR_NULL;
+  if (n_blocks <= 0) return DFE_ERR_DIMS;
+  k_wino_weights_multi<<<n_blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(table, blockmap);
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
 }
 
 // ---- weight gradient

@@ -95,6 +95,9 @@ class FlatAllReduce(torch.nn.Module):
         tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
         if tensors and self.world > 1:
             dist._broadcast_coalesced(dist.group.WORLD, tensors, 250 * 1024 * 1024, 0)
+            if tensors[0].is_cuda:
+                from . import ops
+                ops.wino_weights.invalidate()       # written through .data: no version bump for the cached filters to miss on
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)

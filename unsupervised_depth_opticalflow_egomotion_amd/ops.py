@@ -643,23 +643,129 @@ def planeconv_backward(gy, x, w, want_x=True, want_w=True):
 
 
 # --------------------------------------------------------------------------- Winograd F(2x2, 3x3) on the fp32 matrix cores
+class WinoWeightCache:
+    """Transformed filters (U = G g G^T, both orientations) of the parameters the Winograd kernel has been called with, kept
+    across steps.  A training step uses every filter twice (forward, data gradient) and each call used to launch its own
+    transform (96 launches of ~5.6 us per step of the joint model); the filters only change in the optimiser step, so
+    ``optim.FusedAdam.step`` calls ``refresh()``: ONE launch (dfe_wino_transform_weights_multi) on the optimiser's stream,
+    right behind the update -- whatever orders the next step's network streams behind the update orders them behind this.
+
+    Validity: an entry is used only while the parameter object it was made for is alive, still owns the same storage and its
+    autograd version counter equals the one recorded at the refresh -- ``load_state_dict``, ``copy_`` or any other in-place
+    torch operation makes the entry miss, and the call transforms for itself (into its own scratch, on its own stream) as
+    before.  FusedAdam writes parameters through raw pointers (no version bump), which is why it is the one that refreshes.
+    Only ``refresh`` writes the cached buffers.  ``DFE_WINO_CACHE=0`` turns the cache off."""
+
+    def __init__(self):
+        self.enabled = os.environ.get("DFE_WINO_CACHE", "1") != "0"
+        self.entries = {}        # (data_ptr, Co, Ci of the weight tensor) -> entry
+        self.table = None        # device tables of the last refresh (rebuilt when the membership changes)
+        self.blockmap = None
+        self.members = None
+        self.hits = self.misses = 0
+        if os.environ.get("DFE_WINO_CACHE_STATS"):
+            import atexit
+            import sys
+            atexit.register(lambda: sys.stderr.write("[dfe] wino weight cache: %d filters, %d hits, %d misses\n"
+                                                     % (len(self.entries), self.hits, self.misses)))
+
+    def lookup(self, w, transposed):
+        """The cached U for this call or None (transform per call).  Registers the parameter on first sight."""
+        if not self.enabled or not w.is_cuda or w.dim() != 4:
+            return None
+        key = (w.data_ptr(), int(w.shape[0]), int(w.shape[1]))
+        e = self.entries.get(key)
+        if e is None:
+            # only leaf parameters are worth keeping (a temporary's address is reused by unrelated tensors)
+            if isinstance(w, torch.nn.Parameter):
+                import weakref
+                self.entries[key] = {"ref": weakref.ref(w), "version": -1, "U": None, "device": w.device}
+            self.misses += 1
+            return None
+        p = e["ref"]()
+        if p is None or p.data_ptr() != key[0]:
+            del self.entries[key]
+            self.misses += 1
+            return None
+        if e["U"] is None or e["version"] != w._version or e["version"] != p._version:
+            self.misses += 1
+            return None
+        self.hits += 1
+        return e["U"][1 if transposed else 0]
+
+    def invalidate(self):
+        for e in self.entries.values():
+            e["version"] = -1
+
+    def refresh(self):
+        """Transform every registered filter (forward and data-gradient orientation) in one launch on the current stream."""
+        if not self.enabled:
+            return
+        lib = get_lib()
+        live = []
+        for key, e in list(self.entries.items()):
+            p = e["ref"]()
+            if p is None or p.data_ptr() != key[0] or not p.is_contiguous() or p.dtype != torch.float32:
+                del self.entries[key]
+                continue
+            live.append((key, e, p))
+        if not live:
+            return
+        dev = live[0][2].device
+        live = [t for t in live if t[2].device == dev]
+        members = tuple(k for k, _, _ in live)
+        if members != self.members:
+            rows, bmap, nb = [], [], 0
+            for key, e, p in live:
+                Co, Ci = key[1], key[2]
+                if e["U"] is None:
+                    e["U"] = (torch.empty(lib.dfe_wino_weight_floats(Ci, Co), device=dev, dtype=torch.float32),
+                              torch.empty(lib.dfe_wino_weight_floats(Co, Ci), device=dev, dtype=torch.float32))
+                # forward: conv Ci -> Co, U[Kpad(Co)][Ci]; data gradient: conv Co -> Ci on the transposed, flipped filter
+                for tr, (K, C) in enumerate(((Co, Ci), (Ci, Co))):
+                    n = int(lib.dfe_wino_transform_blocks(C, K))
+                    rows.append([key[0], e["U"][tr].data_ptr(), K, C, tr, nb])
+                    bmap.extend([len(rows) - 1] * n)
+                    nb += n
+            self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            self.blockmap = torch.tensor(bmap, dtype=torch.int32).to(dev)
+            self.members = members
+        check(lib.dfe_wino_transform_weights_multi(ptr(self.table), ptr(self.blockmap), int(self.blockmap.numel()), stream_ptr()),
+              "dfe_wino_transform_weights_multi")
+        for _, e, p in live:
+            e["version"] = p._version
+
+
+wino_weights = WinoWeightCache()
+
+
 def wino_conv3x3(x, w, padding=1, transposed=False, dilation=1):
     """3x3 stride-1 convolution of x [B,Ci,H,W] (no bias) on dfe_wino_conv3x3.  ``transposed``: w is the forward filter
     [Ci,Co,3,3] of a convolution whose output gradient is x; the result is its data gradient.  ``dilation`` > 1: a dilated
-    convolution with padding = dilation (``padding`` is ignored)."""
+    convolution with padding = dilation (``padding`` is ignored).  Parameters' transformed filters come from
+    ``wino_weights`` when it holds them (dfe_wino_conv3x3_u)."""
+    U = wino_weights.lookup(w, transposed)
     x, w = f32c(x), f32c(w)
     B, Ci, H, W = x.shape
     Co = int(w.shape[1] if transposed else w.shape[0])
     P, d = int(padding), int(dilation)
     lib = get_lib()
+    if d > 1:
+        y = torch.empty(B, Co, H, W, device=x.device, dtype=torch.float32)
+    else:
+        y = torch.empty(B, Co, H + 2 * P - 2, W + 2 * P - 2, device=x.device, dtype=torch.float32)
+    if U is not None:
+        npart = 0 if d > 1 else lib.dfe_wino_scratch_floats(B, Ci, Co, H, W, P) - lib.dfe_wino_weight_floats(Ci, Co)
+        part = torch.empty(npart, device=x.device, dtype=torch.float32) if npart > 0 else None
+        check(lib.dfe_wino_conv3x3_u(ptr(x), ptr(U), ptr(y), y.stride(0), ptr(part), npart, B, Ci, Co, H, W, P, d, stream_ptr()),
+              "dfe_wino_conv3x3_u")
+        return y
     nws = lib.dfe_wino_weight_floats(Ci, Co) if d > 1 else lib.dfe_wino_scratch_floats(B, Ci, Co, H, W, P)
     wbuf = torch.empty(nws, device=x.device, dtype=torch.float32)
     if d > 1:
-        y = torch.empty(B, Co, H, W, device=x.device, dtype=torch.float32)
         check(lib.dfe_wino_conv3x3_dilated(ptr(x), ptr(w), ptr(y), y.stride(0), ptr(wbuf), B, Ci, Co, H, W, d, int(bool(transposed)),
                                            stream_ptr()), "dfe_wino_conv3x3_dilated")
         return y
-    y = torch.empty(B, Co, H + 2 * P - 2, W + 2 * P - 2, device=x.device, dtype=torch.float32)
     check(lib.dfe_wino_conv3x3(ptr(x), ptr(w), ptr(y), y.stride(0), ptr(wbuf), nws, B, Ci, Co, H, W, P, int(bool(transposed)),
                                stream_ptr()), "dfe_wino_conv3x3")
     return y

@@ -142,4 +142,8 @@ class FusedAdam(torch.optim.Optimizer):
                     new = torch.tensor(t, dtype=torch.float32)
                     for p in ps:
                         self.state[p]["step"] = new
+        # the parameters changed behind autograd's back (raw pointers, no version bump): the Winograd kernel's cached
+        # transformed filters are rebuilt here, in one launch on this stream, right behind the update
+        from . import ops
+        ops.wino_weights.refresh()
         return loss
