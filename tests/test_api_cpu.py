@@ -687,3 +687,19 @@ def test_winograd_dispatch_rule_is_shape_logic_only(monkeypatch):
     assert not el(FakeCuda(64, 512, 128, 416), (64, 512, 3, 3), 512, (1, 1), (1, 1), (1, 1))          # > 2^30 elements: 32-bit offsets
     monkeypatch.setattr(convs, "WINO_MIN_TILES", 0)
     assert not el(x, (128, 128, 3, 3), 128, (1, 1), (1, 1), (1, 1))                                   # switched off
+
+
+def test_wino_weight_cache_host_logic_without_a_gpu():
+    """ops.WinoWeightCache never holds host tensors (there is no CPU path to cache for) and refresh() with nothing registered
+    is a no-op that does not touch the device; DFE_WINO_CACHE=0 turns lookups off."""
+    import torch
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+
+    cache = ops.WinoWeightCache()
+    w = torch.nn.Parameter(torch.randn(8, 8, 3, 3))
+    assert cache.lookup(w, False) is None and cache.lookup(w, True) is None and not cache.entries
+    cache.refresh()
+    cache.invalidate()
+    assert cache.table is None and cache.hits == 0
+    cache.enabled = False
+    assert cache.lookup(w, False) is None and cache.misses == 0

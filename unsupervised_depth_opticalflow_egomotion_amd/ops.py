@@ -699,7 +699,7 @@ class WinoWeightCache:
 
     def refresh(self):
         """Transform every registered filter (forward and data-gradient orientation) in one launch on the current stream."""
-        if not self.enabled:
+        if not self.enabled or not self.entries:
             return
         lib = get_lib()
         live = []
