@@ -9,6 +9,7 @@ Workloads (BASELINE.json configs; synthetic KITTI-shaped inputs, seed 1234 + ran
 Unit: frame pair = one (target, source) direction of one triplet; a batch of B triplets is 2B pairs.
 """
 import argparse
+import ctypes
 import glob
 import hashlib
 import json
@@ -475,6 +476,12 @@ def main():
         out["kernel_ms"] = segs
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args, 2 * args.batch)
+        # keep the JSON line the LAST line of stdout: RCCL prints a "Librccl path" banner through C stdio when the communicator
+        # is made, which a pipe buffers until exit -- flush it out before the line
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_ddp:
         import torch.distributed as dist
