@@ -470,6 +470,16 @@ def main():
     }
     if evidence is not None:
         out["multi_gpu"] = evidence
+    if world > 1:
+        # every rank empties its C stdio (RCCL's banners) before rank 0 prints: the JSON line stays the last line of the
+        # launcher's merged stdout
+        import torch.distributed as dist
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        dist.barrier()
     if rank == 0:
         roof, segs = point_fwd_roofline(args, args.mode if wl.name == "train_step" else "geom", fwd_ms, bwd_ms)
         out["roofline"] = roof
