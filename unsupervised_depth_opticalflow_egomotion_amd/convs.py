@@ -141,17 +141,39 @@ def _wino_eligible(x, w_shape, cin, stride, padding, dilation, groups=1):
     return (B * ((Ho + 1) // 2) * ((Wo + 1) // 2) >= WINO_MIN_TILES and C >= WINO_MIN_CHANNELS and x.numel() < (1 << 30))
 
 
-# Weight gradient in the Winograd domain (dfe_wino_wgrad3x3), OPT-IN (DFE_WINO_WGRAD_MIN_CHANNELS=96 routes the layers with at
-# least that many input and output channels there; 0 = never, the default): correct and reproducible, 1.05-1.2x MIOpen's
-# implicit GEMM + transposes on the wide layers in isolation (tools/wino_bench.py) but 0.15 ms SLOWER per step when it runs
-# beside the other stream's kernels (21.69 against 21.54 ms): its LDS-staged transposes and MIOpen's are both hidden, its
-# MFMA time is not shorter yet.
-WINO_WGRAD_MIN_CHANNELS = int(os.environ.get("DFE_WINO_WGRAD_MIN_CHANNELS", "0"))
+# Weight gradient in the Winograd domain (dfe_wino_wgrad3x3, csrc/ops_wino_wgrad.hip; round 5): raw NCHW rows staged in LDS, every
+# wave transforms the tiles of its (channel, tile) lanes in registers and feeds the fp32 matrix cores -- no layout transposes, no
+# zero fill, no atomics (MIOpen: NHWC implicit GEMM + three batched transposes + a fill per call, split-K float atomics).
+# 1.2-2.9x MIOpen on every 3x3 stride-1 layer of the step with >= 32 channels on both sides (tools/wgrad_bench.py,
+# profiles/r05_wgrad_bench.md); dilated layers (element-wise strided staging) only tie and stay on MIOpen.  DFE_WINO_WGRAD=0: MIOpen's weight gradients everywhere.
+WINO_WGRAD = os.environ.get("DFE_WINO_WGRAD", "1") != "0"
+WINO_WGRAD_MIN_MACS = float(os.environ.get("DFE_WINO_WGRAD_MIN_GMAC", "0.8")) * 1e9      # direct multiply-adds of the layer
+WINO_WGRAD_DILATED = os.environ.get("DFE_WINO_WGRAD_DILATED", "0") == "1"
 
 
-def _wino_wgrad_eligible(x, gy, w_shape, padding, d):
-    return (WINO_WGRAD_MIN_CHANNELS > 0 and d == 1 and padding in ((0, 0), (1, 1)) and w_shape[0] >= WINO_WGRAD_MIN_CHANNELS
-            and w_shape[1] >= WINO_WGRAD_MIN_CHANNELS and x.shape[3] % 2 == 0 and gy.shape[3] % 2 == 0 and gy.is_contiguous())
+def _wino_wgrad_eligible(x, gy_shape, w_shape, padding, d):
+    """x [B,Ci,H,W] (fp32, HIP), the output gradient's shape, the filter's shape, padding pair, dilation."""
+    if not WINO_WGRAD or _STATE["dtype"] is not None or x.dtype != torch.float32 or not x.is_cuda or x.dim() != 4:
+        return False
+    if d > 1 and not (WINO_WGRAD_DILATED and padding == (d, d) and x.shape[2] % d == 0 and x.shape[3] % d == 0):
+        return False
+    if d == 1 and padding not in ((0, 0), (1, 1)):
+        return False
+    Co, Ci = int(w_shape[0]), int(w_shape[1])
+    if tuple(w_shape[2:]) != (3, 3) or Ci != x.shape[1] or min(Co, Ci) < 32:
+        return False
+    n_out = gy_shape[0] * Co * gy_shape[2] * gy_shape[3]
+    return float(n_out) * Ci * 9 >= WINO_WGRAD_MIN_MACS and x.numel() < (1 << 30) and n_out < (1 << 30)
+
+
+def _wgrad_route(x, w_shape, stride, padding, dilation, groups):
+    """A layer whose forward pass stays on MIOpen but whose weight gradient takes dfe_wino_wgrad3x3 (few tiles, many channels)."""
+    if groups != 1 or stride != (1, 1) or dilation[0] != dilation[1] or x.dim() != 4:
+        return False
+    d = dilation[0]
+    ho = x.shape[2] if d > 1 else x.shape[2] + 2 * padding[0] - 2
+    wo = x.shape[3] if d > 1 else x.shape[3] + 2 * padding[1] - 2
+    return ho >= 1 and wo >= 1 and _wino_wgrad_eligible(x, (x.shape[0], w_shape[0], ho, wo), w_shape, padding, d)
 
 
 def raw_forward(x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1)):
@@ -176,18 +198,25 @@ def raw_backward(gy, x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1), want_
                          [want_x, want_w, want_b])
         return _high(gx), _high(gw), (gb.float() if gb is not None else None)
     d = dilation[0]
+    own_w = want_w and stride == (1, 1) and tuple(w.shape[2:]) == (3, 3) and dilation == (d, d) and \
+        _wino_wgrad_eligible(x, gy.shape, w.shape, padding, d)
+    gx = gw = gb = None
     if want_x and (padding in ((1, 1), (0, 0)) or (d > 1 and padding == (d, d))) and \
             _wino_eligible(gy, w.shape, w.shape[0], stride, (d, d) if d > 1 else (1, 1), dilation):
         from . import ops
         # the data gradient = the same kernel on the transposed filter (full correlation, padding 2, for a valid convolution)
         gx = ops.wino_conv3x3(gy, w, 1 if padding != (0, 0) else 2, transposed=True, dilation=d)
-        if not (want_w or want_b):
-            return gx, None, None
-        if want_w and not want_b and _wino_wgrad_eligible(x, gy, w.shape, padding, d):
-            return gx, ops.wino_wgrad3x3(x, gy, padding[0]), None
-        _, gw, gb = _cb(gy, x, w, bias_sizes, list(stride), list(padding), list(dilation), False, [0, 0], 1, [False, want_w, want_b])
-        return gx, gw, gb
-    return _cb(gy, x, w, bias_sizes, list(stride), list(padding), list(dilation), False, [0, 0], 1, [want_x, want_w, want_b])
+        want_x = False
+    if own_w:
+        from . import ops
+        gw = ops.wino_wgrad3x3(x, gy, padding[0] if d == 1 else 1, d)
+        want_w = False
+    if want_x or want_w or want_b:
+        r = _cb(gy, x, w, bias_sizes, list(stride), list(padding), list(dilation), False, [0, 0], 1, [want_x, want_w, want_b])
+        gx = r[0] if want_x else gx
+        gw = r[1] if want_w else gw
+        gb = r[2] if want_b else gb
+    return gx, gw, gb
 
 
 class _ConvFn(torch.autograd.Function):
@@ -265,7 +294,8 @@ def conv2d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1):
     if dilation[0] > 1 and _phase_eligible(x, w, stride, padding, dilation, groups):
         y = _phase_conv(x, w, dilation[0])
         return y if bias is None else y + bias.view(1, -1, 1, 1)
-    if groups == 1 and _wino_eligible(x, w.shape, w.shape[1], stride, padding, dilation):
+    if groups == 1 and (_wino_eligible(x, w.shape, w.shape[1], stride, padding, dilation) or
+                        _wgrad_route(x, w.shape, stride, padding, dilation, groups)):
         y = _RawConvFn.apply(x, w, stride, padding, dilation)
         return y if bias is None else y + bias.view(1, -1, 1, 1)
     if not (x.is_cuda and groups == 1 and _STATE["dtype"] is not None):

@@ -12,7 +12,7 @@
 // for its tile, the 16 positions of 8 output channels: the output transform is register arithmetic and the 2x2 outputs leave
 // as stores that are contiguous across the wave.  The data gradient is the same kernel on the transposed, tap-reversed
 // filter; dilated layers run on the phase images; planes too small to fill the chip split their input channels over blocks
-// (fixed-order partial outputs).  k_wino_wgrad is the weight gradient in the same domain (opt-in).
+// (fixed-order partial outputs).  The weight gradient in the same domain: ops_wino_wgrad.hip.
 // Same numerics class as the MIOpen kernels it replaces (fp32 Winograd F(2,3)); sums in a fixed order: reproducible.
 // Bound: MFMA (2.25 x 157 TFLOP/s effective at 100 % of the fp32 matrix pipe; measured 51 %).
 #include "dfe_internal.h"
@@ -351,213 +351,6 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
     }
 }
 
-// ---------------------------------------------------------------------- weight gradient in the Winograd domain
-//     dg[k][c] = G^T [ sum_tiles (A dY A^T)[k][tile] (.) (B^T d B)[c][tile] ] G
-// 16 GEMMs dU[xi] (k x c) = dM[xi] (k x tiles) * V[xi]^T (tiles x c) whose reduction runs over the TILES: the MFMA's K index is
-// the lane group, so a wave needs (channel, tile) fragments with the channels along its lanes -- the transpose of how the
-// image is read.  A block (64 output x 32 input channels, a range of tiles) therefore works in chunks of 8 tiles: all 256
-// threads load (lanes along the tiles: coalesced pair loads, neighbours by DPP as in the forward kernel) and transform the
-// chunk's 64 x 8 output-gradient tiles and 32 x 8 input patches into LDS ([tile][channel][16 positions], 20-float pitch),
-// then the four waves (2 output-channel halves x 2 input-channel halves) read their fragments as 16-byte LDS loads and
-// run 2 x 32 MFMAs each.  No layout transposes of the operands, no zero fill, no atomics: every block writes its partial
-// dU and k_wino_wgrad_final adds the partials in split order and applies G^T . G.
-constexpr int WG_TT = 8, WG_KB = 64, WG_CB = 32;
-constexpr int WG_MP = WG_KB * WN_XP + 4, WG_VP = WG_CB * WN_XP + 4;      // floats per tile: + 4 keeps the writers' banks apart
-
-template <int PP>      // the forward convolution's padding (0 or 1); W and Wo even, x and gy 8-byte aligned
-__global__ void __launch_bounds__(256, 2) k_wino_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part,
-                                                       long gbs, int C, int K, int H, int W, int TH, int TW, int ntiles, int tps, int Kp,
-                                                       int Cp) {
-  extern __shared__ float lds[];
-  float* Ms = lds;                       // [WG_TT][WG_KB][WN_XP] (+4 per tile)
-  float* Vs = lds + WG_TT * WG_MP;       // [WG_TT][WG_CB][WN_XP] (+4 per tile)
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int split = blockIdx.x, cb0 = blockIdx.y * WG_CB, kb0 = blockIdx.z * WG_KB;
-  const int Ho = H + 2 * PP - 2, Wo = W + 2 * PP - 2, HW = H * W, HWo = Ho * Wo;
-  const int t0 = split * tps, tend = min(ntiles, t0 + tps);
-  // producer role: tile t of the chunk, channel group g
-  const int t = tid & 7, g = tid >> 3;
-  // consumer role
-  const int i = lane & 15, kq = lane >> 4, csub = wv & 1, kp = wv >> 1;
-  constexpr bool USE_L = PP == 1, USE_R = true;
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  auto shr1 = [](float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true)); };
-  auto shl1 = [](float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xF, 0xF, true)); };
-  f32x4 acc[2][16];
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int s = 0; s < 16; ++s) acc[h][s] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  const char* xc = reinterpret_cast<const char*>(x);
-  const char* gc = reinterpret_cast<const char*>(gy);
-  // The chunk's loads are issued one chunk ahead (registers), so that they are in flight under the previous chunk's MFMAs;
-  // the transforms and the LDS writes follow the barrier that ends those MFMAs.
-  f32x2 gr[2][2], xo[4], xe[4];
-  unsigned fl = 0;      // bits 0-1: dM item j has data; 2-5: patch row inside; 6 okL, 7 okR, 8 edge_l, 9 edge_r
-  auto load_chunk = [&](int tc) {
-    const int tile = tc + t;
-    const bool tv = tile < tend;
-    const int tl = min(tile, ntiles - 1);
-    const int b = tl / (TH * TW), tr = tl - b * TH * TW, ty = tr / TW, tx = tr - ty * TW;
-    fl = 0;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int k = kb0 + g + 32 * j;
-      const bool okk = tv && k < K && 2 * tx < Wo;
-      const long base = (b * gbs + static_cast<long>(okk ? k : 0) * HWo + (2 * ty) * Wo + 2 * tx) * 4;
-      const bool r0ok = okk && 2 * ty < Ho, r1ok = okk && 2 * ty + 1 < Ho;
-      gr[j][0] = *reinterpret_cast<const f32x2*>(r0ok ? gc + base : gc);
-      gr[j][1] = *reinterpret_cast<const f32x2*>(r1ok ? gc + base + 4L * Wo : gc);
-      if (!r0ok) gr[j][0] = f32x2{0.0f, 0.0f};
-      if (!r1ok) gr[j][1] = f32x2{0.0f, 0.0f};
-    }
-    const int c = cb0 + g;
-    const bool okc = tv && c < C;
-    const bool okL = tx >= 1, okR = 2 * tx + 3 < W, okO = 2 * tx + 1 < W;
-    const bool edge_l = USE_L && okL && t == 0;
-    const bool edge_r = USE_R && okR && (t == 7 || tx == TW - 1 || tile + 1 >= tend);
-    fl |= (okL ? 64u : 0u) | (okR ? 128u : 0u) | (edge_l ? 256u : 0u) | (edge_r ? 512u : 0u);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int yy = 2 * ty - PP + r;
-      const bool rok = okc && yy >= 0 && yy < H;
-      const long rowb = ((static_cast<long>(b) * C + (okc ? c : 0)) * HW + (rok ? yy : 0) * static_cast<long>(W)) * 4;
-      const bool lo = rok && okO, le = rok && (edge_l || edge_r);
-      xo[r] = *reinterpret_cast<const f32x2*>(lo ? xc + rowb + 8L * tx : xc);
-      xe[r] = *reinterpret_cast<const f32x2*>(le ? xc + rowb + 8L * (edge_l ? tx - 1 : tx + 1) : xc);
-      if (!lo) xo[r] = f32x2{0.0f, 0.0f};
-      if (!le) xe[r] = f32x2{0.0f, 0.0f};
-      fl |= rok ? (4u << r) : 0u;
-    }
-  };
-  auto store_chunk = [&]() {
-    // output-gradient tiles of output channels kb0 + g and kb0 + g + 32: dM = A dY A^T
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const f32x2 r0 = gr[j][0], r1 = gr[j][1];
-      float m[16];
-      const float a0[4] = {r0[0], r0[0] + r1[0], r0[0] - r1[0], -r1[0]};
-      const float a1[4] = {r0[1], r0[1] + r1[1], r0[1] - r1[1], -r1[1]};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { m[4 * q] = a0[q]; m[4 * q + 1] = a0[q] + a1[q]; m[4 * q + 2] = a0[q] - a1[q]; m[4 * q + 3] = -a1[q]; }
-      float* dst = Ms + t * WG_MP + (g + 32 * j) * WN_XP;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]};
-    }
-    // input patch of input channel cb0 + g: V = B^T d B (own pairs + DPP neighbours; the edge lanes' own loads)
-    const bool okL = fl & 64u, okR = fl & 128u, edge_l = fl & 256u, edge_r = fl & 512u;
-    float d[16];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool rok = fl & (4u << r);
-      const f32x2 o = xo[r], e = xe[r];
-      float l2 = 0.0f, r1 = 0.0f, r2 = 0.0f;
-      if (USE_L) { l2 = shr1(o[1]); l2 = okL ? (edge_l ? e[1] : l2) : 0.0f; }
-      r1 = shl1(o[0]); r1 = okR ? (edge_r ? e[0] : r1) : 0.0f;
-      if (PP == 0) { r2 = shl1(o[1]); r2 = okR ? (edge_r ? e[1] : r2) : 0.0f; }
-      if (!rok) { l2 = 0.0f; r1 = 0.0f; r2 = 0.0f; }
-      if (PP == 1) { d[4 * r] = l2; d[4 * r + 1] = o[0]; d[4 * r + 2] = o[1]; d[4 * r + 3] = r1; }
-      else { d[4 * r] = o[0]; d[4 * r + 1] = o[1]; d[4 * r + 2] = r1; d[4 * r + 3] = r2; }
-    }
-    float tt[16], v[16];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      tt[j] = d[j] - d[8 + j];
-      tt[4 + j] = d[4 + j] + d[8 + j];
-      tt[8 + j] = d[8 + j] - d[4 + j];
-      tt[12 + j] = d[4 + j] - d[12 + j];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      v[q * 4 + 0] = tt[q * 4] - tt[q * 4 + 2];
-      v[q * 4 + 1] = tt[q * 4 + 1] + tt[q * 4 + 2];
-      v[q * 4 + 2] = tt[q * 4 + 2] - tt[q * 4 + 1];
-      v[q * 4 + 3] = tt[q * 4 + 1] - tt[q * 4 + 3];
-    }
-    float* dst = Vs + t * WG_VP + g * WN_XP;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-  };
-  if (t0 < tend) { load_chunk(t0); store_chunk(); }
-  __syncthreads();
-  for (int tc = t0; tc < tend; tc += WG_TT) {
-    const bool more = tc + WG_TT < tend;
-    if (more) load_chunk(tc + WG_TT);
-    // ---- consume: 2 steps of 4 tiles
-#pragma unroll
-    for (int ts = 0; ts < 2; ++ts) {
-      const int tt = 4 * ts + kq;
-      float bv[16];
-      const float* vp = Vs + tt * WG_VP + (16 * csub + i) * WN_XP;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 w4 = *reinterpret_cast<const f32x4*>(vp + 4 * q);
-        bv[4 * q] = w4[0]; bv[4 * q + 1] = w4[1]; bv[4 * q + 2] = w4[2]; bv[4 * q + 3] = w4[3];
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float av[16];
-        const float* mp = Ms + tt * WG_MP + (32 * kp + 16 * h + i) * WN_XP;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 w4 = *reinterpret_cast<const f32x4*>(mp + 4 * q);
-          av[4 * q] = w4[0]; av[4 * q + 1] = w4[1]; av[4 * q + 2] = w4[2]; av[4 * q + 3] = w4[3];
-        }
-#pragma unroll
-        for (int s = 0; s < 16; ++s) acc[h][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc[h][s], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-    if (more) { store_chunk(); __syncthreads(); }
-  }
-  // D[m][n]: rows m = 4 kq + r -> output channel, column n = i -> input channel; partial dU laid out [split][k][c][16]
-  float* po = part + static_cast<long>(split) * Kp * Cp * 16;
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int k = kb0 + 32 * kp + 16 * h + 4 * kq + r, c = cb0 + 16 * csub + i;
-      float* o = po + (static_cast<long>(k) * Cp + c) * 16;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<f32x4*>(o + 4 * q) = f32x4{acc[h][4 * q][r], acc[h][4 * q + 1][r], acc[h][4 * q + 2][r], acc[h][4 * q + 3][r]};
-    }
-}
-
-// gw[k][c][3][3] = G^T (sum over the splits of dU[k][c]) G
-__global__ void __launch_bounds__(256) k_wino_wgrad_final(const float* __restrict__ part, float* __restrict__ gw, int S, int K, int C,
-                                                          int Kp, int Cp) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= K * C) return;
-  const int c = idx % C, k = idx / C;
-  f32x4 u[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) u[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  const float* p = part + (static_cast<long>(k) * Cp + c) * 16;
-  for (int s = 0; s < S; ++s) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(p + static_cast<long>(s) * Kp * Cp * 16 + 4 * q);
-      u[q][0] += v[0]; u[q][1] += v[1]; u[q][2] += v[2]; u[q][3] += v[3];
-    }
-  }
-  // rows: G^T dU
-  float tm[3][4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    tm[0][s] = u[0][s] + 0.5f * (u[1][s] + u[2][s]);
-    tm[1][s] = 0.5f * (u[1][s] - u[2][s]);
-    tm[2][s] = 0.5f * (u[1][s] + u[2][s]) + u[3][s];
-  }
-  float* o = gw + static_cast<long>(idx) * 9;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    o[a * 3 + 0] = tm[a][0] + 0.5f * (tm[a][1] + tm[a][2]);
-    o[a * 3 + 1] = 0.5f * (tm[a][1] - tm[a][2]);
-    o[a * 3 + 2] = 0.5f * (tm[a][1] + tm[a][2]) + tm[a][3];
-  }
-}
-
 }  // namespace dfe
 
 #define DFE_LAUNCH_CHECK() do { if (hipGetLastError() != hipSuccess) return DFE_ERR_LAUNCH; } while (0)
@@ -688,55 +481,6 @@ extern "C" int dfe_wino_transform_weights_multi(const long* table, const int* bl
   if (!table || !blockmap) return DFE_ERR_NULL;
   if (n_blocks <= 0) return DFE_ERR_DIMS;
   k_wino_weights_multi<<<n_blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(table, blockmap);
-  DFE_LAUNCH_CHECK();
-  return DFE_OK;
-}
-
-// ---- weight gradient
-static int wg_splits(long ntiles, int Kp, int Cp) {
-  const long pairs = static_cast<long>(Kp / WG_KB) * (Cp / WG_CB);
-  long S = (768 + pairs - 1) / pairs;
-  const long maxS = (ntiles + WG_TT - 1) / WG_TT;
-  if (S > maxS) S = maxS;
-  if (S < 1) S = 1;
-  return static_cast<int>(S);
-}
-
-extern "C" long dfe_wino_wgrad_floats(int B, int Ci, int Co, int H, int W, int P) {
-  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || P < 0 || P > 1) return 0;
-  const int Ho = H + 2 * P - 2, Wo = W + 2 * P - 2;
-  if (Ho < 1 || Wo < 1) return 0;
-  const int Kp = (Co + WG_KB - 1) / WG_KB * WG_KB, Cp = (Ci + WG_CB - 1) / WG_CB * WG_CB;
-  const long ntiles = static_cast<long>(B) * ((Ho + 1) / 2) * ((Wo + 1) / 2);
-  return static_cast<long>(wg_splits(ntiles, Kp, Cp)) * Kp * Cp * 16;
-}
-
-extern "C" int dfe_wino_wgrad3x3(const float* x, const float* gy, long gy_batch_stride, float* gweight, float* ws, int B, int Ci, int Co,
-                                 int H, int W, int P, void* stream) {
-  if (!x || !gy || !gweight || !ws) return DFE_ERR_NULL;
-  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return DFE_ERR_DIMS;
-  if (P < 0 || P > 1) return DFE_ERR_UNSUPPORTED;
-  const int Ho = H + 2 * P - 2, Wo = W + 2 * P - 2;
-  if (Ho < 1 || Wo < 1) return DFE_ERR_DIMS;
-  if (W % 2 || Wo % 2 || (reinterpret_cast<uintptr_t>(x) & 7) || (reinterpret_cast<uintptr_t>(gy) & 7) || gy_batch_stride % 2 ||
-      (reinterpret_cast<uintptr_t>(ws) & 15))
-    return DFE_ERR_UNSUPPORTED;
-  if (gy_batch_stride < static_cast<long>(Co) * Ho * Wo) return DFE_ERR_DIMS;
-  const int TH = (Ho + 1) / 2, TW = (Wo + 1) / 2;
-  const long ntiles = static_cast<long>(B) * TH * TW;
-  if (ntiles >= (1L << 31) || Co > 65535 * WG_KB || Ci > 65535 * WG_CB) return DFE_ERR_DIMS;
-  const int Kp = (Co + WG_KB - 1) / WG_KB * WG_KB, Cp = (Ci + WG_CB - 1) / WG_CB * WG_CB;
-  const int S = wg_splits(ntiles, Kp, Cp);
-  int tps = static_cast<int>((ntiles + S - 1) / S);
-  tps = (tps + WG_TT - 1) / WG_TT * WG_TT;
-  const int S2 = static_cast<int>((ntiles + tps - 1) / tps);      // splits that actually have tiles
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid(S2, Cp / WG_CB, Kp / WG_KB);
-  const size_t lds_bytes = sizeof(float) * WG_TT * (WG_MP + WG_VP);
-  if (P == 1) k_wino_wgrad<1><<<grid, 256, lds_bytes, st>>>(x, gy, ws, gy_batch_stride, Ci, Co, H, W, TH, TW, static_cast<int>(ntiles), tps, Kp, Cp);
-  else k_wino_wgrad<0><<<grid, 256, lds_bytes, st>>>(x, gy, ws, gy_batch_stride, Ci, Co, H, W, TH, TW, static_cast<int>(ntiles), tps, Kp, Cp);
-  DFE_LAUNCH_CHECK();
-  k_wino_wgrad_final<<<(Co * Ci + 255) / 256, 256, 0, st>>>(ws, gweight, S2, Co, Ci, Kp, Cp);
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }

@@ -771,16 +771,24 @@ def wino_conv3x3(x, w, padding=1, transposed=False, dilation=1):
     return y
 
 
-def wino_wgrad3x3(x, gy, padding=1):
-    """Weight gradient [Co,Ci,3,3] of a 3x3 stride-1 convolution of x [B,Ci,H,W] with ``padding`` in {0, 1} for the output
-    gradient gy [B,Co,Ho,Wo], on dfe_wino_wgrad3x3 (Winograd domain, fp32 MFMA)."""
-    x, gy = f32c(x), f32c(gy)
+def wino_wgrad3x3(x, gy, padding=1, dilation=1):
+    """Weight gradient [Co,Ci,3,3] of a 3x3 stride-1 convolution of x [B,Ci,H,W] with ``padding`` in {0, 1} (or dilated with
+    padding = dilation) for the output gradient gy [B,Co,Ho,Wo], on dfe_wino_wgrad3x3 (Winograd domain, fp32 MFMA).  x and gy
+    may be batch-strided views (channel slices of concatenated buffers)."""
+    def dense_chw(t):
+        return t.dtype == torch.float32 and t.stride(3) == 1 and t.stride(2) == t.shape[3] and t.stride(1) == t.shape[2] * t.shape[3]
+    x = x if dense_chw(x) else f32c(x)
+    gy = gy if dense_chw(gy) else f32c(gy)
     B, Ci, H, W = x.shape
-    Co, P = int(gy.shape[1]), int(padding)
+    Co, P, d = int(gy.shape[1]), int(padding), int(dilation)
     lib = get_lib()
     gw = torch.empty(Co, Ci, 3, 3, device=x.device, dtype=torch.float32)
-    ws = torch.empty(lib.dfe_wino_wgrad_floats(B, Ci, Co, H, W, P), device=x.device, dtype=torch.float32)
-    check(lib.dfe_wino_wgrad3x3(ptr(x), ptr(gy), gy.stride(0), ptr(gw), ptr(ws), B, Ci, Co, H, W, P, stream_ptr()), "dfe_wino_wgrad3x3")
+    n = lib.dfe_wino_wgrad_floats(B, Ci, Co, H, W, P, d)
+    if n <= 0:
+        raise _lib.DfeError("dfe_wino_wgrad3x3: unsupported shape %s dilation %d" % (tuple(x.shape), d))
+    ws = torch.empty(n, device=x.device, dtype=torch.float32)
+    check(lib.dfe_wino_wgrad3x3(ptr(x), x.stride(0), ptr(gy), gy.stride(0), ptr(gw), ptr(ws), B, Ci, Co, H, W, P, d, stream_ptr()),
+          "dfe_wino_wgrad3x3")
     return gw
 
 
@@ -1193,9 +1201,14 @@ class ThinConv3x3Fn(torch.autograd.Function):
             else:
                 gp = convs.raw_backward(gy, p, weight, 1, 0, 1, True, False)[0]
         if ctx.needs_input_grad[1]:
-            gw = torch.empty_like(weight)
-            part = torch.empty(lib.dfe_wgrad3x3_partials_floats(B, Ci, Co, H, W), device=p.device)
-            check(lib.dfe_wgrad3x3_fwd(ptr(p), ptr(gy), ptr(gw), ptr(part), B, Ci, Co, H, W, stream_ptr()), "dfe_wgrad3x3_fwd")
+            if Co >= 32 and Ci >= 64 and convs.WINO_WGRAD:
+                # round 5: the Winograd-domain kernel is faster on the 32-output-channel layers (96 -> 32 at 130x418 x 12:
+                # 229 against 374 us; 64 -> 32 at 66x210: 60 against 70); 16 output channels stay here (133 against 304)
+                gw = wino_wgrad3x3(p, gy, 0)
+            else:
+                gw = torch.empty_like(weight)
+                part = torch.empty(lib.dfe_wgrad3x3_partials_floats(B, Ci, Co, H, W), device=p.device)
+                check(lib.dfe_wgrad3x3_fwd(ptr(p), ptr(gy), ptr(gw), ptr(part), B, Ci, Co, H, W, stream_ptr()), "dfe_wgrad3x3_fwd")
         return gp, gw
 
 
