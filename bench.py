@@ -338,9 +338,11 @@ def point_fwd_roofline(args, mode, fwd_ms, bwd_ms):
     t_valu = byte_models.valu_time_s(kernel, threads, valu_per_wave)
     valu_frac = None if t_valu is None else round(t_valu / (t_ms * 1e-3), 4)
     hbm_frac = round(achieved / HBM_PEAK_GBS, 4)
-    roof = {"bound": "valu" if (valu_frac is not None and valu_frac > hbm_frac) else "hbm",
-            "bound_note": "the larger of frac (algorithmic bytes / time / HBM peak) and valu_frac (VALU instructions x measured issue cycles / time); "
-                          "achieved / peak / frac stay the HBM roofline SURVEY 8(d) prices this kernel against",
+    top = max(hbm_frac, valu_frac or 0.0)
+    roof = {"bound": "latency" if top < 0.6 else ("valu" if (valu_frac or 0.0) > hbm_frac else "hbm"),
+            "bound_note": "latency = the launch sits under BOTH roofs (frac = algorithmic bytes / time / HBM peak and valu_frac = VALU instructions x "
+                          "measured issue cycles / time are both < 0.6): waves waiting at 5-6 waves per SIMD (PMC: wait-issue 0.44, wait-memory "
+                          "0.31 of wave cycles); achieved / peak / frac stay the HBM roofline SURVEY 8(d) prices this kernel against",
             "valu_frac": valu_frac, "valu_insts_per_wave": valu_per_wave if valu_per_wave is not None else byte_models.VALU_PER_WAVE.get(kernel),
             "valu_cycles_per_inst": round(byte_models.VALU_CYCLES_PER_INST, 2), "valu_source": valu_src,
             "limiter": POINT_LIMITER.get(mode), "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

@@ -658,6 +658,9 @@ class WinoWeightCache:
 
     def __init__(self):
         self.enabled = os.environ.get("DFE_WINO_CACHE", "1") != "0"
+        # DFE_WINO_CACHE_VERIFY=1: every hit re-transforms the filter and compares (synchronises; a debugging mode that catches
+        # writes the version counters cannot see)
+        self.verify = os.environ.get("DFE_WINO_CACHE_VERIFY", "0") == "1"
         self.entries = {}        # (data_ptr, Co, Ci of the weight tensor) -> entry
         self.table = None        # device tables of the last refresh (rebuilt when the membership changes)
         self.blockmap = None
@@ -677,23 +680,49 @@ class WinoWeightCache:
         e = self.entries.get(key)
         if e is None:
             # only leaf parameters are worth keeping (a temporary's address is reused by unrelated tensors)
-            if isinstance(w, torch.nn.Parameter):
+            # (and only what refresh() can transform: a non-fp32 / non-contiguous parameter would be registered again on every call)
+            if isinstance(w, torch.nn.Parameter) and w.dtype == torch.float32 and w.is_contiguous():
                 import weakref
                 self.entries[key] = {"ref": weakref.ref(w), "version": -1, "U": None, "device": w.device}
+                self.members = None      # the device table of the last refresh no longer describes the membership
             self.misses += 1
             return None
         p = e["ref"]()
         if p is None or p.data_ptr() != key[0]:
+            # the Parameter died (its address may already belong to another tensor -- or to a NEW Parameter of the same shape,
+            # which would re-register under the same key: the table must be rebuilt, its U pointers are about to be freed)
             del self.entries[key]
+            self.members = None
             self.misses += 1
             return None
         if e["U"] is None or e["version"] != w._version or e["version"] != p._version:
             self.misses += 1
             return None
         self.hits += 1
-        return e["U"][1 if transposed else 0]
+        U = e["U"][1 if transposed else 0]
+        if self.verify and not torch.equal(U, self.transform_now(w, transposed)):
+            raise _lib.DfeError("WinoWeightCache: the cached filters of a %s parameter are stale -- it was written without a version "
+                                "bump (p.data.mul_/copy_, a raw-pointer kernel) after the last refresh; call "
+                                "ops.wino_weights.invalidate() after such writes" % (tuple(w.shape),))
+        return U
+
+    @staticmethod
+    def transform_now(w, transposed):
+        """U of ``w`` by a one-entry launch of the same kernel refresh() uses (DFE_WINO_CACHE_VERIFY=1; tests)."""
+        lib = get_lib()
+        Co, Ci = int(w.shape[0]), int(w.shape[1])
+        K, C = (Ci, Co) if transposed else (Co, Ci)
+        U = torch.empty(lib.dfe_wino_weight_floats(C, K), device=w.device, dtype=torch.float32)
+        n = int(lib.dfe_wino_transform_blocks(C, K))
+        table = torch.tensor([[w.data_ptr(), U.data_ptr(), K, C, int(bool(transposed)), 0]], dtype=torch.int64).to(w.device)
+        bmap = torch.zeros(n, dtype=torch.int32, device=w.device)
+        check(lib.dfe_wino_transform_weights_multi(ptr(table), ptr(bmap), n, stream_ptr()), "dfe_wino_transform_weights_multi")
+        return U
 
     def invalidate(self):
+        """Call after any write to a registered parameter that does not bump its autograd version counter (``p.data.copy_`` /
+        ``mul_``, EMA or weight surgery through ``.data``, another raw-pointer kernel): every entry misses until the next
+        refresh().  ddp.FlatAllReduce (after its ``.data`` broadcast) and the checkpoint loaders call it."""
         for e in self.entries.values():
             e["version"] = -1
 
@@ -707,14 +736,16 @@ class WinoWeightCache:
             p = e["ref"]()
             if p is None or p.data_ptr() != key[0] or not p.is_contiguous() or p.dtype != torch.float32:
                 del self.entries[key]
+                self.members = None
                 continue
             live.append((key, e, p))
         if not live:
             return
         dev = live[0][2].device
         live = [t for t in live if t[2].device == dev]
-        members = tuple(k for k, _, _ in live)
-        if members != self.members:
+        # the table is rebuilt whenever the membership changed OR any live entry has no buffers yet (a re-registered key)
+        members = tuple((k, id(e)) for k, e, _ in live)
+        if members != self.members or any(e["U"] is None for _, e, _ in live):
             rows, bmap, nb = [], [], 0
             for key, e, p in live:
                 Co, Ci = key[1], key[2]
@@ -730,6 +761,8 @@ class WinoWeightCache:
             self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
             self.blockmap = torch.tensor(bmap, dtype=torch.int32).to(dev)
             self.members = members
+        for _, e, _ in live:         # exception-safe: nothing is valid until the launch has been enqueued
+            e["version"] = -1
         check(lib.dfe_wino_transform_weights_multi(ptr(self.table), ptr(self.blockmap), int(self.blockmap.numel()), stream_ptr()),
               "dfe_wino_transform_weights_multi")
         for _, e, p in live:
