@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=120, help="timed steps (default: a timed region of >= 2 s at ~20 ms per step)")
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=4, help="triplets per GPU")
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=832)
@@ -449,9 +449,16 @@ def main():
     from unsupervised_depth_opticalflow_egomotion_amd import loss_stack as LS
     barrier(world)
     LS.timing_begin()           # HIP events between the fused stack's launches (stream-ordered, no host sync)
+    # stream-ordered marks (no host sync): the whole region, and its first 20 steps (what rounds 1-4 timed) for comparison
+    ev_beg, ev_20, ev_end = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    ev_beg.record()
+    for i in range(args.steps):
         wl.step()
+        if i == 19:
+            ev_20.record()
+    ev_end.record()
+    t_host = time.perf_counter() - t0      # the host has ENQUEUED every step (it runs ahead of the GPU when the GPU is the bound)
     barrier(world)
     dt_local = time.perf_counter() - t0
     dt = max_over_ranks(dt_local, world, dev)
@@ -462,6 +469,11 @@ def main():
     out = {
         "metric": "frame-pairs/sec (%dx%d, %s mode)" % (args.width, args.height, args.mode if wl.name == "train_step" else "geom"), "value": round(value, 2), "unit": "frame-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+        # host time to enqueue one step (launches + autograd bookkeeping): the floor the step cannot go below without fewer
+        # launches or a captured graph; equal to ms_per_step when the host is the bound
+        "host_enqueue_ms": round(1e3 * t_host / args.steps, 4), "timed_region_s": round(dt, 3),
+        "ms_per_step_first20": round(ev_beg.elapsed_time(ev_20) / 20.0, 4) if args.steps >= 20 else None,
+        "ms_per_step_gpu_events": round(ev_beg.elapsed_time(ev_end) / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.amp == "off" else args.amp, "data": "synthetic",
         "config": {"workload": wl.name + ": mode=%s, %dx%d, batch=%d/GPU, num_scales=%d, fwd+bwd%s" % (
             args.mode if wl.name == "train_step" else "geom", args.width, args.height, args.batch, args.scales,
