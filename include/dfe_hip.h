@@ -278,17 +278,17 @@ int dfe_wino_conv3x3(const float* x, const float* weight, float* y, long y_batch
 /* weight gradient of the same convolutions in the Winograd domain (replaces aten::convolution_backward's weight output for the
  * reference's 3x3 stride-1 layers, depth_model.py:13-58,135-191, pwc_tf.py:28-95): gweight [Co,Ci,3,3] = d/dw of
  * conv(x [B,Ci,H,W], w, padding P in {0, 1}) for the output gradient gy; element (b,ci,i) of x at x + b * x_batch_stride +
- * ci * H*W + i, element (b,co,i) of gy at gy + b * gy_batch_stride + co * Ho*Wo + i.  dilation > 1: a dilated convolution with
- * padding = dilation (P is ignored; H and W multiples of the dilation; gy has x's size).  Straight from NCHW: no layout
+ * ci * H*W + i, element (b,co,i) of gy at gy + b * gy_batch_stride + co * Ho*Wo + i.  Straight from NCHW: no layout
  * transposes, no zero fill, no atomics (fixed-order partial sums in ws: dfe_wino_wgrad_floats floats); any size and
- * channel count. */
-long dfe_wino_wgrad_floats(int B, int Ci, int Co, int H, int W, int P, int dilation);
-/* tuning hook (process-wide, not for concurrent use): tile = 0 (by channel counts) / 11 / 12 / 21 / 22 forces the wave tile
- * (16 MH x 16 NH channels); blocks1 / blocks2 > 0: the grid-size targets of the one- / two-blocks-per-CU kernels.  The
- * workspace size follows the setting: query dfe_wino_wgrad_floats after changing it. */
-int dfe_wino_wgrad_tune(int tile, int blocks1, int blocks2);
+ * channel count.  A dilated layer (pwc_tf.py:31-36) is this call on its dilation x dilation phase images (B d^2 samples of
+ * H/d x W/d pixels, P = 1), which the caller gathers. */
+long dfe_wino_wgrad_floats(int B, int Ci, int Co, int H, int W, int P);
+/* tuning hook (process-wide, not for concurrent use): tile = 0 (by shape) / 11 / 12 / 21 forces the wave tile (16 MH x 16 NH
+ * channels); blocks1 / blocks2 > 0: the grid-size targets of the 64- / 128-accumulator kernels; chunk = 8 / 12 tiles per
+ * barrier (0: keep).  The workspace size follows the setting: query dfe_wino_wgrad_floats after changing it. */
+int dfe_wino_wgrad_tune(int tile, int blocks1, int blocks2, int chunk);
 int dfe_wino_wgrad3x3(const float* x, long x_batch_stride, const float* gy, long gy_batch_stride, float* gweight, float* ws, int B,
-                      int Ci, int Co, int H, int W, int P, int dilation, void* stream);
+                      int Ci, int Co, int H, int W, int P, void* stream);
 /* the same for a DILATED 3x3 convolution with padding = dilation (pwc_tf.py:31-36 context network: dilation 2, 4, 8, 16): the
  * Winograd tiles live on the dilation x dilation phase images; H and W must be multiples of the dilation.  y has x's size. */
 int dfe_wino_conv3x3_dilated(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, int B, int Ci, int Co,

@@ -73,21 +73,51 @@ def test_wino_dilated_conv_matches_float64(shape):
     assert float((gx.double() - rgx).abs().max()) <= 2e-5 * float(rgx.abs().max())
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 64, 16, 24, 1), (3, 40, 70, 10, 12, 1), (2, 33, 17, 8, 6, 0), (1, 3, 5, 4, 4, 1), (2, 96, 32, 34, 50, 0),
-                                   (4, 128, 128, 32, 104, 1), (1, 16, 16, 64, 208, 1)])
+WGRAD_SHAPES = [(2, 64, 64, 16, 24, 1, 1), (3, 40, 70, 10, 12, 1, 1), (2, 33, 17, 8, 6, 0, 1), (1, 3, 5, 4, 4, 1, 1), (2, 96, 32, 34, 50, 0, 1),
+                (4, 128, 128, 32, 104, 1, 1), (1, 16, 16, 64, 208, 1, 1), (1, 70, 35, 7, 9, 1, 1), (2, 5, 3, 3, 3, 1, 1), (1, 65, 65, 5, 31, 0, 1),
+                (2, 130, 40, 9, 13, 1, 1), (1, 64, 64, 13, 27, 1, 1), (1, 64, 64, 4, 106, 0, 1), (2, 224, 64, 12, 50, 1, 1),
+                (1, 32, 32, 16, 32, 2, 2), (1, 40, 36, 32, 64, 4, 4), (2, 33, 17, 8, 12, 2, 2), (1, 24, 16, 32, 48, 8, 8), (1, 8, 8, 64, 64, 16, 16)]
+
+
+@pytest.mark.parametrize("shape", WGRAD_SHAPES)
 def test_wino_wgrad_matches_float64(shape):
-    """the Winograd-domain weight gradient against float64 aten (padding 1 and valid; channel counts off the 64 / 32 tiles)."""
-    B, Ci, Co, H, W, P = shape
+    """the Winograd-domain weight gradient (csrc/ops_wino_wgrad.hip) against float64 aten: padding 1 and valid, dilated layers (on
+    their phase images), sizes off the 2x2 tiles and the 12-tile chunks, channel counts off the 32 / 64 tiles -- with every
+    wave tile and chunk size the kernel is built for.  3e-5 of scale (measured <= 1e-6); bit-reproducible."""
+    from unsupervised_depth_opticalflow_egomotion_amd._lib import get_lib
+    B, Ci, Co, H, W, P, d = shape
     torch.manual_seed(sum(shape))
     x = torch.randn(B, Ci, H, W, device=dev())
     w = torch.randn(Co, Ci, 3, 3, device=dev())
-    gy = torch.randn(B, Co, H + 2 * P - 2, W + 2 * P - 2, device=dev())
-    gw = ops.wino_wgrad3x3(x, gy, P)
-    ref = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), None, [1, 1], [P, P], [1, 1], False, [0, 0], 1,
+    gy = torch.randn(B, Co, H if d > 1 else H + 2 * P - 2, W if d > 1 else W + 2 * P - 2, device=dev())
+    ref = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), None, [1, 1], [P, P], [d, d], False, [0, 0], 1,
                                               [False, True, False])[1]
-    err, scale = float((gw.double() - ref).abs().max()), float(ref.abs().max())
-    assert err <= 3e-5 * scale, (err, scale)
-    assert torch.equal(gw, ops.wino_wgrad3x3(x, gy, P))
+    scale = float(ref.abs().max())
+    lib = get_lib()
+    try:
+        for tile, chunk in ((0, 12), (11, 12), (11, 8), (21, 12), (21, 8), (12, 8)):
+            assert lib.dfe_wino_wgrad_tune(tile, 0, 0, chunk) == 0
+            gw = ops.wino_wgrad3x3(x, gy, 1 if d > 1 else P, d)
+            err = float((gw.double() - ref).abs().max())
+            assert err <= 3e-5 * scale, (tile, chunk, err, scale)
+            assert torch.equal(gw, ops.wino_wgrad3x3(x, gy, 1 if d > 1 else P, d)), (tile, chunk)
+    finally:
+        lib.dfe_wino_wgrad_tune(0, 0, 0, 12)
+
+
+def test_wino_wgrad_reads_batch_strided_views_and_rejects_bad_arguments():
+    """x / gy as channel slices of wider buffers (the PWC decoder's concatenated tensors) are read in place; bad arguments
+    come back as error codes."""
+    from unsupervised_depth_opticalflow_egomotion_amd._lib import get_lib
+    torch.manual_seed(3)
+    xb = torch.randn(2, 80, 12, 20, device=dev())
+    gb = torch.randn(2, 50, 12, 20, device=dev())
+    x, gy = xb[:, 16:], gb[:, :40]
+    gw = ops.wino_wgrad3x3(x, gy, 1)
+    assert torch.equal(gw, ops.wino_wgrad3x3(x.contiguous(), gy.contiguous(), 1))
+    lib = get_lib()
+    assert lib.dfe_wino_wgrad3x3(None, 0, None, 0, None, None, 1, 1, 1, 4, 4, 1, None) == -1
+    assert lib.dfe_wino_wgrad_floats(1, 8, 8, 4, 4, 2) == 0 and lib.dfe_wino_wgrad_tune(22, 0, 0, 0) != 0
 
 
 # ---- transformed filters kept across steps (ops.WinoWeightCache, dfe_wino_transform_weights_multi / dfe_wino_conv3x3_u)

@@ -64,7 +64,7 @@ def check(tiles, dev):
         scale = float(ref.abs().max())
         row = []
         for t in tiles:
-            assert lib.dfe_wino_wgrad_tune(t, 0, 0) == 0
+            assert lib.dfe_wino_wgrad_tune(t, 0, 0, 0) == 0
             g = ops.wino_wgrad3x3(x, gy, P if d == 1 else 1, d)
             err = float((g.double() - ref).abs().max()) / scale
             rep = bool(torch.equal(g, ops.wino_wgrad3x3(x, gy, P if d == 1 else 1, d)))
@@ -72,7 +72,7 @@ def check(tiles, dev):
             bad += (err > 3e-5) or not rep
         m = float((aten_wgrad(x, w, gy, P, d).double() - ref).abs().max()) / scale
         print("check %-34s aten-fp32 %.1e | %s" % (shape, m, " | ".join(row)), flush=True)
-    lib.dfe_wino_wgrad_tune(0, 0, 0)
+    lib.dfe_wino_wgrad_tune(0, 0, 0, 0)
     print("CHECK", "FAILED (%d)" % bad if bad else "ok", flush=True)
     return bad
 
@@ -107,11 +107,11 @@ def main():
                 continue
             tb = 1e9
             for (b1, b2) in blocks:
-                lib.dfe_wino_wgrad_tune(t, b1, b2)
+                lib.dfe_wino_wgrad_tune(t, b1, b2, 0)
                 tb = min(tb, ev(lambda: ops.wino_wgrad3x3(x, gy, P if d == 1 else 1, d), a.iters))
             cells.append("%.1f (%.0f)" % (tb, fl / tb / 1e6))
             best = min(best, tb)
-        lib.dfe_wino_wgrad_tune(0, 768, 512)
+        lib.dfe_wino_wgrad_tune(0, 768, 512, 0)
         ref = aten_wgrad(x.double(), w.double(), gy.double(), P, d)
         err = float((ops.wino_wgrad3x3(x, gy, P if d == 1 else 1, d).double() - ref).abs().max() / ref.abs().max())
         tot_m += t_m; tot_b += min(best, t_m)

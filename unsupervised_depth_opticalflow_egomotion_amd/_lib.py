@@ -48,9 +48,9 @@ _SIGNATURES = {
     "dfe_wino_weight_floats": [_I, _I],
     "dfe_wino_conv3x3": [_P, _P, _P, ctypes.c_long, _P, ctypes.c_long, _I, _I, _I, _I, _I, _I, _I, _P],
     "dfe_wino_scratch_floats": [_I, _I, _I, _I, _I, _I],
-    "dfe_wino_wgrad_floats": [_I, _I, _I, _I, _I, _I, _I],
-    "dfe_wino_wgrad_tune": [_I, _I, _I],
-    "dfe_wino_wgrad3x3": [_P, ctypes.c_long, _P, ctypes.c_long, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dfe_wino_wgrad_floats": [_I, _I, _I, _I, _I, _I],
+    "dfe_wino_wgrad_tune": [_I, _I, _I, _I],
+    "dfe_wino_wgrad3x3": [_P, ctypes.c_long, _P, ctypes.c_long, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dfe_wino_conv3x3_dilated": [_P, _P, _P, ctypes.c_long, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dfe_wino_transform_blocks": [_I, _I],
     "dfe_wino_transform_weights_multi": [_P, _P, _I, _P],

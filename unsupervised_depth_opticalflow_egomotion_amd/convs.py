@@ -145,17 +145,20 @@ def _wino_eligible(x, w_shape, cin, stride, padding, dilation, groups=1):
 # wave transforms the tiles of its (channel, tile) lanes in registers and feeds the fp32 matrix cores -- no layout transposes, no
 # zero fill, no atomics (MIOpen: NHWC implicit GEMM + three batched transposes + a fill per call, split-K float atomics).
 # 1.2-2.9x MIOpen on every 3x3 stride-1 layer of the step with >= 32 channels on both sides (tools/wgrad_bench.py,
-# profiles/r05_wgrad_bench.md); dilated layers (element-wise strided staging) only tie and stay on MIOpen.  DFE_WINO_WGRAD=0: MIOpen's weight gradients everywhere.
+# profiles/r05_wgrad_bench.md).  DFE_WINO_WGRAD=0: MIOpen's weight gradients everywhere.
 WINO_WGRAD = os.environ.get("DFE_WINO_WGRAD", "1") != "0"
 WINO_WGRAD_MIN_MACS = float(os.environ.get("DFE_WINO_WGRAD_MIN_GMAC", "0.8")) * 1e9      # direct multiply-adds of the layer
-WINO_WGRAD_DILATED = os.environ.get("DFE_WINO_WGRAD_DILATED", "0") == "1"
+# dilated layers: the same kernel on the d x d phase images (two strided copies, ops.phase_images) up to this dilation -- 247 / 270 us
+# against MIOpen's 359 / 342 at dilation 2 / 4 (8 x 128 -> 128 @ 64x208); at 8 / 16 the phase images are 8x26 / 4x13 pixels, too
+# short for the kernel's 12-tile chunks (307 / 211 against 297 / 144): those two stay on MIOpen
+WINO_WGRAD_MAX_DILATION = int(os.environ.get("DFE_WINO_WGRAD_MAX_DILATION", "4"))
 
 
 def _wino_wgrad_eligible(x, gy_shape, w_shape, padding, d):
     """x [B,Ci,H,W] (fp32, HIP), the output gradient's shape, the filter's shape, padding pair, dilation."""
     if not WINO_WGRAD or _STATE["dtype"] is not None or x.dtype != torch.float32 or not x.is_cuda or x.dim() != 4:
         return False
-    if d > 1 and not (WINO_WGRAD_DILATED and padding == (d, d) and x.shape[2] % d == 0 and x.shape[3] % d == 0):
+    if d > 1 and not (d <= WINO_WGRAD_MAX_DILATION and padding == (d, d) and x.shape[2] % d == 0 and x.shape[3] % d == 0):
         return False
     if d == 1 and padding not in ((0, 0), (1, 1)):
         return False

@@ -14,7 +14,7 @@
 //     stand against 12 MH + 32 NH vector adds;
 //   * the reduction over the tiles is split over blocks (chunks of tiles); every block applies G^T . G to its partial sums and
 //     writes [split][k][c][9]; k_wgrad_sum adds the splits in order.  No atomics: bit-reproducible.
-// Dilated layers (pwc_tf.py:31-36) run on the dilation x dilation phase images (GEN: scalar strided loads into the same LDS image).
+// Dilated layers (pwc_tf.py:31-36) are this kernel on their dilation x dilation phase images, gathered by the caller (convs.py).
 // Bound: MFMA (2.25 x 157 TFLOP/s effective at 100 % of the fp32 matrix pipe).
 #include "dfe_internal.h"
 #include "dfe_device.h"
@@ -46,12 +46,12 @@ struct WgCfg {
   static constexpr int NXT = (CIB + 7) / 8, NGT = (COB + GCH - 1) / GCH;
 };
 
-// PP: the forward convolution's padding in (phase-image) pixels, 0 or 1.  GEN: element-wise strided loads (dilation > 1).
-template <int MH, int NH, int WM, int WN, int TWC, int PP, bool GEN>
+// PP: the forward convolution's padding, 0 or 1
+template <int MH, int NH, int WM, int WN, int TWC, int PP>
 __global__ void __launch_bounds__(256, 2)
 k_wino_wgrad2(const float* __restrict__ x, long xbs, const float* __restrict__ gy, long gbs, float* __restrict__ part, int C, int K,
               int W, int HW, int Hq, int Wq, int Ho, int Wo, int gW, int gHW, int TH, int cpr, int TWn, int nchunks, int cps, int ncit,
-              int ntb, int dil, int abl) {
+              int ntb) {
   typedef WgCfg<MH, NH, WM, WN, TWC> Cfg;
   constexpr int WG_XP = Cfg::XP, WG_XCS = Cfg::XCS, WG_GP = Cfg::GP, WG_GCS = Cfg::GCS, WG_TWC = TWC;
   constexpr int S = PP == 1 ? 3 : 0;       // LDS column of a chunk's first patch column: global column 16 cx - PP sits at S
@@ -69,41 +69,31 @@ k_wino_wgrad2(const float* __restrict__ x, long xbs, const float* __restrict__ g
   const int gq_ = tid & (Cfg::GSL - 1), gr_ = (tid / Cfg::GSL) & 1, gc_ = tid / (2 * Cfg::GSL);
   const int xl0 = xc_ * WG_XCS + xr_ * WG_XP + 4 * xq_;
   const int gl0 = Cfg::CIB * WG_XCS + gc_ * WG_GCS + gr_ * WG_GP + 4 * gq_;
-  const int xg0 = (cib0 + xc_) * HW + ((xr_ - PP) * W + (4 * xq_ - CS)) * dil;
-  const int gg0 = (cob0 + gc_) * gHW + (gr_ * gW + 4 * gq_) * dil;
+  const int xg0 = (cib0 + xc_) * HW + (xr_ - PP) * W + (4 * xq_ - CS);
+  const int gg0 = (cob0 + gc_) * gHW + gr_ * gW + 4 * gq_;
   wg_f32x4 xr[Cfg::NXT], gr[Cfg::NGT];
-  const int dd = dil * dil;
   int cx = c_beg % cpr, ty = (c_beg / cpr) % TH, img = c_beg / cpr / TH;       // the chunk load_chunk stages next
   auto load_chunk = [&]() {
-    if (abl & 1) {
-#pragma unroll
-      for (int k = 0; k < Cfg::NXT; ++k) xr[k] = wg_f32x4{1.0f, 2.0f, 3.0f, 4.0f};
-#pragma unroll
-      for (int k = 0; k < Cfg::NGT; ++k) gr[k] = wg_f32x4{1.0f, 2.0f, 3.0f, 4.0f};
-      return;
-    }
-    int b = img, py = 0, px = 0;
-    if (GEN) { b = img / dd; const int ph = img - b * dd; py = ph / dil; px = ph - py * dil; }
-    const long xb = b * xbs + static_cast<long>(py + dil * 2 * ty) * W + px + dil * 2 * TWC * cx;
-    const long gb = b * gbs + static_cast<long>(py + dil * 2 * ty) * gW + px + dil * 2 * TWC * cx;
+    const long xb = img * xbs + static_cast<long>(2 * ty) * W + 2 * TWC * cx;
+    const long gb = img * gbs + static_cast<long>(2 * ty) * gW + 2 * TWC * cx;
     {
       const int col = 2 * TWC * cx + 4 * xq_ - CS, yy = 2 * ty - PP + xr_;
       const bool rok = xq_ < Cfg::XU && yy >= 0 && yy < Hq;
-      const bool full = !GEN && rok && col >= 0 && col + 3 < Wq, some = rok && col + 3 >= 0 && col < Wq;
+      const bool full = rok && col >= 0 && col + 3 < Wq, some = rok && col + 3 >= 0 && col < Wq;
       const float* p0 = x + xb + xg0;
 #pragma unroll
       for (int k = 0; k < Cfg::NXT; ++k) {
         const float* p = p0 + static_cast<long>(8 * k) * HW;
         const bool cok = xc_ + 8 * k < Cfg::CIB && cib0 + xc_ + 8 * k < C;
         wg_f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (!GEN) {            // straight-line: one 16-byte load from a safe address, zero unless the slot lies inside
+        {            // straight-line: one 16-byte load from a safe address, zero unless the slot lies inside
           const WgQuadU u = *reinterpret_cast<const WgQuadU*>(full && cok ? p : x);
           if (full && cok) v = wg_f32x4{u.a, u.b, u.c, u.d};
         }
-        if ((GEN || !full) && some && cok) {      // image edges (and every slot of a dilated layer): element by element
+        if (!full && some && cok) {      // a slot that straddles the image's edge: element by element
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            if (col + j >= 0 && col + j < Wq) v[j] = p[j * dil];
+            if (col + j >= 0 && col + j < Wq) v[j] = p[j];
         }
         xr[k] = v;
       }
@@ -111,21 +101,21 @@ k_wino_wgrad2(const float* __restrict__ x, long xbs, const float* __restrict__ g
     {
       const int col = 2 * TWC * cx + 4 * gq_, oy = 2 * ty + gr_;
       const bool rok = gq_ < Cfg::GU && oy < Ho;
-      const bool full = !GEN && rok && col + 3 < Wo, some = rok && col < Wo;
+      const bool full = rok && col + 3 < Wo, some = rok && col < Wo;
       const float* p0 = gy + gb + gg0;
 #pragma unroll
       for (int k = 0; k < Cfg::NGT; ++k) {
         const float* p = p0 + static_cast<long>(Cfg::GCH * k) * gHW;
         const bool cok = gc_ + Cfg::GCH * k < Cfg::COB && cob0 + gc_ + Cfg::GCH * k < K;
         wg_f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (!GEN) {
+        {
           const WgQuadU u = *reinterpret_cast<const WgQuadU*>(full && cok ? p : gy);
           if (full && cok) v = wg_f32x4{u.a, u.b, u.c, u.d};
         }
-        if ((GEN || !full) && some && cok) {
+        if (!full && some && cok) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            if (col + j < Wo) v[j] = p[j * dil];
+            if (col + j < Wo) v[j] = p[j];
         }
         gr[k] = v;
       }
@@ -218,14 +208,12 @@ k_wino_wgrad2(const float* __restrict__ x, long xbs, const float* __restrict__ g
     const float* buf = lds + cur * Cfg::BUF;
     const int tiles = min(WG_TWC, TWn - WG_TWC * tcx);
     if (++tcx == cpr) tcx = 0;
-    if (!(abl & 2)) {
-      step(buf, 0);
-      if (tiles > 4) step(buf, 1);
-      if (TWC > 8 && tiles > 8) step(buf, 2);
-    }
+    step(buf, 0);
+    if (tiles > 4) step(buf, 1);
+    if (TWC > 8 && tiles > 8) step(buf, 2);
     if (more) {
-      if (!(abl & 4)) store_chunk(lds + (cur ^ 1) * Cfg::BUF);      // its last readers passed the previous barrier
-      if (!(abl & 8)) __syncthreads();
+      store_chunk(lds + (cur ^ 1) * Cfg::BUF);      // its last readers passed the previous barrier
+      __syncthreads();
       cur ^= 1;
     }
   }
@@ -291,23 +279,20 @@ __global__ void __launch_bounds__(256) k_wgrad_sum(const float* __restrict__ par
 using namespace dfe;
 
 namespace {
-struct WgPlan { int mh, nh, twc, ncot, ncit, nchunks, cps, S, cpr, TH, TWn, Hq, Wq, Ho, Wo; };
+struct WgPlan { int mh, nh, twc, ncot, ncit, nchunks, cps, S, cpr, TH, TWn, Ho, Wo; };
 
 int wg_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-// tuning knobs (dfe_wino_wgrad_tune): forced wave tile (0 = by channel counts), block targets of the 256- / 128-accumulator kernels
-int g_wg_tune[5] = {wg_env("DFE_WGRAD_TILE", 0), wg_env("DFE_WGRAD_BLOCKS1", 768), wg_env("DFE_WGRAD_BLOCKS2", 512), wg_env("DFE_WGRAD_ABL", 0), wg_env("DFE_WGRAD_CHUNK", 12)};
+// tuning knobs (dfe_wino_wgrad_tune): forced wave tile (0 = by shape), block targets of the 64- / 128-accumulator kernels, chunk
+int g_wg_tune[4] = {wg_env("DFE_WGRAD_TILE", 0), wg_env("DFE_WGRAD_BLOCKS1", 768), wg_env("DFE_WGRAD_BLOCKS2", 512), wg_env("DFE_WGRAD_CHUNK", 12)};
 
-// H, W: the input's size; P: the forward padding (0 / 1; dilation > 1: padding = dilation, i.e. 1 in phase coordinates)
-bool wg_plan(int B, int Ci, int Co, int H, int W, int P, int dil, WgPlan* pl) {
-  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || dil < 1) return false;
-  if (dil > 1 && (H % dil || W % dil)) return false;
-  if (P < 0 || P > 1) return false;
+// H, W: the input's size; P: the forward padding (0 / 1)
+bool wg_plan(int B, int Ci, int Co, int H, int W, int P, WgPlan* pl) {
+  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || P < 0 || P > 1) return false;
   WgPlan p;
-  p.Hq = H / dil; p.Wq = W / dil;
-  p.Ho = p.Hq + 2 * P - 2; p.Wo = p.Wq + 2 * P - 2;
+  p.Ho = H + 2 * P - 2; p.Wo = W + 2 * P - 2;
   if (p.Ho < 1 || p.Wo < 1) return false;
   p.TH = (p.Ho + 1) / 2; p.TWn = (p.Wo + 1) / 2;
-  const int force = g_wg_tune[0];      // 22 / 21 / 12 / 11: force the wave tile (16 MH x 16 NH channels)
+  const int force = g_wg_tune[0];      // 21 / 12 / 11: force the wave tile (16 MH x 16 NH channels)
   // wave tile (16 MH x 16 NH channels; a block = 2 x 2 waves), from tools/wgrad_bench.py (profiles/r05_wgrad_bench.md): 32 x 32 blocks
   // (64 accumulators per wave, three blocks per CU) win wherever 64-channel tiles would be padded or the layer is thin;
   // 64 x 32 blocks (128 accumulators, two per CU) when there are many input channels to share each staged gy tile between
@@ -315,10 +300,10 @@ bool wg_plan(int B, int Ci, int Co, int H, int W, int P, int dil, WgPlan* pl) {
   const int co_pad = (Co + 63) / 64 * 64 - Co;
   p.mh = (Co >= 64 && co_pad < 16 && Ci >= 192) ? 2 : 1; p.nh = 1;
   if (force >= 11 && force != 22) { p.mh = force / 10; p.nh = force % 10; }
-  // 12-tile chunks (3 steps per barrier) where two blocks still share a CU's LDS: every tile but 32 x 64 (and 64 x 64)
-  p.twc = (p.nh == 2 || g_wg_tune[4] == 8) ? 8 : 12;
+  // 12-tile chunks (3 steps per barrier) where two blocks still share a CU's LDS: every tile but 32 x 64
+  p.twc = (p.nh == 2 || g_wg_tune[3] == 8) ? 8 : 12;
   p.cpr = (p.TWn + p.twc - 1) / p.twc;
-  const long nch = static_cast<long>(B) * dil * dil * p.TH * p.cpr;
+  const long nch = static_cast<long>(B) * p.TH * p.cpr;
   if (nch >= (1L << 30)) return false;
   p.nchunks = static_cast<int>(nch);
   p.ncot = (Co + 32 * p.mh - 1) / (32 * p.mh); p.ncit = (Ci + 32 * p.nh - 1) / (32 * p.nh);
@@ -333,54 +318,50 @@ bool wg_plan(int B, int Ci, int Co, int H, int W, int P, int dil, WgPlan* pl) {
 }
 }  // namespace
 
-extern "C" int dfe_wino_wgrad_tune(int tile, int blocks1, int blocks2) {
+extern "C" int dfe_wino_wgrad_tune(int tile, int blocks1, int blocks2, int chunk) {
   if (tile != 0 && tile != 11 && tile != 12 && tile != 21) return DFE_ERR_UNSUPPORTED;
+  if (chunk != 0 && chunk != 8 && chunk != 12) return DFE_ERR_UNSUPPORTED;
   g_wg_tune[0] = tile;
   if (blocks1 > 0) g_wg_tune[1] = blocks1;
   if (blocks2 > 0) g_wg_tune[2] = blocks2;
-  if (blocks1 < 0) g_wg_tune[3] = -blocks1 - 1;      // diagnostic: ablation mask
-  if (blocks2 < 0) g_wg_tune[4] = -blocks2;          // chunk size 8 / 12
+  if (chunk > 0) g_wg_tune[3] = chunk;
   return DFE_OK;
 }
 
-extern "C" long dfe_wino_wgrad_floats(int B, int Ci, int Co, int H, int W, int P, int dilation) {
+extern "C" long dfe_wino_wgrad_floats(int B, int Ci, int Co, int H, int W, int P) {
   WgPlan p;
-  if (!wg_plan(B, Ci, Co, H, W, dilation > 1 ? 1 : P, dilation, &p)) return 0;
+  if (!wg_plan(B, Ci, Co, H, W, P, &p)) return 0;
   return static_cast<long>(p.S) * Co * Ci * 9;
 }
 
-template <int MH, int NH, int TWC, int PP, bool GEN>
-static void wg_launch(const WgPlan& p, const float* x, long xbs, const float* gy, long gbs, float* ws, int Ci, int Co, int H, int W, int dil,
+template <int MH, int NH, int TWC, int PP>
+static void wg_launch(const WgPlan& p, const float* x, long xbs, const float* gy, long gbs, float* ws, int Ci, int Co, int H, int W,
                       hipStream_t st) {
   typedef WgCfg<MH, NH, 2, 2, TWC> Cfg;
   const int ntb = p.ncot * p.ncit;
   const size_t lds_bytes = sizeof(float) * 2 * Cfg::BUF;
-  const int gW = dil > 1 ? W : p.Wo, gHW = dil > 1 ? H * W : p.Ho * p.Wo;
-  auto kern = k_wino_wgrad2<MH, NH, 2, 2, TWC, PP, GEN>;
+  auto kern = k_wino_wgrad2<MH, NH, 2, 2, TWC, PP>;
   static bool attr_set = false;      // > 64 KB of dynamic LDS needs the opt-in attribute once per kernel
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)); attr_set = true; }
-  kern<<<static_cast<unsigned>(ntb) * p.S, 256, lds_bytes, st>>>(x, xbs, gy, gbs, ws, Ci, Co, W, H * W, p.Hq, p.Wq, p.Ho, p.Wo, gW, gHW, p.TH,
-                                                                   p.cpr, p.TWn, p.nchunks, p.cps, p.ncit, ntb, dil, g_wg_tune[3]);
+  kern<<<static_cast<unsigned>(ntb) * p.S, 256, lds_bytes, st>>>(x, xbs, gy, gbs, ws, Ci, Co, W, H * W, H, W, p.Ho, p.Wo, p.Wo, p.Ho * p.Wo, p.TH,
+                                                                   p.cpr, p.TWn, p.nchunks, p.cps, p.ncit, ntb);
 }
 
 extern "C" int dfe_wino_wgrad3x3(const float* x, long x_batch_stride, const float* gy, long gy_batch_stride, float* gweight, float* ws, int B,
-                                 int Ci, int Co, int H, int W, int P, int dilation, void* stream) {
+                                 int Ci, int Co, int H, int W, int P, void* stream) {
   if (!x || !gy || !gweight || !ws) return DFE_ERR_NULL;
   if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return DFE_ERR_DIMS;
-  if (P < 0 || P > 1 || dilation < 1) return DFE_ERR_UNSUPPORTED;
-  if (dilation > 1) P = 1;
+  if (P < 0 || P > 1) return DFE_ERR_UNSUPPORTED;
   WgPlan p;
-  if (!wg_plan(B, Ci, Co, H, W, P, dilation, &p)) return dilation > 1 ? DFE_ERR_UNSUPPORTED : DFE_ERR_DIMS;
-  const long gplane = dilation > 1 ? static_cast<long>(H) * W : static_cast<long>(p.Ho) * p.Wo;
+  if (!wg_plan(B, Ci, Co, H, W, P, &p)) return DFE_ERR_DIMS;
+  const long gplane = static_cast<long>(p.Ho) * p.Wo;
   if (x_batch_stride < static_cast<long>(Ci) * H * W || gy_batch_stride < Co * gplane) return DFE_ERR_DIMS;
   // 32-bit offsets inside one sample
   if (static_cast<long>(Ci) * H * W >= (1L << 30) || Co * gplane >= (1L << 30) || static_cast<long>(Co) * Ci * 9 >= (1L << 30)) return DFE_ERR_DIMS;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const bool gen = dilation > 1;
 #define WG_GO(MHV, NHV, TWV) do { \
-    if (gen) wg_launch<MHV, NHV, TWV, 1, true>(p, x, x_batch_stride, gy, gy_batch_stride, ws, Ci, Co, H, W, dilation, st); \
-    else if (P == 1) wg_launch<MHV, NHV, TWV, 1, false>(p, x, x_batch_stride, gy, gy_batch_stride, ws, Ci, Co, H, W, 1, st); \
-    else wg_launch<MHV, NHV, TWV, 0, false>(p, x, x_batch_stride, gy, gy_batch_stride, ws, Ci, Co, H, W, 1, st); } while (0)
+    if (P == 1) wg_launch<MHV, NHV, TWV, 1>(p, x, x_batch_stride, gy, gy_batch_stride, ws, Ci, Co, H, W, st); \
+    else wg_launch<MHV, NHV, TWV, 0>(p, x, x_batch_stride, gy, gy_batch_stride, ws, Ci, Co, H, W, st); } while (0)
   if (p.mh == 2 && p.twc == 12) WG_GO(2, 1, 12);
   else if (p.mh == 2) WG_GO(2, 1, 8);
   else if (p.nh == 2) WG_GO(1, 2, 8);

@@ -804,24 +804,36 @@ def wino_conv3x3(x, w, padding=1, transposed=False, dilation=1):
     return y
 
 
+def phase_images(t, d):
+    """[B,C,H,W] -> [B d^2, C, H/d, W/d]: the d x d phase images x[:, :, p::d, q::d] stacked along the batch (one strided copy).
+    A dilation-d 3x3 convolution with padding d is a dense 3x3 convolution with padding 1 on them."""
+    B, C, H, W = t.shape
+    return t.reshape(B, C, H // d, d, W // d, d).permute(0, 3, 5, 1, 2, 4).reshape(B * d * d, C, H // d, W // d)
+
+
 def wino_wgrad3x3(x, gy, padding=1, dilation=1):
     """Weight gradient [Co,Ci,3,3] of a 3x3 stride-1 convolution of x [B,Ci,H,W] with ``padding`` in {0, 1} (or dilated with
-    padding = dilation) for the output gradient gy [B,Co,Ho,Wo], on dfe_wino_wgrad3x3 (Winograd domain, fp32 MFMA).  x and gy
-    may be batch-strided views (channel slices of concatenated buffers)."""
+    padding = dilation: on the phase images) for the output gradient gy [B,Co,Ho,Wo], on dfe_wino_wgrad3x3 (Winograd domain,
+    fp32 MFMA).  x and gy may be batch-strided views (channel slices of concatenated buffers)."""
+    d = int(dilation)
+    if d > 1:
+        if x.shape[2] % d or x.shape[3] % d or gy.shape[2:] != x.shape[2:]:
+            raise _lib.DfeError("wino_wgrad3x3: a dilated layer needs H and W to be multiples of the dilation and padding = dilation")
+        x, gy, padding = phase_images(x, d), phase_images(gy, d), 1
     def dense_chw(t):
         return t.dtype == torch.float32 and t.stride(3) == 1 and t.stride(2) == t.shape[3] and t.stride(1) == t.shape[2] * t.shape[3]
     x = x if dense_chw(x) else f32c(x)
     gy = gy if dense_chw(gy) else f32c(gy)
     B, Ci, H, W = x.shape
-    Co, P, d = int(gy.shape[1]), int(padding), int(dilation)
+    Co, P = int(gy.shape[1]), int(padding)
     lib = get_lib()
     gw = torch.empty(Co, Ci, 3, 3, device=x.device, dtype=torch.float32)
-    n = lib.dfe_wino_wgrad_floats(B, Ci, Co, H, W, P, d)
+    n = lib.dfe_wino_wgrad_floats(B, Ci, Co, H, W, P)
     if n <= 0:
-        raise _lib.DfeError("dfe_wino_wgrad3x3: unsupported shape %s dilation %d" % (tuple(x.shape), d))
+        raise _lib.DfeError("dfe_wino_wgrad3x3: unsupported shape %s padding %d" % (tuple(x.shape), P))
     ws = torch.empty(n, device=x.device, dtype=torch.float32)
-    check(lib.dfe_wino_wgrad3x3(ptr(x), x.stride(0), ptr(gy), gy.stride(0), ptr(gw), ptr(ws), B, Ci, Co, H, W, P, d, stream_ptr()),
-          "dfe_wino_wgrad3x3")
+    check(lib.dfe_wino_wgrad3x3(ptr(x, strided=True), x.stride(0), ptr(gy, strided=True), gy.stride(0), ptr(gw), ptr(ws), B, Ci, Co, H, W, P,
+                                stream_ptr()), "dfe_wino_wgrad3x3")
     return gw
 
 
