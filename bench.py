@@ -418,6 +418,10 @@ def multi_gpu_evidence(wl, world, rank, dev, dt_local, args):
           "rccl_ranks": int(ids[1].item()), "rank_id_allreduce_ok": bool(ids_ok),
           "ms_per_step_min": round(min(times), 4), "ms_per_step_max": round(max(times), 4),
           "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE")}
+    if hasattr(model, "message_bytes"):      # ddp.FlatAllReduce: one message per network branch, issued from backward
+        ev["allreduce_message_bytes"] = model.message_bytes()
+        ev["allreduce_issue_order"] = list(model._order or model.branches)
+        ev["messages_issued_from_backward"] = int(model.early_hits)
     if sums is not None:
         ev["param_checksum_rank0"] = sums[0]
         ev["param_checksums_equal"] = all(s_ == sums[0] for s_ in sums)

@@ -227,6 +227,125 @@ def test_two_process_gloo_matches_single_process(tmp_path, strategy, monkeypatch
     np.testing.assert_allclose(g2.numpy(), g1.numpy(), rtol=2e-5, atol=1e-7)
 
 
+class _ThreeBranches(torch.nn.Module):
+    """Three independent branches under the joint model's names (depth_net / pose_net / fpyramid + pwc_model)."""
+
+    def __init__(self):
+        super().__init__()
+        mk = lambda: torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(), torch.nn.Linear(8, 1))
+        self.depth_net, self.pose_net, self.fpyramid, self.pwc_model = mk(), mk(), mk(), torch.nn.Linear(1, 1)
+
+    def forward(self, x, use=("depth", "pose", "flow")):
+        out = x.new_zeros(x.shape[0], 1)
+        if "flow" in use:
+            out = out + self.pwc_model(self.fpyramid(x))
+        if "pose" in use:
+            out = out + 2.0 * self.pose_net(x)
+        if "depth" in use:
+            out = out + 3.0 * self.depth_net(x)
+        return out
+
+
+def _branch_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    from unsupervised_depth_opticalflow_egomotion_amd import ddp
+    torch.set_num_threads(1)
+    ddp.init_process_group("gloo")
+    torch.manual_seed(0)
+    net = _ThreeBranches()
+    model = ddp.wrap(net)
+    assert type(model).__name__ == "FlatAllReduce" and model.branches == ["depth_net", "pose_net", "flow"]
+    torch.manual_seed(5)
+    x = torch.randn(8, 6)
+    xs = x[ddp.shard_indices(8, world, rank)]
+    res = {}
+
+    def grads():
+        return {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
+    # step 1: calibration (no trigger yet: everything is reduced in reduce_gradients); step 2: the three messages leave from backward
+    for step in (1, 2):
+        net.zero_grad()
+        model(xs).pow(2).mean().backward()
+        model.reduce_gradients()
+        res["step%d" % step] = grads()
+    res["early_hits"] = model.early_hits
+    res["order"], res["triggers"] = list(model._order), dict(model.triggers)
+    res["in_flat"] = all(model._flat.data_ptr() <= p.grad.data_ptr() < model._flat.data_ptr() + 4 * model._flat.numel()
+                         for p in net.parameters())
+    res["bytes"] = model.message_bytes()
+    # a gradient that changes after its branch's message left (second backward pass before the step): reduced again
+    net.zero_grad()
+    model(xs).pow(2).mean().backward()
+    model(xs).abs().mean().backward()
+    model.reduce_gradients()
+    res["two_backwards"] = grads()
+    # ranks whose sets of parameters with gradients differ: rank 1 runs without the pose branch, nobody runs the flow branch
+    net.zero_grad()
+    model(xs, use=("depth", "pose") if rank == 0 else ("depth",)).pow(2).mean().backward()
+    model.reduce_gradients()
+    res["partial"] = grads()
+    # a rank without any gradient still joins the collectives
+    net.zero_grad()
+    if rank == 0:
+        model(xs).pow(2).mean().backward()
+    model.reduce_gradients()
+    res["one_rank"] = grads()
+    torch.save(res, out + str(rank))
+    torch.distributed.destroy_process_group()
+
+
+def test_branch_overlapped_reducer_two_ranks(tmp_path, monkeypatch):
+    """ddp.FlatAllReduce (round 5): one all-reduce per network branch, issued from backward by ONE hook per branch.  Two gloo
+    ranks: gradients equal the single-process ones; from step 2 on all three messages leave during backward; a second
+    backward pass before the step is detected and reduced again; ranks with different sets of gradients neither hang nor
+    diverge (a gradient on any rank -> the averaged gradient on every rank; none anywhere -> None)."""
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("DFE_DP_STRATEGY", "flat")
+    out = str(tmp_path / "b.pt")
+    mp.spawn(_branch_worker, args=(2, 29500 + (os.getpid() % 2000) + 19, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + "0"), torch.load(out + "1")
+    torch.manual_seed(0)
+    net = _ThreeBranches()
+    torch.manual_seed(5)
+    x = torch.randn(8, 6)
+
+    def single(loss_fns, use=("depth", "pose", "flow")):
+        net.zero_grad()
+        for f in loss_fns:
+            # equal shards + averaging = the mean over the two shards' losses
+            sum(f(net(x[i::2], use)) for i in (0, 1)).mul(0.5).backward()
+        return {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
+    sq, ab = (lambda y: y.pow(2).mean()), (lambda y: y.abs().mean())
+    ref = single([sq])
+    for r in (r0, r1):
+        for key in ("step1", "step2"):
+            for n in ref:
+                np.testing.assert_allclose(r[key][n].numpy(), ref[n].numpy(), rtol=1e-5, atol=1e-7, err_msg=key + n)
+        assert r["early_hits"] >= 3 and r["in_flat"] and sorted(r["order"]) == ["depth_net", "flow", "pose_net"]
+        assert r["bytes"] == {"depth_net": 4 * (65 + 4), "pose_net": 4 * (65 + 4), "flow": 4 * (67 + 6)}
+        # the trigger of a branch = its FIRST layer's weight or bias (the last gradient backward produces there)
+        assert r["triggers"]["depth_net"].startswith("depth_net.0.") and r["triggers"]["flow"].startswith("fpyramid.0.")
+    assert r0["order"] == r1["order"]
+    ref2 = single([sq, ab])
+    for r in (r0, r1):
+        for n in ref2:
+            np.testing.assert_allclose(r["two_backwards"][n].numpy(), ref2[n].numpy(), rtol=1e-5, atol=1e-7, err_msg="two " + n)
+    # partial: depth from both ranks; pose only from rank 0 (averaged with rank 1's zeros); flow from nobody
+    net.zero_grad()
+    (0.5 * (sq(net(x[0::2], ("depth", "pose"))) + sq(net(x[1::2], ("depth",))))).backward()
+    for r in (r0, r1):
+        for n, p in net.named_parameters():
+            if n.startswith(("fpyramid", "pwc_model")):
+                assert r["partial"][n] is None, n
+            else:
+                np.testing.assert_allclose(r["partial"][n].numpy(), p.grad.numpy(), rtol=1e-5, atol=1e-7, err_msg="partial " + n)
+    net.zero_grad()
+    (0.5 * sq(net(x[0::2]))).backward()
+    for r in (r0, r1):
+        for n, p in net.named_parameters():
+            np.testing.assert_allclose(r["one_rank"][n].numpy(), p.grad.numpy(), rtol=1e-5, atol=1e-7, err_msg="one " + n)
+
+
 class _RealDepthNets(torch.nn.Module):
     """The product's own Depth_Model (ResNet-18 encoder incl. the never-used fc, grouped BatchNorm, fused-decoder
     modules on their host path) under a ``depth_net.`` prefix like Model_depth, plus a learnable pose."""

@@ -2,10 +2,10 @@
 
 Replaces the reference's single-process ``nn.DataParallel`` (train.py:59-60,277-283).  Every loss term is a
 per-sample (B,) vector with per-sample normalisers, so equal shards + gradient averaging reproduce the
-single-process gradient.  One collective per step: the all-reduce of 21.06 M fp32 gradients (84 MB:
-the model's 21.57 M parameters minus the never-used 513 k of ``depth_net.encoder.encoder.fc``) -- as ONE flat message
-after backward (``FlatAllReduce``, the default since round 4) or bucketed and overlapped with backward by torch's
-DistributedDataParallel (``strategy="torch"``).  The loss-stack kernels themselves are single-GPU; nothing on the data
+single-process gradient.  The one exchange per step is the all-reduce of 21.06 M fp32 gradients (84 MB:
+the model's 21.57 M parameters minus the never-used 513 k of ``depth_net.encoder.encoder.fc``) -- as one flat message per
+network branch, issued as that branch's backward pass ends (``FlatAllReduce``, the default) or bucketed and overlapped
+with backward by torch's DistributedDataParallel (``strategy="torch"``).  The loss-stack kernels themselves are single-GPU; nothing on the data
 path is exchanged."""
 import os
 
@@ -59,39 +59,70 @@ def unused_parameter_names(model):
             if ".encoder.encoder.fc." in n or n.startswith("encoder.encoder.fc.")]
 
 
+def _branch_of(name):
+    """The network a parameter belongs to: the three branches of the joint model run their backward passes on their own
+    streams (models.run_networks) and finish at different times."""
+    head = name.split(".", 1)[0]
+    return "flow" if head in ("fpyramid", "pwc_model") else head
+
+
 class FlatAllReduce(torch.nn.Module):
-    """The model's replica in a data-parallel job, round 4's default (``wrap(strategy="flat")``).
+    """The model's replica in a data-parallel job, the default (``wrap(strategy="flat")``).
 
-    One collective per step, issued AFTER backward: the gradients are copied into ONE persistent flat fp32 buffer (a
-    single multi-tensor copy kernel), all-reduced in place as one 84 MB message -- the size RCCL's ring over xGMI is most
-    efficient at -- and handed to the optimiser as views of that buffer (no copy back: ``optim.FusedAdam`` refreshes its
-    gradient pointers every step).  ``make_optimizer`` hooks ``reduce_gradients`` in front of ``optimizer.step()``, so the
-    reference's loop (``loss.backward(); optimizer.step()``, train.py:215-216) needs no extra call.
+    The gradients live in ONE persistent flat fp32 buffer, one contiguous segment per network branch (depth / pose / flow:
+    57 / 5 / 22 MB of the joint model's 84 MB), and each segment is all-reduced as one message -- the sizes RCCL's ring
+    over xGMI is efficient at -- and handed to the optimiser as views of the buffer (no copy back: ``optim.FusedAdam``
+    refreshes its gradient pointers every step).
 
-    Why not torch's DistributedDataParallel (``strategy="torch"`` keeps it): measured on MI355X at world size 1 around the
-    real joint model (profiles/r04_ddp_overhead.txt; plain step 25.3 ms) its reducer costs 2.5-3.1 ms per step in
-    per-parameter autograd hooks and bookkeeping (250 parameters) before any byte is communicated -- a weak-scaling
-    ceiling of 0.89-0.91 -- and its ``static_graph`` mode, which would halve that, silently stops reducing this model's
-    gradients on the device (cross-rank parameter checksums diverge: bench.py's multi_gpu evidence caught it).  This
-    class costs 0.1 ms per step at world size 1; what it gives up is the overlap of the all-reduce with backward
-    (~1 ms of ring time at 8 GPUs, exposed: expected efficiency ~0.96).
+    Overlap without per-parameter hooks (round 5).  torch's DistributedDataParallel pays 2.5-3.1 ms per step for its 250
+    autograd hooks (profiles/r04_ddp_overhead.txt).  Here ONE hook per branch sits on the parameter whose gradient arrives
+    last in that branch (found on the first backward pass: the first layer's weight): when it fires, every gradient of the
+    branch has been enqueued, so the branch's segment is filled by one multi-tensor copy and its all-reduce is issued with
+    ``async_op=True`` right there -- the communicator's (high-priority) stream waits for the stream the hook runs on and the
+    ring runs under the other branches' backward kernels.  ``reduce_gradients`` (hooked in front of ``optimizer.step()`` by
+    ``make_optimizer``; the reference's loop, train.py:215-216, needs no extra call) only waits for the three messages;
+    whatever was not issued by then (first step, a branch without gradients) is reduced there.  At 8 GPUs only the branch
+    that finishes last stays exposed.  Safety nets: the collectives are always issued in ONE fixed branch order on every
+    rank; a gradient that changes after its branch was reduced (a second backward pass, late accumulation) is detected by
+    identity + version and the branch is reduced again; every segment carries a presence word per parameter, so ranks
+    whose sets of parameters with gradients differ neither hang nor diverge (a parameter with a gradient on ANY rank gets
+    the averaged gradient on EVERY rank, as with DistributedDataParallel; one without a gradient anywhere keeps ``None``).
 
     The never-used ``fc`` parameters are left out (no gradient ever exists for them).  Parameters and buffers start from
     rank 0's values (one coalesced broadcast at construction); BatchNorm's running statistics are NOT re-broadcast every
     forward: train-mode forwards do not read them and rank 0's are what checkpoints hold either way (the reference's
     DataParallel keeps device 0's and discards the replicas', train.py:59-60)."""
 
-    def __init__(self, module, ignore=()):
+    def __init__(self, module, ignore=(), overlap=None):
         super().__init__()
         self.module = module
         self.world = dist.get_world_size()
         self.backend = dist.get_backend()
         self.ignored = sorted(ignore)
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad and n not in set(ignore)]
+        # flat order: branch by branch (first appearance), parameters in module order inside a branch
+        order = []
+        for n, _ in named:
+            if _branch_of(n) not in order:
+                order.append(_branch_of(n))
+        named.sort(key=lambda t: order.index(_branch_of(t[0])))
+        self._names = [n for n, _ in named]
         self._params = [p for _, p in named]
+        self.branches = order
+        self._members = {k: [i for i, n in enumerate(self._names) if _branch_of(n) == k] for k in order}
         self._numel = sum(p.numel() for p in self._params)
         self._flat = None
         self._views = None
+        self._seg = None                 # branch -> (offset, gradient floats, total floats incl. the presence words)
+        self.overlap = (os.environ.get("DFE_DP_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
+        self._order = None               # the fixed order the branches' collectives are issued in (= arrival order, step 1)
+        self._arrival = []               # calibration (first backward): parameter indices in arrival order
+        self._hooks = []
+        self._ready, self._issued, self._work, self._sig = set(), [], {}, {}
+        self.early_hits = 0              # branches whose all-reduce was issued from backward (statistics / tests)
+        if self.overlap:
+            for i, p in enumerate(self._params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, i=i: self._arrival.append(i)))
         tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
         if tensors and self.world > 1:
             dist._broadcast_coalesced(dist.group.WORLD, tensors, 250 * 1024 * 1024, 0)
@@ -102,40 +133,129 @@ class FlatAllReduce(torch.nn.Module):
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
+    def message_bytes(self):
+        """Per-branch all-reduce message sizes in bytes (gradients + one presence word per parameter)."""
+        return {k: 4 * (sum(self._params[i].numel() for i in self._members[k]) + len(self._members[k])) for k in self.branches}
+
     def _buffers_for(self, ref):
         if self._flat is None or self._flat.device != ref.device:
-            self._flat = torch.zeros(self._numel, device=ref.device, dtype=torch.float32)
-            self._views, off = [], 0
-            for p in self._params:
-                self._views.append(self._flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
+            total = self._numel + len(self._params)
+            self._flat = torch.zeros(total, device=ref.device, dtype=torch.float32)
+            self._views, self._seg, self._present, off = [None] * len(self._params), {}, {}, 0
+            for k in self.branches:
+                beg = off
+                for i in self._members[k]:
+                    p = self._params[i]
+                    self._views[i] = self._flat[off:off + p.numel()].view_as(p)
+                    off += p.numel()
+                self._present[k] = self._flat[off:off + len(self._members[k])]
+                off += len(self._members[k])
+                self._seg[k] = (beg, off - beg)
         return self._flat, self._views
+
+    # ------------------------------------------------------------------ one branch
+    def _issue(self, k):
+        """Fill branch k's segment from the gradients that exist and start its all-reduce (asynchronous)."""
+        idx = self._members[k]
+        grads = [self._params[i].grad for i in idx]
+        ref = next((g for g in grads if g is not None), self._params[idx[0]])
+        flat, views = self._buffers_for(ref)
+        have = [j for j, g in enumerate(grads) if g is not None]
+        if len(have) == len(idx):
+            torch._foreach_copy_([views[i] for i in idx], grads)
+            self._present[k].fill_(1.0)
+        else:
+            present = torch.zeros(len(idx))
+            for j in have:
+                present[j] = 1.0
+            self._present[k].copy_(present)
+            for j, i in enumerate(idx):
+                if grads[j] is None:
+                    views[i].zero_()              # a parameter without a gradient on this rank contributes zeros
+            if have:
+                torch._foreach_copy_([views[idx[j]] for j in have], [grads[j] for j in have])
+        beg, n = self._seg[k]
+        seg = flat[beg:beg + n]
+        if self.backend == "nccl":
+            self._work[k] = (dist.all_reduce(seg, op=dist.ReduceOp.AVG, async_op=True), seg, len(have) == len(idx))
+        else:
+            self._work[k] = (dist.all_reduce(seg, async_op=True), seg, len(have) == len(idx))
+        self._sig[k] = self._signature(k)
+        self._issued.append(k)
+
+    def _signature(self, k):
+        """Identity + version of the branch's first and last gradients: a second backward pass (or any in-place accumulation)
+        after the branch's message left changes them."""
+        idx = self._members[k]
+        return tuple((id(g), g._version) if g is not None else None for g in (self._params[idx[0]].grad, self._params[idx[-1]].grad))
+
+    def _pump(self):
+        """Issue every ready branch whose predecessors (in the fixed order) have been issued."""
+        for k in self._order:
+            if k in self._issued:
+                continue
+            if k not in self._ready:
+                break
+            self._issue(k)
+            self.early_hits += 1
+
+    def _trigger(self, k):
+        # backward of a second loss in the same step: the branch was already reduced -> reduce_gradients sees the changed
+        # versions and reduces it again
+        if k in self._issued or any(self._params[i].grad is None for i in self._members[k]):
+            return
+        self._ready.add(k)
+        self._pump()
+
+    def _arm(self):
+        """After the first backward pass: one trigger per branch, on the parameter whose gradient arrived last."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        last, pos = {}, {i: n for n, i in enumerate(self._arrival)}
+        for k in self.branches:
+            seen = [i for i in self._members[k] if i in pos]
+            if seen:
+                last[k] = max(seen, key=lambda i: pos[i])
+        # fixed issue order on every rank: branches in the order their backward passes finished (the same graph on every rank),
+        # branches that produced nothing last
+        self._order = sorted(self.branches, key=lambda k: pos[last[k]] if k in last else len(pos) + self.branches.index(k))
+        self.triggers = {k: self._names[i] for k, i in last.items()}
+        for k, i in last.items():
+            self._hooks.append(self._params[i].register_post_accumulate_grad_hook(lambda _p, k=k: self._trigger(k)))
+        self._arrival = None
 
     @torch.no_grad()
     def reduce_gradients(self):
-        """Average the gradients over the ranks (call once after backward; ``make_optimizer`` does it before every step)."""
-        grads = [p.grad for p in self._params]
-        if all(g is not None for g in grads):        # the steady state: every reducible parameter has a gradient
-            flat, views = self._buffers_for(grads[0])
-            torch._foreach_copy_(views, grads)
-            have = None
-        else:
-            have = [i for i, g in enumerate(grads) if g is not None]
-            if not have:
-                return
-            flat, views = self._buffers_for(grads[have[0]])
-            present = set(have)
-            for i, v in enumerate(views):            # a parameter without a gradient this step contributes zeros
-                if i not in present:
-                    v.zero_()
-            torch._foreach_copy_([views[i] for i in have], [grads[i] for i in have])
-        if self.backend == "nccl":
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG)
-        else:
-            dist.all_reduce(flat)
-            flat.div_(self.world)
-        for i in (range(len(views)) if have is None else have):
-            self._params[i].grad = views[i]
+        """Average the gradients over the ranks (call once after backward; ``make_optimizer`` does it before every step):
+        waits for the branch messages issued during backward and reduces whatever is left, in the fixed order."""
+        if self.overlap and self._arrival is not None and self._arrival:
+            self._arm()
+        order = self._order or self.branches
+        for k in order:
+            stale = False
+            if k in self._issued:       # issued from backward: still the gradients it copied?
+                stale = self._signature(k) != self._sig[k]
+                if stale:
+                    self._work.pop(k)[0].wait()
+                    self._issued.remove(k)
+            if k not in self._issued:
+                self._issue(k)
+        for k in order:
+            work, seg, complete = self._work.pop(k)
+            work.wait()
+            if self.backend != "nccl":
+                seg.div_(self.world)
+            idx = self._members[k]
+            if complete:
+                for i in idx:
+                    self._params[i].grad = self._views[i]
+            else:       # rare: some parameter had no gradient here -- does any rank have one?  (one device -> host copy)
+                present = self._present[k].cpu()
+                for j, i in enumerate(idx):
+                    if float(present[j]) > 0.0:
+                        self._params[i].grad = self._views[i]
+        self._ready, self._issued, self._sig = set(), [], {}
 
 
 def wrap(model, device=None, bucket_cap_mb=25, force=False, strategy=None):
