@@ -306,6 +306,13 @@ long dfe_wino_transform_blocks(int Ci, int Co);
 int dfe_wino_transform_weights_multi(const long* table, const int* blockmap, int n_blocks, void* stream);
 int dfe_wino_conv3x3_u(const float* x, const float* U, float* y, long y_batch_stride, float* part, long part_floats, int B, int Ci,
                        int Co, int H, int W, int P, int dilation, void* stream);
+/* dfe_wino_conv3x3_u with the bias + activation epilogue inside the output transform (net_utils.py:7-11 conv() = Conv2d +
+ * LeakyReLU(0.1); pwc_tf.py:113-118): y = act(conv(x) + bias[co]), act(v) = v > 0 ? v : slope * v (slope 1: bias only; bias may
+ * be null) -- bit for bit what dfe_bias_act_fwd makes of dfe_wino_conv3x3_u's output -- written to y and, when y2 is not null,
+ * to the same (b, co, i) of y2 (batch stride y2_batch_stride): the two concatenated buffers a PWC decoder layer feeds. */
+int dfe_wino_conv3x3_u_act(const float* x, const float* U, const float* bias, float slope, float* y, long y_batch_stride, float* y2,
+                           long y2_batch_stride, float* part, long part_floats, int B, int Ci, int Co, int H, int W, int P,
+                           int dilation, void* stream);
 
 /* ---- 1x1 convolutions on tiny planes (H*W <= 256, B*H*W <= 4096): PoseCNN's pose_conv and refinement head
  * (pose_cnn.py:32,43,48: Conv2d(256 | 24 | 12, 12, 1) on 2x7 planes).  x [B,Ci,H,W], weight [Co,Ci] (= [Co,Ci,1,1]).

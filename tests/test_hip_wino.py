@@ -120,6 +120,51 @@ def test_wino_wgrad_reads_batch_strided_views_and_rejects_bad_arguments():
     assert lib.dfe_wino_wgrad_floats(1, 8, 8, 4, 4, 2) == 0 and lib.dfe_wino_wgrad_tune(22, 0, 0, 0) != 0
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 64, 64, 208, 1, 1), (1, 115, 128, 32, 104, 1, 1), (2, 96, 32, 34, 50, 0, 1), (3, 17, 33, 7, 9, 1, 1),
+                                   (2, 24, 16, 12, 20, 1, 1), (12, 512, 512, 8, 26, 1, 1), (2, 130, 40, 8, 8, 0, 1), (2, 32, 32, 16, 32, 1, 4),
+                                   (1, 40, 20, 16, 48, 1, 8)])
+def test_wino_fused_epilogue_is_the_separate_pass_bit_for_bit(shape):
+    """dfe_wino_conv3x3_u_act (round 5): bias + LeakyReLU inside the output transform, written to one or two destination
+    buffers at channel offsets -- equal, bit for bit, to dfe_bias_act_fwd applied to the plain kernel's output (plain,
+    half-tile, channel-split, valid and dilated forms; cached and per-call filters)."""
+    B, Ci, Co, H, W, P, d = shape
+    torch.manual_seed(sum(shape))
+    x = torch.randn(B, Ci, H, W, device=dev())
+    w = torch.randn(Co, Ci, 3, 3, device=dev()) / (3.0 * Ci ** 0.5)
+    bias = torch.randn(Co, device=dev())
+    plain = ops.wino_conv3x3(x, w, P, dilation=d)
+    for slope in (0.1, 0.0, 1.0):
+        ref = ops.bias_act(plain.clone(), bias, slope)
+        y = ops.wino_conv3x3(x, w, P, dilation=d, bias=bias, slope=slope)
+        assert torch.equal(y, ref), slope
+    ref = ops.bias_act(plain.clone(), bias, 0.1)
+    d1 = torch.full((B, Co + 5, *plain.shape[2:]), 7.0, device=dev())
+    d2 = torch.full((B, Co + 3, *plain.shape[2:]), 9.0, device=dev())
+    r = ops.wino_conv3x3(x, w, P, dilation=d, bias=bias, slope=0.1, out=d1, out_off=2, out2=d2, out2_off=3)
+    assert r is d1 and torch.equal(d1[:, 2:2 + Co], ref) and torch.equal(d2[:, 3:], ref)
+    assert bool((d1[:, :2] == 7.0).all()) and bool((d1[:, 2 + Co:] == 7.0).all()) and bool((d2[:, :3] == 9.0).all())
+    assert torch.equal(ops.wino_conv3x3(x, w, P, dilation=d, slope=0.1), ops.bias_act(plain.clone(), None, 0.1))     # no bias
+
+
+def test_conv_bias_act_function_matches_the_two_node_graph():
+    """ops.ConvBiasActFn (net_utils.conv on the Winograd kernel: one launch forward, one autograd node) against
+    bias_act(conv2d(...)): outputs and the input / bias gradients equal bit for bit (same kernels underneath)."""
+    from unsupervised_depth_opticalflow_egomotion_amd import convs
+    torch.manual_seed(21)
+    for (B, Ci, Co, H, W, d) in [(2, 32, 48, 32, 104, 1), (1, 64, 64, 32, 64, 2)]:
+        conv = torch.nn.Conv2d(Ci, Co, 3, 1, d, d).to(dev())
+        x = torch.randn(B, Ci, H, W, device=dev(), requires_grad=True)
+        assert ops.conv_bias_act_eligible(x, conv)
+        y = ops.conv_bias_act(x, conv, 0.1)
+        g = torch.randn_like(y)
+        gx, gw, gb = torch.autograd.grad(y, [x, conv.weight, conv.bias], g)
+        y2 = ops.bias_act(convs.conv2d(x, conv.weight, None, 1, d, d), conv.bias, 0.1)
+        gx2, gw2, gb2 = torch.autograd.grad(y2, [x, conv.weight, conv.bias], g)
+        assert torch.equal(y, y2) and torch.equal(gx, gx2) and torch.equal(gb, gb2)
+        # (small layers' weight gradients are MIOpen's: split-K float atomics, not reproducible bit for bit)
+        assert float((gw - gw2).abs().max()) <= 1e-5 * float(gw2.abs().max())
+
+
 # ---- transformed filters kept across steps (ops.WinoWeightCache, dfe_wino_transform_weights_multi / dfe_wino_conv3x3_u)
 CACHE_SHAPES = [(2, 64, 64, 64, 208, 1, 1), (1, 115, 128, 32, 104, 1, 1), (2, 96, 32, 34, 50, 0, 1), (3, 17, 33, 7, 9, 1, 1),
                 (2, 24, 16, 12, 20, 1, 1), (12, 512, 512, 8, 26, 1, 1), (2, 130, 40, 8, 8, 0, 1), (2, 32, 32, 16, 32, 1, 4),

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "dfe_wino_transform_blocks": [_I, _I],
     "dfe_wino_transform_weights_multi": [_P, _P, _I, _P],
     "dfe_wino_conv3x3_u": [_P, _P, _P, ctypes.c_long, _P, ctypes.c_long, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dfe_wino_conv3x3_u_act": [_P, _P, _P, ctypes.c_float, _P, ctypes.c_long, _P, ctypes.c_long, _P, ctypes.c_long, _I, _I, _I, _I, _I, _I, _I, _P],
     "dfe_conv1x1_small_supported": [_I, _I, _I, _I, _I],
     "dfe_conv1x1_small_fwd": [_P, _P, _P, ctypes.c_float, _P, _I, _I, _I, _I, _I, _P],
     "dfe_conv1x1_small_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -26,6 +26,13 @@ namespace dfe {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Optional epilogue of the output transform (round 5): y = act(conv + bias[k]) with act(v) = v > 0 ? v : slope v -- the arithmetic
+// of dfe_bias_act_fwd / _fwd2 (ops_epilogue.hip), bit for bit, written to y and (optionally) to the same channels of a second
+// buffer: the PWC decoder's concatenated inputs (pwc_tf.py:113-118) and net_utils.conv's Conv2d + LeakyReLU (net_utils.py:7-11)
+// no longer pay a read-modify-write pass over every convolution output.  bias == nullptr and slope == 1: no epilogue.
+struct WinoEpi { const float* bias; float slope; float* y2; long y2bs; };
+__device__ __forceinline__ float wino_act(float v, float bv, float slope) { v += bv; return v > 0.0f ? v : v * slope; }
+
 constexpr int WN_CC = 16;        // input channels per staged weight slab
 constexpr int WN_XP = 20;        // LDS floats per (channel, k): 16 positions + 4 pad (16-byte reads, 64 banks over 16 lanes)
 
@@ -79,14 +86,17 @@ __global__ void __launch_bounds__(256) k_wino_weights_multi(const long* __restri
   else wino_weight_one<false>(w, U, K, C, Kpad, idx);
 }
 
-// y[b][k][i] = sum over the channel splits of part[sp][b][k][i], in split order
-__global__ void __launch_bounds__(256) k_wino_sum(const float* __restrict__ part, float* __restrict__ y, long ybs, int nsp, int B, long KHW) {
+// y[b][k][i] = act(sum over the channel splits of part[sp][b][k][i], in split order, + bias[k])
+__global__ void __launch_bounds__(256) k_wino_sum(const float* __restrict__ part, float* __restrict__ y, long ybs, int nsp, int B, long KHW,
+                                                  long HWo, WinoEpi epi) {
   const long idx = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
   if (idx >= B * KHW) return;
   float s = part[idx];
   for (int k = 1; k < nsp; ++k) s += part[static_cast<long>(k) * B * KHW + idx];
-  const long b = idx / KHW;
-  y[b * ybs + (idx - b * KHW)] = s;
+  const long b = idx / KHW, r = idx - b * KHW;
+  if (epi.bias || epi.slope != 1.0f) s = wino_act(s, epi.bias ? epi.bias[r / HWo] : 0.0f, epi.slope);
+  y[b * ybs + r] = s;
+  if (epi.y2) epi.y2[b * epi.y2bs + r] = s;
 }
 
 // x [B,C,H,W]; y [B,K,Ho,Wo], Ho = H + 2P - 2, Wo = W + 2P - 2 (P = 1: zero padding, 0: valid, 2: full); element (b,k,i) of y at
@@ -100,7 +110,7 @@ template <int PP, int NW, int NH>   // PP = 0 / 1 / 2: the padding, pair loads (
                                     // exist (1 when Co <= 16: half the MFMAs, half the accumulators)
 __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restrict__ x, const float* __restrict__ U, float* __restrict__ y,
                                                        long ybs, int B, int C, int K, int H, int W, int P, int TH, int TW, int ntiles,
-                                                       unsigned nkt, int dil, unsigned nsp, int cps, float* __restrict__ part) {
+                                                       unsigned nkt, int dil, unsigned nsp, int cps, float* __restrict__ part, WinoEpi epi) {
   extern __shared__ float lds[];      // [WN_CC][32][WN_XP]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
   // logical block id = tile block * nkt + kt, dealt so that the nkt blocks of one tile range (they load the same patches)
@@ -324,7 +334,11 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
   const int oy = 2 * ty, ox = 2 * tx;
   const int sy = dil * Wo, sx = dil;                // strides of the 2x2 outputs in y
   const long kplane = static_cast<long>(Ho) * Wo;
-  float* yb = (nsp > 1 ? part + (static_cast<long>(sp) * B + b) * K * kplane : y + b * ybs) + static_cast<long>(py + dil * oy) * Wo + px + dil * ox;
+  const long ooff = static_cast<long>(py + dil * oy) * Wo + px + dil * ox;
+  float* yb = (nsp > 1 ? part + (static_cast<long>(sp) * B + b) * K * kplane : y + b * ybs) + ooff;
+  // with channel splits the epilogue belongs to k_wino_sum (the partial outputs are sums of a part of the channels)
+  const bool fused = nsp == 1 && (epi.bias != nullptr || epi.slope != 1.0f);
+  float* y2b = (nsp == 1 && epi.y2) ? epi.y2 + b * epi.y2bs + ooff : nullptr;
 #pragma unroll
   for (int h = 0; h < NH; ++h)
 #pragma unroll
@@ -337,8 +351,13 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
         t0[s] = (acc[h][s][r] + acc[h][4 + s][r]) + acc[h][8 + s][r];
         t1[s] = (acc[h][4 + s][r] - acc[h][8 + s][r]) - acc[h][12 + s][r];
       }
-      const float y00 = (t0[0] + t0[1]) + t0[2], y01 = (t0[1] - t0[2]) - t0[3];
-      const float y10 = (t1[0] + t1[1]) + t1[2], y11 = (t1[1] - t1[2]) - t1[3];
+      float y00 = (t0[0] + t0[1]) + t0[2], y01 = (t0[1] - t0[2]) - t0[3];
+      float y10 = (t1[0] + t1[1]) + t1[2], y11 = (t1[1] - t1[2]) - t1[3];
+      if (fused) {
+        const float bv = epi.bias ? epi.bias[k] : 0.0f;
+        y00 = wino_act(y00, bv, epi.slope); y01 = wino_act(y01, bv, epi.slope);
+        y10 = wino_act(y10, bv, epi.slope); y11 = wino_act(y11, bv, epi.slope);
+      }
       float* o = yb + static_cast<long>(k) * Ho * Wo;
       if (oy < Hoq) {
         if (ox < Woq) o[0] = y00;
@@ -347,6 +366,17 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
       if (oy + 1 < Hoq) {
         if (ox < Woq) o[sy] = y10;
         if (ox + 1 < Woq) o[sy + sx] = y11;
+      }
+      if (y2b) {
+        float* o2 = y2b + static_cast<long>(k) * Ho * Wo;
+        if (oy < Hoq) {
+          if (ox < Woq) o2[0] = y00;
+          if (ox + 1 < Woq) o2[sx] = y01;
+        }
+        if (oy + 1 < Hoq) {
+          if (ox < Woq) o2[sy] = y10;
+          if (ox + 1 < Woq) o2[sy + sx] = y11;
+        }
       }
     }
 }
@@ -390,14 +420,14 @@ static WinoSplit wino_split(long ntiles, int Kpad, int Ci, int B, int Co, int Ho
 // weight == nullptr: wbuf already holds the transformed filters (dfe_wino_conv3x3_u) and is only read; part / part_floats: room
 // for the channel splits' partial outputs (may be null / 0)
 static int wino_run(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, float* part, long part_floats, int B,
-                    int Ci, int Co, int H, int W, int P, int dil, int transposed_weight, void* stream) {
+                    int Ci, int Co, int H, int W, int P, int dil, int transposed_weight, void* stream, WinoEpi epi = WinoEpi{nullptr, 1.0f, nullptr, 0}) {
   if (!x || !y || !wbuf) return DFE_ERR_NULL;
   const int rc = wn_dims(B, Ci, Co, H, W, P);
   if (rc != DFE_OK) return rc;
   if (dil < 1 || (dil > 1 && (P != 1 || H % dil != 0 || W % dil != 0 || H / dil < 2 || W / dil < 2))) return DFE_ERR_UNSUPPORTED;
   // dil > 1: padding = dil in pixels = 1 in phase coordinates: the output has the input's size
   const int Ho = dil > 1 ? H : H + 2 * P - 2, Wo = dil > 1 ? W : W + 2 * P - 2;
-  if (y_batch_stride < static_cast<long>(Co) * Ho * Wo) return DFE_ERR_DIMS;
+  if (y_batch_stride < static_cast<long>(Co) * Ho * Wo || (epi.y2 && epi.y2bs < static_cast<long>(Co) * Ho * Wo)) return DFE_ERR_DIMS;
   if ((reinterpret_cast<uintptr_t>(wbuf) & 15) != 0) return DFE_ERR_UNSUPPORTED;
   if (part && (reinterpret_cast<uintptr_t>(part) & 15) != 0) return DFE_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -426,7 +456,7 @@ static int wino_run(const float* x, const float* weight, float* y, long y_batch_
     const unsigned g = static_cast<unsigned>(nblk);
     const int nt = static_cast<int>(ntiles);
     const int pp = pair ? P : -1;
-#define WN_LAUNCH(PPV, NHV) k_wino_fwd16<PPV, 4, NHV><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt, dil, static_cast<unsigned>(sp.nsp), sp.cps, part)
+#define WN_LAUNCH(PPV, NHV) k_wino_fwd16<PPV, 4, NHV><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt, dil, static_cast<unsigned>(sp.nsp), sp.cps, part, epi)
     if (Co <= 16) {
       if (pp == 1) WN_LAUNCH(1, 1); else if (pp == 0) WN_LAUNCH(0, 1); else if (pp == 2) WN_LAUNCH(2, 1); else WN_LAUNCH(-1, 1);
     } else {
@@ -436,7 +466,7 @@ static int wino_run(const float* x, const float* weight, float* y, long y_batch_
     DFE_LAUNCH_CHECK();
     if (sp.nsp > 1) {
       const long khw = static_cast<long>(Co) * Ho * Wo, n = B * khw;
-      k_wino_sum<<<static_cast<unsigned>((n + 255) / 256), 256, 0, st>>>(part, y, y_batch_stride, sp.nsp, B, khw);
+      k_wino_sum<<<static_cast<unsigned>((n + 255) / 256), 256, 0, st>>>(part, y, y_batch_stride, sp.nsp, B, khw, static_cast<long>(Ho) * Wo, epi);
     }
   }
   DFE_LAUNCH_CHECK();
@@ -470,6 +500,13 @@ extern "C" int dfe_wino_conv3x3_u(const float* x, const float* U, float* y, long
                                   int Co, int H, int W, int P, int dilation, void* stream) {
   return wino_run(x, nullptr, y, y_batch_stride, const_cast<float*>(U), part, part_floats, B, Ci, Co, H, W, dilation > 1 ? 1 : P, dilation, 0,
                   stream);
+}
+
+extern "C" int dfe_wino_conv3x3_u_act(const float* x, const float* U, const float* bias, float slope, float* y, long y_batch_stride, float* y2,
+                                      long y2_batch_stride, float* part, long part_floats, int B, int Ci, int Co, int H, int W, int P,
+                                      int dilation, void* stream) {
+  return wino_run(x, nullptr, y, y_batch_stride, const_cast<float*>(U), part, part_floats, B, Ci, Co, H, W, dilation > 1 ? 1 : P, dilation, 0,
+                  stream, WinoEpi{bias, slope, y2, y2_batch_stride});
 }
 
 extern "C" long dfe_wino_transform_blocks(int Ci, int Co) {

@@ -772,21 +772,42 @@ class WinoWeightCache:
 wino_weights = WinoWeightCache()
 
 
-def wino_conv3x3(x, w, padding=1, transposed=False, dilation=1):
-    """3x3 stride-1 convolution of x [B,Ci,H,W] (no bias) on dfe_wino_conv3x3.  ``transposed``: w is the forward filter
-    [Ci,Co,3,3] of a convolution whose output gradient is x; the result is its data gradient.  ``dilation`` > 1: a dilated
-    convolution with padding = dilation (``padding`` is ignored).  Parameters' transformed filters come from
-    ``wino_weights`` when it holds them (dfe_wino_conv3x3_u)."""
+def wino_conv3x3(x, w, padding=1, transposed=False, dilation=1, bias=None, slope=1.0, out=None, out_off=0, out2=None, out2_off=0):
+    """3x3 stride-1 convolution of x [B,Ci,H,W] on dfe_wino_conv3x3.  ``transposed``: w is the forward filter [Ci,Co,3,3] of a
+    convolution whose output gradient is x; the result is its data gradient.  ``dilation`` > 1: a dilated convolution with
+    padding = dilation (``padding`` is ignored).  Parameters' transformed filters come from ``wino_weights`` when it holds
+    them (dfe_wino_conv3x3_u).
+
+    ``bias`` / ``slope`` / ``out`` / ``out2`` (round 5): the epilogue act(conv + bias), act(v) = v > 0 ? v : slope v, inside the
+    kernel's output transform (dfe_wino_conv3x3_u_act), written to channels out_off.. of ``out`` (a contiguous NCHW buffer with
+    at least that many channels; default: a fresh tensor) and, if given, to channels out2_off.. of ``out2`` as well."""
+    fused = bias is not None or float(slope) != 1.0 or out is not None or out2 is not None
     U = wino_weights.lookup(w, transposed)
     x, w = f32c(x), f32c(w)
     B, Ci, H, W = x.shape
     Co = int(w.shape[1] if transposed else w.shape[0])
     P, d = int(padding), int(dilation)
     lib = get_lib()
-    if d > 1:
-        y = torch.empty(B, Co, H, W, device=x.device, dtype=torch.float32)
-    else:
-        y = torch.empty(B, Co, H + 2 * P - 2, W + 2 * P - 2, device=x.device, dtype=torch.float32)
+    Ho, Wo = (H, W) if d > 1 else (H + 2 * P - 2, W + 2 * P - 2)
+    if fused:
+        if U is None:
+            U = WinoWeightCache.transform_now(w, transposed)
+        y = torch.empty(B, Co, Ho, Wo, device=x.device, dtype=torch.float32) if out is None else out
+        HWo = Ho * Wo
+        for t in (y, out2):
+            if t is not None and not (t.is_contiguous() and t.dtype == torch.float32 and tuple(t.shape[2:]) == (Ho, Wo) and t.shape[0] == B):
+                raise _lib.DfeError("wino_conv3x3: out / out2 must be contiguous fp32 [B, >= Co, Ho, Wo] buffers")
+        if y.shape[1] < int(out_off) + Co or (out2 is not None and out2.shape[1] < int(out2_off) + Co):
+            raise _lib.DfeError("wino_conv3x3: the output channels do not fit the destination buffer")
+        p1 = ctypes.c_void_p(y.data_ptr() + 4 * int(out_off) * HWo)
+        p2 = ctypes.c_void_p(out2.data_ptr() + 4 * int(out2_off) * HWo) if out2 is not None else None
+        npart = 0 if d > 1 else lib.dfe_wino_scratch_floats(B, Ci, Co, H, W, P) - lib.dfe_wino_weight_floats(Ci, Co)
+        part = torch.empty(npart, device=x.device, dtype=torch.float32) if npart > 0 else None
+        check(lib.dfe_wino_conv3x3_u_act(ptr(x), ptr(U), ptr(f32c(bias)) if bias is not None else None, float(slope), p1, y.stride(0), p2,
+                                         out2.stride(0) if out2 is not None else 0, ptr(part), npart, B, Ci, Co, H, W, P, d, stream_ptr()),
+              "dfe_wino_conv3x3_u_act")
+        return y
+    y = torch.empty(B, Co, Ho, Wo, device=x.device, dtype=torch.float32)
     if U is not None:
         npart = 0 if d > 1 else lib.dfe_wino_scratch_floats(B, Ci, Co, H, W, P) - lib.dfe_wino_weight_floats(Ci, Co)
         part = torch.empty(npart, device=x.device, dtype=torch.float32) if npart > 0 else None
@@ -802,6 +823,53 @@ def wino_conv3x3(x, w, padding=1, transposed=False, dilation=1):
     check(lib.dfe_wino_conv3x3(ptr(x), ptr(w), ptr(y), y.stride(0), ptr(wbuf), nws, B, Ci, Co, H, W, P, int(bool(transposed)),
                                stream_ptr()), "dfe_wino_conv3x3")
     return y
+
+
+class ConvBiasActFn(torch.autograd.Function):
+    """``act(conv2d(x, w, stride 1, padding = dilation) + bias)`` for a 3x3 layer the Winograd kernel takes -- net_utils.conv()
+    = Conv2d + LeakyReLU(0.1) (net_utils.py:7-11: FeaturePyramid's stride-1 layers, PWC's context network) -- as ONE launch
+    forward (the epilogue inside the output transform) and one autograd node: backward = dfe_bias_act_bwd (gz = gy act'(y),
+    bias gradient) + the convolution's data / weight gradients (convs.raw_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, slope, padding, dilation):
+        y = wino_conv3x3(x, w, padding, dilation=dilation, bias=bias, slope=slope)
+        ctx.save_for_backward(x, w, y)
+        ctx.cfg = (float(slope), int(padding), int(dilation), bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = get_lib()
+        x, w, y = ctx.saved_tensors
+        slope, P, d, has_bias = ctx.cfg
+        B, C, H, W = y.shape
+        if gy.dtype != torch.float32:
+            gy = gy.float()
+        if not (gy.stride(3) == 1 and gy.stride(2) == W and gy.stride(1) == H * W and gy.stride(0) >= C * H * W):
+            gy = gy.contiguous()
+        gz = torch.empty_like(y)
+        gb = part = None
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = torch.empty(C, device=y.device, dtype=torch.float32)
+            part = torch.empty(lib.dfe_bias_act_partials_floats(B, C, H, W), device=y.device, dtype=torch.float32)
+        check(lib.dfe_bias_act_bwd(ptr(y), ptr(gy, strided=True), gy.stride(0), ptr(gz), ptr(gb), ptr(part), B, C, H, W, slope,
+                                   stream_ptr()), "dfe_bias_act_bwd")
+        pad = (d, d) if d > 1 else (P, P)
+        gx, gw, _ = convs.raw_backward(gz, x, w, (1, 1), pad, (d, d), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return gx, gw, gb, None, None, None
+
+
+def conv_bias_act_eligible(x, conv):
+    """A Conv2d whose forward the Winograd kernel runs (convs._wino_eligible: 3x3, stride 1, padding 1 or dilated with
+    padding = dilation, enough tiles and channels, fp32)."""
+    return (os.environ.get("DFE_WINO_EPILOGUE", "1") != "0" and conv.bias is not None and conv.groups == 1
+            and convs._wino_eligible(x, conv.weight.shape, conv.in_channels, conv.stride, conv.padding, conv.dilation, conv.groups)
+            and conv.padding == ((1, 1) if conv.dilation == (1, 1) else conv.dilation))
+
+
+def conv_bias_act(x, conv, slope):
+    return ConvBiasActFn.apply(x, conv.weight, conv.bias, float(slope), int(conv.padding[0]), int(conv.dilation[0]))
 
 
 def phase_images(t, d):
@@ -962,16 +1030,21 @@ class DenseDecodeFn(torch.autograd.Function):
             planeconv_fwd_into(cat[1], w[3], b[3], slope, cat[2], co[2], cat[3], 0)
             planeconv_fwd_into(cat[2], w[4], b[4], slope, x4, 0, cat[3], co[3])
         else:
-            z0 = convs.raw_forward(x, w[0], 1, 1)
-            epilogue(z0, 0, z0, 0, cat[0], 0)                                   # x0: in place (conv_1's input) + cat0[:, :128]
-            z = convs.raw_forward(z0, w[1], 1, 1)
-            epilogue(z, 1, cat[0], co[0], cat[1], 0)                            # x1
-            z = convs.raw_forward(cat[0], w[2], 1, 1)
-            epilogue(z, 2, cat[1], co[1], cat[2], 0)                            # x2
-            z = convs.raw_forward(cat[1], w[3], 1, 1)
-            epilogue(z, 3, cat[2], co[2], cat[3], 0)                            # x3
-            x4 = convs.raw_forward(cat[2], w[4], 1, 1)
-            epilogue(x4, 4, x4, 0, cat[3], co[3])                               # x4: in place (returned) + cat3[:, 64:]
+            fuse = os.environ.get("DFE_WINO_EPILOGUE", "1") != "0"
+
+            def layer(inp, k, d1, d1_off, d2, d2_off):
+                """act(conv_k(inp) + b_k) into channels d1_off.. of d1 (None: a fresh tensor, returned) and d2_off.. of d2"""
+                if fuse and convs._wino_eligible(inp, w[k].shape, w[k].shape[1], (1, 1), (1, 1), (1, 1)):
+                    # round 5: the epilogue inside the Winograd kernel's output transform (one launch, no pass over z)
+                    return wino_conv3x3(inp, w[k], 1, bias=b[k], slope=slope, out=d1, out_off=d1_off, out2=d2, out2_off=d2_off)
+                z = convs.raw_forward(inp, w[k], 1, 1)
+                epilogue(z, k, z if d1 is None else d1, d1_off, d2, d2_off)
+                return z
+            z0 = layer(x, 0, None, 0, cat[0], 0)                                # x0: conv_1's input + cat0[:, :128]
+            layer(z0, 1, cat[0], co[0], cat[1], 0)                              # x1
+            layer(cat[0], 2, cat[1], co[1], cat[2], 0)                          # x2
+            layer(cat[1], 3, cat[2], co[2], cat[3], 0)                          # x3
+            x4 = layer(cat[2], 4, None, 0, cat[3], co[3])                       # x4: returned + cat3[:, 64:]
         if flow_head_eligible(cat[3], w[5], b[5]):
             flow = flow_head_fwd_raw(cat[3], f32c(w[5]), f32c(b[5]))
         else:

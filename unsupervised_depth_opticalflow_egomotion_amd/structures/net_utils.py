@@ -20,6 +20,8 @@ class ConvAct(nn.Sequential):
         if (c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1) and c.groups == 1
                 and ops.planeconv_eligible(x, c.weight)):   # FeaturePyramid's top levels (8x26, 4x13): small-plane MFMA kernels
             return ops.planeconv_act(x, c.weight, c.bias, self[1].negative_slope)
+        if ops.conv_bias_act_eligible(x, c):        # round 5: bias + LeakyReLU inside the Winograd kernel's output transform
+            return ops.conv_bias_act(x, c, self[1].negative_slope)
         z = convs.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
         return ops.bias_act(z, c.bias, self[1].negative_slope)
 
