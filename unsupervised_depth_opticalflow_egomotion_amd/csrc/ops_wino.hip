@@ -25,6 +25,7 @@ namespace dfe {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Optional epilogue of the output transform (round 5): y = act(conv + bias[k]) with act(v) = v > 0 ? v : slope v -- the arithmetic
 // of dfe_bias_act_fwd / _fwd2 (ops_epilogue.hip), bit for bit, written to y and (optionally) to the same channels of a second
@@ -185,7 +186,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
   const char* xc = reinterpret_cast<const char*>(x);
   float dn[16];                       // PAIR: dn[2 i], dn[2 i + 1] = the own pair of row i; dn[8 + 2 i], dn[9 + 2 i] = an edge lane's L / R pair
   unsigned mn;
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
+
   auto issue = [&](int c) {
     mn = c < Cend ? inb : 0u;
     const unsigned cb = 4u * static_cast<unsigned>(c < Cend ? c : 0) * HW;
@@ -339,6 +340,11 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
   // with channel splits the epilogue belongs to k_wino_sum (the partial outputs are sums of a part of the channels)
   const bool fused = nsp == 1 && (epi.bias != nullptr || epi.slope != 1.0f);
   float* y2b = (nsp == 1 && epi.y2) ? epi.y2 + b * epi.y2bs + ooff : nullptr;
+  // 8-byte stores of a tile's row pairs: dense layers with an even output width and 8-byte aligned planes (every plane starts
+  // at an even float offset: batch strides and Ho * Wo even)
+  const bool even_w = dil == 1 && (Wo & 1) == 0;
+  const bool pair_st = even_w && (reinterpret_cast<uintptr_t>(nsp > 1 ? part : y) & 7) == 0 && ((nsp > 1 ? 0 : ybs) & 1) == 0;
+  const bool pair_st2 = even_w && y2b && (reinterpret_cast<uintptr_t>(epi.y2) & 7) == 0 && (epi.y2bs & 1) == 0;
 #pragma unroll
   for (int h = 0; h < NH; ++h)
 #pragma unroll
@@ -359,23 +365,37 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
         y10 = wino_act(y10, bv, epi.slope); y11 = wino_act(y11, bv, epi.slope);
       }
       float* o = yb + static_cast<long>(k) * Ho * Wo;
-      if (oy < Hoq) {
-        if (ox < Woq) o[0] = y00;
-        if (ox + 1 < Woq) o[sx] = y01;
-      }
-      if (oy + 1 < Hoq) {
-        if (ox < Woq) o[sy] = y10;
-        if (ox + 1 < Woq) o[sy + sx] = y11;
+      if (pair_st) {        // Wo even, 8-byte aligned rows: a tile's two outputs of a row leave as one 8-byte store (16 lanes = 128 bytes)
+        if (ox < Woq) {
+          if (oy < Hoq) *reinterpret_cast<f32x2*>(o) = f32x2{y00, y01};
+          if (oy + 1 < Hoq) *reinterpret_cast<f32x2*>(o + sy) = f32x2{y10, y11};
+        }
+      } else {
+        if (oy < Hoq) {
+          if (ox < Woq) o[0] = y00;
+          if (ox + 1 < Woq) o[sx] = y01;
+        }
+        if (oy + 1 < Hoq) {
+          if (ox < Woq) o[sy] = y10;
+          if (ox + 1 < Woq) o[sy + sx] = y11;
+        }
       }
       if (y2b) {
         float* o2 = y2b + static_cast<long>(k) * Ho * Wo;
-        if (oy < Hoq) {
-          if (ox < Woq) o2[0] = y00;
-          if (ox + 1 < Woq) o2[sx] = y01;
-        }
-        if (oy + 1 < Hoq) {
-          if (ox < Woq) o2[sy] = y10;
-          if (ox + 1 < Woq) o2[sy + sx] = y11;
+        if (pair_st2) {
+          if (ox < Woq) {
+            if (oy < Hoq) *reinterpret_cast<f32x2*>(o2) = f32x2{y00, y01};
+            if (oy + 1 < Hoq) *reinterpret_cast<f32x2*>(o2 + sy) = f32x2{y10, y11};
+          }
+        } else {
+          if (oy < Hoq) {
+            if (ox < Woq) o2[0] = y00;
+            if (ox + 1 < Woq) o2[sx] = y01;
+          }
+          if (oy + 1 < Hoq) {
+            if (ox < Woq) o2[sy] = y10;
+            if (ox + 1 < Woq) o2[sy + sx] = y11;
+          }
         }
       }
     }
