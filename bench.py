@@ -48,8 +48,6 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--miopen-benchmark", type=int, default=0, help="torch.backends.cudnn.benchmark (MIOpen exhaustive find)")
-    ap.add_argument("--amp", default="off", choices=["off", "bf16"], help="opt-in mixed precision of the networks' convolutions (SURVEY 8(f) "
-                    "rank 1): bf16 MIOpen kernels with fp32 accumulation; glue, loss stack and optimiser stay fp32. The default line is fp32")
     ap.add_argument("--net-streams", type=int, default=None, help="1 = the three networks one after the other on one stream; 3 = flow / pose "
                     "nets on side streams (default: the package default)")
     return ap.parse_args()
@@ -433,9 +431,6 @@ def main():
     args = parse()
     launch_ranks_if_needed(args)
     torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
-    if args.amp == "bf16":
-        from unsupervised_depth_opticalflow_egomotion_amd import convs
-        convs.set_compute_dtype(torch.bfloat16)
     if args.net_streams is not None:
         from unsupervised_depth_opticalflow_egomotion_amd import models
         models._DEFAULT_NET_STREAMS = args.net_streams
@@ -478,11 +473,10 @@ def main():
         "host_enqueue_ms": round(1e3 * t_host / args.steps, 4), "timed_region_s": round(dt, 3),
         "ms_per_step_first20": round(ev_beg.elapsed_time(ev_20) / 20.0, 4) if args.steps >= 20 else None,
         "ms_per_step_gpu_events": round(ev_beg.elapsed_time(ev_end) / args.steps, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.amp == "off" else args.amp, "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl.name + ": mode=%s, %dx%d, batch=%d/GPU, num_scales=%d, fwd+bwd%s" % (
             args.mode if wl.name == "train_step" else "geom", args.width, args.height, args.batch, args.scales,
-            "+Adam" if wl.name == "train_step" else "") + ("" if args.amp == "off" else
-            " [OPT-IN mixed precision, not the headline: convolutions in %s with fp32 accumulation; glue, loss stack, optimiser fp32]" % args.amp),
+            "+Adam" if wl.name == "train_step" else ""),
             "global_batch": args.batch * world, "parallelism": "dp%d" % world,
             "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE"), "miopen_user_db": miopen_db_status()},
     }

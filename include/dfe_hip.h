@@ -227,17 +227,6 @@ long dfe_wgrad3x3_partials_floats(int B, int Ci, int Co, int H, int W);
 int dfe_wgrad3x3_fwd(const float* p, const float* gy, float* gweight, float* partials, int B, int Ci, int Co, int H, int W,
                      void* stream);
 
-/* ---- forward / data-gradient pass of the decoder's thinnest 3x3 convolutions on the matrix cores (fp32 MFMA):
- * out [B,16,Ho,Wo][co][y][x] = sum_{ci,ky,kx} weight[co][ci][ky][kx] * in[b][ci][y+ky-P][x+kx-P] (zero outside in),
- * in [B,Ci,Hi,Wi], Ho = Hi + 2P - 2, Wo = Wi + 2P - 2.  P = 0: valid convolution of a pre-padded activation (forward);
- * P = 1: zero-padded "same" convolution (net_utils.conv(16, 16), feature_pyramid.py: forward, and its data gradient with
- * transposed_weight = 1); P = 2: full correlation = the data gradient of the P = 0 form with transposed_weight = 1:
- * ``weight`` is then the forward kernel
- * w [16,16,3,3] and is read as weight'[co'][ci'][ky][kx] = w[ci'][co'][2-ky][2-kx].  Output channels must be 16, Ci 16 or
- * 32 (16 when transposed) (DFE_ERR_UNSUPPORTED otherwise: the caller keeps MIOpen); out 16-byte aligned. */
-int dfe_thin_conv3x3(const float* in, const float* weight, float* out, int B, int Ci, int Co, int Hi, int Wi, int P,
-                     int transposed_weight, void* stream);
-
 /* ---- 3x3 / stride 1 / pad 1 convolutions on small planes (H*W <= 4096 per sample) on the fp32 matrix cores: PWC's decoder
  * levels 6 and 5 (pwc_tf.py:28-47 conv6_0 .. conv5_4 = Conv2d(3x3, pad 1, bias) + LeakyReLU(0.1), called at
  * pwc_tf.py:113-135), where MIOpen's kernels are launch- and layout-bound (10-45 us forward, 26-126 us per weight gradient
@@ -324,14 +313,6 @@ int dfe_conv1x1_small_fwd(const float* x, const float* weight, const float* bias
                           int H, int W, void* stream);
 int dfe_conv1x1_small_bwd(const float* gy, const float* x, const float* weight, float* gx, float* gweight, int B, int Ci, int Co,
                           int H, int W, void* stream);
-
-/* ---- layout-changing casts at the door of MIOpen's bf16 convolutions (opt-in mixed-precision mode, SURVEY.md 8(f) rank 1:
- * the nets of depth_model.py:60-211 / pwc_tf.py:108-179 in bf16; never the headline).  MIOpen's bf16 kernels are NHWC:
- * dfe_cast_f32_nchw_to_bf16_nhwc: y[b][p][c] = bf16(x[b][c][p]), round to nearest even like torch's .to(torch.bfloat16);
- * dfe_cast_bf16_nhwc_to_f32_nchw: y[b][c][p] = float(x[b][p][c]).  x / y contiguous, HW = H * W; y of the first is what
- * torch calls a channels_last bf16 tensor.  One pass instead of a cast plus MIOpen's own transpose. */
-int dfe_cast_f32_nchw_to_bf16_nhwc(const float* x, void* y, int B, int C, long HW, void* stream);
-int dfe_cast_bf16_nhwc_to_f32_nchw(const void* x, float* y, int B, int C, long HW, void* stream);
 
 /* ---- grouped training-mode BatchNorm2d (+ residual + ReLU) of the depth encoder (SURVEY.md 8(f) rank 1;
  * depth_model.py:60-95 = torchvision BasicBlock conv-bn-relu-conv-bn-(+identity)-relu; model_geometry.py:786-788 calls the

@@ -82,8 +82,9 @@ def test_error_strings_and_argument_checks_without_gpu():
     assert lib.dfe_wino_conv3x3_dilated(P, P, P, 4 * 8 * 9, P, 1, 4, 4, 8, 9, 2, 0, None) == -4  # W not a multiple of the dilation
     assert lib.dfe_wino_conv3x3(P, P, P, 1 << 40, P, 1 << 30, 64, 256, 4, 512, 512, 1, 0, None) == -2   # 32-bit offsets: B*Ci*H*W < 2^30
     assert lib.dfe_wino_wgrad_floats(8, 128, 128, 64, 208, 1) > 0 and lib.dfe_wino_wgrad_floats(8, 128, 128, 64, 208, 2) == 0
-    assert lib.dfe_wino_wgrad3x3(P, P, 128 * 64 * 208, P, P, 8, 128, 128, 64, 207, 1, None) == -4      # odd width: pair loads
-    assert lib.dfe_wino_wgrad3x3(P, None, 0, P, P, 1, 4, 4, 8, 8, 1, None) == -1
+    assert lib.dfe_wino_wgrad3x3(P, 4 * 8 * 8, None, 0, P, P, 1, 4, 4, 8, 8, 1, None) == -1
+    assert lib.dfe_wino_wgrad3x3(P, 4 * 8 * 8, P, 4 * 8 * 8, P, P, 1, 4, 4, 8, 8, 2, None) == -4 and lib.dfe_wino_wgrad_floats(1, 4, 4, 8, 8, 1) > 0
+    assert lib.dfe_wino_conv3x3_u_act(P, None, None, 1.0, P, 4 * 8 * 8, None, 0, None, 0, 1, 4, 4, 8, 8, 1, 1, None) == -1
     # transformed filters kept across calls: blocks per filter, argument checks
     assert lib.dfe_wino_transform_blocks(64, 64) == 16 and lib.dfe_wino_transform_blocks(5, 33) == 2 and lib.dfe_wino_transform_blocks(0, 3) == 0
     assert lib.dfe_wino_transform_weights_multi(None, P, 4, None) == -1 and lib.dfe_wino_transform_weights_multi(P, P, 0, None) == -2
@@ -93,7 +94,6 @@ def test_error_strings_and_argument_checks_without_gpu():
     assert lib.dfe_wino_conv3x3(P, None, P, 4 * 8 * 8, P, 1 << 20, 1, 4, 4, 8, 8, 1, 0, None) == -1
     assert lib.dfe_conv1x1_small_supported(4, 256, 12, 2, 7) == 1 and lib.dfe_conv1x1_small_supported(4, 16, 16, 64, 208) == 0
     assert lib.dfe_conv1x1_small_fwd(P, None, None, 1.0, P, 4, 12, 12, 2, 7, None) == -1
-    assert lib.dfe_cast_f32_nchw_to_bf16_nhwc(None, P, 1, 4, 16, None) == -1 and lib.dfe_cast_bf16_nhwc_to_f32_nchw(P, P, 0, 4, 16, None) == -2
 
 
 def test_no_cpu_fallback():
@@ -153,6 +153,62 @@ def test_synthetic_dataset_contract():
     np.testing.assert_allclose(k[1, 0].numpy(), k[0, 0].numpy() / 2)
     a, b = make_loss_stack_inputs(1, 32, 96, 3, seed=9), make_loss_stack_inputs(1, 32, 96, 3, seed=9)
     assert np.array_equal(a.flows_fwd[0], b.flows_fwd[0]) and len(a.flows_fwd) == 4
+
+
+def _tile_pixel_host(p, W, H, TW, float_path):
+    """csrc/loss_stack_exact.h tile_pixel<TW> restated with numpy: the reciprocal-multiply estimate in float32 exactly as the
+    device evaluates it + the integer fix-up (float_path), or the integer-division overload."""
+    p = p.astype(np.uint32)
+    Wu, TR = np.uint32(W), np.uint32(64 // TW)
+    LG = {8: 3, 16: 4, 32: 5}[TW]
+
+    def quot(num, den):
+        if not float_path:
+            return num // np.uint32(den)
+        if den == TR * Wu:
+            r = np.float32(np.float32(1.0) / np.float32(W)) * np.float32(np.float32(1.0) / np.float32(TR))
+            q = ((num.astype(np.float32) + np.float32(0.5)) * r).astype(np.uint32)
+        elif den == Wu:
+            q = ((num.astype(np.float32) + np.float32(0.5)) * np.float32(np.float32(1.0) / np.float32(W))).astype(np.uint32)
+        else:
+            q = ((num.astype(np.float32) + np.float32(0.5)) / np.float32(den)).astype(np.uint32)
+        lo = q * np.uint32(den)
+        return np.where(num < lo, q - 1, np.where(num - lo >= np.uint32(den), q + 1, q)).astype(np.uint32)
+    g = quot(p, TR * Wu)
+    q = p - g * TR * Wu
+    WT = Wu & ~np.uint32(TW - 1)
+    inside = g < np.uint32(H) // TR
+    full = q < TR * WT
+    px_t = np.uint32(TW) * (q >> np.uint32(6)) + (q & np.uint32(TW - 1))
+    py_t = TR * g + ((q & np.uint32(63)) >> np.uint32(LG))
+    wr = max(int(Wu - WT), 1)
+    e = np.where(full, 0, q - TR * WT).astype(np.uint32)
+    r = quot(e, np.uint32(wr))
+    px_e, py_e = WT + e - r * np.uint32(wr), TR * g + r
+    py_r = quot(p, Wu)
+    px_r = p - py_r * Wu
+    px = np.where(inside, np.where(full, px_t, px_e), px_r)
+    py = np.where(inside, np.where(full, py_t, py_e), py_r)
+    return px.astype(np.int64), py.astype(np.int64)
+
+
+@pytest.mark.parametrize("hw", [(256, 832), (128, 416), (64, 208), (375, 1242), (187, 621), (93, 310), (46, 155), (23, 77), (11, 38),
+                                (130, 418), (7, 9), (4, 16), (1, 1), (3, 1000), (1024, 4096)])
+def test_tile_pixel_is_a_bijection_for_the_kitti_pyramids(hw):
+    """the pointwise kernels' pixel order (a wave = a 16 x 4 tile) must visit every pixel exactly once.  Both
+    overloads (reciprocal multiply + integer fix-up; integer divisions), every tile width, every level of the 832x256 and the
+    1242x375 six-scale pyramids, ragged and large (2^22 pixels: beyond the float estimate's own margin) sizes."""
+    H, W = hw
+    p = np.arange(H * W, dtype=np.int64)
+    for TW in (8, 16, 32):
+        ref = None
+        for float_path in (True, False):
+            px, py = _tile_pixel_host(p, W, H, TW, float_path)
+            assert px.min() >= 0 and px.max() < W and py.min() >= 0 and py.max() < H
+            lin = py * W + px
+            assert np.array_equal(np.sort(lin), p), (hw, TW, float_path)
+            ref = lin if ref is None else ref
+            assert np.array_equal(lin, ref)          # the two overloads are the same map
 
 
 # ---------------------------------------------------------------------------------- 2-process gloo DDP

@@ -920,95 +920,3 @@ def test_thin_conv_function_and_eligibility():
         gclose(res[0][2], res[1][2], rel=2e-4, atol=1e-9)
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 7, 32), (1, 32, 5, 48), (2, 16, 9, 40), (3, 16, 33, 61)])
-def test_thin_conv3x3_mfma(shape):
-    """dfe_thin_conv3x3 (fp32 MFMA): the forward pass on a pre-padded input and, for 16 -> 16, the data gradient with
-    the weights read transposed, against F.conv2d and its input gradient in fp64 on the CPU (2e-6 of the scale);
-    widths that are not multiples of 16 or 4 exercise the partial-tile and narrow-store paths."""
-    import torch.nn.functional as F
-    from unsupervised_depth_opticalflow_egomotion_amd._lib import get_lib, ptr, stream_ptr, check
-    lib = get_lib()
-    B, Ci, H, W = shape
-    rng = np.random.RandomState(sum(shape))
-    p = rng.randn(B, Ci, H + 2, W + 2).astype(np.float32)
-    w = (rng.randn(16, Ci, 3, 3) * 0.2).astype(np.float32)
-    gy = rng.randn(B, 16, H, W).astype(np.float32)
-    pd = torch.from_numpy(p).double().requires_grad_(True)
-    ref = F.conv2d(pd, torch.from_numpy(w).double())
-    (ref * torch.from_numpy(gy).double()).sum().backward()
-    ph, wh, gh = G(p), G(w), G(gy)         # keep the device tensors alive across the raw-pointer calls
-    out = torch.empty(B, 16, H, W, device=dev())
-    check(lib.dfe_thin_conv3x3(ptr(ph), ptr(wh), ptr(out), B, Ci, 16, H + 2, W + 2, 0, 0, stream_ptr()), "fwd")
-    gclose(out, ref.detach().float(), rel=2e-6)
-    if Ci == 16:
-        gp = torch.empty(B, 16, H + 2, W + 2, device=dev())
-        check(lib.dfe_thin_conv3x3(ptr(gh), ptr(wh), ptr(gp), B, 16, 16, H, W, 2, 1, stream_ptr()), "dgrad")
-        gclose(gp, pd.grad.float(), rel=2e-6)
-
-
-def test_conv_bf16_compute_dtype():
-    """convs.compute_dtype(torch.bfloat16): fp32 in, fp32 out, bf16 inside -- values and gradients within bf16 rounding
-    of the fp32 convolution (relative 2e-2 of the tensor's scale), parameters' gradients fp32."""
-    from unsupervised_depth_opticalflow_egomotion_amd import convs
-    torch.manual_seed(4)
-    x = torch.randn(2, 32, 24, 40, device=dev(), requires_grad=True)
-    w = (0.05 * torch.randn(48, 32, 3, 3, device=dev())).requires_grad_(True)
-    r = torch.randn(2, 48, 24, 40, device=dev())
-    y0 = torch.nn.functional.conv2d(x, w, None, 1, 1)
-    g0 = torch.autograd.grad((y0 * r).sum(), (x, w))
-    with convs.compute_dtype(torch.bfloat16):
-        y1 = convs.conv2d(x, w, None, 1, 1)
-        g1 = torch.autograd.grad((y1 * r).sum(), (x, w))
-    assert y1.dtype == torch.float32 and g1[0].dtype == torch.float32 and g1[1].dtype == torch.float32
-    for a, c in zip((y1,) + g1, (y0,) + g0):
-        assert float((a - c).abs().max()) <= 2e-2 * float(c.abs().max())
-    assert float((y1 - y0).abs().max()) > 0      # it really ran in reduced precision
-
-
-def test_thin_conv_same_16_16_matches_miopen():
-    """ops.ThinConvSameFn (dfe_thin_conv3x3 with P = 1 + dfe_wgrad3x3 on a zero-padded copy): values and all gradients of
-    the zero-padded 16 -> 16 3x3 convolution of FeaturePyramid's conv2 against F.conv2d on the device (fp32 both:
-    summation order only)."""
-    from unsupervised_depth_opticalflow_egomotion_amd import ops
-    torch.manual_seed(6)
-    for B, H, W in ((2, 128, 416), (1, 130, 432)):
-        x = torch.randn(B, 16, H, W, device=dev(), requires_grad=True)
-        w = (0.1 * torch.randn(16, 16, 3, 3, device=dev())).requires_grad_(True)
-        r = torch.randn(B, 16, H, W, device=dev())
-        y0 = torch.nn.functional.conv2d(x, w, None, 1, 1)
-        g0 = torch.autograd.grad((y0 * r).sum(), (x, w))
-        y1 = ops.ThinConvSameFn.apply(x, w)
-        g1 = torch.autograd.grad((y1 * r).sum(), (x, w))
-        for a, c in zip((y1,) + g1, (y0,) + g0):
-            assert float((a - c).abs().max()) <= 2e-5 * max(float(c.abs().max()), 1.0)
-    # since round 4 the fused Winograd kernel takes the layer wherever it is eligible; the thin kernels keep it only when that
-    # kernel is switched off
-    from unsupervised_depth_opticalflow_egomotion_amd import convs
-    conv = torch.nn.Conv2d(16, 16, 3, 1, 1)
-    assert not ops.thin_conv_same_eligible(x, conv) and convs._wino_eligible(x, conv.weight.shape, 16, (1, 1), (1, 1), (1, 1))
-    old = convs.WINO_MIN_TILES
-    convs.WINO_MIN_TILES = 0
-    try:
-        assert ops.thin_conv_same_eligible(x, conv) and not ops.thin_conv_same_eligible(x[:, :, :64, :208], conv)
-    finally:
-        convs.WINO_MIN_TILES = old
-
-
-@pytest.mark.parametrize("shape", [(2, 32, 8, 26), (3, 81, 4, 13), (1, 3, 7, 5), (2, 128, 64, 208), (128, 115, 3, 3), (1, 1, 1, 1)])
-def test_layout_changing_bf16_casts_match_torch(shape):
-    """dfe_cast_f32_nchw_to_bf16_nhwc / dfe_cast_bf16_nhwc_to_f32_nchw (the opt-in bf16 mode's door to MIOpen) against
-    torch's .to(bfloat16, channels_last) / .float(): bit-identical, NaN and infinities included."""
-    from unsupervised_depth_opticalflow_egomotion_amd import convs
-    dev = torch.device("cuda:0")
-    torch.manual_seed(1)
-    x = torch.randn(*shape, device=dev) * 3.0
-    flat = x.view(-1)
-    if flat.numel() > 8:
-        flat[1], flat[3], flat[5] = float("nan"), float("inf"), float("-inf")
-        flat[7] = 1.00390625        # a tie: rounds to even
-    y = convs._f32_nchw_to_bf16_nhwc(x)
-    ref = x.to(torch.bfloat16, memory_format=torch.channels_last)
-    assert y.dtype == torch.bfloat16 and (y.stride() == ref.stride() or shape[1] == 1 or shape[2] * shape[3] == 1)
-    assert torch.equal(y.view(torch.int16), ref.view(torch.int16))
-    z = convs._bf16_nhwc_to_f32_nchw(ref) if not ref.is_contiguous() else ref.float()
-    assert z.is_contiguous() and torch.equal(z.view(torch.int32), ref.float().contiguous().view(torch.int32))

@@ -52,11 +52,6 @@ def train(cfg):
     if dev is None:
         raise RuntimeError("train.py needs a HIP device: the loss stack has no CPU fallback")
     ops.set_align_corners(bool(getattr(cfg, "align_corners", False)))
-    if getattr(cfg, "amp", "off") == "bf16":
-        from unsupervised_depth_opticalflow_egomotion_amd import convs
-        convs.set_compute_dtype(torch.bfloat16)
-        if rank == 0:
-            print("mixed precision: convolutions in bf16 (fp32 accumulate), everything else fp32")
     model = get_model(cfg.mode)(cfg)
     if cfg.mode == "geom":
         for attr, path in (("flow_pretrained_model", ("fpyramid.", "pwc_model.")),
@@ -137,9 +132,6 @@ if __name__ == "__main__":
     ap.add_argument("--num_iterations", type=int, default=None)
     ap.add_argument("--device_pipeline", action="store_true",
                     help="feed raw uint8 triplets and run resize / flip / normalise on the device (ops.prepare_triplets)")
-    ap.add_argument("--amp", default="off", choices=["off", "bf16"],
-                    help="opt-in mixed precision: the networks' convolutions run in bf16 on MIOpen (fp32 accumulation, fp32 master "
-                         "weights); BatchNorm, the glue kernels, the loss stack and Adam stay fp32 (convs.py)")
     args = ap.parse_args()
     with open(args.config_file) as fh:
         cfg = yaml.safe_load(fh)

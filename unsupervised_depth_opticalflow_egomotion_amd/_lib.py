@@ -40,11 +40,8 @@ _SIGNATURES = {
     "dfe_pose_partials_floats": [_I, _I, _I],
     "dfe_inverse_warp2_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dfe_inverse_warp2_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "dfe_thin_conv3x3": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dfe_wgrad3x3_partials_floats": [_I, _I, _I, _I, _I],
     "dfe_wgrad3x3_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "dfe_cast_f32_nchw_to_bf16_nhwc": [_P, _P, _I, _I, ctypes.c_long, _P],
-    "dfe_cast_bf16_nhwc_to_f32_nchw": [_P, _P, _I, _I, ctypes.c_long, _P],
     "dfe_wino_weight_floats": [_I, _I],
     "dfe_wino_conv3x3": [_P, _P, _P, ctypes.c_long, _P, ctypes.c_long, _I, _I, _I, _I, _I, _I, _I, _P],
     "dfe_wino_scratch_floats": [_I, _I, _I, _I, _I, _I],

@@ -1,22 +1,19 @@
-"""The one door to MIOpen's convolutions (the networks' FLOPs; everything else on the step is this build's HIP code).
+"""The one door to the networks' convolutions: MIOpen's, or this build's fp32 matrix-core kernels where they win -- the
+fused Winograd F(2x2, 3x3) kernel for the forward pass and the data gradient of the 3x3 stride-1 layers (csrc/ops_wino.hip,
+round 4), its weight gradient in the same domain (csrc/ops_wino_wgrad.hip, round 5).  Everything is fp32.
 
-What is decided here, per call and invisible to the modules' state dicts, is the **compute dtype** (``compute_dtype``):
-``None`` = fp32, the default and the only mode the parity contract and the headline bench line use.  ``torch.bfloat16`` is
-the opt-in mixed-precision mode of SURVEY.md 8(f) rank 1 (``train.py --amp bf16`` / ``bench.py --amp bf16``): activations
-and weights are cast to bf16 at the convolution's door, MIOpen runs on the bf16 matrix cores with fp32 accumulation, and
-the result is cast back -- every glue kernel, every normalisation, the whole loss stack and the optimiser stay fp32 (master
-weights are the fp32 parameters themselves).
+``raw_forward`` / ``raw_backward`` are the same decisions for code that already lives inside an autograd Function
+(ops.DenseDecodeFn, ops.ThinConv3x3Fn, ops.ConvBiasActFn).
 
-``raw_forward`` / ``raw_backward`` are the same decision for code that already lives inside an autograd Function
-(ops.DenseDecodeFn, ops.ThinConv3x3Fn).
+Removed in round 5 (measured, never the headline, slower than fp32 since the Winograd kernel: 24.05 against 21.63 ms in round
+4): the opt-in bf16 mode (``--amp bf16``: casts at every convolution's door, MIOpen's bf16 kernels).  What it would take to
+pay -- activations kept bf16 channels-last between the convolutions, ~25 glue kernels in a second dtype and layout -- is
+priced in profiles/r04_nhwc_probe.txt; git history holds the code (convs.py, csrc/ops_cast.hip at round 4's HEAD).
 
 Measured and not adopted (round 3, profiles/r03_conv_swaps.txt): computing a stride-1 "same" convolution's forward pass
-with MIOpen's backward-data kernels on the flipped, channel-transposed weights (and vice versa).  The census of isolated
-calls (profiles/r03_conv_census.txt) shows lopsided pairs (dilation 8: forward 51 TFLOP/s, backward-data 87), but the
-transposed problem lands on the same kernels: 458 -> 432 us at best, within noise everywhere else."""
+with MIOpen's backward-data kernels on the flipped, channel-transposed weights (and vice versa): 458 -> 432 us at best."""
 from __future__ import annotations
 
-import contextlib
 import os
 
 import torch
@@ -26,81 +23,6 @@ import torch.nn.functional as F
 from . import miopen_tuning
 
 miopen_tuning.activate()      # before the first convolution: MIOpen reads MIOPEN_USER_DB_PATH when it first opens its databases
-
-_STATE = {"dtype": None}
-
-# Reduced-precision mode, measured in round 4 and NOT adopted (DFE_AMP_NHWC=1 switches it on): the operands go to MIOpen
-# as CHANNELS-LAST bf16 tensors with PYTORCH_MIOPEN_SUGGEST_NHWC=1, so that its NHWC implicit GEMMs need no transposes of
-# their own.  The convolutions themselves run ~25 % faster that way (tools/nhwc_probe.py).  First with ATen's strided cast +
-# permute kernels at the door: 24.2 / 24.5 ms per step against 21.6 / 25.2 with NCHW casts.  Then with this build's one-pass
-# transposing casts (csrc/ops_cast.hip, bit-identical to torch's): 25.3 / 26.3 against 24.4 / 24.8 on the same box -- the
-# layout change at EVERY convolution's door costs what MIOpen's transposes cost.  The mode pays only when activations stay
-# bf16 channels-last between the convolutions.
-_AMP_NHWC = os.environ.get("DFE_AMP_NHWC", "0") == "1"
-
-
-def _low(t, dt):
-    """fp32 NCHW -> compute dtype (channels-last when _AMP_NHWC and 4-d: one transposing cast of this build for bf16)."""
-    if _AMP_NHWC and t.dim() == 4:
-        if dt is torch.bfloat16 and t.is_cuda and t.dtype == torch.float32:
-            return _f32_nchw_to_bf16_nhwc(t)
-        return t.to(dt, memory_format=torch.channels_last)
-    return t.to(dt)
-
-
-def _high(t):
-    """compute dtype (any layout) -> fp32 NCHW contiguous: what every glue kernel of this build takes."""
-    if t is None:
-        return None
-    if (_AMP_NHWC and t.dtype == torch.bfloat16 and t.dim() == 4 and t.is_cuda and not t.is_contiguous()
-            and t.is_contiguous(memory_format=torch.channels_last)):
-        return _bf16_nhwc_to_f32_nchw(t)
-    return t.to(torch.float32, memory_format=torch.contiguous_format)
-
-
-def _f32_nchw_to_bf16_nhwc(t):
-    import ctypes
-    from ._lib import check, get_lib, ptr, stream_ptr
-    t = t.contiguous()
-    B, C, H, W = t.shape
-    y = torch.empty((B, C, H, W), dtype=torch.bfloat16, device=t.device, memory_format=torch.channels_last)
-    if y.numel():
-        check(get_lib().dfe_cast_f32_nchw_to_bf16_nhwc(ptr(t), ctypes.c_void_p(y.data_ptr()), B, C, H * W, stream_ptr()),
-              "dfe_cast_f32_nchw_to_bf16_nhwc")
-    return y
-
-
-def _bf16_nhwc_to_f32_nchw(t):
-    import ctypes
-    from ._lib import check, get_lib, ptr, stream_ptr
-    B, C, H, W = t.shape
-    y = torch.empty((B, C, H, W), dtype=torch.float32, device=t.device)
-    if y.numel():
-        check(get_lib().dfe_cast_bf16_nhwc_to_f32_nchw(ctypes.c_void_p(t.data_ptr()), ptr(y), B, C, H * W, stream_ptr()),
-              "dfe_cast_bf16_nhwc_to_f32_nchw")
-    return y
-
-
-def set_compute_dtype(dtype):
-    if dtype not in (None, torch.bfloat16, torch.float16):
-        raise ValueError("compute dtype must be None (fp32), torch.bfloat16 or torch.float16")
-    if dtype is not None and _AMP_NHWC:
-        os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")      # read by ATen's MIOpen wrapper; fp32 calls pass NCHW tensors and are not affected
-    _STATE["dtype"] = dtype
-
-
-def get_compute_dtype():
-    return _STATE["dtype"]
-
-
-@contextlib.contextmanager
-def compute_dtype(dtype):
-    old = _STATE["dtype"]
-    set_compute_dtype(dtype)
-    try:
-        yield
-    finally:
-        _STATE["dtype"] = old
 
 
 def _pair(v):
@@ -121,7 +43,7 @@ WINO_DILATED = os.environ.get("DFE_WINO_DILATED", "1") == "1"     # dilated laye
 def _wino_eligible(x, w_shape, cin, stride, padding, dilation, groups=1):
     """x [B,cin,H,W] convolved 3x3 / stride 1 with ``padding`` in {0, 1} (or dilated with padding = dilation dividing H and
     W): enough tiles and reduction channels?"""
-    if (WINO_MIN_TILES <= 0 or _STATE["dtype"] is not None or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4
+    if (WINO_MIN_TILES <= 0 or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4
             or groups != 1 or tuple(w_shape[2:]) != (3, 3) or stride != (1, 1) or dilation[0] != dilation[1]):
         return False
     B, C, H, W = x.shape
@@ -156,7 +78,7 @@ WINO_WGRAD_MAX_DILATION = int(os.environ.get("DFE_WINO_WGRAD_MAX_DILATION", "4")
 
 def _wino_wgrad_eligible(x, gy_shape, w_shape, padding, d):
     """x [B,Ci,H,W] (fp32, HIP), the output gradient's shape, the filter's shape, padding pair, dilation."""
-    if not WINO_WGRAD or _STATE["dtype"] is not None or x.dtype != torch.float32 or not x.is_cuda or x.dim() != 4:
+    if not WINO_WGRAD or x.dtype != torch.float32 or not x.is_cuda or x.dim() != 4:
         return False
     if d > 1 and not (d <= WINO_WGRAD_MAX_DILATION and padding == (d, d) and x.shape[2] % d == 0 and x.shape[3] % d == 0):
         return False
@@ -182,9 +104,6 @@ def _wgrad_route(x, w_shape, stride, padding, dilation, groups):
 def raw_forward(x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1)):
     """y = conv(x, w) without bias, fp32 in / fp32 out, no autograd of its own."""
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
-    dt = _STATE["dtype"]
-    if dt is not None:
-        return _high(F.conv2d(_low(x, dt), _low(w, dt), None, stride, padding, dilation))
     if _wino_eligible(x, w.shape, w.shape[1], stride, padding, dilation):
         from . import ops
         return ops.wino_conv3x3(x, w, padding[0], dilation=dilation[0])
@@ -194,12 +113,7 @@ def raw_forward(x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1)):
 def raw_backward(gy, x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1), want_x=True, want_w=True, want_b=False):
     """(gx, gw, gb) of y = conv(x, w) + b; fp32 in / fp32 out."""
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
-    dt = _STATE["dtype"]
     bias_sizes = [int(w.shape[0])] if want_b else None
-    if dt is not None:
-        gx, gw, gb = _cb(_low(gy, dt), _low(x, dt), _low(w, dt), bias_sizes, list(stride), list(padding), list(dilation), False, [0, 0], 1,
-                         [want_x, want_w, want_b])
-        return _high(gx), _high(gw), (gb.float() if gb is not None else None)
     d = dilation[0]
     own_w = want_w and stride == (1, 1) and tuple(w.shape[2:]) == (3, 3) and dilation == (d, d) and \
         _wino_wgrad_eligible(x, gy.shape, w.shape, padding, d)
@@ -220,28 +134,6 @@ def raw_backward(gy, x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1), want_
         gw = r[1] if want_w else gw
         gb = r[2] if want_b else gb
     return gx, gw, gb
-
-
-class _ConvFn(torch.autograd.Function):
-    """conv2d without bias in the reduced compute dtype (used only when one is set)."""
-
-    @staticmethod
-    def forward(ctx, x, w, stride, padding, dilation):
-        dt = _STATE["dtype"]
-        ctx.cfg = (stride, padding, dilation, dt)
-        xs = x if dt is None else _low(x, dt)     # the activation is kept in the compute dtype (half the footprint in bf16)
-        ctx.save_for_backward(xs, w)
-        if dt is not None:
-            return _high(F.conv2d(xs, _low(w, dt), None, stride, padding, dilation))
-        return raw_forward(x, w, stride, padding, dilation)
-
-    @staticmethod
-    def backward(ctx, gy):
-        xs, w = ctx.saved_tensors
-        stride, padding, dilation, dt = ctx.cfg
-        with compute_dtype(dt):
-            gx, gw, _ = raw_backward(gy, xs, w, stride, padding, dilation, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return gx, gw, None, None, None
 
 
 # Dilated 3x3 "same" convolutions (PWC's context network, pwc_tf.py:31-36: dilation 2, 4, 8, 16 at 64x208) as a dense 3x3
@@ -288,8 +180,7 @@ class _RawConvFn(torch.autograd.Function):
 
 
 def conv2d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1):
-    """``F.conv2d``; in the reduced compute dtype when one is set (HIP tensors, groups == 1); dilated 3x3 "same"
-    convolutions on the phase images (above)."""
+    """``F.conv2d`` with this build's kernels where they are eligible (fp32 HIP tensors, groups == 1)."""
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
     if groups == 1 and dilation[0] > 1 and _wino_eligible(x, w.shape, w.shape[1], stride, padding, dilation):
         y = _RawConvFn.apply(x, w, stride, padding, dilation)
@@ -301,10 +192,7 @@ def conv2d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1):
                         _wgrad_route(x, w.shape, stride, padding, dilation, groups)):
         y = _RawConvFn.apply(x, w, stride, padding, dilation)
         return y if bias is None else y + bias.view(1, -1, 1, 1)
-    if not (x.is_cuda and groups == 1 and _STATE["dtype"] is not None):
-        return F.conv2d(x, w, bias, stride, padding, dilation, groups)
-    y = _ConvFn.apply(x, w, stride, padding, dilation)
-    return y if bias is None else y + bias.view(1, -1, 1, 1)
+    return F.conv2d(x, w, bias, stride, padding, dilation, groups)
 
 
 class Conv2d(nn.Conv2d):

@@ -46,6 +46,13 @@ __device__ __forceinline__ void split_pixel(unsigned p, int W, float rW, unsigne
   px = p - py * static_cast<unsigned>(W);
 }
 
+// quotient estimate q ~ p / d from a reciprocal multiply, made exact by one integer step either way (the float
+// estimate's margin is ~0.5 / p relative; a wrong row GROUP would break the tile map's bijection silently as images grow)
+__device__ __forceinline__ unsigned fix_quotient(unsigned q, unsigned p, unsigned d) {
+  const unsigned lo = q * d;
+  return p < lo ? q - 1u : (p - lo >= d ? q + 1u : q);
+}
+
 // Pixel order of the pointwise kernels.  TW = 0: thread p of a scale computes pixel p (a wave = 64 consecutive pixels of a
 // row).  TW = 8 / 16 / 32: a wave covers a TW x (64 / TW) tile -- the bilinear taps of both warps then fall into a few
 // cache lines of 5 rows instead of 2 x 64-pixel row segments shifted by the flow, which is what the texture path is busy
@@ -59,16 +66,16 @@ __device__ __forceinline__ void tile_pixel(unsigned p, int W, int H, float rW, u
   constexpr unsigned TWu = TW > 0 ? TW : 1, TR = 64u / TWu, LG = TWu == 8 ? 3u : TWu == 16 ? 4u : 5u;
   static_assert(TW == 0 || TW == 8 || TW == 16 || TW == 32, "tile width");
   const unsigned Wu = static_cast<unsigned>(W);
-  const unsigned g = static_cast<unsigned>((static_cast<float>(p) + 0.5f) * (rW * (1.0f / static_cast<float>(TR))));   // p / (TR * W)
+  const unsigned g = fix_quotient(static_cast<unsigned>((static_cast<float>(p) + 0.5f) * (rW * (1.0f / static_cast<float>(TR)))), p, TR * Wu);   // p / (TR * W)
   if (g < static_cast<unsigned>(H) / TR) {
     const unsigned q = p - g * TR * Wu, WT = Wu & ~(TWu - 1u);
     if (q < TR * WT) { px = TWu * (q >> 6) + (q & (TWu - 1u)); py = TR * g + ((q & 63u) >> LG); }
     else {
       const unsigned e = q - TR * WT, wr = Wu - WT;
-      const unsigned r = static_cast<unsigned>((static_cast<float>(e) + 0.5f) / static_cast<float>(wr));
+      const unsigned r = fix_quotient(static_cast<unsigned>((static_cast<float>(e) + 0.5f) / static_cast<float>(wr)), e, wr);
       px = WT + e - r * wr; py = TR * g + r;
     }
-  } else split_pixel(p, W, rW, px, py);
+  } else { split_pixel(p, W, rW, px, py); py = fix_quotient(py, p, Wu); px = p - py * Wu; }
 }
 
 // the same map with integer divisions (kernels that carry no reciprocal table)

@@ -595,7 +595,7 @@ PLANECONV_MAX_HW = int(os.environ.get("DFE_PLANECONV_MAX_HW", "208"))
 
 
 def planeconv_eligible(x, w):
-    if PLANECONV_MAX_HW <= 0 or not x.is_cuda or convs.get_compute_dtype() is not None or x.dim() != 4:
+    if PLANECONV_MAX_HW <= 0 or not x.is_cuda or x.dim() != 4:
         return False
     B, Ci, H, W = x.shape
     return (x.dtype == torch.float32 and w.dtype == torch.float32 and tuple(w.shape[1:]) == (Ci, 3, 3)
@@ -978,7 +978,7 @@ class Conv1x1SmallFn(torch.autograd.Function):
 
 
 def conv1x1_small_eligible(x, conv):
-    return (PLANECONV_MAX_HW > 0 and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and convs.get_compute_dtype() is None
+    return (PLANECONV_MAX_HW > 0 and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32
             and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
             and get_lib().dfe_conv1x1_small_supported(x.shape[0], x.shape[1], conv.out_channels, x.shape[2], x.shape[3]) == 1)
 
@@ -1048,8 +1048,7 @@ class DenseDecodeFn(torch.autograd.Function):
         if flow_head_eligible(cat[3], w[5], b[5]):
             flow = flow_head_fwd_raw(cat[3], f32c(w[5]), f32c(b[5]))
         else:
-            flow = F.conv2d(cat[3], w[5], b[5], 1, 1) if convs.get_compute_dtype() is None else \
-                convs.raw_forward(cat[3], w[5], 1, 1) + b[5].view(1, -1, 1, 1)
+            flow = F.conv2d(cat[3], w[5], b[5], 1, 1)
         ctx.save_for_backward(x, z0, *cat, *w)
         ctx.slope, ctx.co, ctx.plane = slope, co, plane
         ctx.set_materialize_grads(False)
@@ -1254,8 +1253,7 @@ def flow_head_bwd_raw(x, weight, gout, want_w=True, want_b=True):
 
 
 def flow_head_eligible(x, weight, bias=None):
-    """PWC's predict_flow layers (pwc_tf.py:39-40): two output channels, 3x3, channel count a multiple of 8.  The head
-    kernels compute in fp32 whatever ``convs.compute_dtype`` says (activations are fp32 between the convolutions' doors)."""
+    """PWC's predict_flow layers (pwc_tf.py:39-40): two output channels, 3x3, channel count a multiple of 8."""
     return (os.environ.get("DFE_FLOW_HEAD", "1") != "0" and x.is_cuda
             and x.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and weight.shape[0] == 2
             and weight.shape[1] == x.shape[1] and x.shape[1] % 8 == 0 and bias is not None)
@@ -1279,29 +1277,15 @@ class FlowHeadFn(torch.autograd.Function):
 
 
 class ThinConv3x3Fn(torch.autograd.Function):
-    """Valid 3x3 convolution of a pre-padded activation, bias-free, for the decoder's thin full-resolution layers.
-    The weight gradient -- a (Co x 9 Ci) contraction over B*H*W pixels -- always runs the fp32-MFMA kernel
-    dfe_wgrad3x3_fwd; the 16 -> 16 layer (256x832, where MIOpen reaches 40 TFLOP/s) also runs its forward and data
-    gradient on dfe_thin_conv3x3, the other layers keep MIOpen for those two passes."""
-
-    @staticmethod
-    def _mfma_passes(p, weight):
-        """16 -> 16 on dfe_thin_conv3x3 -- unless the fused Winograd kernel takes the layer (round 4: 154 / 157 us against
-        165 / 186 for the forward pass / data gradient at 258x834 x 12): then raw_forward / raw_backward route it there."""
-        return (weight.shape[0] == 16 and weight.shape[1] == 16 and
-                not convs._wino_eligible(p, weight.shape, weight.shape[1], (1, 1), (0, 0), (1, 1)))
+    """Valid 3x3 convolution of a pre-padded activation, bias-free, for the decoder's thin full-resolution layers (at most 32
+    output channels at >= 64x208 pixels).  Forward and data gradient: convs.raw_forward / raw_backward (the half-tile Winograd
+    kernel since round 4; round 3's dfe_thin_conv3x3 was removed in round 5).  Weight gradient -- a (Co x 9 Ci) contraction over
+    B*H*W pixels: 16 output channels on dfe_wgrad3x3_fwd (fp32 MFMA straight from NCHW), 32 on the Winograd-domain kernel."""
 
     @staticmethod
     def forward(ctx, p, weight):
         ctx.save_for_backward(p, weight)
-        if not ThinConv3x3Fn._mfma_passes(p, weight):
-            return convs.raw_forward(p, weight)
-        lib = get_lib()
-        weight = f32c(weight)
-        B, Ci, Hp, Wp = p.shape
-        out = torch.empty(B, 16, Hp - 2, Wp - 2, device=p.device)
-        check(lib.dfe_thin_conv3x3(ptr(p), ptr(weight), ptr(out), B, Ci, 16, Hp, Wp, 0, 0, stream_ptr()), "dfe_thin_conv3x3")
-        return out
+        return convs.raw_forward(p, weight)
 
     @staticmethod
     def backward(ctx, gy):
@@ -1312,12 +1296,7 @@ class ThinConv3x3Fn(torch.autograd.Function):
         Co, H, W = weight.shape[0], Hp - 2, Wp - 2
         gp = gw = None
         if ctx.needs_input_grad[0]:
-            if ThinConv3x3Fn._mfma_passes(p, weight):
-                gp = torch.empty_like(p)
-                check(lib.dfe_thin_conv3x3(ptr(gy), ptr(f32c(weight)), ptr(gp), B, Co, Ci, H, W, 2, 1, stream_ptr()),
-                      "dfe_thin_conv3x3 (data gradient)")
-            else:
-                gp = convs.raw_backward(gy, p, weight, 1, 0, 1, True, False)[0]
+            gp = convs.raw_backward(gy, p, weight, 1, 0, 1, True, False)[0]
         if ctx.needs_input_grad[1]:
             if Co >= 32 and Ci >= 64 and convs.WINO_WGRAD:
                 # round 5: the Winograd-domain kernel is faster on the 32-output-channel layers (96 -> 32 at 130x418 x 12:
@@ -1328,52 +1307,6 @@ class ThinConv3x3Fn(torch.autograd.Function):
                 part = torch.empty(lib.dfe_wgrad3x3_partials_floats(B, Ci, Co, H, W), device=p.device)
                 check(lib.dfe_wgrad3x3_fwd(ptr(p), ptr(gy), ptr(gw), ptr(part), B, Ci, Co, H, W, stream_ptr()), "dfe_wgrad3x3_fwd")
         return gp, gw
-
-
-class ThinConvSameFn(torch.autograd.Function):
-    """Zero-padded 3x3 "same" convolution 16 -> 16, bias-free (FeaturePyramid's conv2 at 128x416, feature_pyramid.py /
-    net_utils.conv): forward and data gradient on dfe_thin_conv3x3 with P = 1 (MIOpen: 88 / 82 us at 12 x 16 x 128 x 416,
-    25-36 TFLOP/s; here 54 us forward), weight gradient on dfe_wgrad3x3_fwd over a zero-padded copy of the input
-    (MIOpen: 119 us)."""
-
-    @staticmethod
-    def forward(ctx, x, weight):
-        lib = get_lib()
-        x, weight = f32c(x), f32c(weight)
-        B, _, H, W = x.shape
-        out = torch.empty(B, 16, H, W, device=x.device)
-        check(lib.dfe_thin_conv3x3(ptr(x), ptr(weight), ptr(out), B, 16, 16, H, W, 1, 0, stream_ptr()), "dfe_thin_conv3x3 (same)")
-        ctx.save_for_backward(x, weight)
-        return out
-
-    @staticmethod
-    def backward(ctx, gy):
-        lib = get_lib()
-        x, weight = ctx.saved_tensors
-        gy = f32c(gy)
-        B, _, H, W = x.shape
-        gx = gw = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.empty_like(x)
-            check(lib.dfe_thin_conv3x3(ptr(gy), ptr(weight), ptr(gx), B, 16, 16, H, W, 1, 1, stream_ptr()), "dfe_thin_conv3x3 (same, data gradient)")
-        if ctx.needs_input_grad[1]:
-            p = torch.nn.functional.pad(x, (1, 1, 1, 1))
-            gw = torch.empty_like(weight)
-            part = torch.empty(lib.dfe_wgrad3x3_partials_floats(B, 16, 16, H, W), device=x.device)
-            check(lib.dfe_wgrad3x3_fwd(ptr(p), ptr(gy), ptr(gw), ptr(part), B, 16, 16, H, W, stream_ptr()), "dfe_wgrad3x3_fwd")
-        return gx, gw
-
-
-def thin_conv_same_eligible(x, conv):
-    """FeaturePyramid-style 16 -> 16 3x3 stride-1 pad-1 layers on planes of at least 128 x 416 (where it was measured)."""
-    from . import convs
-    if os.environ.get("DFE_THIN_SAME", "1") == "0" or convs.get_compute_dtype() is not None:
-        return False
-    if convs._wino_eligible(x, conv.weight.shape, conv.in_channels, conv.stride, conv.padding, conv.dilation, conv.groups):
-        return False        # the fused Winograd kernel takes the layer (37 against ~57 us at 128x416 x 12)
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.in_channels == 16 and conv.out_channels == 16
-            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
-            and conv.groups == 1 and x.shape[3] % 16 == 0 and x.shape[2] * x.shape[3] >= 128 * 416)
 
 
 def thin_conv3x3_eligible(p, weight):

@@ -15,8 +15,6 @@ class ConvAct(nn.Sequential):
         if not x.is_cuda:
             return super().forward(x)
         c = self[0]
-        if ops.thin_conv_same_eligible(x, c):       # FeaturePyramid conv2: fp32 MFMA kernels (ops.ThinConvSameFn)
-            return ops.bias_act(ops.ThinConvSameFn.apply(x, c.weight), c.bias, self[1].negative_slope)
         if (c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1) and c.groups == 1
                 and ops.planeconv_eligible(x, c.weight)):   # FeaturePyramid's top levels (8x26, 4x13): small-plane MFMA kernels
             return ops.planeconv_act(x, c.weight, c.bias, self[1].negative_slope)
