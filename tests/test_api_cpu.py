@@ -155,6 +155,24 @@ def test_synthetic_dataset_contract():
     assert np.array_equal(a.flows_fwd[0], b.flows_fwd[0]) and len(a.flows_fwd) == 4
 
 
+def test_profiler_keeps_the_reference_interface(capsys):
+    """profiling.Profiler = core/visualize/profiler.py's report_process / report_all / reset (no GPU needed); ranges are free
+    when profiling is off."""
+    from unsupervised_depth_opticalflow_egomotion_amd import profiling
+    assert not profiling.enabled()
+    with profiling.range("section"):
+        pass
+    pr = profiling.Profiler()
+    pr.report_process("load")
+    pr.report_all("whole")
+    out = capsys.readouterr().out
+    assert "load\t: " in out and "whole\t: " in out
+    quiet = profiling.Profiler(silent=True)
+    assert quiet.report_process("x") is None and quiet.report_all("y") is None
+    quiet.reset(silent=False)
+    assert quiet.silent is False
+
+
 def _tile_pixel_host(p, W, H, TW, float_path):
     """csrc/loss_stack_exact.h tile_pixel<TW> restated with numpy: the reciprocal-multiply estimate in float32 exactly as the
     device evaluates it + the integer fix-up (float_path), or the integer-division overload."""

@@ -534,8 +534,10 @@ def test_train_cli_smoke(tmp_path):
     ck = torch.load(os.path.join(str(tmp_path), "depth", "last.pth"), map_location="cpu")
     assert set(ck.keys()) == {"iteration", "model_state_dict", "optimizer_state_dict"} and ck["iteration"] == 2
     assert any(k.startswith("depth_net.encoder.encoder.layer1.0.conv1") for k in ck["model_state_dict"])
-    out = subprocess.run(base + ["--num_iterations", "3", "--resume"], capture_output=True, text=True, cwd=repo, timeout=600)
+    # --profile (core/visualize/profiler.py): roctx ranges per HIP launcher + the Profiler's section times
+    out = subprocess.run(base + ["--num_iterations", "3", "--resume", "--profile"], capture_output=True, text=True, cwd=repo, timeout=600)
     assert out.returncode == 0 and "iter      2 total" in out.stdout, out.stderr[-2000:]
+    assert all(("%s\t: " % k) in out.stdout for k in ("forward", "backward", "optimizer")), out.stdout[-1500:]
 
 
 def _bench_json(out):

@@ -11,4 +11,4 @@ for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ
   f=$(find /tmp/pw$i -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then cp "$f" $OUT/${TAG}_wino_pmc_pass$i.csv; FILES="$FILES $OUT/${TAG}_wino_pmc_pass$i.csv"; else tail -5 /tmp/pw$i.log; fi
 done
-python3 $R/tools/pmc_by_kernel.py "k_wino_fwd16|k_wino_wgrad<" $FILES > $OUT/${TAG}_wino_pmc.txt
+python3 $R/tools/pmc_by_kernel.py "k_wino_fwd16|k_wino_wgrad2" $FILES > $OUT/${TAG}_wino_pmc.txt

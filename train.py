@@ -83,6 +83,11 @@ def train(cfg):
         dataset = synthetic.SyntheticRawTriplets(n_iter * cfg.batch_size * world, (375, 1242), (h, w), cfg.num_scales, seed=1234)
     else:
         dataset = synthetic.SyntheticTriplets(n_iter * cfg.batch_size * world, (h, w), cfg.num_scales, seed=1234)
+    prof = None
+    if getattr(cfg, "profile", False):       # the reference's Profiler marks (core/visualize/profiler.py) + roctx ranges per HIP launcher
+        from unsupervised_depth_opticalflow_egomotion_amd import profiling
+        profiling.enable()
+        prof = profiling.Profiler(silent=rank != 0)
     t0 = time.time()
     for it in range(start, cfg.num_iterations):
         base = (it - start) * cfg.batch_size * world + rank * cfg.batch_size
@@ -94,7 +99,9 @@ def train(cfg):
                 [torch.stack([s[i] for s in samples]).to(dev, non_blocking=True) for i in (1, 2)]
         else:
             inputs = [torch.stack([s[i] for s in samples]).to(dev, non_blocking=True) for i in range(3)]
-        loss, loss_pack, mask_pack = train_step(model, optimizer, inputs, cfg)
+        if prof is not None:
+            prof.reset()
+        loss, loss_pack, mask_pack = train_step(model, optimizer, inputs, cfg, prof if (prof is not None and it % cfg.log_interval == 0) else None)
         if rank == 0 and it % cfg.log_interval == 0:
             print_loss(it, loss_pack, weights, loss)
         if rank == 0 and (it + 1) % cfg.save_interval == 0:
@@ -130,6 +137,9 @@ if __name__ == "__main__":
     ap.add_argument("--fix_pose", action="store_true")
     ap.add_argument("--fix_flow", action="store_true")
     ap.add_argument("--num_iterations", type=int, default=None)
+    ap.add_argument("--profile", action="store_true",
+                    help="roctx ranges around every HIP launcher (rocprofv3 --marker-trace) and the reference Profiler's forward / backward / "
+                         "optimizer wall times at every log interval (synchronises the device at each mark)")
     ap.add_argument("--device_pipeline", action="store_true",
                     help="feed raw uint8 triplets and run resize / flip / normalise on the device (ops.prepare_triplets)")
     args = ap.parse_args()

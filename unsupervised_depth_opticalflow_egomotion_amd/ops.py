@@ -1280,7 +1280,7 @@ class ThinConv3x3Fn(torch.autograd.Function):
     """Valid 3x3 convolution of a pre-padded activation, bias-free, for the decoder's thin full-resolution layers (at most 32
     output channels at >= 64x208 pixels).  Forward and data gradient: convs.raw_forward / raw_backward (the half-tile Winograd
     kernel since round 4; round 3's dfe_thin_conv3x3 was removed in round 5).  Weight gradient -- a (Co x 9 Ci) contraction over
-    B*H*W pixels: 16 output channels on dfe_wgrad3x3_fwd (fp32 MFMA straight from NCHW), 32 on the Winograd-domain kernel."""
+    B*H*W pixels: the Winograd-domain kernel from 32 input channels up, dfe_wgrad3x3_fwd (fp32 MFMA straight from NCHW) for 16 -> 16."""
 
     @staticmethod
     def forward(ctx, p, weight):
@@ -1298,9 +1298,10 @@ class ThinConv3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gp = convs.raw_backward(gy, p, weight, 1, 0, 1, True, False)[0]
         if ctx.needs_input_grad[1]:
-            if Co >= 32 and Ci >= 64 and convs.WINO_WGRAD:
-                # round 5: the Winograd-domain kernel is faster on the 32-output-channel layers (96 -> 32 at 130x418 x 12:
-                # 229 against 374 us; 64 -> 32 at 66x210: 60 against 70); 16 output channels stay here (133 against 304)
+            if Ci >= 32 and convs.WINO_WGRAD:
+                # round 5: the Winograd-domain kernel is faster wherever there are >= 32 input channels (96 -> 32 at 130x418 x 12:
+                # 229 against 374 us; 64 -> 32 at 66x210: 60 against 70; 32 -> 16 at 130x418: 102 against ~124); the 16 -> 16
+                # layer at 258x834 stays here (133 against 304)
                 gw = wino_wgrad3x3(p, gy, 0)
             else:
                 gw = torch.empty_like(weight)

@@ -72,10 +72,21 @@ def total_loss(loss_pack, cfg):
     return total
 
 
-def train_step(model, optimizer, inputs, cfg):
+def train_step(model, optimizer, inputs, cfg, profiler=None):
+    """``profiler``: a profiling.Profiler (train.py --profile): the reference's per-section wall times (synchronising marks)."""
+    from . import profiling
     optimizer.zero_grad(set_to_none=True)
-    loss_pack, mask_pack = model(inputs)
-    loss = total_loss(loss_pack, cfg)
-    loss.backward()
-    optimizer.step()
+    with profiling.range("forward"):
+        loss_pack, mask_pack = model(inputs)
+        loss = total_loss(loss_pack, cfg)
+    if profiler is not None:
+        profiler.report_process("forward")
+    with profiling.range("backward"):
+        loss.backward()
+    if profiler is not None:
+        profiler.report_process("backward")
+    with profiling.range("optimizer"):
+        optimizer.step()
+    if profiler is not None:
+        profiler.report_process("optimizer")
     return loss, loss_pack, mask_pack
