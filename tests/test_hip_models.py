@@ -622,8 +622,12 @@ noise = max(float((x - y).abs().max()) for x, y in zip(a0, a1))
 diff = max(float((x - y).abs().max()) for x, y in zip(a0, b))
 diff_t = max(float((x - y).abs().max()) for x, y in zip(a0, c))
 scale = max(float(x.abs().max()) for x in a0)
-print("RESULT " + json.dumps({"noise": noise, "diff": diff, "diff_torch": diff_t, "scale": scale, "allreduce": float(t), "losses": [la0, lb, lc],
-                              "info": info, "info_torch": info_t}))
+n_all = sum(x.numel() for x in a0)
+thr = max(4.0 * noise, 1e-6 * scale)
+frac = sum(int(((x - y).abs() > thr).sum()) for x, y in zip(a0, b)) / n_all          # elements beyond the run-to-run yardstick
+frac_t = sum(int(((x - y).abs() > thr).sum()) for x, y in zip(a0, c)) / n_all
+print("RESULT " + json.dumps({"noise": noise, "diff": diff, "diff_torch": diff_t, "frac": frac, "frac_torch": frac_t, "scale": scale,
+                              "allreduce": float(t), "losses": [la0, lb, lc], "info": info, "info_torch": info_t}))
 """
 
 
@@ -654,10 +658,16 @@ def test_rccl_world1_ddp_on_the_real_joint_model():
     assert info_t["type"] == "DistributedDataParallel" and info_t["bucket_view"] and info_t["fc_has_no_grad"]
     for i in (info, info_t):
         assert i["ignored"] == ["depth_net.encoder.encoder.fc.bias", "depth_net.encoder.encoder.fc.weight"]
-    assert r["diff"] <= max(4.0 * r["noise"], 1e-6 * r["scale"]), r
-    assert r["diff_torch"] <= max(4.0 * r["noise"], 1e-6 * r["scale"]), r
+    # Two Adam steps move a parameter by <= 2 lr = 2e-4 whatever its gradient's size (the update is ~ lr * sign(g) at first), so
+    # an element whose tiny gradient changes sign between two runs differs by up to 2e-4: the MAXIMUM difference only says
+    # "within two steps" (round 5: with this build's reproducible weight gradients the run-to-run noise fell to ~3e-5 and a
+    # 1.2e-4 maximum tripped the old 4 x noise bound).  What a broken reduction would show is MANY such elements and a
+    # different loss: at most 1e-4 of the 21.6 M elements may exceed the run-to-run yardstick, and the losses must agree.
+    assert r["diff"] <= 4.1e-4 * r["scale"] and r["diff_torch"] <= 4.1e-4 * r["scale"], r
+    assert r["frac"] <= 1e-4 and r["frac_torch"] <= 1e-4, r
     for k in (1, 2):
         assert abs(r["losses"][0][0] - r["losses"][k][0]) <= 1e-4 * abs(r["losses"][0][0])
+        assert abs(r["losses"][0][1] - r["losses"][k][1]) <= 1e-4 * abs(r["losses"][0][1])      # the second step saw the same update
 
 
 def test_bench_force_ddp_prints_the_multi_gpu_block_on_one_gpu():

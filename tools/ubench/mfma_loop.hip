@@ -183,6 +183,78 @@ void runp(const char* name, int blocks, int steps, float* out) {
   printf("%-44s blocks %4d occ %d: %8.1f us  ideal %7.1f us  pipe %5.1f %%\n", name, blocks, OCC, ms * 1e3, ideal_us, 100.0 * ideal_us / (ms * 1e3));
 }
 
+// 32x32x2 variant (weight-gradient shape): a lane owns (channel = lane & 31, tile = lane >> 5); per step of 2 tiles it reads a raw 2x2
+// gy tile and a raw 4x4 x patch from LDS, transforms both (12 + 32 adds) and issues 16 v_mfma_f32_32x32x2_f32 on 16 accumulators of
+// 16 registers (32 x 32 channels x 16 positions = 256 accumulator registers, one wave per SIMD).  PIPE: operands read a step ahead.
+template <int PIPE>
+__global__ void __launch_bounds__(256, 1) k_loop32(float* __restrict__ out, int steps) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, ch = lane & 31, tq = lane >> 5;
+  for (int i = tid; i < 12288; i += 256) lds[i] = 0.001f * (i % 97);
+  __syncthreads();
+  f32x16 acc[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[s][j] = 0.f;
+  const float* gb = lds + ((wv & 1) * 32 + ch) * 56 + 2 * tq;            // gy: [64 ch][2 rows][24] + pad
+  const float* xb = lds + 4096 + ((wv >> 1) * 32 + ch) * 136 + 2 * tq + 3;   // x: [64 ch][4 rows][32] + pad
+  int opq = 0;
+  auto rd = [&](int st, float (&m)[16], float (&v)[16]) {
+    const float* p = gb + (st % 6) * 4 + opq;
+    const f32x2 r0 = *reinterpret_cast<const f32x2*>(p), r1 = *reinterpret_cast<const f32x2*>(p + 24);
+    const float a0[4] = {r0[0], r0[0] + r1[0], r0[0] - r1[0], r1[0]};
+    const float a1[4] = {r0[1], r0[1] + r1[1], r0[1] - r1[1], r1[1]};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { m[4 * q] = a0[q]; m[4 * q + 1] = a0[q] + a1[q]; m[4 * q + 2] = a0[q] - a1[q]; m[4 * q + 3] = a1[q]; }
+    const float* px = xb + (st % 6) * 4 + opq;
+    float d[16], t[16];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f32x2 mid = *reinterpret_cast<const f32x2*>(px + r * 32 + 1);
+      d[4 * r] = px[r * 32]; d[4 * r + 1] = mid[0]; d[4 * r + 2] = mid[1]; d[4 * r + 3] = px[r * 32 + 3];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { t[j] = d[j] - d[8 + j]; t[4 + j] = d[4 + j] + d[8 + j]; t[8 + j] = d[8 + j] - d[4 + j]; t[12 + j] = d[4 + j] - d[12 + j]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i * 4] = t[i * 4] - t[i * 4 + 2]; v[i * 4 + 1] = t[i * 4 + 1] + t[i * 4 + 2]; v[i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1]; v[i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3]; }
+  };
+  float ma[16], va[16], mb[16], vb[16];
+  rd(0, ma, va);
+  for (int st = 0; st < steps; st += 2) {
+    asm volatile("" : "+s"(opq));
+    if (PIPE) rd(st + 1, mb, vb);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(ma[s], va[s], acc[s], 0, 0, 0);
+    if (!PIPE) rd(st + 1, mb, vb);
+    asm volatile("" : "+s"(opq));
+    if (PIPE) rd(st + 2, ma, va);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(mb[s], vb[s], acc[s], 0, 0, 0);
+    if (!PIPE) rd(st + 2, ma, va);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int s = 0; s < 16; ++s)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sum += acc[s][j];
+  out[blockIdx.x * 256 + tid] = sum;
+}
+
+template <int PIPE>
+void run32(const char* name, int blocks, int steps, float* out) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k_loop32<PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 49152);
+  for (int i = 0; i < 2; ++i) k_loop32<PIPE><<<blocks, 256, 49152>>>(out, steps);
+  hipEventRecord(a);
+  for (int i = 0; i < 5; ++i) k_loop32<PIPE><<<blocks, 256, 49152>>>(out, steps);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b); ms /= 5;
+  const double mfma = double(blocks) * 4 * steps * 16;                    // 64-cycle MFMAs
+  const double ideal_us = mfma * 64.0 / 1024.0 / 2400.0;
+  printf("%-44s blocks %4d occ 1: %8.1f us  ideal %7.1f us  pipe %5.1f %%\n", name, blocks, ms * 1e3, ideal_us, 100.0 * ideal_us / (ms * 1e3));
+}
+
 int main() {
   float* out; hipMalloc(&out, 4096 * 256 * 4);
   const int steps = 2000;
@@ -202,5 +274,7 @@ int main() {
   runp<1, 1>("pipelined, compiler-scheduled, 1 wave", 256, steps, out);
   runp<2, 1>("pipelined, sched_barrier, 1 wave", 256, steps, out);
   runp<3, 1>("pipelined, sched_group_barrier, 1 wave", 256, steps, out);
+  run32<0>("32x32x2, 256 accumulators, 1 wave", 256, steps, out);
+  run32<1>("32x32x2, 256 accumulators, pipelined, 1 wave", 256, steps, out);
   return 0;
 }

@@ -34,11 +34,15 @@ struct WgCfg {
   static constexpr int COB = 16 * MH * WM, CIB = 16 * NH * WN;
   static constexpr int XU = TWC == 8 ? 6 : 8;          // 16-byte slots of an x row that are loaded (2 TWC + 2 columns + alignment)
   static constexpr int XP = 4 * XU;                    // x row in LDS, floats
-  static constexpr int XCS = 4 * XP + 8;               // floats per input channel: 4 rows + 8 (channel stride / 8 odd: 16 lanes x 4 tiles hit 64 banks)
+  // floats per input channel: 4 rows + 4.  A wave reads 8-byte pairs: lane group {0-31} = 16 channels x 2 tiles, each lane two
+  // of the 64 banks; with the channel stride / 4 ODD the 16 channels start at 16 different multiples of 4 banks and the two tiles
+  // take banks {0,1} / {2,3} of that window: conflict-free.  (Round 5's first version -- stride / 8 odd, the odd patch column read
+  // as single dwords -- spent 68 % of its LDS cycles in bank conflicts with the LDS array 64 % busy: profiles/r05_wino_pmc.txt.)
+  static constexpr int XCS = 4 * XP + 4;
   static constexpr int GU = TWC / 2;                   // 16-byte slots of a gy row
   static constexpr int GSL = TWC == 8 ? 4 : 8;         // ... as dealt to the threads (a power of two)
   static constexpr int GP = 2 * TWC;                   // gy row in LDS
-  static constexpr int GCS = 2 * GP + 8;               // floats per output channel
+  static constexpr int GCS = 2 * GP + 4;               // floats per output channel (stride / 4 odd, as XCS)
   static constexpr int BUF = CIB * XCS + COB * GCS;    // floats per LDS buffer
   // staging: x rows are dealt as 8 slots (XU used): thread = (slot of the row, row, channel mod 8); a thread's slots differ only
   // in the channel.  gy rows as GSL slots: thread = (slot, row, channel mod 256 / (2 GSL))
@@ -167,9 +171,10 @@ k_wino_wgrad2(const float* __restrict__ x, long xbs, const float* __restrict__ g
       float d[16], t[16], v[16];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (PP == 1) {         // patch column 0 at an odd LDS column: dword, aligned pair, dword
-          const wg_f32x2 mid = *reinterpret_cast<const wg_f32x2*>(p + r * WG_XP + 1);
-          d[4 * r] = p[r * WG_XP]; d[4 * r + 1] = mid[0]; d[4 * r + 2] = mid[1]; d[4 * r + 3] = p[r * WG_XP + 3];
+        if (PP == 1) {         // patch column 0 at an odd LDS column: three aligned pairs (dword reads would meet 4 to a bank)
+          const wg_f32x2 lo = *reinterpret_cast<const wg_f32x2*>(p + r * WG_XP - 1), mid = *reinterpret_cast<const wg_f32x2*>(p + r * WG_XP + 1),
+                         hi = *reinterpret_cast<const wg_f32x2*>(p + r * WG_XP + 3);
+          d[4 * r] = lo[1]; d[4 * r + 1] = mid[0]; d[4 * r + 2] = mid[1]; d[4 * r + 3] = hi[0];
         } else {
           const wg_f32x2 lo = *reinterpret_cast<const wg_f32x2*>(p + r * WG_XP), hi = *reinterpret_cast<const wg_f32x2*>(p + r * WG_XP + 2);
           d[4 * r] = lo[0]; d[4 * r + 1] = lo[1]; d[4 * r + 2] = hi[0]; d[4 * r + 3] = hi[1];
@@ -298,7 +303,7 @@ bool wg_plan(int B, int Ci, int Co, int H, int W, int P, WgPlan* pl) {
   // 64 x 32 blocks (128 accumulators, two per CU) when there are many input channels to share each staged gy tile between
   // (the 64 x 64 form -- 256 accumulators, one wave per SIMD -- spills in the compiler's hands and was dropped)
   const int co_pad = (Co + 63) / 64 * 64 - Co;
-  p.mh = (Co >= 64 && co_pad < 16 && Ci >= 192) ? 2 : 1; p.nh = 1;
+  p.mh = (Co >= 64 && co_pad < 16 && Ci >= 128) ? 2 : 1; p.nh = 1;
   if (force >= 11 && force != 22) { p.mh = force / 10; p.nh = force % 10; }
   // 12-tile chunks (3 steps per barrier) where two blocks still share a CU's LDS: every tile but 32 x 64
   p.twc = (p.nh == 2 || g_wg_tune[3] == 8) ? 8 : 12;
