@@ -85,7 +85,7 @@ def run_level(B, C, H, W, do_check, only_corr=False, iters=50):
     wf = lambda: check(lib.dfe_warp_flow_fwd(ptr(f2), ptr(flow), ptr(warped), B, C, H, W, 0, 0, s), "wf")
     wb = lambda: check(lib.dfe_warp_flow_bwd(ptr(f2), ptr(flow), ptr(gy), ptr(gflow), ptr(gx2), ptr(ws), B, C, H, W, 0, 0, s), "wb")
     res["warp_flow_fwd"] = (timeit(wf, iters), (2 * C + 2) * HW * 4 * B)
-    res["warp_flow_bwd (zero-fill + max + scatter + convert: 4 launches)"] = (timeit(wb, iters), (4 * C + 4) * HW * 4 * B)
+    res["warp_flow_bwd (levels >= 16x52: header fill + max + flow gradient + inverse map (count, scan, fill) + gather; below: zero-fill + max + scatter + convert)"] = (timeit(wb, iters), (4 * C + 4) * HW * 4 * B)
     x = torch.empty(B, lib.dfe_pwc_level_channels(C), H, W, device=dev)
     gxl = torch.randn_like(x)
     g_w, g_c1, g_c2, g_fl = torch.empty_like(f1), torch.empty_like(f1), torch.empty_like(f1), torch.empty_like(flow)
@@ -93,7 +93,7 @@ def run_level(B, C, H, W, do_check, only_corr=False, iters=50):
     lb = lambda: check(lib.dfe_pwc_level_bwd(ptr(f1), ptr(f2), ptr(flow), ptr(warped), ptr(gxl), ptr(g_w), ptr(g_c1), ptr(g_c2), ptr(ws),
                                              ptr(g_fl), B, C, H, W, 0, s), "lvlb")
     res["pwc_level_fwd (warp + corr + c1 / flow planes: 2 launches)"] = (timeit(lv, iters), ((2 * C + 2) + (2 * C + 81) + 2 * (C + 2)) * HW * 4 * B)
-    res["pwc_level_bwd (zero-fill + corr both gradients + warp scatter + convert: 4 launches)"] = (timeit(lb, iters), (2 * (2 * C + 81) + (C + 2) + (4 * C + 4)) * HW * 4 * B)
+    res["pwc_level_bwd (levels >= 16x52: header fill + corr both gradients + flow gradient + inverse map (3 launches) + gather; below: zero-fill + corr + scatter + convert)"] = (timeit(lb, iters), (2 * (2 * C + 81) + (C + 2) + (4 * C + 4)) * HW * 4 * B)
     return res, err
 
 

@@ -258,13 +258,15 @@ k_wino_wgrad2(const float* __restrict__ x, long xbs, const float* __restrict__ g
       }
 }
 
-// gw[i] = sum over the splits of part[s][i]: 8 groups of consecutive splits are summed side by side (each in split order) and
-// the 8 group sums are added in group order -- a fixed association, whatever the timing
-__global__ void __launch_bounds__(256) k_wgrad_sum(const float* __restrict__ part, float* __restrict__ gw, int S, long n) {
-  __shared__ float sm[8][32];
+// gw[i] = sum over the splits of part[s][i]: SG groups of consecutive splits are summed side by side (each in split order) and
+// the SG group sums are added in group order -- a fixed association, whatever the timing.  32 groups when there are many splits
+// (64 x 64 filters: up to 768 splits of 36 k outputs -- 8 groups left every thread a chain of ~100 dependent loads).
+template <int SG>
+__global__ void __launch_bounds__(32 * SG) k_wgrad_sum(const float* __restrict__ part, float* __restrict__ gw, int S, long n) {
+  __shared__ float sm[SG][32];
   const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
   const long idx = static_cast<long>(blockIdx.x) * 32 + o;
-  const int per = (S + 7) / 8, s0 = g * per, s1 = min(S, s0 + per);
+  const int per = (S + SG - 1) / SG, s0 = g * per, s1 = min(S, s0 + per);
   float s = 0.0f;
   if (idx < n)
     for (int k = s0; k < s1; ++k) s += part[k * n + idx];
@@ -273,7 +275,7 @@ __global__ void __launch_bounds__(256) k_wgrad_sum(const float* __restrict__ par
   if (g == 0 && idx < n) {
     float t = sm[0][o];
 #pragma unroll
-    for (int j = 1; j < 8; ++j) t += sm[j][o];
+    for (int j = 1; j < SG; ++j) t += sm[j][o];
     gw[idx] = t;
   }
 }
@@ -375,7 +377,8 @@ extern "C" int dfe_wino_wgrad3x3(const float* x, long x_batch_stride, const floa
 #undef WG_GO
   DFE_LAUNCH_CHECK();
   const long n = static_cast<long>(Co) * Ci * 9;
-  k_wgrad_sum<<<static_cast<unsigned>((n + 31) / 32), 256, 0, st>>>(ws, gweight, p.S, n);
+  if (p.S > 64) k_wgrad_sum<32><<<static_cast<unsigned>((n + 31) / 32), 1024, 0, st>>>(ws, gweight, p.S, n);
+  else k_wgrad_sum<8><<<static_cast<unsigned>((n + 31) / 32), 256, 0, st>>>(ws, gweight, p.S, n);
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
