@@ -315,51 +315,6 @@ __global__ void __launch_bounds__(256) k_wfg_fill(const float* __restrict__ flow
   }
 }
 
-// The inverse map of one sample in ONE block (round 5; replaces hipMemsetAsync + k_wfg_count + k_wfg_scan + k_wfg_fill where a
-// sample's counters fit in LDS): counters in LDS, an in-block exclusive scan, the entries filled through LDS cursors.  Block 0 also
-// clears the workspace's header (the bound of the contributions is max-reduced into it by the kernels that follow).  The entry
-// order inside a list depends on the LDS atomics' order; the gather's integer sums do not (above).  grid: B, block: 1024.
-constexpr int WFG_BUILD_MAX_HW = 14336;      // (HW + 1024) ints of LDS <= 60 KB
-__global__ void __launch_bounds__(1024) k_wfg_build(const float* __restrict__ flow, unsigned* __restrict__ header, int* __restrict__ off,
-                                                    int2* __restrict__ ent, int H, int W, int use_mask, int ac) {
-  extern __shared__ int wfg_sh[];
-  const int b = blockIdx.x, t = threadIdx.x, HW = H * W;
-  int* cnt = wfg_sh;
-  int* part = wfg_sh + HW;
-  if (b == 0 && t < SCATTER_HEADER_BYTES / 4) header[t] = 0u;
-  for (int i = t; i < HW; i += 1024) cnt[i] = 0;
-  __syncthreads();
-  const float* f = flow + static_cast<long>(b) * 2 * HW;
-  for (int p = t; p < HW; p += 1024) {
-    int q[4]; float w[4];
-    const int n = wfg_taps(f, p, H, W, use_mask, ac, q, w);
-    for (int k = 0; k < n; ++k) atomicAdd(cnt + q[k], 1);
-  }
-  __syncthreads();
-  const int per = (HW + 1023) / 1024, lo = min(t * per, HW), hi = min(lo + per, HW);
-  int s = 0;
-  for (int i = lo; i < hi; ++i) s += cnt[i];
-  part[t] = s;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {          // Hillis-Steele inclusive scan of the 1024 run sums
-    const int v = (t >= d) ? part[t - d] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  int run = part[t] - s;
-  int* o = off + static_cast<long>(b) * (HW + 1);
-  for (int i = lo; i < hi; ++i) { const int c = cnt[i]; o[i] = run; cnt[i] = run; run += c; }     // cnt becomes the list's cursor
-  if (t == 1023) o[HW] = part[1023];
-  __syncthreads();
-  int2* e = ent + static_cast<long>(b) * 4 * HW;
-  for (int p = t; p < HW; p += 1024) {
-    int q[4]; float w[4];
-    const int n = wfg_taps(f, p, H, W, use_mask, ac, q, w);
-    for (int k = 0; k < n; ++k) e[atomicAdd(cnt + q[k], 1)] = make_int2(p, __float_as_int(w[k]));
-  }
-}
-
 // grid: (ceil(HW / 64), ceil(C / 8), B); block: one wave, lane = target pixel
 __global__ void __launch_bounds__(64) k_wfg_gather(const float* __restrict__ gout, const int* __restrict__ off, const int2* __restrict__ ent,
                                                    const unsigned* __restrict__ header, float* __restrict__ gx, int C, int HW) {
@@ -716,40 +671,21 @@ static void launch_warp_flow_bwd(dim3 g, hipStream_t st, const float* x, const f
     k_warp_flow_bwd<4><<<g, 64 * 4, 0, st>>>(x, flow, gout, gflow, gx_ws, gflow_add, gfa_bs, C, H, W, use_mask, ac);
 }
 
-// gx of warp_flow by the gather path, in two halves around the kernels that max-reduce the contributions' bound into the header:
-// warp_gx_prepare clears the header and -- where a sample's counters fit in LDS -- builds the inverse map in ONE launch; otherwise it
-// only clears header + counters and warp_gx_gather builds the map (count, scan, fill) before it gathers.
-static bool wfg_one_launch(long HW) {
-  static const bool on = [] { const char* e = getenv("DFE_WFG_BUILD"); return !e || atoi(e) != 0; }();
-  return on && HW <= WFG_BUILD_MAX_HW;
-}
-
-static int warp_gx_prepare(const float* flow, void* ws, int B, int H, int W, int use_mask, int ac, hipStream_t st) {
-  const long HW = static_cast<long>(H) * W;
-  if (reinterpret_cast<uintptr_t>(ws) & 15) return DFE_ERR_DIMS;
-  if (wfg_one_launch(HW)) {
-    const WfgWs w = wfg_layout(ws, B, HW);
-    k_wfg_build<<<B, 1024, sizeof(int) * (HW + 1024), st>>>(flow, w.header, w.off, w.ent, H, W, use_mask, ac);
-    DFE_LAUNCH_CHECK();
-    return DFE_OK;
-  }
-  if (hipMemsetAsync(ws, 0, wfg_head_bytes(B, HW), st) != hipSuccess) return DFE_ERR_LAUNCH;
-  return DFE_OK;
-}
-
+// gx of warp_flow by the gather path: the workspace's header holds the bound and its counters are zero (wfg_head_bytes).
+// (Round 5 measured the map built by ONE launch -- a block per sample, counters and cursors in LDS, in-block scan -- against these
+// three: 143.6 / 81.3 / 50.0 us for the level backward at 64x208 / 32x104 / 16x52, B = 8, against 133.2 / 82.1 / 54.2: eight blocks
+// cannot walk 13 312 pixels three times as fast as 416 can; removed.)
 static int warp_gx_gather(const float* flow, const float* gout, float* gx, void* ws, int B, int C, int H, int W, int use_mask, int ac,
                           hipStream_t st) {
   const long HW = static_cast<long>(H) * W;
   const WfgWs w = wfg_layout(ws, B, HW);
-  if (!wfg_one_launch(HW)) {
-    const dim3 gp(static_cast<unsigned>((HW + 255) / 256), B);
-    k_wfg_count<<<gp, 256, 0, st>>>(flow, w.cnt, H, W, use_mask, ac);
-    DFE_LAUNCH_CHECK();
-    k_wfg_scan<<<B, 1024, 0, st>>>(w.cnt, w.off, static_cast<int>(HW));
-    DFE_LAUNCH_CHECK();
-    k_wfg_fill<<<gp, 256, 0, st>>>(flow, w.cnt, w.off, w.ent, H, W, use_mask, ac);
-    DFE_LAUNCH_CHECK();
-  }
+  const dim3 gp(static_cast<unsigned>((HW + 255) / 256), B);
+  k_wfg_count<<<gp, 256, 0, st>>>(flow, w.cnt, H, W, use_mask, ac);
+  DFE_LAUNCH_CHECK();
+  k_wfg_scan<<<B, 1024, 0, st>>>(w.cnt, w.off, static_cast<int>(HW));
+  DFE_LAUNCH_CHECK();
+  k_wfg_fill<<<gp, 256, 0, st>>>(flow, w.cnt, w.off, w.ent, H, W, use_mask, ac);
+  DFE_LAUNCH_CHECK();
   k_wfg_gather<<<dim3(static_cast<unsigned>((HW + 63) / 64), (C + WF_CK - 1) / WF_CK, B), 64, 0, st>>>(gout, w.off, w.ent, w.header, gx, C, static_cast<int>(HW));
   DFE_LAUNCH_CHECK();
   return DFE_OK;
@@ -809,7 +745,8 @@ int dfe_warp_flow_bwd(const float* x, const float* flow, const float* gout, floa
   const long HW = static_cast<long>(H) * W, n = static_cast<long>(B) * C * HW;
   if (gx && wfg_eligible(C, HW) && getenv("DFE_WARP_SCATTER") == nullptr) {
     // large planes: gx as a gather over the inverse map of the flow (above); the bound of the contributions first
-    { const int rc = warp_gx_prepare(flow, gx_ws, B, H, W, use_mask, align_corners, st); if (rc != DFE_OK) return rc; }
+    if (reinterpret_cast<uintptr_t>(gx_ws) & 15) return DFE_ERR_DIMS;
+    if (hipMemsetAsync(gx_ws, 0, wfg_head_bytes(B, HW), st) != hipSuccess) return DFE_ERR_LAUNCH;
     { const int rc = scatter_amax_into(static_cast<unsigned*>(gx_ws), gout, n, st); if (rc != DFE_OK) return rc; }
     if (gflow) {
       launch_warp_flow_bwd(g, st, x, flow, gout, gflow, nullptr, nullptr, 0, C, H, W, use_mask, align_corners);
@@ -964,8 +901,8 @@ int dfe_pwc_level_bwd(const float* c1, const float* c2, const float* flow, const
   const long n = static_cast<long>(B) * C * HW;
   const bool gather = g_c2 && wfg_eligible(C, HW) && getenv("DFE_WARP_SCATTER") == nullptr;
   if (gather) {
-    const int rc = warp_gx_prepare(flow, g_c2_ws, B, H, W, 0, align_corners, st);
-    if (rc != DFE_OK) return rc;
+    if (reinterpret_cast<uintptr_t>(g_c2_ws) & 15) return DFE_ERR_DIMS;
+    if (hipMemsetAsync(g_c2_ws, 0, wfg_head_bytes(B, HW), st) != hipSuccess) return DFE_ERR_LAUNCH;
   } else if (g_c2) { const int rc = scatter_begin_bound(g_c2_ws, n, st); if (rc != DFE_OK) return rc; }
   // dL/dc1 = correlation gradient + the concatenated copy's slice; dL/dwarped
   { const int rc = launch_corr_bwd(c1, warped, gx, xbs, gx_c1, xbs, g_c1, g_warped, g_c2 ? static_cast<unsigned*>(g_c2_ws) : nullptr, B, C, H, W, st); if (rc != DFE_OK) return rc; }
