@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--miopen-benchmark", type=int, default=0, help="torch.backends.cudnn.benchmark (MIOpen exhaustive find)")
+    ap.add_argument("--graph", action="store_true", help="opt-in, never the default line: the training step captured in a hipGraph and replayed "
+                    "(train_step.GraphedTrainStep; single process).  The roofline kernel is then timed in eager steps AFTER the timed region")
     ap.add_argument("--net-streams", type=int, default=None, help="1 = the three networks one after the other on one stream; 3 = flow / pose "
                     "nets on side streams (default: the package default)")
     return ap.parse_args()
@@ -217,7 +219,9 @@ class TrainStepWorkload:
         if world > 1:
             self.find_warmup(world)
         self.model = ddp.wrap(self.model, dev, force=bool(getattr(args, "force_ddp", False)))
-        self.opt = make_optimizer(self.model, self.cfg.lr)
+        self.use_graph = bool(getattr(args, "graph", False)) and world == 1 and not getattr(args, "force_ddp", False)
+        self.opt = make_optimizer(self.model, self.cfg.lr, capturable=self.use_graph)
+        self.graphed = None
 
     def find_warmup(self, world):
         """N ranks of one node share one MIOpen user find-db.  Rank 0 runs one forward + backward of the bare model
@@ -236,8 +240,12 @@ class TrainStepWorkload:
                 torch.cuda.synchronize()
             dist.barrier()
 
-    def step(self):
-        from unsupervised_depth_opticalflow_egomotion_amd.train_step import train_step
+    def step(self, eager=False):
+        from unsupervised_depth_opticalflow_egomotion_amd.train_step import GraphedTrainStep, train_step
+        if self.use_graph and not eager:
+            if self.graphed is None:
+                self.graphed = GraphedTrainStep(self.model, self.opt, self.inputs, self.cfg)
+            return self.graphed()[0]
         return train_step(self.model, self.opt, self.inputs, self.cfg)[0]
 
     def cpu_step_fn(self, threads):
@@ -461,6 +469,13 @@ def main():
     barrier(world)
     dt_local = time.perf_counter() - t0
     dt = max_over_ranks(dt_local, world, dev)
+    graph_mode = bool(getattr(wl, "use_graph", False))
+    if graph_mode:      # events recorded inside a captured graph cannot be read back: time the roofline kernel in eager steps, after the region
+        LS.timing_collect()
+        LS.timing_begin()
+        for _ in range(5):
+            wl.step(eager=True)
+        torch.cuda.synchronize()
     fwd_ms, bwd_ms = LS.timing_collect()
     evidence = multi_gpu_evidence(wl, world, rank, dev, dt_local, args) if (world > 1 or args.force_ddp) else None
     pairs_per_step = 2 * args.batch * world
@@ -476,7 +491,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl.name + ": mode=%s, %dx%d, batch=%d/GPU, num_scales=%d, fwd+bwd%s" % (
             args.mode if wl.name == "train_step" else "geom", args.width, args.height, args.batch, args.scales,
-            "+Adam" if wl.name == "train_step" else ""),
+            "+Adam" if wl.name == "train_step" else "") + (" [OPT-IN: the step replayed from a hipGraph; roofline kernel timed in eager steps after the region]" if getattr(wl, "use_graph", False) else ""),
             "global_batch": args.batch * world, "parallelism": "dp%d" % world,
             "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE"), "miopen_user_db": miopen_db_status()},
     }

@@ -57,6 +57,11 @@ int dfe_pose_vec2mat_bwd(const float* vec, const float* gT34, const float* gE, f
 int dfe_adam_chunk(void);
 int dfe_adam_step(const void* table, const int* blockmap, int nblocks, double lr, double beta1, double beta2, double eps,
                   double bias_correction1, double bias_correction2, void* stream);
+/* the same update with the step count on the device (a step replayed from a hipGraph: train.py --graph): one extra one-thread
+ * launch increments *step_count (a device double) and forms the two bias-correction coefficients in coef (two device floats),
+ * which the update kernel reads. */
+int dfe_adam_step_dev(const void* table, const int* blockmap, int nblocks, double lr, double beta1, double beta2, double eps,
+                      double* step_count, float* coef, void* stream);
 
 /* ---- order-independent scatter-add workspace (csrc/dfe_scatter.h) -----------------------------
  * Adjoint of a bilinear gather with respect to the sampled tensor: contributions are scaled by a power of two, rounded

@@ -521,6 +521,41 @@ def test_network_streams_stress_many_forward_backward_passes_with_a_churning_all
     assert worst <= max(4.0 * noise, 1e-3 * scale), (worst, noise, scale)
 
 
+def test_graphed_train_step_matches_the_eager_step():
+    """train_step.GraphedTrainStep (train.py --graph): the step captured in a hipGraph with optim.FusedAdam(capturable=True).
+    From equal seeds, 3 warm-up steps + 3 replays give the same losses as 6 eager steps to the step's run-to-run noise
+    (MIOpen's split-K atomics; the bias corrections come from the device-side step count: frozen ones would show by step 5),
+    the state_dict carries the device's step count, and new inputs reach the graph through the static tensors."""
+    from unsupervised_depth_opticalflow_egomotion_amd.train_step import GraphedTrainStep, make_cfg, make_optimizer, train_step
+    from unsupervised_depth_opticalflow_egomotion_amd.models import get_model
+    cfg = make_cfg()
+    batches = [[torch.from_numpy(a).to(dev()) for a in synthetic.make_triplet_batch(1, 256, 832, 3, seed=s)] for s in (1, 2)]
+
+    def run(graph):
+        torch.manual_seed(0)
+        model = get_model("geom")(cfg).to(dev()).train()
+        opt = make_optimizer(model, 1e-3, capturable=graph)
+        losses = []
+        order = [batches[1], batches[0], batches[1]]
+        if graph:
+            g = GraphedTrainStep(model, opt, batches[0], cfg, warmup=3)          # 3 eager steps, then the capture (which runs nothing)
+            for inp in order:
+                losses.append(float(g(inp)[0].detach()))
+        else:
+            for inp in [batches[0]] * 3 + order:
+                losses.append(float(train_step(model, opt, inp, cfg)[0].detach()))
+            losses = losses[3:]
+        torch.cuda.synchronize()
+        step = opt.state_dict()["state"][0]["step"]
+        return losses, float(step)
+    le, se = run(False)
+    lg, sg = run(True)
+    assert se == 6.0 and sg == 6.0, (se, sg)
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 2e-3 * abs(a), (le, lg)
+    assert abs(le[0] - le[1]) > 1e-4 * abs(le[0])          # the two batches differ: the graph really saw new inputs
+
+
 def test_train_cli_smoke(tmp_path):
     """train.py with the reference's flags: 2 iterations, checkpoint written in the reference's format, resume."""
     import subprocess, sys

@@ -21,7 +21,7 @@ import yaml
 
 from unsupervised_depth_opticalflow_egomotion_amd import ddp, ops, synthetic
 from unsupervised_depth_opticalflow_egomotion_amd.models import get_model
-from unsupervised_depth_opticalflow_egomotion_amd.train_step import train_step, make_optimizer, LOSS_WEIGHT_ATTR
+from unsupervised_depth_opticalflow_egomotion_amd.train_step import train_step, make_optimizer, GraphedTrainStep, LOSS_WEIGHT_ATTR
 
 
 class pObject(object):
@@ -70,7 +70,8 @@ def train(cfg):
                     p.requires_grad = False
     model.train()
     model = ddp.wrap(model, dev)
-    optimizer = make_optimizer(model, cfg.lr)
+    use_graph = bool(getattr(cfg, "graph", False)) and world == 1
+    optimizer = make_optimizer(model, cfg.lr, capturable=use_graph)
     start = 0
     if cfg.resume:
         fn = "iter_{}.pth".format(cfg.iter_start) if cfg.iter_start > 0 else "last.pth"
@@ -83,7 +84,7 @@ def train(cfg):
         dataset = synthetic.SyntheticRawTriplets(n_iter * cfg.batch_size * world, (375, 1242), (h, w), cfg.num_scales, seed=1234)
     else:
         dataset = synthetic.SyntheticTriplets(n_iter * cfg.batch_size * world, (h, w), cfg.num_scales, seed=1234)
-    prof = None
+    prof, graphed = None, None
     if getattr(cfg, "profile", False):       # the reference's Profiler marks (core/visualize/profiler.py) + roctx ranges per HIP launcher
         from unsupervised_depth_opticalflow_egomotion_amd import profiling
         profiling.enable()
@@ -101,7 +102,12 @@ def train(cfg):
             inputs = [torch.stack([s[i] for s in samples]).to(dev, non_blocking=True) for i in range(3)]
         if prof is not None:
             prof.reset()
-        loss, loss_pack, mask_pack = train_step(model, optimizer, inputs, cfg, prof if (prof is not None and it % cfg.log_interval == 0) else None)
+        if use_graph:      # one hipGraph launch per iteration (train_step.GraphedTrainStep): captured on the first batch
+            if graphed is None:
+                graphed = GraphedTrainStep(model, optimizer, inputs, cfg)
+            loss, loss_pack, mask_pack = graphed(inputs)
+        else:
+            loss, loss_pack, mask_pack = train_step(model, optimizer, inputs, cfg, prof if (prof is not None and it % cfg.log_interval == 0) else None)
         if rank == 0 and it % cfg.log_interval == 0:
             print_loss(it, loss_pack, weights, loss)
         if rank == 0 and (it + 1) % cfg.save_interval == 0:
@@ -137,6 +143,10 @@ if __name__ == "__main__":
     ap.add_argument("--fix_pose", action="store_true")
     ap.add_argument("--fix_flow", action="store_true")
     ap.add_argument("--num_iterations", type=int, default=None)
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole training step (three network streams, loss stack, backward, Adam) in a hipGraph after three "
+                         "eager steps and replay it: one launch per iteration (single process, static shapes; pays when the host is the "
+                         "bound, e.g. small batches)")
     ap.add_argument("--profile", action="store_true",
                     help="roctx ranges around every HIP launcher (rocprofv3 --marker-trace) and the reference Profiler's forward / backward / "
                          "optimizer wall times at every log interval (synchronises the device at each mark)")

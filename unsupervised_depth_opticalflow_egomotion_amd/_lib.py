@@ -36,6 +36,7 @@ _SIGNATURES = {
     "dfe_scatter_ws_bytes": [ctypes.c_long],
     "dfe_adam_chunk": [],
     "dfe_adam_step": [_P, _P, _I, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _P],
+    "dfe_adam_step_dev": [_P, _P, _I, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _P, _P, _P],
     "dfe_warp_flow_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dfe_pose_partials_floats": [_I, _I, _I],
     "dfe_inverse_warp2_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -25,9 +25,21 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
   p = p - step_size * m / denom;
 }
 
-// grid: x = block of the block map; blockmap[2k] = tensor, blockmap[2k+1] = chunk
+// The step count on the DEVICE (a training step replayed from a hipGraph cannot take its bias corrections as kernel arguments:
+// they would stay those of the captured step).  One thread: t = ++count; coef = {lr / (1 - b1^t), sqrt(1 - b2^t)}, formed in double.
+__global__ void k_adam_tick(double* __restrict__ count, float* __restrict__ coef, double lr, double b1, double b2) {
+  const double t = count[0] + 1.0;
+  count[0] = t;
+  coef[0] = static_cast<float>(lr / (1.0 - pow(b1, t)));
+  coef[1] = static_cast<float>(sqrt(1.0 - pow(b2, t)));
+}
+
+// grid: x = block of the block map; blockmap[2k] = tensor, blockmap[2k+1] = chunk.  coef != nullptr: step_size and c2s come from
+// device memory (k_adam_tick), the arguments of those names are ignored.
 __global__ void __launch_bounds__(256) k_adam_step(const AdamRec* __restrict__ table, const int* __restrict__ blockmap,
-                                                   float b1c, float b2, float b2c, float step_size, float c2s, float eps) {
+                                                   float b1c, float b2, float b2c, float step_size, float c2s, float eps,
+                                                   const float* __restrict__ coef) {
+  if (coef) { step_size = coef[0]; c2s = coef[1]; }
   const int t = blockmap[2 * blockIdx.x], c = blockmap[2 * blockIdx.x + 1];
   const AdamRec r = table[t];
   const long long base = static_cast<long long>(c) * ADAM_CHUNK;
@@ -70,6 +82,18 @@ extern "C" int dfe_adam_step(const void* table, const int* blockmap, int nblocks
   const float c2s = static_cast<float>(sqrt(bias_correction2));
   dfe::k_adam_step<<<nblocks, 256, 0, static_cast<hipStream_t>(stream)>>>(static_cast<const dfe::AdamRec*>(table), blockmap,
                                                                         static_cast<float>(1.0 - beta1), static_cast<float>(beta2),
-                                                                        static_cast<float>(1.0 - beta2), step_size, c2s, static_cast<float>(eps));
+                                                                        static_cast<float>(1.0 - beta2), step_size, c2s, static_cast<float>(eps), nullptr);
+  return hipGetLastError() == hipSuccess ? DFE_OK : DFE_ERR_LAUNCH;
+}
+
+extern "C" int dfe_adam_step_dev(const void* table, const int* blockmap, int nblocks, double lr, double beta1, double beta2, double eps,
+                                 double* step_count, float* coef, void* stream) {
+  if (!table || !blockmap || !step_count || !coef) return DFE_ERR_NULL;
+  if (nblocks <= 0) return DFE_ERR_DIMS;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  dfe::k_adam_tick<<<1, 1, 0, st>>>(step_count, coef, lr, beta1, beta2);
+  if (hipGetLastError() != hipSuccess) return DFE_ERR_LAUNCH;
+  dfe::k_adam_step<<<nblocks, 256, 0, st>>>(static_cast<const dfe::AdamRec*>(table), blockmap, static_cast<float>(1.0 - beta1),
+                                            static_cast<float>(beta2), static_cast<float>(1.0 - beta2), 0.0f, 1.0f, static_cast<float>(eps), coef);
   return hipGetLastError() == hipSuccess ? DFE_OK : DFE_ERR_LAUNCH;
 }

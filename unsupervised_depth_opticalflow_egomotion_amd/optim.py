@@ -18,13 +18,17 @@ from ._lib import check, get_lib, stream_ptr
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
+        """``capturable``: the step count lives on the device (dfe_adam_step_dev), so that a whole training step -- this
+        ``step()`` included -- can be captured in a hipGraph and replayed (train_step.GraphedTrainStep, train.py --graph);
+        ``state_dict()`` reads the count back.  All parameters of a group must then step together."""
         if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
             raise ValueError("invalid Adam hyper-parameters")
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
-                        capturable=False, differentiable=False, fused=None)
+                        capturable=bool(capturable), differentiable=False, fused=None)
         super().__init__(params, defaults)
         self._plans = {}
+        self._dev_count = {}          # capturable groups: group index -> (step count [1] float64, coefficients [2] float32) on the device
 
     MAX_PLANS = 8
 
@@ -32,6 +36,12 @@ class FusedAdam(torch.optim.Optimizer):
         """As torch.optim.Adam's.  Inside this optimiser the parameters of a group share ONE step-count tensor (one
         increment per step instead of ~250); a checkpoint must not carry that sharing -- torch.optim.Adam increments
         every parameter's count, i.e. a shared one once per parameter -- so every entry gets its own copy here."""
+        for gi, (count, _) in self._dev_count.items():      # capturable: the count advanced on the device (graph replays)
+            t = float(count.cpu()[0])
+            for p in self.param_groups[gi]["params"]:
+                st = self.state.get(p)
+                if st and "step" in st:
+                    st["step"] = torch.tensor(t, dtype=torch.float32)
         sd = super().state_dict()
         sd["state"] = {k: ({**v, "step": v["step"].clone()} if "step" in v else v) for k, v in sd["state"].items()}
         return sd
@@ -39,6 +49,7 @@ class FusedAdam(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._plans = {}                       # the moment tensors were replaced
+        self._dev_count = {}                   # re-seeded from the loaded counts at the next step
 
     def _fingerprint(self, params):
         """Cheap check that the cached parameter / moment pointers are still the live ones."""
@@ -112,20 +123,36 @@ class FusedAdam(torch.optim.Optimizer):
                 plan = self._plan(gi, ps)
                 host = plan["host"]
                 host[:, 1] = torch.tensor([g.data_ptr() for _, g in pg], dtype=torch.int64)
+                capturing = torch.cuda.is_current_stream_capturing()
                 k = plan["turn"]
                 plan["turn"] = (k + 1) % len(plan["pinned"])
-                if plan["events"][k] is not None:
+                if plan["events"][k] is not None and not capturing:
                     plan["events"][k].synchronize()
                 plan["pinned"][k].copy_(host)
-                plan["table"].copy_(plan["pinned"][k], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
-                plan["events"][k] = ev
+                plan["table"].copy_(plan["pinned"][k], non_blocking=True)     # (captured: a copy node that re-reads this pinned buffer)
+                if capturing:
+                    plan["events"][k] = None
+                else:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    plan["events"][k] = ev
                 t = t0 + 1.0
                 b1, b2 = group["betas"]
-                check(lib.dfe_adam_step(ctypes.c_void_p(plan["table"].data_ptr()), ctypes.c_void_p(plan["blockmap"].data_ptr()),
-                                        plan["nblocks"], float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                        1.0 - b1 ** t, 1.0 - b2 ** t, stream_ptr()), "dfe_adam_step")
+                if group.get("capturable"):
+                    if len(by_step) != 1:
+                        raise NotImplementedError("FusedAdam(capturable=True): all parameters of a group must step together")
+                    dc = self._dev_count.get(gi)
+                    if dc is None:      # seeded from the host count once; from then on the device count is the truth
+                        dc = self._dev_count[gi] = (torch.full((1,), t0, dtype=torch.float64, device=dev),
+                                                    torch.zeros(2, dtype=torch.float32, device=dev))
+                    check(lib.dfe_adam_step_dev(ctypes.c_void_p(plan["table"].data_ptr()), ctypes.c_void_p(plan["blockmap"].data_ptr()),
+                                                plan["nblocks"], float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                ctypes.c_void_p(dc[0].data_ptr()), ctypes.c_void_p(dc[1].data_ptr()), stream_ptr()),
+                          "dfe_adam_step_dev")
+                else:
+                    check(lib.dfe_adam_step(ctypes.c_void_p(plan["table"].data_ptr()), ctypes.c_void_p(plan["blockmap"].data_ptr()),
+                                            plan["nblocks"], float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                            1.0 - b1 ** t, 1.0 - b2 ** t, stream_ptr()), "dfe_adam_step")
                 first = self.state[ps[0]]["step"]
                 shared = all(self.state[p]["step"] is first for p in ps)
                 if shared:
