@@ -66,7 +66,7 @@ def _wino_eligible(x, w_shape, cin, stride, padding, dilation, groups=1):
 # Weight gradient in the Winograd domain (dfe_wino_wgrad3x3, csrc/ops_wino_wgrad.hip; round 5): raw NCHW rows staged in LDS, every
 # wave transforms the tiles of its (channel, tile) lanes in registers and feeds the fp32 matrix cores -- no layout transposes, no
 # zero fill, no atomics (MIOpen: NHWC implicit GEMM + three batched transposes + a fill per call, split-K float atomics).
-# 1.2-2.9x MIOpen on every 3x3 stride-1 layer of the step with >= 32 channels on both sides (tools/wgrad_bench.py,
+# 1.2-3.0x MIOpen on every 3x3 stride-1 layer of the step with >= 16 channels on both sides (tools/wgrad_bench.py,
 # profiles/r05_wgrad_bench.md).  DFE_WINO_WGRAD=0: MIOpen's weight gradients everywhere.
 WINO_WGRAD = os.environ.get("DFE_WINO_WGRAD", "1") != "0"
 WINO_WGRAD_MIN_MACS = float(os.environ.get("DFE_WINO_WGRAD_MIN_GMAC", "0.8")) * 1e9      # direct multiply-adds of the layer
@@ -85,7 +85,7 @@ def _wino_wgrad_eligible(x, gy_shape, w_shape, padding, d):
     if d == 1 and padding not in ((0, 0), (1, 1)):
         return False
     Co, Ci = int(w_shape[0]), int(w_shape[1])
-    if tuple(w_shape[2:]) != (3, 3) or Ci != x.shape[1] or min(Co, Ci) < 32:
+    if tuple(w_shape[2:]) != (3, 3) or Ci != x.shape[1] or min(Co, Ci) < 16:      # (16 -> 16 at 128x416 x 12: 83 against MIOpen's 129 us)
         return False
     n_out = gy_shape[0] * Co * gy_shape[2] * gy_shape[3]
     return float(n_out) * Ci * 9 >= WINO_WGRAD_MIN_MACS and x.numel() < (1 << 30) and n_out < (1 << 30)
