@@ -523,37 +523,51 @@ def test_network_streams_stress_many_forward_backward_passes_with_a_churning_all
 
 def test_graphed_train_step_matches_the_eager_step():
     """train_step.GraphedTrainStep (train.py --graph): the step captured in a hipGraph with optim.FusedAdam(capturable=True).
-    From equal seeds, 3 warm-up steps + 3 replays give the same losses as 6 eager steps to the step's run-to-run noise
-    (MIOpen's split-K atomics; the bias corrections come from the device-side step count: frozen ones would show by step 5),
-    the state_dict carries the device's step count, and new inputs reach the graph through the static tensors."""
+    Compared STEP BY STEP from one state, not trajectory against trajectory: with Adam at lr 1e-3 the first updates are
+    lr * sign(g), so the float atomics in MIOpen's weight gradients flip the elements whose gradient is near zero and two EAGER
+    runs of six steps already differ by 0.7 % in the loss (measured: 3.5215 / 3.5458).  So: 3 warm-up steps + the capture, the
+    model and optimiser state are copied into an eager twin (capturable=False), and then replays and eager steps run side by
+    side on the same two batches.  The forward pass has no atomics: the first loss agrees to 1e-5; the second (one noisy update
+    later) to 5e-4.  The parameter updates of the confidently updated elements (|delta| > lr / 2) agree to 2 % of lr on 99.9 % of
+    them at both steps -- a step count frozen at capture time would be off by 6.5 % in the bias-correction factor at step 5 --
+    the state_dict carries the device's step count, and the new inputs reach the graph through the static tensors."""
+    import copy
     from unsupervised_depth_opticalflow_egomotion_amd.train_step import GraphedTrainStep, make_cfg, make_optimizer, train_step
     from unsupervised_depth_opticalflow_egomotion_amd.models import get_model
-    cfg = make_cfg()
+    cfg, lr = make_cfg(), 1e-3
     batches = [[torch.from_numpy(a).to(dev()) for a in synthetic.make_triplet_batch(1, 256, 832, 3, seed=s)] for s in (1, 2)]
-
-    def run(graph):
-        torch.manual_seed(0)
-        model = get_model("geom")(cfg).to(dev()).train()
-        opt = make_optimizer(model, 1e-3, capturable=graph)
-        losses = []
-        order = [batches[1], batches[0], batches[1]]
-        if graph:
-            g = GraphedTrainStep(model, opt, batches[0], cfg, warmup=3)          # 3 eager steps, then the capture (which runs nothing)
-            for inp in order:
-                losses.append(float(g(inp)[0].detach()))
-        else:
-            for inp in [batches[0]] * 3 + order:
-                losses.append(float(train_step(model, opt, inp, cfg)[0].detach()))
-            losses = losses[3:]
+    flat = lambda m: torch.cat([p.detach().flatten() for p in m.parameters()]).clone()
+    torch.manual_seed(0)
+    model = get_model("geom")(cfg).to(dev()).train()
+    opt = make_optimizer(model, lr, capturable=True)
+    g = GraphedTrainStep(model, opt, batches[0], cfg, warmup=3)          # 3 eager steps, then the capture (which runs nothing)
+    torch.cuda.synchronize()
+    snap_m, snap_o = copy.deepcopy(model.state_dict()), copy.deepcopy(opt.state_dict())
+    assert float(snap_o["state"][0]["step"]) == 3.0
+    twin = get_model("geom")(cfg).to(dev()).train()
+    twin.load_state_dict(snap_m)
+    opt_t = make_optimizer(twin, lr)
+    opt_t.load_state_dict(snap_o)
+    p_g, p_e = [flat(model)], [flat(twin)]
+    assert torch.equal(p_g[0], p_e[0])
+    l_g, l_e = [], []
+    for inp in (batches[1], batches[0]):
+        l_g.append(float(g(inp)[0].detach()))
+        l_e.append(float(train_step(twin, opt_t, inp, cfg)[0].detach()))
         torch.cuda.synchronize()
-        step = opt.state_dict()["state"][0]["step"]
-        return losses, float(step)
-    le, se = run(False)
-    lg, sg = run(True)
-    assert se == 6.0 and sg == 6.0, (se, sg)
-    for a, b in zip(le, lg):
-        assert abs(a - b) <= 2e-3 * abs(a), (le, lg)
-    assert abs(le[0] - le[1]) > 1e-4 * abs(le[0])          # the two batches differ: the graph really saw new inputs
+        p_g.append(flat(model)); p_e.append(flat(twin))
+    assert float(opt.state_dict()["state"][0]["step"]) == 5.0 and float(opt_t.state_dict()["state"][0]["step"]) == 5.0
+    assert abs(l_g[0] - l_e[0]) <= 1e-5 * abs(l_e[0]), (l_g, l_e)
+    assert abs(l_g[1] - l_e[1]) <= 5e-4 * abs(l_e[1]), (l_g, l_e)
+    assert abs(l_g[0] - l_g[1]) > 1e-2 * abs(l_g[0])                     # the second batch is a different one: the inputs arrive
+    fracs = []
+    for k in (1, 2):
+        d_g, d_e = p_g[k] - p_g[k - 1], p_e[k] - p_e[k - 1]
+        sure = d_e.abs() > 0.5 * lr
+        assert int(sure.sum()) > 0.2 * d_e.numel()                       # about half of the elements at these steps
+        fracs.append(float(((d_g - d_e).abs()[sure] <= 0.02 * lr).float().mean()))
+    print("\ngraph test: losses replayed %s eager %s; updates agreeing to 2%% of lr: %s" % (l_g, l_e, fracs))
+    assert min(fracs) >= 0.999, fracs                                     # measured 0.99998 .. 1.0
 
 
 def test_train_cli_smoke(tmp_path):
