@@ -905,6 +905,62 @@ def wino_wgrad3x3(x, gy, padding=1, dilation=1):
     return gw
 
 
+def _dense_chw(t):
+    return t.dtype == torch.float32 and t.stride(3) == 1 and t.stride(2) == t.shape[3] and t.stride(1) == t.shape[2] * t.shape[3]
+
+
+def sconv_wgrad_supported(x_shape, co, k, stride, padding):
+    """Whether dfe_sconv_wgrad takes the layer (csrc/ops_sconv.hip: 3x3 with Ci >= 16, the 3- / 9-channel stems, 5x5 x 16)."""
+    B, Ci, H, W = (int(v) for v in x_shape)
+    return get_lib().dfe_sconv_wgrad_floats(B, Ci, int(co), H, W, int(k), int(stride), int(padding)) > 0
+
+
+def sconv_wgrad(x, gy, k, stride, padding):
+    """Weight gradient [Co,Ci,k,k] of a strided k x k convolution of x [B,Ci,H,W] for the output gradient gy [B,Co,Ho,Wo], on
+    dfe_sconv_wgrad (fp32 MFMA straight from NCHW; depth_model.py:60-95, feature_pyramid.py:7-36, pose_cnn.py:14-36).  x and gy may
+    be batch-strided views."""
+    x = x if _dense_chw(x) else f32c(x)
+    gy = gy if _dense_chw(gy) else f32c(gy)
+    B, Ci, H, W = x.shape
+    Co, k, s, P = int(gy.shape[1]), int(k), int(stride), int(padding)
+    if tuple(gy.shape[2:]) != ((H + 2 * P - k) // s + 1, (W + 2 * P - k) // s + 1) or gy.shape[0] != B:
+        raise _lib.DfeError("sconv_wgrad: gy %s does not belong to x %s with k %d stride %d padding %d" % (tuple(gy.shape), tuple(x.shape), k, s, P))
+    lib = get_lib()
+    n = lib.dfe_sconv_wgrad_floats(B, Ci, Co, H, W, k, s, P)
+    if n <= 0:
+        raise _lib.DfeError("dfe_sconv_wgrad: unsupported layer %s -> %d, k %d stride %d padding %d" % (tuple(x.shape), Co, k, s, P))
+    gw = torch.empty(Co, Ci, k, k, device=x.device, dtype=torch.float32)
+    ws = torch.empty(n, device=x.device, dtype=torch.float32)
+    check(lib.dfe_sconv_wgrad(ptr(x, strided=True), x.stride(0), ptr(gy, strided=True), gy.stride(0), ptr(gw), ptr(ws), B, Ci, Co, H, W, k, s, P,
+                              stream_ptr()), "dfe_sconv_wgrad")
+    return gw
+
+
+def sconv_fwd_supported(x_shape, co, k):
+    B, Ci, H, W = (int(v) for v in x_shape)
+    return get_lib().dfe_sconv_fwd_floats(B, Ci, int(co), H, W, int(k)) > 0
+
+
+def sconv_fwd(x, w, bias=None, slope=1.0, out=None):
+    """act(conv2d(x, w, stride 2, padding k // 2) + bias) for k in {3, 5, 7} on dfe_sconv_fwd (fp32 MFMA straight from NCHW;
+    depth_model.py:60-95, feature_pyramid.py:7-36, pose_cnn.py:14-36).  slope: 1 none, 0 ReLU, 0.1 LeakyReLU."""
+    x = x if _dense_chw(x) else f32c(x)
+    w = f32c(w)
+    B, Ci, H, W = x.shape
+    Co, k = int(w.shape[0]), int(w.shape[2])
+    lib = get_lib()
+    n = lib.dfe_sconv_fwd_floats(B, Ci, Co, H, W, k)
+    if n <= 0 or w.shape[1] != Ci or w.shape[3] != k:
+        raise _lib.DfeError("dfe_sconv_fwd: unsupported layer %s * %s" % (tuple(x.shape), tuple(w.shape)))
+    P = k // 2
+    Ho, Wo = (H + 2 * P - k) // 2 + 1, (W + 2 * P - k) // 2 + 1
+    y = out if out is not None else torch.empty(B, Co, Ho, Wo, device=x.device, dtype=torch.float32)
+    ws = torch.empty(n, device=x.device, dtype=torch.float32)
+    check(lib.dfe_sconv_fwd(ptr(x, strided=True), x.stride(0), ptr(w), None if bias is None else ptr(f32c(bias)), float(slope), ptr(y, strided=True),
+                            y.stride(0), ptr(ws), B, Ci, Co, H, W, k, stream_ptr()), "dfe_sconv_fwd")
+    return y
+
+
 class PlaneConvActFn(torch.autograd.Function):
     """act(conv3x3(x, w, pad 1) + bias) on a small plane as one operator (PoseCNN's refinement convolutions,
     pose_cnn.py:43-46, 66-69: Conv2d(12, 12, 3, 1, 1) + ReLU on 2x7 planes): dfe_planeconv_fwd with the epilogue inside;
