@@ -300,6 +300,11 @@ int dfe_sconv_wgrad(const float* x, long x_batch_stride, const float* gy, long g
 long dfe_sconv_fwd_floats(int B, int Ci, int Co, int H, int W, int K);
 int dfe_sconv_fwd(const float* x, long x_batch_stride, const float* weight, const float* bias, float slope, float* y,
                   long y_batch_stride, float* ws, int B, int Ci, int Co, int H, int W, int K, void* stream);
+/* dfe_sconv_dgrad: gx [B,Ci,H,W] = the data gradient of the same convolution (K in {1, 3, 5}, stride 2, padding K / 2) for gy
+ * [B,Co,Ho,Wo]; every element of gx is written.  ws as dfe_sconv_fwd's, dfe_sconv_dgrad_floats(...) floats. */
+long dfe_sconv_dgrad_floats(int B, int Ci, int Co, int H, int W, int K);
+int dfe_sconv_dgrad(const float* gy, long gy_batch_stride, const float* weight, float* gx, long gx_batch_stride, float* ws, int B,
+                    int Ci, int Co, int H, int W, int K, void* stream);
 /* the same for a DILATED 3x3 convolution with padding = dilation (pwc_tf.py:31-36 context network: dilation 2, 4, 8, 16): the
  * Winograd tiles live on the dilation x dilation phase images; H and W must be multiples of the dilation.  y has x's size. */
 int dfe_wino_conv3x3_dilated(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, int B, int Ci, int Co,

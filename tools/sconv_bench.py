@@ -11,15 +11,17 @@ from unsupervised_depth_opticalflow_egomotion_amd import ops          # noqa: E4
 from unsupervised_depth_opticalflow_egomotion_amd._lib import get_lib  # noqa: E402
 
 # (B, Ci, Co, H, W, K, stride, P): the step's strided layers (12 frames through DepthNet / FeaturePyramid, 4 triplets through PoseCNN)
+ONE_BY_ONE = [(12, 64, 128, 64, 208, 1, 2, 0), (12, 128, 256, 32, 104, 1, 2, 0), (12, 256, 512, 16, 52, 1, 2, 0)]
 LAYERS = [(12, 3, 64, 256, 832, 7, 2, 3), (12, 64, 128, 64, 208, 3, 2, 1), (12, 128, 256, 32, 104, 3, 2, 1), (12, 256, 512, 16, 52, 3, 2, 1),
           (12, 3, 16, 256, 832, 3, 2, 1), (12, 16, 32, 128, 416, 3, 2, 1), (12, 32, 64, 64, 208, 3, 2, 1), (12, 64, 96, 32, 104, 3, 2, 1),
           (12, 96, 128, 16, 52, 3, 2, 1), (12, 128, 196, 8, 26, 3, 2, 1),
           (4, 9, 16, 256, 832, 7, 2, 3), (4, 16, 32, 128, 416, 5, 2, 2), (4, 32, 64, 64, 208, 3, 2, 1), (4, 64, 128, 32, 104, 3, 2, 1),
-          (4, 128, 256, 16, 52, 3, 2, 1), (4, 256, 256, 8, 26, 3, 2, 1), (4, 256, 256, 4, 13, 3, 2, 1)]
+          (4, 128, 256, 16, 52, 3, 2, 1), (4, 256, 256, 8, 26, 3, 2, 1), (4, 256, 256, 4, 13, 3, 2, 1)] + ONE_BY_ONE
 
 CHECKS = [(2, 16, 16, 8, 12, 3, 2, 1), (1, 3, 64, 20, 36, 7, 2, 3), (2, 9, 16, 17, 23, 7, 2, 3), (1, 16, 32, 19, 27, 5, 2, 2), (3, 40, 70, 10, 13, 3, 2, 1),
           (2, 3, 16, 9, 11, 3, 2, 1), (1, 64, 128, 64, 208, 3, 2, 1), (2, 33, 17, 7, 9, 3, 2, 1), (1, 256, 256, 4, 13, 3, 2, 1), (2, 96, 128, 16, 52, 3, 2, 1),
-          (1, 17, 20, 5, 130, 3, 2, 1), (1, 3, 5, 6, 6, 3, 2, 1), (2, 16, 16, 4, 4, 3, 2, 0), (1, 20, 40, 9, 9, 3, 1, 1)]
+          (1, 17, 20, 5, 130, 3, 2, 1), (1, 3, 5, 6, 6, 3, 2, 1), (2, 16, 16, 4, 4, 3, 2, 0), (1, 20, 40, 9, 9, 3, 1, 1),
+          (2, 64, 128, 9, 13, 1, 2, 0), (1, 24, 40, 8, 12, 1, 2, 0), (2, 70, 33, 13, 7, 3, 2, 1), (1, 16, 32, 21, 27, 5, 2, 2)]
 
 
 def ev(fn, n):
@@ -51,6 +53,7 @@ def aten_bwd(x, w, gy, S, P, mask):
 OURS = {
     "wgrad": lambda x, w, gy, K, S, P: ops.sconv_wgrad(x, gy, K, S, P),
     "fwd": lambda x, w, gy, K, S, P: ops.sconv_fwd(x, w),
+    "dgrad": lambda x, w, gy, K, S, P: ops.sconv_dgrad(gy, w, x.shape),
 }
 ATEN = {
     "wgrad": lambda x, w, gy, K, S, P: aten_bwd(x, w, gy, S, P, [False, True, False])[1],
@@ -59,6 +62,7 @@ ATEN = {
 }
 SUPPORTED = {
     "wgrad": lambda shape: ops.sconv_wgrad_supported(shape[:1] + shape[1:2] + shape[3:5], shape[2], shape[5], shape[6], shape[7]),
+    "dgrad": lambda shape: shape[6] == 2 and shape[7] == shape[5] // 2 and ops.sconv_dgrad_supported(shape[:1] + shape[1:2] + shape[3:5], shape[2], shape[5]),
     "fwd": lambda shape: shape[6] == 2 and shape[7] == shape[5] // 2 and ops.sconv_fwd_supported(shape[:1] + shape[1:2] + shape[3:5], shape[2], shape[5]),
 }
 

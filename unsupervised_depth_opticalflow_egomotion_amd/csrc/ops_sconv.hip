@@ -458,6 +458,190 @@ k_sconv_fwd(const float* __restrict__ x, const float* __restrict__ wp, const flo
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Data gradient of the stride-2 convolution: gx[ci][iy][ix] = sum_(co, ky, kx) w[co][ci][ky][kx] gy[co][(iy + P - ky) / 2][(ix + P - kx) / 2]
+// over the taps that divide evenly.  Input pixel (2u + py, 2v + px) only meets the taps with ky = (py + P) mod 2, kx = (px + P) mod 2:
+// four stride-1 correlations of gy with sub-filters, one per PHASE (py, px).  A block owns COB input channels x a tile of (u, v)
+// positions and keeps the four phases' accumulators; per group of four OUTPUT channels it reads the (2 x 2 for 3x3, 3 x 3 for 5x5)
+// shifted gy operands once and every tap's filter operand once: MFMA count = the forward's, no zero-stuffed work.  The filter slab
+// is k_sconv_pack<true>'s [co / 4][tap][co % 4][Ci]; gy is staged unsplit (stride 1).  1x1 (the ResNet down-sampling shortcuts,
+// depth_model.py:31-36): phase (0, 0) gets w^T gy, the three others zeros.
+struct ScDg {
+  long gbs, xbs;
+  int Ci, Co, H, W, Ho, Wo;        // gx is [Ci][H][W], gy [Co][Ho][Wo]
+  int TH, TW, RI, NSLOT, XRS, XCS;
+  int CB, nck, cps, nsplit;
+  int cpr, rpi, ntile, ncit;
+  int Cip, WRS, wl4;
+};
+
+template <int K, int MT, int NT, int WM, int WN, int XSH, int NXL, int NWL>
+__global__ void __launch_bounds__(256, 2)
+k_sconv_dgrad(const float* __restrict__ gy, const float* __restrict__ wp, float* __restrict__ gx, float* __restrict__ part, const ScDg g) {
+  constexpr int KK = K * K, P = K / 2, CIB = 16 * MT * WM;
+  // row shift of tap ky: gy row = u + (py + P - ky) / 2 with py = (ky + P) & 1; DMIN / ND: the smallest shift, the number of shifts
+  constexpr int DMIN = K == 5 ? -1 : 0, ND = K == 1 ? 1 : (K == 3 ? 2 : 3), DXA = ((DMIN % 4) + 4) % 4;
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i = lane & 15, kq = lane >> 4;
+  const int wm = wv / WN, wn = wv % WN;
+  const unsigned lid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int cb_i = static_cast<int>(lid % static_cast<unsigned>(g.ncit));
+  const int tile = static_cast<int>((lid / static_cast<unsigned>(g.ncit)) % static_cast<unsigned>(g.ntile));
+  const int split = static_cast<int>(lid / (static_cast<unsigned>(g.ncit) * static_cast<unsigned>(g.ntile)));
+  const int cib0 = cb_i * CIB;
+  const int cx = tile % g.cpr, ry = (tile / g.cpr) % g.rpi, img = tile / g.cpr / g.rpi;
+  const int u0 = ry * g.TH, v0 = cx * g.TW;
+  const int c_beg = split * g.cps, c_end = min(g.nck, c_beg + g.cps);
+  const int gHW = g.Ho * g.Wo, HW = g.H * g.W;
+  const int XTOT = g.CB * g.XCS;
+
+  int boff[NT], pu[NT], pv[NT], aoff[MT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int p = (wn * NT + j) * 16 + i, ul = p / g.TW, vl = p - ul * g.TW;
+    const bool ok = ul < g.TH;
+    boff[j] = kq * g.XCS + (ok ? ul * g.XRS + vl : 0) + DXA;
+    pu[j] = ok ? u0 + ul : -1; pv[j] = v0 + vl;
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) aoff[mt] = XTOT + kq * g.WRS + (wm * MT + mt) * 16 + i;
+
+  constexpr int xncg = 256 >> XSH;
+  const int xpos = tid & ((1 << XSH) - 1), xcg = tid >> XSH;
+  const int xr_ = xpos / g.NSLOT, xs_ = xpos - xr_ * g.NSLOT;
+  const bool xact = xpos < g.RI * g.NSLOT;
+  const int xl0 = xcg * g.XCS + xr_ * g.XRS + 4 * xs_;
+  const int oy = u0 + DMIN + xr_, ox = v0 + DMIN - DXA + 4 * xs_;
+  const bool rowok = xact && oy >= 0 && oy < g.Ho;
+  const bool full = rowok && ox >= 0 && ox + 3 < g.Wo;
+  const bool cut = rowok && !full && ox + 3 >= 0 && ox < g.Wo;
+  const float* gb = gy + img * g.gbs;
+  constexpr int WQ = CIB / 4;
+  sc_f32x4 xr[NXL], wr[NWL];
+  auto load_chunk = [&](int c) {
+    const int off0 = (c * g.CB + xcg) * gHW + oy * g.Wo + ox;
+#pragma unroll
+    for (int jj = 0; jj < NXL; ++jj) {
+      const int ch = xcg + jj * xncg;
+      const bool ok = full && ch < g.CB && c * g.CB + ch < g.Co;
+      const ScQuadU u = *reinterpret_cast<const ScQuadU*>(gb + (ok ? off0 + jj * xncg * gHW : 0));
+      xr[jj] = sc_f32x4{ok ? u.a : 0.0f, ok ? u.b : 0.0f, ok ? u.c : 0.0f, ok ? u.d : 0.0f};
+    }
+    if (cut) {
+#pragma unroll
+      for (int jj = 0; jj < NXL; ++jj) {
+        const int ch = xcg + jj * xncg;
+        if (ch < g.CB && c * g.CB + ch < g.Co) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (ox + e >= 0 && ox + e < g.Wo) xr[jj][e] = gb[off0 + jj * xncg * gHW + e];
+        }
+      }
+    }
+    const float* wsrc = wp + static_cast<long>(c) * g.CB * KK * g.Cip + cib0;
+#pragma unroll
+    for (int jj = 0; jj < NWL; ++jj) {
+      const int e = tid + 256 * jj, row = e / WQ, q = e - row * WQ;
+      wr[jj] = e < g.wl4 ? *reinterpret_cast<const sc_f32x4*>(wsrc + static_cast<long>(row) * g.Cip + 4 * q) : sc_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+  };
+  auto store_chunk = [&]() {
+    if (xact) {
+#pragma unroll
+      for (int jj = 0; jj < NXL; ++jj)
+        if (xcg + jj * xncg < g.CB) *reinterpret_cast<sc_f32x4*>(lds + xl0 + jj * xncg * g.XCS) = xr[jj];
+    }
+#pragma unroll
+    for (int jj = 0; jj < NWL; ++jj) {
+      const int e = tid + 256 * jj, row = e / WQ, q = e - row * WQ;
+      if (e < g.wl4) *reinterpret_cast<sc_f32x4*>(lds + XTOT + row * g.WRS + 4 * q) = wr[jj];
+    }
+  };
+
+  sc_f32x4 acc[2][2][MT][NT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[a][b][mt][j] = sc_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+  if (c_beg < c_end) {
+    load_chunk(c_beg);
+    store_chunk();
+  }
+  __syncthreads();
+  const int nc4 = g.CB >> 2;
+  for (int c = c_beg; c < c_end; ++c) {
+    const bool more = c + 1 < c_end;
+    if (more) load_chunk(c + 1);
+    for (int c4 = 0; c4 < nc4; ++c4) {
+      // the shifted gy operands of this channel group, then filter row by filter row
+      float b[ND][ND][NT];
+      const int bb = c4 * 4 * g.XCS;
+#pragma unroll
+      for (int dy = 0; dy < ND; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < ND; ++dx)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) b[dy][dx][j] = lds[boff[j] + bb + dy * g.XRS + dx];
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        constexpr int dummy = 0; (void)dummy;
+        const int py = (ky + P) & 1, dy = (py + P - ky) / 2 - DMIN;
+        float a[K][MT];
+        const int ab = (c4 * KK + ky * K) * 4 * g.WRS;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) a[kx][mt] = lds[aoff[mt] + ab + kx * 4 * g.WRS];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          const int px = (kx + P) & 1, dx = (px + P - kx) / 2 - DMIN;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[py][px][mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kx][mt], b[dy][dx][j], acc[py][px][mt][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+    if (more) {
+      store_chunk();
+      __syncthreads();
+    }
+  }
+
+  // ---- gx (or this split's partial sums): the two column phases of a position are neighbours
+  const int nimg = g.ntile / (g.cpr * g.rpi);
+  float* ob = g.nsplit == 1 ? gx + img * g.xbs : part + (static_cast<long>(split) * nimg + img) * g.Ci * HW;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ci = cib0 + (wm * MT + mt) * 16 + 4 * kq + r;
+      if (ci >= g.Ci) continue;
+      float* oc = ob + static_cast<long>(ci) * HW;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (pu[j] < 0) continue;
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+          const int iy = 2 * pu[j] + py, ix = 2 * pv[j];
+          if (iy >= g.H || ix >= g.W) continue;
+          float* o = oc + iy * g.W + ix;
+          o[0] = acc[py][0][mt][j][r];
+          if (ix + 1 < g.W) o[1] = acc[py][1][mt][j][r];
+        }
+      }
+    }
+}
+
 }  // namespace dfe
 
 #define DFE_LAUNCH_CHECK() do { if (hipGetLastError() != hipSuccess) return DFE_ERR_LAUNCH; } while (0)
@@ -685,6 +869,101 @@ extern "C" int dfe_sconv_fwd(const float* x, long x_batch_stride, const float* w
   if (g.nsplit > 1) {
     const long per_img = Co * oplane, n = per_img * B;
     k_sconv_sum<<<static_cast<unsigned>((n + 255) / 256), 256, 0, st>>>(part, y, y_batch_stride, per_img, n, g.nsplit, static_cast<int>(oplane), bias, slope);
+    DFE_LAUNCH_CHECK();
+  }
+  return DFE_OK;
+}
+
+// ---- data gradient, host side
+namespace {
+bool sc_dg_plan(int B, int Ci, int Co, int H, int W, int K, ScDg* out, int* t32) {
+  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || (K != 1 && K != 3 && K != 5)) return false;
+  const int P = K / 2, KK = K * K;
+  ScDg g = {};
+  g.Ci = Ci; g.Co = Co; g.H = H; g.W = W;
+  g.Ho = (H + 2 * P - K) / 2 + 1; g.Wo = (W + 2 * P - K) / 2 + 1;
+  if (g.Ho < 1 || g.Wo < 1 || static_cast<long>(Co) * g.Ho * g.Wo < 4) return false;
+  *t32 = Ci <= 32;
+  const int CIB = *t32 ? 32 : 64, NPIX = *t32 ? 128 : 64;
+  const int cop = (Co + 3) / 4 * 4;
+  g.CB = K == 5 ? std::min(8, cop) : std::min(16, cop);
+  g.nck = (cop + g.CB - 1) / g.CB;
+  g.Cip = (Ci + 63) / 64 * 64;
+  g.WRS = CIB + 16;
+  g.wl4 = g.CB * KK * CIB / 4;
+  g.ncit = (Ci + CIB - 1) / CIB;
+  const int dmin = K == 5 ? -1 : 0, nd = K == 1 ? 1 : (K == 3 ? 2 : 3), dxa = ((dmin % 4) + 4) % 4;
+  // positions (u, v) of the half-resolution grid whose phases the block writes: U x V = ceil(H / 2) x ceil(W / 2)
+  const int U = (H + 1) / 2, V = (W + 1) / 2;
+  double best = 0.0;
+  for (int tw = std::min(64, (V + 3) / 4 * 4); tw >= 4; tw -= 4) {
+    const int th = std::min(NPIX / tw, U);
+    if (th < 1) continue;
+    const int ri = th + nd - 1, nslot = (tw + nd - 1 + dxa + 3) / 4;
+    if (ri * nslot > 64) continue;
+    const int xrs = 4 * nslot, xcs = sc_pad16(ri * xrs);
+    if (sizeof(float) * (static_cast<size_t>(g.CB) * xcs + static_cast<size_t>(g.CB) * KK * g.WRS + 64) > 76 * 1024) continue;
+    const int cpr = (V + tw - 1) / tw, rpi = (U + th - 1) / th;
+    const double eff = static_cast<double>(U) * V / (static_cast<double>(cpr) * rpi * NPIX);
+    if (eff > best + 1e-9) { best = eff; g.TW = tw; g.TH = th; g.RI = ri; g.NSLOT = nslot; g.XRS = xrs; g.XCS = xcs; g.cpr = cpr; g.rpi = rpi; }
+  }
+  if (best == 0.0) return false;
+  const long nt = static_cast<long>(B) * g.cpr * g.rpi;
+  if (nt * g.ncit >= (1L << 24)) return false;
+  g.ntile = static_cast<int>(nt);
+  const long blocks = nt * g.ncit;
+  long sp = blocks >= 384 ? 1 : std::min<long>(g.nck, (512 + blocks - 1) / blocks);
+  g.cps = static_cast<int>((g.nck + sp - 1) / sp);
+  g.nsplit = (g.nck + g.cps - 1) / g.cps;
+  *out = g;
+  return true;
+}
+
+long sc_dg_packed_floats(const ScDg& g, int K) { return static_cast<long>(g.nck) * g.CB * K * K * g.Cip + 64; }
+
+template <int K, int MT, int NT, int WM, int WN, int NXL, int NWL>
+void sc_dg_launch(const ScDg& g, const float* gy, const float* wp, float* gx, float* part, hipStream_t st) {
+  const size_t lds_bytes = sizeof(float) * (static_cast<size_t>(g.CB) * g.XCS + static_cast<size_t>(g.CB) * K * K * g.WRS + 64);
+  auto kern = k_sconv_dgrad<K, MT, NT, WM, WN, 6, NXL, NWL>;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_set = true; }
+  kern<<<static_cast<unsigned>(g.ntile) * g.ncit * g.nsplit, 256, lds_bytes, st>>>(gy, wp, gx, part, g);
+}
+}  // namespace
+
+extern "C" long dfe_sconv_dgrad_floats(int B, int Ci, int Co, int H, int W, int K) {
+  ScDg g; int t32;
+  if (!sc_dg_plan(B, Ci, Co, H, W, K, &g, &t32)) return 0;
+  return sc_dg_packed_floats(g, K) + (g.nsplit > 1 ? static_cast<long>(g.nsplit) * B * Ci * H * W : 0);
+}
+
+extern "C" int dfe_sconv_dgrad(const float* gy, long gy_batch_stride, const float* weight, float* gx, long gx_batch_stride, float* ws, int B,
+                               int Ci, int Co, int H, int W, int K, void* stream) {
+  if (!gy || !weight || !gx || !ws) return DFE_ERR_NULL;
+  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return DFE_ERR_DIMS;
+  ScDg g; int t32;
+  if (!sc_dg_plan(B, Ci, Co, H, W, K, &g, &t32)) return DFE_ERR_UNSUPPORTED;
+  const long oplane = static_cast<long>(g.Ho) * g.Wo, iplane = static_cast<long>(H) * W;
+  if (gx_batch_stride < Ci * iplane || gy_batch_stride < Co * oplane) return DFE_ERR_DIMS;
+  if (Ci * iplane >= (1L << 30) || Co * oplane >= (1L << 30)) return DFE_ERR_DIMS;
+  if (reinterpret_cast<uintptr_t>(ws) % 16) return DFE_ERR_DIMS;
+  g.gbs = gy_batch_stride; g.xbs = gx_batch_stride;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rows = g.nck * g.CB * K * K;
+  const long npk = static_cast<long>(rows) * g.Cip;
+  k_sconv_pack<true><<<static_cast<unsigned>((npk + 255) / 256), 256, 0, st>>>(weight, ws, Co, Ci, K * K, g.Cip, rows);
+  DFE_LAUNCH_CHECK();
+  float* part = ws + sc_dg_packed_floats(g, K);
+  if (K == 3 && !t32) sc_dg_launch<3, 2, 2, 2, 2, 4, 9>(g, gy, ws, gx, part, st);
+  else if (K == 3) sc_dg_launch<3, 2, 2, 1, 4, 4, 5>(g, gy, ws, gx, part, st);
+  else if (K == 5 && !t32) sc_dg_launch<5, 2, 2, 2, 2, 2, 13>(g, gy, ws, gx, part, st);
+  else if (K == 5) sc_dg_launch<5, 2, 2, 1, 4, 2, 7>(g, gy, ws, gx, part, st);
+  else if (!t32) sc_dg_launch<1, 2, 2, 2, 2, 4, 1>(g, gy, ws, gx, part, st);
+  else sc_dg_launch<1, 2, 2, 1, 4, 4, 1>(g, gy, ws, gx, part, st);
+  DFE_LAUNCH_CHECK();
+  if (g.nsplit > 1) {
+    const long per_img = Ci * iplane, n = per_img * B;
+    k_sconv_sum<<<static_cast<unsigned>((n + 255) / 256), 256, 0, st>>>(part, gx, gx_batch_stride, per_img, n, g.nsplit, static_cast<int>(iplane), nullptr, 1.0f);
     DFE_LAUNCH_CHECK();
   }
   return DFE_OK;
