@@ -283,8 +283,8 @@ long dfe_wino_wgrad_floats(int B, int Ci, int Co, int H, int W, int P);
 int dfe_wino_wgrad_tune(int tile, int blocks1, int blocks2, int chunk);
 int dfe_wino_wgrad3x3(const float* x, long x_batch_stride, const float* gy, long gy_batch_stride, float* gweight, float* ws, int B,
                       int Ci, int Co, int H, int W, int P, void* stream);
-/* STRIDED convolutions straight from NCHW on the fp32 matrix cores (csrc/ops_sconv.hip; replaces MIOpen's transposed NHWC calls for
- * nn.Conv2d(..., stride=2): depth_model.py:60-95 ResNet stem / down-sampling, feature_pyramid.py:7-36, pose_cnn.py:14-36).
+/* Weight gradient of a STRIDED convolution straight from NCHW on the fp32 matrix cores (csrc/ops_sconv.hip; replaces MIOpen's
+ * transposed NHWC calls for nn.Conv2d(..., stride=2): depth_model.py:60-95 ResNet stem, feature_pyramid.py:7-36, pose_cnn.py:14-36).
  * x [B,Ci,H,W], gy [B,Co,Ho,Wo] (Ho = (H + 2P - K) / stride + 1), both with a batch stride in floats; K x K filters, K <= 7.
  * dfe_sconv_wgrad: gweight [Co,Ci,K,K] = the weight gradient; ws holds dfe_sconv_wgrad_floats(...) floats of split partials,
  * added in split order (no atomics: bit-reproducible).  0 floats / DFE_ERR_UNSUPPORTED: a shape outside the kernel family
@@ -294,17 +294,6 @@ int dfe_sconv_tune(int blocks, int rows);
 long dfe_sconv_wgrad_floats(int B, int Ci, int Co, int H, int W, int K, int stride, int P);
 int dfe_sconv_wgrad(const float* x, long x_batch_stride, const float* gy, long gy_batch_stride, float* gweight, float* ws, int B,
                     int Ci, int Co, int H, int W, int K, int stride, int P, void* stream);
-/* dfe_sconv_fwd: y [B,Co,Ho,Wo] = act(conv(x, weight [Co,Ci,K,K], stride 2, padding K / 2) + bias), K in {3, 5, 7}; bias may be NULL,
- * slope is the negative slope of the activation (1: none, 0: ReLU, 0.1: net_utils.conv's LeakyReLU).  ws (16-byte aligned) holds
- * dfe_sconv_fwd_floats(...) floats: the filter packed for the kernel and, for thin layers, the channel splits' partial sums. */
-long dfe_sconv_fwd_floats(int B, int Ci, int Co, int H, int W, int K);
-int dfe_sconv_fwd(const float* x, long x_batch_stride, const float* weight, const float* bias, float slope, float* y,
-                  long y_batch_stride, float* ws, int B, int Ci, int Co, int H, int W, int K, void* stream);
-/* dfe_sconv_dgrad: gx [B,Ci,H,W] = the data gradient of the same convolution (K in {1, 3, 5}, stride 2, padding K / 2) for gy
- * [B,Co,Ho,Wo]; every element of gx is written.  ws as dfe_sconv_fwd's, dfe_sconv_dgrad_floats(...) floats. */
-long dfe_sconv_dgrad_floats(int B, int Ci, int Co, int H, int W, int K);
-int dfe_sconv_dgrad(const float* gy, long gy_batch_stride, const float* weight, float* gx, long gx_batch_stride, float* ws, int B,
-                    int Ci, int Co, int H, int W, int K, void* stream);
 /* the same for a DILATED 3x3 convolution with padding = dilation (pwc_tf.py:31-36 context network: dilation 2, 4, 8, 16): the
  * Winograd tiles live on the dilation x dilation phase images; H and W must be multiples of the dilation.  y has x's size. */
 int dfe_wino_conv3x3_dilated(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, int B, int Ci, int Co,

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""The strided convolutions of csrc/ops_sconv.hip against MIOpen (aten, its layout transposes and fills included) on the networks'
+"""The strided weight gradient of csrc/ops_sconv.hip against MIOpen (aten, its layout transposes and fills included) on the networks'
 stride-2 layers: parity against float64 aten first (odd sizes, ragged channel counts), then HIP-event time per call.
+(profiles/r05_sconv_bench_all.md was made by this tool while the forward and data-gradient kernels of the family existed.)
 
-    python tools/sconv_bench.py [--iters 20] [--check-only] [--pass wgrad,fwd,dgrad]
+    python tools/sconv_bench.py [--iters 20] [--check-only] [--blocks 512,768]
 """
 import argparse, os, sys
 import torch
@@ -52,8 +53,6 @@ def aten_bwd(x, w, gy, S, P, mask):
 
 OURS = {
     "wgrad": lambda x, w, gy, K, S, P: ops.sconv_wgrad(x, gy, K, S, P),
-    "fwd": lambda x, w, gy, K, S, P: ops.sconv_fwd(x, w),
-    "dgrad": lambda x, w, gy, K, S, P: ops.sconv_dgrad(gy, w, x.shape),
 }
 ATEN = {
     "wgrad": lambda x, w, gy, K, S, P: aten_bwd(x, w, gy, S, P, [False, True, False])[1],
@@ -62,8 +61,6 @@ ATEN = {
 }
 SUPPORTED = {
     "wgrad": lambda shape: ops.sconv_wgrad_supported(shape[:1] + shape[1:2] + shape[3:5], shape[2], shape[5], shape[6], shape[7]),
-    "dgrad": lambda shape: shape[6] == 2 and shape[7] == shape[5] // 2 and ops.sconv_dgrad_supported(shape[:1] + shape[1:2] + shape[3:5], shape[2], shape[5]),
-    "fwd": lambda shape: shape[6] == 2 and shape[7] == shape[5] // 2 and ops.sconv_fwd_supported(shape[:1] + shape[1:2] + shape[3:5], shape[2], shape[5]),
 }
 
 

@@ -51,10 +51,6 @@ _SIGNATURES = {
     "dfe_sconv_tune": [_I, _I],
     "dfe_sconv_wgrad_floats": [_I, _I, _I, _I, _I, _I, _I, _I],
     "dfe_sconv_wgrad": [_P, ctypes.c_long, _P, ctypes.c_long, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "dfe_sconv_fwd_floats": [_I, _I, _I, _I, _I, _I],
-    "dfe_sconv_fwd": [_P, ctypes.c_long, _P, _P, ctypes.c_float, _P, ctypes.c_long, _P, _I, _I, _I, _I, _I, _I, _P],
-    "dfe_sconv_dgrad_floats": [_I, _I, _I, _I, _I, _I],
-    "dfe_sconv_dgrad": [_P, ctypes.c_long, _P, _P, ctypes.c_long, _P, _I, _I, _I, _I, _I, _I, _P],
     "dfe_wino_wgrad3x3": [_P, ctypes.c_long, _P, ctypes.c_long, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dfe_wino_conv3x3_dilated": [_P, _P, _P, ctypes.c_long, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dfe_wino_transform_blocks": [_I, _I],
@@ -124,7 +120,7 @@ _RESTYPES = {"dfe_error_string": ctypes.c_char_p, "dfe_geom_workspace_floats": c
              "dfe_bias_act_partials_floats": ctypes.c_long, "dfe_glue_partials_floats": ctypes.c_long,
              "dfe_bn_partials_floats": ctypes.c_long, "dfe_disp_head_partials_floats": ctypes.c_long,
              "dfe_flow_head_partials_floats": ctypes.c_long,
-             "dfe_wgrad3x3_partials_floats": ctypes.c_long, "dfe_planeconv_ws_floats": ctypes.c_long, "dfe_wino_weight_floats": ctypes.c_long, "dfe_wino_scratch_floats": ctypes.c_long, "dfe_wino_wgrad_floats": ctypes.c_long, "dfe_sconv_wgrad_floats": ctypes.c_long, "dfe_sconv_dgrad_floats": ctypes.c_long, "dfe_sconv_fwd_floats": ctypes.c_long, "dfe_wino_transform_blocks": ctypes.c_long,
+             "dfe_wgrad3x3_partials_floats": ctypes.c_long, "dfe_planeconv_ws_floats": ctypes.c_long, "dfe_wino_weight_floats": ctypes.c_long, "dfe_wino_scratch_floats": ctypes.c_long, "dfe_wino_wgrad_floats": ctypes.c_long, "dfe_sconv_wgrad_floats": ctypes.c_long, "dfe_wino_transform_blocks": ctypes.c_long,
              "dfe_geom_maskpack_offset_bytes": ctypes.c_long, "dfe_scatter_ws_bytes": ctypes.c_long}
 
 

@@ -101,31 +101,32 @@ def _wgrad_route(x, w_shape, stride, padding, dilation, groups):
     return ho >= 1 and wo >= 1 and _wino_wgrad_eligible(x, (x.shape[0], w_shape[0], ho, wo), w_shape, padding, d)
 
 
-# Stride-2 layers (the ResNet18 encoder's stem and down-sampling convolutions depth_model.py:60-95, FeaturePyramid's 3x3 / 2 layers
-# feature_pyramid.py:7-36, PoseCNN's 7x7, 5x5, 3x3 / 2 layers pose_cnn.py:14-36): csrc/ops_sconv.hip reads NCHW directly -- one launch
-# per pass plus the filter packing / split sum, where MIOpen wrapped its NHWC implicit GEMMs in two or three layout transposes and
-# a zero fill (13 launches per layer and step).  tools/sconv_bench.py: forward and data gradient on a par with MIOpen's whole
-# call, the weight gradients of the 3- and 9-channel stems 2x faster.  DFE_SCONV=0: back to MIOpen.
+# Weight gradients of the stride-2 layers with thin inputs (the ResNet18 encoder's 7x7 stem depth_model.py:60-95, FeaturePyramid's
+# 3 -> 16 and 16 -> 32 layers feature_pyramid.py:7-36, PoseCNN's 7x7 x 9 and 5x5 x 16 layers pose_cnn.py:14-36): csrc/ops_sconv.hip
+# reads NCHW directly -- one launch plus the split sum, where MIOpen wrapped an NHWC implicit GEMM in three layout transposes and a
+# zero fill and ran at 6 - 40 TFLOP/s: 164 against 328 us (12 x 3 -> 64 @ 256x832, 7x7), 63 against 138 us (4 x 9 -> 16, 7x7);
+# tools/sconv_bench.py, profiles/r05_sconv_bench_all.md.  Step: 19.00 -> 18.90 ms.  Wider layers (MIOpen at 64 - 70 TFLOP/s, this
+# kernel at 50 - 57) and the forward / data-gradient kernels of the same family lost in the step and are not routed
+# (EXPERIMENT_LOG.md "strided convolutions").  DFE_SCONV=0: back to MIOpen.
 SCONV = os.environ.get("DFE_SCONV", "1") != "0"
-SCONV_MAX_CI = int(os.environ.get("DFE_SCONV_MAX_CI", "32"))              # forward / data gradient: layers with at most this many input channels
-SCONV_WGRAD_MAX_CI = int(os.environ.get("DFE_SCONV_WGRAD_MAX_CI", "16"))   # weight gradient
+SCONV_WGRAD_MAX_CI = int(os.environ.get("DFE_SCONV_WGRAD_MAX_CI", "16"))
 
 
 def _sconv_route(x, w_shape, stride, padding, dilation, groups=1):
-    """A stride-2 k x k layer (k in {3, 5, 7}, padding k // 2) of fp32 NCHW tensors on the GPU."""
+    """A stride-2 k x k layer (k in {3, 5, 7}, padding k // 2) of fp32 NCHW tensors on the GPU whose weight gradient
+    dfe_sconv_wgrad takes."""
     k = int(w_shape[2])
-    return (SCONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and groups == 1 and tuple(stride) == (2, 2)
+    if not (SCONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and groups == 1 and tuple(stride) == (2, 2)
             and tuple(dilation) == (1, 1) and int(w_shape[3]) == k and k in (3, 5, 7) and tuple(padding) == (k // 2, k // 2)
-            and x.numel() < (1 << 30))
+            and int(w_shape[1]) <= SCONV_WGRAD_MAX_CI and x.numel() < (1 << 30)):
+        return False
+    from . import ops
+    return ops.sconv_wgrad_supported(x.shape, w_shape[0], k, 2, k // 2)
 
 
 def raw_forward(x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1)):
     """y = conv(x, w) without bias, fp32 in / fp32 out, no autograd of its own."""
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
-    if _sconv_route(x, w.shape, stride, padding, dilation):
-        from . import ops
-        if w.shape[1] <= SCONV_MAX_CI and ops.sconv_fwd_supported(x.shape, w.shape[0], w.shape[2]):
-            return ops.sconv_fwd(x, w)
     if _wino_eligible(x, w.shape, w.shape[1], stride, padding, dilation):
         from . import ops
         return ops.wino_conv3x3(x, w, padding[0], dilation=dilation[0])
@@ -140,15 +141,10 @@ def raw_backward(gy, x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1), want_
     own_w = want_w and stride == (1, 1) and tuple(w.shape[2:]) == (3, 3) and dilation == (d, d) and \
         _wino_wgrad_eligible(x, gy.shape, w.shape, padding, d)
     gx = gw = gb = None
-    if (want_x or want_w) and _sconv_route(x, w.shape, stride, padding, dilation):
+    if want_w and _sconv_route(x, w.shape, stride, padding, dilation):
         from . import ops
-        k = int(w.shape[2])
-        if want_x and k in (3, 5) and w.shape[1] <= SCONV_MAX_CI and ops.sconv_dgrad_supported(x.shape, w.shape[0], k):
-            gx = ops.sconv_dgrad(gy, w, x.shape)
-            want_x = False
-        if want_w and w.shape[1] <= SCONV_WGRAD_MAX_CI and ops.sconv_wgrad_supported(x.shape, w.shape[0], k, 2, k // 2):
-            gw = ops.sconv_wgrad(x, gy, k, 2, k // 2)
-            want_w = False
+        gw = ops.sconv_wgrad(x, gy, int(w.shape[2]), 2, int(w.shape[2]) // 2)
+        want_w = False
     if want_x and (padding in ((1, 1), (0, 0)) or (d > 1 and padding == (d, d))) and \
             _wino_eligible(gy, w.shape, w.shape[0], stride, (d, d) if d > 1 else (1, 1), dilation):
         from . import ops

@@ -1,18 +1,20 @@
-// The networks' STRIDED convolutions on the fp32 matrix cores, straight from NCHW (reference layers: the ResNet18 encoder's 7x7/2
-// stem and 3x3/2 down-sampling convolutions depth_model.py:60-95, FeaturePyramid's six 3x3/2 layers feature_pyramid.py:7-36,
-// PoseCNN's 7x7/2, 5x5/2 and 3x3/2 layers pose_cnn.py:14-36).  MIOpen ran each of them as an NHWC implicit GEMM wrapped in two or
-// three layout transposes and (weight gradients) a zero fill: 13 launches per layer and step for forward + both gradients, a
-// quarter of the step's launches for 3.8 of its 24.7 ms of kernel time.  Here every pass is ONE launch (+ a fixed-order sum of
-// the split partials) that stages raw NCHW rows in LDS and reads the matrix-core operands from there:
-//   * weight gradient (k_sconv_wgrad): dW[co][ci][ky][kx] = sum_pixels gy[co][oy][ox] x[ci][S oy + D ky - P][S ox + D kx - P] is a
-//     GEMM (co) x (ci, ky, kx) whose reduction runs over the output pixels.  v_mfma_f32_16x16x4_f32 takes "one row / column per
-//     lane & 15, one of four reduction slots per lane >> 4": the A operand is gy[co = lane & 15][pixel 4 g + (lane >> 4)], the B
-//     operand x at the lane's OWN (ci, ky, kx) column for the same pixel -- a per-lane LDS offset fixed for the whole kernel plus
-//     the step's uniform pixel offset.  For stride 2 the staged x rows are split into even and odd columns so that the four
-//     pixels of a step are four consecutive words.  Columns are either "one filter tap per 16-lane tile, 16 input channels
-//     across the lanes" (Ci >= 16) or the flattened (ci, ky, kx) index (the 3- and 9-channel stems, 5x5).  The pixel range is
-//     split over blocks; partials [split][co][ci][ky][kx] are added in split order by k_wgrad_sum: no atomics, bit-reproducible.
+// Weight gradients of the networks' STRIDED convolutions on the fp32 matrix cores, straight from NCHW (reference layers: the ResNet18
+// encoder's 7x7/2 stem depth_model.py:60-95, FeaturePyramid's first 3x3/2 layers feature_pyramid.py:7-36, PoseCNN's 7x7/2 and 5x5/2
+// layers pose_cnn.py:14-36).  MIOpen ran them as NHWC implicit GEMMs wrapped in three layout transposes and a zero fill and reached
+// 6 - 40 TFLOP/s on the 3-, 9- and 16-channel inputs (profiles/r05_sconv_bench_all.md); here ONE launch (+ a fixed-order sum of the
+// split partials) stages raw NCHW rows in LDS and reads the matrix-core operands from there:
+//     dW[co][ci][ky][kx] = sum_pixels gy[co][oy][ox] x[ci][S oy + D ky - P][S ox + D kx - P]
+// is a GEMM (co) x (ci, ky, kx) whose reduction runs over the output pixels.  v_mfma_f32_16x16x4_f32 takes "one row / column per
+// lane & 15, one of four reduction slots per lane >> 4": the A operand is gy[co = lane & 15][pixel 4 g + (lane >> 4)], the B
+// operand x at the lane's OWN (ci, ky, kx) column for the same pixel -- a per-lane LDS offset fixed for the whole kernel plus
+// the step's uniform pixel offset.  For stride 2 the staged x rows are split into even and odd columns so that the four
+// pixels of a step are four consecutive words.  Columns are either "one filter tap per 16-lane tile, 16 input channels
+// across the lanes" (Ci >= 16) or the flattened (ci, ky, kx) index (the 3- and 9-channel stems, 5x5).  The pixel range is
+// split over blocks; partials [split][co][ci][ky][kx] are added in split order by k_wgrad_sum: no atomics, bit-reproducible.
 // Bound: MFMA (157 TFLOP/s fp32 dense) for the wide layers, HBM for the 3-channel stems.
+// (Round 5 also built the forward pass and the data gradient in this style -- filter slab packed [ci / 4][tap][ci % 4][Co], the data
+// gradient as four phase correlations -- correct and on a par with MIOpen's whole call per layer, but the step lost 0.05 - 0.15 ms
+// with them: removed, EXPERIMENT_LOG.md "strided convolutions".)
 #include "dfe_internal.h"
 #include "dfe_device.h"
 #include "dfe_wgrad_sum.h"
@@ -261,387 +263,6 @@ k_sconv_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Forward: y[co][oy][ox] = act(bias[co] + sum_(ci, ky, kx) w[co][ci][ky][kx] x[ci][2 oy + ky - P][2 ox + kx - P]), K x K, stride 2,
-// P = K / 2.  A GEMM (co) x (pixels) whose reduction runs over (ci, ky, kx): a step of v_mfma_f32_16x16x4_f32 takes four INPUT
-// CHANNELS at one tap.  The A operand is the filter w[co = lane & 15][ci = 4 c4 + (lane >> 4)][tap] from a slab that k_sconv_pack laid
-// out as rows [ci / 4][tap][ci % 4][Co] (16-byte copies into LDS, no index arithmetic in the loop), the B operand the staged x at the
-// lane's own output pixel (a per-lane LDS offset) plus the tap's uniform offset; x rows are split into even and odd columns as in the
-// weight gradient.  A block = COB output channels x a tile of TH x TW output pixels (16 NT WN pixels, numbered row-major inside the
-// tile), the input channels in chunks of CB; thin layers split the chunks over blocks and k_sconv_sum adds the partials in order.
-struct ScFw {
-  long xbs, ybs;
-  int Ci, Co, H, W, Ho, Wo;
-  int TH, TW, RI, NSLOT, QW, XRS, XCS;
-  int CB, nck, cps, nsplit;      // channels per chunk, chunks, chunks per split
-  int cpr, rpi, ntile, ncot;
-  int Cop, WRS;                  // padded output channels of the packed filter; LDS row stride of the filter slab
-  int wl4;                       // 16-byte words of a chunk's filter slab
-  float slope;
-};
-
-// wp[g4][t][k][Cop] = w[co][4 g4 + k][t] (zero past Ci / Co); TRANSPOSED (data gradient): wp[g4][t][k][Cip] = w[4 g4 + k][ci][t]
-template <bool TRANSPOSED>
-__global__ void k_sconv_pack(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int KK, int Mp, int rows) {
-  const long idx = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (idx >= static_cast<long>(rows) * Mp) return;
-  const int m = static_cast<int>(idx % Mp), row = static_cast<int>(idx / Mp);
-  const int k = row & 3, t = (row >> 2) % KK, g4 = (row >> 2) / KK, r = 4 * g4 + k;
-  float v = 0.0f;
-  if (!TRANSPOSED) { if (m < Co && r < Ci) v = w[(static_cast<long>(m) * Ci + r) * KK + t]; }
-  else { if (m < Ci && r < Co) v = w[(static_cast<long>(r) * Ci + m) * KK + t]; }
-  wp[idx] = v;
-}
-
-__global__ void k_sconv_sum(const float* __restrict__ part, float* __restrict__ y, long ybs, long per_img, long n, int S, int HWo,
-                            const float* __restrict__ bias, float slope) {
-  const long idx = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (idx >= n) return;
-  float s = 0.0f;
-  for (int k = 0; k < S; ++k) s += part[k * n + idx];
-  const long b = idx / per_img, r = idx - b * per_img;
-  if (bias) s += bias[r / HWo];
-  if (slope != 1.0f) s = s > 0.0f ? s : s * slope;
-  y[b * ybs + r] = s;
-}
-
-template <int K, int MT, int NT, int WM, int WN, int XSH, int NXL, int NWL>
-__global__ void __launch_bounds__(256, 2)
-k_sconv_fwd(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
-            float* __restrict__ part, const ScFw g) {
-  constexpr int KK = K * K, P = K / 2, DX = (4 - P % 4) % 4, COB = 16 * MT * WM;
-  extern __shared__ float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i = lane & 15, kq = lane >> 4;
-  const int wm = wv / WN, wn = wv % WN;
-  const unsigned lid = xcd_swizzle(blockIdx.x, gridDim.x);
-  // block = (co block fastest: the blocks that share an x window are neighbours, pixel tile, split)
-  const int cb_i = static_cast<int>(lid % static_cast<unsigned>(g.ncot));
-  const int tile = static_cast<int>((lid / static_cast<unsigned>(g.ncot)) % static_cast<unsigned>(g.ntile));
-  const int split = static_cast<int>(lid / (static_cast<unsigned>(g.ncot) * static_cast<unsigned>(g.ntile)));
-  const int cob0 = cb_i * COB;
-  const int cx = tile % g.cpr, ry = (tile / g.cpr) % g.rpi, img = tile / g.cpr / g.rpi;
-  const int oy0 = ry * g.TH, ox0 = cx * g.TW;
-  const int c_beg = split * g.cps, c_end = min(g.nck, c_beg + g.cps);
-  const int HW = g.H * g.W, HWo = g.Ho * g.Wo;
-  const int XTOT = g.CB * g.XCS;
-
-  // ---- the lane's output pixels and operand offsets
-  int boff[NT], opix[NT], aoff[MT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int p = (wn * NT + j) * 16 + i, oyl = p / g.TW, oxl = p - oyl * g.TW;
-    const bool ok = oyl < g.TH && oy0 + oyl < g.Ho && ox0 + oxl < g.Wo;
-    boff[j] = kq * g.XCS + (ok ? 2 * oyl * g.XRS + oxl : 0);
-    opix[j] = ok ? (oy0 + oyl) * g.Wo + ox0 + oxl : -1;
-  }
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) aoff[mt] = XTOT + kq * g.WRS + (wm * MT + mt) * 16 + i;
-
-  // ---- staging: x as in the weight gradient (thread = (row, slot) position, channels 256 >> XSH apart), the filter slab by 16-byte words
-  constexpr int xncg = 256 >> XSH;
-  const int xpos = tid & ((1 << XSH) - 1), xcg = tid >> XSH;
-  const int xr_ = xpos / g.NSLOT, xs_ = xpos - xr_ * g.NSLOT;
-  const bool xact = xpos < g.RI * g.NSLOT;
-  const int xl0 = xcg * g.XCS + xr_ * g.XRS + 2 * xs_;
-  const int iy = 2 * oy0 - P + xr_, ix = 2 * ox0 - P - DX + 4 * xs_;
-  const bool rowok = xact && iy >= 0 && iy < g.H;
-  const bool full = rowok && ix >= 0 && ix + 3 < g.W;
-  const bool cut = rowok && !full && ix + 3 >= 0 && ix < g.W;
-  const float* xb = x + img * g.xbs;
-  constexpr int WQ = COB / 4;      // 16-byte words per filter row of this block
-  sc_f32x4 xr[NXL], wr[NWL];
-  auto load_chunk = [&](int c) {
-    const int off0 = (c * g.CB + xcg) * HW + iy * g.W + ix;
-#pragma unroll
-    for (int jj = 0; jj < NXL; ++jj) {
-      const int ch = xcg + jj * xncg;
-      const bool ok = full && ch < g.CB && c * g.CB + ch < g.Ci;
-      const ScQuadU u = *reinterpret_cast<const ScQuadU*>(xb + (ok ? off0 + jj * xncg * HW : 0));
-      xr[jj] = sc_f32x4{ok ? u.a : 0.0f, ok ? u.b : 0.0f, ok ? u.c : 0.0f, ok ? u.d : 0.0f};
-    }
-    if (cut) {
-#pragma unroll
-      for (int jj = 0; jj < NXL; ++jj) {
-        const int ch = xcg + jj * xncg;
-        if (ch < g.CB && c * g.CB + ch < g.Ci) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (ix + e >= 0 && ix + e < g.W) xr[jj][e] = xb[off0 + jj * xncg * HW + e];
-        }
-      }
-    }
-    const float* wsrc = wp + static_cast<long>(c) * g.CB * KK * g.Cop + cob0;
-#pragma unroll
-    for (int jj = 0; jj < NWL; ++jj) {
-      const int e = tid + 256 * jj, row = e / WQ, q = e - row * WQ;
-      wr[jj] = e < g.wl4 ? *reinterpret_cast<const sc_f32x4*>(wsrc + static_cast<long>(row) * g.Cop + 4 * q) : sc_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    }
-  };
-  auto store_chunk = [&]() {
-    if (xact) {
-#pragma unroll
-      for (int jj = 0; jj < NXL; ++jj)
-        if (xcg + jj * xncg < g.CB) {
-          float* d = lds + xl0 + jj * xncg * g.XCS;
-          *reinterpret_cast<sc_f32x2*>(d) = sc_f32x2{xr[jj][0], xr[jj][2]};
-          *reinterpret_cast<sc_f32x2*>(d + g.QW) = sc_f32x2{xr[jj][1], xr[jj][3]};
-        }
-    }
-#pragma unroll
-    for (int jj = 0; jj < NWL; ++jj) {
-      const int e = tid + 256 * jj, row = e / WQ, q = e - row * WQ;
-      if (e < g.wl4) *reinterpret_cast<sc_f32x4*>(lds + XTOT + row * g.WRS + 4 * q) = wr[jj];
-    }
-  };
-
-  sc_f32x4 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[mt][j] = sc_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
-  if (c_beg < c_end) {
-    load_chunk(c_beg);
-    store_chunk();
-  }
-  __syncthreads();
-  const int nc4 = g.CB >> 2;
-  for (int c = c_beg; c < c_end; ++c) {
-    const bool more = c + 1 < c_end;
-    if (more) load_chunk(c + 1);
-    for (int c4 = 0; c4 < nc4; ++c4)
-      for (int ky = 0; ky < K; ++ky) {
-        // one filter row: the operands of its K taps are all requested before the first MFMA
-        const int ab = (c4 * KK + ky * K) * 4 * g.WRS, bb = c4 * 4 * g.XCS + ky * g.XRS;
-        float a[K][MT], b[K][NT];
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) a[kx][mt] = lds[aoff[mt] + ab + kx * 4 * g.WRS];
-#pragma unroll
-          for (int j = 0; j < NT; ++j) b[kx][j] = lds[boff[j] + bb + ((kx + DX) & 1) * g.QW + ((kx + DX) >> 1)];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kx][mt], b[kx][j], acc[mt][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    __syncthreads();
-    if (more) {
-      store_chunk();
-      __syncthreads();
-    }
-  }
-
-  // ---- epilogue: bias + activation and y, or this split's partial sums
-  const bool direct = g.nsplit == 1;
-  const int nimg = g.ntile / (g.cpr * g.rpi);
-  float* ob = direct ? y + img * g.ybs : part + (static_cast<long>(split) * nimg + img) * g.Co * HWo;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = cob0 + (wm * MT + mt) * 16 + 4 * kq + r;
-      if (co >= g.Co) continue;
-      const float bv = (direct && bias) ? bias[co] : 0.0f;
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        if (opix[j] >= 0) {
-          float v = acc[mt][j][r];
-          if (direct) { v += bv; v = v > 0.0f ? v : v * g.slope; }
-          ob[static_cast<long>(co) * HWo + opix[j]] = v;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Data gradient of the stride-2 convolution: gx[ci][iy][ix] = sum_(co, ky, kx) w[co][ci][ky][kx] gy[co][(iy + P - ky) / 2][(ix + P - kx) / 2]
-// over the taps that divide evenly.  Input pixel (2u + py, 2v + px) only meets the taps with ky = (py + P) mod 2, kx = (px + P) mod 2:
-// four stride-1 correlations of gy with sub-filters, one per PHASE (py, px).  A block owns COB input channels x a tile of (u, v)
-// positions and keeps the four phases' accumulators; per group of four OUTPUT channels it reads the (2 x 2 for 3x3, 3 x 3 for 5x5)
-// shifted gy operands once and every tap's filter operand once: MFMA count = the forward's, no zero-stuffed work.  The filter slab
-// is k_sconv_pack<true>'s [co / 4][tap][co % 4][Ci]; gy is staged unsplit (stride 1).  1x1 (the ResNet down-sampling shortcuts,
-// depth_model.py:31-36): phase (0, 0) gets w^T gy, the three others zeros.
-struct ScDg {
-  long gbs, xbs;
-  int Ci, Co, H, W, Ho, Wo;        // gx is [Ci][H][W], gy [Co][Ho][Wo]
-  int TH, TW, RI, NSLOT, XRS, XCS;
-  int CB, nck, cps, nsplit;
-  int cpr, rpi, ntile, ncit;
-  int Cip, WRS, wl4;
-};
-
-template <int K, int MT, int NT, int WM, int WN, int XSH, int NXL, int NWL>
-__global__ void __launch_bounds__(256, 2)
-k_sconv_dgrad(const float* __restrict__ gy, const float* __restrict__ wp, float* __restrict__ gx, float* __restrict__ part, const ScDg g) {
-  constexpr int KK = K * K, P = K / 2, CIB = 16 * MT * WM;
-  // row shift of tap ky: gy row = u + (py + P - ky) / 2 with py = (ky + P) & 1; DMIN / ND: the smallest shift, the number of shifts
-  constexpr int DMIN = K == 5 ? -1 : 0, ND = K == 1 ? 1 : (K == 3 ? 2 : 3), DXA = ((DMIN % 4) + 4) % 4;
-  extern __shared__ float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i = lane & 15, kq = lane >> 4;
-  const int wm = wv / WN, wn = wv % WN;
-  const unsigned lid = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int cb_i = static_cast<int>(lid % static_cast<unsigned>(g.ncit));
-  const int tile = static_cast<int>((lid / static_cast<unsigned>(g.ncit)) % static_cast<unsigned>(g.ntile));
-  const int split = static_cast<int>(lid / (static_cast<unsigned>(g.ncit) * static_cast<unsigned>(g.ntile)));
-  const int cib0 = cb_i * CIB;
-  const int cx = tile % g.cpr, ry = (tile / g.cpr) % g.rpi, img = tile / g.cpr / g.rpi;
-  const int u0 = ry * g.TH, v0 = cx * g.TW;
-  const int c_beg = split * g.cps, c_end = min(g.nck, c_beg + g.cps);
-  const int gHW = g.Ho * g.Wo, HW = g.H * g.W;
-  const int XTOT = g.CB * g.XCS;
-
-  int boff[NT], pu[NT], pv[NT], aoff[MT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int p = (wn * NT + j) * 16 + i, ul = p / g.TW, vl = p - ul * g.TW;
-    const bool ok = ul < g.TH;
-    boff[j] = kq * g.XCS + (ok ? ul * g.XRS + vl : 0) + DXA;
-    pu[j] = ok ? u0 + ul : -1; pv[j] = v0 + vl;
-  }
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) aoff[mt] = XTOT + kq * g.WRS + (wm * MT + mt) * 16 + i;
-
-  constexpr int xncg = 256 >> XSH;
-  const int xpos = tid & ((1 << XSH) - 1), xcg = tid >> XSH;
-  const int xr_ = xpos / g.NSLOT, xs_ = xpos - xr_ * g.NSLOT;
-  const bool xact = xpos < g.RI * g.NSLOT;
-  const int xl0 = xcg * g.XCS + xr_ * g.XRS + 4 * xs_;
-  const int oy = u0 + DMIN + xr_, ox = v0 + DMIN - DXA + 4 * xs_;
-  const bool rowok = xact && oy >= 0 && oy < g.Ho;
-  const bool full = rowok && ox >= 0 && ox + 3 < g.Wo;
-  const bool cut = rowok && !full && ox + 3 >= 0 && ox < g.Wo;
-  const float* gb = gy + img * g.gbs;
-  constexpr int WQ = CIB / 4;
-  sc_f32x4 xr[NXL], wr[NWL];
-  auto load_chunk = [&](int c) {
-    const int off0 = (c * g.CB + xcg) * gHW + oy * g.Wo + ox;
-#pragma unroll
-    for (int jj = 0; jj < NXL; ++jj) {
-      const int ch = xcg + jj * xncg;
-      const bool ok = full && ch < g.CB && c * g.CB + ch < g.Co;
-      const ScQuadU u = *reinterpret_cast<const ScQuadU*>(gb + (ok ? off0 + jj * xncg * gHW : 0));
-      xr[jj] = sc_f32x4{ok ? u.a : 0.0f, ok ? u.b : 0.0f, ok ? u.c : 0.0f, ok ? u.d : 0.0f};
-    }
-    if (cut) {
-#pragma unroll
-      for (int jj = 0; jj < NXL; ++jj) {
-        const int ch = xcg + jj * xncg;
-        if (ch < g.CB && c * g.CB + ch < g.Co) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (ox + e >= 0 && ox + e < g.Wo) xr[jj][e] = gb[off0 + jj * xncg * gHW + e];
-        }
-      }
-    }
-    const float* wsrc = wp + static_cast<long>(c) * g.CB * KK * g.Cip + cib0;
-#pragma unroll
-    for (int jj = 0; jj < NWL; ++jj) {
-      const int e = tid + 256 * jj, row = e / WQ, q = e - row * WQ;
-      wr[jj] = e < g.wl4 ? *reinterpret_cast<const sc_f32x4*>(wsrc + static_cast<long>(row) * g.Cip + 4 * q) : sc_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    }
-  };
-  auto store_chunk = [&]() {
-    if (xact) {
-#pragma unroll
-      for (int jj = 0; jj < NXL; ++jj)
-        if (xcg + jj * xncg < g.CB) *reinterpret_cast<sc_f32x4*>(lds + xl0 + jj * xncg * g.XCS) = xr[jj];
-    }
-#pragma unroll
-    for (int jj = 0; jj < NWL; ++jj) {
-      const int e = tid + 256 * jj, row = e / WQ, q = e - row * WQ;
-      if (e < g.wl4) *reinterpret_cast<sc_f32x4*>(lds + XTOT + row * g.WRS + 4 * q) = wr[jj];
-    }
-  };
-
-  sc_f32x4 acc[2][2][MT][NT];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[a][b][mt][j] = sc_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
-  if (c_beg < c_end) {
-    load_chunk(c_beg);
-    store_chunk();
-  }
-  __syncthreads();
-  const int nc4 = g.CB >> 2;
-  for (int c = c_beg; c < c_end; ++c) {
-    const bool more = c + 1 < c_end;
-    if (more) load_chunk(c + 1);
-    for (int c4 = 0; c4 < nc4; ++c4) {
-      // the shifted gy operands of this channel group, then filter row by filter row
-      float b[ND][ND][NT];
-      const int bb = c4 * 4 * g.XCS;
-#pragma unroll
-      for (int dy = 0; dy < ND; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < ND; ++dx)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) b[dy][dx][j] = lds[boff[j] + bb + dy * g.XRS + dx];
-#pragma unroll
-      for (int ky = 0; ky < K; ++ky) {
-        constexpr int dummy = 0; (void)dummy;
-        const int py = (ky + P) & 1, dy = (py + P - ky) / 2 - DMIN;
-        float a[K][MT];
-        const int ab = (c4 * KK + ky * K) * 4 * g.WRS;
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) a[kx][mt] = lds[aoff[mt] + ab + kx * 4 * g.WRS];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-          const int px = (kx + P) & 1, dx = (px + P - kx) / 2 - DMIN;
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-              acc[py][px][mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kx][mt], b[dy][dx][j], acc[py][px][mt][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    __syncthreads();
-    if (more) {
-      store_chunk();
-      __syncthreads();
-    }
-  }
-
-  // ---- gx (or this split's partial sums): the two column phases of a position are neighbours
-  const int nimg = g.ntile / (g.cpr * g.rpi);
-  float* ob = g.nsplit == 1 ? gx + img * g.xbs : part + (static_cast<long>(split) * nimg + img) * g.Ci * HW;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ci = cib0 + (wm * MT + mt) * 16 + 4 * kq + r;
-      if (ci >= g.Ci) continue;
-      float* oc = ob + static_cast<long>(ci) * HW;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        if (pu[j] < 0) continue;
-#pragma unroll
-        for (int py = 0; py < 2; ++py) {
-          const int iy = 2 * pu[j] + py, ix = 2 * pv[j];
-          if (iy >= g.H || ix >= g.W) continue;
-          float* o = oc + iy * g.W + ix;
-          o[0] = acc[py][0][mt][j][r];
-          if (ix + 1 < g.W) o[1] = acc[py][1][mt][j][r];
-        }
-      }
-    }
-}
-
 }  // namespace dfe
 
 #define DFE_LAUNCH_CHECK() do { if (hipGetLastError() != hipSuccess) return DFE_ERR_LAUNCH; } while (0)
@@ -771,200 +392,5 @@ extern "C" int dfe_sconv_wgrad(const float* x, long x_batch_stride, const float*
   if (ns > 64) k_wgrad_sum<32><<<static_cast<unsigned>((n + 31) / 32), 1024, 0, st>>>(ws, gweight, ns, n);
   else k_wgrad_sum<8><<<static_cast<unsigned>((n + 31) / 32), 256, 0, st>>>(ws, gweight, ns, n);
   DFE_LAUNCH_CHECK();
-  return DFE_OK;
-}
-
-// ---- forward, host side
-namespace {
-int sc_pad16(int v) { return v + ((48 - (v & 31)) & 31); }      // the next stride with stride % 32 == 16
-
-struct ScFwCfg { int k, t32, cb, nwl; };      // the instantiations: filter size, 32- or 64-channel block, channels per chunk, filter words per thread
-
-bool sc_fw_plan(int B, int Ci, int Co, int H, int W, int K, ScFw* out, int* t32) {
-  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || (K != 3 && K != 5 && K != 7)) return false;
-  if (static_cast<long>(Ci) * H * W < 4) return false;
-  const int P = K / 2, DX = (4 - P % 4) % 4, KK = K * K;
-  ScFw g = {};
-  g.Ci = Ci; g.Co = Co; g.H = H; g.W = W;
-  g.Ho = (H + 2 * P - K) / 2 + 1; g.Wo = (W + 2 * P - K) / 2 + 1;
-  if (g.Ho < 1 || g.Wo < 1) return false;
-  *t32 = Co <= 32;
-  const int COB = *t32 ? 32 : 64, NPIX = 128;
-  const int cip = (Ci + 3) / 4 * 4;
-  g.CB = K == 3 ? std::min(8, cip) : 4;
-  g.nck = (cip + g.CB - 1) / g.CB;
-  g.Cop = (Co + 63) / 64 * 64;
-  g.WRS = COB + 16;
-  g.wl4 = g.CB * KK * COB / 4;
-  g.ncot = (Co + COB - 1) / COB;
-  // the pixel tile: TW (even: the staged window starts on a multiple of four columns) x TH <= 128 pixels whose window fits the 256
-  // staging positions and the LDS; the most useful pixels per tile
-  double best = 0.0;
-  for (int tw = std::min(64, (g.Wo + 1) / 2 * 2); tw >= 2; tw -= 2) {
-    const int th = std::min(NPIX / tw, g.Ho);
-    if (th < 1) continue;
-    const int ri = 2 * (th - 1) + K, nslot = (2 * (tw - 1) + K + DX + 3) / 4;
-    if (ri * nslot > 256) continue;
-    const int qw = 2 * nslot, xrs = 2 * qw, xcs = sc_pad16(ri * xrs);
-    if (sizeof(float) * (static_cast<size_t>(g.CB) * xcs + static_cast<size_t>(g.CB) * KK * g.WRS + 64) > 80 * 1024) continue;
-    const int cpr = (g.Wo + tw - 1) / tw, rpi = (g.Ho + th - 1) / th;
-    const double eff = static_cast<double>(g.Ho) * g.Wo / (static_cast<double>(cpr) * rpi * NPIX);
-    if (eff > best + 1e-9) { best = eff; g.TW = tw; g.TH = th; g.RI = ri; g.NSLOT = nslot; g.QW = qw; g.XRS = xrs; g.XCS = xcs; g.cpr = cpr; g.rpi = rpi; }
-  }
-  if (best == 0.0) return false;
-  const long nt = static_cast<long>(B) * g.cpr * g.rpi;
-  if (nt * g.ncot >= (1L << 24)) return false;
-  g.ntile = static_cast<int>(nt);
-  // thin layers: the channel chunks are split over blocks until there are two blocks per CU
-  const long blocks = nt * g.ncot;
-  long sp = blocks >= 384 ? 1 : std::min<long>(g.nck, (512 + blocks - 1) / blocks);
-  g.cps = static_cast<int>((g.nck + sp - 1) / sp);
-  g.nsplit = (g.nck + g.cps - 1) / g.cps;
-  *out = g;
-  return true;
-}
-
-long sc_fw_packed_floats(const ScFw& g, int K) { return static_cast<long>(g.nck) * g.CB * K * K * g.Cop + 64; }
-
-template <int K, int MT, int NT, int WM, int WN, int NXL, int NWL>
-void sc_fw_launch(const ScFw& g, const float* x, const float* wp, const float* bias, float* y, float* part, hipStream_t st) {
-  const size_t lds_bytes = sizeof(float) * (static_cast<size_t>(g.CB) * g.XCS + static_cast<size_t>(g.CB) * K * K * g.WRS + 64);
-  auto kern = k_sconv_fwd<K, MT, NT, WM, WN, 8, NXL, NWL>;
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_set = true; }
-  kern<<<static_cast<unsigned>(g.ntile) * g.ncot * g.nsplit, 256, lds_bytes, st>>>(x, wp, bias, y, part, g);
-}
-}  // namespace
-
-extern "C" long dfe_sconv_fwd_floats(int B, int Ci, int Co, int H, int W, int K) {
-  ScFw g; int t32;
-  if (!sc_fw_plan(B, Ci, Co, H, W, K, &g, &t32)) return 0;
-  return sc_fw_packed_floats(g, K) + (g.nsplit > 1 ? static_cast<long>(g.nsplit) * B * Co * g.Ho * g.Wo : 0);
-}
-
-extern "C" int dfe_sconv_fwd(const float* x, long x_batch_stride, const float* weight, const float* bias, float slope, float* y,
-                             long y_batch_stride, float* ws, int B, int Ci, int Co, int H, int W, int K, void* stream) {
-  if (!x || !weight || !y || !ws) return DFE_ERR_NULL;
-  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return DFE_ERR_DIMS;
-  ScFw g; int t32;
-  if (!sc_fw_plan(B, Ci, Co, H, W, K, &g, &t32)) return DFE_ERR_UNSUPPORTED;
-  const long oplane = static_cast<long>(g.Ho) * g.Wo;
-  if (x_batch_stride < static_cast<long>(Ci) * H * W || y_batch_stride < Co * oplane) return DFE_ERR_DIMS;
-  if (static_cast<long>(Ci) * H * W >= (1L << 30) || Co * oplane >= (1L << 30)) return DFE_ERR_DIMS;
-  if (reinterpret_cast<uintptr_t>(ws) % 16) return DFE_ERR_DIMS;
-  g.xbs = x_batch_stride; g.ybs = y_batch_stride; g.slope = slope;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int rows = g.nck * g.CB * K * K;
-  const long npk = static_cast<long>(rows) * g.Cop;
-  k_sconv_pack<false><<<static_cast<unsigned>((npk + 255) / 256), 256, 0, st>>>(weight, ws, Co, Ci, K * K, g.Cop, rows);
-  DFE_LAUNCH_CHECK();
-  float* part = ws + sc_fw_packed_floats(g, K);
-  if (K == 3 && !t32) sc_fw_launch<3, 2, 4, 2, 2, 8, 5>(g, x, ws, bias, y, part, st);
-  else if (K == 3) sc_fw_launch<3, 2, 2, 1, 4, 8, 3>(g, x, ws, bias, y, part, st);
-  else if (K == 5 && !t32) sc_fw_launch<5, 2, 4, 2, 2, 4, 7>(g, x, ws, bias, y, part, st);
-  else if (K == 5) sc_fw_launch<5, 2, 2, 1, 4, 4, 4>(g, x, ws, bias, y, part, st);
-  else if (!t32) sc_fw_launch<7, 2, 4, 2, 2, 4, 13>(g, x, ws, bias, y, part, st);
-  else sc_fw_launch<7, 2, 2, 1, 4, 4, 7>(g, x, ws, bias, y, part, st);
-  DFE_LAUNCH_CHECK();
-  if (g.nsplit > 1) {
-    const long per_img = Co * oplane, n = per_img * B;
-    k_sconv_sum<<<static_cast<unsigned>((n + 255) / 256), 256, 0, st>>>(part, y, y_batch_stride, per_img, n, g.nsplit, static_cast<int>(oplane), bias, slope);
-    DFE_LAUNCH_CHECK();
-  }
-  return DFE_OK;
-}
-
-// ---- data gradient, host side
-namespace {
-bool sc_dg_plan(int B, int Ci, int Co, int H, int W, int K, ScDg* out, int* t32) {
-  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || (K != 1 && K != 3 && K != 5)) return false;
-  const int P = K / 2, KK = K * K;
-  ScDg g = {};
-  g.Ci = Ci; g.Co = Co; g.H = H; g.W = W;
-  g.Ho = (H + 2 * P - K) / 2 + 1; g.Wo = (W + 2 * P - K) / 2 + 1;
-  if (g.Ho < 1 || g.Wo < 1 || static_cast<long>(Co) * g.Ho * g.Wo < 4) return false;
-  *t32 = Ci <= 32;
-  const int CIB = *t32 ? 32 : 64, NPIX = *t32 ? 128 : 64;
-  const int cop = (Co + 3) / 4 * 4;
-  g.CB = K == 5 ? std::min(8, cop) : std::min(16, cop);
-  g.nck = (cop + g.CB - 1) / g.CB;
-  g.Cip = (Ci + 63) / 64 * 64;
-  g.WRS = CIB + 16;
-  g.wl4 = g.CB * KK * CIB / 4;
-  g.ncit = (Ci + CIB - 1) / CIB;
-  const int dmin = K == 5 ? -1 : 0, nd = K == 1 ? 1 : (K == 3 ? 2 : 3), dxa = ((dmin % 4) + 4) % 4;
-  // positions (u, v) of the half-resolution grid whose phases the block writes: U x V = ceil(H / 2) x ceil(W / 2)
-  const int U = (H + 1) / 2, V = (W + 1) / 2;
-  double best = 0.0;
-  for (int tw = std::min(64, (V + 3) / 4 * 4); tw >= 4; tw -= 4) {
-    const int th = std::min(NPIX / tw, U);
-    if (th < 1) continue;
-    const int ri = th + nd - 1, nslot = (tw + nd - 1 + dxa + 3) / 4;
-    if (ri * nslot > 64) continue;
-    const int xrs = 4 * nslot, xcs = sc_pad16(ri * xrs);
-    if (sizeof(float) * (static_cast<size_t>(g.CB) * xcs + static_cast<size_t>(g.CB) * KK * g.WRS + 64) > 76 * 1024) continue;
-    const int cpr = (V + tw - 1) / tw, rpi = (U + th - 1) / th;
-    const double eff = static_cast<double>(U) * V / (static_cast<double>(cpr) * rpi * NPIX);
-    if (eff > best + 1e-9) { best = eff; g.TW = tw; g.TH = th; g.RI = ri; g.NSLOT = nslot; g.XRS = xrs; g.XCS = xcs; g.cpr = cpr; g.rpi = rpi; }
-  }
-  if (best == 0.0) return false;
-  const long nt = static_cast<long>(B) * g.cpr * g.rpi;
-  if (nt * g.ncit >= (1L << 24)) return false;
-  g.ntile = static_cast<int>(nt);
-  const long blocks = nt * g.ncit;
-  long sp = blocks >= 384 ? 1 : std::min<long>(g.nck, (512 + blocks - 1) / blocks);
-  g.cps = static_cast<int>((g.nck + sp - 1) / sp);
-  g.nsplit = (g.nck + g.cps - 1) / g.cps;
-  *out = g;
-  return true;
-}
-
-long sc_dg_packed_floats(const ScDg& g, int K) { return static_cast<long>(g.nck) * g.CB * K * K * g.Cip + 64; }
-
-template <int K, int MT, int NT, int WM, int WN, int NXL, int NWL>
-void sc_dg_launch(const ScDg& g, const float* gy, const float* wp, float* gx, float* part, hipStream_t st) {
-  const size_t lds_bytes = sizeof(float) * (static_cast<size_t>(g.CB) * g.XCS + static_cast<size_t>(g.CB) * K * K * g.WRS + 64);
-  auto kern = k_sconv_dgrad<K, MT, NT, WM, WN, 6, NXL, NWL>;
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_set = true; }
-  kern<<<static_cast<unsigned>(g.ntile) * g.ncit * g.nsplit, 256, lds_bytes, st>>>(gy, wp, gx, part, g);
-}
-}  // namespace
-
-extern "C" long dfe_sconv_dgrad_floats(int B, int Ci, int Co, int H, int W, int K) {
-  ScDg g; int t32;
-  if (!sc_dg_plan(B, Ci, Co, H, W, K, &g, &t32)) return 0;
-  return sc_dg_packed_floats(g, K) + (g.nsplit > 1 ? static_cast<long>(g.nsplit) * B * Ci * H * W : 0);
-}
-
-extern "C" int dfe_sconv_dgrad(const float* gy, long gy_batch_stride, const float* weight, float* gx, long gx_batch_stride, float* ws, int B,
-                               int Ci, int Co, int H, int W, int K, void* stream) {
-  if (!gy || !weight || !gx || !ws) return DFE_ERR_NULL;
-  if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return DFE_ERR_DIMS;
-  ScDg g; int t32;
-  if (!sc_dg_plan(B, Ci, Co, H, W, K, &g, &t32)) return DFE_ERR_UNSUPPORTED;
-  const long oplane = static_cast<long>(g.Ho) * g.Wo, iplane = static_cast<long>(H) * W;
-  if (gx_batch_stride < Ci * iplane || gy_batch_stride < Co * oplane) return DFE_ERR_DIMS;
-  if (Ci * iplane >= (1L << 30) || Co * oplane >= (1L << 30)) return DFE_ERR_DIMS;
-  if (reinterpret_cast<uintptr_t>(ws) % 16) return DFE_ERR_DIMS;
-  g.gbs = gy_batch_stride; g.xbs = gx_batch_stride;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int rows = g.nck * g.CB * K * K;
-  const long npk = static_cast<long>(rows) * g.Cip;
-  k_sconv_pack<true><<<static_cast<unsigned>((npk + 255) / 256), 256, 0, st>>>(weight, ws, Co, Ci, K * K, g.Cip, rows);
-  DFE_LAUNCH_CHECK();
-  float* part = ws + sc_dg_packed_floats(g, K);
-  if (K == 3 && !t32) sc_dg_launch<3, 2, 2, 2, 2, 4, 9>(g, gy, ws, gx, part, st);
-  else if (K == 3) sc_dg_launch<3, 2, 2, 1, 4, 4, 5>(g, gy, ws, gx, part, st);
-  else if (K == 5 && !t32) sc_dg_launch<5, 2, 2, 2, 2, 2, 13>(g, gy, ws, gx, part, st);
-  else if (K == 5) sc_dg_launch<5, 2, 2, 1, 4, 2, 7>(g, gy, ws, gx, part, st);
-  else if (!t32) sc_dg_launch<1, 2, 2, 2, 2, 4, 1>(g, gy, ws, gx, part, st);
-  else sc_dg_launch<1, 2, 2, 1, 4, 4, 1>(g, gy, ws, gx, part, st);
-  DFE_LAUNCH_CHECK();
-  if (g.nsplit > 1) {
-    const long per_img = Ci * iplane, n = per_img * B;
-    k_sconv_sum<<<static_cast<unsigned>((n + 255) / 256), 256, 0, st>>>(part, gx, gx_batch_stride, per_img, n, g.nsplit, static_cast<int>(iplane), nullptr, 1.0f);
-    DFE_LAUNCH_CHECK();
-  }
   return DFE_OK;
 }

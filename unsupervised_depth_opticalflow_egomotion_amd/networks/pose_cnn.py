@@ -38,8 +38,6 @@ class PoseCNN(nn.Module):
                 return ops.planeconv_act(x, conv.weight, conv.bias, 0.0)     # the 2x7 refinement planes: this build's MFMA kernels
             if ops.conv1x1_small_eligible(x, conv):
                 return ops.conv1x1_small(x, conv, 0.0)
-            if ops.conv_bias_act_eligible(x, conv):        # the 7x7 / 5x5 / 3x3 stride-2 layers: bias + ReLU inside dfe_sconv_fwd
-                return ops.conv_bias_act(x, conv, 0.0)
             return ops.bias_act(convs.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups),
                                 conv.bias, 0.0)
         return self.relu(conv(x))

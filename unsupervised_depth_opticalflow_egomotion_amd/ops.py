@@ -832,20 +832,17 @@ class ConvBiasActFn(torch.autograd.Function):
     bias gradient) + the convolution's data / weight gradients (convs.raw_backward)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, slope, padding, dilation, stride=1):
-        if stride == 2:      # the strided layers (feature_pyramid.py:7-36, pose_cnn.py:14-36): the epilogue inside dfe_sconv_fwd
-            y = sconv_fwd(x, w, bias, slope)
-        else:
-            y = wino_conv3x3(x, w, padding, dilation=dilation, bias=bias, slope=slope)
+    def forward(ctx, x, w, bias, slope, padding, dilation):
+        y = wino_conv3x3(x, w, padding, dilation=dilation, bias=bias, slope=slope)
         ctx.save_for_backward(x, w, y)
-        ctx.cfg = (float(slope), int(padding), int(dilation), bias is not None, int(stride))
+        ctx.cfg = (float(slope), int(padding), int(dilation), bias is not None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         lib = get_lib()
         x, w, y = ctx.saved_tensors
-        slope, P, d, has_bias, stride = ctx.cfg
+        slope, P, d, has_bias = ctx.cfg
         B, C, H, W = y.shape
         if gy.dtype != torch.float32:
             gy = gy.float()
@@ -859,23 +856,20 @@ class ConvBiasActFn(torch.autograd.Function):
         check(lib.dfe_bias_act_bwd(ptr(y), ptr(gy, strided=True), gy.stride(0), ptr(gz), ptr(gb), ptr(part), B, C, H, W, slope,
                                    stream_ptr()), "dfe_bias_act_bwd")
         pad = (d, d) if d > 1 else (P, P)
-        gx, gw, _ = convs.raw_backward(gz, x, w, (stride, stride), pad, (d, d), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return gx, gw, gb, None, None, None, None
+        gx, gw, _ = convs.raw_backward(gz, x, w, (1, 1), pad, (d, d), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return gx, gw, gb, None, None, None
 
 
 def conv_bias_act_eligible(x, conv):
     """A Conv2d whose forward the Winograd kernel runs (convs._wino_eligible: 3x3, stride 1, padding 1 or dilated with
-    padding = dilation, enough tiles and channels, fp32) or the strided kernel (convs._sconv_route: k x k, stride 2, padding k // 2)."""
-    if os.environ.get("DFE_WINO_EPILOGUE", "1") == "0" or conv.bias is None or conv.groups != 1:
-        return False
-    if convs._sconv_route(x, conv.weight.shape, conv.stride, conv.padding, conv.dilation, conv.groups):
-        return conv.in_channels <= convs.SCONV_MAX_CI and sconv_fwd_supported(x.shape, conv.out_channels, conv.kernel_size[0])
-    return (convs._wino_eligible(x, conv.weight.shape, conv.in_channels, conv.stride, conv.padding, conv.dilation, conv.groups)
+    padding = dilation, enough tiles and channels, fp32)."""
+    return (os.environ.get("DFE_WINO_EPILOGUE", "1") != "0" and conv.bias is not None and conv.groups == 1
+            and convs._wino_eligible(x, conv.weight.shape, conv.in_channels, conv.stride, conv.padding, conv.dilation, conv.groups)
             and conv.padding == ((1, 1) if conv.dilation == (1, 1) else conv.dilation))
 
 
 def conv_bias_act(x, conv, slope):
-    return ConvBiasActFn.apply(x, conv.weight, conv.bias, float(slope), int(conv.padding[0]), int(conv.dilation[0]), int(conv.stride[0]))
+    return ConvBiasActFn.apply(x, conv.weight, conv.bias, float(slope), int(conv.padding[0]), int(conv.dilation[0]))
 
 
 def phase_images(t, d):
@@ -940,54 +934,6 @@ def sconv_wgrad(x, gy, k, stride, padding):
     check(lib.dfe_sconv_wgrad(ptr(x, strided=True), x.stride(0), ptr(gy, strided=True), gy.stride(0), ptr(gw), ptr(ws), B, Ci, Co, H, W, k, s, P,
                               stream_ptr()), "dfe_sconv_wgrad")
     return gw
-
-
-def sconv_fwd_supported(x_shape, co, k):
-    B, Ci, H, W = (int(v) for v in x_shape)
-    return get_lib().dfe_sconv_fwd_floats(B, Ci, int(co), H, W, int(k)) > 0
-
-
-def sconv_fwd(x, w, bias=None, slope=1.0, out=None):
-    """act(conv2d(x, w, stride 2, padding k // 2) + bias) for k in {3, 5, 7} on dfe_sconv_fwd (fp32 MFMA straight from NCHW;
-    depth_model.py:60-95, feature_pyramid.py:7-36, pose_cnn.py:14-36).  slope: 1 none, 0 ReLU, 0.1 LeakyReLU."""
-    x = x if _dense_chw(x) else f32c(x)
-    w = f32c(w)
-    B, Ci, H, W = x.shape
-    Co, k = int(w.shape[0]), int(w.shape[2])
-    lib = get_lib()
-    n = lib.dfe_sconv_fwd_floats(B, Ci, Co, H, W, k)
-    if n <= 0 or w.shape[1] != Ci or w.shape[3] != k:
-        raise _lib.DfeError("dfe_sconv_fwd: unsupported layer %s * %s" % (tuple(x.shape), tuple(w.shape)))
-    P = k // 2
-    Ho, Wo = (H + 2 * P - k) // 2 + 1, (W + 2 * P - k) // 2 + 1
-    y = out if out is not None else torch.empty(B, Co, Ho, Wo, device=x.device, dtype=torch.float32)
-    ws = torch.empty(n, device=x.device, dtype=torch.float32)
-    check(lib.dfe_sconv_fwd(ptr(x, strided=True), x.stride(0), ptr(w), None if bias is None else ptr(f32c(bias)), float(slope), ptr(y, strided=True),
-                            y.stride(0), ptr(ws), B, Ci, Co, H, W, k, stream_ptr()), "dfe_sconv_fwd")
-    return y
-
-
-def sconv_dgrad_supported(x_shape, co, k):
-    B, Ci, H, W = (int(v) for v in x_shape)
-    return get_lib().dfe_sconv_dgrad_floats(B, Ci, int(co), H, W, int(k)) > 0
-
-
-def sconv_dgrad(gy, w, x_shape):
-    """Data gradient [B,Ci,H,W] of conv2d(x, w, stride 2, padding k // 2), k in {1, 3, 5}, for gy, on dfe_sconv_dgrad."""
-    gy = gy if _dense_chw(gy) else f32c(gy)
-    w = f32c(w)
-    B, Ci, H, W = (int(v) for v in x_shape)
-    Co, k = int(w.shape[0]), int(w.shape[2])
-    lib = get_lib()
-    n = lib.dfe_sconv_dgrad_floats(B, Ci, Co, H, W, k)
-    P = k // 2
-    if n <= 0 or w.shape[1] != Ci or tuple(gy.shape) != (B, Co, (H + 2 * P - k) // 2 + 1, (W + 2 * P - k) // 2 + 1):
-        raise _lib.DfeError("dfe_sconv_dgrad: unsupported layer gy %s * %s -> %s" % (tuple(gy.shape), tuple(w.shape), tuple(x_shape)))
-    gx = torch.empty(B, Ci, H, W, device=gy.device, dtype=torch.float32)
-    ws = torch.empty(n, device=gy.device, dtype=torch.float32)
-    check(lib.dfe_sconv_dgrad(ptr(gy, strided=True), gy.stride(0), ptr(w), ptr(gx), gx.stride(0), ptr(ws), B, Ci, Co, H, W, k, stream_ptr()),
-          "dfe_sconv_dgrad")
-    return gx
 
 
 class PlaneConvActFn(torch.autograd.Function):
