@@ -18,6 +18,7 @@ for b in 1 2; do timeout 600 python bench.py --batch $b --no-cpu-baseline 2>/dev
 python tools/instep_roofline.py $out/r05_bench_line.json > $out/r05_instep_roofline.md
 # A/B of the round's switches in the step (alternating, same box)
 for i in 1 2; do for v in 0 1; do DFE_WINO_WGRAD=$v timeout 600 python bench.py --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('DFE_WINO_WGRAD=$v', d['ms_per_step'])"; done; done > $out/r05_wgrad_step_ab.txt 2>&1; cat $out/r05_wgrad_step_ab.txt
+for i in 1 2; do for v in 0 1; do DFE_SCONV=$v timeout 600 python bench.py --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('DFE_SCONV=$v', d['ms_per_step'])"; done; done > $out/r05_sconv_step_ab.txt 2>&1; cat $out/r05_sconv_step_ab.txt
 # steady-state kernel trace of the train step
 timeout 600 python bench.py --steps 2 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
 rm -rf /tmp/prof_ts
@@ -28,8 +29,11 @@ python tools/stream_kernels.py $t 4 45 15 > $out/r05_stream_kernels.txt; python 
 # the convolution kernels of this build against MIOpen + what their waves wait for
 python tools/wgrad_bench.py --iters 20 > $out/r05_wgrad_bench.md 2>&1
 python tools/wino_bench.py > $out/r05_wino_bench.md 2>&1
+python tools/sconv_bench.py > $out/r05_sconv_bench.md 2>&1
 bash tools/pmc_wino.sh r05
 ./tools/ubench/mfma_loop > $out/r05_mfma_loop.txt 2>&1
+./tools/ubench/mfma_chain > $out/r05_mfma_chain.txt 2>&1
+./tools/ubench/mfma_feed > $out/r05_mfma_feed.txt 2>&1
 # PWC-side kernels: algorithmic-byte table
 python tools/corr_bench.py --check > $out/r05_pwc_roofline_table.md 2>&1
 ls $out | grep r05 | tr '\n' ' '

@@ -187,17 +187,22 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
   float dn[16];                       // PAIR: dn[2 i], dn[2 i + 1] = the own pair of row i; dn[8 + 2 i], dn[9 + 2 i] = an edge lane's L / R pair
   unsigned mn;
 
+  // issue(c) is called with c = cbeg + kq, cbeg + kq + 4, ...: the channel's byte offset is kept incrementally (a per-lane 32-bit
+  // multiply is a quarter-rate instruction, and every vector instruction beside the fp32 MFMAs costs its full issue time:
+  // profiles/r05_mfma_feed.txt)
+  unsigned cbl = 4u * static_cast<unsigned>(cbeg + kq) * HW;
+  const unsigned cstep = 16u * static_cast<unsigned>(HW);
   auto issue = [&](int c) {
-    mn = c < Cend ? inb : 0u;
-    const unsigned cb = 4u * static_cast<unsigned>(c < Cend ? c : 0) * HW;
+    const bool cok = c < Cend;
+    mn = cok ? inb : 0u;
+    const unsigned cb = cok ? cbl : 0u;
+    cbl += cstep;
     if (PAIR) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const f32x2 p = *reinterpret_cast<const f32x2*>(xc + (off[i] + cb));
         dn[2 * i] = p[0]; dn[2 * i + 1] = p[1];
       }
-#pragma unroll
-      for (int i = 8; i < 16; ++i) dn[i] = 0.0f;      // defined on every lane (the selects below must not see an undefined value)
       if (edge_l || edge_r) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -262,6 +267,9 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
       for (int q = 0; q < 16; ++q) d[q] = ((mn >> q) & 1u) ? dn[q] : 0.0f;
     }
   };
+#pragma unroll
+  for (int i = 8; i < 16; ++i) dn[i] = 0.0f;      // the edge pairs: defined on every lane (the selects must not see an undefined value),
+                                                  // once -- only the edge lanes ever write them again
   issue(cbeg + kq);
   // weight slabs of 8 input channels, double-buffered: slab i + 1 travels global -> registers under the two steps of slab i
   // and is written to the other LDS buffer before the chunk's single barrier
