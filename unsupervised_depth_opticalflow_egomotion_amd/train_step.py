@@ -120,6 +120,11 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.outputs = train_step(model, optimizer, self.static_inputs, cfg)
+        # The captured filter refresh (ops.WinoWeightCache.refresh inside optimizer.step) reads the cache's device tables of THIS
+        # moment; the cache replaces them when another model registers filters.  Hold them: a replay must never read freed memory
+        # (found by the eager-twin test: the twin's registration freed the table, the next replay scattered filters through it).
+        from . import ops
+        self._cache_tables = (ops.wino_weights.table, ops.wino_weights.blockmap)
 
     def __call__(self, inputs=None):
         if inputs is not None:
