@@ -85,6 +85,16 @@ def test_error_strings_and_argument_checks_without_gpu():
     assert lib.dfe_wino_wgrad3x3(P, 4 * 8 * 8, None, 0, P, P, 1, 4, 4, 8, 8, 1, None) == -1
     assert lib.dfe_wino_wgrad3x3(P, 4 * 8 * 8, P, 4 * 8 * 8, P, P, 1, 4, 4, 8, 8, 2, None) == -4 and lib.dfe_wino_wgrad_floats(1, 4, 4, 8, 8, 1) > 0
     assert lib.dfe_wino_conv3x3_u_act(P, None, None, 1.0, P, 4 * 8 * 8, None, 0, None, 0, 1, 4, 4, 8, 8, 1, 1, None) == -1
+    # strided weight gradient (csrc/ops_sconv.hip): the planner runs on the host
+    assert lib.dfe_sconv_wgrad_floats(12, 3, 64, 256, 832, 7, 2, 3) == 768 * 64 * 3 * 49          # one round of three blocks per CU, one slab
+    assert lib.dfe_sconv_wgrad_floats(4, 9, 16, 256, 832, 7, 2, 3) > 0 and lib.dfe_sconv_wgrad_floats(4, 16, 32, 128, 416, 5, 2, 2) > 0
+    assert lib.dfe_sconv_wgrad_floats(12, 16, 32, 128, 416, 3, 2, 1) > 0 and lib.dfe_sconv_wgrad_floats(1, 20, 40, 9, 9, 3, 1, 1) > 0
+    assert lib.dfe_sconv_wgrad_floats(1, 64, 64, 16, 16, 5, 2, 2) == 0 and lib.dfe_sconv_wgrad_floats(1, 8, 8, 16, 16, 3, 3, 1) == 0
+    assert lib.dfe_sconv_wgrad_floats(1, 8, 8, 16, 16, 8, 2, 4) == 0 and lib.dfe_sconv_wgrad_floats(0, 8, 8, 16, 16, 3, 2, 1) == 0
+    assert lib.dfe_sconv_wgrad(P, 4 * 8 * 8, None, 0, P, P, 1, 4, 4, 8, 8, 3, 2, 1, None) == -1
+    assert lib.dfe_sconv_wgrad(P, 4 * 8 * 8, P, 4 * 4 * 4, P, P, 1, 4, 4, 8, 8, 9, 2, 4, None) == -4
+    assert lib.dfe_sconv_wgrad(P, 1, P, 4 * 4 * 4, P, P, 1, 4, 4, 8, 8, 3, 2, 1, None) == -2                # batch stride smaller than a sample
+    assert lib.dfe_sconv_tune(0, 0) == 0
     # transformed filters kept across calls: blocks per filter, argument checks
     assert lib.dfe_wino_transform_blocks(64, 64) == 16 and lib.dfe_wino_transform_blocks(5, 33) == 2 and lib.dfe_wino_transform_blocks(0, 3) == 0
     assert lib.dfe_wino_transform_weights_multi(None, P, 4, None) == -1 and lib.dfe_wino_transform_weights_multi(P, P, 0, None) == -2
