@@ -421,7 +421,7 @@ def multi_gpu_evidence(wl, world, rank, dev, dt_local, args):
     dist.all_gather(times, torch.tensor([1e3 * dt_local / args.steps], device=dev, dtype=torch.float64))
     times = [float(t.item()) for t in times]
     ev = {"data_parallel": type(model).__name__ if model is not None else None, "backend": dist.get_backend(), "collective_library": "RCCL" if dist.get_backend() == "nccl" else dist.get_backend(),
-          "rccl_ranks": int(ids[1].item()), "rank_id_allreduce_ok": bool(ids_ok),
+          "ranks": int(ids[1].item()), "rank_id_allreduce_ok": bool(ids_ok),
           "ms_per_step_min": round(min(times), 4), "ms_per_step_max": round(max(times), 4),
           "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE")}
     if hasattr(model, "message_bytes"):      # ddp.FlatAllReduce: one message per network branch, issued from backward

@@ -30,7 +30,10 @@ extern "C" {
 #define DFE_ERR_WORKSPACE (-5)   /* workspace too small */
 
 #define DFE_MAX_SCALES 8
-#define DFE_ABI_VERSION 1
+/* Bumped whenever an exported signature changes or an entry point is removed (2: round 5 changed dfe_wino_wgrad3x3 and
+ * removed dfe_thin_conv3x3 / dfe_cast_*; later values: see the comments of the entry points).  _lib.py compares the
+ * library's value with this header's. */
+#define DFE_ABI_VERSION 2
 
 int dfe_abi_version(void);
 const char* dfe_error_string(int code);

@@ -654,6 +654,46 @@ GENERATORS = dict(G1=gen_g1, G2=gen_g2, G3=gen_g3, G4=gen_g4, G5=gen_g5, G6=gen_
 AC_INDEPENDENT = {"G3", "G4", "G10"}   # no grid_sample inside (G11: register_depth samples with grid_sample)
 
 
+# ------------------------------------------------------------------------------------ G12
+def g12_inputs():
+    """Inputs for the legacy signatures of inverse_warp.py (:30-107,148-224): first-generation warp, quaternion poses."""
+    r = rng(1212)
+    b, h, w = 2, 24, 40
+    img = r.random((b, 3, h, w)).astype(np.float32)
+    depth = (0.3 + 0.7 * r.random((b, h, w))).astype(np.float32)
+    pose = synthetic.robust_pose((0.04 * r.standard_normal((b, 6))).astype(np.float32))
+    pose[:, 0] += 0.05
+    wgt = r.standard_normal((b, 3, h, w)).astype(np.float32)
+    return dict(img=img, depth=depth, pose=pose, K=kmat(b, h, w), wgt=wgt)
+
+
+def gen_g12(ref, out):
+    iw = ref["iw"]
+    c = g12_inputs()
+    K = T(c["K"])
+    out["quat2mat"] = N(iw.quat2mat(T(c["pose"])[:, 3:]))
+    out["pose_mat_quat"] = N(iw.pose_vec2mat(T(c["pose"]), "quat"))
+    iw.pixel_coords = None
+    cam = iw.pixel2cam(T(c["depth"]), K.inverse())
+    out["pixel2cam"] = N(cam)
+    proj = K @ iw.pose_vec2mat(T(c["pose"]))
+    out["cam2pixel"] = N(iw.cam2pixel(cam, proj[:, :, :3], proj[:, :, -1:]))
+    out["cam2pixel_change_shape"] = N(iw.cam2pixel_change_shape(cam, proj[:, :, :3], proj[:, :, -1:]))
+    g2, z2 = iw.cam2pixel2(cam, proj[:, :, :3], proj[:, :, -1:], "zeros")
+    out["cam2pixel2_grid"], out["cam2pixel2_z"] = N(g2), N(z2)
+    out["skew"] = N(iw.skewsymmetric(T(c["pose"])[:, :3].to("cpu")))
+    out["meshgrid"] = N(iw.meshgrid(5, 7))
+    for mode in ("euler", "quat"):
+        d, p = T(c["depth"], True), T(c["pose"], True)
+        y, valid = iw.inverse_warp(T(c["img"]), d, p, K, rotation_mode=mode)
+        (y * T(c["wgt"])).sum().backward()
+        out["iw_%s_img" % mode], out["iw_%s_valid" % mode] = N(y), packmask(valid.float())
+        out["iw_%s_gdepth" % mode], out["iw_%s_gpose" % mode] = N(d.grad), N(p.grad)
+
+
+GENERATORS["G12"] = gen_g12
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")

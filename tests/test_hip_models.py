@@ -540,7 +540,7 @@ def test_graphed_train_step_matches_the_eager_step():
     torch.manual_seed(0)
     model = get_model("geom")(cfg).to(dev()).train()
     opt = make_optimizer(model, lr, capturable=True)
-    g = GraphedTrainStep(model, opt, batches[0], cfg, warmup=3)          # 3 eager steps, then the capture (which runs nothing)
+    g = GraphedTrainStep(model, opt, batches[0], cfg, warmup=3, restore=False)   # 3 eager steps that TRAIN, then the capture (which runs nothing)
     try:      # the graph is destroyed HERE, failing or not: a hipGraph that a failed test's traceback keeps alive until the
               # interpreter exits is torn down after the HIP runtime (one full-suite run ended in a core dump that way)
         torch.cuda.synchronize()
@@ -570,6 +570,63 @@ def test_graphed_train_step_matches_the_eager_step():
             fracs.append(float(((d_g - d_e).abs()[sure] <= 0.02 * lr).float().mean()))
         print("\ngraph test: losses replayed %s eager %s; updates agreeing to 2%% of lr: %s" % (l_g, l_e, fracs))
         assert fracs[0] >= 0.999 and fracs[1] >= 0.99, fracs                  # measured 0.99998 .. 1.0 / 0.997 .. 1.0 (the second step starts from the first's noise)
+    finally:
+        del g
+        torch.cuda.synchronize()
+
+
+def test_graphed_train_step_construction_trains_nothing_and_guards_its_capture():
+    """(1) building a GraphedTrainStep leaves parameters, BatchNorm buffers and Adam's state where they were (the
+    warm-up steps are undone in place), so the first replay is optimiser step 1 on that batch and equals an eager first step
+    from the same state; (2) eager optimiser steps after the capture do not leak their gradient pointers into the next replay
+    (the captured table copy reads a pinned buffer of its own); (3) a changed lr or a load_state_dict after the capture is
+    refused instead of being silently ignored."""
+    import copy
+    from unsupervised_depth_opticalflow_egomotion_amd.train_step import GraphedTrainStep, make_cfg, make_optimizer, train_step
+    from unsupervised_depth_opticalflow_egomotion_amd.models import get_model
+    cfg, lr = make_cfg(mode="depth"), 1e-3
+    batches = [[torch.from_numpy(a).to(dev()) for a in synthetic.make_triplet_batch(1, 256, 832, 3, seed=s)] for s in (3, 4)]
+    flat = lambda m: torch.cat([t.detach().flatten() for t in list(m.parameters()) + list(m.buffers())]).clone()
+    torch.manual_seed(0)
+    model = get_model("depth")(cfg).to(dev()).train()
+    opt = make_optimizer(model, lr, capturable=True)
+    before = flat(model)
+    init_m = copy.deepcopy(model.state_dict())
+    g = GraphedTrainStep(model, opt, batches[0], cfg, warmup=2)
+    try:
+        torch.cuda.synchronize()
+        assert torch.equal(flat(model), before)
+        sd = opt.state_dict()
+        assert all(float(v["step"]) == 0.0 and float(v["exp_avg"].abs().max()) == 0.0 and float(v["exp_avg_sq"].abs().max()) == 0.0
+                   for v in sd["state"].values())
+        twin = get_model("depth")(cfg).to(dev()).train()
+        twin.load_state_dict(init_m)
+        opt_t = make_optimizer(twin, lr)
+        l_g = float(g(batches[0])[0].detach())
+        l_e = float(train_step(twin, opt_t, batches[0], cfg)[0].detach())
+        torch.cuda.synchronize()
+        assert abs(l_g - l_e) <= 1e-5 * abs(l_e), (l_g, l_e)
+        assert float(opt.state_dict()["state"][0]["step"]) == 1.0
+        d_g, d_e = flat(model) - before, flat(twin) - before
+        sure = d_e.abs() > 0.5 * lr
+        assert float(((d_g - d_e).abs()[sure] <= 0.02 * lr).float().mean()) >= 0.999
+        # (2) five eager steps cycle the whole pinned ring; the next replay must still update from ITS gradients
+        for _ in range(5):
+            train_step(model, opt, batches[1], cfg)
+        torch.cuda.synchronize()
+        mid = flat(model)
+        l2 = float(g(batches[0])[0].detach())
+        torch.cuda.synchronize()
+        moved = (flat(model) - mid).abs()
+        assert np.isfinite(l2) and float(moved.max()) <= 1.5 * lr and float((moved > 0).float().mean()) > 0.5
+        # (3)
+        opt.param_groups[0]["lr"] = lr / 2
+        with pytest.raises(RuntimeError, match="lr / betas / eps"):
+            g()
+        opt.param_groups[0]["lr"] = lr
+        opt.load_state_dict(copy.deepcopy(opt.state_dict()))
+        with pytest.raises(RuntimeError, match="load_state_dict"):
+            g()
     finally:
         del g
         torch.cuda.synchronize()
@@ -619,7 +676,7 @@ def test_bench_two_ranks_on_one_gpu(mode):
     assert j["value"] > 0 and "roofline" in j and "cpu_baseline" not in j   # CPU baseline only at N=1
     # the N > 1 line carries its own evidence that the replicas exchanged gradients (bench.multi_gpu_evidence)
     mg = j["multi_gpu"]
-    assert mg["backend"] == "gloo" and mg["rccl_ranks"] == 2 and mg["rank_id_allreduce_ok"] is True
+    assert mg["backend"] == "gloo" and mg["ranks"] == 2 and mg["rank_id_allreduce_ok"] is True
     assert mg["param_checksums_equal"] is True and mg["shards_differ"] is True
     assert 0 < mg["ms_per_step_min"] <= mg["ms_per_step_max"] <= j["ms_per_step"] * 1.001 + 1e-6
 
@@ -733,7 +790,7 @@ def test_bench_force_ddp_prints_the_multi_gpu_block_on_one_gpu():
                                     "--batch", "2", "--no-cpu-baseline"], capture_output=True, text=True, cwd=repo, env=clean, timeout=900))
     mg = j["multi_gpu"]
     assert j["n_gpus"] == 1 and mg["data_parallel"] == "FlatAllReduce" and mg["backend"] == "nccl" and mg["collective_library"] == "RCCL"
-    assert mg["rccl_ranks"] == 1 and mg["rank_id_allreduce_ok"] is True and mg["param_checksums_equal"] is True
+    assert mg["ranks"] == 1 and mg["rank_id_allreduce_ok"] is True and mg["param_checksums_equal"] is True
     assert set(mg["allreduce_message_bytes"]) == {"depth_net", "pose_net", "flow"} and mg["messages_issued_from_backward"] >= 3
 
 
@@ -748,7 +805,7 @@ def test_bench_gpus_flag_launches_the_ranks_itself():
     j = _bench_json(subprocess.run(base + ["--gpus", "2", "--backend", "gloo"], capture_output=True, text=True, cwd=repo,
                                    env=dict(clean, DFE_BENCH_ALL_ON_DEVICE0="1"), timeout=900))
     assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2"
-    assert j["multi_gpu"]["rccl_ranks"] == 2 and j["multi_gpu"]["param_checksums_equal"] is True
+    assert j["multi_gpu"]["ranks"] == 2 and j["multi_gpu"]["param_checksums_equal"] is True
     # under a profiler preload the GPU is already initialised in this process: it must not start ranks
     out = subprocess.run(base + ["--gpus", "2", "--backend", "gloo"], capture_output=True, text=True, cwd=repo,
                          env=dict(clean, DFE_BENCH_ALL_ON_DEVICE0="1", LD_PRELOAD="/nonexistent/librocprofiler-sdk-tool.so"), timeout=300)   # ld.so warns and carries on

@@ -920,3 +920,33 @@ def test_thin_conv_function_and_eligibility():
         gclose(res[0][2], res[1][2], rel=2e-4, atol=1e-9)
 
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ac", [False, True])
+def test_legacy_inverse_warp_euler_golden(golden_dir, ac):
+    """The first-generation ``inverse_warp`` (inverse_warp.py:190-224) in Euler mode = rigid flow + bilinear warp on the HIP
+    operators, against golden G12 (the reference's function): image 2e-5, validity equal away from the +-1 border (the
+    reference thresholds 2U/(w-1)-1, the composition (U-x)+x: decisions within 1e-5 of the border may differ), gradients
+    1e-4 of scale."""
+    import os
+    from tests.golden import make_golden as MG
+    from unsupervised_depth_opticalflow_egomotion_amd.structures import inverse_warp as iw
+    g = np.load(os.path.join(golden_dir, "G12_ac%d.npz" % ac))
+    c = MG.g12_inputs()
+    dev = torch.device("cuda:0")
+    T = lambda a, grad=False: torch.from_numpy(np.ascontiguousarray(a)).float().to(dev).requires_grad_(grad)   # noqa: E731
+    d, p = T(c["depth"], True), T(c["pose"], True)
+    y, valid = iw.inverse_warp(T(c["img"]), d, p, T(c["K"]), rotation_mode="euler", align_corners=ac)
+    (y * T(c["wgt"])).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["iw_euler_img"], rtol=0, atol=2e-5)
+    want = np.unpackbits(g["iw_euler_valid"])[:valid.numel()].reshape(valid.shape).astype(bool)
+    grid = np.abs(g["cam2pixel"]).max(-1)
+    safe = np.abs(grid - 1.0) > 1e-5
+    assert valid.dtype == torch.bool and np.array_equal(valid.cpu().numpy()[safe], want[safe]) and safe.mean() > 0.99
+    for mine, key in ((d.grad, "iw_euler_gdepth"), (p.grad, "iw_euler_gpose")):
+        np.testing.assert_allclose(mine.cpu().numpy(), g[key], rtol=1e-4, atol=1e-4 * np.abs(g[key]).max())
+    # quaternion mode on the device (tensor expressions + grid_sample)
+    d2, p2 = T(c["depth"], True), T(c["pose"], True)
+    y2, v2 = iw.inverse_warp(T(c["img"]), d2, p2, T(c["K"]), rotation_mode="quat", align_corners=ac)
+    np.testing.assert_allclose(y2.detach().cpu().numpy(), g["iw_quat_img"], rtol=0, atol=2e-5)

@@ -135,6 +135,13 @@ def header_symbols(path: str = HEADER_PATH):
     return sorted(set(re.findall(r"\b(dfe_[a-z0-9_]+)\s*\(", text)))
 
 
+def header_abi_version(path: str = HEADER_PATH) -> int:
+    """``DFE_ABI_VERSION`` as include/dfe_hip.h states it: bumped whenever an exported signature changes or disappears, so a
+    stale libdfe_hip.so is refused at load time instead of being called with shifted arguments."""
+    with open(path) as fh:
+        return int(re.search(r"#define\s+DFE_ABI_VERSION\s+(\d+)", fh.read()).group(1))
+
+
 def get_lib():
     """Load libdfe_hip.so once; raise loudly when it has not been built."""
     global _lib
@@ -152,8 +159,9 @@ def get_lib():
                 if name in _SIGNATURES:
                     fn.argtypes = _SIGNATURES[name]
                 fn.restype = _RESTYPES.get(name, ctypes.c_int)
-            if lib.dfe_abi_version() != 1:
-                raise DfeError("libdfe_hip.so ABI version mismatch")
+            if lib.dfe_abi_version() != header_abi_version():
+                raise DfeError("libdfe_hip.so ABI version %d != include/dfe_hip.h's DFE_ABI_VERSION %d: a stale build; "
+                               "rebuild with __graft_entry__.build()" % (lib.dfe_abi_version(), header_abi_version()))
             _lib = lib
     return _lib
 

@@ -82,11 +82,18 @@ class FlatAllReduce(torch.nn.Module):
     ring runs under the other branches' backward kernels.  ``reduce_gradients`` (hooked in front of ``optimizer.step()`` by
     ``make_optimizer``; the reference's loop, train.py:215-216, needs no extra call) only waits for the three messages;
     whatever was not issued by then (first step, a branch without gradients) is reduced there.  At 8 GPUs only the branch
-    that finishes last stays exposed.  Safety nets: the collectives are always issued in ONE fixed branch order on every
-    rank; a gradient that changes after its branch was reduced (a second backward pass, late accumulation) is detected by
-    identity + version and the branch is reduced again; every segment carries a presence word per parameter, so ranks
-    whose sets of parameters with gradients differ neither hang nor diverge (a parameter with a gradient on ANY rank gets
-    the averaged gradient on EVERY rank, as with DistributedDataParallel; one without a gradient anywhere keeps ``None``).
+    that finishes last stays exposed.  Safety nets: the collectives are always issued in ONE branch order on every rank --
+    the static module order until the ranks have AGREED on a calibrated one (round 6: ``_agree``, one 8-byte-per-branch
+    collective per step while calibrating, none afterwards: the triggers are armed only once EVERY rank has seen a first
+    backward pass that produced every branch's gradients, and the order every rank then uses is rank 0's; a rank whose
+    first steps lack a branch keeps the whole job in calibration, it does not make the ranks issue differently sized
+    messages in different orders); a gradient that changes after its branch was reduced (a second backward pass, late
+    accumulation, a backward pass after a skipped optimiser step) is detected -- the branch's trigger fires again, or
+    identity + version differ -- and the branch is reduced again; every segment carries a presence word per parameter, so
+    ranks whose sets of parameters with gradients differ neither hang nor diverge (a parameter with a gradient on ANY rank
+    gets the averaged gradient on EVERY rank, as with DistributedDataParallel; one without a gradient anywhere keeps
+    ``None``).  What the ranks must share is the PROGRAM (the same number of backward passes per step), as with
+    DistributedDataParallel.
 
     The never-used ``fc`` parameters are left out (no gradient ever exists for them).  Parameters and buffers start from
     rank 0's values (one coalesced broadcast at construction); BatchNorm's running statistics are NOT re-broadcast every
@@ -119,6 +126,8 @@ class FlatAllReduce(torch.nn.Module):
         self._arrival = []               # calibration (first backward): parameter indices in arrival order
         self._hooks = []
         self._ready, self._issued, self._work, self._sig = set(), [], {}, {}
+        self._dirty, self._events = set(), {}
+        self.calibration_steps = 0       # reduce_gradients calls spent agreeing on the order (statistics / tests)
         self.early_hits = 0              # branches whose all-reduce was issued from backward (statistics / tests)
         if self.overlap:
             for i, p in enumerate(self._params):
@@ -160,6 +169,9 @@ class FlatAllReduce(torch.nn.Module):
         grads = [self._params[i].grad for i in idx]
         ref = next((g for g in grads if g is not None), self._params[idx[0]])
         flat, views = self._buffers_for(ref)
+        ev = self._events.pop(k, None)
+        if ev is not None:      # issued from ANOTHER branch's hook (it was blocked by the fixed order): this stream has not
+            torch.cuda.current_stream().wait_event(ev)      # waited for the one that produced branch k's gradients
         have = [j for j, g in enumerate(grads) if g is not None]
         if len(have) == len(idx):
             torch._foreach_copy_([views[i] for i in idx], grads)
@@ -200,26 +212,52 @@ class FlatAllReduce(torch.nn.Module):
             self.early_hits += 1
 
     def _trigger(self, k):
-        # backward of a second loss in the same step: the branch was already reduced -> reduce_gradients sees the changed
-        # versions and reduces it again
-        if k in self._issued or any(self._params[i].grad is None for i in self._members[k]):
+        # a trigger that fires for a branch whose message has left (backward of a second loss in the same step, or a new
+        # backward pass after a step that was skipped): the branch is reduced again in reduce_gradients, whatever the
+        # allocator made of the gradients' identities
+        if k in self._issued:
+            self._dirty.add(k)
+            return
+        if any(self._params[i].grad is None for i in self._members[k]):
             return
         self._ready.add(k)
+        g = self._params[self._members[k][0]].grad
+        if g.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()         # on the stream this branch's backward runs on (the hook's current stream)
+            self._events[k] = ev
         self._pump()
 
-    def _arm(self):
-        """After the first backward pass: one trigger per branch, on the parameter whose gradient arrived last."""
+    def _agree(self):
+        """Calibration, once per ``reduce_gradients`` until armed -- on EVERY rank, whatever its own backward produced: the
+        ranks agree (a) that each of them has seen a backward pass producing every branch's full gradient set, and (b) on
+        ONE issue order, rank 0's arrival order.  Until (a) holds everywhere nothing is armed and this step's collectives go
+        out in the static module order.  One small all-reduce (MIN of the completeness flags) and, on the step that arms,
+        one broadcast of ``len(branches)`` integers."""
+        self.calibration_steps += 1
+        pos = {i: n for n, i in enumerate(self._arrival)}
+        last = {}
+        for k in self.branches:
+            seen = [i for i in self._members[k] if i in pos]
+            if len(seen) == len(self._members[k]):
+                last[k] = max(seen, key=lambda i: pos[i])
+        dev = self._params[0].device if self.backend == "nccl" else torch.device("cpu")
+        flag = torch.tensor([1 if len(last) == len(self.branches) else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            self._arrival.clear()        # not every rank is ready: calibrate again on the next backward pass
+            return
+        mine = sorted(range(len(self.branches)), key=lambda b: pos[last[self.branches[b]]])
+        order = torch.tensor(mine, dtype=torch.int64, device=dev)
+        dist.broadcast(order, src=0)
+        self._arm([self.branches[b] for b in order.tolist()], last)
+
+    def _arm(self, order, last):
+        """One trigger per branch, on the parameter whose gradient arrived last on THIS rank; the issue order is the agreed one."""
         for h in self._hooks:
             h.remove()
         self._hooks = []
-        last, pos = {}, {i: n for n, i in enumerate(self._arrival)}
-        for k in self.branches:
-            seen = [i for i in self._members[k] if i in pos]
-            if seen:
-                last[k] = max(seen, key=lambda i: pos[i])
-        # fixed issue order on every rank: branches in the order their backward passes finished (the same graph on every rank),
-        # branches that produced nothing last
-        self._order = sorted(self.branches, key=lambda k: pos[last[k]] if k in last else len(pos) + self.branches.index(k))
+        self._order = list(order)
         self.triggers = {k: self._names[i] for k, i in last.items()}
         for k, i in last.items():
             self._hooks.append(self._params[i].register_post_accumulate_grad_hook(lambda _p, k=k: self._trigger(k)))
@@ -229,13 +267,17 @@ class FlatAllReduce(torch.nn.Module):
     def reduce_gradients(self):
         """Average the gradients over the ranks (call once after backward; ``make_optimizer`` does it before every step):
         waits for the branch messages issued during backward and reduces whatever is left, in the fixed order."""
-        if self.overlap and self._arrival is not None and self._arrival:
-            self._arm()
-        order = self._order or self.branches
+        if self.overlap and self._order is None:
+            self._agree()               # every rank, every step until armed (a collective: not conditional on local state)
+            armed_now = self._order is not None
+        else:
+            armed_now = False
+        # the step that arms still goes out in the static order (nothing was issued from its backward)
+        order = self.branches if (self._order is None or armed_now) else self._order
         for k in order:
             stale = False
             if k in self._issued:       # issued from backward: still the gradients it copied?
-                stale = self._signature(k) != self._sig[k]
+                stale = k in self._dirty or self._signature(k) != self._sig[k]
                 if stale:
                     self._work.pop(k)[0].wait()
                     self._issued.remove(k)
@@ -256,6 +298,7 @@ class FlatAllReduce(torch.nn.Module):
                     if float(present[j]) > 0.0:
                         self._params[i].grad = self._views[i]
         self._ready, self._issued, self._sig = set(), [], {}
+        self._dirty, self._events = set(), {}
 
 
 def wrap(model, device=None, bucket_cap_mb=25, force=False, strategy=None):

@@ -29,6 +29,11 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._plans = {}
         self._dev_count = {}          # capturable groups: group index -> (step count [1] float64, coefficients [2] float32) on the device
+        # what a captured step (hipGraph) reads by ADDRESS: plans (table, block map, its own pinned pointer table) and the
+        # device counts.  Held for the optimiser's lifetime, so that a replay can never read freed memory; ``capture_epoch``
+        # moves whenever they stop being the live ones (load_state_dict) and GraphedTrainStep refuses to replay across that.
+        self._captured = []
+        self.capture_epoch = 0
 
     MAX_PLANS = 8
 
@@ -50,6 +55,8 @@ class FusedAdam(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         self._plans = {}                       # the moment tensors were replaced
         self._dev_count = {}                   # re-seeded from the loaded counts at the next step
+        if self._captured:
+            self.capture_epoch += 1            # a graph captured before this point updates the OLD moments: re-capture
 
     def _fingerprint(self, params):
         """Cheap check that the cached parameter / moment pointers are still the live ones."""
@@ -124,15 +131,22 @@ class FusedAdam(torch.optim.Optimizer):
                 host = plan["host"]
                 host[:, 1] = torch.tensor([g.data_ptr() for _, g in pg], dtype=torch.int64)
                 capturing = torch.cuda.is_current_stream_capturing()
-                k = plan["turn"]
-                plan["turn"] = (k + 1) % len(plan["pinned"])
-                if plan["events"][k] is not None and not capturing:
-                    plan["events"][k].synchronize()
-                plan["pinned"][k].copy_(host)
-                plan["table"].copy_(plan["pinned"][k], non_blocking=True)     # (captured: a copy node that re-reads this pinned buffer)
                 if capturing:
-                    plan["events"][k] = None
+                    # the graph's copy node re-reads its source on every replay: a pinned buffer of its OWN, outside the ring
+                    # the eager steps cycle through (an eager step after the capture would otherwise leave its gradient
+                    # pointers where the next replay picks them up)
+                    if "graph_pinned" not in plan:
+                        plan["graph_pinned"] = torch.empty(len(ps), 5, dtype=torch.int64).pin_memory()
+                    plan["graph_pinned"].copy_(host)
+                    plan["table"].copy_(plan["graph_pinned"], non_blocking=True)
+                    self._captured.append(plan)
                 else:
+                    k = plan["turn"]
+                    plan["turn"] = (k + 1) % len(plan["pinned"])
+                    if plan["events"][k] is not None:
+                        plan["events"][k].synchronize()
+                    plan["pinned"][k].copy_(host)
+                    plan["table"].copy_(plan["pinned"][k], non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record()
                     plan["events"][k] = ev
@@ -145,6 +159,8 @@ class FusedAdam(torch.optim.Optimizer):
                     if dc is None:      # seeded from the host count once; from then on the device count is the truth
                         dc = self._dev_count[gi] = (torch.full((1,), t0, dtype=torch.float64, device=dev),
                                                     torch.zeros(2, dtype=torch.float32, device=dev))
+                    if capturing:
+                        self._captured.append(dc)
                     check(lib.dfe_adam_step_dev(ctypes.c_void_p(plan["table"].data_ptr()), ctypes.c_void_p(plan["blockmap"].data_ptr()),
                                                 plan["nblocks"], float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                                 ctypes.c_void_p(dc[0].data_ptr()), ctypes.c_void_p(dc[1].data_ptr()), stream_ptr()),

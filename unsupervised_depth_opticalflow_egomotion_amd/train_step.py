@@ -100,15 +100,21 @@ class GraphedTrainStep:
     MI355X 17.9 ms eager -> 8.4 ms replayed; at B = 4 the GPU is the bound: 19.6 -> 19.4).
     Requirements: static shapes; an optimiser made with ``make_optimizer(..., capturable=True)`` (the step count on the device);
     a single process (a data-parallel reducer's collectives are not captured: use the eager step there).  ``warmup`` eager steps
-    run first on a side stream (they train, like every other step), then one step is captured; ``__call__`` copies the new batch
-    into the static input tensors and replays.  The returned loss / loss_pack / mask_pack are the graph's static outputs."""
+    run first on a side stream (allocator, MIOpen's solver choice, the Winograd filter cache); with ``restore`` (default) the
+    parameters, buffers and optimiser state they changed are put back IN PLACE afterwards, so constructing the object trains
+    nothing: the first ``__call__`` is the first optimiser step on that batch and Adam's count stays equal to the caller's
+    iteration count (checkpoints: train.py's ``iteration`` key).  ``__call__`` copies the new batch into the static input tensors
+    and replays.  The returned loss / loss_pack / mask_pack are the graph's static outputs.
+    The graph holds lr / betas / eps as kernel arguments and the optimiser's tables by address: ``__call__`` raises if a
+    hyper-parameter changed or ``optimizer.load_state_dict`` ran since the capture (build a new GraphedTrainStep then)."""
 
-    def __init__(self, model, optimizer, inputs, cfg, warmup=3):
+    def __init__(self, model, optimizer, inputs, cfg, warmup=3, restore=True):
         import torch
         if hasattr(model, "reduce_gradients") or type(model).__name__ == "DistributedDataParallel":
             raise NotImplementedError("GraphedTrainStep: single-process training only (collectives are not captured)")
         self.model, self.optimizer, self.cfg = model, optimizer, cfg
         self.static_inputs = [t.clone() for t in inputs]
+        saved = self._snapshot() if restore else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -116,6 +122,8 @@ class GraphedTrainStep:
                 train_step(model, optimizer, self.static_inputs, cfg)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if saved is not None:
+            self._restore(saved)
         optimizer.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
@@ -125,8 +133,65 @@ class GraphedTrainStep:
         # (found by the eager-twin test: the twin's registration freed the table, the next replay scattered filters through it).
         from . import ops
         self._cache_tables = (ops.wino_weights.table, ops.wino_weights.blockmap)
+        self._hyper = self._hyper_now()
+        self._epoch = getattr(optimizer, "capture_epoch", 0)
+
+    def _hyper_now(self):
+        return [(float(g["lr"]), tuple(float(b) for b in g["betas"]), float(g["eps"])) for g in self.optimizer.param_groups]
+
+    def _snapshot(self):
+        """Parameters, buffers and the optimiser's state before the warm-up steps (device copies; ~3x the model)."""
+        opt = self.optimizer
+        state = {}
+        for group in opt.param_groups:
+            for p in group["params"]:
+                st = opt.state.get(p)
+                if st:
+                    state[p] = {k: (v.clone() if hasattr(v, "clone") else v) for k, v in st.items()}
+        dev_count = {gi: [t.clone() for t in dc] for gi, dc in getattr(opt, "_dev_count", {}).items()}
+        return ([p.detach().clone() for p in self.model.parameters()], [b.detach().clone() for b in self.model.buffers()],
+                state, dev_count)
+
+    def _restore(self, saved):
+        """Put the snapshot back IN PLACE (every address the capture is about to record stays what it is)."""
+        import torch
+        params, buffers, state, dev_count = saved
+        opt = self.optimizer
+        with torch.no_grad():
+            for p, v in zip(self.model.parameters(), params):
+                p.copy_(v)
+            for b, v in zip(self.model.buffers(), buffers):
+                b.copy_(v)
+            for group in opt.param_groups:
+                for p in group["params"]:
+                    st = opt.state.get(p)
+                    if not st:
+                        continue
+                    old = state.get(p)
+                    for k, v in st.items():
+                        if not hasattr(v, "copy_"):
+                            continue
+                        if old is not None and k in old:
+                            v.copy_(old[k])
+                        else:           # created by the warm-up: back to its initial value (zero moments, count 0)
+                            v.zero_()
+            for gi, dc in getattr(opt, "_dev_count", {}).items():
+                if gi in dev_count:
+                    for t, v in zip(dc, dev_count[gi]):
+                        t.copy_(v)
+                else:
+                    dc[0].zero_()
+        from . import ops
+        ops.wino_weights.invalidate()       # parameters written in place without a step: cached transformed filters are stale
+        ops.wino_weights.refresh()
 
     def __call__(self, inputs=None):
+        if self._hyper_now() != self._hyper:
+            raise RuntimeError("GraphedTrainStep: lr / betas / eps changed since the capture (they are kernel arguments of the "
+                               "captured optimiser step): build a new GraphedTrainStep")
+        if getattr(self.optimizer, "capture_epoch", 0) != self._epoch:
+            raise RuntimeError("GraphedTrainStep: optimizer.load_state_dict() ran since the capture (the graph updates the "
+                               "previous moment tensors): build a new GraphedTrainStep")
         if inputs is not None:
             for dst, src in zip(self.static_inputs, inputs):
                 if dst.data_ptr() != src.data_ptr():
