@@ -614,10 +614,11 @@ def test_graphed_train_step_construction_trains_nothing_and_guards_its_capture()
         for _ in range(5):
             train_step(model, opt, batches[1], cfg)
         torch.cuda.synchronize()
-        mid = flat(model)
+        pflat = lambda m: torch.cat([t.detach().flatten() for t in m.parameters()]).clone()   # (buffers: BatchNorm's counters move by 1 per pass)
+        mid = pflat(model)
         l2 = float(g(batches[0])[0].detach())
         torch.cuda.synchronize()
-        moved = (flat(model) - mid).abs()
+        moved = (pflat(model) - mid).abs()
         assert np.isfinite(l2) and float(moved.max()) <= 1.5 * lr and float((moved > 0).float().mean()) > 0.5
         # (3)
         opt.param_groups[0]["lr"] = lr / 2

@@ -82,6 +82,8 @@ class FusedAdam(torch.optim.Optimizer):
         # copy synchronise the stream, i.e. stall the host once per step); a buffer is reused only after its copy ran
         plan = {"host": torch.tensor(rows, dtype=torch.int64),
                 "pinned": [torch.empty(len(rows), 5, dtype=torch.int64).pin_memory() for _ in range(4)],
+                # the captured step's own source buffer (see step()): allocated here, pinning memory is not capturable
+                "graph_pinned": torch.empty(len(rows), 5, dtype=torch.int64).pin_memory(),
                 "events": [None] * 4, "turn": 0,
                 "table": torch.empty(len(rows), 5, dtype=torch.int64, device=dev),
                 "blockmap": torch.tensor(blocks, dtype=torch.int32).to(dev), "nblocks": len(blocks),
@@ -135,8 +137,6 @@ class FusedAdam(torch.optim.Optimizer):
                     # the graph's copy node re-reads its source on every replay: a pinned buffer of its OWN, outside the ring
                     # the eager steps cycle through (an eager step after the capture would otherwise leave its gradient
                     # pointers where the next replay picks them up)
-                    if "graph_pinned" not in plan:
-                        plan["graph_pinned"] = torch.empty(len(ps), 5, dtype=torch.int64).pin_memory()
                     plan["graph_pinned"].copy_(host)
                     plan["table"].copy_(plan["graph_pinned"], non_blocking=True)
                     self._captured.append(plan)
