@@ -34,6 +34,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct WinoEpi { const float* bias; float slope; float* y2; long y2bs; };
 __device__ __forceinline__ float wino_act(float v, float bv, float slope) { v += bv; return v > 0.0f ? v : v * slope; }
 
+#ifndef WINO_SCHED
+#define WINO_SCHED 1             // 0: the round-5 loop (compiler-placed operand reads)
+#endif
 constexpr int WN_CC = 16;        // input channels per staged weight slab
 constexpr int WN_XP = 20;        // LDS floats per (channel, k): 16 positions + 4 pad (16-byte reads, 64 banks over 16 lanes)
 
@@ -111,12 +114,19 @@ template <int PP, int NW, int NH>   // PP = 0 / 1 / 2: the padding, pair loads (
                                     // exist (1 when Co <= 16: half the MFMAs, half the accumulators)
 __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restrict__ x, const float* __restrict__ U, float* __restrict__ y,
                                                        long ybs, int B, int C, int K, int H, int W, int P, int TH, int TW, int ntiles,
-                                                       unsigned nkt, int dil, unsigned nsp, int cps, float* __restrict__ part, WinoEpi epi) {
+                                                       unsigned nkt, int dil, unsigned nsp, int cps, float* __restrict__ part, WinoEpi epi,
+                                                       unsigned nitems) {
   extern __shared__ float lds[];      // [WN_CC][32][WN_XP]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
-  // logical block id = tile block * nkt + kt, dealt so that the nkt blocks of one tile range (they load the same patches)
-  // run on the same XCD at about the same time and share its L2
-  const unsigned lid = xcd_swizzle(blockIdx.x, gridDim.x);
+  // Round 6: a block is PERSISTENT -- the launch has one round of blocks (two per CU) and a block walks the work items
+  // blockIdx.x, blockIdx.x + gridDim.x, ...: no block launch, kernel-argument load and cold first patch per item, and the
+  // stores of one item drain under the loop of the next (1-2.5 % per layer).  (gridDim.x == nitems: one item per block, the
+  // round-5 behaviour.)
+  for (unsigned item = blockIdx.x; item < nitems; item += gridDim.x) {
+  if (item != blockIdx.x) __syncthreads();      // the previous item's last slab is still being read by slower waves
+  // logical item id = tile block * nkt + kt, dealt so that the nkt items of one tile range (they load the same patches)
+  // run on the same XCD at about the same time and share its L2 (gridDim.x is a multiple of 8: a block's items stay on its XCD)
+  const unsigned lid = xcd_swizzle(item, nitems);
   // nsp > 1: the input channels are split over nsp blocks (planes too small to fill the chip otherwise); each writes its partial
   // output to part[sp] (the output transform is linear) and k_wino_sum adds them in split order
   const int kt = static_cast<int>(lid % nkt), sp = static_cast<int>((lid / nkt) % nsp), tb = static_cast<int>(lid / (nkt * nsp));
@@ -302,6 +312,14 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
     const float* slab = lds + cur * SLAB;
     for (int cs = 0; cs < nc; cs += 4) {
       float d[16], t[16], v[16];
+      // Round 6: the step's filter reads are software-pipelined by hand.  hipcc put each half's four ds_read_b128 right in front of
+      // the 16 MFMAs that consume them: two exposed LDS latencies per step.  Here the first two quads are read at the top of the
+      // step (their latency passes under the gather and the transform), the others two MFMA groups ahead of their use, through
+      // a ring of three quad registers; the order is pinned with sched_group_barrier.
+      const float* up = slab + (min(cs + kq, nc - 1) * 32 + n) * WN_XP;    // a lane past the last channel holds a zero patch
+      auto ldU = [&](int h, int q) { return *reinterpret_cast<const f32x4*>(up + h * 16 * WN_XP + 4 * q); };
+      f32x4 ua, ub, uc;
+      if (NH == 2 && WINO_SCHED) { ua = ldU(0, 0); ub = ldU(0, 1); __builtin_amdgcn_sched_barrier(0); }
       gather(d);
       issue(c0 + cs + 4 + kq);                      // the next step's patch
 #pragma unroll
@@ -318,7 +336,29 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
         v[i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1];
         v[i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
       }
-      const float* up = slab + (min(cs + kq, nc - 1) * 32 + n) * WN_XP;    // a lane past the last channel holds a zero patch
+      if (NH == 2 && WINO_SCHED) {
+        auto mfma4 = [&](int h, int q, const f32x4& u) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[h][4 * q + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[j], v[4 * q + j], acc[h][4 * q + j], 0, 0, 0);
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        uc = ldU(0, 2);
+        mfma4(0, 0, ua); ua = ldU(0, 3);
+        mfma4(0, 1, ub); ub = ldU(1, 0);
+        mfma4(0, 2, uc); uc = ldU(1, 1);
+        mfma4(0, 3, ua); ua = ldU(1, 2);
+        mfma4(1, 0, ub); ub = ldU(1, 3);
+        mfma4(1, 1, uc);
+        mfma4(1, 2, ua);
+        mfma4(1, 3, ub);
+#define SGB_DS(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
+#define SGB_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+        SGB_DS(1); SGB_MFMA(4); SGB_DS(1); SGB_MFMA(4); SGB_DS(1); SGB_MFMA(4); SGB_DS(1); SGB_MFMA(4); SGB_DS(1); SGB_MFMA(4); SGB_DS(1); SGB_MFMA(12);
+#undef SGB_DS
+#undef SGB_MFMA
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         float u[16];
@@ -338,7 +378,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
     }
   }
   // D[i][j]: lane holds tile j = n and the output channels i = 4 kq + r of each 16-channel half
-  if (tb * (16 * NW) + wv * 16 + n >= ntiles) return;
+  if (tb * (16 * NW) + wv * 16 + n >= ntiles) continue;
   const int Hoq = (PP >= 0 || dil == 1) ? Ho : H / dil, Woq = (PP >= 0 || dil == 1) ? Wo : W / dil;   // outputs per phase image
   const int oy = 2 * ty, ox = 2 * tx;
   const int sy = dil * Wo, sx = dil;                // strides of the 2x2 outputs in y
@@ -407,6 +447,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
         }
       }
     }
+  }   // items
 }
 
 }  // namespace dfe
@@ -481,10 +522,13 @@ static int wino_run(const float* x, const float* weight, float* y, long y_batch_
     if (nblk >= (1L << 31)) return DFE_ERR_DIMS;
     static const bool pair_ok = [] { const char* e = getenv("DFE_WINO_PAIR"); return !e || atoi(e) != 0; }();
     const bool pair = pair_ok && dil == 1 && W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0;
-    const unsigned g = static_cast<unsigned>(nblk);
+    const unsigned nitems = static_cast<unsigned>(nblk);
+    // one resident round: two blocks per CU (launch bounds) x 256 CUs; DFE_WINO_PERSIST=0: one block per item
+    static const int persist = [] { const char* e = getenv("DFE_WINO_PERSIST"); return e ? atoi(e) : 512; }();
+    const unsigned g = persist > 0 ? std::min(nitems, static_cast<unsigned>(persist)) : nitems;
     const int nt = static_cast<int>(ntiles);
     const int pp = pair ? P : -1;
-#define WN_LAUNCH(PPV, NHV) k_wino_fwd16<PPV, 4, NHV><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt, dil, static_cast<unsigned>(sp.nsp), sp.cps, part, epi)
+#define WN_LAUNCH(PPV, NHV) k_wino_fwd16<PPV, 4, NHV><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt, dil, static_cast<unsigned>(sp.nsp), sp.cps, part, epi, nitems)
     if (Co <= 16) {
       if (pp == 1) WN_LAUNCH(1, 1); else if (pp == 0) WN_LAUNCH(0, 1); else if (pp == 2) WN_LAUNCH(2, 1); else WN_LAUNCH(-1, 1);
     } else {
