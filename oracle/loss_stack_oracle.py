@@ -312,6 +312,46 @@ def _unit(flow):
     return flow / _l2norm(flow).repeat(1, 2, 1, 1)
 
 
+class occ_exp:
+    """How the occlusion weights' 2-way softmax (model_geometry.py:119-130) evaluates its exponential (test-only switch;
+    default = the reference's own call).
+
+    ``host``: ``F.softmax`` of the machine the oracle runs on -- what the reference does; its ``exp`` is a vendor routine
+    (<= 1 ulp, not reproducible across hosts).
+    ``cr``: the softmax written out -- m = max(dl, dr); e_i = exp(d_i - m); w_i = 1 - e_i / (e_l + e_r), fp32 operations in
+    that order -- with the exponential CORRECTLY ROUNDED (float64 evaluation rounded once to fp32).  This is the function the
+    HIP kernels decide the occlusion bits on (dfe_device.h ``occ_exp``): in this mode the bits are compared for EQUALITY,
+    no noise floor.  The weights themselves differ from ``host`` by <= 2 ulp; the hard decisions only where |w - 0.48| is inside
+    that."""
+    mode = "host"
+
+    def __init__(self, mode="host"):
+        self.new = mode
+
+    def __enter__(self):
+        self.old = occ_exp.mode
+        occ_exp.mode = self.new
+        return self
+
+    def __exit__(self, *exc):
+        occ_exp.mode = self.old
+        return False
+
+    @staticmethod
+    def weights(dl, dr):
+        """1 - softmax([dl, dr]) over the channel dimension, [B, 2, H, W]."""
+        if occ_exp.mode == "host":
+            return 1 - F.softmax(torch.cat((dl, dr), 1), 1)
+        if occ_exp.mode != "cr":
+            raise ValueError(occ_exp.mode)
+        m = torch.maximum(dl, dr)
+        el, er = torch.exp((dl - m).double()).float(), torch.exp((dr - m).double()).float()
+        ssum = el + er
+        w = torch.cat((1 - el / ssum, 1 - er / ssum), 1)
+        soft = 1 - F.softmax(torch.cat((dl, dr), 1), 1)        # (gradients, where a caller wants them: the reference's graph)
+        return soft + (w - soft).detach()
+
+
 class GeomLossOracle:
     """The ``compute_*`` / ``fusion_*`` methods of the reference models, stateless.
 
@@ -369,7 +409,7 @@ class GeomLossOracle:
             v_bwd.append(1 - (il == 0).prod(1, keepdim=True).type_as(il))
             dl = torch.abs(it - il).mean(1, True)
             dr = torch.abs(it - ir).mean(1, True)
-            wgt = 1 - F.softmax(torch.cat((dl, dr), 1), 1)
+            wgt = occ_exp.weights(dl, dr)
             with torch.no_grad():
                 hard = (wgt > 0.48).float()
                 w_bwd.append(hard[:, 0:1])
@@ -588,7 +628,7 @@ class GeomLossOracle:
                     out["valid_" + tag].append(torch.minimum((cover - 0.9999).abs(), torch.where(keep > 0, nz, inf)))
                 dl = torch.abs(it - warped[0]).mean(1, True)
                 dr = torch.abs(it - warped[1]).mean(1, True)
-                wgt = 1 - F.softmax(torch.cat((dl, dr), 1), 1)
+                wgt = occ_exp.weights(dl, dr)
                 out["occ_bwd"].append((wgt[:, 0:1] - 0.48).abs())
                 out["occ_fwd"].append((wgt[:, 1:2] - 0.48).abs())
                 down = disp_list[0].size(2) / h

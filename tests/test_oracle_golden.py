@@ -318,3 +318,22 @@ def test_g10_evaluation_metrics(golden_dir):
     for gd, pd, want in zip(c["gt_depths"], c["pred_depths"], g["compute_errors"]):
         m = gd > 0
         np.testing.assert_allclose(EO.compute_errors(gd[m].astype(np.float64), pd[m].astype(np.float64)), want, rtol=1e-12)
+
+
+def test_oracle_cr_exp_mode_moves_decisions_only_inside_the_exp_floor():
+    """oracle.occ_exp("cr") (round 6): the occlusion softmax written out with a correctly rounded exponential.  Against the
+    host's own F.softmax the WEIGHTS move by a few ulp; a hard decision may only move where |w - 0.48| lies inside the exp
+    noise floor of tests/_margins.py -- the canonical function is a statement of the reference's, not a different one."""
+    import torch
+    from oracle import loss_stack_oracle as O
+    from tests import _margins as M
+    g = torch.Generator().manual_seed(5)
+    dl = 0.3 * torch.rand(4, 1, 128, 416, generator=g)
+    dr = dl + 0.08 + 0.02 * torch.randn(4, 1, 128, 416, generator=g)      # |dl - dr| around the flip point 0.08
+    host = O.occ_exp.weights(dl, dr)
+    with O.occ_exp("cr"):
+        cr = O.occ_exp.weights(dl, dr)
+    assert float((host - cr).abs().max()) <= 3e-7
+    flips = (host > 0.48) != (cr > 0.48)
+    assert bool(((host - 0.48).abs()[flips] < M.TAU["occ"]).all())
+    assert int(((host > 0.48) & (host < 0.52)).sum()) > 1000            # the test does sit on the threshold

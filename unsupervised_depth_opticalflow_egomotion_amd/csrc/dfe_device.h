@@ -276,9 +276,22 @@ __device__ __forceinline__ float mean3_abs_diff(float a0, float a1, float a2, fl
 
 // 1 - softmax([dl, dr]) > 0.48, evaluated through the softmax as the reference does
 // (model_geometry.py:119-130).  Returns soft weights too (Model_flow uses them).
+// Round 6: the ONE transcendental that feeds a mask decision, exp(-|dl - dr|), is evaluated so that the decision is the one the
+// CORRECTLY ROUNDED exponential gives -- no library's last bit can move it.  The hard weight flips where
+// tt / (1 + tt) crosses 0.48, i.e. at tt = 0.48 / 0.52 = 0.923077 (the other weight is >= 0.5 whatever tt is); a <= 2-ulp
+// expf (1.2e-7 here) plus the few roundings of the chain behind it cannot carry a value across that point from further than
+// 1e-6 away.  So: the fast expf everywhere, and inside the band |tt - 0.923077| < 4e-6 (about 4 pixels in 10^5; a divergent
+// branch almost no wave takes) RN32 of the float64 exponential -- correctly rounded unless the float64 value lies within 2^-29
+// (relative) of a float32 rounding boundary.  oracle/loss_stack_oracle.py's ``cr_exp`` mode states the same function.
+__device__ __forceinline__ float occ_exp(float a) {      // exp(-a), a >= 0
+  float tt = expf(-a);
+  if (fabsf(tt - 0.92307692f) < 4e-6f) tt = static_cast<float>(exp(-static_cast<double>(a)));
+  return tt;
+}
+
 __device__ __forceinline__ void occ_weights(float dl, float dr, float& w_bwd, float& w_fwd) {
   // softmax([dl, dr]): exp(x - max) is exactly 1 for the larger entry, so only one exp is evaluated
-  const float tt = expf(-fabsf(dl - dr));
+  const float tt = occ_exp(fabsf(dl - dr));
   const float el = (dl >= dr) ? 1.0f : tt, er = (dr >= dl) ? 1.0f : tt;
   const float sum = el + er;
   w_bwd = 1.0f - el / sum;

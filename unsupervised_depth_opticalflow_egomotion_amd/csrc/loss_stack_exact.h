@@ -120,7 +120,7 @@ __device__ __forceinline__ Proj project_fast(const Camera& c, int x, int y, floa
 
 // (1 - softmax([dl, dr])) > 0.48 with e / sum through RN(1 / sum): same bits as occ_weights()
 __device__ __forceinline__ void occ_decide(float dl, float dr, bool& occ_bwd, bool& occ_fwd) {
-  const float tt = expf(-fabsf(dl - dr));
+  const float tt = occ_exp(fabsf(dl - dr));
   const float el = (dl >= dr) ? 1.0f : tt, er = (dr >= dl) ? 1.0f : tt;
   const float sum = el + er, rs = rcp_cr(sum);
   occ_bwd = (1.0f - div_cr(el, sum, rs)) > 0.48f;
