@@ -33,14 +33,7 @@ extern "C" {
 /* Bumped whenever an exported signature changes or an entry point is removed (2: round 5 changed dfe_wino_wgrad3x3 and
  * removed dfe_thin_conv3x3 / dfe_cast_*; later values: see the comments of the entry points).  _lib.py compares the
  * library's value with this header's. */
-#define DFE_ABI_VERSION 3
-
-/* ---- ticket words (ABI 3, round 6).  Entry points with an ``int* tickets`` argument fold the small launch that used to add their
- * per-block partial results into the producing kernel: the block that arrives last at an integer counter runs the finisher's
- * arithmetic (same loads, same order: bit-identical, no float atomics).  tickets: DFE_TICKET_WORDS ints of device memory owned by
- * the caller, ZERO before the first use; every call leaves them zero, so one buffer serves every call on a stream -- calls that
- * may run CONCURRENTLY (different streams) need different buffers.  NULL: the separate finishing launch, as before. */
-#define DFE_TICKET_WORDS 4096
+#define DFE_ABI_VERSION 2
 
 int dfe_abi_version(void);
 const char* dfe_error_string(int code);
@@ -255,10 +248,9 @@ int dfe_wgrad3x3_fwd(const float* p, const float* gy, float* gweight, float* par
  * results are reproducible).  DFE_ERR_UNSUPPORTED (dfe_planeconv_supported == 0) for larger planes: the caller keeps MIOpen. */
 int dfe_planeconv_supported(int B, int Ci, int Co, int H, int W);
 long dfe_planeconv_ws_floats(int B, int Ci, int Co, int H, int W);
-/* tickets (forward / data gradient): see "ticket words" -- the last of a tile's channel-split blocks adds the partial planes */
 int dfe_planeconv_fwd(const float* x, const float* weight, const float* bias, float slope, float* dst1, long dst1_batch_stride,
-                      float* dst2, long dst2_batch_stride, float* ws, int* tickets, int B, int Ci, int Co, int H, int W, void* stream);
-int dfe_planeconv_dgrad(const float* gy, const float* weight, float* gx, float* ws, int* tickets, int B, int Ci, int Co, int H, int W,
+                      float* dst2, long dst2_batch_stride, float* ws, int B, int Ci, int Co, int H, int W, void* stream);
+int dfe_planeconv_dgrad(const float* gy, const float* weight, float* gx, float* ws, int B, int Ci, int Co, int H, int W,
                         void* stream);
 int dfe_planeconv_wgrad(const float* gy, const float* x, float* gweight, float* ws, int B, int Ci, int Co, int H, int W,
                         void* stream);
@@ -320,15 +312,15 @@ int dfe_wino_conv3x3_dilated(const float* x, const float* weight, float* y, long
  * scratch for the channel splits (dfe_wino_scratch_floats - dfe_wino_weight_floats; may be null / 0: no splits). */
 long dfe_wino_transform_blocks(int Ci, int Co);
 int dfe_wino_transform_weights_multi(const long* table, const int* blockmap, int n_blocks, void* stream);
-int dfe_wino_conv3x3_u(const float* x, const float* U, float* y, long y_batch_stride, float* part, long part_floats, int* tickets,
-                       int B, int Ci, int Co, int H, int W, int P, int dilation, void* stream);      /* tickets: see "ticket words" */
+int dfe_wino_conv3x3_u(const float* x, const float* U, float* y, long y_batch_stride, float* part, long part_floats, int B, int Ci,
+                       int Co, int H, int W, int P, int dilation, void* stream);
 /* dfe_wino_conv3x3_u with the bias + activation epilogue inside the output transform (net_utils.py:7-11 conv() = Conv2d +
  * LeakyReLU(0.1); pwc_tf.py:113-118): y = act(conv(x) + bias[co]), act(v) = v > 0 ? v : slope * v (slope 1: bias only; bias may
  * be null) -- bit for bit what dfe_bias_act_fwd makes of dfe_wino_conv3x3_u's output -- written to y and, when y2 is not null,
  * to the same (b, co, i) of y2 (batch stride y2_batch_stride): the two concatenated buffers a PWC decoder layer feeds. */
 int dfe_wino_conv3x3_u_act(const float* x, const float* U, const float* bias, float slope, float* y, long y_batch_stride, float* y2,
-                           long y2_batch_stride, float* part, long part_floats, int* tickets, int B, int Ci, int Co, int H, int W,
-                           int P, int dilation, void* stream);
+                           long y2_batch_stride, float* part, long part_floats, int B, int Ci, int Co, int H, int W, int P,
+                           int dilation, void* stream);
 
 /* ---- 1x1 convolutions on tiny planes (H*W <= 256, B*H*W <= 4096): PoseCNN's pose_conv and refinement head
  * (pose_cnn.py:32,43,48: Conv2d(256 | 24 | 12, 12, 1) on 2x7 planes).  x [B,Ci,H,W], weight [Co,Ci] (= [Co,Ci,1,1]).
@@ -367,7 +359,7 @@ int dfe_bn_bwd(const float* x, const float* y, const float* gy, const float* wei
 long dfe_bias_act_partials_floats(int B, int C, int H, int W);
 int dfe_bias_act_fwd(float* z, const float* bias, int B, int C, int H, int W, float slope, void* stream);
 int dfe_bias_act_bwd(const float* y, const float* gy, long gy_batch_stride, float* gz, float* gbias, float* partials,
-                     int* tickets, int B, int C, int H, int W, float slope, void* stream);
+                     int B, int C, int H, int W, float slope, void* stream);
 
 /* The same epilogue inside a DenseNet-style block (PWC_tf's decoder levels, pwc_tf.py:113-117 and the same five lines
  * per level: x2 = conv(cat(x0, x1)), x3 = conv(cat(x1, x2)) ...): act(z + bias) is written straight into the channel
@@ -377,8 +369,8 @@ int dfe_bias_act_bwd(const float* y, const float* gy, long gy_batch_stride, floa
 int dfe_bias_act_fwd2(const float* z, const float* bias, float* dst1, long dst1_batch_stride, float* dst2,
                       long dst2_batch_stride, int B, int C, int H, int W, float slope, void* stream);
 int dfe_bias_act_bwd2(const float* y, long y_batch_stride, const float* g1, long g1_batch_stride, const float* g2,
-                      long g2_batch_stride, float* gz, float* gbias, float* partials, int* tickets, int B, int C, int H,
-                      int W, float slope, void* stream);
+                      long g2_batch_stride, float* gz, float* gbias, float* partials, int B, int C, int H, int W,
+                      float slope, void* stream);
 /* With gbias == NULL and partials != NULL dfe_bias_act_bwd / dfe_bias_act_bwd2 only write the per-block partial sums; the
  * bias gradients of up to 8 such layers of one plane size (a PWC decoder level: pwc_tf.py:113-117) are then finished by
  * ONE launch: host arrays of n device pointers / channel counts; same summation order as the single-layer finish. */

@@ -44,7 +44,7 @@ def test_error_strings_and_argument_checks_without_gpu():
     P = ctypes.c_void_p(16)
     assert lib.dfe_bias_act_fwd(None, None, 1, 1, 8, 8, 0.1, None) == -1
     assert lib.dfe_bias_act_fwd(P, None, 0, 1, 8, 8, 0.1, None) == -2
-    assert lib.dfe_bias_act_bwd(P, P, 10, P, None, None, None, 1, 4, 8, 8, 0.1, None) == -2      # batch stride < C*H*W
+    assert lib.dfe_bias_act_bwd(P, P, 10, P, None, None, 1, 4, 8, 8, 0.1, None) == -2      # batch stride < C*H*W
     assert lib.dfe_bias_act_partials_floats(4, 16, 64, 208) == 4 * 16 * 7                  # ceil(13312 / 2048) blocks per plane
     assert lib.dfe_elu_pad_fwd(P, None, P, 1, 1, 1, 5, 1, None) == -2                      # 1-pixel planes cannot be reflected
     assert lib.dfe_elu_pad_bwd(None, None, P, P, None, None, 1, 1, 4, 4, 1, None) == -1    # ELU backward needs x
@@ -65,9 +65,9 @@ def test_error_strings_and_argument_checks_without_gpu():
         ws = lib.dfe_planeconv_ws_floats(B, Ci, Co, H, W)
         assert ws >= max(B * Co * H * W, B * Ci * H * W, Co * Ci * 9), (B, Ci, Co, H, W, ws)   # one partial plane of each pass at least
     assert lib.dfe_planeconv_ws_floats(8, 64, 64, 64, 208) == 0
-    assert lib.dfe_planeconv_fwd(None, P, None, 0.1, P, 0, None, 0, P, None, 1, 4, 4, 4, 4, None) == -1
-    assert lib.dfe_planeconv_fwd(P, P, None, 0.1, P, 10, None, 0, P, None, 1, 4, 4, 4, 4, None) == -2      # batch stride < Co*H*W
-    assert lib.dfe_planeconv_dgrad(P, P, P, P, None, 8, 64, 64, 64, 208, None) == -4                        # unsupported: larger plane
+    assert lib.dfe_planeconv_fwd(None, P, None, 0.1, P, 0, None, 0, P, 1, 4, 4, 4, 4, None) == -1
+    assert lib.dfe_planeconv_fwd(P, P, None, 0.1, P, 10, None, 0, P, 1, 4, 4, 4, 4, None) == -2      # batch stride < Co*H*W
+    assert lib.dfe_planeconv_dgrad(P, P, P, P, 8, 64, 64, 64, 208, None) == -4                        # unsupported: larger plane
     assert lib.dfe_planeconv_wgrad(P, P, None, P, 1, 4, 4, 4, 4, None) == -1
     # fused Winograd convolution (ops_wino.hip) and the tiny 1x1 convolutions: argument checks and scratch sizes
     assert lib.dfe_wino_weight_floats(64, 64) == 64 * 64 * 16 and lib.dfe_wino_weight_floats(5, 33) == 64 * 5 * 16
@@ -84,7 +84,7 @@ def test_error_strings_and_argument_checks_without_gpu():
     assert lib.dfe_wino_wgrad_floats(8, 128, 128, 64, 208, 1) > 0 and lib.dfe_wino_wgrad_floats(8, 128, 128, 64, 208, 2) == 0
     assert lib.dfe_wino_wgrad3x3(P, 4 * 8 * 8, None, 0, P, P, 1, 4, 4, 8, 8, 1, None) == -1
     assert lib.dfe_wino_wgrad3x3(P, 4 * 8 * 8, P, 4 * 8 * 8, P, P, 1, 4, 4, 8, 8, 2, None) == -4 and lib.dfe_wino_wgrad_floats(1, 4, 4, 8, 8, 1) > 0
-    assert lib.dfe_wino_conv3x3_u_act(P, None, None, 1.0, P, 4 * 8 * 8, None, 0, None, 0, None, 1, 4, 4, 8, 8, 1, 1, None) == -1
+    assert lib.dfe_wino_conv3x3_u_act(P, None, None, 1.0, P, 4 * 8 * 8, None, 0, None, 0, 1, 4, 4, 8, 8, 1, 1, None) == -1
     # strided weight gradient (csrc/ops_sconv.hip): the planner runs on the host
     assert lib.dfe_sconv_wgrad_floats(12, 3, 64, 256, 832, 7, 2, 3) == 768 * 64 * 3 * 49          # one round of three blocks per CU, one slab
     assert lib.dfe_sconv_wgrad_floats(4, 9, 16, 256, 832, 7, 2, 3) > 0 and lib.dfe_sconv_wgrad_floats(4, 16, 32, 128, 416, 5, 2, 2) > 0
@@ -98,9 +98,9 @@ def test_error_strings_and_argument_checks_without_gpu():
     # transformed filters kept across calls: blocks per filter, argument checks
     assert lib.dfe_wino_transform_blocks(64, 64) == 16 and lib.dfe_wino_transform_blocks(5, 33) == 2 and lib.dfe_wino_transform_blocks(0, 3) == 0
     assert lib.dfe_wino_transform_weights_multi(None, P, 4, None) == -1 and lib.dfe_wino_transform_weights_multi(P, P, 0, None) == -2
-    assert lib.dfe_wino_conv3x3_u(P, None, P, 4 * 8 * 8, None, 0, None, 1, 4, 4, 8, 8, 1, 1, None) == -1
-    assert lib.dfe_wino_conv3x3_u(P, P, P, 4 * 8 * 8, ctypes.c_void_p(20), 64, None, 1, 4, 4, 8, 8, 1, 1, None) == -4    # partial sums not 16-byte aligned
-    assert lib.dfe_wino_conv3x3_u(P, P, P, 4 * 8 * 9, None, 0, None, 1, 4, 4, 8, 9, 1, 2, None) == -4    # W not a multiple of the dilation
+    assert lib.dfe_wino_conv3x3_u(P, None, P, 4 * 8 * 8, None, 0, 1, 4, 4, 8, 8, 1, 1, None) == -1
+    assert lib.dfe_wino_conv3x3_u(P, P, P, 4 * 8 * 8, ctypes.c_void_p(20), 64, 1, 4, 4, 8, 8, 1, 1, None) == -4    # partial sums not 16-byte aligned
+    assert lib.dfe_wino_conv3x3_u(P, P, P, 4 * 8 * 9, None, 0, 1, 4, 4, 8, 9, 1, 2, None) == -4    # W not a multiple of the dilation
     assert lib.dfe_wino_conv3x3(P, None, P, 4 * 8 * 8, P, 1 << 20, 1, 4, 4, 8, 8, 1, 0, None) == -1
     assert lib.dfe_conv1x1_small_supported(4, 256, 12, 2, 7) == 1 and lib.dfe_conv1x1_small_supported(4, 16, 16, 64, 208) == 0
     assert lib.dfe_conv1x1_small_fwd(P, None, None, 1.0, P, 4, 12, 12, 2, 7, None) == -1

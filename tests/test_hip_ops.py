@@ -2,7 +2,6 @@
 golden vectors.  Tolerances (fp32): maps 1e-5 abs for bilinear outputs on [0,1] images, 2e-5
 for SSIM maps, pixel coordinates 2e-3 px (one fp32 ulp at x~800 is 6e-5 and the projection
 chains ~10 roundings), grads 1e-4 relative to the gradient scale, masks bit-exact."""
-import ctypes
 import os
 
 import numpy as np
@@ -951,71 +950,3 @@ def test_legacy_inverse_warp_euler_golden(golden_dir, ac):
     d2, p2 = T(c["depth"], True), T(c["pose"], True)
     y2, v2 = iw.inverse_warp(T(c["img"]), d2, p2, T(c["K"]), rotation_mode="quat", align_corners=ac)
     np.testing.assert_allclose(y2.detach().cpu().numpy(), g["iw_quat_img"], rtol=0, atol=2e-5)
-
-
-@pytest.mark.gpu
-def test_folded_finishers_are_bit_identical_to_the_separate_launches(monkeypatch):
-    """Round 6: the small finishing launches -- k_wino_sum (channel splits of small planes), k_planeconv_finish
-    (forward / data gradient), k_bias_grad_final / _multi -- are folded into their producers: the block that draws the last
-    ticket runs the finisher's arithmetic.  Same loads, same order: every output must EQUAL what ``DFE_TICKETS=0`` (the separate
-    launches) produces, run after run, and the ticket words must be zero again after every call."""
-    from unsupervised_depth_opticalflow_egomotion_amd import ops
-    from unsupervised_depth_opticalflow_egomotion_amd._lib import get_lib, ptr, stream_ptr, check
-    dev = torch.device("cuda:0")
-    torch.manual_seed(3)
-    lib = get_lib()
-
-    def both(fn):
-        monkeypatch.setenv("DFE_TICKETS", "0")
-        ref = fn()
-        monkeypatch.setenv("DFE_TICKETS", "1")
-        outs = [fn() for _ in range(3)]
-        torch.cuda.synchronize()
-        for o in outs:
-            for a, b in zip(o, ref):
-                assert torch.equal(a, b)
-        pool = next(iter(ops._TICKETS.values()))
-        assert int(pool.abs().sum()) == 0
-
-    # Winograd forward with channel splits (planes too small to fill the chip), plain and with the fused epilogue + two outputs
-    for (B, ci, co, H, W) in ((12, 256, 256, 16, 52), (12, 512, 512, 8, 26), (8, 179, 128, 16, 52)):
-        x = torch.randn(B, ci, H, W, device=dev)
-        w = torch.nn.Parameter(torch.randn(co, ci, 3, 3, device=dev) * 0.05)
-        bias = torch.randn(co, device=dev)
-        assert ops.wino_weights.lookup(w, False) is None
-        ops.wino_weights.refresh()
-        assert lib.dfe_wino_scratch_floats(B, ci, co, H, W, 1) > lib.dfe_wino_weight_floats(ci, co)      # the shape does split
-        both(lambda: (ops.wino_conv3x3(x, w, 1),))
-        def fused():
-            o1 = torch.zeros(B, co + 3, H, W, device=dev); o2 = torch.zeros(B, co + 5, H, W, device=dev)
-            ops.wino_conv3x3(x, w, 1, bias=bias, slope=0.1, out=o1, out_off=3, out2=o2, out2_off=2)
-            return o1, o2
-        both(fused)
-        gy = torch.randn(B, co, H, W, device=dev)
-        assert ops.wino_weights.lookup(w, True) is not None
-        both(lambda: (ops.wino_conv3x3(gy, w, 1, transposed=True),))
-    # small-plane convolutions (PWC levels 6 and 5)
-    for (B, ci, co, H, W) in ((8, 196, 128, 4, 13), (8, 128, 96, 8, 26), (8, 32, 2, 4, 13)):
-        x = torch.randn(B, ci, H, W, device=dev); w = torch.randn(co, ci, 3, 3, device=dev) * 0.05; b = torch.randn(co, device=dev)
-        gy = torch.randn(B, co, H, W, device=dev)
-        if not ops.planeconv_eligible(x, w):
-            continue
-        both(lambda: (ops.planeconv_forward(x, w, b, 0.1),))
-        both(lambda: (ops.planeconv_backward(gy, x, w, True, False)[0],))
-    # bias + activation backward: single slice and the dense-block form
-    for (B, C, H, W) in ((8, 128, 64, 208), (8, 96, 16, 52), (12, 16, 128, 416), (3, 5, 7, 9)):
-        y = torch.randn(B, C, H, W, device=dev); g1 = torch.randn(B, C + 4, H, W, device=dev); g2 = torch.randn(B, C, H, W, device=dev)
-
-        def bwd(two):
-            gz = torch.empty(B, C, H, W, device=dev); gb = torch.empty(C, device=dev)
-            part = torch.empty(lib.dfe_bias_act_partials_floats(B, C, H, W), device=dev)
-            sl = ctypes.c_void_p(g1.data_ptr() + 4 * 2 * H * W)
-            if two:
-                check(lib.dfe_bias_act_bwd2(ptr(y), y.stride(0), sl, g1.stride(0), ptr(g2), g2.stride(0), ptr(gz), ptr(gb), ptr(part),
-                                            ops.tickets(), B, C, H, W, 0.1, stream_ptr()), "bwd2")
-            else:
-                check(lib.dfe_bias_act_bwd(ptr(y), sl, g1.stride(0), ptr(gz), ptr(gb), ptr(part), ops.tickets(), B, C, H, W, 0.1,
-                                           stream_ptr()), "bwd")
-            return gz, gb
-        both(lambda: bwd(False))
-        both(lambda: bwd(True))

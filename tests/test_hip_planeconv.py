@@ -62,7 +62,7 @@ def test_planeconv_rejects_large_planes_and_null():
     x = torch.zeros(1, 4, 64, 208, device=dev())
     w = torch.zeros(4, 4, 3, 3, device=dev())
     assert not ops.planeconv_eligible(x, w)
-    assert lib.dfe_planeconv_fwd(None, None, None, 1.0, None, 0, None, 0, None, None, 1, 1, 1, 1, 1, None) != 0
+    assert lib.dfe_planeconv_fwd(None, None, None, 1.0, None, 0, None, 0, None, 1, 1, 1, 1, 1, None) != 0
 
 
 def test_planeconv_nonfinite_inputs_propagate():

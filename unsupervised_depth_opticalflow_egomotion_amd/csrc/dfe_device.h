@@ -455,49 +455,6 @@ __device__ __forceinline__ void block_sum(float (&vals)[N], float* smem, float* 
   __syncthreads();
 }
 
-// ---- Round 6: finishers folded into their producers ("last arriver" election).
-// Several kernels split a reduction over blocks, write per-block partials and used to be followed by a tiny launch that adds the
-// partials in a FIXED order (k_bias_grad_final, k_wino_sum, k_planeconv_finish ...: ~130 launches of 4-7 us per training step,
-// each on its stream's critical path).  Instead, the blocks that contribute to one output group take a ticket from an integer
-// counter after their partial is globally visible; the block that draws the last ticket runs the finisher's arithmetic --
-// the same loads in the same order, so the result is bit-identical and independent of which block came last.  No float atomics.
-// The counter is an atomicInc that wraps to zero on the last arrival: the caller's ticket words (zero before the first use) are
-// zero again when the launch ends.  DFE_TICKET_WORDS words per stream suffice for every entry point that takes ``tickets``.
-//
-// block_arrives_last: call from ALL threads of the block once the block's partial stores have been issued (by any of its
-// threads); true in every thread of the one block that arrived last, whose subsequent loads see every other block's partial.
-__device__ __forceinline__ bool block_arrives_last(unsigned* ticket, unsigned n_blocks) {
-  __shared__ int s_last_arriver;
-  __threadfence();                       // release: this thread's partial stores are visible device-wide before the ticket is drawn
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned t = atomicInc(ticket, n_blocks - 1u);
-    s_last_arriver = (t == n_blocks - 1u) ? 1 : 0;
-  }
-  __syncthreads();
-  const bool last = s_last_arriver != 0;
-  if (last) __threadfence();             // acquire: nothing this block reads from here on comes out of a stale cache line
-  return last;
-}
-
-// The one-wave-per-channel bias-gradient finisher (k_bias_grad_final / k_glue_bias_final), run by wave 0 of the last arriver:
-// gbias[c] = sum over b, k of part[(b * C + c) * nblk + k], lane-strided then a fixed DPP tree -- that kernel's exact order.
-__device__ __forceinline__ void bias_grad_finish(const float* part, float* gbias, int B, int C, int c, int nblk) {
-  if (threadIdx.x >= 64) return;
-  const int lane = threadIdx.x;
-  float s = 0.0f;
-  for (int b = 0; b < B; ++b) {
-    const float* p = part + (static_cast<long>(b) * C + c) * nblk;
-    for (int k = lane; k < nblk; k += 64) s += __builtin_nontemporal_load(p + k);
-  }
-  s = dpp_add<0xB1>(s); s = dpp_add<0x4E>(s); s = dpp_add<0x141>(s); s = dpp_add<0x140>(s);
-  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 0));
-  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 16));
-  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 32));
-  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 48));
-  if (lane == 0) gbias[c] = (r0 + r1) + (r2 + r3);
-}
-
 // (n, c) plane of an NCHW tensor for launches with grid = (chunks, C, N): n * C + c (both limits 65535)
 __device__ __forceinline__ unsigned plane_id() { return blockIdx.z * gridDim.y + blockIdx.y; }
 

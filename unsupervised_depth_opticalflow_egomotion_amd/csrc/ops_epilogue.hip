@@ -47,9 +47,9 @@ __global__ void __launch_bounds__(EP_BLOCK) k_bias_act_fwd(float* __restrict__ z
 
 template <bool VEC>
 __global__ void __launch_bounds__(EP_BLOCK) k_bias_act_bwd(const float* __restrict__ y, const float* __restrict__ gy,
-                                                           float* __restrict__ gz, float* part,
+                                                           float* __restrict__ gz, float* __restrict__ part,
                                                            int HW, long gy_plane_stride, long gy_batch_stride, int C,
-                                                           float slope, float* gbias, unsigned* tickets) {
+                                                           float slope) {
   __shared__ float red[4 * (EP_BLOCK / 64)];
   const int b = plane_id() / C, c = plane_id() - b * C;
   const float* py = y + static_cast<long>(plane_id()) * HW;
@@ -77,11 +77,7 @@ __global__ void __launch_bounds__(EP_BLOCK) k_bias_act_bwd(const float* __restri
       if (e < HW) { const float g = py[e] > 0.0f ? pg[e] : pg[e] * slope; pz[e] = g; acc[0] += g; }
     }
   }
-  if (part) {
-    block_sum<1>(acc, red, part + static_cast<long>(plane_id()) * gridDim.x + blockIdx.x);
-    // round 6: the channel's last block finishes the bias gradient (k_bias_grad_final's arithmetic) instead of a launch of its own
-    if (tickets && block_arrives_last(tickets + c, gridDim.x * gridDim.z)) bias_grad_finish(part, gbias, gridDim.z, C, c, gridDim.x);
-  }
+  if (part) block_sum<1>(acc, red, part + static_cast<long>(plane_id()) * gridDim.x + blockIdx.x);
 }
 
 // gbias[c] = sum over b, chunks of part[(b*C + c)*nchunk + chunk] in a fixed order; one wave per channel
@@ -166,8 +162,8 @@ __global__ void __launch_bounds__(EP_BLOCK) k_bias_act_fwd2(const float* z, cons
 template <bool VEC>
 __global__ void __launch_bounds__(EP_BLOCK) k_bias_act_bwd2(const float* y, long y_bs, const float* g1,
                                                             long g1_bs, const float* g2, long g2_bs,
-                                                            float* gz, float* part, int C, int HW,
-                                                            float slope, float* gbias, unsigned* tickets) {
+                                                            float* gz, float* __restrict__ part, int C, int HW,
+                                                            float slope) {
   __shared__ float red[4 * (EP_BLOCK / 64)];
   const int b = plane_id() / C, c = plane_id() - b * C;
   const long co = static_cast<long>(c) * HW;
@@ -203,11 +199,7 @@ __global__ void __launch_bounds__(EP_BLOCK) k_bias_act_bwd2(const float* y, long
       }
     }
   }
-  if (part) {
-    block_sum<1>(acc, red, part + static_cast<long>(plane_id()) * gridDim.x + blockIdx.x);
-    // round 6: the channel's last block finishes the bias gradient (k_bias_grad_final's arithmetic) instead of a launch of its own
-    if (tickets && block_arrives_last(tickets + c, gridDim.x * gridDim.z)) bias_grad_finish(part, gbias, gridDim.z, C, c, gridDim.x);
-  }
+  if (part) block_sum<1>(acc, red, part + static_cast<long>(plane_id()) * gridDim.x + blockIdx.x);
 }
 
 }  // namespace dfe
@@ -236,7 +228,7 @@ extern "C" int dfe_bias_act_fwd(float* z, const float* bias, int B, int C, int H
 }
 
 extern "C" int dfe_bias_act_bwd(const float* y, const float* gy, long gy_batch_stride, float* gz, float* gbias,
-                                float* partials, int* tickets, int B, int C, int H, int W, float slope, void* stream) {
+                                float* partials, int B, int C, int H, int W, float slope, void* stream) {
   if (!y || !gy || !gz || (gbias && !partials)) return DFE_ERR_NULL;
   const long hw = static_cast<long>(H) * W;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || hw >= (1L << 31) || C > 65535 || B > 65535) return DFE_ERR_DIMS;
@@ -246,11 +238,10 @@ extern "C" int dfe_bias_act_bwd(const float* y, const float* gy, long gy_batch_s
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* part = partials;      // written whenever given: gbias == NULL leaves the finish to dfe_bias_grad_final_multi
   const bool vec = hw % 4 == 0 && aligned16(y) && aligned16(gy) && aligned16(gz) && gy_batch_stride % 4 == 0;
-  unsigned* tk = (gbias && tickets && C <= DFE_TICKET_WORDS) ? reinterpret_cast<unsigned*>(tickets) : nullptr;
-  if (vec) k_bias_act_bwd<true><<<g, EP_BLOCK, 0, st>>>(y, gy, gz, part, static_cast<int>(hw), hw, gy_batch_stride, C, slope, gbias, tk);
-  else k_bias_act_bwd<false><<<g, EP_BLOCK, 0, st>>>(y, gy, gz, part, static_cast<int>(hw), hw, gy_batch_stride, C, slope, gbias, tk);
+  if (vec) k_bias_act_bwd<true><<<g, EP_BLOCK, 0, st>>>(y, gy, gz, part, static_cast<int>(hw), hw, gy_batch_stride, C, slope);
+  else k_bias_act_bwd<false><<<g, EP_BLOCK, 0, st>>>(y, gy, gz, part, static_cast<int>(hw), hw, gy_batch_stride, C, slope);
   DFE_LAUNCH_CHECK();
-  if (gbias && !tk) {
+  if (gbias) {
     k_bias_grad_final<<<C, 64, 0, st>>>(partials, gbias, B, C, nchunk);
     DFE_LAUNCH_CHECK();
   }
@@ -274,8 +265,8 @@ extern "C" int dfe_bias_act_fwd2(const float* z, const float* bias, float* dst1,
 }
 
 extern "C" int dfe_bias_act_bwd2(const float* y, long y_batch_stride, const float* g1, long g1_batch_stride, const float* g2,
-                                 long g2_batch_stride, float* gz, float* gbias, float* partials, int* tickets, int B, int C, int H,
-                                 int W, float slope, void* stream) {
+                                 long g2_batch_stride, float* gz, float* gbias, float* partials, int B, int C, int H, int W,
+                                 float slope, void* stream) {
   if (!y || !g1 || !gz || (gbias && !partials)) return DFE_ERR_NULL;
   const long hw = static_cast<long>(H) * W;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || hw >= (1L << 31) || C > 65535 || B > 65535) return DFE_ERR_DIMS;
@@ -286,11 +277,10 @@ extern "C" int dfe_bias_act_bwd2(const float* y, long y_batch_stride, const floa
   float* part = partials;      // written whenever given: gbias == NULL leaves the finish to dfe_bias_grad_final_multi
   const bool vec = hw % 4 == 0 && aligned16(y) && aligned16(g1) && aligned16(gz) && y_batch_stride % 4 == 0 &&
                    g1_batch_stride % 4 == 0 && (!g2 || (aligned16(g2) && g2_batch_stride % 4 == 0));
-  unsigned* tk = (gbias && tickets && C <= DFE_TICKET_WORDS) ? reinterpret_cast<unsigned*>(tickets) : nullptr;
-  if (vec) k_bias_act_bwd2<true><<<g, EP_BLOCK, 0, st>>>(y, y_batch_stride, g1, g1_batch_stride, g2, g2_batch_stride, gz, part, C, static_cast<int>(hw), slope, gbias, tk);
-  else k_bias_act_bwd2<false><<<g, EP_BLOCK, 0, st>>>(y, y_batch_stride, g1, g1_batch_stride, g2, g2_batch_stride, gz, part, C, static_cast<int>(hw), slope, gbias, tk);
+  if (vec) k_bias_act_bwd2<true><<<g, EP_BLOCK, 0, st>>>(y, y_batch_stride, g1, g1_batch_stride, g2, g2_batch_stride, gz, part, C, static_cast<int>(hw), slope);
+  else k_bias_act_bwd2<false><<<g, EP_BLOCK, 0, st>>>(y, y_batch_stride, g1, g1_batch_stride, g2, g2_batch_stride, gz, part, C, static_cast<int>(hw), slope);
   DFE_LAUNCH_CHECK();
-  if (gbias && !tk) {
+  if (gbias) {
     k_bias_grad_final<<<C, 64, 0, st>>>(partials, gbias, B, C, nchunk);
     DFE_LAUNCH_CHECK();
   }

@@ -18,7 +18,6 @@
 //     32 x 32 channel tile); k_planeconv_finish adds the per-block partial planes in unit order.
 // Bound: launch latency and the LDS round trip of one chunk (the whole of level 6 is 0.5 GFLOP and 2.5 MB of weights).
 #include "dfe_internal.h"
-#include "dfe_device.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdlib>
@@ -41,12 +40,10 @@ __device__ __forceinline__ int fdiv(int idx, float inv) { return static_cast<int
 // DGRAD = false: w [N][Ck][3][3],  out[n][p] = sum_{c,t} x[c][p + d(t)] * w[n][c][t]
 // DGRAD = true : w [Ck][N][3][3],  out[n][p] = sum_{c,t} x[c][p + d(t)] * w[c][n][8 - t]      (x = the output gradient)
 // LDS: xs [PC_CC][XP] (rows r0-1 .. r0+RB-2 of the plane with a zero border, pitch W+2), wl [16*NSUB][KP] ([n][c*9 + t])
-struct PcFin { const float* bias; float* d1; long bs1; float* d2; long bs2; float slope; unsigned* tickets; };
-
 template <int NSUB, bool DGRAD, int XT>
-__global__ void __launch_bounds__(256) k_planeconv(const float* __restrict__ x, const float* __restrict__ w, float* part,
+__global__ void __launch_bounds__(256) k_planeconv(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ part,
                                                    int B, int Ck, int N, int H, int W, int KS, int cps, int RB, int XP, int KP,
-                                                   float inv_wp, PcFin fin) {
+                                                   float inv_wp) {
   extern __shared__ float lds[];
   constexpr int NT = 16 * NSUB, WT = NT * PC_KW / 256;
   float* xs = lds;
@@ -153,31 +150,6 @@ __global__ void __launch_bounds__(256) k_planeconv(const float* __restrict__ x, 
       for (int r = 0; r < 4; ++r) {
         const int pp = m0 + 16 * wv + 4 * kq + r;
         if (pp < HW) po[static_cast<long>(n) * HW + pp] = acc[s][0][r] + acc[s][1][r];
-      }
-    }
-  }
-  // Round 6: with ticket words the last of the KS blocks of this (pixel tile, channel tile, sample) runs k_planeconv_finish's
-  // arithmetic for the tile -- the KS partial planes added in slot order, bias, activation, the one or two destinations
-  if (!fin.tickets) return;
-  if (!block_arrives_last(fin.tickets + ((static_cast<unsigned>(b) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x), KS)) return;
-  const long total = static_cast<long>(B) * N * HW;
-#pragma unroll
-  for (int s = 0; s < NSUB; ++s) {
-    const int n = n0 + 16 * s + m;
-    if (n < N) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int pp = m0 + 16 * wv + 4 * kq + r;
-        if (pp < HW) {
-          const long rr = static_cast<long>(n) * HW + pp;
-          const float* q = part + static_cast<long>(b) * N * HW + rr;
-          float v = __builtin_nontemporal_load(q);
-          for (int k = 1; k < KS; ++k) v += __builtin_nontemporal_load(q + k * total);
-          if (fin.bias) v += fin.bias[n];
-          v = v > 0.0f ? v : v * fin.slope;
-          fin.d1[b * fin.bs1 + rr] = v;
-          if (fin.d2) fin.d2[b * fin.bs2 + rr] = v;
-        }
       }
     }
   }
@@ -398,32 +370,29 @@ int pc_dims(int B, int Ci, int Co, int H, int W) {
 }
 
 template <int NSUB, bool DGRAD, int XT>
-int pc_launch(const float* x, const float* w, float* part, int B, int Ck, int N, int H, int W, const PcCfg& g, hipStream_t st, const PcFin& fin) {
+int pc_launch(const float* x, const float* w, float* part, int B, int Ck, int N, int H, int W, const PcCfg& g, hipStream_t st) {
   const dim3 grid(g.ntm, g.ntn, B * g.KS);
   const int Wp = W + 2;
   k_planeconv<NSUB, DGRAD, XT><<<grid, 256, g.lds, st>>>(x, w, part, B, Ck, N, H, W, g.KS, g.cps, g.RB, g.XP, g.KP,
-                                                         1.0f / static_cast<float>(Wp), fin);
+                                                         1.0f / static_cast<float>(Wp));
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
 
 template <int NSUB, bool DGRAD>
-int pc_launch_xt(const float* x, const float* w, float* part, int B, int Ck, int N, int H, int W, const PcCfg& g, hipStream_t st, const PcFin& fin) {
-  if (g.xt <= 6) return pc_launch<NSUB, DGRAD, 6>(x, w, part, B, Ck, N, H, W, g, st, fin);
-  if (g.xt <= 12) return pc_launch<NSUB, DGRAD, 12>(x, w, part, B, Ck, N, H, W, g, st, fin);
-  return pc_launch<NSUB, DGRAD, PC_XT_MAX>(x, w, part, B, Ck, N, H, W, g, st, fin);
+int pc_launch_xt(const float* x, const float* w, float* part, int B, int Ck, int N, int H, int W, const PcCfg& g, hipStream_t st) {
+  if (g.xt <= 6) return pc_launch<NSUB, DGRAD, 6>(x, w, part, B, Ck, N, H, W, g, st);
+  if (g.xt <= 12) return pc_launch<NSUB, DGRAD, 12>(x, w, part, B, Ck, N, H, W, g, st);
+  return pc_launch<NSUB, DGRAD, PC_XT_MAX>(x, w, part, B, Ck, N, H, W, g, st);
 }
 
 int pc_run(bool dgrad, const float* x, const float* w, const float* bias, float slope, float* d1, long bs1, float* d2, long bs2,
-           float* ws, int* tickets, int B, int Ck, int N, int H, int W, hipStream_t st) {
+           float* ws, int B, int Ck, int N, int H, int W, hipStream_t st) {
   const PcCfg g = pc_cfg(B, Ck, N, H, W);
-  const bool fold = tickets && static_cast<long>(B) * g.ntn * g.ntm <= DFE_TICKET_WORDS;
-  const PcFin fin{bias, d1, bs1, d2, bs2, slope, fold ? reinterpret_cast<unsigned*>(tickets) : nullptr};
   int rc;
-  if (g.nsub == 4) rc = dgrad ? pc_launch_xt<4, true>(x, w, ws, B, Ck, N, H, W, g, st, fin) : pc_launch_xt<4, false>(x, w, ws, B, Ck, N, H, W, g, st, fin);
-  else rc = dgrad ? pc_launch_xt<2, true>(x, w, ws, B, Ck, N, H, W, g, st, fin) : pc_launch_xt<2, false>(x, w, ws, B, Ck, N, H, W, g, st, fin);
+  if (g.nsub == 4) rc = dgrad ? pc_launch_xt<4, true>(x, w, ws, B, Ck, N, H, W, g, st) : pc_launch_xt<4, false>(x, w, ws, B, Ck, N, H, W, g, st);
+  else rc = dgrad ? pc_launch_xt<2, true>(x, w, ws, B, Ck, N, H, W, g, st) : pc_launch_xt<2, false>(x, w, ws, B, Ck, N, H, W, g, st);
   if (rc != DFE_OK) return rc;
-  if (fold) return DFE_OK;
   const long HW = static_cast<long>(H) * W, total = B * N * HW;
   k_planeconv_finish<<<static_cast<unsigned>((total + 255) / 256), 256, 0, st>>>(
       ws, bias, d1, bs1, d2, bs2, static_cast<int>(total), static_cast<int>(N * HW), static_cast<int>(HW), g.KS, slope,
@@ -449,25 +418,25 @@ extern "C" long dfe_planeconv_ws_floats(int B, int Ci, int Co, int H, int W) {
 }
 
 extern "C" int dfe_planeconv_fwd(const float* x, const float* weight, const float* bias, float slope, float* dst1,
-                                 long dst1_batch_stride, float* dst2, long dst2_batch_stride, float* ws, int* tickets, int B, int Ci,
-                                 int Co, int H, int W, void* stream) {
+                                 long dst1_batch_stride, float* dst2, long dst2_batch_stride, float* ws, int B, int Ci, int Co,
+                                 int H, int W, void* stream) {
   if (!x || !weight || !dst1 || !ws) return DFE_ERR_NULL;
   const int rc = pc_dims(B, Ci, Co, H, W);
   if (rc != DFE_OK) return rc;
   if (!dfe_planeconv_supported(B, Ci, Co, H, W)) return DFE_ERR_UNSUPPORTED;
   const long chw = static_cast<long>(Co) * H * W;
   if (dst1_batch_stride < chw || (dst2 && dst2_batch_stride < chw)) return DFE_ERR_DIMS;
-  return pc_run(false, x, weight, bias, slope, dst1, dst1_batch_stride, dst2, dst2_batch_stride, ws, tickets, B, Ci, Co, H, W,
+  return pc_run(false, x, weight, bias, slope, dst1, dst1_batch_stride, dst2, dst2_batch_stride, ws, B, Ci, Co, H, W,
                 static_cast<hipStream_t>(stream));
 }
 
-extern "C" int dfe_planeconv_dgrad(const float* gy, const float* weight, float* gx, float* ws, int* tickets, int B, int Ci, int Co,
-                                   int H, int W, void* stream) {
+extern "C" int dfe_planeconv_dgrad(const float* gy, const float* weight, float* gx, float* ws, int B, int Ci, int Co, int H, int W,
+                                   void* stream) {
   if (!gy || !weight || !gx || !ws) return DFE_ERR_NULL;
   const int rc = pc_dims(B, Ci, Co, H, W);
   if (rc != DFE_OK) return rc;
   if (!dfe_planeconv_supported(B, Ci, Co, H, W)) return DFE_ERR_UNSUPPORTED;
-  return pc_run(true, gy, weight, nullptr, 1.0f, gx, static_cast<long>(Ci) * H * W, nullptr, 0, ws, tickets, B, Co, Ci, H, W,
+  return pc_run(true, gy, weight, nullptr, 1.0f, gx, static_cast<long>(Ci) * H * W, nullptr, 0, ws, B, Co, Ci, H, W,
                 static_cast<hipStream_t>(stream));
 }
 

@@ -114,8 +114,8 @@ template <int PP, int NW, int NH>   // PP = 0 / 1 / 2: the padding, pair loads (
                                     // exist (1 when Co <= 16: half the MFMAs, half the accumulators)
 __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restrict__ x, const float* __restrict__ U, float* __restrict__ y,
                                                        long ybs, int B, int C, int K, int H, int W, int P, int TH, int TW, int ntiles,
-                                                       unsigned nkt, int dil, unsigned nsp, int cps, float* part, WinoEpi epi,
-                                                       unsigned nitems, unsigned* tickets) {
+                                                       unsigned nkt, int dil, unsigned nsp, int cps, float* __restrict__ part, WinoEpi epi,
+                                                       unsigned nitems) {
   extern __shared__ float lds[];      // [WN_CC][32][WN_XP]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
   // Round 6: a block is PERSISTENT -- the launch has one round of blocks (two per CU) and a block walks the work items
@@ -378,95 +378,75 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
     }
   }
   // D[i][j]: lane holds tile j = n and the output channels i = 4 kq + r of each 16-channel half
-  const bool live = tb * (16 * NW) + wv * 16 + n < ntiles;
+  if (tb * (16 * NW) + wv * 16 + n >= ntiles) continue;
   const int Hoq = (PP >= 0 || dil == 1) ? Ho : H / dil, Woq = (PP >= 0 || dil == 1) ? Wo : W / dil;   // outputs per phase image
   const int oy = 2 * ty, ox = 2 * tx;
   const int sy = dil * Wo, sx = dil;                // strides of the 2x2 outputs in y
   const long kplane = static_cast<long>(Ho) * Wo;
   const long ooff = static_cast<long>(py + dil * oy) * Wo + px + dil * ox;
+  float* yb = (nsp > 1 ? part + (static_cast<long>(sp) * B + b) * K * kplane : y + b * ybs) + ooff;
+  // with channel splits the epilogue belongs to k_wino_sum (the partial outputs are sums of a part of the channels)
+  const bool fused = nsp == 1 && (epi.bias != nullptr || epi.slope != 1.0f);
+  float* y2b = (nsp == 1 && epi.y2) ? epi.y2 + b * epi.y2bs + ooff : nullptr;
   // 8-byte stores of a tile's row pairs: dense layers with an even output width and 8-byte aligned planes (every plane starts
   // at an even float offset: batch strides and Ho * Wo even)
   const bool even_w = dil == 1 && (Wo & 1) == 0;
-  auto store4 = [&](float* o, bool pair, float y00, float y01, float y10, float y11) {
-    if (pair) {        // Wo even, 8-byte aligned rows: a tile's two outputs of a row leave as one 8-byte store (16 lanes = 128 bytes)
-      if (ox < Woq) {
-        if (oy < Hoq) *reinterpret_cast<f32x2*>(o) = f32x2{y00, y01};
-        if (oy + 1 < Hoq) *reinterpret_cast<f32x2*>(o + sy) = f32x2{y10, y11};
-      }
-    } else {
-      if (oy < Hoq) {
-        if (ox < Woq) o[0] = y00;
-        if (ox + 1 < Woq) o[sx] = y01;
-      }
-      if (oy + 1 < Hoq) {
-        if (ox < Woq) o[sy] = y10;
-        if (ox + 1 < Woq) o[sy + sx] = y11;
-      }
-    }
-  };
-  // final outputs: the epilogue y = act(v + bias[k]) and the one or two destinations
-  float* const yfin = y + b * ybs + ooff;
-  float* const y2fin = epi.y2 ? epi.y2 + b * epi.y2bs + ooff : nullptr;
-  const bool has_epi = epi.bias != nullptr || epi.slope != 1.0f;
-  const bool pair_y = even_w && (reinterpret_cast<uintptr_t>(y) & 7) == 0 && (ybs & 1) == 0;
-  const bool pair_y2 = even_w && y2fin && (reinterpret_cast<uintptr_t>(epi.y2) & 7) == 0 && (epi.y2bs & 1) == 0;
-  auto finish4 = [&](int k, float y00, float y01, float y10, float y11) {
-    if (has_epi) {
-      const float bv = epi.bias ? epi.bias[k] : 0.0f;
-      y00 = wino_act(y00, bv, epi.slope); y01 = wino_act(y01, bv, epi.slope);
-      y10 = wino_act(y10, bv, epi.slope); y11 = wino_act(y11, bv, epi.slope);
-    }
-    store4(yfin + static_cast<long>(k) * kplane, pair_y, y00, y01, y10, y11);
-    if (y2fin) store4(y2fin + static_cast<long>(k) * kplane, pair_y2, y00, y01, y10, y11);
-  };
-  // with channel splits this block's outputs are PARTIAL sums: they go to part[sp] unfinished
-  float* const pb = nsp > 1 ? part + (static_cast<long>(sp) * B + b) * K * kplane + ooff : nullptr;
-  const bool pair_p = even_w && (reinterpret_cast<uintptr_t>(part) & 7) == 0;
-  if (live) {
+  const bool pair_st = even_w && (reinterpret_cast<uintptr_t>(nsp > 1 ? part : y) & 7) == 0 && ((nsp > 1 ? 0 : ybs) & 1) == 0;
+  const bool pair_st2 = even_w && y2b && (reinterpret_cast<uintptr_t>(epi.y2) & 7) == 0 && (epi.y2bs & 1) == 0;
 #pragma unroll
-    for (int h = 0; h < NH; ++h)
+  for (int h = 0; h < NH; ++h)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int k = kt * 32 + 16 * h + 4 * kq + r;
-        if (k >= K) continue;
-        float t0[4], t1[4];
+    for (int r = 0; r < 4; ++r) {
+      const int k = kt * 32 + 16 * h + 4 * kq + r;
+      if (k >= K) continue;
+      float t0[4], t1[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          t0[s] = (acc[h][s][r] + acc[h][4 + s][r]) + acc[h][8 + s][r];
-          t1[s] = (acc[h][4 + s][r] - acc[h][8 + s][r]) - acc[h][12 + s][r];
+      for (int s = 0; s < 4; ++s) {
+        t0[s] = (acc[h][s][r] + acc[h][4 + s][r]) + acc[h][8 + s][r];
+        t1[s] = (acc[h][4 + s][r] - acc[h][8 + s][r]) - acc[h][12 + s][r];
+      }
+      float y00 = (t0[0] + t0[1]) + t0[2], y01 = (t0[1] - t0[2]) - t0[3];
+      float y10 = (t1[0] + t1[1]) + t1[2], y11 = (t1[1] - t1[2]) - t1[3];
+      if (fused) {
+        const float bv = epi.bias ? epi.bias[k] : 0.0f;
+        y00 = wino_act(y00, bv, epi.slope); y01 = wino_act(y01, bv, epi.slope);
+        y10 = wino_act(y10, bv, epi.slope); y11 = wino_act(y11, bv, epi.slope);
+      }
+      float* o = yb + static_cast<long>(k) * Ho * Wo;
+      if (pair_st) {        // Wo even, 8-byte aligned rows: a tile's two outputs of a row leave as one 8-byte store (16 lanes = 128 bytes)
+        if (ox < Woq) {
+          if (oy < Hoq) *reinterpret_cast<f32x2*>(o) = f32x2{y00, y01};
+          if (oy + 1 < Hoq) *reinterpret_cast<f32x2*>(o + sy) = f32x2{y10, y11};
         }
-        const float y00 = (t0[0] + t0[1]) + t0[2], y01 = (t0[1] - t0[2]) - t0[3];
-        const float y10 = (t1[0] + t1[1]) + t1[2], y11 = (t1[1] - t1[2]) - t1[3];
-        if (nsp > 1) store4(pb + static_cast<long>(k) * kplane, pair_p, y00, y01, y10, y11);
-        else finish4(k, y00, y01, y10, y11);
+      } else {
+        if (oy < Hoq) {
+          if (ox < Woq) o[0] = y00;
+          if (ox + 1 < Woq) o[sx] = y01;
+        }
+        if (oy + 1 < Hoq) {
+          if (ox < Woq) o[sy] = y10;
+          if (ox + 1 < Woq) o[sy + sx] = y11;
+        }
       }
-  }
-  // Round 6: the nsp blocks of one (tile block, k-tile) draw tickets; the one that arrives last adds the nsp partial outputs of
-  // its own lanes' positions in split order -- k_wino_sum's arithmetic, which only runs when the caller gave no ticket words
-  if (nsp > 1 && tickets) {
-    if (block_arrives_last(tickets + (static_cast<unsigned>(tb) * nkt + kt), nsp) && live) {
-      const long sstride = static_cast<long>(B) * K * kplane;
-      const float* p0 = part + static_cast<long>(b) * K * kplane + ooff;
-#pragma unroll
-      for (int h = 0; h < NH; ++h)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = kt * 32 + 16 * h + 4 * kq + r;
-          if (k >= K) continue;
-          const float* q = p0 + static_cast<long>(k) * kplane;
-          const bool c0 = ox < Woq, c1 = ox + 1 < Woq, r0 = oy < Hoq, r1 = oy + 1 < Hoq;
-          float v00 = 0.0f, v01 = 0.0f, v10 = 0.0f, v11 = 0.0f;
-          for (unsigned u = 0; u < nsp; ++u) {
-            const float* e = q + u * sstride;
-            const float a00 = (r0 && c0) ? __builtin_nontemporal_load(e) : 0.0f, a01 = (r0 && c1) ? __builtin_nontemporal_load(e + sx) : 0.0f;
-            const float a10 = (r1 && c0) ? __builtin_nontemporal_load(e + sy) : 0.0f, a11 = (r1 && c1) ? __builtin_nontemporal_load(e + sy + sx) : 0.0f;
-            if (u == 0) { v00 = a00; v01 = a01; v10 = a10; v11 = a11; }
-            else { v00 += a00; v01 += a01; v10 += a10; v11 += a11; }
+      if (y2b) {
+        float* o2 = y2b + static_cast<long>(k) * Ho * Wo;
+        if (pair_st2) {
+          if (ox < Woq) {
+            if (oy < Hoq) *reinterpret_cast<f32x2*>(o2) = f32x2{y00, y01};
+            if (oy + 1 < Hoq) *reinterpret_cast<f32x2*>(o2 + sy) = f32x2{y10, y11};
           }
-          finish4(k, v00, v01, v10, v11);
+        } else {
+          if (oy < Hoq) {
+            if (ox < Woq) o2[0] = y00;
+            if (ox + 1 < Woq) o2[sx] = y01;
+          }
+          if (oy + 1 < Hoq) {
+            if (ox < Woq) o2[sy] = y10;
+            if (ox + 1 < Woq) o2[sy + sx] = y11;
+          }
         }
+      }
     }
-  }
   }   // items
 }
 
@@ -509,8 +489,7 @@ static WinoSplit wino_split(long ntiles, int Kpad, int Ci, int B, int Co, int Ho
 // weight == nullptr: wbuf already holds the transformed filters (dfe_wino_conv3x3_u) and is only read; part / part_floats: room
 // for the channel splits' partial outputs (may be null / 0)
 static int wino_run(const float* x, const float* weight, float* y, long y_batch_stride, float* wbuf, float* part, long part_floats, int B,
-                    int Ci, int Co, int H, int W, int P, int dil, int transposed_weight, void* stream, WinoEpi epi = WinoEpi{nullptr, 1.0f, nullptr, 0},
-                    int* tickets = nullptr) {
+                    int Ci, int Co, int H, int W, int P, int dil, int transposed_weight, void* stream, WinoEpi epi = WinoEpi{nullptr, 1.0f, nullptr, 0}) {
   if (!x || !y || !wbuf) return DFE_ERR_NULL;
   const int rc = wn_dims(B, Ci, Co, H, W, P);
   if (rc != DFE_OK) return rc;
@@ -549,9 +528,7 @@ static int wino_run(const float* x, const float* weight, float* y, long y_batch_
     const unsigned g = persist > 0 ? std::min(nitems, static_cast<unsigned>(persist)) : nitems;
     const int nt = static_cast<int>(ntiles);
     const int pp = pair ? P : -1;
-    // ticket words given: the last of a tile range's nsp blocks adds the partial outputs (no k_wino_sum launch)
-    unsigned* tk = (sp.nsp > 1 && tickets && nblk / sp.nsp <= DFE_TICKET_WORDS) ? reinterpret_cast<unsigned*>(tickets) : nullptr;
-#define WN_LAUNCH(PPV, NHV) k_wino_fwd16<PPV, 4, NHV><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt, dil, static_cast<unsigned>(sp.nsp), sp.cps, part, epi, nitems, tk)
+#define WN_LAUNCH(PPV, NHV) k_wino_fwd16<PPV, 4, NHV><<<g, 256, lds_bytes, st>>>(x, wbuf, y, y_batch_stride, B, Ci, Co, H, W, P, TH, TW, nt, nkt, dil, static_cast<unsigned>(sp.nsp), sp.cps, part, epi, nitems)
     if (Co <= 16) {
       if (pp == 1) WN_LAUNCH(1, 1); else if (pp == 0) WN_LAUNCH(0, 1); else if (pp == 2) WN_LAUNCH(2, 1); else WN_LAUNCH(-1, 1);
     } else {
@@ -559,7 +536,7 @@ static int wino_run(const float* x, const float* weight, float* y, long y_batch_
     }
 #undef WN_LAUNCH
     DFE_LAUNCH_CHECK();
-    if (sp.nsp > 1 && !tk) {
+    if (sp.nsp > 1) {
       const long khw = static_cast<long>(Co) * Ho * Wo, n = B * khw;
       k_wino_sum<<<static_cast<unsigned>((n + 255) / 256), 256, 0, st>>>(part, y, y_batch_stride, sp.nsp, B, khw, static_cast<long>(Ho) * Wo, epi);
     }
@@ -591,17 +568,17 @@ extern "C" int dfe_wino_conv3x3_dilated(const float* x, const float* weight, flo
   return wino_run(x, weight, y, y_batch_stride, wbuf, nullptr, 0, B, Ci, Co, H, W, 1, dilation, transposed_weight, stream);
 }
 
-extern "C" int dfe_wino_conv3x3_u(const float* x, const float* U, float* y, long y_batch_stride, float* part, long part_floats,
-                                  int* tickets, int B, int Ci, int Co, int H, int W, int P, int dilation, void* stream) {
+extern "C" int dfe_wino_conv3x3_u(const float* x, const float* U, float* y, long y_batch_stride, float* part, long part_floats, int B, int Ci,
+                                  int Co, int H, int W, int P, int dilation, void* stream) {
   return wino_run(x, nullptr, y, y_batch_stride, const_cast<float*>(U), part, part_floats, B, Ci, Co, H, W, dilation > 1 ? 1 : P, dilation, 0,
-                  stream, WinoEpi{nullptr, 1.0f, nullptr, 0}, tickets);
+                  stream);
 }
 
 extern "C" int dfe_wino_conv3x3_u_act(const float* x, const float* U, const float* bias, float slope, float* y, long y_batch_stride, float* y2,
-                                      long y2_batch_stride, float* part, long part_floats, int* tickets, int B, int Ci, int Co, int H, int W,
-                                      int P, int dilation, void* stream) {
+                                      long y2_batch_stride, float* part, long part_floats, int B, int Ci, int Co, int H, int W, int P,
+                                      int dilation, void* stream) {
   return wino_run(x, nullptr, y, y_batch_stride, const_cast<float*>(U), part, part_floats, B, Ci, Co, H, W, dilation > 1 ? 1 : P, dilation, 0,
-                  stream, WinoEpi{bias, slope, y2, y2_batch_stride}, tickets);
+                  stream, WinoEpi{bias, slope, y2, y2_batch_stride});
 }
 
 extern "C" long dfe_wino_transform_blocks(int Ci, int Co) {

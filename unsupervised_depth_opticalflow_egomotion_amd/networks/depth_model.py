@@ -123,7 +123,9 @@ class Depth_Model(nn.Module):
         larger convolutions.  ``batched``: the frames already stacked along the batch ([n*B,3,H,W]), when the caller has
         them in that layout.  Returns one disparity list per frame."""
         n, B = len(frames), frames[0].shape[0]
-        bns = [m for m in self.modules() if isinstance(m, resnet.FrameBatchNorm2d)]
+        bns = self.__dict__.get("_frame_bns")      # (walking ~140 modules per step cost 0.2 ms of host time: cached; the set of
+        if bns is None:                            # BatchNorm layers of a built network does not change)
+            bns = self.__dict__["_frame_bns"] = [m for m in self.modules() if isinstance(m, resnet.FrameBatchNorm2d)]
         defer = self.training and frames[0].is_cuda
         for m in bns:
             m.groups = n

@@ -38,24 +38,6 @@ def scatter_ws(n, device):
 
 
 # --------------------------------------------------------------------------- cameras
-_TICKETS = {}
-
-
-def tickets():
-    """The calling stream's ticket words (include/dfe_hip.h "ticket words", ABI 3): DFE_TICKET_WORDS zeroed int32 on the current
-    device, one buffer per HIP stream -- kernels on one stream run in order and leave the words zero, kernels on different
-    streams (the three network branches) may overlap and must not share them.  DFE_TICKETS=0: no folding (the separate finishing
-    launches of round 5; A/B switch)."""
-    if os.environ.get("DFE_TICKETS", "1") == "0":
-        return None
-    st = torch.cuda.current_stream()
-    key = (st.device_index, st.cuda_stream)
-    t = _TICKETS.get(key)
-    if t is None:
-        t = _TICKETS[key] = torch.zeros(4096, dtype=torch.int32, device=torch.device("cuda", st.device_index))
-    return ctypes.c_void_p(t.data_ptr())
-
-
 def prepare_cameras(pose, K, downscales):
     """pose [B,ndir,6] or [B,6], K [B,3,3] -> opaque camera buffer [B*ndir*len(downscales), 66]."""
     lib = get_lib()
@@ -597,7 +579,7 @@ class BiasActFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[1]:
             gb = torch.empty(C, device=y.device, dtype=torch.float32)
             part = torch.empty(lib.dfe_bias_act_partials_floats(B, C, H, W), device=y.device, dtype=torch.float32)
-        check(lib.dfe_bias_act_bwd(ptr(y), ptr(gy, strided=True), gy.stride(0), ptr(gz), ptr(gb), ptr(part), tickets(), B, C, H, W, ctx.slope,
+        check(lib.dfe_bias_act_bwd(ptr(y), ptr(gy, strided=True), gy.stride(0), ptr(gz), ptr(gb), ptr(part), B, C, H, W, ctx.slope,
                                    stream_ptr()), "dfe_bias_act_bwd")
         return gz, gb, None
 
@@ -610,6 +592,8 @@ def bias_act(z, bias, slope):
 # Planes of at most this many pixels per sample take the dfe_planeconv_* kernels inside DenseDecodeFn (PWC levels 6 and 5 of
 # a 256x832 frame: 52 and 208 pixels); 0 = every layer stays on MIOpen.
 PLANECONV_MAX_HW = int(os.environ.get("DFE_PLANECONV_MAX_HW", "208"))
+WINO_EPILOGUE = os.environ.get("DFE_WINO_EPILOGUE", "1") != "0"      # switches read once at import (246 environment reads per step before)
+FLOW_HEAD = os.environ.get("DFE_FLOW_HEAD", "1") != "0"
 
 
 def planeconv_eligible(x, w):
@@ -632,7 +616,7 @@ def planeconv_fwd_into(x, w, bias, slope, d1, d1_off=0, d2=None, d2_off=0):
     p2 = ctypes.c_void_p(d2.data_ptr() + 4 * d2_off * HW) if d2 is not None else None
     ws = _planeconv_ws(B, Ci, Co, H, W, x.device)
     check(get_lib().dfe_planeconv_fwd(ptr(x), ptr(w), ptr(bias), float(slope), p1, d1.stride(0), p2,
-                                      d2.stride(0) if d2 is not None else 0, ptr(ws), tickets(), B, Ci, Co, H, W, stream_ptr()),
+                                      d2.stride(0) if d2 is not None else 0, ptr(ws), B, Ci, Co, H, W, stream_ptr()),
           "dfe_planeconv_fwd")
 
 
@@ -653,7 +637,7 @@ def planeconv_backward(gy, x, w, want_x=True, want_w=True):
     gx = gw = None
     if want_x:
         gx = torch.empty_like(x)
-        check(lib.dfe_planeconv_dgrad(ptr(gy), ptr(w), ptr(gx), ptr(ws), tickets(), B, Ci, Co, H, W, stream_ptr()), "dfe_planeconv_dgrad")
+        check(lib.dfe_planeconv_dgrad(ptr(gy), ptr(w), ptr(gx), ptr(ws), B, Ci, Co, H, W, stream_ptr()), "dfe_planeconv_dgrad")
     if want_w:
         gw = torch.empty_like(w)
         check(lib.dfe_planeconv_wgrad(ptr(gy), ptr(x), ptr(gw), ptr(ws), B, Ci, Co, H, W, stream_ptr()), "dfe_planeconv_wgrad")
@@ -822,16 +806,14 @@ def wino_conv3x3(x, w, padding=1, transposed=False, dilation=1, bias=None, slope
         npart = 0 if d > 1 else lib.dfe_wino_scratch_floats(B, Ci, Co, H, W, P) - lib.dfe_wino_weight_floats(Ci, Co)
         part = torch.empty(npart, device=x.device, dtype=torch.float32) if npart > 0 else None
         check(lib.dfe_wino_conv3x3_u_act(ptr(x), ptr(U), ptr(f32c(bias)) if bias is not None else None, float(slope), p1, y.stride(0), p2,
-                                         out2.stride(0) if out2 is not None else 0, ptr(part), npart, tickets() if part is not None else None,
-                                         B, Ci, Co, H, W, P, d, stream_ptr()),
+                                         out2.stride(0) if out2 is not None else 0, ptr(part), npart, B, Ci, Co, H, W, P, d, stream_ptr()),
               "dfe_wino_conv3x3_u_act")
         return y
     y = torch.empty(B, Co, Ho, Wo, device=x.device, dtype=torch.float32)
     if U is not None:
         npart = 0 if d > 1 else lib.dfe_wino_scratch_floats(B, Ci, Co, H, W, P) - lib.dfe_wino_weight_floats(Ci, Co)
         part = torch.empty(npart, device=x.device, dtype=torch.float32) if npart > 0 else None
-        check(lib.dfe_wino_conv3x3_u(ptr(x), ptr(U), ptr(y), y.stride(0), ptr(part), npart, tickets() if part is not None else None,
-                                     B, Ci, Co, H, W, P, d, stream_ptr()),
+        check(lib.dfe_wino_conv3x3_u(ptr(x), ptr(U), ptr(y), y.stride(0), ptr(part), npart, B, Ci, Co, H, W, P, d, stream_ptr()),
               "dfe_wino_conv3x3_u")
         return y
     nws = lib.dfe_wino_weight_floats(Ci, Co) if d > 1 else lib.dfe_wino_scratch_floats(B, Ci, Co, H, W, P)
@@ -873,7 +855,7 @@ class ConvBiasActFn(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             gb = torch.empty(C, device=y.device, dtype=torch.float32)
             part = torch.empty(lib.dfe_bias_act_partials_floats(B, C, H, W), device=y.device, dtype=torch.float32)
-        check(lib.dfe_bias_act_bwd(ptr(y), ptr(gy, strided=True), gy.stride(0), ptr(gz), ptr(gb), ptr(part), tickets(), B, C, H, W, slope,
+        check(lib.dfe_bias_act_bwd(ptr(y), ptr(gy, strided=True), gy.stride(0), ptr(gz), ptr(gb), ptr(part), B, C, H, W, slope,
                                    stream_ptr()), "dfe_bias_act_bwd")
         pad = (d, d) if d > 1 else (P, P)
         gx, gw, _ = convs.raw_backward(gz, x, w, (1, 1), pad, (d, d), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
@@ -883,7 +865,7 @@ class ConvBiasActFn(torch.autograd.Function):
 def conv_bias_act_eligible(x, conv):
     """A Conv2d whose forward the Winograd kernel runs (convs._wino_eligible: 3x3, stride 1, padding 1 or dilated with
     padding = dilation, enough tiles and channels, fp32)."""
-    return (os.environ.get("DFE_WINO_EPILOGUE", "1") != "0" and conv.bias is not None and conv.groups == 1
+    return (WINO_EPILOGUE and conv.bias is not None and conv.groups == 1
             and convs._wino_eligible(x, conv.weight.shape, conv.in_channels, conv.stride, conv.padding, conv.dilation, conv.groups)
             and conv.padding == ((1, 1) if conv.dilation == (1, 1) else conv.dilation))
 
@@ -981,7 +963,7 @@ class PlaneConvActFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = torch.empty(C, device=y.device, dtype=torch.float32)
             part = torch.empty(lib.dfe_bias_act_partials_floats(B, C, H, W), device=y.device, dtype=torch.float32)
-        check(lib.dfe_bias_act_bwd(ptr(y), ptr(gy), gy.stride(0), ptr(gz), ptr(gb), ptr(part), tickets(), B, C, H, W, ctx.slope,
+        check(lib.dfe_bias_act_bwd(ptr(y), ptr(gy), gy.stride(0), ptr(gz), ptr(gb), ptr(part), B, C, H, W, ctx.slope,
                                    stream_ptr()), "dfe_bias_act_bwd")
         gx, gw = planeconv_backward(gz, x, w, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return gx, gw, gb, None
@@ -1019,7 +1001,7 @@ class Conv1x1SmallFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = torch.empty(Co, device=y.device, dtype=torch.float32)
             part = torch.empty(lib.dfe_bias_act_partials_floats(B, Co, H, W), device=y.device, dtype=torch.float32)
-        check(lib.dfe_bias_act_bwd(ptr(y), ptr(gy), gy.stride(0), ptr(gz), ptr(gb), ptr(part), tickets(), B, Co, H, W, ctx.slope,
+        check(lib.dfe_bias_act_bwd(ptr(y), ptr(gy), gy.stride(0), ptr(gz), ptr(gb), ptr(part), B, Co, H, W, ctx.slope,
                                    stream_ptr()), "dfe_bias_act_bwd")
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
@@ -1081,7 +1063,7 @@ class DenseDecodeFn(torch.autograd.Function):
             planeconv_fwd_into(cat[1], w[3], b[3], slope, cat[2], co[2], cat[3], 0)
             planeconv_fwd_into(cat[2], w[4], b[4], slope, x4, 0, cat[3], co[3])
         else:
-            fuse = os.environ.get("DFE_WINO_EPILOGUE", "1") != "0"
+            fuse = WINO_EPILOGUE
 
             def layer(inp, k, d1, d1_off, d2, d2_off):
                 """act(conv_k(inp) + b_k) into channels d1_off.. of d1 (None: a fresh tensor, returned) and d2_off.. of d2"""
@@ -1127,20 +1109,17 @@ class DenseDecodeFn(torch.autograd.Function):
             c = co[k]
             gz = torch.empty(B, c, H, W, device=dev, dtype=torch.float32)
             gb = part = None
-            if nb(k):       # round 6: the channel's last block finishes the bias gradient inside the launch (ticket words); without
-                            # them only the per-block partial sums, and the level's bias gradients are finished by ONE launch below
+            if nb(k):       # only the per-block partial sums now; the level's bias gradients are finished by ONE launch below
                 gb = torch.empty(c, device=dev, dtype=torch.float32)
                 part = torch.empty(lib.dfe_bias_act_partials_floats(B, c, H, W), device=dev, dtype=torch.float32)
-                if tk is None:
-                    pending.append((part, gb, c))
+                pending.append((part, gb, c))
             sl = lambda t, off: ctypes.c_void_p(t.data_ptr() + 4 * off * HW)
             check(lib.dfe_bias_act_bwd2(sl(ysrc, y_off), ysrc.stride(0), sl(g1, g1_off), g1.stride(0),
                                         sl(g2, g2_off) if g2 is not None else None, g2.stride(0) if g2 is not None else 0,
-                                        ptr(gz), ptr(gb) if tk is not None else None, ptr(part), tk, B, c, H, W, slope, st), "dfe_bias_act_bwd2")
+                                        ptr(gz), None, ptr(part), B, c, H, W, slope, st), "dfe_bias_act_bwd2")
             return gz, gb
 
         pending = []
-        tk = tickets()
 
         gw, gbias = [None] * 6, [None] * 6
         if g_flow is not None:
@@ -1308,7 +1287,7 @@ def flow_head_bwd_raw(x, weight, gout, want_w=True, want_b=True):
 
 def flow_head_eligible(x, weight, bias=None):
     """PWC's predict_flow layers (pwc_tf.py:39-40): two output channels, 3x3, channel count a multiple of 8."""
-    return (os.environ.get("DFE_FLOW_HEAD", "1") != "0" and x.is_cuda
+    return (FLOW_HEAD and x.is_cuda
             and x.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and weight.shape[0] == 2
             and weight.shape[1] == x.shape[1] and x.shape[1] % 8 == 0 and bias is not None)
 
