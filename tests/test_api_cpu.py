@@ -1026,3 +1026,32 @@ def test_legacy_inverse_warp_signatures_vs_reference_golden(golden_dir, ac):
     np.testing.assert_allclose(g2.numpy(), g["cam2pixel2_grid"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(z2.numpy(), g["cam2pixel2_z"], rtol=0, atol=2e-6)
     assert np.array_equal(g2.numpy() == 2.0, g["cam2pixel2_grid"] == 2.0)
+
+
+def test_occupancy_critical_kernels_keep_their_resources():
+    """Round 6 lost 3 ms of step time to FOUR BYTES of static LDS in k_wino_fwd16 (two blocks per CU -> one: +45 % on every
+    Winograd layer; EXPERIMENT_LOG round-6 appendix) -- nothing a parity test can see.  This reads the resource metadata of the
+    built library (tools/kernel_meta.py: the code objects' AMDGPU notes, no GPU needed) and holds the matrix kernels to what
+    their launch configuration assumes: no static LDS beside the dynamic buffers, at most 256 registers (two waves per SIMD),
+    no register spills to memory, no scratch; the per-sample prepare kernels are the only ones allowed scratch."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import kernel_meta
+    ks = kernel_meta.kernels()
+    assert len(ks) > 150
+    by = lambda sub: [k for k in ks if sub in k["name"]]      # noqa: E731
+    wino, wgrad = by("k_wino_fwd16"), by("k_wino_wgrad2")
+    assert len(wino) == 8 and len(wgrad) >= 8
+    for k in wino + wgrad + by("k_sconv_wgrad") + by("11k_planeconvI"):
+        assert k["lds"] == 0, (k["name"], "static LDS in a kernel whose occupancy is sized by its dynamic LDS")
+        assert k["vgpr"] + k["agpr"] <= 512 // 2 or "planeconv" in k["name"] or "sconv" in k["name"], k
+        assert k["vgpr_spill"] == 0 and k["scratch"] == 0, k
+    for k in wino + wgrad:
+        assert k["vgpr"] <= 256 and k["agpr"] == 0, k
+    allowed_scratch = ("k_prepare_cameras", "k_pose_mats_bwd", "k_geom_prepare")
+    for k in ks:
+        if k["scratch"] > 0 or k["vgpr_spill"] > 0:
+            assert any(a in k["name"] for a in allowed_scratch), k
+    # the pointwise kernels of the loss stack: at least five waves per SIMD
+    for k in by("k_geom_point_fwdILb0E") + by("k_geom_point_bwdILb0E"):
+        assert k["vgpr"] <= 96, k
