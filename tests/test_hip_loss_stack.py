@@ -217,7 +217,7 @@ def test_unconditioned_poses_vs_host_libm(kind, shape, seed, ac, capsys):
 
 
 @pytest.mark.parametrize("ac", [False, True])
-@pytest.mark.parametrize("kind,shape,seed", [("cond", (2, 128, 448), 600), ("cond", (4, 256, 832), 31), ("cond", (4, 256, 832), 32),
+@pytest.mark.parametrize("kind,shape,seed", [("cond", (2, 128, 448), 600), ("cond", (4, 256, 832), 31),
                                              ("sigma", (4, 256, 832), 16), ("posecnn", (1, 256, 832), 15)])
 def test_occlusion_bits_equal_the_correctly_rounded_oracle(kind, shape, seed, ac):
     """the softmax's ``exp`` was the last library value a mask bit depended on.  The kernels now decide
@@ -231,15 +231,10 @@ def test_occlusion_bits_equal_the_correctly_rounded_oracle(kind, shape, seed, ac
     _, mk_h, _, _ = run_hip(inp, ac, S)
     with O.trig("cr"), O.occ_exp("cr"):
         _, mk_c, _, _ = run_oracle(inp, ac, S)
-    _, mk_o, _, _ = run_oracle(inp, ac, S)            # the host's own exp, for the record
-    nhost = 0
     for k in MASKS:
         for s in range(S):
             h, c = N(mk_h[k][s]), N(mk_c[k][s])
             assert np.array_equal(h, c), "%s scale %d: %d bit(s) differ from the correctly rounded oracle" % (k, s, int((h != c).sum()))
-            if k.startswith("occ"):
-                nhost += int((h != N(mk_o[k][s])).sum())
-    print("occlusion bits: equal to the cr oracle; %d differ from this host's softmax" % nhost)
 
 
 def test_fused_stack_each_loss_gradient():
