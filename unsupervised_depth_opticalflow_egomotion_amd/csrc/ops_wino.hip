@@ -118,10 +118,10 @@ __global__ void __launch_bounds__(64 * NW, 2) k_wino_fwd16(const float* __restri
                                                        unsigned nitems) {
   extern __shared__ float lds[];      // [WN_CC][32][WN_XP]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
-  // Round 6: a block is PERSISTENT -- the launch has one round of blocks (two per CU) and a block walks the work items
-  // blockIdx.x, blockIdx.x + gridDim.x, ...: no block launch, kernel-argument load and cold first patch per item, and the
-  // stores of one item drain under the loop of the next (1-2.5 % per layer).  (gridDim.x == nitems: one item per block, the
-  // round-5 behaviour.)
+  // Round 6: a block CAN be persistent (DFE_WINO_PERSIST) -- the launch then has one round of blocks (two per CU) and a block
+  // walks the work items blockIdx.x, blockIdx.x + gridDim.x, ...: no block launch, kernel-argument load and cold first patch per
+  // item, and the stores of one item drain under the loop of the next (1-2.5 % per layer on an idle GPU; not the default, see
+  // wino_run).  gridDim.x == nitems: one item per block.
   for (unsigned item = blockIdx.x; item < nitems; item += gridDim.x) {
   if (item != blockIdx.x) __syncthreads();      // the previous item's last slab is still being read by slower waves
   // logical item id = tile block * nkt + kt, dealt so that the nkt items of one tile range (they load the same patches)
@@ -523,8 +523,10 @@ static int wino_run(const float* x, const float* weight, float* y, long y_batch_
     static const bool pair_ok = [] { const char* e = getenv("DFE_WINO_PAIR"); return !e || atoi(e) != 0; }();
     const bool pair = pair_ok && dil == 1 && W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0;
     const unsigned nitems = static_cast<unsigned>(nblk);
-    // one resident round: two blocks per CU (launch bounds) x 256 CUs; DFE_WINO_PERSIST=0: one block per item
-    static const int persist = [] { const char* e = getenv("DFE_WINO_PERSIST"); return e ? atoi(e) : 512; }();
+    // DFE_WINO_PERSIST=512: one resident round of persistent blocks (two per CU x 256 CUs).  Default 0 = one block per item: the
+    // persistent form is 1-2.5 % faster per layer on an idle GPU and 0.08 ms SLOWER in the training step (18.93 against 18.85 ms,
+    // three alternating pairs on one box) -- resident blocks leave the other streams' kernels no slot to slip into
+    static const int persist = [] { const char* e = getenv("DFE_WINO_PERSIST"); return e ? atoi(e) : 0; }();
     const unsigned g = persist > 0 ? std::min(nitems, static_cast<unsigned>(persist)) : nitems;
     const int nt = static_cast<int>(ntiles);
     const int pp = pair ? P : -1;
