@@ -51,14 +51,17 @@ def main():
              for sh, sd in TS.STRICT.items() for ac in (0, 1)]
     cases += [("B=4 256x832 (configs[2]) ac=%d" % ac, synthetic.make_loss_stack_inputs(4, 256, 832, 3, seed=1234), ac, 3, False) for ac in (0, 1)]
     cases += [("B=4 256x832 + depth terms ac=0", synthetic.make_loss_stack_inputs(4, 256, 832, 3, seed=1234), 0, 3, True)]
-    cases += [("B=2 375x1242 S=6 (configs[4]) ac=0", synthetic.make_loss_stack_inputs(2, 375, 1242, 6, seed=55, num_flow_scales=6), 0, 6, False)]
+    cases += [("B=2 375x1242 S=6 (configs[4]) ac=%d" % ac, synthetic.make_loss_stack_inputs(2, 375, 1242, 6, seed=55, num_flow_scales=6), ac, 6, False) for ac in (0, 1)]
     for name, inp, ac, S, dt in cases:
         print("%-46s %6d %9d %7d %10.2e %10.2e %10.2e %10.2e" % ((name,) + errors(inp, bool(ac), S, dt)))
     print()
-    print("unconditioned poses: device vs oracle with correctly rounded cos/sin (cr) and with this host's libm (host)")
+    print("unconditioned poses: device vs oracle with correctly rounded cos/sin and exp (cr, exp cr), cos/sin only (cr), and with this host's libm (host)")
     for kind, shape, seed in (("sigma", (2, 128, 448), 12), ("sigma", (4, 256, 832), 16), ("posecnn", (1, 256, 832), 15)):
         for ac in (0, 1):
             inp = TS.raw_pose_inputs(kind, shape, seed)
+            with O.trig("cr"), O.occ_exp("cr"):      # round 6: the canonical function of the occlusion softmax as well
+                r = errors(inp, bool(ac), 3)
+            print("%-46s %6d %9d %7d %10.2e %10.2e %10.2e %10.2e" % (("raw %s %s ac=%d  [cr, exp cr]" % (kind, shape, ac),) + r))
             with O.trig("cr"):
                 r = errors(inp, bool(ac), 3)
             print("%-46s %6d %9d %7d %10.2e %10.2e %10.2e %10.2e" % (("raw %s %s ac=%d  [cr]" % (kind, shape, ac),) + r))
