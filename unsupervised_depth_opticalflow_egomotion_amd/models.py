@@ -106,10 +106,18 @@ def _side_streams(dev):
     against 12.7 ms of kernels), 0,-1 / 0,0 measure 0.18 ms better in a plain process (21.77 against 21.95) -- but a
     normal-priority side stream is only concurrent while it gets a hardware queue of its own: with a process group alive
     (RCCL's or gloo's streams present) the flow branch at priority 0 ran SERIALISED behind the depth branch, 27.0 ms =
-    the one-stream time, against 22.2 with both side streams high.  High-priority streams have their own queues: kept."""
-    key = (dev.type, dev.index)
+    the one-stream time, against 22.2 with both side streams high.  High-priority streams have their own queues.
+    Round 6 re-measured both (three alternating rounds on one box): plain process 18.79 ms at -1,-1 against 18.59 at 0,0 / 0,-1
+    (the replayed hipGraph: 19.04 against 18.50) -- at equal priority the dispatcher deals workgroups to the depth and flow
+    branches in turn instead of letting the flow branch's kernels cut in front of the longer depth branch --, under a world-size-1
+    RCCL group 19.15 ms at -1,-1 against 23.3 at 0,0.  So the default now FOLLOWS THE PROCESS: 0,0 while no process group
+    exists, -1,-1 once one does (the streams are re-made if a group appears later); DFE_STREAM_PRIORITIES overrides both."""
+    import os
+    pg = torch.distributed.is_available() and torch.distributed.is_initialized()
+    key = (dev.type, dev.index, pg)
     if key not in _SIDE_STREAMS:
-        pf, pp = (int(v) for v in __import__("os").environ.get("DFE_STREAM_PRIORITIES", "-1,-1").split(","))
+        env = os.environ.get("DFE_STREAM_PRIORITIES")
+        pf, pp = (int(v) for v in env.split(",")) if env else ((-1, -1) if pg else (0, 0))
         _SIDE_STREAMS[key] = (torch.cuda.Stream(dev, priority=pf), torch.cuda.Stream(dev, priority=pp))
     return _SIDE_STREAMS[key]
 
