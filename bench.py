@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 # indistinguishable: 32.44 (default, dynamic hybrid) / 32.56 and 32.51 (normal, cold and warm find-db) / 32.42 ms
 # (hybrid).  The variable is passed through and reported in the JSON line so a run under another mode is labelled.
 
+import unsupervised_depth_opticalflow_egomotion_amd as dfe_pkg  # noqa: E402  (first: it raises GPU_MAX_HW_QUEUES before HIP initialises)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -493,7 +494,8 @@ def main():
             args.mode if wl.name == "train_step" else "geom", args.width, args.height, args.batch, args.scales,
             "+Adam" if wl.name == "train_step" else "") + (" [OPT-IN: the step replayed from a hipGraph; roofline kernel timed in eager steps after the region]" if getattr(wl, "use_graph", False) else ""),
             "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-            "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE"), "miopen_user_db": miopen_db_status()},
+            "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE"), "miopen_user_db": miopen_db_status(),
+            "hw_queues": dfe_pkg.HW_QUEUES, "stream_priorities": os.environ.get("DFE_STREAM_PRIORITIES", "auto")},
     }
     if evidence is not None:
         out["multi_gpu"] = evidence

@@ -1055,3 +1055,34 @@ def test_occupancy_critical_kernels_keep_their_resources():
     # the pointwise kernels of the loss stack: at least five waves per SIMD
     for k in by("k_geom_point_fwdILb0E") + by("k_geom_point_bwdILb0E"):
         assert k["vgpr"] <= 96, k
+
+
+def test_hw_queue_limit_is_raised_only_when_it_can_take_effect(monkeypatch):
+    """The package raises GPU_MAX_HW_QUEUES to 8 at import (three network streams + a process group's streams need more than the
+    runtime's 4 queues); a value the user exported wins, and models._side_streams only drops the high stream priorities under a
+    process group when >= 8 queues are in effect."""
+    import unsupervised_depth_opticalflow_egomotion_amd as pkg
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    assert pkg._hw_queue_limit() == 8 and os.environ["GPU_MAX_HW_QUEUES"] == "8"      # no GPU here: HIP is never initialised
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
+    assert pkg._hw_queue_limit() == 4 and os.environ["GPU_MAX_HW_QUEUES"] == "4"
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "16")
+    assert pkg._hw_queue_limit() == 16
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
+    assert pkg._hw_queue_limit() == 4 and "GPU_MAX_HW_QUEUES" not in os.environ      # too late to change: report the default
+
+    from unsupervised_depth_opticalflow_egomotion_amd import models
+    made = []
+    monkeypatch.setattr(torch.cuda, "Stream", lambda dev, priority=0: made.append(priority) or ("stream", priority))
+    monkeypatch.delenv("DFE_STREAM_PRIORITIES", raising=False)
+    for pg, queues, want in ((False, 4, (0, 0)), (True, 4, (-1, -1)), (True, 8, (0, 0)), (False, 8, (0, 0))):
+        monkeypatch.setattr(models, "_SIDE_STREAMS", {})
+        monkeypatch.setattr(pkg, "HW_QUEUES", queues)
+        monkeypatch.setattr(torch.distributed, "is_initialized", lambda pg=pg: pg)
+        got = models._side_streams(torch.device("cuda", 0))
+        assert (got[0][1], got[1][1]) == want, (pg, queues, got)
+    monkeypatch.setenv("DFE_STREAM_PRIORITIES", "-1,0")
+    monkeypatch.setattr(models, "_SIDE_STREAMS", {})
+    got = models._side_streams(torch.device("cuda", 0))
+    assert (got[0][1], got[1][1]) == (-1, 0)

@@ -111,13 +111,17 @@ def _side_streams(dev):
     (the replayed hipGraph: 19.04 against 18.50) -- at equal priority the dispatcher deals workgroups to the depth and flow
     branches in turn instead of letting the flow branch's kernels cut in front of the longer depth branch --, under a world-size-1
     RCCL group 19.15 ms at -1,-1 against 23.3 at 0,0.  So the default now FOLLOWS THE PROCESS: 0,0 while no process group
-    exists, -1,-1 once one does (the streams are re-made if a group appears later); DFE_STREAM_PRIORITIES overrides both."""
+    exists, -1,-1 once one does (the streams are re-made if a group appears later); DFE_STREAM_PRIORITIES overrides both.
+    The serialisation under a process group is the HIP runtime running out of hardware queues (GPU_MAX_HW_QUEUES, default 4):
+    with 8 the same run measures 19.04 ms at 0,0 against 19.24 at -1,-1 (profiles/r06_hw_queues.txt), so when the package
+    raised the limit before HIP initialised (or the user exported >= 8; see the package's HW_QUEUES) 0,0 is used there too."""
     import os
+    from . import HW_QUEUES
     pg = torch.distributed.is_available() and torch.distributed.is_initialized()
     key = (dev.type, dev.index, pg)
     if key not in _SIDE_STREAMS:
         env = os.environ.get("DFE_STREAM_PRIORITIES")
-        pf, pp = (int(v) for v in env.split(",")) if env else ((-1, -1) if pg else (0, 0))
+        pf, pp = (int(v) for v in env.split(",")) if env else ((-1, -1) if pg and HW_QUEUES < 8 else (0, 0))
         _SIDE_STREAMS[key] = (torch.cuda.Stream(dev, priority=pf), torch.cuda.Stream(dev, priority=pp))
     return _SIDE_STREAMS[key]
 
