@@ -1063,14 +1063,25 @@ def test_hw_queue_limit_is_raised_only_when_it_can_take_effect(monkeypatch):
     process group when >= 8 queues are in effect."""
     import unsupervised_depth_opticalflow_egomotion_amd as pkg
     monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
-    assert pkg._hw_queue_limit() == 8 and os.environ["GPU_MAX_HW_QUEUES"] == "8"      # no GPU here: HIP is never initialised
+    assert not pkg._kfd_is_open()                                                       # no GPU here: the runtime never starts
+    assert pkg._hw_queue_limit() == 8 and os.environ["GPU_MAX_HW_QUEUES"] == "8"
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
     assert pkg._hw_queue_limit() == 4 and os.environ["GPU_MAX_HW_QUEUES"] == "4"
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "16")
     assert pkg._hw_queue_limit() == 16
+    # the runtime already started: only the environment the process was started with counts, and nothing is written
     monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    monkeypatch.setattr(pkg, "_initial_env", lambda name: None)
+    assert pkg._hw_queue_limit(started=True) == 4 and "GPU_MAX_HW_QUEUES" not in os.environ
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")                                        # set too late by the script itself
+    assert pkg._hw_queue_limit(started=True) == 4
+    monkeypatch.setattr(pkg, "_initial_env", lambda name: "8")                          # exported in the shell
+    assert pkg._hw_queue_limit(started=True) == 8
+    monkeypatch.undo()
+    assert pkg._initial_env("PATH") == os.environ["PATH"] and pkg._initial_env("DFE_NO_SUCH_VARIABLE") is None
     monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
-    assert pkg._hw_queue_limit() == 4 and "GPU_MAX_HW_QUEUES" not in os.environ      # too late to change: report the default
+    monkeypatch.setattr(pkg, "_initial_env", lambda name: None)
+    assert pkg._hw_queue_limit() == 4
 
     from unsupervised_depth_opticalflow_egomotion_amd import models
     made = []
