@@ -338,6 +338,25 @@ __device__ __forceinline__ void ssim_partials(float mx, float my, float exx, flo
   d_eyy = d_exx;
 }
 
+// The backward pass's form: the SSIM value AND its partials wrt (my, eyy, exy) from one reciprocal (v_rcp_f32 + one Newton step,
+// ~1 ulp) instead of two IEEE divisions (2 x ~10 instructions, the rcp at quarter rate).  Gradients are compared with a tolerance;
+// the forward's value stays the exactly divided one (ssim_from_means).
+__device__ __forceinline__ float ssim_value_partials_y(float mx, float my, float exx, float eyy, float exy,
+                                                       float& d_my, float& d_eyy, float& d_exy) {
+  const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+  const float mxx = mx * mx, myy = my * my, mxy = mx * my;
+  const float n1 = 2.0f * mxy + C1, n2 = 2.0f * (exy - mxy) + C2;
+  const float d1 = mxx + myy + C1, d2 = (exx - mxx) + (eyy - myy) + C2;
+  const float den = d1 * d2;
+  float inv = __builtin_amdgcn_rcpf(den);
+  inv = __fmaf_rn(__fmaf_rn(-den, inv, 1.0f), inv, inv);
+  const float s = n1 * n2 * inv;
+  d_my = (2.0f * mx * (n2 - n1) - s * (2.0f * my * (d2 - d1))) * inv;
+  d_exy = 2.0f * n1 * inv;
+  d_eyy = -s * d1 * inv;
+  return s;
+}
+
 // ---------------------------------------------------------------- resize helpers
 // ATen upsample_bilinear2d source index, align_corners=False: max(0, fma(scale, dst+0.5, -0.5))
 // (the CPU build contracts the expression into one FMA -- probed bit-for-bit)

@@ -6,12 +6,21 @@
 namespace dfe {
 
 constexpr int GS_BLOCK = 256;   // threads per block of the pointwise kernels (1 pixel / thread)
-constexpr int RS_COLS = 62, RS_ROWS = 8;   // rolling SSIM forward: valid columns per wave (64 lanes - 2 halo), rows per wave
+#ifndef DFE_RS_ROWS
+#define DFE_RS_ROWS 8
+#endif
+#ifndef DFE_FS_ROWS
+#define DFE_FS_ROWS 8
+#endif
+#ifndef DFE_RSB_ROWS
+#define DFE_RSB_ROWS 8
+#endif
+constexpr int RS_COLS = 62, RS_ROWS = DFE_RS_ROWS;   // rolling SSIM forward: valid columns per wave (64 lanes - 2 halo), rows per wave
                                             // (measured: rows 4/6/8/16/32 -> 24.2/22.8/21.9/24.0/30.3 us; LDS tile kernel 33 us)
 constexpr int DSM_ROWS = 8;                 // rolling disparity-smoothness kernels: full-res rows per wave (62 valid columns)
-constexpr int FS_ROWS = 8;                  // rolling flow-smoothness kernels: rows per wave (62 valid columns);
+constexpr int FS_ROWS = DFE_FS_ROWS;                  // rolling flow-smoothness kernels: rows per wave (62 valid columns);
                                             // measured 2/4/8 rows -> 24.9/20.6/16.3 us (per-pixel kernel: 24.3 us)
-constexpr int RSB_COLS = 60, RSB_ROWS = 8;  // rolling SSIM backward: 2-lane halo on each side
+constexpr int RSB_COLS = 60, RSB_ROWS = DFE_RSB_ROWS;  // rolling SSIM backward: 2-lane halo on each side
                                             // (measured: rows 5/8/16 -> 49.2/44.4/48.0 us; LDS tile kernel 56.9 us)
 
 // ---- per-block partial sums of k_geom_point_fwd (per direction d: index d*PT_PER_DIR + i)
@@ -86,7 +95,7 @@ void geom_dev(const dfe_geom_args* a, const GeomLayout& L, GeomDev* D);
 
 // ---- rolling-window SSIM helpers (forward and backward kernels)
 struct RowSums { float v[15]; };   // per channel: sum x, y, xx, yy, xy over the 3 horizontal neighbours
-struct RowRaw { float a[3], b[3]; };   // masked target / warped values of one row at this lane's column
+struct RowRaw { float a[3], b[3], vo; };   // masked target / warped values of one row at this lane's column, and the mask weight
 
 // issue the 7 loads of one row (returns zeros outside the image); kept separate from the DPP sums so that
 // the loads of rows y+2.. are in flight while row y is reduced (software prefetch: ~2 waves per SIMD only)
@@ -116,8 +125,64 @@ __device__ __forceinline__ RowRaw ssim_load(const float* __restrict__ it, const 
   const float vo = in ? wq : 0.0f;
 #pragma unroll
   for (int c = 0; c < 3; ++c) { r.a[c] = in ? ta[c] * vo : 0.0f; r.b[c] = in ? tb[c] : 0.0f; }
+  r.vo = vo;
   return r;
 }
+
+// The same row through buffer loads (round 6): the three planes of the target, of the reconstruction and the mask as raw buffer
+// resources (wave-uniform bases), the lane's column as a 32-bit byte offset, the row and the channel in the scalar offset.  A lane
+// outside the image carries an offset past the end of the buffer and the hardware returns zeros: no 64-bit address arithmetic and
+// no selects per value (ssim_load spends ~35 vector instructions per row on them, this form ~8).  Same values, same arithmetic.
+constexpr unsigned SSIM_OOB = 0x7ffffff0u;      // + any scalar offset of a real tensor stays below 2^32 and past every buffer's end
+struct SsimBuf {
+  __amdgpu_buffer_rsrc_t it, yw, mk;
+  unsigned need, N4, W4, colf;                  // colf: the lane's column as a byte offset into a float plane, SSIM_OOB outside [0, W)
+  int H, W;
+};
+__device__ __forceinline__ SsimBuf ssim_buf(const float* it, const float* yw, const unsigned char* mk, unsigned need, int x, int H, int W, int N) {
+  SsimBuf S;
+  S.it = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(it), 0, 12 * N, 0x00020000);
+  S.yw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(yw), 0, 12 * N, 0x00020000);
+  S.mk = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(mk), 0, need == 0u ? 4 * N : N, 0x00020000);
+  S.need = need; S.N4 = 4u * N; S.W4 = 4u * W; S.H = H; S.W = W;
+  const bool col_in = x >= 0 && x < W;
+  S.colf = col_in ? 4u * static_cast<unsigned>(x) : SSIM_OOB;
+  return S;
+}
+__device__ __forceinline__ RowRaw ssim_load(const SsimBuf& S, int y) {      // y is wave-uniform
+  RowRaw r;
+  const bool row_in = y >= 0 && y < S.H;
+  const unsigned vf = row_in ? S.colf : SSIM_OOB, rowf = row_in ? static_cast<unsigned>(y) * S.W4 : 0u;
+  float ta[3], tb[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    ta[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(S.it, vf, rowf + c * S.N4, 0));
+    tb[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(S.yw, vf, rowf + c * S.N4, 0));
+  }
+  float vo;
+  if (S.need == 0u) vo = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(S.mk, vf, rowf, 0));
+  else {
+    const unsigned vb = vf >> 2;                    // the byte plane's offset; SSIM_OOB >> 2 is still past its end
+    const unsigned bits = __builtin_amdgcn_raw_buffer_load_b8(S.mk, vb, row_in ? static_cast<unsigned>(y) * static_cast<unsigned>(S.W) : 0u, 0);
+    vo = ((bits & S.need) == S.need) ? 1.0f : 0.0f;      // an out-of-range lane reads 0: need != 0, so vo = 0
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { r.a[c] = ta[c] * vo; r.b[c] = tb[c]; }
+  r.vo = vo;
+  return r;
+}
+
+// the pointer form behind the same interface (DFE_SSIM_BUF=0: the A/B build)
+struct SsimPtr { const float* it; const float* yw; const unsigned char* mk; unsigned need; int x, H, W, N; };
+__device__ __forceinline__ RowRaw ssim_load(const SsimPtr& S, int y) { return ssim_load(S.it, S.yw, S.mk, S.need, y, S.x, S.H, S.W, S.N); }
+#ifndef DFE_SSIM_BUF
+#define DFE_SSIM_BUF 1
+#endif
+#if DFE_SSIM_BUF
+#define SSIM_SOURCE(it, yw, mk, need, x, H, W, N) ssim_buf(it, yw, mk, need, x, H, W, N)
+#else
+#define SSIM_SOURCE(it, yw, mk, need, x, H, W, N) SsimPtr{it, yw, mk, need, x, H, W, N}
+#endif
 
 __device__ __forceinline__ RowSums ssim_hsum(const RowRaw& w) {
   RowSums r;

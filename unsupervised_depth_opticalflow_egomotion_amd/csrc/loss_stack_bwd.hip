@@ -20,6 +20,10 @@
 #ifndef DFE_PB_TILE
 #define DFE_PB_TILE 16
 #endif
+// 1: the SSIM backward takes value and partials from one refined reciprocal (dfe_device.h: ssim_value_partials_y); 0: two divisions
+#ifndef DFE_SSIM_BWD_RCP
+#define DFE_SSIM_BWD_RCP 1
+#endif
 
 namespace dfe {
 
@@ -76,28 +80,42 @@ __device__ __forceinline__ CoefH ssim_coef_hsum(const RowSums& r0, const RowSums
     const float mx = ((r0.v[c * 5] + r1.v[c * 5]) + r2.v[c * 5]) * r9, my = ((r0.v[c * 5 + 1] + r1.v[c * 5 + 1]) + r2.v[c * 5 + 1]) * r9;
     const float exx = ((r0.v[c * 5 + 2] + r1.v[c * 5 + 2]) + r2.v[c * 5 + 2]) * r9, eyy = ((r0.v[c * 5 + 3] + r1.v[c * 5 + 3]) + r2.v[c * 5 + 3]) * r9;
     const float exy = ((r0.v[c * 5 + 4] + r1.v[c * 5 + 4]) + r2.v[c * 5 + 4]) * r9;
+#if DFE_SSIM_BWD_RCP
+    float d_my, d_eyy, d_exy;
+    const float v = (1.0f - ssim_value_partials_y(mx, my, exx, eyy, exy, d_my, d_eyy, d_exy)) * 0.5f;
+    if (in && v >= 0.0f && v <= 1.0f) {   // coefficients exist only at real pixels; clamp passes gradient on [0,1]
+      c_my = d_my * gscale; c_eyy = d_eyy * gscale; c_exy = d_exy * gscale;
+    }
+#else
     const float v = (1.0f - ssim_from_means(mx, my, exx, eyy, exy)) / 2.0f;
     if (in && v >= 0.0f && v <= 1.0f) {   // coefficients exist only at real pixels; clamp passes gradient on [0,1]
       float d_mx, d_my, d_exx, d_eyy, d_exy;
       ssim_partials(mx, my, exx, eyy, exy, d_mx, d_my, d_exx, d_eyy, d_exy);
       c_my = d_my * gscale; c_eyy = d_eyy * gscale; c_exy = d_exy * gscale;
     }
+#endif
     o.v[c * 3 + 0] = wave_nbr_sum(c_my); o.v[c * 3 + 1] = wave_nbr_sum(c_eyy); o.v[c * 3 + 2] = wave_nbr_sum(c_exy);
   }
   return o;
 }
 
-__device__ __forceinline__ void ssim_grad_store(const CoefH& a, const CoefH& bq, const CoefH& cq, const RowRaw& ctr, float vo,
-                                                float* __restrict__ gw, int q, int N) {
+// gw: the three gradient planes as a buffer (wave-uniform base), voff = the lane's column as a byte offset, rowoff = row * W * 4 (scalar)
+__device__ __forceinline__ void ssim_grad_store(const CoefH& a, const CoefH& bq, const CoefH& cq, const RowRaw& ctr,
+                                                __amdgpu_buffer_rsrc_t gw, unsigned voff, unsigned rowoff, unsigned N4) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float s0 = (a.v[c * 3] + bq.v[c * 3]) + cq.v[c * 3], s1 = (a.v[c * 3 + 1] + bq.v[c * 3 + 1]) + cq.v[c * 3 + 1];
     const float s2 = (a.v[c * 3 + 2] + bq.v[c * 3 + 2]) + cq.v[c * 3 + 2];
-    gw[q + c * N] = ((s0 + 2.0f * ctr.b[c] * s1 + ctr.a[c] * s2) * (1.0f / 9.0f)) * vo;
+    const float g = ((s0 + 2.0f * ctr.b[c] * s1 + ctr.a[c] * s2) * (1.0f / 9.0f)) * ctr.vo;
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g), gw, voff, rowoff + c * N4, 0);
   }
 }
 
-__global__ void __launch_bounds__(64) k_geom_ssim_bwd_roll(GeomDev D, GeomBwd G, int rigid) {
+#ifndef DFE_SSIM_BWD_WAVES
+#define DFE_SSIM_BWD_WAVES 5     // waves per SIMD the register allocation must leave room for (<= 96 VGPRs): at B = 4 the launch has 4 736 waves
+#endif                           // and the chip holds 4 096 at 4 per SIMD (101 VGPRs as compiled freely) -- a second, 16 %-full round
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DFE_SSIM_BWD_WAVES)))
+k_geom_ssim_bwd_roll(GeomDev D, GeomBwd G, int rigid) {
   const unsigned nunit_total = D.rollb_start[D.S];
   const unsigned unit = xcd_swizzle(blockIdx.x, nunit_total);
   const int b = blockIdx.y >> 1, d = blockIdx.y & 1;
@@ -116,51 +134,50 @@ __global__ void __launch_bounds__(64) k_geom_ssim_bwd_roll(GeomDev D, GeomBwd G,
                        G.coef[(static_cast<long>(b) * D.S + s) * CF_COUNT + d * CF_PER_DIR + (rigid ? CF_DEPTH : CF_VO)];
   const bool col_in = x >= 0 && x < W;
   const bool lane_ok = threadIdx.x >= 2 && threadIdx.x <= RSB_COLS + 1 && col_in;
+  const auto SB = SSIM_SOURCE(it, yw, mk, need, x, H, W, N);
+  const __amdgpu_buffer_rsrc_t gwb = __builtin_amdgcn_make_buffer_rsrc(gw, 0, 12 * N, 0x00020000);
+#if DFE_SSIM_BUF
+  const unsigned gcol = SB.colf;                                  // stores are made by the lanes with lane_ok only: inside the image
+#else
+  const unsigned gcol = 4u * static_cast<unsigned>(x);
+#endif
+  const unsigned N4 = 4u * N, W4 = 4u * W;
   // prologue: row sums of rows y0-2, y0-1, y0; coefficient sums of rows y0-1 (and y0 inside the loop)
-  RowRaw w0 = ssim_load(it, yw, mk, need, y0 - 2, x, H, W, N), w1 = ssim_load(it, yw, mk, need, y0 - 1, x, H, W, N);
-  RowRaw w2 = ssim_load(it, yw, mk, need, y0, x, H, W, N), w3 = ssim_load(it, yw, mk, need, y0 + 1, x, H, W, N);
+  RowRaw w0 = ssim_load(SB, y0 - 2), w1 = ssim_load(SB, y0 - 1);
+  RowRaw w2 = ssim_load(SB, y0), w3 = ssim_load(SB, y0 + 1);
   RowSums ha = ssim_hsum(w0), hb = ssim_hsum(w1), hc = ssim_hsum(w2);
   CoefH ca = ssim_coef_hsum(ha, hb, hc, gscale, col_in && y0 - 1 >= 0 && y0 - 1 < H);   // coefficients of row y0-1
   RowSums hd = ssim_hsum(w3);
   CoefH cb = ssim_coef_hsum(hb, hc, hd, gscale, col_in && y0 < H);                        // row y0
   // invariant at the top of each third of the loop body for gradient row g:
   //   h?,h?: row sums of rows g, g+1 ; c?,c?: coefficient sums of rows g-1, g
-  RowRaw nx = ssim_load(it, yw, mk, need, y0 + 2, x, H, W, N);
+  RowRaw nx = ssim_load(SB, y0 + 2);
   for (int g = y0; g < yend; g += 3) {
     // ---- gradient row g: needs row sums g+2 -> coefficients g+1
     {
-      const RowRaw pf = ssim_load(it, yw, mk, need, g + 3, x, H, W, N);
-      const RowRaw ctr = ssim_load(it, yw, mk, need, g, x, H, W, N);
+      const RowRaw pf = ssim_load(SB, g + 3);
+      const RowRaw ctr = ssim_load(SB, g);
       ha = ssim_hsum(nx);                                                                   // rows: hc=g, hd=g+1, ha=g+2
       CoefH cc = ssim_coef_hsum(hc, hd, ha, gscale, col_in && g + 1 < H);                   // row g+1
-      if (lane_ok && g < yend) {
-        const int q = g * W + x;
-        ssim_grad_store(ca, cb, cc, ctr, ssim_weight_at(mk, need, q), gw, q, N);
-      }
+      if (lane_ok && g < yend) ssim_grad_store(ca, cb, cc, ctr, gwb, gcol, static_cast<unsigned>(g) * W4, N4);
       ca = cc; nx = pf;   // now: cb = row g, ca = row g+1
     }
     // ---- gradient row g+1
     {
-      const RowRaw pf = ssim_load(it, yw, mk, need, g + 4, x, H, W, N);
-      const RowRaw ctr = ssim_load(it, yw, mk, need, g + 1, x, H, W, N);
+      const RowRaw pf = ssim_load(SB, g + 4);
+      const RowRaw ctr = ssim_load(SB, g + 1);
       hb = ssim_hsum(nx);                                                                   // rows: hd=g+1, ha=g+2, hb=g+3
       CoefH cc = ssim_coef_hsum(hd, ha, hb, gscale, col_in && g + 2 < H);                   // row g+2
-      if (lane_ok && g + 1 < yend) {
-        const int q = (g + 1) * W + x;
-        ssim_grad_store(cb, ca, cc, ctr, ssim_weight_at(mk, need, q), gw, q, N);
-      }
+      if (lane_ok && g + 1 < yend) ssim_grad_store(cb, ca, cc, ctr, gwb, gcol, static_cast<unsigned>(g + 1) * W4, N4);
       cb = cc; nx = pf;   // now: ca = row g+1, cb = row g+2
     }
     // ---- gradient row g+2
     {
-      const RowRaw pf = ssim_load(it, yw, mk, need, g + 5, x, H, W, N);
-      const RowRaw ctr = ssim_load(it, yw, mk, need, g + 2, x, H, W, N);
+      const RowRaw pf = ssim_load(SB, g + 5);
+      const RowRaw ctr = ssim_load(SB, g + 2);
       hc = ssim_hsum(nx);                                                                   // rows: ha=g+2, hb=g+3, hc=g+4
       CoefH cc = ssim_coef_hsum(ha, hb, hc, gscale, col_in && g + 3 < H);                   // row g+3
-      if (lane_ok && g + 2 < yend) {
-        const int q = (g + 2) * W + x;
-        ssim_grad_store(ca, cb, cc, ctr, ssim_weight_at(mk, need, q), gw, q, N);
-      }
+      if (lane_ok && g + 2 < yend) ssim_grad_store(ca, cb, cc, ctr, gwb, gcol, static_cast<unsigned>(g + 2) * W4, N4);
       // rotate for the next iteration (gradient row g+3): row sums hc=g+3?? -> rename below
       ca = cb; cb = cc; nx = pf;    // ca = row g+2, cb = row g+3
       const RowSums t0 = hb, t1 = hc;   // rows g+3, g+4

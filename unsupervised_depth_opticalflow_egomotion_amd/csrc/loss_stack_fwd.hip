@@ -768,20 +768,21 @@ __global__ void __launch_bounds__(64) k_geom_ssim_fwd_roll(GeomDev D, float* __r
   const unsigned need = D.mode == 2 ? 0u : (rigid ? rigid_ssim_mask(D.mode) : DFE_MASK_VALID_BWD | DFE_MASK_OCC_BWD) << d;
   const bool lane_ok = threadIdx.x >= 1 && threadIdx.x <= RS_COLS && x < W;
   float acc = 0.0f;
-  RowRaw w0 = ssim_load(it, yw, mk, need, y0 - 1, x, H, W, N);
-  RowRaw w1 = ssim_load(it, yw, mk, need, y0, x, H, W, N);
-  RowRaw w2 = ssim_load(it, yw, mk, need, y0 + 1, x, H, W, N);
+  const auto SB = SSIM_SOURCE(it, yw, mk, need, x, H, W, N);
+  RowRaw w0 = ssim_load(SB, y0 - 1);
+  RowRaw w1 = ssim_load(SB, y0);
+  RowRaw w2 = ssim_load(SB, y0 + 1);
   RowSums ra = ssim_hsum(w0), rb0 = ssim_hsum(w1);
   // rows are consumed three at a time so that the rolling window is addressed statically (registers);
   // w2 always holds the raw values of row y+1, and two further rows are loading
   for (int y = y0; y < y0 + RS_ROWS; y += 3) {
-    const RowRaw n2 = ssim_load(it, yw, mk, need, y + 2, x, H, W, N);
+    const RowRaw n2 = ssim_load(SB, y + 2);
     const RowSums rc = ssim_hsum(w2);
     if (lane_ok && y < H && y < y0 + RS_ROWS) acc += ssim_out(ra, rb0, rc);
-    const RowRaw n3 = ssim_load(it, yw, mk, need, y + 3, x, H, W, N);
+    const RowRaw n3 = ssim_load(SB, y + 3);
     ra = ssim_hsum(n2);
     if (lane_ok && y + 1 < H && y + 1 < y0 + RS_ROWS) acc += ssim_out(rb0, rc, ra);
-    w2 = ssim_load(it, yw, mk, need, y + 4, x, H, W, N);
+    w2 = ssim_load(SB, y + 4);
     rb0 = ssim_hsum(n3);
     if (lane_ok && y + 2 < H && y + 2 < y0 + RS_ROWS) acc += ssim_out(rc, ra, rb0);
   }
