@@ -256,9 +256,16 @@ __device__ __forceinline__ void rigid_grid_d(const Proj& p, const Divisor dw, co
 
 // Back-propagate (gU, gV) = dL/dU, dL/dV (and optionally gZ = dL/dZ) of one pixel to
 // depth and to the 12 camera sums (dL/db[3], dL/dA[9]) -- SURVEY.md A.3.
+// 1 / x for GRADIENT arithmetic (compared with a tolerance, never feeding a decision): v_rcp_f32 + one Newton step, ~1 ulp,
+// 3 instructions where the IEEE division takes ~10 (two of them quarter rate).  x must be a normal, non-zero float.
+__device__ __forceinline__ float rcp_nr(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  return __fmaf_rn(__fmaf_rn(-x, r, 1.0f), r, r);
+}
+
 __device__ __forceinline__ void project_backward(const Proj& p, float depth, float gU, float gV, float gZ,
                                                  float& gdepth, float acc[12]) {
-  float invZ = 1.0f / p.Z;
+  float invZ = rcp_nr(p.Z);
   float gX = gU * invZ, gY = gV * invZ;
   float gZr = p.clamped ? 0.0f : (gZ - (gU * p.U + gV * p.V) * invZ);
   gdepth = gX * p.q0 + gY * p.q1 + gZr * p.q2;

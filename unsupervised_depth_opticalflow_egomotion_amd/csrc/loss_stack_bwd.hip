@@ -191,8 +191,16 @@ k_geom_ssim_bwd_roll(GeomDev D, GeomBwd G, int rigid) {
 // the rigid warps (G.gyr), and the depth-consistency term's gradient wrt the computed depth (the projection's Z), the
 // rigid coordinate (through the sampled source disparity) and the source disparity itself (bilinear scatter in 64-bit
 // fixed point, dfe_scatter.h: order-independent).
+#ifndef DFE_PB_WPE
+#define DFE_PB_WPE 0             // 0: the compiler's own register budget (90 VGPRs = 5 waves per SIMD)
+#endif
+#if DFE_PB_WPE
+#define DFE_PB_ATTR __attribute__((amdgpu_waves_per_eu(DFE_PB_WPE, DFE_PB_WPE)))
+#else
+#define DFE_PB_ATTR
+#endif
 template <bool DT>
-__global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomT T, GeomBwd G) {
+__global__ void __launch_bounds__(GS_BLOCK) DFE_PB_ATTR k_geom_point_bwd(GeomDev D, GeomT T, GeomBwd G) {
   __shared__ float red[PB_COUNT * 4 * (GS_BLOCK / 64)];
   const unsigned nblk_total = D.blk_start[D.S];
   const unsigned blk = xcd_swizzle(blockIdx.x, nblk_total);
@@ -299,8 +307,8 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomT T,
         }
         const float sx = D.ac ? static_cast<float>(W - 1) / 2.0f : static_cast<float>(W) / 2.0f;
         const float sy = D.ac ? static_cast<float>(H - 1) / 2.0f : static_cast<float>(H) / 2.0f;
-        if (lx) gU = gix * sx * (2.0f / static_cast<float>(W - 1));
-        if (ly) gV = giy * sy * (2.0f / static_cast<float>(H - 1));
+        if (lx) gU = gix * sx * (2.0f * rcp_nr(static_cast<float>(W - 1)));
+        if (ly) gV = giy * sy * (2.0f * rcp_nr(static_cast<float>(H - 1)));
       }
       if (s == 0) {
         // depth-flow consistency |rigid - flow| on valid*occ*dyna (model_geometry.py:716-732, scale 0 only)
@@ -317,10 +325,10 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomT T,
         const float r = sqrtf(l0 * l0 + l1 * l1), div = r + 1e-6f;
         const float x2 = x1 + fu[d], y2 = y1 + fv[d];
         const float n = (x2 * l0 + y2 * l1) + l2;
-        const float ge = g_epi / static_cast<float>(N), sg = sgn(n);
-        gfu += ge * sg * l0 / div; gfv += ge * sg * l1 / div;
-        const float tail = (r > 0.0f) ? fabsf(n) / (div * div * r) : 0.0f;
-        const float dl0 = ge * (sg * x2 / div - tail * l0), dl1 = ge * (sg * y2 / div - tail * l1), dl2 = ge * sg / div;
+        const float ge = g_epi * rcp_nr(static_cast<float>(N)), sg = sgn(n), idiv = rcp_nr(div);     // div >= 1e-6
+        gfu += ge * sg * l0 * idiv; gfv += ge * sg * l1 * idiv;
+        const float tail = (r > 0.0f) ? fabsf(n) * idiv * idiv * rcp_nr(r > 0.0f ? r : 1.0f) : 0.0f;
+        const float dl0 = ge * (sg * x2 * idiv - tail * l0), dl1 = ge * (sg * y2 * idiv - tail * l1), dl2 = ge * sg * idiv;
         float* aF = acc + d * PB_PER_DIR + 12;
         aF[0] = dl0 * x1; aF[1] = dl0 * y1; aF[2] = dl0;
         aF[3] = dl1 * x1; aF[4] = dl1 * y1; aF[5] = dl1;
@@ -338,9 +346,9 @@ __global__ void __launch_bounds__(GS_BLOCK) k_geom_point_bwd(GeomDev D, GeomT T,
           const float nb = l2norm2(fu[0], fv[0]);
           const float uu = fu[1] / nf, uv = fv[1] / nf;
           const float au = sgn(uu + fu[0] / nb) * k, av = sgn(uv + fv[0] / nb) * k;
-          const float ir = (rf > 0.0f) ? 1.0f / (rf * nf * nf) : 0.0f;
-          gfu += au * (1.0f / nf - fu[1] * fu[1] * ir) + av * (-fv[1] * fu[1] * ir);
-          gfv += au * (-fu[1] * fv[1] * ir) + av * (1.0f / nf - fv[1] * fv[1] * ir);
+          const float ir = (rf > 0.0f) ? 1.0f / (rf * nf * nf) : 0.0f, inf_ = rcp_nr(nf);     // nf >= 1e-12
+          gfu += au * (inf_ - fu[1] * fu[1] * ir) + av * (-fv[1] * fu[1] * ir);
+          gfv += au * (-fu[1] * fv[1] * ir) + av * (inf_ - fv[1] * fv[1] * ir);
         }
       }
       if (G.gflow[d][s]) { G.gflow[d][s][o2] = gfu; G.gflow[d][s][o2 + N] = gfv; }
@@ -403,9 +411,9 @@ __global__ void __launch_bounds__(GS_BLOCK) k_flow_point_bwd(GeomDev D, GeomBwd 
         const float nb = l2norm2(fu[0], fv[0]);
         const float uu = fu[1] / nf, uv = fv[1] / nf;
         const float au = sgn(uu + fu[0] / nb) * k, av = sgn(uv + fv[0] / nb) * k;
-        const float ir = (rf > 0.0f) ? 1.0f / (rf * nf * nf) : 0.0f;
-        gfu += au * (1.0f / nf - fu[1] * fu[1] * ir) + av * (-fv[1] * fu[1] * ir);
-        gfv += au * (-fu[1] * fv[1] * ir) + av * (1.0f / nf - fv[1] * fv[1] * ir);
+        const float ir = (rf > 0.0f) ? 1.0f / (rf * nf * nf) : 0.0f, inf_ = rcp_nr(nf);     // nf >= 1e-12
+        gfu += au * (inf_ - fu[1] * fu[1] * ir) + av * (-fv[1] * fu[1] * ir);
+        gfv += au * (-fu[1] * fv[1] * ir) + av * (inf_ - fv[1] * fv[1] * ir);
       }
     }
     if (G.gflow[d][s]) { G.gflow[d][s][o2] = gfu; G.gflow[d][s][o2 + N] = gfv; }
