@@ -1055,6 +1055,10 @@ def test_occupancy_critical_kernels_keep_their_resources():
     # the pointwise kernels of the loss stack: at least five waves per SIMD
     for k in by("k_geom_point_fwdILb0E") + by("k_geom_point_bwdILb0E"):
         assert k["vgpr"] <= 96, k
+    # the rolling SSIM backward: 4 736 waves at the headline shape; at 97+ registers the chip holds 4 096 and the launch runs a
+    # second, 16 %-full round (51 us instead of 39: profiles/r06_ssim_bwd_experiment.md)
+    ssim_bwd = by("k_geom_ssim_bwd_roll")
+    assert len(ssim_bwd) == 1 and ssim_bwd[0]["vgpr"] <= 96 and ssim_bwd[0]["scratch"] == 0, ssim_bwd
 
 
 def test_hw_queue_limit_is_raised_only_when_it_can_take_effect(monkeypatch):

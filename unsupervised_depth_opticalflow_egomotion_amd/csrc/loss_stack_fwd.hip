@@ -927,6 +927,7 @@ __global__ void __launch_bounds__(256) k_geom_reduce_fwd(GeomDev D, const float*
                                     const float* __restrict__ dpart, int ndunit, float* __restrict__ sums,
                                     float* __restrict__ dsum) {
   __shared__ double lds[256][SUM_COUNT + 1];
+  __shared__ double parts[8][SUM_COUNT + 1];
   const int s = blockIdx.x, b = blockIdx.y, S = D.S, B = D.B, t = threadIdx.x;
   if (s < S) {
     double a[SUM_COUNT];
@@ -953,9 +954,19 @@ __global__ void __launch_bounds__(256) k_geom_reduce_fwd(GeomDev D, const float*
 #pragma unroll
     for (int i = 0; i < SUM_COUNT; ++i) lds[t][i] = a[i];
     __syncthreads();
+    // column sums in two fixed-order stages (as k_geom_pose_finalize): 8 x 26 threads add 32 per-thread sums each, then 26 threads add
+    // the 8 parts -- one thread per column walking all 256 was a chain of 256 dependent double adds, ~10 us of a launch nothing overlaps
+    if (t < 8 * SUM_COUNT) {
+      const int c = t % SUM_COUNT, pt = t / SUM_COUNT;
+      double v = 0.0;
+      for (int k = pt * 32; k < pt * 32 + 32; ++k) v += lds[k][c];
+      parts[pt][c] = v;
+    }
+    __syncthreads();
     if (t < SUM_COUNT) {
       double v = 0.0;
-      for (int k = 0; k < 256; ++k) v += lds[k][t];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v += parts[k][t];
       sums[(static_cast<long>(b) * S + s) * SUM_COUNT + t] = static_cast<float>(v);
     }
   } else {
@@ -969,9 +980,17 @@ __global__ void __launch_bounds__(256) k_geom_reduce_fwd(GeomDev D, const float*
 #pragma unroll
     for (int i = 0; i < 6; ++i) lds[t][i] = a[i];
     __syncthreads();
+    if (t < 8 * 6) {
+      const int c = t % 6, pt = t / 6;
+      double v = 0.0;
+      for (int k = pt * 32; k < pt * 32 + 32; ++k) v += lds[k][c];
+      parts[pt][c] = v;
+    }
+    __syncthreads();
     if (t < 6) {
       double v = 0.0;
-      for (int k = 0; k < 256; ++k) v += lds[k][t];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v += parts[k][t];
       dsum[((t >> 1) * B + b) * 2 + (t & 1)] = static_cast<float>(v);
     }
   }
@@ -997,9 +1016,18 @@ __global__ void __launch_bounds__(256) k_geom_reduce_dt(GeomDev D, const float* 
 #pragma unroll
   for (int i = 0; i < 4; ++i) lds[t][i] = a[i];
   __syncthreads();
+  __shared__ double parts[8][4];
+  if (t < 8 * 4) {
+    const int c = t % 4, pt = t / 4;
+    double v = 0.0;
+    for (int k = pt * 32; k < pt * 32 + 32; ++k) v += lds[k][c];
+    parts[pt][c] = v;
+  }
+  __syncthreads();
   if (t < 4) {
     double v = 0.0;
-    for (int k = 0; k < 256; ++k) v += lds[k][t];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += parts[k][t];
     sums2[(static_cast<long>(b) * S + s) * 4 + t] = static_cast<float>(v);
   }
 }
