@@ -5,7 +5,10 @@
 
 namespace dfe {
 
-constexpr int GS_BLOCK = 256;   // threads per block of the pointwise kernels (1 pixel / thread)
+#ifndef DFE_GS_BLOCK
+#define DFE_GS_BLOCK 256
+#endif
+constexpr int GS_BLOCK = DFE_GS_BLOCK;   // threads per block of the pointwise kernels (1 pixel / thread)
 #ifndef DFE_RS_ROWS
 #define DFE_RS_ROWS 8
 #endif
