@@ -19,12 +19,15 @@ constexpr int GS_BLOCK = DFE_GS_BLOCK;   // threads per block of the pointwise k
 #define DFE_RSB_ROWS 8
 #endif
 constexpr int RS_COLS = 62, RS_ROWS = DFE_RS_ROWS;   // rolling SSIM forward: valid columns per wave (64 lanes - 2 halo), rows per wave
-                                            // (measured: rows 4/6/8/16/32 -> 24.2/22.8/21.9/24.0/30.3 us; LDS tile kernel 33 us)
+                                            // (measured: rows 4/6/8/16/32 -> 24.2/22.8/21.9/24.0/30.3 us; LDS tile kernel 33 us;
+                                            // round 6 in the step: 6/8/9/12 rows -> 26.5/27.4/27.9/28.5)
 constexpr int DSM_ROWS = 8;                 // rolling disparity-smoothness kernels: full-res rows per wave (62 valid columns)
 constexpr int FS_ROWS = DFE_FS_ROWS;                  // rolling flow-smoothness kernels: rows per wave (62 valid columns);
                                             // measured 2/4/8 rows -> 24.9/20.6/16.3 us (per-pixel kernel: 24.3 us)
 constexpr int RSB_COLS = 60, RSB_ROWS = DFE_RSB_ROWS;  // rolling SSIM backward: 2-lane halo on each side
-                                            // (measured: rows 5/8/16 -> 49.2/44.4/48.0 us; LDS tile kernel 56.9 us)
+                                            // (measured: rows 5/8/16 -> 49.2/44.4/48.0 us; LDS tile kernel 56.9 us; round 6, with the
+                                            // 96-register kernel: 9/12/15 rows -> 49.4/44.8/45.6 against 46.6 in the step, and
+                                            // k_geom_flow_smooth_bwd, which shares this strip table, 29.1/33.5/38.3 against 28.3)
 
 // ---- per-block partial sums of k_geom_point_fwd (per direction d: index d*PT_PER_DIR + i)
 enum { PT_M_TEX = 0, PT_L1_DEPTH, PT_M_RIG, PT_L1_RIG, PT_M_DYN, PT_L1_DYN, PT_M_VO, PT_FDIFF, PT_EPI, PT_PER_DIR };
