@@ -16,11 +16,18 @@ for i in range(121):
     wl.step()
     host.append(time.perf_counter() - t0)
     evs[i + 1].record()
-    if i in (4,):      # the bench's barrier after the warm-up
-        torch.cuda.synchronize()
+    if i in (4, 29, 59, 89):      # 4: the bench's barrier after the warm-up; 29: a bare synchronisation; 59: + 50 ms of idle GPU;
+        torch.cuda.synchronize()  # 89: the synchronisation followed at once by a 2 ms filler kernel sequence on the same stream
+        if i == 59:
+            time.sleep(0.05)
+        if i == 89:
+            x = torch.empty(64 << 20, device=dev)
+            for _ in range(40):
+                x.add_(1.0)
 torch.cuda.synchronize()
 ts = [evs[i].elapsed_time(evs[i + 1]) for i in range(121)]
 print("gpu ms per step:", " ".join("%.2f" % t for t in ts))
+print("steps after the synchronisations (6, 31, 61, 91):", ts[5], ts[30], ts[60], ts[90], " median of the rest", sorted(ts[6:])[len(ts[6:]) // 2])
 print("host ms per step:", " ".join("%.2f" % (1e3 * h) for h in host))
 print("mem reserved MB", torch.cuda.memory_reserved() / 2**20, "num alloc retries", torch.cuda.memory_stats().get("num_alloc_retries"))
 print("segments", torch.cuda.memory_stats().get("segment.all.allocated"))
