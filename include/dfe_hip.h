@@ -30,10 +30,10 @@ extern "C" {
 #define DFE_ERR_WORKSPACE (-5)   /* workspace too small */
 
 #define DFE_MAX_SCALES 8
-/* Bumped whenever an exported signature changes or an entry point is removed (2: round 5 changed dfe_wino_wgrad3x3 and
- * removed dfe_thin_conv3x3 / dfe_cast_*; later values: see the comments of the entry points).  _lib.py compares the
- * library's value with this header's. */
-#define DFE_ABI_VERSION 2
+/* Bumped whenever an exported signature changes, an entry point is removed or the host side starts to rely on a new one
+ * (2: round 5 changed dfe_wino_wgrad3x3 and removed dfe_thin_conv3x3 / dfe_cast_*; 3: round 6 added dfe_pwc_level_map_bytes /
+ * _fwd_map / _bwd_map, which ops.py calls).  _lib.py compares the library's value with this header's. */
+#define DFE_ABI_VERSION 3
 
 int dfe_abi_version(void);
 const char* dfe_error_string(int code);
@@ -173,6 +173,17 @@ int dfe_pwc_level_fwd(const float* c1, const float* c2, const float* flow, float
 int dfe_pwc_level_bwd(const float* c1, const float* c2, const float* flow, const float* warped, const float* gx,
                       float* g_warped, float* g_c1, float* g_c2, void* g_c2_ws, float* g_flow, int B, int C, int H,
                       int W, int align_corners, void* stream);
+/* The same operator with the backward's inverse map built in the FORWARD pass (ABI 3; C >= 8): `map` (dfe_pwc_level_map_bytes
+ * bytes, 16-byte aligned, caller-allocated, contents undefined on entry) receives, per pixel of c2, the list of (source pixel,
+ * bilinear weight) taps of warp(c2, flow) that read it -- the feature warp counts them while it samples -- and must reach
+ * dfe_pwc_level_bwd_map unchanged.  That backward is three launches at every level (correlation gradients, flow gradient, gather)
+ * and returns the bits dfe_pwc_level_bwd returns.  DFE_ERR_UNSUPPORTED for C < 8 (use the pair above). */
+long dfe_pwc_level_map_bytes(int B, int H, int W);
+int dfe_pwc_level_fwd_map(const float* c1, const float* c2, const float* flow, float* warped, float* x, void* map, int B, int C,
+                          int H, int W, int align_corners, void* stream);
+int dfe_pwc_level_bwd_map(const float* c1, const float* c2, const float* flow, const float* warped, const float* gx,
+                          float* g_warped, float* g_c1, float* g_c2, void* map, float* g_flow, int B, int C, int H, int W,
+                          int align_corners, void* stream);
 
 /* ---- pyramids: mode 0 = F.interpolate(bilinear, align_corners=False) (model_geometry.py:65-72),
  * mode 1 = F.interpolate(area) == adaptive_avg_pool2d (model_geometry.py:91, model_flow.py:58-64). */

@@ -452,6 +452,49 @@ def test_pwc_level_input(shape):
     assert torch.equal(f3.grad, f.grad)
 
 
+@pytest.mark.parametrize("shape,flow_kind", [((2, 128, 8, 26), "smooth"), ((2, 96, 16, 52), "rough"), ((3, 32, 64, 208), "smooth"),
+                                             ((1, 20, 7, 10), "rough"), ((2, 8, 5, 9), "zero"), ((2, 16, 12, 20), "collapse"),
+                                             ((1, 196, 4, 13), "out")])
+def test_pwc_level_map_built_in_the_forward_pass(shape, flow_kind, monkeypatch):
+    """dfe_pwc_level_fwd_map / _bwd_map (the inverse map of the feature warp counted in the forward pass, three backward launches
+    at every level) against dfe_pwc_level_fwd / _bwd (the map per backward call on the large levels, the 64-bit scatter on the
+    small ones): outputs and ALL gradients bit for bit -- every contribution is rounded as the scatter rounds it and integer sums
+    do not depend on the order of a list -- on smooth, rough, zero, out-of-view flows and a flow that sends every pixel to one
+    target.  A second backward pass through the same graph (the bound of the first pass is still in the map) stays within the
+    gradient tolerance."""
+    from unsupervised_depth_opticalflow_egomotion_amd import ops
+    B, C, H, W = shape
+    r = MG.rng(63)
+    c1 = r.standard_normal(shape).astype(np.float32)
+    c2 = r.standard_normal(shape).astype(np.float32)
+    if flow_kind == "smooth":
+        flow = (np.repeat(np.repeat(r.standard_normal((B, 2, (H + 3) // 4, (W + 3) // 4)), 4, 2), 4, 3)[:, :, :H, :W] * 2.0).astype(np.float32)
+    elif flow_kind == "rough":
+        flow = (r.standard_normal((B, 2, H, W)) * 4.0).astype(np.float32)
+    elif flow_kind == "zero":
+        flow = np.zeros((B, 2, H, W), np.float32)
+    elif flow_kind == "out":
+        flow = (r.standard_normal((B, 2, H, W)) * 30.0).astype(np.float32)
+    else:       # every pixel samples (almost) the same point: one target pixel collects H*W contributions
+        ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+        flow = np.stack([W / 2 + 0.25 - xs, H / 2 + 0.25 - ys])[None].repeat(B, 0).astype(np.float32)
+    wgt = r.standard_normal((B, 81 + C + 2, H, W)).astype(np.float32)
+    outs = {}
+    for use_map in (True, False):
+        monkeypatch.setattr(ops, "PWC_LEVEL_MAP", use_map)
+        a, b, f = G(c1, True), G(c2, True), G(flow, True)
+        x = ops.pwc_level_input(a, b, f)
+        (x * G(wgt)).sum().backward(retain_graph=use_map)
+        outs[use_map] = (x.detach().clone(), a.grad.clone(), b.grad.clone(), f.grad.clone())
+        if use_map:
+            g1 = b.grad.clone()
+            b.grad = None
+            (x * G(wgt * 0.37)).sum().backward()           # a second pass through the same map
+            gclose(b.grad, 0.37 * g1)
+    for u, v in zip(outs[True], outs[False]):
+        assert torch.equal(u, v)
+
+
 @pytest.mark.parametrize("shape,out_hw,mult,pre", [((8, 2, 4, 13), (8, 26), 2.0, False), ((8, 2, 32, 104), (64, 208), 2.0, False),
                                                    ((2, 2, 64, 208), (256, 832), 4.0, True), ((2, 2, 8, 26), (32, 104), 4.0, True),
                                                    ((1, 3, 7, 9), (10, 31), 1.5, True), ((2, 1, 16, 20), (16, 20), 4.0, False)])

@@ -93,6 +93,14 @@ def run_level(B, C, H, W, do_check, only_corr=False, iters=50):
     lb = lambda: check(lib.dfe_pwc_level_bwd(ptr(f1), ptr(f2), ptr(flow), ptr(warped), ptr(gxl), ptr(g_w), ptr(g_c1), ptr(g_c2), ptr(ws),
                                              ptr(g_fl), B, C, H, W, 0, s), "lvlb")
     res["pwc_level_fwd (warp + corr + c1 / flow planes: 2 launches)"] = (timeit(lv, iters), ((2 * C + 2) + (2 * C + 81) + 2 * (C + 2)) * HW * 4 * B)
+    # round 6: the inverse map of the feature warp built in the forward pass (what PwcLevelInputFn runs when dL/dc2 is wanted)
+    mp = torch.empty(lib.dfe_pwc_level_map_bytes(B, H, W), device=dev, dtype=torch.uint8)
+    lvm = lambda: check(lib.dfe_pwc_level_fwd_map(ptr(f1), ptr(f2), ptr(flow), ptr(warped), ptr(x), ptr(mp), B, C, H, W, 0, s), "lvlm")
+    lbm = lambda: check(lib.dfe_pwc_level_bwd_map(ptr(f1), ptr(f2), ptr(flow), ptr(warped), ptr(gxl), ptr(g_w), ptr(g_c1), ptr(g_c2), ptr(mp),
+                                                  ptr(g_fl), B, C, H, W, 0, s), "lvlbm")
+    res["pwc_level_fwd_map (planes > 1024 px: zero-fill + warp with tap count + scan + fill + corr; smaller: warp + one-launch map + corr)"] = (timeit(lvm, iters), ((2 * C + 2) + (2 * C + 81) + 2 * (C + 2)) * HW * 4 * B)
+    lvm()
+    res["pwc_level_bwd_map (corr both gradients + flow gradient + gather: 3 launches at every level)"] = (timeit(lbm, iters), (2 * (2 * C + 81) + (C + 2) + (4 * C + 4)) * HW * 4 * B)
     res["pwc_level_bwd (levels >= 16x52: header fill + corr both gradients + flow gradient + inverse map (3 launches) + gather; below: zero-fill + corr + scatter + convert)"] = (timeit(lb, iters), (2 * (2 * C + 81) + (C + 2) + (4 * C + 4)) * HW * 4 * B)
     return res, err
 
@@ -168,9 +176,11 @@ def main():
         return
     print("correlation per training step (one PWC pass over the 2B pairs): fwd %.1f + bwd %.1f us"
           % (tot["corr_fwd"], tot["corr_bwd (g1 + g2, one launch)"]))
-    lv = [k for k in tot if k.startswith("pwc_level")]
-    print("level inputs per training step (levels 5..2 run the fused operator; level 6 the plain correlation): fwd %.1f + bwd %.1f us"
-          % (tot[lv[0]], tot[lv[1]]))
+    g = lambda pre: sum(v for k, v in tot.items() if k.startswith(pre + " "))      # noqa: E731
+    print("fused level input over the five levels, map built in the forward pass (what the training step runs): fwd %.1f + bwd %.1f = %.1f us"
+          % (g("pwc_level_fwd_map"), g("pwc_level_bwd_map"), g("pwc_level_fwd_map") + g("pwc_level_bwd_map")))
+    print("the same with the map built per backward call (round 5; DFE_PWC_LEVEL_MAP=0):                           fwd %.1f + bwd %.1f = %.1f us"
+          % (g("pwc_level_fwd"), g("pwc_level_bwd"), g("pwc_level_fwd") + g("pwc_level_bwd")))
 
 
 if __name__ == "__main__":

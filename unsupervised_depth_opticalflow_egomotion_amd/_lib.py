@@ -103,6 +103,9 @@ _SIGNATURES = {
     "dfe_pwc_level_channels": [_I],
     "dfe_pwc_level_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_pwc_level_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dfe_pwc_level_map_bytes": [_I, _I, _I],
+    "dfe_pwc_level_fwd_map": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dfe_pwc_level_bwd_map": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dfe_resize": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dfe_resize_bilinear_fwd": [_P, _P, _I, _I, _I, _I, _I, ctypes.c_float, _I, _P],
     "dfe_resize_bilinear_bwd": [_P, _P, _I, _I, _I, _I, _I, ctypes.c_float, _I, _P],
@@ -119,7 +122,7 @@ _SIGNATURES = {
 _RESTYPES = {"dfe_error_string": ctypes.c_char_p, "dfe_geom_workspace_floats": ctypes.c_long,
              "dfe_bias_act_partials_floats": ctypes.c_long, "dfe_glue_partials_floats": ctypes.c_long,
              "dfe_bn_partials_floats": ctypes.c_long, "dfe_disp_head_partials_floats": ctypes.c_long,
-             "dfe_flow_head_partials_floats": ctypes.c_long,
+             "dfe_flow_head_partials_floats": ctypes.c_long, "dfe_pwc_level_map_bytes": ctypes.c_long,
              "dfe_wgrad3x3_partials_floats": ctypes.c_long, "dfe_planeconv_ws_floats": ctypes.c_long, "dfe_wino_weight_floats": ctypes.c_long, "dfe_wino_scratch_floats": ctypes.c_long, "dfe_wino_wgrad_floats": ctypes.c_long, "dfe_sconv_wgrad_floats": ctypes.c_long, "dfe_wino_transform_blocks": ctypes.c_long,
              "dfe_geom_maskpack_offset_bytes": ctypes.c_long, "dfe_scatter_ws_bytes": ctypes.c_long}
 

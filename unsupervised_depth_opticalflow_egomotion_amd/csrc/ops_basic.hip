@@ -115,8 +115,11 @@ __global__ void k_pose_mats_bwd(const float* __restrict__ vec, const float* __re
 // all in flight together.  grid: x = pixel blocks of 64, y = channel chunk, z = sample.
 constexpr int WF_CK = 8;
 
+// cnt != nullptr (dfe_pwc_level_fwd_map): the blocks of the first channel chunk also count, per target pixel, the taps that hit it --
+// the first pass of the inverse map the backward's gather walks (k_wfg_count's work, on the taps this thread computes anyway).
 __global__ void __launch_bounds__(64) k_warp_flow_fwd(const float* __restrict__ x, const float* __restrict__ flow,
-                                                      float* __restrict__ out, int C, int H, int W, int use_mask, int ac) {
+                                                      float* __restrict__ out, int C, int H, int W, int use_mask, int ac,
+                                                      int* __restrict__ cnt) {
   const int b = blockIdx.z, c0 = blockIdx.y * WF_CK, HW = H * W;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= HW) return;
@@ -127,6 +130,13 @@ __global__ void __launch_bounds__(64) k_warp_flow_fwd(const float* __restrict__ 
   Tap t = make_tap(ix, iy, H, W);
   float keep = 1.0f;
   if (use_mask) keep = (tap_cover(t) < 0.9999f) ? 0.0f : 1.0f;
+  if (cnt && blockIdx.y == 0 && keep != 0.0f) {          // the same taps, in-bounds tests and non-zero-weight rule as wfg_taps
+    int* cb = cnt + static_cast<long>(b) * HW + t.y0 * W + t.x0;
+    if (t.in_nw && t.nw != 0.0f) atomicAdd(cb, 1);
+    if (t.in_ne && t.ne != 0.0f) atomicAdd(cb + 1, 1);
+    if (t.in_sw && t.sw != 0.0f) atomicAdd(cb + W, 1);
+    if (t.in_se && t.se != 0.0f) atomicAdd(cb + W + 1, 1);
+  }
   const int nch = min(WF_CK, C - c0);
   Corners q[WF_CK];
 #pragma unroll
@@ -312,6 +322,42 @@ __global__ void __launch_bounds__(256) k_wfg_fill(const float* __restrict__ flow
   for (int k = 0; k < n; ++k) {
     const int slot = atomicSub(cnt + static_cast<long>(b) * HW + q[k], 1) - 1;
     ent[static_cast<long>(b) * 4 * HW + off[static_cast<long>(b) * (HW + 1) + q[k]] + slot] = make_int2(p, __float_as_int(w[k]));
+  }
+}
+
+// The whole map of a SMALL plane (H*W <= 1024: PWC levels 4-6) in one launch: a block per sample, thread = source pixel; counters,
+// exclusive scan and slot cursors live in LDS, so there is no zero-fill, no global counter array and no second walk of the flow.
+// (For the large planes this form loses -- eight blocks cannot walk 13 312 pixels as fast as 416 can: round 5 -- and the three
+// launches above stay.)  Block 0 also clears the word that receives the backward's bound.  grid: B
+constexpr int WFG_SMALL_HW = 1024;
+__global__ void __launch_bounds__(WFG_SMALL_HW) k_wfg_map_small(const float* __restrict__ flow, unsigned* __restrict__ header, int* __restrict__ off,
+                                                                int2* __restrict__ ent, int H, int W, int use_mask, int ac) {
+  __shared__ int cnt[WFG_SMALL_HW], pre[WFG_SMALL_HW], first[WFG_SMALL_HW];
+  const int b = blockIdx.x, HW = H * W, t = threadIdx.x;
+  cnt[t] = 0;
+  if (b == 0 && t == 0) *header = 0u;
+  __syncthreads();
+  int q[4]; float w[4];
+  const int n = t < HW ? wfg_taps(flow + static_cast<long>(b) * 2 * HW, t, H, W, use_mask, ac, q, w) : 0;
+  for (int k = 0; k < n; ++k) atomicAdd(&cnt[q[k]], 1);
+  __syncthreads();
+  const int mine = cnt[t];
+  pre[t] = mine;
+  __syncthreads();
+  for (int d = 1; d < WFG_SMALL_HW; d <<= 1) {          // Hillis-Steele inclusive scan
+    const int v = (t >= d) ? pre[t - d] : 0;
+    __syncthreads();
+    pre[t] += v;
+    __syncthreads();
+  }
+  first[t] = pre[t] - mine;
+  int* o = off + static_cast<long>(b) * (HW + 1);
+  if (t < HW) o[t] = pre[t] - mine;
+  if (t == HW - 1) o[HW] = pre[t];
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {
+    const int slot = atomicSub(&cnt[q[k]], 1) - 1;
+    ent[static_cast<long>(b) * 4 * HW + first[q[k]] + slot] = make_int2(t, __float_as_int(w[k]));
   }
 }
 
@@ -729,7 +775,7 @@ int dfe_warp_flow_fwd(const float* x, const float* flow, float* out, int B, int 
   DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
   DFE_REQUIRE(B <= 65535 && (C + WF_CK - 1) / WF_CK <= 65535, DFE_ERR_DIMS);
   dim3 g(static_cast<unsigned>((static_cast<long>(H) * W + 63) / 64), (C + WF_CK - 1) / WF_CK, B);
-  k_warp_flow_fwd<<<g, 64, 0, static_cast<hipStream_t>(stream)>>>(x, flow, out, C, H, W, use_mask, align_corners);
+  k_warp_flow_fwd<<<g, 64, 0, static_cast<hipStream_t>(stream)>>>(x, flow, out, C, H, W, use_mask, align_corners, nullptr);
   DFE_LAUNCH_CHECK();
   return DFE_OK;
 }
@@ -876,7 +922,7 @@ int dfe_pwc_level_fwd(const float* c1, const float* c2, const float* flow, float
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long HW = static_cast<long>(H) * W, xbs = static_cast<long>(dfe_pwc_level_channels(C)) * HW;
   dim3 gw(static_cast<unsigned>((HW + 63) / 64), (C + WF_CK - 1) / WF_CK, B);
-  k_warp_flow_fwd<<<gw, 64, 0, st>>>(c2, flow, warped, C, H, W, 0, align_corners);
+  k_warp_flow_fwd<<<gw, 64, 0, st>>>(c2, flow, warped, C, H, W, 0, align_corners, nullptr);
   DFE_LAUNCH_CHECK();
   // the correlation kernel also writes the c1 and flow planes behind the cost volume (the c1 tiles it stages anyway)
   { const int rc = launch_corr_fwd(c1, warped, x, xbs, x + static_cast<long>(CR_K) * CR_K * HW, flow, B, C, H, W, st); if (rc != DFE_OK) return rc; }
@@ -914,6 +960,79 @@ int dfe_pwc_level_bwd(const float* c1, const float* c2, const float* flow, const
   }
   if (gather) return warp_gx_gather(flow, g_warped, g_c2, g_c2_ws, B, C, H, W, 0, align_corners, st);
   if (g_c2) return scatter_finish(g_c2_ws, g_c2, n, st);
+  return DFE_OK;
+}
+
+// ---------------------------------------------------------------- the same level with the inverse map built in the FORWARD pass
+// (round 6).  The backward's gather needs, per target pixel of c2, the list of (source pixel, weight) taps that
+// hit it; the taps depend on the flow only, which the forward's feature warp reads anyway.  dfe_pwc_level_fwd_map counts them in
+// the warp kernel and finishes the map (scan, fill) behind it; `map` (dfe_pwc_level_map_bytes) travels to the backward, which is then
+// three launches at every level -- correlation gradients (+ the bound of dL/dwarped), flow gradient, gather -- with no zero-fill, no
+// counting passes and, on the small levels, no 64-bit atomics and no conversion pass.  Same bits as dfe_pwc_level_bwd: every
+// contribution is rounded as the scatter rounds it and integer sums do not depend on the order of a list.  C >= 8.
+// A second backward pass through the same map (retain_graph) finds the first pass's bound in the header: the larger of the two is
+// used (still a bound of every contribution; the quantum is then that of the larger one).
+long dfe_pwc_level_map_bytes(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return DFE_ERR_DIMS;
+  const long HW = static_cast<long>(H) * W;
+  long o = SCATTER_HEADER_BYTES + 4L * B * HW + 4L * B * (HW + 1);      // wfg_layout: header | cnt | off | (16-byte aligned) ent
+  o = (o + 15) & ~15L;
+  return o + 8L * 4 * B * HW;
+}
+
+int dfe_pwc_level_fwd_map(const float* c1, const float* c2, const float* flow, float* warped, float* x, void* map, int B, int C,
+                          int H, int W, int align_corners, void* stream) {
+  DFE_REQUIRE(c1 && c2 && flow && warped && x && map, DFE_ERR_NULL);
+  DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, DFE_ERR_DIMS);
+  DFE_REQUIRE(B <= 65535 && (C + WF_CK - 1) / WF_CK <= 65535, DFE_ERR_DIMS);
+  const long HW = static_cast<long>(H) * W, xbs = static_cast<long>(dfe_pwc_level_channels(C)) * HW;
+  DFE_REQUIRE(C >= WFG_MIN_C && HW < (1l << 28), DFE_ERR_UNSUPPORTED);
+  if (reinterpret_cast<uintptr_t>(map) & 15) return DFE_ERR_DIMS;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const WfgWs w = wfg_layout(map, B, HW);
+  dim3 gw(static_cast<unsigned>((HW + 63) / 64), (C + WF_CK - 1) / WF_CK, B);
+  if (HW <= WFG_SMALL_HW && getenv("DFE_WFG_MAP_LARGE") == nullptr) {          // levels 4-6: the map in one launch beside the warp
+    k_warp_flow_fwd<<<gw, 64, 0, st>>>(c2, flow, warped, C, H, W, 0, align_corners, nullptr);
+    DFE_LAUNCH_CHECK();
+    k_wfg_map_small<<<B, WFG_SMALL_HW, 0, st>>>(flow, w.header, w.off, w.ent, H, W, 0, align_corners);
+    DFE_LAUNCH_CHECK();
+  } else {
+    if (hipMemsetAsync(map, 0, wfg_head_bytes(B, HW), st) != hipSuccess) return DFE_ERR_LAUNCH;     // the bound's word and the counters
+    k_warp_flow_fwd<<<gw, 64, 0, st>>>(c2, flow, warped, C, H, W, 0, align_corners, w.cnt);
+    DFE_LAUNCH_CHECK();
+    k_wfg_scan<<<B, 1024, 0, st>>>(w.cnt, w.off, static_cast<int>(HW));
+    DFE_LAUNCH_CHECK();
+    k_wfg_fill<<<dim3(static_cast<unsigned>((HW + 255) / 256), B), 256, 0, st>>>(flow, w.cnt, w.off, w.ent, H, W, 0, align_corners);
+    DFE_LAUNCH_CHECK();
+  }
+  { const int rc = launch_corr_fwd(c1, warped, x, xbs, x + static_cast<long>(CR_K) * CR_K * HW, flow, B, C, H, W, st); if (rc != DFE_OK) return rc; }
+  DFE_LAUNCH_CHECK();
+  return DFE_OK;
+}
+
+int dfe_pwc_level_bwd_map(const float* c1, const float* c2, const float* flow, const float* warped, const float* gx,
+                          float* g_warped, float* g_c1, float* g_c2, void* map, float* g_flow, int B, int C, int H, int W,
+                          int align_corners, void* stream) {
+  DFE_REQUIRE(c1 && c2 && flow && warped && gx && g_warped && g_c1 && map, DFE_ERR_NULL);
+  DFE_REQUIRE(g_c2 || g_flow, DFE_ERR_NULL);
+  DFE_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && B <= 65535, DFE_ERR_DIMS);
+  const long HW = static_cast<long>(H) * W, xbs = static_cast<long>(dfe_pwc_level_channels(C)) * HW;
+  DFE_REQUIRE(C >= WFG_MIN_C && HW < (1l << 28), DFE_ERR_UNSUPPORTED);
+  if (reinterpret_cast<uintptr_t>(map) & 15) return DFE_ERR_DIMS;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float* gx_c1 = gx + static_cast<long>(CR_K) * CR_K * HW;
+  const float* gx_flow = gx_c1 + static_cast<long>(C) * HW;
+  const WfgWs w = wfg_layout(map, B, HW);
+  { const int rc = launch_corr_bwd(c1, warped, gx, xbs, gx_c1, xbs, g_c1, g_warped, g_c2 ? w.header : nullptr, B, C, H, W, st); if (rc != DFE_OK) return rc; }
+  DFE_LAUNCH_CHECK();
+  if (g_flow) {
+    launch_warp_flow_bwd(dim3(static_cast<unsigned>((HW + 63) / 64), 1, B), st, c2, flow, g_warped, g_flow, nullptr, gx_flow, xbs, C, H, W, 0, align_corners);
+    DFE_LAUNCH_CHECK();
+  }
+  if (g_c2) {
+    k_wfg_gather<<<dim3(static_cast<unsigned>((HW + 63) / 64), (C + WF_CK - 1) / WF_CK, B), 64, 0, st>>>(g_warped, w.off, w.ent, w.header, g_c2, C, static_cast<int>(HW));
+    DFE_LAUNCH_CHECK();
+  }
   return DFE_OK;
 }
 

@@ -297,8 +297,16 @@ class PwcLevelInputFn(torch.autograd.Function):
         B, C, H, W = c1.shape
         warped = torch.empty_like(c2)
         x = torch.empty(B, lib.dfe_pwc_level_channels(C), H, W, device=c1.device, dtype=torch.float32)
-        check(lib.dfe_pwc_level_fwd(ptr(c1), ptr(c2), ptr(flow), ptr(warped), ptr(x), B, C, H, W, align_corners,
-                                    stream_ptr()), "dfe_pwc_level_fwd")
+        # when dL/dc2 will be asked for, the feature warp also counts its taps per target pixel and the inverse map the backward's
+        # gather walks is finished here (dfe_pwc_level_fwd_map): the backward pass is then three launches at every level
+        ctx.map = None
+        if PWC_LEVEL_MAP and ctx.needs_input_grad[1] and C >= 8:
+            ctx.map = torch.empty(lib.dfe_pwc_level_map_bytes(B, H, W), device=c1.device, dtype=torch.uint8)
+            check(lib.dfe_pwc_level_fwd_map(ptr(c1), ptr(c2), ptr(flow), ptr(warped), ptr(x), ptr(ctx.map), B, C, H, W, align_corners,
+                                            stream_ptr()), "dfe_pwc_level_fwd_map")
+        else:
+            check(lib.dfe_pwc_level_fwd(ptr(c1), ptr(c2), ptr(flow), ptr(warped), ptr(x), B, C, H, W, align_corners,
+                                        stream_ptr()), "dfe_pwc_level_fwd")
         ctx.save_for_backward(c1, c2, flow, warped)
         ctx.ac = align_corners
         return x
@@ -313,9 +321,13 @@ class PwcLevelInputFn(torch.autograd.Function):
         g_c2 = torch.empty_like(c2) if ctx.needs_input_grad[1] else None    # every element written by the library
         g_flow = torch.empty_like(flow) if (ctx.needs_input_grad[2] or g_c2 is None) else None
         g_warped = torch.empty_like(c2)
-        ws = scatter_ws(c2.numel(), c2.device) if g_c2 is not None else None
-        check(lib.dfe_pwc_level_bwd(ptr(c1), ptr(c2), ptr(flow), ptr(warped), ptr(gx), ptr(g_warped), ptr(g_c1),
-                                    ptr(g_c2), ptr(ws), ptr(g_flow), B, C, H, W, ctx.ac, stream_ptr()), "dfe_pwc_level_bwd")
+        if ctx.map is not None and g_c2 is not None:
+            check(lib.dfe_pwc_level_bwd_map(ptr(c1), ptr(c2), ptr(flow), ptr(warped), ptr(gx), ptr(g_warped), ptr(g_c1),
+                                            ptr(g_c2), ptr(ctx.map), ptr(g_flow), B, C, H, W, ctx.ac, stream_ptr()), "dfe_pwc_level_bwd_map")
+        else:
+            ws = scatter_ws(c2.numel(), c2.device) if g_c2 is not None else None
+            check(lib.dfe_pwc_level_bwd(ptr(c1), ptr(c2), ptr(flow), ptr(warped), ptr(gx), ptr(g_warped), ptr(g_c1),
+                                        ptr(g_c2), ptr(ws), ptr(g_flow), B, C, H, W, ctx.ac, stream_ptr()), "dfe_pwc_level_bwd")
         return g_c1, g_c2, (g_flow if ctx.needs_input_grad[2] else None), None
 
 
@@ -594,6 +606,7 @@ def bias_act(z, bias, slope):
 PLANECONV_MAX_HW = int(os.environ.get("DFE_PLANECONV_MAX_HW", "208"))
 WINO_EPILOGUE = os.environ.get("DFE_WINO_EPILOGUE", "1") != "0"      # switches read once at import (246 environment reads per step before)
 FLOW_HEAD = os.environ.get("DFE_FLOW_HEAD", "1") != "0"
+PWC_LEVEL_MAP = os.environ.get("DFE_PWC_LEVEL_MAP", "1") != "0"      # the PWC level's inverse map built in its forward pass (PwcLevelInputFn)
 
 
 def planeconv_eligible(x, w):
